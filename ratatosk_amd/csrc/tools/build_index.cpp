@@ -1,0 +1,275 @@
+// rtk_build_index: minimal, deterministic producer of the two index files `Ratatosk correct -1` consumes:
+//   PREFIX.index.k31.fasta.gz   unitigs of the compacted de Bruijn graph (one FASTA record per unitig)
+//   PREFIX.index.k31.rtsk       per-unitig data records (format: ../common/rtsk_io.hpp)
+//
+// This is NOT the reference's `index` step (src/Graph.cpp:1561-3366 `addCoverage`, Bifrost `build`):
+// that step is out of the hot-path scope and cannot be built here (Bifrost is
+// absent). It only has to emit the reference's *file formats* with semantically equivalent content so
+// the correction path has inputs:
+//   * unitigs        = maximal non-branching paths over canonical k-mers seen >= --min-count times
+//   * colours        = ids of the short-read pairs having >= 1 k-mer on the unitig (sorted u32)
+//   * kmCov          = number of read k-mers mapped on the unitig (unphased coverage, bits 31..61)
+//   * branching bit  = >1 predecessors or >1 successors            (reference: src/Graph.cpp:1997)
+//   * edge bits      = neighbour shares >= min_cov_vertices colours (reference: src/Graph.cpp:1999-2017)
+//   * global/local   = simplified form of the colour compaction of src/Graph.cpp:2874-2985
+//   * SNP-ambiguity, haplotype and short-cycle annotations are left empty (their producers
+//     `detectSNPs`/`detectShortCycles` are index-time code outside the scope).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <queue>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../common/fastx.hpp"
+#include "../common/kmer.hpp"
+#include "../common/rtsk_io.hpp"
+
+using namespace rtk;
+
+static const uint64_t EMPTY = ~0ULL;
+
+struct KTable { // open addressing: canonical k-mer -> 64-bit value
+    std::vector<uint64_t> keys, vals;
+    size_t n = 0, mask = 0;
+    explicit KTable(size_t cap_pow2 = 1 << 20) { keys.assign(cap_pow2, EMPTY); vals.assign(cap_pow2, 0); mask = cap_pow2 - 1; }
+    void grow() {
+        std::vector<uint64_t> ok, ov; ok.swap(keys); ov.swap(vals);
+        keys.assign(ok.size() * 2, EMPTY); vals.assign(ok.size() * 2, 0); mask = keys.size() - 1; n = 0;
+        for (size_t i = 0; i < ok.size(); ++i) if (ok[i] != EMPTY) *slot(ok[i], true) = ov[i];
+    }
+    uint64_t* slot(uint64_t key, bool insert) {
+        if (insert && (n + 1) * 10 > keys.size() * 6) grow();
+        size_t i = hash64(key) & mask;
+        while (true) {
+            if (keys[i] == key) return &vals[i];
+            if (keys[i] == EMPTY) { if (!insert) return nullptr; keys[i] = key; ++n; return &vals[i]; }
+            i = (i + 1) & mask;
+        }
+    }
+};
+
+struct Unitig { std::string seq; std::vector<uint32_t> colours; uint64_t cov = 0; };
+
+int main(int argc, char** argv) {
+    std::vector<std::string> in_files;
+    std::string prefix = "out";
+    int k = 31;
+    unsigned min_count = 2;
+    size_t min_cov_vertices = 2;
+    double global_cov_factor = 3.0, min_color_sharing = 0.5;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char* n) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "rtk_build_index: missing value for %s\n", n); exit(2); } return argv[++i]; };
+        if (a == "-s") in_files.push_back(need("-s"));
+        else if (a == "-o") prefix = need("-o");
+        else if (a == "-k") k = atoi(need("-k"));
+        else if (a == "--min-count") min_count = static_cast<unsigned>(atoi(need("--min-count")));
+        else if (a == "--global-cov-factor") global_cov_factor = atof(need("--global-cov-factor"));
+        else { fprintf(stderr, "rtk_build_index: unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=31)] [--min-count 2] [--global-cov-factor 3.0]\n"); return 2; }
+    const uint64_t mask = kmer_mask(k);
+
+    // ---- pass 1: count canonical k-mers ----
+    KTable cnt(1 << 22);
+    {
+        std::string name, seq, qual;
+        for (size_t f = 0; f < in_files.size(); ++f) {
+            FastxReader fr;
+            if (!fr.open(in_files[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", in_files[f].c_str()); return 1; }
+            while (fr.next(name, seq, qual)) {
+                uint64_t fw = 0; int valid = 0;
+                for (size_t i = 0; i < seq.size(); ++i) {
+                    const int b = base2bits(seq[i]);
+                    if (b < 0) { valid = 0; fw = 0; continue; }
+                    fw = ((fw << 2) | static_cast<uint64_t>(b)) & mask;
+                    if (++valid >= k) ++*cnt.slot(kmer_canonical(fw, k), true);
+                }
+            }
+        }
+    }
+    // ---- solid k-mers, sorted: unitig construction is independent of table layout ----
+    std::vector<uint64_t> solid;
+    for (size_t i = 0; i < cnt.keys.size(); ++i) if (cnt.keys[i] != EMPTY && cnt.vals[i] >= min_count) solid.push_back(cnt.keys[i]);
+    std::sort(solid.begin(), solid.end());
+    { KTable tmp(16); cnt.keys.swap(tmp.keys); cnt.vals.swap(tmp.vals); } // free
+    size_t cap = 16; while (cap * 6 < solid.size() * 10 + 16) cap <<= 1; cap <<= 1;
+    KTable km(cap); // canonical solid k-mer -> 0 (unvisited) or (unitig+1)<<32 | offset<<1 | fw_flag
+    for (size_t i = 0; i < solid.size(); ++i) *km.slot(solid[i], true) = 0;
+    fprintf(stderr, "rtk_build_index: %zu solid %d-mers\n", solid.size(), k);
+
+    auto in_graph = [&](uint64_t oriented) -> bool { return km.slot(kmer_canonical(oriented, k), false) != nullptr; };
+    auto succs = [&](uint64_t x, uint64_t out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const uint64_t y = ((x << 2) | b) & mask; if (in_graph(y)) out[n++] = y; } return n; };
+    auto preds = [&](uint64_t x, uint64_t out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const uint64_t y = (x >> 2) | (b << (2 * (k - 1))); if (in_graph(y)) out[n++] = y; } return n; };
+
+    // ---- unitigs: maximal non-branching paths ----
+    std::vector<Unitig> U;
+    {
+        std::set<uint64_t> in_this; // canonical k-mers of the unitig being built (cycle / hairpin guard)
+        for (size_t si = 0; si < solid.size(); ++si) {
+            uint64_t* v0 = km.slot(solid[si], false);
+            if (*v0 != 0) continue;
+            in_this.clear(); in_this.insert(solid[si]);
+            std::vector<uint64_t> fwd(1, solid[si]), bwd; // oriented k-mers
+            uint64_t nb[4], nb2[4];
+            for (uint64_t x = solid[si];;) { // extend forward
+                if (succs(x, nb) != 1) break;
+                const uint64_t y = nb[0];
+                if (preds(y, nb2) != 1) break;
+                const uint64_t cy = kmer_canonical(y, k);
+                if (in_this.count(cy) || *km.slot(cy, false) != 0) break;
+                in_this.insert(cy); fwd.push_back(y); x = y;
+            }
+            for (uint64_t x = solid[si];;) { // extend backward
+                if (preds(x, nb) != 1) break;
+                const uint64_t y = nb[0];
+                if (succs(y, nb2) != 1) break;
+                const uint64_t cy = kmer_canonical(y, k);
+                if (in_this.count(cy) || *km.slot(cy, false) != 0) break;
+                in_this.insert(cy); bwd.push_back(y); x = y;
+            }
+            std::vector<uint64_t> path(bwd.rbegin(), bwd.rend());
+            path.insert(path.end(), fwd.begin(), fwd.end());
+            Unitig u;
+            u.seq = kmer_decode(path[0], k);
+            for (size_t i = 1; i < path.size(); ++i) u.seq.push_back(bits2base(static_cast<int>(path[i] & 3)));
+            const uint64_t uid = U.size();
+            for (size_t i = 0; i < path.size(); ++i) {
+                bool is_fw; const uint64_t c = kmer_canonical(path[i], k, &is_fw);
+                *km.slot(c, false) = ((uid + 1) << 32) | (static_cast<uint64_t>(i) << 1) | (is_fw ? 1ULL : 0ULL);
+            }
+            U.push_back(u);
+        }
+    }
+    fprintf(stderr, "rtk_build_index: %zu unitigs\n", U.size());
+
+    // ---- pass 2: colours (pair ids) and coverage ----
+    {
+        std::string name, seq, qual, prev_name;
+        uint32_t pair_id = 0; bool first = true;
+        for (size_t f = 0; f < in_files.size(); ++f) {
+            FastxReader fr; fr.open(in_files[f]);
+            while (fr.next(name, seq, qual)) {
+                if (name.size() > 2 && name[name.size() - 2] == '/' && (name[name.size() - 1] == '1' || name[name.size() - 1] == '2')) name.erase(name.size() - 2);
+                if (first) { first = false; prev_name = name; }
+                else if (name != prev_name) { ++pair_id; prev_name = name; }
+                uint64_t fw = 0; int valid = 0;
+                for (size_t i = 0; i < seq.size(); ++i) {
+                    const int b = base2bits(seq[i]);
+                    if (b < 0) { valid = 0; fw = 0; continue; }
+                    fw = ((fw << 2) | static_cast<uint64_t>(b)) & mask;
+                    if (++valid >= k) {
+                        const uint64_t* v = km.slot(kmer_canonical(fw, k), false);
+                        if (v) {
+                            Unitig& u = U[(*v >> 32) - 1];
+                            ++u.cov;
+                            if (u.colours.empty() || u.colours.back() != pair_id) u.colours.push_back(pair_id);
+                        }
+                    }
+                }
+            }
+        }
+        for (size_t i = 0; i < U.size(); ++i) { std::sort(U[i].colours.begin(), U[i].colours.end()); U[i].colours.erase(std::unique(U[i].colours.begin(), U[i].colours.end()), U[i].colours.end()); }
+    }
+
+    // ---- adjacency, branching, edge bits ----
+    const size_t n = U.size();
+    struct Nb { int64_t u[2][4]; }; // [dir 0 = fw successors, 1 = successors of the reverse strand][base] -> unitig id or -1
+    std::vector<Nb> adj(n);
+    std::vector<uint64_t> kmcov(n, 0), shared(n, 0);
+    auto shared_count = [&](const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) -> size_t {
+        size_t i = 0, j = 0, c = 0;
+        while (i < a.size() && j < b.size()) { if (a[i] < b[j]) ++i; else if (b[j] < a[i]) ++j; else { ++c; ++i; ++j; } }
+        return c;
+    };
+    for (size_t u = 0; u < n; ++u) {
+        const std::string& s = U[u].seq;
+        uint64_t tail, head;
+        kmer_encode(s.c_str() + s.size() - k, k, tail);
+        kmer_encode(s.c_str(), k, head);
+        const uint64_t ends[2] = { tail, kmer_revcomp(head, k) }; // last k-mer in walk direction fw / rev
+        int deg[2] = {0, 0};
+        for (int d = 0; d < 2; ++d) for (uint64_t b = 0; b < 4; ++b) {
+            adj[u].u[d][b] = -1;
+            const uint64_t y = ((ends[d] << 2) | b) & mask;
+            const uint64_t* v = km.slot(kmer_canonical(y, k), false);
+            if (!v) continue;
+            const size_t w = (*v >> 32) - 1;
+            adj[u].u[d][b] = static_cast<int64_t>(w);
+            ++deg[d];
+            if (shared_count(U[u].colours, U[w].colours) >= min_cov_vertices) shared[u] |= (d == 0) ? ((1ULL << b) << 4) : (1ULL << b); // idx(A,C,G,T)=1,2,4,8 (src/Common.hpp:260,358)
+        }
+        const uint64_t cov = std::min<uint64_t>(U[u].cov, 0x7fffffffULL);
+        kmcov[u] = (cov << 31) | ((deg[0] > 1 || deg[1] > 1) ? (1ULL << 63) : 0ULL);
+    }
+
+    // ---- global / local colour split (simplified restatement of src/Graph.cpp:2874-2985) ----
+    std::vector<std::vector<uint32_t> > global_ids(n), local_ids(n);
+    {
+        double tot_cov = 0, tot_km = 0;
+        for (size_t u = 0; u < n; ++u) { tot_cov += static_cast<double>(U[u].cov); tot_km += static_cast<double>(U[u].seq.size() - k + 1); }
+        const double est_cov = tot_km > 0 ? tot_cov / tot_km : 0.0;
+        auto kcov = [&](size_t u) { return static_cast<double>(static_cast<long long>(static_cast<double>(U[u].cov) / static_cast<double>(U[u].seq.size() - k + 1) + 0.5)); };
+        std::vector<std::pair<double, size_t> > seeds;
+        for (size_t u = 0; u < n; ++u) if ((kmcov[u] >> 63) && kcov(u) >= global_cov_factor * est_cov) seeds.push_back(std::make_pair(-kcov(u), u));
+        std::sort(seeds.begin(), seeds.end());
+        std::vector<char> visited(n, 0);
+        for (size_t si = 0; si < seeds.size(); ++si) {
+            const size_t u0 = seeds[si].second;
+            if (visited[u0]) continue;
+            std::vector<uint32_t> inter = U[u0].colours;
+            size_t max_card_inter = static_cast<size_t>(static_cast<double>(inter.size()) * min_color_sharing);
+            std::set<size_t> seen, valid; seen.insert(u0);
+            std::queue<size_t> q; q.push(u0);
+            while (!q.empty()) {
+                const size_t x = q.front(); q.pop();
+                std::vector<std::pair<double, size_t> > nbs;
+                for (int d = 0; d < 2; ++d) for (int b = 0; b < 4; ++b) { const int64_t w = adj[x].u[d][b]; if (w >= 0 && seen.insert(static_cast<size_t>(w)).second && !visited[w]) nbs.push_back(std::make_pair(-kcov(static_cast<size_t>(w)), static_cast<size_t>(w))); }
+                std::sort(nbs.begin(), nbs.end());
+                for (size_t j = 0; j < nbs.size(); ++j) {
+                    const size_t w = nbs[j].second;
+                    std::vector<uint32_t> li;
+                    std::set_intersection(inter.begin(), inter.end(), U[w].colours.begin(), U[w].colours.end(), std::back_inserter(li));
+                    if (static_cast<double>(li.size()) >= static_cast<double>(U[w].colours.size()) * min_color_sharing && li.size() >= max_card_inter && !li.empty()) {
+                        inter.swap(li);
+                        max_card_inter = std::max(max_card_inter, static_cast<size_t>(static_cast<double>(U[w].colours.size()) * min_color_sharing));
+                        valid.insert(w); q.push(w);
+                    }
+                }
+            }
+            if (!valid.empty()) {
+                valid.insert(u0);
+                for (std::set<size_t>::const_iterator it = valid.begin(); it != valid.end(); ++it) {
+                    global_ids[*it] = inter; visited[*it] = 1;
+                    std::set_difference(U[*it].colours.begin(), U[*it].colours.end(), inter.begin(), inter.end(), std::back_inserter(local_ids[*it]));
+                }
+            }
+        }
+        size_t ng = 0;
+        for (size_t u = 0; u < n; ++u) { if (global_ids[u].empty()) local_ids[u] = U[u].colours; else ++ng; }
+        fprintf(stderr, "rtk_build_index: est. k-mer coverage %.2f, %zu unitigs carry a global colour set\n", est_cov, ng);
+    }
+
+    // ---- write ----
+    {
+        gzFile gz = gzopen((prefix + ".index.k" + std::to_string(k) + ".fasta.gz").c_str(), "wb6");
+        if (!gz) { fprintf(stderr, "rtk_build_index: cannot write fasta.gz\n"); return 1; }
+        for (size_t u = 0; u < n; ++u) { gzprintf(gz, ">%zu\n", u); gzwrite(gz, U[u].seq.data(), static_cast<unsigned>(U[u].seq.size())); gzputc(gz, '\n'); }
+        gzclose(gz);
+        std::ofstream out((prefix + ".index.k" + std::to_string(k) + ".rtsk").c_str(), std::ios::binary);
+        for (size_t u = 0; u < n; ++u) {
+            RtskRecord r;
+            disk_kmer_from_string(U[u].seq.c_str(), k, r.head);
+            r.kmcov = kmcov[u]; r.shared = shared[u];
+            r.global_ids = global_ids[u]; r.local_ids = local_ids[u];
+            rtsk_write_record(out, r);
+        }
+    }
+    return 0;
+}
