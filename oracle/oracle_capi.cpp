@@ -1,0 +1,153 @@
+// ORACLE (test infrastructure): flat C entry points so tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg can drive the CPU restatement through ctypes. Nothing in the product links this.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "oracle_correct.hpp"
+#include "oracle_myers.hpp"
+
+using namespace orc;
+
+extern "C" {
+
+struct orc_opts { // mirrors the pass-1 fields of Correct_Opt (reference: src/Common.hpp:101-156)
+    uint64_t insert_sz, min_cov_vertices, max_len_weak_region1, max_km_cov;
+    double weak_region_len_factor, large_k_factor, min_score;
+    int32_t max_qual, out_qual;
+};
+
+static Opt toOpt(const orc_opts* o) {
+    Opt r;
+    if (o) { r.insert_sz = o->insert_sz; r.min_cov_vertices = o->min_cov_vertices; r.max_len_weak_region1 = o->max_len_weak_region1; r.max_km_cov = o->max_km_cov;
+             r.weak_region_len_factor = o->weak_region_len_factor; r.large_k_factor = o->large_k_factor; r.min_score = o->min_score; r.max_qual = o->max_qual; r.out_qual = o->out_qual; }
+    return r;
+}
+
+void* orc_graph_load(const char* fasta_gz, const char* rtsk, int k, char* err, int errcap) {
+    Graph* g = new Graph();
+    try { g->load(fasta_gz, rtsk, k); }
+    catch (const std::exception& e) { if (err && errcap > 0) { strncpy(err, e.what(), errcap - 1); err[errcap - 1] = 0; } delete g; return nullptr; }
+    return g;
+}
+
+void orc_graph_free(void* g) { delete static_cast<Graph*>(g); }
+
+void orc_graph_stats(void* gp, uint64_t* n_unitigs, uint64_t* n_kmers, uint64_t* max_km_cov_001) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    *n_unitigs = g->seq.size(); *n_kmers = g->kmap.size(); *max_km_cov_001 = g->maxKmerCoverage(0.001);
+}
+
+// unitig record: sequence + the two data words + colour sets, for cross-checking the product's flat graph
+int orc_unitig(void* gp, uint64_t u, char* seq, uint64_t seq_cap, uint64_t* seq_len, uint64_t* kmcov, uint64_t* shared, int64_t* global_id,
+               uint32_t* local, uint64_t local_cap, uint64_t* n_local) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    if (u >= g->seq.size()) return -1;
+    *seq_len = g->seq[u].size();
+    if (seq && seq_cap >= g->seq[u].size()) memcpy(seq, g->seq[u].data(), g->seq[u].size());
+    *kmcov = g->info[u].kmcov; *shared = g->info[u].shared; *global_id = g->info[u].global_id;
+    *n_local = g->info[u].local.size();
+    for (size_t i = 0; i < g->info[u].local.size() && i < local_cap; ++i) local[i] = g->info[u].local[i];
+    return 0;
+}
+
+int orc_global_set(void* gp, int64_t id, uint32_t* out, uint64_t cap, uint64_t* n) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    if (id < 0 || static_cast<size_t>(id) >= g->globals.size()) return -1;
+    *n = g->globals[id].size();
+    for (size_t i = 0; i < g->globals[id].size() && i < cap; ++i) out[i] = g->globals[id][i];
+    return 0;
+}
+
+// neighbours of unitig u walking fw (dir 0) / on the reverse strand (dir 1): out[b] = unitig<<1|strand or -1, b in A,C,G,T
+void orc_neighbours(void* gp, uint64_t u, int dir, int64_t out[4]) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    UM um(static_cast<int32_t>(u), 0, g->nkm(static_cast<int32_t>(u)), dir == 0);
+    UM s[4]; char b[4]; int n;
+    g->successors(um, s, b, n);
+    for (int i = 0; i < 4; ++i) out[i] = -1;
+    for (int i = 0; i < n; ++i) { const int bi = b[i] == 'A' ? 0 : (b[i] == 'C' ? 1 : (b[i] == 'G' ? 2 : 3)); out[bi] = (static_cast<int64_t>(s[i].unitig) << 1) | (s[i].strand ? 1 : 0); }
+}
+
+int orc_myers(const char* q, int qlen, const char* t, int tlen, int k, int mode, int want_path, int use_iupac,
+              int* n_loc, int* end_locs, int cap_locs, char* cigar, int cap_cigar) {
+    const AlignResult a = myers_align(q, qlen, t, tlen, k, static_cast<AlignMode>(mode), want_path != 0, use_iupac != 0);
+    *n_loc = static_cast<int>(a.endLocations.size());
+    for (size_t i = 0; i < a.endLocations.size() && static_cast<int>(i) < cap_locs; ++i) end_locs[i] = a.endLocations[i];
+    if (cigar && cap_cigar > 0) { const std::string c = want_path ? alignment_to_cigar(a.alignment) : std::string(); strncpy(cigar, c.c_str(), cap_cigar - 1); cigar[cap_cigar - 1] = 0; }
+    return a.editDistance;
+}
+
+// per-window exact hits [A1]: out[p] = unitig<<33 | dist<<1 | strand, or -1
+void orc_exact(void* gp, const char* seq, uint64_t len, int64_t* out) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    const std::string s(seq, len);
+    const size_t nw = len >= static_cast<size_t>(g->k) ? len - g->k + 1 : 0;
+    for (size_t i = 0; i < nw; ++i) out[i] = -1;
+    const std::vector<Anchor> v = searchExact(*g, s, nullptr);
+    for (size_t i = 0; i < v.size(); ++i) out[v[i].first] = (static_cast<int64_t>(v[i].second.unitig) << 33) | (static_cast<int64_t>(v[i].second.dist) << 1) | (v[i].second.strand ? 1 : 0);
+}
+
+static void packAnchors(const std::vector<Anchor>& v, int64_t* out, uint64_t cap) {
+    for (size_t i = 0; i < v.size() && i < cap; ++i) { out[4 * i] = static_cast<int64_t>(v[i].first); out[4 * i + 1] = v[i].second.unitig; out[4 * i + 2] = v[i].second.dist; out[4 * i + 3] = v[i].second.strand ? 1 : 0; }
+}
+
+// full getSeeds: anchors as (pos, unitig, dist, strand) quadruples
+int orc_seeds(void* gp, const orc_opts* o, const char* seq, uint64_t len, uint64_t* n_solid, int64_t* solid, uint64_t* n_weak, int64_t* weak, uint64_t cap) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    const Opt opt = toOpt(o);
+    const std::pair<std::vector<Anchor>, std::vector<Anchor> > p = getSeeds(*g, opt, std::string(seq, len), nullptr);
+    *n_solid = p.first.size(); *n_weak = p.second.size();
+    packAnchors(p.first, solid, cap); packAnchors(p.second, weak, cap);
+    return (p.first.size() <= cap && p.second.size() <= cap) ? 0 : 1;
+}
+
+// mask + raw inexact hits (before sort/dedup/filters), for checking the device inexact-lookup stage on its own
+int orc_inexact(void* gp, const orc_opts* o, const char* seq, uint64_t len, char* masked_out, uint64_t* n_hits, int64_t* hits, uint64_t cap) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    const Opt opt = toOpt(o);
+    const std::string s(seq, len);
+    std::vector<Anchor> ex = searchExact(*g, s, nullptr); // already position-sorted, one hit per position
+    const std::string m = maskForInexact(*g, opt, s, ex);
+    if (masked_out) memcpy(masked_out, m.data(), m.size());
+    const std::vector<Anchor> v = searchInexact(*g, m, nullptr);
+    *n_hits = v.size();
+    packAnchors(v, hits, cap);
+    return v.size() <= cap ? 0 : 1;
+}
+
+// The per-read body of the reference's worker loop over a batch, N threads pulling read tickets
+// (reference: src/Ratatosk.cpp:727-904). Outputs are malloc'd; free with orc_free.
+int orc_correct_batch(void* gp, const orc_opts* o, uint64_t n, const char* const* seq, const char* const* qual, const uint32_t* len,
+                      char** out_seq, char** out_qual, uint32_t* out_len, int n_threads, uint64_t* counters /*8*/) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    const Opt opt = toOpt(o);
+    std::atomic<uint64_t> ticket(0);
+    std::vector<Counters> cs(n_threads > 0 ? n_threads : 1);
+    auto work = [&](int t) {
+        while (true) {
+            const uint64_t i = ticket.fetch_add(1);
+            if (i >= n) break;
+            const std::pair<std::string, std::string> r = correctRead(*g, opt, std::string(seq[i], len[i]), qual && qual[i] ? std::string(qual[i], len[i]) : std::string(), &cs[t]);
+            out_len[i] = static_cast<uint32_t>(r.first.size());
+            out_seq[i] = static_cast<char*>(malloc(r.first.size() + 1)); memcpy(out_seq[i], r.first.c_str(), r.first.size() + 1);
+            out_qual[i] = static_cast<char*>(malloc(r.second.size() + 1)); memcpy(out_qual[i], r.second.c_str(), r.second.size() + 1);
+        }
+    };
+    if (n_threads <= 1) work(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t); for (size_t t = 0; t < th.size(); ++t) th[t].join(); }
+    if (counters) {
+        Counters tot; for (size_t t = 0; t < cs.size(); ++t) tot.add(cs[t]);
+        counters[0] = tot.n_probe; counters[1] = tot.n_verify; counters[2] = tot.n_expand; counters[3] = tot.n_colour_elem;
+        counters[4] = tot.n_path_base; counters[5] = tot.n_align; counters[6] = tot.n_align_cells; counters[7] = tot.n_regions;
+    }
+    return 0;
+}
+
+void orc_free(void* p) { free(p); }
+
+} // extern "C"

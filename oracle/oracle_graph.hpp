@@ -1,0 +1,100 @@
+// ORACLE (test infrastructure, never shipped, never on the product path).
+//
+// Minimal CPU model of the graph queries the reference's hot path makes into Bifrost
+// (absent from /root/reference: un-vendored submodule `pmelsted/bifrost`, pinned commit unknown,
+// API level >= v1.2 -- SURVEY.md §0.3, §8c). Every function cites the reference call site whose
+// behaviour it stands for. Assumptions about Bifrost semantics are tagged [A1]..[A5]:
+//   [A1] searchSequence exact: one (pos, UM{len=1}) per all-ACGT window whose canonical k-mer is in the graph.
+//   [A2] searchSequence inexact: graph k-mers reachable from the read by ONE edit, reported at the read
+//        position of the first read base they use:
+//          substitution  read[p..p+k) with one base replaced;
+//          "insertion"   k-1 read bases read[p..p+k-1) plus one inserted base (read lacks a base);
+//          "deletion"    k+1 read bases read[p..p+k+1) minus one interior base (read has an extra base);
+//        a window touching a non-ACGT character never matches.
+//   [A3] getSuccessors(): existing neighbours of the unitig end in walk direction, base order A,C,G,T,
+//        as whole-unitig mappings (dist=0, len=size-k+1).
+//   [A4] on-disk Kmer = 2 x u64, 2 bits/base (A0 C1 G2 T3), first base in the MSBs of word 0.
+//   [A5] FASTA/FASTQ records: name = header up to the first whitespace.
+// "Parity unpinned" for everything that depends on [A1]-[A3]: the reference has no tests and its binary
+// cannot be built here.
+#ifndef RTK_ORACLE_GRAPH_HPP
+#define RTK_ORACLE_GRAPH_HPP
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace orc {
+
+typedef std::vector<uint32_t> IdSet; // sorted, unique pair ids ("colours")
+
+struct UM { // restatement of Bifrost const_UnitigMap as used by the reference
+    int32_t unitig;  // -1 == isEmpty
+    uint32_t dist;   // 0-based k-mer offset on the forward unitig
+    uint32_t len;    // number of k-mers mapped
+    bool strand;
+    UM() : unitig(-1), dist(0), len(0), strand(true) {}
+    UM(int32_t u, uint32_t d, uint32_t l, bool s) : unitig(u), dist(d), len(l), strand(s) {}
+    bool isEmpty() const { return unitig < 0; }
+    bool operator==(const UM& o) const { return unitig == o.unitig && dist == o.dist && len == o.len && strand == o.strand; }
+    bool operator!=(const UM& o) const { return !(*this == o); }
+};
+
+struct UnitigInfo { // restatement of the read side of src/UnitigData.hpp:258-491
+    uint64_t kmcov;   // bit63 branching, bits31..61 unphased cov, bits0..30 phased cov (UnitigData.hpp:576)
+    uint64_t shared;  // bit8 short cycle, bits4..7 fw edge mask, bits0..3 bw edge mask (UnitigData.hpp:577)
+    int32_t global_id; // index into Graph::globals or -1 (SharedPairID global pointer)
+    IdSet local;
+    bool has_ambiguity;
+    UnitigInfo() : kmcov(0), shared(0), global_id(-1), has_ambiguity(false) {}
+};
+
+struct Graph {
+    int k;
+    std::vector<std::string> seq;
+    std::vector<UnitigInfo> info;
+    std::vector<IdSet> globals;
+    std::unordered_map<uint64_t, uint64_t> kmap; // canonical k-mer -> unitig<<32 | offset<<1 | (stored orientation == canonical)
+
+    // loads PREFIX unitig FASTA(.gz) + .rtsk (formats: SURVEY.md Appendix B). Throws std::runtime_error.
+    void load(const std::string& fasta_gz, const std::string& rtsk, int k_);
+
+    size_t usize(int32_t u) const { return seq[u].size(); }
+    uint32_t nkm(int32_t u) const { return static_cast<uint32_t>(seq[u].size()) - k + 1; }
+
+    // Bifrost find(km, extremities_only=false) on a k-mer given as text; empty UM if absent / non-ACGT. [A1]
+    UM findKmer(const char* s) const;
+    UM findKmerCode(uint64_t fw_code) const;
+
+    std::string mapped(const UM& um) const;                 // const_UnitigMap::mappedSequenceToString
+    bool sameUnitig(const UM& a, const UM& b) const { return a.unitig == b.unitig; } // isSameReferenceUnitig
+    void successors(const UM& um, UM out[4], char base[4], int& n) const; // getSuccessors() [A3]
+    int nbSuccessors(const UM& um) const;
+
+    // UnitigData accessors
+    bool isBranching(int32_t u) const { return (info[u].kmcov >> 63) & 1ULL; }
+    bool isShortCycle(int32_t u) const { return (info[u].shared >> 8) & 1ULL; }
+    bool hasSharedPids(int32_t u) const { return (info[u].shared & 0xffULL) != 0; }
+    bool getSharedPids(int32_t u, bool strand, char c) const; // UnitigData.hpp:275-284
+    double kmerCoverage(int32_t u) const;                     // UnitigData.hpp:396-399
+    size_t cardinality(int32_t u) const;                      // SharedPairID::cardinality
+    IdSet allIds(int32_t u) const;                            // SharedPairID::toPairID
+    const IdSet* globalSet(int32_t u) const { return info[u].global_id >= 0 ? &globals[info[u].global_id] : nullptr; }
+    size_t sharedCount(int32_t u, const IdSet& b) const;      // getNumberSharedPairID(SharedPairID, PairID) exact
+    size_t sharedCount(int32_t a, int32_t b) const;           // getNumberSharedPairID(SharedPairID, SharedPairID) exact
+
+    size_t maxKmerCoverage(double top_ratio) const;           // src/Graph.cpp:825-841
+};
+
+// sorted-set algebra standing in for PairID operators (src/PairID.cpp)
+IdSet set_union(const IdSet& a, const IdSet& b);
+IdSet set_inter(const IdSet& a, const IdSet& b);
+IdSet set_diff(const IdSet& a, const IdSet& b);
+size_t set_inter_card(const IdSet& a, const IdSet& b);
+
+std::string revcomp(const std::string& s);
+
+} // namespace orc
+
+#endif
