@@ -31,6 +31,111 @@ const EqTable& eqt() { static const EqTable t; return t; }
 
 bool iupac_equal(unsigned char a, unsigned char b) { return eqt().eq[a][b]; }
 
+namespace {
+
+inline bool eqc(bool iu, unsigned char a, unsigned char b) { return iu ? iupac_equal(a, b) : (a == b); }
+
+// One unbanded Myers pass of query (m > 0) over target (n > 0) with NW boundaries.
+// col_last[i] (optional) = D[i+1][n] for every query row i; stores (optional) keep the delta vectors of every column.
+struct Cols { std::vector<uint64_t> Pv, Mv, Ph, Mh; };
+int nw_pass(const char* q, int m, const char* t, int n, bool iu, std::vector<int>* col_last, Cols* store) {
+    const int W = (m + 63) / 64, last_bit = (m - 1) & 63;
+    std::vector<uint64_t> peq(static_cast<size_t>(256) * W, 0);
+    bool have[256]; memset(have, 0, sizeof(have));
+    for (int j = 0; j < n; ++j) {
+        const unsigned char c = static_cast<unsigned char>(t[j]);
+        if (have[c]) continue;
+        have[c] = true;
+        uint64_t* p = &peq[static_cast<size_t>(c) * W];
+        for (int i = 0; i < m; ++i) if (eqc(iu, static_cast<unsigned char>(q[i]), c)) p[i >> 6] |= 1ULL << (i & 63);
+    }
+    std::vector<uint64_t> Pv(W, ~0ULL), Mv(W, 0);
+    if (store) { store->Pv.resize(static_cast<size_t>(W) * n); store->Mv.resize(store->Pv.size()); store->Ph.resize(store->Pv.size()); store->Mh.resize(store->Pv.size()); }
+    int score = m;
+    for (int j = 0; j < n; ++j) {
+        const uint64_t* e = &peq[static_cast<size_t>(static_cast<unsigned char>(t[j])) * W];
+        int hin = 1;
+        for (int w = 0; w < W; ++w) {
+            uint64_t Eq = e[w];
+            const uint64_t pv = Pv[w], mv = Mv[w];
+            const uint64_t Xv = Eq | mv;
+            if (hin < 0) Eq |= 1ULL;
+            const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+            uint64_t Ph = mv | ~(Xh | pv), Mh = pv & Xh;
+            if (store) { store->Ph[static_cast<size_t>(j) * W + w] = Ph; store->Mh[static_cast<size_t>(j) * W + w] = Mh; }
+            const int bit = (w == W - 1) ? last_bit : 63;
+            const int hout = static_cast<int>((Ph >> bit) & 1ULL) - static_cast<int>((Mh >> bit) & 1ULL);
+            Ph <<= 1; Mh <<= 1;
+            if (hin > 0) Ph |= 1ULL; else if (hin < 0) Mh |= 1ULL;
+            Pv[w] = Mh | ~(Xv | Ph); Mv[w] = Ph & Xv;
+            if (store) { store->Pv[static_cast<size_t>(j) * W + w] = Pv[w]; store->Mv[static_cast<size_t>(j) * W + w] = Mv[w]; }
+            hin = hout;
+        }
+        score += hin;
+    }
+    if (col_last) {
+        col_last->resize(m);
+        int v = n; // D[0][n]
+        for (int i = 0; i < m; ++i) { v += static_cast<int>((Pv[i >> 6] >> (i & 63)) & 1ULL) - static_cast<int>((Mv[i >> 6] >> (i & 63)) & 1ULL); (*col_last)[i] = v; }
+    }
+    return score;
+}
+
+// Canonical NW traceback preferring up (insert) > left (delete) > diagonal (reference: src/edlib.cpp:1021-1137).
+void traceback(const char* q, int m, const char* t, int n, bool iu, std::vector<unsigned char>& out) {
+    Cols c;
+    int cur = nw_pass(q, m, t, n, iu, nullptr, &c);
+    const int W = (m + 63) / 64;
+    std::vector<unsigned char> aln;
+    int i = m, j = n;
+    while (i > 0 && j > 0) {
+        const int r = i - 1, cc = j - 1, w = r >> 6, b = r & 63;
+        const size_t idx = static_cast<size_t>(cc) * W + w;
+        const int vd = static_cast<int>((c.Pv[idx] >> b) & 1ULL) - static_cast<int>((c.Mv[idx] >> b) & 1ULL);
+        const int hd = static_cast<int>((c.Ph[idx] >> b) & 1ULL) - static_cast<int>((c.Mh[idx] >> b) & 1ULL);
+        if (vd == 1) { aln.push_back(1); --i; cur -= 1; }
+        else if (hd == 1) { aln.push_back(2); --j; cur -= 1; }
+        else {
+            const int left = cur - hd;
+            int diag;
+            if (cc == 0) diag = i - 1;
+            else { const size_t idl = static_cast<size_t>(cc - 1) * W + w; diag = left - (static_cast<int>((c.Pv[idl] >> b) & 1ULL) - static_cast<int>((c.Mv[idl] >> b) & 1ULL)); }
+            aln.push_back(diag == cur ? 0 : 3);
+            --i; --j; cur = diag;
+        }
+    }
+    while (i > 0) { aln.push_back(1); --i; }
+    while (j > 0) { aln.push_back(2); --j; }
+    out.insert(out.end(), aln.rbegin(), aln.rend());
+}
+
+// obtainAlignment (reference: src/edlib.cpp:1164-1216): traceback below 1 MB of table, else the Hirschberg split of
+// src/edlib.cpp:1234-1399: target halved at n/2, the first query row (ascending) whose left+right scores add up to the
+// optimum, then the row -1 boundary, then the last row.
+void obtain_alignment(const char* q, int m, const char* t, int n, int best, bool iu, std::vector<unsigned char>& out) {
+    if (m == 0 || n == 0) { out.insert(out.end(), static_cast<size_t>(m + n), static_cast<unsigned char>(m == 0 ? 2 : 1)); return; }
+    const long long W = (m + 63) / 64;
+    if ((2LL * 8 + 4) * W * n + 8LL * n < 1024 * 1024) { traceback(q, m, t, n, iu, out); return; }
+    const int lh = n / 2, rh = n - lh;
+    if (lh == 0) { fprintf(stderr, "oracle_myers: Hirschberg with a 1-column target is undefined in the reference\n"); abort(); }
+    std::vector<int> L, Rr;
+    nw_pass(q, m, t, lh, iu, &L, nullptr);
+    std::string rq(q, m), rt(t + lh, rh);
+    std::reverse(rq.begin(), rq.end()); std::reverse(rt.begin(), rt.end());
+    nw_pass(rq.c_str(), m, rt.c_str(), rh, iu, &Rr, nullptr);
+    // R(i) = cost of aligning q[i..m) with the right half = Rr[m-1-i]
+    int split = -2, left_score = 0, right_score = 0;
+    for (int qi = 0; qi + 1 < m; ++qi) if (L[qi] + Rr[m - 2 - qi] == best) { split = qi; left_score = L[qi]; right_score = Rr[m - 2 - qi]; break; }
+    if (split == -2 && lh + Rr[m - 1] == best) { split = -1; left_score = lh; right_score = Rr[m - 1]; }
+    if (split == -2 && L[m - 1] + rh == best) { split = m - 1; left_score = L[m - 1]; right_score = rh; }
+    if (split == -2) { fprintf(stderr, "oracle_myers: no Hirschberg split found (inconsistent best score)\n"); abort(); }
+    const int ul = split + 1;
+    obtain_alignment(q, ul, t, lh, left_score, iu, out);
+    obtain_alignment(q + ul, m - ul, t + lh, rh, right_score, iu, out);
+}
+
+} // namespace
+
 AlignResult myers_align(const char* query, int m, const char* target, int n, int k, AlignMode mode, bool want_path, bool use_iupac) {
     AlignResult res;
     // zero-length special cases (reference: src/edlib.cpp:161-179) -- returned before any path is built
@@ -55,17 +160,7 @@ AlignResult myers_align(const char* query, int m, const char* target, int n, int
         for (int i = 0; i < m; ++i) if (use_iupac ? iupac_equal(static_cast<unsigned char>(query[i]), c) : (static_cast<unsigned char>(query[i]) == c)) p[i >> 6] |= 1ULL << (i & 63);
     }
 
-    if (want_path) {
-        const long long sz = (2LL * 8 + 4) * W * n + 8LL * n; // the reference's traceback/Hirschberg switch (src/edlib.cpp:1191-1193)
-        if (sz >= 1024 * 1024 && mode == MODE_NW) {
-            fprintf(stderr, "oracle_myers: problem %dx%d would take edlib's Hirschberg path, which this oracle does not restate\n", m, n);
-            abort();
-        }
-    }
-
     std::vector<uint64_t> Pv(W, ~0ULL), Mv(W, 0);
-    std::vector<uint64_t> sPv, sMv, sPh, sMh; // per column copies for the traceback
-    if (want_path) { sPv.resize(static_cast<size_t>(W) * n); sMv.resize(sPv.size()); sPh.resize(sPv.size()); sMh.resize(sPv.size()); }
     std::vector<int> col_score(n);
     int score = m;
     const int top_h = (mode == MODE_HW) ? 0 : 1;
@@ -80,14 +175,12 @@ AlignResult myers_align(const char* query, int m, const char* target, int n, int
             const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
             uint64_t Ph = mv | ~(Xh | pv);
             uint64_t Mh = pv & Xh;
-            if (want_path) { sPh[static_cast<size_t>(j) * W + w] = Ph; sMh[static_cast<size_t>(j) * W + w] = Mh; }
             const int bit = (w == W - 1) ? last_bit : 63;
             const int hout = static_cast<int>((Ph >> bit) & 1ULL) - static_cast<int>((Mh >> bit) & 1ULL);
             Ph <<= 1; Mh <<= 1;
             if (hin > 0) Ph |= 1ULL; else if (hin < 0) Mh |= 1ULL;
             Pv[w] = Mh | ~(Xv | Ph);
             Mv[w] = Ph & Xv;
-            if (want_path) { sPv[static_cast<size_t>(j) * W + w] = Pv[w]; sMv[static_cast<size_t>(j) * W + w] = Mv[w]; }
             hin = hout;
         }
         score += hin;
@@ -115,35 +208,8 @@ AlignResult myers_align(const char* query, int m, const char* target, int n, int
 
     if (want_path) {
         if (mode == MODE_HW) { fprintf(stderr, "oracle_myers: HW path alignment is never requested by the reference hot path\n"); abort(); }
-        std::vector<unsigned char>& aln = res.alignment;
-        int i = m, j = end0 + 1; // rows / columns still to consume
-        if (j > 0) {
-            const long long sz = (2LL * 8 + 4) * W * j + 8LL * j;
-            if (sz >= 1024 * 1024) { fprintf(stderr, "oracle_myers: problem %dx%d would take edlib's Hirschberg path\n", m, j); abort(); }
-        }
-        int cur = (j > 0) ? col_score[j - 1] : m;
-        while (i > 0 && j > 0) {
-            const int r = i - 1, c = j - 1, w = r >> 6, b = r & 63;
-            const size_t idx = static_cast<size_t>(c) * W + w;
-            const int vd = static_cast<int>((sPv[idx] >> b) & 1ULL) - static_cast<int>((sMv[idx] >> b) & 1ULL);
-            const int hd = static_cast<int>((sPh[idx] >> b) & 1ULL) - static_cast<int>((sMh[idx] >> b) & 1ULL);
-            if (vd == 1) { aln.push_back(1); --i; cur -= 1; }
-            else if (hd == 1) { aln.push_back(2); --j; cur -= 1; }
-            else {
-                const int left = cur - hd;
-                int diag;
-                if (c == 0) diag = i - 1;
-                else {
-                    const size_t idl = static_cast<size_t>(c - 1) * W + w;
-                    diag = left - (static_cast<int>((sPv[idl] >> b) & 1ULL) - static_cast<int>((sMv[idl] >> b) & 1ULL));
-                }
-                aln.push_back(diag == cur ? 0 : 3);
-                --i; --j; cur = diag;
-            }
-        }
-        while (i > 0) { aln.push_back(1); --i; }
-        while (j > 0) { aln.push_back(2); --j; }
-        std::reverse(aln.begin(), aln.end());
+        // alignment of the whole query against target[0..end0] (reference: src/edlib.cpp:271-284)
+        obtain_alignment(query, m, target, end0 + 1, res.editDistance, use_iupac, res.alignment);
     }
     return res;
 }

@@ -15,8 +15,9 @@
 // The Ukkonen band of edlib only prunes cells that cannot lie on an optimal path, so these results are
 // band independent; tests/test_oracle_myers.py pins this file against the reference's own edlib.cpp
 // compiled into oracle/_ref (parity pinned for this component).
-// Hirschberg (edlib.cpp:1234-1399) is only taken when 20*ceil(q/64)*t+8*t >= 2^20 (edlib.cpp:1191-1193),
-// which the pass-1 path cannot reach with -w <= 1000; larger problems abort loudly here.
+// When 20*ceil(q/64)*t+8*t >= 2^20 edlib switches from traceback to its Hirschberg split (edlib.cpp:1191-1214,
+// :1234-1399); pass 1 reaches it whenever a long non-terminal sub-path is given qualities
+// (src/GraphTraversal.cpp:573 -> :722-730). The split rule is restated canonically (see obtain_alignment).
 #ifndef RTK_ORACLE_MYERS_HPP
 #define RTK_ORACLE_MYERS_HPP
 
