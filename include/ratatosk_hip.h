@@ -1,0 +1,127 @@
+/*
+ * ratatosk_hip.h -- C ABI of the MI355X-native Ratatosk per-long-read correction path.
+ *
+ * The reference (DecodeGenetics/Ratatosk v0.9.0) has no FFI; its drop-in seam is the body of the
+ * per-read worker loop of `Ratatosk correct -1` (reference: src/Ratatosk.cpp:808-864):
+ *     getSeeds(opt, dbg, read, qual, false, ~0, m_km_um, false)            src/Graph.hpp:14-18
+ *     correctSequence(dbg, opt, read, qual, solid, weak, false, nullptr, ~0, hap_reads, max_km_cov)
+ *                                                                           src/Correction.hpp:32-35
+ * called on a shared read-only graph loaded by dbg.read() + readGraphData() (src/Ratatosk.cpp:1087-1089,
+ * src/Graph.cpp:722). Each entry point below names the reference interface it replaces. Plain pointers
+ * and sizes only; every function returns 0 on success and a negative code on failure, with a message
+ * available from rtk_last_error() (the reference prints to cerr and exit(1)s; a library must not).
+ * All compute runs in HIP kernels on gfx950; there is no CPU fallback: a call fails with
+ * RTK_ERR_NO_DEVICE when no GPU/extension is usable.
+ */
+#ifndef RATATOSK_HIP_H
+#define RATATOSK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTK_OK 0
+#define RTK_ERR_IO (-1)
+#define RTK_ERR_FORMAT (-2)
+#define RTK_ERR_ARG (-3)
+#define RTK_ERR_NO_DEVICE (-4)
+#define RTK_ERR_DEVICE (-5)
+#define RTK_ERR_UNSUPPORTED (-6)
+
+typedef struct rtk_graph rtk_graph; /* compacted coloured de Bruijn graph: host image + HBM image */
+typedef struct rtk_batch rtk_batch; /* one batch of long reads resident in HBM (reference: the >=1 MiB ticket unit, src/Common.hpp:138) */
+
+/* POD mirror of the Correct_Opt fields read by the pass-1 hot path (reference: src/Common.hpp:101-156). */
+typedef struct rtk_opts {
+    uint64_t insert_sz;             /* -i, 500  */
+    uint64_t min_cov_vertices;      /* 2        */
+    uint64_t max_len_weak_region1;  /* -w, 1000 */
+    uint64_t max_km_cov;            /* max(getMaxKmerCoverage(dbg,0.001),128), src/Ratatosk.cpp:625 */
+    double weak_region_len_factor;  /* 0.25     */
+    double large_k_factor;          /* 1.5      */
+    double min_score;               /* 0.0 with one correction round, src/Ratatosk.cpp:847 */
+    int32_t max_qual;               /* -Q, 40   */
+    int32_t out_qual;               /* 1        */
+} rtk_opts;
+
+typedef struct rtk_graph_info {
+    uint64_t n_unitigs, n_kmers, n_bases, n_colour_ids, n_global_sets;
+    uint64_t table_slots, hbm_bytes;
+    uint64_t max_km_cov_top; /* getMaxKmerCoverage(dbg, 0.001), src/Graph.cpp:825-841 */
+    int32_t k, device;
+} rtk_graph_info;
+
+/* Kernel timing and event counters of the last rtk_batch_run (HIP events on the launch stream). */
+typedef struct rtk_stats {
+    double ms_total, ms_lookup_exact, ms_mask, ms_lookup_inexact, ms_seeds, ms_regions, ms_correct, ms_stitch;
+    uint64_t n_windows, n_probes_exact, n_probes_inexact, n_hits_inexact, n_regions, n_region_items, n_arena_overflow;
+    uint64_t n_expand, n_colour_elem, n_path_base, n_align, n_align_cells;
+    uint64_t in_bases, out_bases;
+} rtk_stats;
+
+/* dbg.read(G.fasta.gz) + readGraphData(G.rtsk) (reference: src/Ratatosk.cpp:1087-1089; src/Graph.cpp:722-784).
+ * Parses the unitig FASTA(.gz) and the .rtsk records, rebuilds the k-mer index (the .bfi file is ignored),
+ * flattens everything to SoA/CSR arrays. k must be odd and <= 31 (pass-1 scope). */
+int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out);
+
+/* Copies the flat graph into HBM of `device` (HIP device ordinal). Must precede any compute call. */
+int rtk_graph_upload(rtk_graph* g, int device);
+
+/* Multi-GPU: rank 0 has loaded the graph; the others create an empty shell with rtk_graph_shell(), every rank
+ * exposes its flat buffers so the caller can broadcast them (RCCL over xGMI via torch.distributed), then calls
+ * rtk_graph_adopt_device() to mark the HBM image valid. Buffer order is fixed; sizes come from rank 0's info. */
+int rtk_graph_shell(int k, rtk_graph** out);
+int rtk_graph_n_buffers(const rtk_graph* g);
+int rtk_graph_buffer(rtk_graph* g, int idx, void** dev_ptr, uint64_t* bytes);
+int rtk_graph_alloc_buffers(rtk_graph* g, int device, const uint64_t* bytes, int n, const rtk_graph_info* info);
+int rtk_graph_adopt_device(rtk_graph* g);
+
+int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info);
+void rtk_graph_free(rtk_graph* g);
+
+/* Correct_Opt defaults + max_km_cov derived from the graph (reference: src/Common.hpp:101-156, src/Ratatosk.cpp:625). */
+int rtk_opts_default(const rtk_graph* g, rtk_opts* opts);
+
+/* The per-read loop body over one batch (reference: src/Ratatosk.cpp:808-864): upper-casing, quality clamp,
+ * getSeeds, correctSequence. Inputs are borrowed; out_seq[i]/out_qual[i] are malloc'd NUL-terminated strings
+ * owned by the caller (release with rtk_free). qual may be NULL (FASTA input). */
+int rtk_correct_batch(rtk_graph* g, const rtk_opts* opts, uint32_t n, const char* const* seq, const char* const* qual,
+                      const uint32_t* len, char** out_seq, char** out_qual, uint32_t* out_len);
+
+/* Same work split so that a caller can keep the batch resident in HBM across the timed region:
+ * create = pack + H2D copy, run = kernels only (synchronous), fetch = D2H + unpack. */
+int rtk_batch_create(rtk_graph* g, uint32_t n, const char* const* seq, const char* const* qual, const uint32_t* len, rtk_batch** out);
+int rtk_batch_run(rtk_batch* b, const rtk_opts* opts);
+int rtk_batch_fetch(rtk_batch* b, char** out_seq, char** out_qual, uint32_t* out_len);
+int rtk_batch_get_stats(const rtk_batch* b, rtk_stats* stats);
+void rtk_batch_free(rtk_batch* b);
+
+/* ---- stage-level entry points (used by the parity tests; same kernels as rtk_batch_run) ---- */
+
+/* dbg.searchSequence(s, true, false, false, false, false) (reference: src/Graph.cpp:97): for every k-mer window p of
+ * seq, hits[p] = unitig<<33 | dist<<1 | strand, or -1 when the window is not in the graph / holds a non-ACGT. */
+int rtk_lookup_exact(rtk_graph* g, const char* seq, uint32_t len, int64_t* hits);
+
+/* getSeeds (reference: src/Graph.cpp:3-482): anchors as (pos, unitig, dist, strand) quadruples. */
+int rtk_seeds(rtk_graph* g, const rtk_opts* opts, const char* seq, uint32_t len,
+              uint64_t* n_solid, int64_t* solid, uint64_t* n_weak, int64_t* weak, uint64_t cap);
+
+/* edlibAlign + edlibAlignmentToCigar (reference: src/edlib.cpp:141,298) with the IUPAC equality table of
+ * src/Common.hpp:262-276 (use_iupac=0: edlibDefaultAlignConfig). mode 0 NW, 1 SHW, 2 HW; k<0 unbounded.
+ * dist[i] = editDistance or -1; end_locs holds up to cap_locs locations per problem; cigars (standard format)
+ * are written at cigar + i*cap_cigar when want_path. */
+int rtk_myers_batch(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
+                    const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
+                    int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar);
+
+void rtk_free(void* p);
+const char* rtk_last_error(void);
+const char* rtk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RATATOSK_HIP_H */

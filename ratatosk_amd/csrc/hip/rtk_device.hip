@@ -1,0 +1,300 @@
+// libratatosk_hip.so: HIP kernels for gfx950 + the C ABI of include/ratatosk_hip.h.
+// (Compiled a second time with -DRTK_SIM by tests/hostsim into a developer simulator; see rtk_wave.h.)
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../../include/ratatosk_hip.h"
+#include "../host/flat_graph.hpp"
+#include "rtk_mem.h"
+#include "rtk_myers.h"
+#include "rtk_types.h"
+#include "rtk_wave.h"
+
+#ifdef RTK_SIM
+thread_local int rtk_sim_block_id = 0;
+#endif
+
+// ------------------------------------------------------------------------------------------------ error handling
+static thread_local std::string g_last_error;
+static int rtk_fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+extern "C" const char* rtk_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* rtk_version(void) {
+#ifdef RTK_SIM
+    return "ratatosk-mi355x 0.1 (host simulator)";
+#else
+    return "ratatosk-mi355x 0.1 (gfx950)";
+#endif
+}
+extern "C" void rtk_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------------------------ graph object
+struct rtk_graph {
+    rtk::FlatGraph host;
+    bool has_host = false, on_device = false;
+    int device = -1;
+    void* dbuf[rtk::RTK_N_BUFS];
+    uint64_t dbytes[rtk::RTK_N_BUFS];
+    GraphView dview;
+    rtk_graph_info info;
+    rtk_graph() { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { dbuf[i] = nullptr; dbytes[i] = 0; } memset(&dview, 0, sizeof(dview)); memset(&info, 0, sizeof(info)); }
+};
+
+static void graph_set_view(rtk_graph* g) {
+    GraphView& v = g->dview;
+    v.k = g->info.k; v.n_unitigs = static_cast<uint32_t>(g->info.n_unitigs); v.n_kmers = g->info.n_kmers; v.ht_mask = g->info.table_slots - 1;
+    v.useq = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_USEQ]); v.uoff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_UOFF]);
+    v.adj = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_ADJ]); v.flags = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_FLAGS]);
+    v.kcov = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_KCOV]); v.card = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_CARD]);
+    v.loff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_LOFF]); v.gid = static_cast<const int32_t*>(g->dbuf[rtk::RTK_BUF_GID]);
+    v.goff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_GOFF]); v.col = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_COL]);
+    v.ht = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HT]);
+}
+
+extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out) {
+    if (!unitig_fasta_gz || !rtsk || !out) return rtk_fail(RTK_ERR_ARG, "rtk_graph_load: null argument");
+    std::unique_ptr<rtk_graph> g(new rtk_graph());
+    try { g->host.load(unitig_fasta_gz, rtsk, k, n_threads); }
+    catch (const std::exception& e) { return rtk_fail(RTK_ERR_FORMAT, std::string("rtk_graph_load: ") + e.what()); }
+    g->has_host = true;
+    rtk_graph_info& i = g->info;
+    i.k = k; i.device = -1; i.n_unitigs = g->host.n_unitigs(); i.n_kmers = g->host.n_kmers; i.n_bases = g->host.uoff.back();
+    i.n_colour_ids = g->host.col.size() - 1; i.n_global_sets = g->host.n_global; i.table_slots = g->host.ht.size() / 2; i.hbm_bytes = g->host.bytes();
+    i.max_km_cov_top = g->host.max_km_cov_top;
+    *out = g.release();
+    return RTK_OK;
+}
+
+extern "C" int rtk_graph_shell(int k, rtk_graph** out) {
+    if (!out) return rtk_fail(RTK_ERR_ARG, "rtk_graph_shell: null argument");
+    rtk_graph* g = new rtk_graph(); g->info.k = k; *out = g; return RTK_OK;
+}
+
+extern "C" int rtk_graph_n_buffers(const rtk_graph*) { return rtk::RTK_N_BUFS; }
+
+static int require_device(int device) {
+    const int n = rtk_device_count();
+    if (n <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "no HIP device visible: the correction path has no CPU fallback");
+    if (device < 0 || device >= n) return rtk_fail(RTK_ERR_ARG, "bad device ordinal");
+    return RTK_OK;
+}
+
+extern "C" int rtk_graph_alloc_buffers(rtk_graph* g, int device, const uint64_t* bytes, int n, const rtk_graph_info* info) {
+    if (!g || !bytes || !info || n != rtk::RTK_N_BUFS) return rtk_fail(RTK_ERR_ARG, "rtk_graph_alloc_buffers: bad argument");
+    int rc = require_device(device); if (rc) return rc;
+    try {
+        rtk_set_device(device);
+        for (int i = 0; i < n; ++i) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; }
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
+    g->info = *info; g->info.device = device; g->device = device;
+    return RTK_OK;
+}
+
+extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
+    if (!g || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: graph has no host image");
+    int rc = require_device(device); if (rc) return rc;
+    const rtk::FlatGraph& h = g->host;
+    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data() };
+    const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size() };
+    try {
+        rtk_set_device(device);
+        for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { if (!g->dbuf[i]) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; } rtk_h2d(g->dbuf[i], src[i], bytes[i]); }
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
+    g->device = device; g->info.device = device; g->on_device = true;
+    graph_set_view(g);
+    return RTK_OK;
+}
+
+extern "C" int rtk_graph_buffer(rtk_graph* g, int idx, void** dev_ptr, uint64_t* bytes) {
+    if (!g || idx < 0 || idx >= rtk::RTK_N_BUFS || !dev_ptr || !bytes) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer: bad argument");
+    *dev_ptr = g->dbuf[idx]; *bytes = g->dbytes[idx];
+    return RTK_OK;
+}
+
+extern "C" int rtk_graph_adopt_device(rtk_graph* g) {
+    if (!g) return rtk_fail(RTK_ERR_ARG, "rtk_graph_adopt_device: null");
+    for (int i = 0; i < rtk::RTK_N_BUFS; ++i) if (!g->dbuf[i]) return rtk_fail(RTK_ERR_ARG, "rtk_graph_adopt_device: buffers not allocated");
+    g->on_device = true; graph_set_view(g);
+    return RTK_OK;
+}
+
+extern "C" int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info) { if (!g || !info) return rtk_fail(RTK_ERR_ARG, "rtk_graph_get_info: null"); *info = g->info; return RTK_OK; }
+
+extern "C" void rtk_graph_free(rtk_graph* g) {
+    if (!g) return;
+    for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
+    delete g;
+}
+
+extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
+    if (!o) return rtk_fail(RTK_ERR_ARG, "rtk_opts_default: null");
+    o->insert_sz = 500; o->min_cov_vertices = 2; o->max_len_weak_region1 = 1000;
+    o->max_km_cov = 128; if (g && g->info.max_km_cov_top > 128) o->max_km_cov = g->info.max_km_cov_top; // src/Ratatosk.cpp:625
+    o->weak_region_len_factor = 0.25; o->large_k_factor = 1.5; o->min_score = 0.0; o->max_qual = 40; o->out_qual = 1;
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-wave scratch
+struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };
+
+static uint64_t scratch_bytes(const ScratchCfg& c) {
+    uint64_t b = 0;
+    b += 8ull * 15 * c.w_cap; b += (c.t_cap + 63) / 64 * 64; b += 4ull * c.t_cap; b += 8ull * c.tb_cap_words; b += 8ull * c.r_cap;
+    b += 2ull * ((c.mv_cap + 63) / 64 * 64); b += 4 * 5 * 64; b += 64;
+    return (b + 255) / 256 * 256;
+}
+
+RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
+    MyersScratch s; char* p = base;
+    s.peq = reinterpret_cast<uint64_t*>(p); p += 8ull * 15 * c.w_cap; s.w_cap = c.w_cap;
+    s.tb = reinterpret_cast<uint64_t*>(p); p += 8ull * c.tb_cap_words; s.tb_cap_words = c.tb_cap_words;
+    s.colscore = reinterpret_cast<int32_t*>(p); p += 4ull * c.t_cap; s.t_cap = c.t_cap;
+    s.rowL = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.rowR = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.r_cap = c.r_cap;
+    s.hstack = reinterpret_cast<int32_t*>(p); p += 4 * 5 * 64;
+    s.overflow = reinterpret_cast<uint32_t*>(p); p += 64;
+    s.carry = reinterpret_cast<int8_t*>(p); p += (c.t_cap + 63) / 64 * 64;
+    s.moves = reinterpret_cast<uint8_t*>(p); p += (c.mv_cap + 63) / 64 * 64; s.moves_tmp = reinterpret_cast<uint8_t*>(p); s.mv_cap = c.mv_cap;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ K1: exact k-mer lookup
+// dbg.searchSequence(s, exact) (reference: src/Graph.cpp:97 [A1]). One lane per k-mer window; windows are addressed
+// by their base position in the concatenated read buffer. hits[b] = packed (unitig, dist, strand) or RTK_NO_HIT.
+RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* roff, uint32_t n_reads, uint64_t n_bases, int grid, uint64_t* hits, uint64_t* n_probes_out) {
+    const uint64_t n_tiles = (n_bases + RTK_WAVE - 1) / RTK_WAVE;
+    uint32_t probes = 0;
+    for (uint64_t tile = static_cast<uint64_t>(RTK_BLOCK_ID); tile < n_tiles; tile += static_cast<uint64_t>(grid)) {
+        const uint64_t b = tile * RTK_WAVE + static_cast<uint64_t>(rtk_lane());
+        if (b >= n_bases) continue;
+        // owning read: largest r with roff[r] <= b
+        uint32_t lo = 0, hi = n_reads;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (roff[mid] <= b) lo = mid; else hi = mid; }
+        uint64_t h = RTK_NO_HIT;
+        if (b + static_cast<uint64_t>(g.k) <= roff[lo + 1]) {
+            uint64_t fw = 0; bool ok = true;
+            for (int i = 0; i < g.k; ++i) {
+                const int c = rtk_cls(static_cast<unsigned char>(seq[b + i]));
+                if (c > 3) { ok = false; break; }
+                fw = (fw << 2) | static_cast<uint64_t>(c);
+            }
+            if (ok) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += np; }
+        }
+        hits[b] = h;
+    }
+    if (n_probes_out) { const int tot = rtk_wave_sum(static_cast<int>(probes)); if (rtk_lane() == 0 && tot) rtk_atomic_add(reinterpret_cast<unsigned long long*>(n_probes_out), static_cast<unsigned long long>(tot)); }
+}
+
+static int default_grid() {
+#ifdef RTK_SIM
+    return 64;
+#else
+    return 256 * 16; // 256 CUs x 16 single-wave workgroups
+#endif
+}
+
+extern "C" int rtk_lookup_exact(rtk_graph* g, const char* seq, uint32_t len, int64_t* hits) {
+    if (!g || !seq || !hits) return rtk_fail(RTK_ERR_ARG, "rtk_lookup_exact: null argument");
+    if (!g->on_device) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_lookup_exact: graph is not resident on a device (call rtk_graph_upload)");
+    try {
+        rtk_set_device(g->device);
+        std::string up(seq, len);
+        for (size_t i = 0; i < up.size(); ++i) up[i] = static_cast<char>(toupper(static_cast<unsigned char>(up[i])));
+        char* dseq = static_cast<char*>(rtk_dmalloc(len + 64));
+        uint64_t* droff = static_cast<uint64_t*>(rtk_dmalloc(16));
+        uint64_t* dhits = static_cast<uint64_t*>(rtk_dmalloc(8ull * (len + 1)));
+        const uint64_t roff[2] = {0, len};
+        rtk_h2d(dseq, up.data(), len); rtk_h2d(droff, roff, 16);
+        rtk_launch(k_lookup_exact, default_grid(), 0, g->dview, static_cast<const char*>(dseq), static_cast<const uint64_t*>(droff), 1u, static_cast<uint64_t>(len), default_grid(), dhits, static_cast<uint64_t*>(nullptr));
+        rtk_dsync();
+        std::vector<uint64_t> h(len + 1);
+        rtk_d2h(h.data(), dhits, 8ull * len);
+        const uint32_t nw = len >= static_cast<uint32_t>(g->info.k) ? len - g->info.k + 1 : 0;
+        for (uint32_t i = 0; i < nw; ++i) hits[i] = (h[i] == RTK_NO_HIT) ? -1 : static_cast<int64_t>(h[i]);
+        rtk_dfree(dseq); rtk_dfree(droff); rtk_dfree(dhits);
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K6/K7: Myers batch
+struct MyersProb { uint64_t q_off, t_off; uint32_t qlen, tlen; int32_t k, mode; };
+
+RTK_GLOBAL void k_myers_batch(const MyersProb* probs, uint32_t n, const char* pool, int want_path, int use_iupac, char* scratch, uint64_t scratch_stride, ScratchCfg cfg,
+                              int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status) {
+    const MyersScratch sc = scratch_carve(scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * scratch_stride, cfg);
+    for (uint32_t i = static_cast<uint32_t>(RTK_BLOCK_ID); i < n; i += static_cast<uint32_t>(grid)) {
+        const MyersProb p = probs[i];
+        *sc.overflow = 0;
+        const char* q = pool + p.q_off; const char* t = pool + p.t_off;
+        const MyersResult r = rtk_myers_distance(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.k, p.mode, use_iupac != 0, end_locs + static_cast<uint64_t>(i) * cap_locs, static_cast<int>(cap_locs));
+        dist[i] = r.dist; n_loc[i] = r.nloc;
+        uint32_t nm = 0;
+        if (want_path && r.dist >= 0 && p.qlen > 0 && p.tlen > 0) { // edlib.cpp:271-284 (zero-length inputs return before any path is built)
+            rtk_myers_alignment(sc, q, static_cast<int>(p.qlen), t, r.first + 1, r.dist, use_iupac != 0, &nm);
+            if (nm <= cap_moves) rtk_wcopy(moves_out + static_cast<uint64_t>(i) * cap_moves, sc.moves, nm);
+        }
+        n_moves_out[i] = nm;
+        status[i] = *sc.overflow;
+    }
+}
+
+extern "C" int rtk_myers_batch(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
+                               const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
+                               int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar) {
+    if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || !end_locs) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch: null argument");
+    if (rtk_device_count() <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_myers_batch: no HIP device visible (no CPU fallback)");
+    if (n == 0) return RTK_OK;
+    try {
+        std::vector<MyersProb> probs(n);
+        std::string pool;
+        uint32_t max_q = 1, max_t = 1;
+        for (uint32_t i = 0; i < n; ++i) {
+            probs[i].q_off = pool.size(); pool.append(query[i], qlen[i]);
+            probs[i].t_off = pool.size(); pool.append(target[i], tlen[i]);
+            probs[i].qlen = qlen[i]; probs[i].tlen = tlen[i]; probs[i].k = k[i]; probs[i].mode = mode[i];
+            if (mode[i] == RTK_MODE_HW && want_path) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_myers_batch: HW path alignment is not on the hot path");
+            max_q = std::max(max_q, qlen[i]); max_t = std::max(max_t, tlen[i]);
+        }
+        ScratchCfg cfg;
+        cfg.w_cap = (max_q + 63) / 64 + 1; cfg.t_cap = max_t + 64; cfg.r_cap = max_q + 64; cfg.mv_cap = max_q + max_t + 64;
+        cfg.tb_cap_words = std::max<uint64_t>(4ull * 52429 + 64, 4ull * cfg.w_cap + 64);
+        const int grid = static_cast<int>(std::min<uint32_t>(n, static_cast<uint32_t>(default_grid() / 4 > 0 ? default_grid() / 4 : 1)));
+        const uint64_t stride = scratch_bytes(cfg);
+        const uint32_t cap_moves = want_path ? (max_q + max_t + 8) : 1;
+        char* dpool = static_cast<char*>(rtk_dmalloc(pool.size() + 64));
+        MyersProb* dprobs = static_cast<MyersProb*>(rtk_dmalloc(sizeof(MyersProb) * n));
+        char* dscr = static_cast<char*>(rtk_dmalloc(stride * grid));
+        int32_t* ddist = static_cast<int32_t*>(rtk_dmalloc(4ull * n)); int32_t* dnloc = static_cast<int32_t*>(rtk_dmalloc(4ull * n));
+        int32_t* dlocs = static_cast<int32_t*>(rtk_dmalloc(4ull * n * cap_locs + 8));
+        uint8_t* dmoves = static_cast<uint8_t*>(rtk_dmalloc(static_cast<uint64_t>(n) * cap_moves + 8));
+        uint32_t* dnm = static_cast<uint32_t*>(rtk_dmalloc(4ull * n)); uint32_t* dst = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
+        rtk_h2d(dpool, pool.data(), pool.size()); rtk_h2d(dprobs, probs.data(), sizeof(MyersProb) * n);
+        rtk_launch(k_myers_batch, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst);
+        rtk_dsync();
+        std::vector<uint32_t> st(n), nm(n);
+        rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs);
+        rtk_d2h(st.data(), dst, 4ull * n); rtk_d2h(nm.data(), dnm, 4ull * n);
+        int rc = RTK_OK;
+        for (uint32_t i = 0; i < n; ++i) if (st[i]) rc = rtk_fail(RTK_ERR_DEVICE, "rtk_myers_batch: scratch capacity exceeded on device");
+        if (want_path && cigar && rc == RTK_OK) {
+            std::vector<uint8_t> mv(static_cast<size_t>(n) * cap_moves);
+            rtk_d2h(mv.data(), dmoves, mv.size());
+            static const char code[4] = {'M', 'I', 'D', 'M'};
+            for (uint32_t i = 0; i < n; ++i) { // edlibAlignmentToCigar, EDLIB_CIGAR_STANDARD (edlib.cpp:298-347)
+                std::string c;
+                const uint8_t* a = &mv[static_cast<size_t>(i) * cap_moves];
+                for (uint32_t x = 0; x < nm[i];) { uint32_t y = x; while (y < nm[i] && code[a[y]] == code[a[x]]) ++y; c += std::to_string(y - x); c.push_back(code[a[x]]); x = y; }
+                if (c.size() + 1 > cap_cigar) { rc = rtk_fail(RTK_ERR_ARG, "rtk_myers_batch: cigar buffer too small"); break; }
+                memcpy(cigar + static_cast<size_t>(i) * cap_cigar, c.c_str(), c.size() + 1);
+            }
+        }
+        rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dmoves); rtk_dfree(dnm); rtk_dfree(dst);
+        return rc;
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
+}
+
+#include "rtk_pipeline.inc"

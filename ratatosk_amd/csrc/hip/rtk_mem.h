@@ -1,0 +1,81 @@
+// Device memory / launch shim: HIP on gfx950; plain host memory and a thread pool for the RTK_SIM developer simulator.
+#ifndef RTK_MEM_H
+#define RTK_MEM_H
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <string>
+
+#ifdef RTK_SIM
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#define RTK_GLOBAL inline
+extern thread_local int rtk_sim_block_id;
+#define RTK_BLOCK_ID rtk_sim_block_id
+typedef int rtk_stream_t;
+
+inline void* rtk_dmalloc(uint64_t bytes) { void* p = calloc(bytes ? bytes : 1, 1); if (!p) throw std::runtime_error("sim: out of memory"); return p; }
+inline void rtk_dfree(void* p) { free(p); }
+inline void rtk_h2d(void* d, const void* h, uint64_t n) { if (n) memcpy(d, h, n); }
+inline void rtk_d2h(void* h, const void* d, uint64_t n) { if (n) memcpy(h, d, n); }
+inline void rtk_dzero(void* d, uint64_t n) { if (n) memset(d, 0, n); }
+inline void rtk_dsync() {}
+inline int rtk_device_count() { return 1; }
+inline void rtk_set_device(int) {}
+
+template <class F, class... A>
+inline void rtk_launch(F f, int grid, rtk_stream_t, A... a) {
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 16) nt = 16;
+    if (static_cast<int>(nt) > grid) nt = static_cast<unsigned>(grid > 0 ? grid : 1);
+    std::atomic<int> next(0);
+    auto work = [&]() { while (true) { const int b = next.fetch_add(1); if (b >= grid) break; rtk_sim_block_id = b; f(a...); } };
+    if (nt <= 1) { work(); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
+    for (size_t t = 0; t < th.size(); ++t) th[t].join();
+}
+
+struct RtkTimer { double ms; void start(rtk_stream_t) { ms = 0; } void stop(rtk_stream_t) {} double elapsed() { return 0.0; } };
+
+#else
+
+#include <hip/hip_runtime.h>
+
+#define RTK_GLOBAL __global__
+#define RTK_BLOCK_ID (static_cast<int>(blockIdx.x))
+typedef hipStream_t rtk_stream_t;
+
+inline void rtk_check(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
+inline void* rtk_dmalloc(uint64_t bytes) { void* p = nullptr; rtk_check(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc"); return p; }
+inline void rtk_dfree(void* p) { if (p) (void)hipFree(p); }
+inline void rtk_h2d(void* d, const void* h, uint64_t n) { if (n) rtk_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+inline void rtk_d2h(void* h, const void* d, uint64_t n) { if (n) rtk_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+inline void rtk_dzero(void* d, uint64_t n) { if (n) rtk_check(hipMemset(d, 0, n), "hipMemset"); }
+inline void rtk_dsync() { rtk_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+inline int rtk_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+inline void rtk_set_device(int d) { rtk_check(hipSetDevice(d), "hipSetDevice"); }
+
+template <class F, class... A>
+inline void rtk_launch(F f, int grid, rtk_stream_t s, A... a) {
+    hipLaunchKernelGGL(f, dim3(static_cast<unsigned>(grid)), dim3(64), 0, s, a...);
+    rtk_check(hipGetLastError(), "kernel launch");
+}
+
+struct RtkTimer { // HIP events on the stream the kernels are launched on
+    hipEvent_t a, b; bool ok;
+    RtkTimer() : ok(false) { if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) ok = true; }
+    ~RtkTimer() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+    void start(rtk_stream_t s) { if (ok) (void)hipEventRecord(a, s); }
+    void stop(rtk_stream_t s) { if (ok) (void)hipEventRecord(b, s); }
+    double elapsed() { float ms = 0; if (ok) { (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); } return ms; }
+};
+
+#endif
+
+#endif

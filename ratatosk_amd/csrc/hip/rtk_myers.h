@@ -1,0 +1,350 @@
+// Bit-parallel Myers/Hyyro edit distance on one wavefront, with the observable behaviour of the reference's
+// vendored edlib (reference: src/edlib.cpp:141-296 edlibAlign; :547-704 semi-global; :730-931 NW; :945-1144
+// traceback; :1164-1216 traceback/Hirschberg switch; :1234-1399 Hirschberg; src/Common.hpp:262-276 equalities).
+//
+// Layout: one 64-bit word of the query per lane; the carry between vertically adjacent words travels lane->lane+1
+// with one __shfl_up per step, so the wave sweeps the DP matrix along anti-diagonals ("step s: lane l works on
+// column s-l"). Queries longer than 64 words are processed in row blocks of 64 words; the horizontal deltas leaving
+// a block are parked in a per-column int8 array and picked up by lane 0 of the next block. Whole columns are
+// computed (no Ukkonen band): the band of edlib only prunes cells that cannot lie on an optimal path, so distances,
+// end locations and the traceback are unaffected (see oracle/oracle_myers.hpp; pinned against the reference build).
+// The query profile is indexed by character class (15 IUPAC letters); any other byte is compared on the fly.
+#ifndef RTK_MYERS_H
+#define RTK_MYERS_H
+
+#include "rtk_wave.h"
+
+#define RTK_MODE_NW 0
+#define RTK_MODE_SHW 1
+#define RTK_MODE_HW 2
+
+struct MyersScratch {
+    uint64_t* peq;       // [15 * w_cap]
+    uint32_t w_cap;      // max query words
+    int8_t* carry;       // [t_cap]
+    int32_t* colscore;   // [t_cap] last-row score of every column
+    uint32_t t_cap;      // max target columns
+    uint64_t* tb;        // [tb_cap_words] traceback table, 4 words per (column, query word): Pv, Mv, Ph, Mh
+    uint64_t tb_cap_words;
+    int32_t* rowL;       // [r_cap] Hirschberg: D(left half)[row]
+    int32_t* rowR;       // [r_cap]
+    uint32_t r_cap;
+    uint8_t* moves;      // [mv_cap] alignment moves: 0 match, 1 insert (query only), 2 delete (target only), 3 mismatch
+    uint8_t* moves_tmp;  // [mv_cap]
+    uint32_t mv_cap;
+    int32_t* hstack;     // [5 * 64] explicit Hirschberg stack
+    uint32_t* overflow;  // set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
+};
+
+struct MySeq { // a character sequence read forwards or backwards (Hirschberg aligns reversed halves, edlib.cpp:1259-1263)
+    const char* p; int32_t n; int32_t rev;
+};
+RTK_DEV MySeq rtk_seq(const char* p, int32_t n, int32_t rev = 0) { MySeq s; s.p = p; s.n = n; s.rev = rev; return s; }
+RTK_DEV unsigned char rtk_seq_at(const MySeq& s, int32_t i) { return static_cast<unsigned char>(s.rev ? s.p[s.n - 1 - i] : s.p[i]); }
+
+// character class: 0..3 A C G T, 4..14 M R S V W Y H K D B N, 15 anything else
+RTK_DEV int rtk_cls(unsigned char c) {
+    switch (c) {
+        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+        case 'M': return 4; case 'R': return 5; case 'S': return 6; case 'V': return 7; case 'W': return 8; case 'Y': return 9;
+        case 'H': return 10; case 'K': return 11; case 'D': return 12; case 'B': return 13; case 'N': return 14;
+        default: return 15;
+    }
+}
+
+// 15-bit set of classes a character of class c is equal to (identity + the 28 (code, base) pairs of Common.hpp:262-274)
+RTK_DEV uint32_t rtk_eq_classes(int c, bool iupac) {
+    if (c >= 15) return 0u;
+    uint32_t m = 1u << c;
+    if (!iupac) return m;
+    // base sets of the codes:           M    R    S    V    W    Y    H     K     D     B     N
+    const uint32_t code_set[11] = {0x3, 0x5, 0x6, 0x7, 0x9, 0xA, 0xB, 0xC, 0xD, 0xE, 0xF};
+    if (c < 4) { for (int i = 0; i < 11; ++i) if ((code_set[i] >> c) & 1u) m |= 1u << (4 + i); }
+    else m |= code_set[c - 4];
+    return m;
+}
+
+RTK_DEV bool rtk_chars_equal(unsigned char a, unsigned char b, bool iupac) {
+    if (a == b) return true;
+    const int ca = rtk_cls(a), cb = rtk_cls(b);
+    if (ca >= 15 || cb >= 15) return false;
+    return (rtk_eq_classes(ca, iupac) >> cb) & 1u;
+}
+
+// One Advance_Block step (Myers 1999 / Hyyro 2003). hin, return value in {-1,0,1}; bit = row whose horizontal delta leaves the word.
+RTK_DEV int rtk_myers_step(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hin, int bit, uint64_t& Ph_out, uint64_t& Mh_out) {
+    const uint64_t pv = Pv, mv = Mv;
+    const uint64_t Xv = Eq | mv;
+    if (hin < 0) Eq |= 1ull;
+    const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+    uint64_t Ph = mv | ~(Xh | pv);
+    uint64_t Mh = pv & Xh;
+    Ph_out = Ph; Mh_out = Mh;
+    const int hout = static_cast<int>((Ph >> bit) & 1ull) - static_cast<int>((Mh >> bit) & 1ull);
+    Ph <<= 1; Mh <<= 1;
+    if (hin > 0) Ph |= 1ull; else if (hin < 0) Mh |= 1ull;
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+    return hout;
+}
+
+// Query profile: peq[cls * W + w], bit i of word w set iff query[64w+i] equals a character of class cls.
+RTK_DEV void rtk_myers_build_peq(const MyersScratch& sc, const MySeq& q, int W, bool iupac) {
+    for (int w = rtk_lane(); w < W; w += RTK_WAVE) {
+        uint64_t acc[15];
+        for (int c = 0; c < 15; ++c) acc[c] = 0;
+        const int lim = (q.n - 64 * w) < 64 ? (q.n - 64 * w) : 64;
+        for (int i = 0; i < lim; ++i) {
+            uint32_t m = rtk_eq_classes(rtk_cls(rtk_seq_at(q, 64 * w + i)), iupac);
+            for (int c = 0; c < 15; ++c) acc[c] |= static_cast<uint64_t>((m >> c) & 1u) << i;
+        }
+        for (int c = 0; c < 15; ++c) sc.peq[static_cast<uint64_t>(c) * W + w] = acc[c];
+    }
+    rtk_sync();
+}
+
+RTK_DEV uint64_t rtk_myers_eq_word(const MyersScratch& sc, const MySeq& q, int W, int w, unsigned char tc) {
+    const int cls = rtk_cls(tc);
+    if (cls < 15) return sc.peq[static_cast<uint64_t>(cls) * W + w];
+    uint64_t e = 0; // a byte outside the IUPAC alphabet only equals itself
+    const int lim = (q.n - 64 * w) < 64 ? (q.n - 64 * w) : 64;
+    for (int i = 0; i < lim; ++i) e |= static_cast<uint64_t>(rtk_seq_at(q, 64 * w + i) == tc) << i;
+    return e;
+}
+
+// Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
+// table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
+// top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
+RTK_DEV void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, int store, uint64_t* fin_pv, uint64_t* fin_mv) {
+    const int m = q.n, n = t.n, W = (m + 63) >> 6, last_bit = (m - 1) & 63;
+    rtk_myers_build_peq(sc, q, W, iupac);
+#ifdef RTK_SIM
+    int score = m;
+    // the simulator walks the matrix column by column; per-word state lives in fin arrays or a local buffer
+    uint64_t* Pv = fin_pv; uint64_t* Mv = fin_mv;
+    uint64_t lpv[64], lmv[64]; // only used when the caller does not want the final vectors and W <= 64
+    uint64_t* heapPv = nullptr; uint64_t* heapMv = nullptr;
+    if (!Pv) { if (W <= 64) { Pv = lpv; Mv = lmv; } else { heapPv = new uint64_t[W]; heapMv = new uint64_t[W]; Pv = heapPv; Mv = heapMv; } }
+    for (int w = 0; w < W; ++w) { Pv[w] = ~0ull; Mv[w] = 0; }
+    for (int j = 0; j < n; ++j) {
+        const unsigned char tc = rtk_seq_at(t, j);
+        int hin = top_h;
+        for (int w = 0; w < W; ++w) {
+            uint64_t Ph, Mh;
+            const uint64_t Eq = rtk_myers_eq_word(sc, q, W, w, tc);
+            hin = rtk_myers_step(Pv[w], Mv[w], Eq, hin, (w == W - 1) ? last_bit : 63, Ph, Mh);
+            if (store) { uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(j) * W + w); e[0] = Pv[w]; e[1] = Mv[w]; e[2] = Ph; e[3] = Mh; }
+        }
+        score += hin;
+        sc.colscore[j] = score;
+    }
+    delete[] heapPv; delete[] heapMv;
+#else
+    const int lane = rtk_lane();
+    for (int w0 = 0; w0 < W; w0 += 64) {
+        const int nw = (W - w0) < 64 ? (W - w0) : 64;
+        const int w = w0 + lane;
+        const bool has_word = lane < nw;
+        const bool is_last_word = has_word && (w == W - 1);
+        const bool is_block_tail = (lane == nw - 1);
+        const int bit = is_last_word ? last_bit : 63;
+        uint64_t Pv = ~0ull, Mv = 0ull;
+        int hout_prev = 0;
+        int score = m;
+        const int steps = n + nw - 1;
+        for (int s = 0; s < steps; ++s) {
+            const int col = s - lane;
+            const bool active = has_word && col >= 0 && col < n;
+            int lane0_in = top_h;
+            if (w0 != 0 && lane == 0 && s < n) lane0_in = static_cast<int>(sc.carry[s]);
+            const int hin = rtk_shfl_up1(hout_prev, lane0_in);
+            if (active) {
+                const unsigned char tc = rtk_seq_at(t, col);
+                const uint64_t Eq = rtk_myers_eq_word(sc, q, W, w, tc);
+                uint64_t Ph, Mh;
+                const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
+                if (store) { uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
+                if (is_block_tail) {
+                    if (w0 + nw < W) sc.carry[col] = static_cast<int8_t>(hout);
+                    else { score += hout; sc.colscore[col] = score; }
+                }
+                hout_prev = hout;
+            }
+        }
+        if (fin_pv && has_word) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
+        rtk_sync();
+    }
+#endif
+    rtk_sync();
+}
+
+struct MyersResult { int32_t dist, first, last, nloc; };
+
+// edlibAlign(..., TASK_DISTANCE): edit distance (or -1 if above a non-negative k), first and largest end location and
+// their number. SHW/HW report target position -1 (score m) when m % 64 != 0, like edlib's padded last block
+// (edlib.cpp:658-692). Optionally lists every end location (locs_out, up to cap).
+RTK_DEV MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, int m, const char* t, int n, int k, int mode, bool iupac,
+                                        int32_t* locs_out = nullptr, int cap = 0) {
+    MyersResult r; r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
+    if (m == 0 || n == 0) { // edlib.cpp:161-179
+        if (mode == RTK_MODE_NW) { r.dist = m > n ? m : n; r.first = r.last = n - 1; }
+        else { r.dist = m; r.first = r.last = -1; }
+        r.nloc = 1;
+        if (locs_out && cap > 0) locs_out[0] = r.first;
+        return r;
+    }
+    if (mode == RTK_MODE_NW && k >= 0 && k < (n > m ? n - m : m - n)) return r; // edlib.cpp:744-747
+    if (static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap) { *sc.overflow = 1; return r; }
+    rtk_myers_pass(sc, rtk_seq(q, m), rtk_seq(t, n), mode == RTK_MODE_HW ? 0 : 1, iupac, 0, nullptr, nullptr);
+    if (mode == RTK_MODE_NW) {
+        const int d = sc.colscore[n - 1];
+        if (k >= 0 && d > k) return r;
+        r.dist = d; r.first = r.last = n - 1; r.nloc = 1;
+        if (locs_out && cap > 0) locs_out[0] = n - 1;
+        return r;
+    }
+    // min over columns, then positions of the minimum (lane-strided, reduced across the wave)
+    int best = 0x7fffffff;
+    for (int j = rtk_lane(); j < n; j += RTK_WAVE) { const int v = sc.colscore[j]; best = v < best ? v : best; }
+#ifndef RTK_SIM
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(best, o, 64); best = v < best ? v : best; }
+#endif
+    const bool pseudo = (m & 63) != 0;
+    if (pseudo && m < best) best = m;
+    if (k >= 0 && best > k) return r;
+    r.dist = best;
+    int cnt = 0, first = 0x7fffffff, last = -2;
+    if (pseudo && m == best) { cnt = 1; first = -1; last = -1; if (locs_out && cap > 0) locs_out[0] = -1; }
+    for (int j0 = 0; j0 < n; j0 += RTK_WAVE) {
+        const int j = j0 + rtk_lane();
+        const bool hit = (j < n) && (sc.colscore[j] == best);
+        const uint64_t b = rtk_ballot(hit);
+        if (b) {
+            const int lo = j0 + rtk_ffs(b) - 1;
+            const int hi = j0 + 63 - __builtin_clzll(b);
+            if (lo < first) first = lo;
+            if (hi > last) last = hi;
+            if (locs_out) {
+                const int my = cnt + rtk_popc(b & ((1ull << rtk_lane()) - 1ull));
+                if (hit && my < cap) locs_out[my] = j;
+            }
+            cnt += rtk_popc(b);
+        }
+    }
+    rtk_sync();
+    r.first = first; r.last = last; r.nloc = cnt;
+    return r;
+}
+
+// Canonical NW traceback over the stored table, preferring up (insert) > left (delete) > diagonal
+// (edlib.cpp:1021-1137). Appends the moves (already in forward order) to sc.moves at *n_moves.
+RTK_DEV void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const MySeq& t, bool iupac, uint32_t* n_moves) {
+    const int m = q.n, n = t.n, W = (m + 63) >> 6;
+    rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr);
+    int cur = sc.colscore[n - 1];
+    int i = m, j = n;
+    uint32_t nt = 0; // moves are produced backwards into moves_tmp, from its end
+    uint8_t* tmp = sc.moves_tmp;
+    const uint32_t cap = sc.mv_cap;
+    while (i > 0 && j > 0) {
+        const int r = i - 1, c = j - 1, w = r >> 6, b = r & 63;
+        const uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(c) * W + w);
+        const int vd = static_cast<int>((e[0] >> b) & 1ull) - static_cast<int>((e[1] >> b) & 1ull);
+        const int hd = static_cast<int>((e[2] >> b) & 1ull) - static_cast<int>((e[3] >> b) & 1ull);
+        uint8_t mv;
+        if (vd == 1) { mv = 1; --i; cur -= 1; }
+        else if (hd == 1) { mv = 2; --j; cur -= 1; }
+        else {
+            const int left = cur - hd;
+            int diag;
+            if (c == 0) diag = i - 1;
+            else { const uint64_t* el = sc.tb + 4ull * (static_cast<uint64_t>(c - 1) * W + w); diag = left - (static_cast<int>((el[0] >> b) & 1ull) - static_cast<int>((el[1] >> b) & 1ull)); }
+            mv = (diag == cur) ? 0 : 3;
+            --i; --j; cur = diag;
+        }
+        ++nt; tmp[cap - nt] = mv;
+    }
+    while (i > 0) { ++nt; tmp[cap - nt] = 1; --i; }
+    while (j > 0) { ++nt; tmp[cap - nt] = 2; --j; }
+    rtk_wcopy(sc.moves + *n_moves, tmp + (cap - nt), nt);
+    *n_moves += nt;
+}
+
+// D(query rows, last column) after a pass: out[i] = D[i+1][n], from the final vertical delta vectors.
+RTK_DEV void rtk_myers_column(const uint64_t* fin_pv, const uint64_t* fin_mv, int m, int n, int32_t* out) {
+    const int W = (m + 63) >> 6;
+    // word prefix: value at the top of word w = n + sum over previous words of (popc(P) - popc(M)) restricted to valid rows
+    for (int w0 = 0, base = n; w0 < W; w0 += RTK_WAVE) {
+        const int w = w0 + rtk_lane();
+        int delta = 0;
+        uint64_t pv = 0, mv = 0;
+        if (w < W) {
+            pv = fin_pv[w]; mv = fin_mv[w];
+            const int rows = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+            const uint64_t mask = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
+            pv &= mask; mv &= mask;
+            delta = rtk_popc(pv) - rtk_popc(mv);
+        }
+        int total;
+        const int excl = rtk_wave_excl_scan(delta, &total);
+        if (w < W) {
+            int v = base + excl;
+            const int rows = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+            for (int b = 0; b < rows; ++b) { v += static_cast<int>((pv >> b) & 1ull) - static_cast<int>((mv >> b) & 1ull); out[64 * w + b] = v; }
+        }
+        base += total;
+    }
+    rtk_sync();
+}
+
+// obtainAlignment (edlib.cpp:1164-1216) with the Hirschberg split of edlib.cpp:1234-1399 restated canonically:
+// target halved at n/2; the FIRST query row (ascending) whose left + right scores add up to the optimum, then the
+// row -1 boundary, then the last row. Iterative (explicit stack), emits moves in order into sc.moves.
+RTK_DEV void rtk_myers_alignment(const MyersScratch& sc, const char* q, int m, const char* t, int n, int best, bool iupac, uint32_t* n_moves) {
+    *n_moves = 0;
+    if (static_cast<uint32_t>(m + n) > sc.mv_cap || static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap || static_cast<uint32_t>(m) > sc.r_cap) { *sc.overflow = 1; return; }
+    int32_t* st = sc.hstack;
+    int sp = 0;
+    st[0] = 0; st[1] = m; st[2] = 0; st[3] = n; st[4] = best; sp = 1;
+    uint64_t* fin = sc.tb; // Hirschberg passes do not store the table, so its memory holds the final delta vectors (2 x 2 x W words)
+    while (sp > 0) {
+        --sp;
+        const int q0 = st[5 * sp], qm = st[5 * sp + 1], t0 = st[5 * sp + 2], tn = st[5 * sp + 3], bs = st[5 * sp + 4];
+        if (qm == 0 || tn == 0) { // edlib.cpp:1171-1178
+            rtk_wfill(sc.moves + *n_moves, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn));
+            *n_moves += static_cast<uint32_t>(qm + tn);
+            continue;
+        }
+        const long long W = (qm + 63) >> 6;
+        if ((2LL * 8 + 4) * W * tn + 8LL * tn < 1024 * 1024) { // edlib.cpp:1191-1193
+            if (static_cast<uint64_t>(4 * W * tn) > sc.tb_cap_words) { *sc.overflow = 1; return; }
+            rtk_myers_traceback(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, n_moves);
+            continue;
+        }
+        const int lh = tn / 2, rh = tn - lh;
+        if (lh == 0 || static_cast<uint64_t>(4 * W) > sc.tb_cap_words || sp + 2 > 60) { *sc.overflow = 1; return; }
+        rtk_myers_pass(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, lh), 1, iupac, 0, fin, fin + W);
+        rtk_myers_column(fin, fin + W, qm, lh, sc.rowL);
+        rtk_myers_pass(sc, rtk_seq(q + q0, qm, 1), rtk_seq(t + t0 + lh, rh, 1), 1, iupac, 0, fin + 2 * W, fin + 3 * W);
+        rtk_myers_column(fin + 2 * W, fin + 3 * W, qm, rh, sc.rowR);
+        // R(i) = cost of aligning q[i..qm) with the right half = rowR[qm-1-i]
+        int split = -2;
+        for (int b0 = 0; b0 + 1 < qm && split == -2; b0 += RTK_WAVE) {
+            const int qi = b0 + rtk_lane();
+            const bool ok = (qi + 1 < qm) && (sc.rowL[qi] + sc.rowR[qm - 2 - qi] == bs);
+            const uint64_t bal = rtk_ballot(ok);
+            if (bal) split = b0 + rtk_ffs(bal) - 1;
+        }
+        int ls, rs;
+        if (split >= 0) { ls = sc.rowL[split]; rs = sc.rowR[qm - 2 - split]; }
+        else if (lh + sc.rowR[qm - 1] == bs) { split = -1; ls = lh; rs = sc.rowR[qm - 1]; }
+        else if (sc.rowL[qm - 1] + rh == bs) { split = qm - 1; ls = sc.rowL[qm - 1]; rs = rh; }
+        else { *sc.overflow = 2; return; } // inconsistent optimum: cannot happen for a correct distance
+        const int ul = split + 1;
+        // push right then left so that the left half is emitted first
+        st[5 * sp] = q0 + ul; st[5 * sp + 1] = qm - ul; st[5 * sp + 2] = t0 + lh; st[5 * sp + 3] = rh; st[5 * sp + 4] = rs; ++sp;
+        st[5 * sp] = q0; st[5 * sp + 1] = ul; st[5 * sp + 2] = t0; st[5 * sp + 3] = lh; st[5 * sp + 4] = ls; ++sp;
+    }
+}
+
+#endif

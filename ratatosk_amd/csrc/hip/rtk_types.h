@@ -1,0 +1,103 @@
+// POD views shared by the host loader, the HIP kernels and the C-ABI layer.
+//
+// Flat, read-only image of the compacted coloured de Bruijn graph as it lives in HBM (SoA / CSR):
+// everything the reference reaches through Bifrost's CompactedDBG<UnitigData> on the hot path
+// (reference: src/UnitigData.hpp:258-491, src/SharedPairID.cpp, Bifrost find()/getSuccessors()).
+#ifndef RTK_TYPES_H
+#define RTK_TYPES_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) && !defined(RTK_SIM)
+#include <hip/hip_runtime.h>
+#define RTK_HD __host__ __device__ __forceinline__
+#else
+#define RTK_HD inline
+#endif
+
+#define RTK_NONE32 0xFFFFFFFFu
+#define RTK_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+// per-unitig flag word
+#define RTK_F_EDGE_MASK 0xFFu      // bits 4..7 fw successor-base mask, bits 0..3 bw mask (UnitigData.hpp:275-289)
+#define RTK_F_SHORT_CYCLE (1u << 8) // UnitigData.hpp:302-305
+#define RTK_F_BRANCHING (1u << 9)   // UnitigData.hpp:407-410
+#define RTK_F_AMBIGUITY (1u << 10)  // UnitigData.hpp:483-486
+
+struct GraphView {
+    int32_t k;
+    uint32_t n_unitigs;
+    uint64_t n_kmers;
+    uint64_t ht_mask;          // slots - 1 (power of two)
+    const uint64_t* useq;      // unitig bases, 2 bits each, base i of the pool at bits [2*(i&31), +1] of word i>>5
+    const uint64_t* uoff;      // [n+1] first base of unitig u in the pool
+    const uint32_t* adj;       // [n*8] fw A,C,G,T then reverse-strand A,C,G,T: neighbour unitig<<1|strand or RTK_NONE32
+    const uint32_t* flags;     // [n]
+    const uint32_t* kcov;      // [n] round(cov/(size-k+1)) (UnitigData.hpp:396-399), precomputed in double on the host
+    const uint32_t* card;      // [n] |global| + |local|
+    const uint64_t* loff;      // [n+1] local colour set of u = col[loff[u] .. loff[u+1])
+    const int32_t* gid;        // [n] global colour set id or -1
+    const uint64_t* goff;      // [n_global+1] global set g = col[goff[g] .. goff[g+1])
+    const uint32_t* col;       // sorted u32 pair ids
+    const uint64_t* ht;        // [2*slots] {canonical k-mer, unitig<<32 | dist<<1 | stored_is_canonical}, empty key = RTK_EMPTY_KEY
+};
+
+RTK_HD uint32_t rtk_ulen(const GraphView& g, uint32_t u) { return static_cast<uint32_t>(g.uoff[u + 1] - g.uoff[u]); }
+RTK_HD uint32_t rtk_nkm(const GraphView& g, uint32_t u) { return rtk_ulen(g, u) - static_cast<uint32_t>(g.k) + 1u; }
+RTK_HD uint32_t rtk_base(const GraphView& g, uint64_t pos) { return static_cast<uint32_t>((g.useq[pos >> 5] >> (2 * (pos & 31))) & 3ull); }
+
+RTK_HD uint64_t rtk_hash64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+RTK_HD uint64_t rtk_revcomp(uint64_t x, int k) {
+    x = ~x;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * k);
+}
+
+// Unitig mapping (restates the fields of Bifrost's const_UnitigMap the hot path reads).
+struct UMap {
+    uint32_t unitig; // RTK_NONE32 == isEmpty
+    uint32_t dist;
+    uint32_t len;
+    uint32_t strand; // 1 = forward
+};
+
+RTK_HD UMap rtk_um_empty() { UMap u; u.unitig = RTK_NONE32; u.dist = 0; u.len = 0; u.strand = 1; return u; }
+RTK_HD bool rtk_um_is_empty(const UMap& u) { return u.unitig == RTK_NONE32; }
+RTK_HD bool rtk_um_eq(const UMap& a, const UMap& b) { return a.unitig == b.unitig && a.dist == b.dist && a.len == b.len && a.strand == b.strand; }
+
+// packed anchor hit: unitig<<33 | dist<<1 | strand ; all ones = no hit
+#define RTK_NO_HIT 0xFFFFFFFFFFFFFFFFull
+RTK_HD uint64_t rtk_pack_hit(uint32_t unitig, uint32_t dist, uint32_t strand) { return (static_cast<uint64_t>(unitig) << 33) | (static_cast<uint64_t>(dist) << 1) | (strand & 1u); }
+RTK_HD UMap rtk_unpack_hit(uint64_t h) { UMap u; u.unitig = static_cast<uint32_t>(h >> 33); u.dist = static_cast<uint32_t>((h >> 1) & 0xFFFFFFFFull); u.len = 1; u.strand = static_cast<uint32_t>(h & 1ull); return u; }
+
+// Exact k-mer lookup (Bifrost find(km,false) [A1]): fw = k-mer code in read orientation.
+RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probes) {
+    const uint64_t rc = rtk_revcomp(fw, g.k);
+    const uint64_t can = fw < rc ? fw : rc;
+    uint64_t i = rtk_hash64(can) & g.ht_mask;
+    uint32_t np = 0;
+    while (true) {
+        const uint64_t key = g.ht[2 * i];
+        ++np;
+        if (key == can) {
+            const uint64_t v = g.ht[2 * i + 1];
+            const uint32_t stored_is_can = static_cast<uint32_t>(v & 1ull), query_is_can = (fw <= rc) ? 1u : 0u;
+            if (n_probes) *n_probes = np;
+            return rtk_pack_hit(static_cast<uint32_t>(v >> 32), static_cast<uint32_t>((v & 0xFFFFFFFFull) >> 1), stored_is_can == query_is_can ? 1u : 0u);
+        }
+        if (key == RTK_EMPTY_KEY) { if (n_probes) *n_probes = np; return RTK_NO_HIT; }
+        i = (i + 1) & g.ht_mask;
+    }
+}
+
+#endif

@@ -1,0 +1,89 @@
+// Wavefront execution shim.
+//
+// Execution model of every kernel in this directory: ONE 64-lane wavefront (= one workgroup) owns one work item
+// (a k-mer window tile, a long read, a weak region). Control flow is wave-uniform ("scalar program"); lanes only
+// diverge inside the bulk primitives (copies, 2-bit decode, k-mer probes, bit-parallel Myers, sorted-set algebra).
+// Uniform values are stored by ALL lanes (same address, same value) so that each lane later observes its own store
+// in program order; data produced lane-parallel is published by rtk_sync() at the end of the primitive.
+//
+// RTK_SIM builds the same scalar programs for the host with a 1-lane "wave" (tests/hostsim): a developer
+// simulator used by the CPU-only test tier to exercise the device logic without a GPU. It is a separate shared
+// object, is never linked into libratatosk_hip.so and is not a fallback: the product fails with RTK_ERR_NO_DEVICE
+// when no GPU is present.
+#ifndef RTK_WAVE_H
+#define RTK_WAVE_H
+
+#include <stdint.h>
+#include <string.h>
+
+#ifdef RTK_SIM
+
+#define RTK_DEV inline
+#define RTK_DEVNOINL
+#define RTK_WAVE 1
+inline int rtk_lane() { return 0; }
+inline uint64_t rtk_ballot(bool p) { return p ? 1ull : 0ull; }
+template <class T> inline T rtk_shfl(T v, int) { return v; }
+template <class T> inline T rtk_shfl_up1(T v, T lane0_value) { (void)v; return lane0_value; }
+inline void rtk_sync() {}
+inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
+inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
+template <class T> inline T rtk_atomic_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+#else
+
+#include <hip/hip_runtime.h>
+
+#define RTK_DEV __device__ __forceinline__
+#define RTK_DEVNOINL __device__ __noinline__
+#define RTK_WAVE 64
+__device__ __forceinline__ int rtk_lane() { return static_cast<int>(threadIdx.x) & 63; }
+__device__ __forceinline__ uint64_t rtk_ballot(bool p) { return __ballot(p ? 1 : 0); }
+template <class T> __device__ __forceinline__ T rtk_shfl(T v, int src) { return __shfl(v, src, 64); }
+// value of lane-1 (lane 0 receives lane0_value)
+template <class T> __device__ __forceinline__ T rtk_shfl_up1(T v, T lane0_value) { const T r = __shfl_up(v, 1, 64); return rtk_lane() == 0 ? lane0_value : r; }
+// publishes lane-parallel stores to the other lanes of the (single-wave) workgroup
+__device__ __forceinline__ void rtk_sync() { __syncthreads(); }
+__device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
+template <class T> __device__ __forceinline__ T rtk_atomic_add(T* p, T v) { return atomicAdd(p, v); }
+
+#endif
+
+// 64-bit specialisations of shuffles are provided by HIP for (unsigned) long long; int8/bool go through int.
+
+// wave-wide reductions / scans over one value per lane
+RTK_DEV int rtk_wave_sum(int v) {
+#ifdef RTK_SIM
+    return v;
+#else
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#endif
+}
+
+RTK_DEV int rtk_wave_excl_scan(int v, int* total) { // exclusive prefix sum across lanes
+#ifdef RTK_SIM
+    *total = v; return 0;
+#else
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (rtk_lane() >= o) inc += t; }
+    *total = __shfl(inc, 63, 64);
+    return inc - v;
+#endif
+}
+
+// bulk copy / fill (lane-strided); publishes
+RTK_DEV void rtk_wcopy(void* dst, const void* src, uint64_t n) {
+    char* d = static_cast<char*>(dst); const char* s = static_cast<const char*>(src);
+    for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = s[i];
+    rtk_sync();
+}
+
+RTK_DEV void rtk_wfill(void* dst, int c, uint64_t n) {
+    char* d = static_cast<char*>(dst);
+    for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = static_cast<char>(c);
+    rtk_sync();
+}
+
+#endif

@@ -1,0 +1,159 @@
+// Flat graph construction on the host (product code): index files -> SoA/CSR arrays that are copied to HBM as-is.
+// Reference counterparts: dbg.read() (Bifrost, absent) + readGraphData (src/Graph.cpp:722-784) + the derived
+// quantities the hot path asks of UnitigData (src/UnitigData.hpp:275-410) and getMaxKmerCoverage (src/Graph.cpp:825-841).
+#include "flat_graph.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <map>
+#include <stdexcept>
+
+#include "../common/fastx.hpp"
+#include "../common/kmer.hpp"
+#include "../common/rtsk_io.hpp"
+
+namespace rtk {
+
+GraphView FlatGraph::view() const {
+    GraphView v;
+    v.k = k; v.n_unitigs = n_unitigs(); v.n_kmers = n_kmers; v.ht_mask = ht.size() / 2 - 1;
+    v.useq = useq.data(); v.uoff = uoff.data(); v.adj = adj.data(); v.flags = flags.data(); v.kcov = kcov.data(); v.card = card.data();
+    v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data();
+    return v;
+}
+
+uint64_t FlatGraph::bytes() const {
+    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
+}
+
+void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int /*n_threads*/) {
+    k = k_;
+    if (k < 3 || k > RTK_MAX_K || !(k & 1)) throw std::runtime_error("k must be odd and <= 31 (pass-1 scope; k=63 is a later row)");
+    // ---- unitigs ----
+    std::vector<std::string> seqs;
+    {
+        FastxReader fr;
+        if (!fr.open(fasta_gz)) throw std::runtime_error("cannot open graph file " + fasta_gz);
+        std::string name, seq, qual;
+        while (fr.next(name, seq, qual)) {
+            for (size_t i = 0; i < seq.size(); ++i) seq[i] = static_cast<char>(seq[i] & 0xDF);
+            if (seq.size() < static_cast<size_t>(k)) throw std::runtime_error("unitig shorter than k in " + fasta_gz);
+            seqs.push_back(seq);
+        }
+    }
+    const size_t n = seqs.size();
+    if (n == 0) throw std::runtime_error("empty graph file " + fasta_gz);
+    if (n >= 0x7FFFFFFFull) throw std::runtime_error("too many unitigs for 31-bit ids");
+    uoff.assign(n + 1, 0);
+    for (size_t u = 0; u < n; ++u) uoff[u + 1] = uoff[u] + seqs[u].size();
+    useq.assign((uoff[n] + 31) / 32 + 1, 0);
+    n_kmers = 0;
+    for (size_t u = 0; u < n; ++u) {
+        const std::string& s = seqs[u];
+        n_kmers += s.size() - k + 1;
+        for (size_t i = 0; i < s.size(); ++i) {
+            const int b = base2bits(s[i]);
+            if (b < 0) throw std::runtime_error("non-ACGT character in unitig");
+            const uint64_t p = uoff[u] + i;
+            useq[p >> 5] |= static_cast<uint64_t>(b) << (2 * (p & 31));
+        }
+    }
+    // ---- k-mer -> (unitig, offset, orientation) table, load factor <= 0.5 ----
+    uint64_t slots = 16;
+    while (slots < 2 * n_kmers) slots <<= 1;
+    ht.assign(2 * slots, 0);
+    for (uint64_t i = 0; i < slots; ++i) ht[2 * i] = RTK_EMPTY_KEY;
+    const uint64_t hmask = slots - 1, kmask = kmer_mask(k);
+    for (size_t u = 0; u < n; ++u) {
+        const std::string& s = seqs[u];
+        uint64_t fw = 0;
+        for (size_t i = 0; i < s.size(); ++i) {
+            fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & kmask;
+            if (i + 1 < static_cast<size_t>(k)) continue;
+            bool is_fw; const uint64_t can = kmer_canonical(fw, k, &is_fw);
+            uint64_t h = rtk_hash64(can) & hmask;
+            while (ht[2 * h] != RTK_EMPTY_KEY) {
+                if (ht[2 * h] == can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
+                h = (h + 1) & hmask;
+            }
+            ht[2 * h] = can;
+            ht[2 * h + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
+        }
+    }
+    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; return v; }();
+    // ---- unitig data (.rtsk) ----
+    flags.assign(n, 0); kcov.assign(n, 0); card.assign(n, 0); gid.assign(n, -1); loff.assign(n + 1, 0);
+    std::vector<std::vector<uint32_t> > locals(n);
+    std::vector<std::vector<uint32_t> > globals;
+    std::map<std::vector<uint32_t>, int32_t> gdedup; // identical global sets share one id (reference: src/Graph.cpp:748-771)
+    std::vector<char> seen(n, 0);
+    {
+        std::ifstream in(rtsk.c_str(), std::ios::binary);
+        if (!in.good()) throw std::runtime_error("cannot open unitig data file " + rtsk);
+        RtskRecord r;
+        while (rtsk_read_record(in, r)) {
+            const std::string head = disk_kmer_to_string(r.head, k);
+            uint64_t code;
+            if (!kmer_encode(head.c_str(), k, code)) throw std::runtime_error(".rtsk: bad head k-mer");
+            const uint64_t hit = rtk_find_kmer(gv0, code, nullptr);
+            if (hit == RTK_NO_HIT) throw std::runtime_error(".rtsk: head k-mer not found in the graph (reference aborts too, src/Graph.cpp:773-780)");
+            const UMap um = rtk_unpack_hit(hit);
+            const uint32_t nk = static_cast<uint32_t>(seqs[um.unitig].size()) - k + 1;
+            if (!(um.dist == 0 || um.dist == nk - 1)) throw std::runtime_error(".rtsk: head k-mer is not a unitig extremity");
+            const uint32_t u = um.unitig;
+            if (seen[u]) throw std::runtime_error(".rtsk: two records for one unitig");
+            seen[u] = 1;
+            uint32_t f = static_cast<uint32_t>(r.shared & 0xFFull);
+            if (r.shared & 0x100ull) f |= RTK_F_SHORT_CYCLE;
+            if (r.kmcov >> 63) f |= RTK_F_BRANCHING;
+            if (!r.ambiguity_ids.empty()) f |= RTK_F_AMBIGUITY;
+            flags[u] = f;
+            const uint64_t cov = (r.kmcov & 0x7fffffffull) + ((r.kmcov >> 31) & 0x7fffffffull); // phased + unphased (UnitigData.hpp:371-384)
+            kcov[u] = static_cast<uint32_t>(std::round(static_cast<double>(cov) / static_cast<double>(nk)));
+            locals[u].swap(r.local_ids);
+            if (!r.global_ids.empty()) {
+                std::map<std::vector<uint32_t>, int32_t>::iterator it = gdedup.find(r.global_ids);
+                if (it == gdedup.end()) { it = gdedup.insert(std::make_pair(r.global_ids, static_cast<int32_t>(globals.size()))).first; globals.push_back(r.global_ids); }
+                gid[u] = it->second;
+            }
+            card[u] = static_cast<uint32_t>(locals[u].size() + (gid[u] >= 0 ? globals[gid[u]].size() : 0));
+        }
+    }
+    for (size_t u = 0; u < n; ++u) if (!seen[u]) throw std::runtime_error(".rtsk: unitig without a data record");
+    n_global = globals.size();
+    for (size_t u = 0; u < n; ++u) loff[u + 1] = loff[u] + locals[u].size();
+    goff.assign(globals.size() + 1, 0);
+    goff[0] = loff[n];
+    for (size_t g = 0; g < globals.size(); ++g) goff[g + 1] = goff[g] + globals[g].size();
+    col.assign(goff[globals.size()] + 1, 0);
+    for (size_t u = 0; u < n; ++u) std::copy(locals[u].begin(), locals[u].end(), col.begin() + loff[u]);
+    for (size_t g = 0; g < globals.size(); ++g) std::copy(globals[g].begin(), globals[g].end(), col.begin() + goff[g]);
+    // ---- adjacency ([A3]: neighbours of the unitig end in walk direction, A,C,G,T) ----
+    adj.assign(n * 8, RTK_NONE32);
+    for (size_t u = 0; u < n; ++u) {
+        const std::string& s = seqs[u];
+        uint64_t tail, head;
+        kmer_encode(s.c_str() + s.size() - k, k, tail);
+        kmer_encode(s.c_str(), k, head);
+        const uint64_t ends[2] = { tail, kmer_revcomp(head, k) };
+        for (int d = 0; d < 2; ++d) for (uint64_t b = 0; b < 4; ++b) {
+            const uint64_t y = ((ends[d] << 2) | b) & kmask;
+            const uint64_t hit = rtk_find_kmer(gv0, y, nullptr);
+            if (hit == RTK_NO_HIT) continue;
+            const UMap f = rtk_unpack_hit(hit);
+            const uint32_t nk = static_cast<uint32_t>(seqs[f.unitig].size()) - k + 1;
+            // find(km, extremities_only=true): the k-mer has to open its unitig in walk direction
+            if (!((f.strand && f.dist == 0) || (!f.strand && f.dist == nk - 1))) continue;
+            adj[u * 8 + d * 4 + b] = (f.unitig << 1) | f.strand;
+        }
+    }
+    // ---- getMaxKmerCoverage(dbg, 0.001) ----
+    {
+        std::vector<uint32_t> v(kcov);
+        std::sort(v.begin(), v.end(), [](uint32_t a, uint32_t b) { return a > b; });
+        max_km_cov_top = v[static_cast<size_t>(static_cast<double>(v.size()) * 0.001)];
+    }
+}
+
+} // namespace rtk

@@ -1,0 +1,60 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SIM_LIB = os.path.join(ROOT, "tests", "hostsim", "librtk_hostsim.so")
+BIN = os.path.join(ROOT, "ratatosk_amd", "bin")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    need = [os.path.join(BIN, "rtk_simulate"), os.path.join(BIN, "rtk_build_index"), SIM_LIB,
+            os.path.join(ROOT, "oracle", "liboracle.so"), os.path.join(ROOT, "ratatosk_amd", "libratatosk_hip.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+_ensure_built()
+
+
+def make_dataset(tmpdir, name, sim_args, index_args=()):
+    """Synthetic reference/short/long reads + index, via the repo's own tools. Returns the path prefix."""
+    pre = os.path.join(str(tmpdir), name)
+    subprocess.check_call([os.path.join(BIN, "rtk_simulate"), "--prefix", pre] + [str(a) for a in sim_args], stderr=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + [str(a) for a in index_args], stderr=subprocess.DEVNULL)
+    return pre
+
+
+@pytest.fixture(scope="session")
+def ds_small(tmp_path_factory):
+    """30 kb diploid reference with two-copy repeats: branching graph, global colour sets, 10 % error long reads."""
+    d = tmp_path_factory.mktemp("ds_small")
+    return make_dataset(d, "small", ["--seed", 11, "--ref-len", 30000, "--het", 0.004, "--repeat-frac", 0.1, "--sr-cov", 40, "--sr-err", 0.01,
+                                     "--lr-n", 12, "--lr-len", 3000, "--lr-profile", "ont", "--lr-err", 0.08], ["--global-cov-factor", 1.2])
+
+
+@pytest.fixture(scope="session")
+def ds_clean(tmp_path_factory):
+    """Config-1-like plumbing set: clean haploid graph with long unitigs (same-unitig shortcut, Hirschberg-sized sub-paths)."""
+    d = tmp_path_factory.mktemp("ds_clean")
+    return make_dataset(d, "clean", ["--seed", 1, "--ref-len", 50000, "--sr-cov", 30, "--sr-err", 0.002, "--lr-n", 10, "--lr-len", 5000, "--lr-err", 0.10])
+
+
+def golden_rows():
+    path = os.path.join(ROOT, "tests", "golden", "edlib_golden.tsv")
+    rows = []
+    with open(path) as f:
+        for line in f:
+            q, t, k, mode, want_path, d, locs, cig = line.rstrip("\n").split("\t")
+            rows.append(dict(q="" if q == "-" else q, t="" if t == "-" else t, k=int(k), mode=int(mode), path=bool(int(want_path)), d=int(d),
+                             locs=[] if locs == "-" else [int(x) for x in locs.split(",")], cigar="" if cig == "-" else cig))
+    return rows
