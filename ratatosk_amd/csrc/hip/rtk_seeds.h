@@ -1,0 +1,513 @@
+// Anchor ("seed") stage of the per-read correction on the device: the work of getSeeds
+// (reference: src/Graph.cpp:3-482) after the exact k-mer scan -- masking (:102-191), 1-edit k-mer search
+// (:193, Bifrost searchSequence inexact [A2]), solid/weak split (:201-219), overlap filter (:221-239),
+// keep_non_overlap (src/Alignment.cpp:1017-1199) and the adjacent-run consistency check (:329-372).
+// One wavefront owns one long read (mask, finalize) or one tile of 64 window positions (inexact probes).
+#ifndef RTK_SEEDS_H
+#define RTK_SEEDS_H
+
+#include "rtk_myers.h"
+#include "rtk_sets.h"
+#include "rtk_types.h"
+#include "rtk_wave.h"
+
+struct OptsView {
+    uint32_t insert_sz, min_cov_vertices, max_len_weak_region1, max_km_cov;
+    double weak_region_len_factor, large_k_factor, min_score;
+    int32_t max_qual, out_qual;
+};
+
+struct BatchView {
+    uint32_t n_reads;
+    uint64_t n_bases;
+    const char* seq;          // upper-cased reads, concatenated
+    const uint64_t* roff;     // [n_reads+1]
+    uint64_t* hits;           // [n_bases] exact hit of the window starting at each base (packed, RTK_NO_HIT if none)
+    char* masked;             // [n_bases] the 'N'-masked copy searched inexactly (src/Graph.cpp:102)
+    uint64_t* wdesc;          // [n_bases] group of raw inexact hits of the window: pool offset << 24 | count
+    uint64_t* ipool;          // raw inexact hits {k-mer code in read orientation, packed hit}
+    uint64_t ipool_cap;       // entries
+    unsigned long long* ipool_top;
+    uint32_t* s_pos;          // solid anchor positions of read r at [roff[r], roff[r] + n_solid[r])
+    uint32_t* n_solid;        // [n_reads]
+    uint32_t* wk_pos;         // weak anchors (all reads), read r at [w_off[r], w_off[r] + w_cnt[r])
+    uint64_t* wk_hit;
+    uint64_t wk_cap;
+    unsigned long long* wk_top;
+    uint64_t* w_off;          // [n_reads]
+    uint32_t* w_cnt;          // [n_reads]
+    uint32_t* status;         // [n_reads] non-zero: a scratch capacity was exceeded for this read
+    unsigned long long* counters; // [16] event counters (see rtk_pipeline.inc)
+};
+
+struct SeedScratch {
+    uint32_t* set[6]; uint32_t set_cap;           // sorted-id buffers
+    uint32_t* vpos; uint64_t* vcode; uint64_t* vhit; uint64_t* vkey; uint64_t* vidx; uint32_t v_cap; // weak-hit work lists (vkey/vidx hold 2*v_cap)
+    uint32_t* gstart; uint32_t* gcnt; uint32_t* gps; uint32_t* gpe; uint8_t* gkeep; uint8_t* vflag; // variant groups
+    uint8_t* sflag;                               // per solid candidate
+    uint32_t* overflow;
+};
+
+
+struct SeedScratchCfg { uint32_t set_cap, v_cap, s_cap; };
+
+RTK_HD uint64_t seed_scratch_bytes(const SeedScratchCfg& c) {
+    uint64_t b = 0;
+    b += 6ull * 4 * c.set_cap;                    // set[6]
+    b += 4ull * c.v_cap + 8ull * c.v_cap * 2;     // vpos, vcode, vhit
+    b += 2ull * 8 * (2ull * c.v_cap + 512);       // vkey, vidx (padded to a power of two for the sort)
+    b += 4ull * 4 * c.v_cap + 2ull * c.v_cap;     // gstart, gcnt, gps, gpe, gkeep, vflag
+    b += c.s_cap; b += 64;
+    return (b + 255) / 256 * 256;
+}
+
+RTK_HD SeedScratch seed_scratch_carve(char* base, const SeedScratchCfg& c) {
+    SeedScratch s; char* p = base;
+    s.vcode = reinterpret_cast<uint64_t*>(p); p += 8ull * c.v_cap;
+    s.vhit = reinterpret_cast<uint64_t*>(p); p += 8ull * c.v_cap;
+    s.vkey = reinterpret_cast<uint64_t*>(p); p += 8ull * (2ull * c.v_cap + 512);
+    s.vidx = reinterpret_cast<uint64_t*>(p); p += 8ull * (2ull * c.v_cap + 512);
+    for (int i = 0; i < 6; ++i) { s.set[i] = reinterpret_cast<uint32_t*>(p); p += 4ull * c.set_cap; }
+    s.set_cap = c.set_cap;
+    s.vpos = reinterpret_cast<uint32_t*>(p); p += 4ull * c.v_cap; s.v_cap = c.v_cap;
+    s.gstart = reinterpret_cast<uint32_t*>(p); p += 4ull * c.v_cap; s.gcnt = reinterpret_cast<uint32_t*>(p); p += 4ull * c.v_cap;
+    s.gps = reinterpret_cast<uint32_t*>(p); p += 4ull * c.v_cap; s.gpe = reinterpret_cast<uint32_t*>(p); p += 4ull * c.v_cap;
+    s.overflow = reinterpret_cast<uint32_t*>(p); p += 64;
+    s.gkeep = reinterpret_cast<uint8_t*>(p); p += c.v_cap; s.vflag = reinterpret_cast<uint8_t*>(p); p += c.v_cap;
+    s.sflag = reinterpret_cast<uint8_t*>(p);
+    return s;
+}
+
+#define RTK_CNT_WINDOWS 0
+#define RTK_CNT_PROBES_EXACT 1
+#define RTK_CNT_PROBES_INEXACT 2
+#define RTK_CNT_HITS_INEXACT 3
+#define RTK_CNT_REGIONS 4
+#define RTK_CNT_ITEMS 5
+#define RTK_CNT_OVERFLOW 6
+#define RTK_CNT_EXPAND 7
+#define RTK_CNT_COLOUR 8
+#define RTK_CNT_PATHBASE 9
+#define RTK_CNT_ALIGN 10
+#define RTK_CNT_CELLS 11
+
+RTK_DEV uint32_t rtk_hit_unitig(uint64_t h) { return static_cast<uint32_t>(h >> 33); }
+RTK_DEV bool rtk_is_branching(const GraphView& g, uint32_t u) { return (g.flags[u] & RTK_F_BRANCHING) != 0; }
+
+
+// min(|colours(u) & set|, cap)  (getNumberSharedPairID(SharedPairID, PairID), src/Common.cpp:73-83)
+RTK_DEV uint32_t rtk_shared_with_set(const GraphView& g, uint32_t u, const uint32_t* set, uint32_t n, uint32_t cap) {
+    uint32_t shared = 0;
+    const int32_t gi = g.gid[u];
+    if (gi >= 0) shared = rtk_set_inter_count(g.col + g.goff[gi], static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]), set, n, cap);
+    if (shared < cap) shared += rtk_set_inter_count(g.col + g.loff[u], static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]), set, n, cap - shared);
+    return shared;
+}
+
+// min(|colours(u) & colours(v)|, cap)  (getNumberSharedPairID(SharedPairID, SharedPairID), src/Common.cpp:51-71);
+// global and local parts of one unitig are disjoint, so the four partial intersections add up
+RTK_DEV uint32_t rtk_shared_unitigs(const GraphView& g, uint32_t u, uint32_t v, uint32_t cap) {
+    const int32_t gu = g.gid[u], gv = g.gid[v];
+    const uint32_t* lv = g.col + g.loff[v]; const uint32_t nlv = static_cast<uint32_t>(g.loff[v + 1] - g.loff[v]);
+    if (gu >= 0 && gu == gv) {
+        uint32_t shared = static_cast<uint32_t>(g.goff[gu + 1] - g.goff[gu]);
+        if (shared < cap) shared += rtk_set_inter_count(g.col + g.loff[u], static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]), lv, nlv, cap - shared);
+        return shared;
+    }
+    uint32_t shared = 0;
+    if (gv >= 0) shared = rtk_shared_with_set(g, u, g.col + g.goff[gv], static_cast<uint32_t>(g.goff[gv + 1] - g.goff[gv]), cap);
+    if (shared < cap) shared += rtk_shared_with_set(g, u, lv, nlv, cap - shared);
+    return shared;
+}
+
+// colours(u) = global | local, merged into the running union held in sc.set[cur]; returns new size (0xFFFFFFFF on overflow)
+RTK_DEV uint32_t rtk_union_unitig(const GraphView& g, const SeedScratch& sc, int& cur, uint32_t n_cur, uint32_t u) {
+    const int32_t gi = g.gid[u];
+    if (gi >= 0) {
+        const uint32_t ng = static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]);
+        if (n_cur + ng > sc.set_cap) { *sc.overflow = 1; return 0xFFFFFFFFu; }
+        n_cur = rtk_set_union(sc.set[cur], n_cur, g.col + g.goff[gi], ng, sc.set[cur ^ 1], sc.set[2]);
+        cur ^= 1;
+    }
+    const uint32_t nl = static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]);
+    if (nl) {
+        if (n_cur + nl > sc.set_cap) { *sc.overflow = 1; return 0xFFFFFFFFu; }
+        n_cur = rtk_set_union(sc.set[cur], n_cur, g.col + g.loff[u], nl, sc.set[cur ^ 1], sc.set[2]);
+        cur ^= 1;
+    }
+    return n_cur;
+}
+
+// ---------------------------------------------------------------------------------------------- mask (src/Graph.cpp:102-191)
+RTK_DEV void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
+    const uint64_t base = bv.roff[r];
+    const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
+    const uint32_t k = static_cast<uint32_t>(g.k);
+    rtk_wfill(bv.masked + base, 'N', L);
+    if (L <= k) return; // src/Graph.cpp:49
+    const uint32_t nwin = L - k + 1;
+    const uint64_t* hits = bv.hits + base;
+    int64_t prev = -1, first = -1;
+    for (uint32_t c0 = 0; c0 < nwin; c0 += 64) {
+        uint64_t bal;
+#ifdef RTK_SIM
+        bal = 0; for (uint32_t j = 0; j < 64 && c0 + j < nwin; ++j) if (hits[c0 + j] != RTK_NO_HIT) bal |= 1ull << j;
+#else
+        { const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane()); bal = rtk_ballot(x < nwin && hits[x] != RTK_NO_HIT); }
+#endif
+        if (bal == ~0ull && prev == static_cast<int64_t>(c0) - 1) { if (first < 0) first = c0; prev = c0 + 63; continue; } // inside a run: no gap
+        while (bal) {
+            const uint32_t p = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u;
+            bal &= bal - 1ull;
+            if (prev >= 0 && static_cast<int64_t>(p) != prev + 1) {
+                const uint32_t pv = static_cast<uint32_t>(prev);
+                const uint32_t diff = p - pv;
+                bool unmask = false;
+                if (diff >= o.insert_sz) unmask = true;
+                else if (diff >= o.insert_sz / 2) {
+                    const uint32_t ssl = o.insert_sz - diff;
+                    const uint32_t min_pos_left = (pv < ssl) ? 0u : (pv - ssl);
+                    const uint64_t max_pos_right = static_cast<uint64_t>(p) + ssl;
+                    int cur = 0; uint32_t nL = 0, nR = 0; uint32_t prev_u = RTK_NONE32; bool ovf = false;
+                    for (int64_t x = pv; x > static_cast<int64_t>(min_pos_left) && !ovf; --x) { // G13: index 0 is never visited
+                        const uint64_t h = hits[x];
+                        if (h == RTK_NO_HIT) continue;
+                        if (x == first) break;
+                        const uint32_t u = rtk_hit_unitig(h);
+                        if (prev_u == RTK_NONE32 || u != prev_u) {
+                            if (!rtk_is_branching(g, u)) { nL = rtk_union_unitig(g, sc, cur, nL, u); if (nL == 0xFFFFFFFFu) ovf = true; }
+                            prev_u = u;
+                        }
+                    }
+                    if (!ovf) { // park the left union in set[3]
+                        if (nL > sc.set_cap) ovf = true; else rtk_wcopy(sc.set[3], sc.set[cur], 4ull * nL);
+                    }
+                    cur = 0; prev_u = RTK_NONE32;
+                    for (uint64_t x = p; x < max_pos_right && x < nwin && !ovf; ++x) {
+                        const uint64_t h = hits[x];
+                        if (h == RTK_NO_HIT) continue;
+                        const uint32_t u = rtk_hit_unitig(h);
+                        if (prev_u == RTK_NONE32 || u != prev_u) {
+                            if (!rtk_is_branching(g, u)) { nR = rtk_union_unitig(g, sc, cur, nR, u); if (nR == 0xFFFFFFFFu) ovf = true; }
+                            prev_u = u;
+                        }
+                    }
+                    if (!ovf) unmask = rtk_set_inter_count(sc.set[3], nL, sc.set[cur], nR, o.min_cov_vertices) < o.min_cov_vertices;
+                }
+                if (unmask) rtk_wcopy(bv.masked + base + pv + k, bv.seq + base + pv + k, diff - k);
+            }
+            if (first < 0) first = p;
+            prev = p;
+        }
+    }
+    if (first >= 0) {
+        if (static_cast<uint64_t>(first) >= o.insert_sz / 2) rtk_wcopy(bv.masked + base, bv.seq + base, static_cast<uint64_t>(first) + k - 1);
+        if (L - static_cast<uint64_t>(prev) >= o.insert_sz / 2) rtk_wcopy(bv.masked + base + prev + 1, bv.seq + base + prev + 1, L - static_cast<uint64_t>(prev) - 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- inexact probes (src/Graph.cpp:193 [A2])
+// One tile = 64 consecutive base positions; every candidate window of the tile is expanded by the whole wave into its
+// 93 substitution + 124 "insertion" + 29 "deletion" variants (one variant per lane per round), each probed in the k-mer table.
+#define RTK_N_VARIANTS 246
+RTK_DEV void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile) {
+    const int k = g.k;
+    const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
+#ifdef RTK_SIM
+    const int n_sub = 64;
+#else
+    const int n_sub = 1;
+#endif
+    for (int sub = 0; sub < n_sub; ++sub) { // the 1-lane simulator visits the 64 positions of the tile one after the other
+#ifdef RTK_SIM
+        const uint64_t bb = tile * 64 + static_cast<uint64_t>(sub);
+#else
+        const uint64_t bb = b;
+#endif
+        // per-lane: is the window starting at bb a candidate? how many usable characters follow (k-1, k or k+1)?
+        bool cand = false; uint64_t c_k1 = 0; uint32_t ck = 4, ck1 = 4;
+        if (bb < bv.n_bases) {
+            uint32_t lo = 0, hi = bv.n_reads;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (bv.roff[mid] <= bb) lo = mid; else hi = mid; }
+            const uint64_t rend = bv.roff[lo + 1];
+            if (bb + static_cast<uint64_t>(k) <= rend && rend - bv.roff[lo] > static_cast<uint64_t>(k)) {
+                bool ok = true;
+                for (int i = 0; i < k - 1; ++i) { const int c = rtk_cls(static_cast<unsigned char>(bv.masked[bb + i])); if (c > 3) { ok = false; break; } c_k1 = (c_k1 << 2) | static_cast<uint64_t>(c); }
+                if (ok) {
+                    cand = true;
+                    const int c = rtk_cls(static_cast<unsigned char>(bv.masked[bb + k - 1]));
+                    if (c <= 3) { ck = static_cast<uint32_t>(c); if (bb + static_cast<uint64_t>(k) + 1 <= rend) { const int c2 = rtk_cls(static_cast<unsigned char>(bv.masked[bb + k])); if (c2 <= 3) ck1 = static_cast<uint32_t>(c2); } }
+                }
+            }
+        }
+        uint64_t bal = rtk_ballot(cand);
+        while (bal) {
+            const int sl = rtk_ffs(bal) - 1;
+            bal &= bal - 1ull;
+            const uint64_t w_k1 = rtk_shfl(c_k1, sl);
+            const uint32_t w_ck = rtk_shfl(ck, sl), w_ck1 = rtk_shfl(ck1, sl);
+#ifdef RTK_SIM
+            const uint64_t w_b = bb;
+#else
+            const uint64_t w_b = tile * 64 + static_cast<uint64_t>(sl);
+#endif
+            uint64_t my_code[4]; uint64_t my_hit[4]; int my_n = 0; uint32_t probes = 0;
+            int total = 0;
+#ifdef RTK_SIM
+            // simulator: one lane walks all variants; hits are appended straight to the pool below
+            uint64_t sim_code[RTK_N_VARIANTS], sim_hit[RTK_N_VARIANTS];
+            for (int v = 0; v < RTK_N_VARIANTS; ++v) {
+#else
+            for (int v = rtk_lane(); v < RTK_N_VARIANTS + 63 - ((RTK_N_VARIANTS + 63) % 64); v += 64) {
+#endif
+                uint64_t code = 0; bool valid = false;
+                if (v < 93) { // substitution: needs k characters
+                    if (w_ck <= 3) {
+                        const int oo = v / 3, j = v % 3;
+                        const uint64_t full = (w_k1 << 2) | w_ck;
+                        const int sh = 2 * (k - 1 - oo);
+                        const uint32_t orig = static_cast<uint32_t>((full >> sh) & 3ull);
+                        const uint32_t nb = static_cast<uint32_t>(j) + (static_cast<uint32_t>(j) >= orig ? 1u : 0u);
+                        code = (full & ~(3ull << sh)) | (static_cast<uint64_t>(nb) << sh); valid = true;
+                    }
+                } else if (v < 217) { // graph k-mer has one extra base: k-1 read characters + an inserted one
+                    const int vv = v - 93, oo = vv / 4; const uint64_t nb = static_cast<uint64_t>(vv % 4);
+                    const int rest = k - 1 - oo; // characters after the inserted base
+                    const uint64_t lo_mask = rest ? ((1ull << (2 * rest)) - 1ull) : 0ull;
+                    code = ((w_k1 >> (2 * rest)) << (2 * rest + 2)) | (nb << (2 * rest)) | (w_k1 & lo_mask); valid = true;
+                } else if (v < RTK_N_VARIANTS) { // graph k-mer lacks one interior read base: k+1 read characters
+                    if (w_ck <= 3 && w_ck1 <= 3) {
+                        const int oo = v - 217 + 1; // deleted offset in [1, k-2]
+                        // full2 = k+1 characters; for k = 31 that is exactly 64 bits
+                        const uint64_t full2 = (w_k1 << 4) | (static_cast<uint64_t>(w_ck) << 2) | static_cast<uint64_t>(w_ck1);
+                        const int keep_lo = k - oo; // characters after the deleted one
+                        const uint64_t lo_mask = (1ull << (2 * keep_lo)) - 1ull;
+                        const uint64_t hi = (2 * (keep_lo + 1) >= 64) ? 0ull : (full2 >> (2 * (keep_lo + 1)));
+                        code = (hi << (2 * keep_lo)) | (full2 & lo_mask); valid = true;
+                    }
+                }
+                uint64_t hit = RTK_NO_HIT;
+                if (valid) { uint32_t np; hit = rtk_find_kmer(g, code & ((k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull)), &np); probes += np; }
+#ifdef RTK_SIM
+                if (hit != RTK_NO_HIT) { sim_code[total] = code; sim_hit[total] = hit; ++total; }
+            }
+#else
+                const uint64_t hb = rtk_ballot(hit != RTK_NO_HIT);
+                if (hit != RTK_NO_HIT) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; }
+                total += rtk_popc(hb);
+            }
+#endif
+            if (total > 0) {
+                unsigned long long pbase = 0;
+                if (rtk_lane() == 0) pbase = rtk_atomic_add(bv.ipool_top, static_cast<unsigned long long>(total));
+                pbase = rtk_shfl(pbase, 0);
+                if (pbase + static_cast<unsigned long long>(total) <= bv.ipool_cap) {
+#ifdef RTK_SIM
+                    for (int i = 0; i < total; ++i) { bv.ipool[2 * (pbase + i)] = sim_code[i]; bv.ipool[2 * (pbase + i) + 1] = sim_hit[i]; }
+#else
+                    int tot2; const int off = rtk_wave_excl_scan(my_n, &tot2);
+                    for (int i = 0; i < my_n; ++i) { bv.ipool[2 * (pbase + off + i)] = my_code[i]; bv.ipool[2 * (pbase + off + i) + 1] = my_hit[i]; }
+#endif
+                    if (rtk_lane() == 0) bv.wdesc[w_b] = (static_cast<uint64_t>(pbase) << 24) | static_cast<uint64_t>(total);
+                } else if (rtk_lane() == 0) rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
+            }
+            const int ptot = rtk_wave_sum(static_cast<int>(probes));
+            if (rtk_lane() == 0) { rtk_atomic_add(bv.counters + RTK_CNT_PROBES_INEXACT, static_cast<unsigned long long>(ptot)); if (total) rtk_atomic_add(bv.counters + RTK_CNT_HITS_INEXACT, static_cast<unsigned long long>(total)); }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- finalize (src/Graph.cpp:201-372)
+RTK_DEV bool rtk_char_eq_base(char c, uint32_t b) { return rtk_cls(static_cast<unsigned char>(c)) == static_cast<int>(b); }
+
+// classification of one weak hit (src/Alignment.cpp:1049-1072): returns key or 0 when the hit is dropped
+RTK_DEV uint64_t rtk_weak_key(const char* ref, uint32_t pos, uint64_t code, int k) {
+    auto qb = [&](int i) -> uint32_t { return static_cast<uint32_t>((code >> (2 * (k - 1 - i))) & 3ull); };
+    int l = 0;
+    while (l < k && rtk_char_eq_base(ref[pos + l], qb(l))) ++l;
+    if (l >= k) return 0;
+    int type_var = 0; uint32_t mis = 0;
+    { bool ok = true; for (int i = l + 1; i < k && ok; ++i) ok = rtk_char_eq_base(ref[pos + i], qb(i)); if (ok) { type_var = 1; mis = 1u << qb(l); } }
+    if (!type_var) { bool ok = true; for (int i = 0; i < k - l - 1 && ok; ++i) ok = rtk_char_eq_base(ref[pos + l + i], qb(l + 1 + i)); if (ok) { type_var = 2; mis = 1u << qb(l); } }
+    if (!type_var) { bool ok = true; for (int i = 0; i < k - l - 1 && ok; ++i) ok = rtk_char_eq_base(ref[pos + l + 1 + i], qb(l + i)); if (ok) type_var = 3; }
+    if (type_var == 0 || l == 0 || l == k - 1) return 0;
+    return (static_cast<uint64_t>(pos + static_cast<uint32_t>(l)) << 16) | (static_cast<uint64_t>(mis) << 8) | static_cast<uint64_t>(type_var);
+}
+
+RTK_DEV void rtk_finalize_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
+    const uint64_t base = bv.roff[r];
+    const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
+    const uint32_t k = static_cast<uint32_t>(g.k);
+    if (rtk_lane() == 0) { bv.n_solid[r] = 0; bv.w_cnt[r] = 0; bv.w_off[r] = 0; }
+    if (L <= k) { rtk_sync(); return; }
+    const uint32_t nwin = L - k + 1;
+    const uint64_t* hits = bv.hits + base;
+    uint32_t* s_pos = bv.s_pos + base;
+    // ---- solid = exact hits minus runs that overlap the next run by less than k (src/Graph.cpp:221-239) ----
+    // hit x (run end e, next hit nx after the gap) is dropped iff nx < x + k.
+    uint32_t n1 = 0;
+    for (uint32_t c0 = 0; c0 < nwin; c0 += RTK_WAVE) {
+        const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane());
+        bool keep = false;
+        if (x < nwin && hits[x] != RTK_NO_HIT) {
+            keep = true;
+            uint32_t j = x + 1;
+            while (j < nwin && j < x + k && hits[j] != RTK_NO_HIT) ++j; // j = first non-hit after the run (or limit)
+            if (j < nwin && j < x + k) { // run ended at j-1 < x+k-1: look for the next hit before x+k
+                uint32_t nx = j + 1;
+                while (nx < nwin && nx < x + k && hits[nx] == RTK_NO_HIT) ++nx;
+                if (nx < nwin && nx < x + k) keep = false;
+            }
+        }
+        const uint64_t bal = rtk_ballot(keep);
+        if (keep) s_pos[n1 + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)))] = x;
+        n1 += static_cast<uint32_t>(rtk_popc(bal));
+    }
+    rtk_sync();
+    // ---- adjacent solid anchors on different unitigs must be graph neighbours sharing >= min_cov colours (:329-372) ----
+    for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n1; i += RTK_WAVE) sc.sflag[i] = 0; // 1 = emptied
+    rtk_sync();
+    for (uint32_t c0 = 1; c0 < n1; c0 += RTK_WAVE) {
+        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
+        bool cand = false;
+        if (i < n1 && s_pos[i] - s_pos[i - 1] == 1) cand = rtk_hit_unitig(hits[s_pos[i]]) != rtk_hit_unitig(hits[s_pos[i - 1]]);
+        uint64_t bal = rtk_ballot(cand);
+        while (bal) { // junctions are handled one after the other: the emptiness flags carry across them
+            const uint32_t ii = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u;
+            bal &= bal - 1ull;
+            if (sc.sflag[ii - 1] || sc.sflag[ii]) continue;
+            const UMap ul = rtk_unpack_hit(hits[s_pos[ii - 1]]), ur = rtk_unpack_hit(hits[s_pos[ii]]);
+            // right unitig must be the successor of the left one in walk direction (tail/head k-1 overlap) ...
+            bool invalid = true;
+            const uint32_t* a = g.adj + 8ull * ul.unitig + (ul.strand ? 0 : 4);
+            for (int bb = 0; bb < 4; ++bb) if (a[bb] != RTK_NONE32 && (a[bb] >> 1) == ur.unitig && (a[bb] & 1u) == ur.strand) invalid = false;
+            // ... and share enough colours
+            if (!invalid) invalid = rtk_shared_unitigs(g, ul.unitig, ur.unitig, o.min_cov_vertices) < o.min_cov_vertices;
+            if (invalid) {
+                uint32_t i_l = ii - 1, i_r = ii + 1;
+                i_l -= (i_l != 0) ? 1u : 0u;
+                while (i_l > 0 && s_pos[i_l] == s_pos[i_l + 1] - 1 && rtk_hit_unitig(hits[s_pos[i_l]]) == ul.unitig) { sc.sflag[i_l] = 1; --i_l; }
+                while (i_r < n1 && s_pos[i_r] == s_pos[i_r - 1] + 1 && rtk_hit_unitig(hits[s_pos[i_r]]) == ur.unitig) { sc.sflag[i_r] = 1; ++i_r; }
+                sc.sflag[ii - 1] = 1; sc.sflag[ii] = 1;
+            }
+        }
+    }
+    rtk_sync();
+    uint32_t n2 = 0;
+    for (uint32_t c0 = 0; c0 < n1; c0 += RTK_WAVE) { // in-place compaction (write index never passes read index)
+        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
+        const bool keep = i < n1 && !sc.sflag[i];
+        const uint32_t v = keep ? s_pos[i] : 0;
+        const uint64_t bal = rtk_ballot(keep);
+        rtk_sync();
+        if (keep) s_pos[n2 + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)))] = v;
+        n2 += static_cast<uint32_t>(rtk_popc(bal));
+    }
+    rtk_sync();
+    if (rtk_lane() == 0) bv.n_solid[r] = n2;
+    // ---- weak = raw inexact hits sorted by (pos, mapped k-mer), deduplicated (src/Graph.cpp:201-216) ----
+    uint32_t nv = 0; bool ovf = false;
+    for (uint32_t c0 = 0; c0 < nwin && !ovf; c0 += 64) {
+        uint64_t bal;
+#ifdef RTK_SIM
+        bal = 0; for (uint32_t j = 0; j < 64 && c0 + j < nwin; ++j) if (bv.wdesc[base + c0 + j]) bal |= 1ull << j;
+#else
+        { const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane()); bal = rtk_ballot(x < nwin && bv.wdesc[base + x] != 0); }
+#endif
+        while (bal && !ovf) {
+            const uint32_t p = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u;
+            bal &= bal - 1ull;
+            const uint64_t d = bv.wdesc[base + p];
+            const uint64_t off = d >> 24; const uint32_t cnt = static_cast<uint32_t>(d & 0xFFFFFFull);
+            // sort the group by k-mer code in scratch (vkey/vidx), then append unique codes
+            for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < cnt; i += RTK_WAVE) { sc.vkey[i] = bv.ipool[2 * (off + i)]; sc.vidx[i] = bv.ipool[2 * (off + i) + 1]; }
+            rtk_sync();
+            rtk_sort_pairs(sc.vkey, sc.vidx, cnt);
+            for (uint32_t i = 0; i < cnt && !ovf; ++i) {
+                if (i > 0 && sc.vkey[i] == sc.vkey[i - 1]) continue;
+                if (nv >= sc.v_cap) { ovf = true; break; }
+                sc.vpos[nv] = p; sc.vcode[nv] = sc.vkey[i]; sc.vhit[nv] = sc.vidx[i]; ++nv;
+            }
+        }
+    }
+    if (ovf) { *sc.overflow = 1; nv = 0; }
+    rtk_sync();
+    // ---- keep_non_overlap (src/Alignment.cpp:1017-1199) ----
+    // NB: an inexact hit is never "solid": its mapped k-mer differs from the read window by construction.
+    uint32_t n_keep = 0;
+    if (nv) {
+        const char* ref = bv.seq + base;
+        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nv; i += RTK_WAVE) {
+            const uint64_t key = rtk_weak_key(ref, sc.vpos[i], sc.vcode[i], static_cast<int>(k));
+            sc.vkey[i] = key ? key : ~0ull; sc.vidx[i] = i; sc.vflag[i] = 0;
+        }
+        rtk_sync();
+        rtk_sort_pairs(sc.vkey, sc.vidx, nv);
+        uint32_t nvalid = 0;
+        { // number of classified hits = first index with an all-ones key
+            uint32_t lo = 0, hi = nv; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.vkey[mid] == ~0ull) hi = mid; else lo = mid + 1; } nvalid = lo;
+        }
+        // groups of equal key
+        uint32_t ng = 0;
+        for (uint32_t i = 0; i < nvalid;) {
+            uint32_t j = i; uint32_t ps = 0xFFFFFFFFu, pe = 0;
+            while (j < nvalid && sc.vkey[j] == sc.vkey[i]) { const uint32_t pp = sc.vpos[sc.vidx[j]]; ps = pp < ps ? pp : ps; pe = (pp + k) > pe ? (pp + k) : pe; ++j; }
+            sc.gstart[ng] = i; sc.gcnt[ng] = j - i; sc.gps[ng] = ps; sc.gpe[ng] = pe; sc.gkeep[ng] = 1; ++ng;
+            i = j;
+        }
+        rtk_sync();
+        // a variant is dropped iff another variant overlaps it within k without sharing a unitig (order independent)
+        for (uint32_t gi = static_cast<uint32_t>(rtk_lane()); gi < ng; gi += RTK_WAVE) {
+            const uint64_t k1 = sc.vkey[sc.gstart[gi]]; const uint32_t p1 = static_cast<uint32_t>(k1 >> 16);
+            const uint32_t lower = (p1 < k - 1) ? 0u : (p1 - k + 1); const uint32_t upper = ((p1 + k) >= L) ? L : (p1 + k);
+            bool conflict = false;
+            for (int dir = 0; dir < 2 && !conflict; ++dir) {
+                int64_t gj = dir ? static_cast<int64_t>(gi) + 1 : static_cast<int64_t>(gi) - 1;
+                while (gj >= 0 && gj < static_cast<int64_t>(ng) && !conflict) {
+                    const uint64_t k2 = sc.vkey[sc.gstart[gj]]; const uint32_t p2 = static_cast<uint32_t>(k2 >> 16);
+                    if (p2 < lower || p2 > upper) break;
+                    const bool ov1 = (p1 >= sc.gps[gj]) && (p1 < sc.gpe[gj]);
+                    const bool ov2 = (p2 >= sc.gps[gi]) && (p2 < sc.gpe[gi]);
+                    if (ov1 || ov2) {
+                        bool same = false;
+                        for (uint32_t a = 0; a < sc.gcnt[gi] && !same; ++a) {
+                            const uint64_t ha = sc.vhit[sc.vidx[sc.gstart[gi] + a]];
+                            for (uint32_t b2 = 0; b2 < sc.gcnt[gj] && !same; ++b2) {
+                                const uint64_t hb = sc.vhit[sc.vidx[sc.gstart[gj] + b2]];
+                                same = (rtk_hit_unitig(ha) == rtk_hit_unitig(hb)) && ((ha & 1ull) == (hb & 1ull));
+                            }
+                        }
+                        if (!same) conflict = true;
+                    }
+                    gj += dir ? 1 : -1;
+                }
+            }
+            if (conflict) sc.gkeep[gi] = 0;
+        }
+        rtk_sync();
+        for (uint32_t gi = static_cast<uint32_t>(rtk_lane()); gi < ng; gi += RTK_WAVE) if (sc.gkeep[gi]) for (uint32_t a = 0; a < sc.gcnt[gi]; ++a) sc.vflag[sc.vidx[sc.gstart[gi] + a]] = 1;
+        rtk_sync();
+        // count, reserve space in the weak pool, write in original order
+        for (uint32_t c0 = 0; c0 < nv; c0 += RTK_WAVE) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); n_keep += static_cast<uint32_t>(rtk_popc(rtk_ballot(i < nv && sc.vflag[i]))); }
+        if (n_keep) {
+            unsigned long long wb = 0;
+            if (rtk_lane() == 0) wb = rtk_atomic_add(bv.wk_top, static_cast<unsigned long long>(n_keep));
+            wb = rtk_shfl(wb, 0);
+            if (wb + n_keep > bv.wk_cap) { *sc.overflow = 1; n_keep = 0; }
+            else {
+                uint32_t w = 0;
+                for (uint32_t c0 = 0; c0 < nv; c0 += RTK_WAVE) {
+                    const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
+                    const bool kp = i < nv && sc.vflag[i];
+                    const uint64_t bal = rtk_ballot(kp);
+                    if (kp) { const uint64_t dst = wb + w + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull))); bv.wk_pos[dst] = sc.vpos[i]; bv.wk_hit[dst] = sc.vhit[i]; }
+                    w += static_cast<uint32_t>(rtk_popc(bal));
+                }
+                if (rtk_lane() == 0) { bv.w_off[r] = wb; bv.w_cnt[r] = n_keep; }
+            }
+        }
+    }
+    rtk_sync();
+}
+
+#endif

@@ -1,0 +1,80 @@
+// Wave-cooperative algebra on sorted, duplicate-free u32 arrays in global memory: the colour-set ("PairID")
+// operations of the hot path (reference: src/PairID.cpp:388-548 and_cardinality, operators |, &, -;
+// src/Common.cpp:51-112 getNumberSharedPairID). Every lane takes one element, locates it in the other set by
+// binary search, and survivors are compacted with __ballot + popcount prefix. Outputs must not alias inputs.
+#ifndef RTK_SETS_H
+#define RTK_SETS_H
+
+#include "rtk_wave.h"
+
+RTK_DEV uint32_t rtk_lower_bound(const uint32_t* a, uint32_t n, uint32_t x) { // first index with a[i] >= x
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+RTK_DEV bool rtk_set_contains(const uint32_t* a, uint32_t n, uint32_t x) { const uint32_t i = rtk_lower_bound(a, n, x); return i < n && a[i] == x; }
+
+// out = { x in a : (x in b) == want_in_b }
+RTK_DEV uint32_t rtk_set_filter(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, bool want_in_b, uint32_t* out) {
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < na; i0 += RTK_WAVE) {
+        const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+        uint32_t x = 0; bool keep = false;
+        if (i < na) { x = a[i]; keep = (rtk_set_contains(b, nb, x) == want_in_b); }
+        const uint64_t bal = rtk_ballot(keep);
+        if (keep) out[base + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)))] = x;
+        base += static_cast<uint32_t>(rtk_popc(bal));
+    }
+    rtk_sync();
+    return base;
+}
+
+RTK_DEV uint32_t rtk_set_inter(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t* out) { return rtk_set_filter(a, na, b, nb, true, out); }
+RTK_DEV uint32_t rtk_set_diff(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t* out) { return rtk_set_filter(a, na, b, nb, false, out); }
+
+// |a & b|, stops counting once `cap` is reached (callers only compare against the cap)
+RTK_DEV uint32_t rtk_set_inter_count(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t cap) {
+    if (na > nb) { const uint32_t* t = a; a = b; b = t; const uint32_t tn = na; na = nb; nb = tn; }
+    uint32_t cnt = 0;
+    for (uint32_t i0 = 0; i0 < na && cnt < cap; i0 += RTK_WAVE) {
+        const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+        const bool in = (i < na) && rtk_set_contains(b, nb, a[i]);
+        cnt += static_cast<uint32_t>(rtk_popc(rtk_ballot(in)));
+    }
+    return cnt;
+}
+
+// out = a | b ; tmp holds b \ a (capacity >= nb)
+RTK_DEV uint32_t rtk_set_union(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t* out, uint32_t* tmp) {
+    const uint32_t nd = rtk_set_diff(b, nb, a, na, tmp);
+    for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < na; i += RTK_WAVE) out[i + rtk_lower_bound(tmp, nd, a[i])] = a[i];
+    for (uint32_t j = static_cast<uint32_t>(rtk_lane()); j < nd; j += RTK_WAVE) out[j + rtk_lower_bound(a, na, tmp[j])] = tmp[j];
+    rtk_sync();
+    return na + nd;
+}
+
+// In-place bitonic sort of n (key, value) pairs by (key, value) ascending. Arrays must have room for the next power of two
+// of n (padded with all-ones keys).
+RTK_DEV void rtk_sort_pairs(uint64_t* key, uint64_t* val, uint32_t n) {
+    if (n < 2) return;
+    uint32_t p = 1; while (p < n) p <<= 1;
+    for (uint32_t i = n + static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) { key[i] = ~0ull; val[i] = ~0ull; }
+    rtk_sync();
+    for (uint32_t kk = 2; kk <= p; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t ki = key[i], kl = key[l], vi = val[i], vl = val[l];
+                    const bool gt = (ki > kl) || (ki == kl && vi > vl);
+                    const bool up = ((i & kk) == 0);
+                    if (gt == up) { key[i] = kl; key[l] = ki; val[i] = vl; val[l] = vi; }
+                }
+            }
+            rtk_sync();
+        }
+    }
+}
+
+#endif

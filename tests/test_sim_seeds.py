@@ -1,0 +1,29 @@
+"""Anchor stage (mask, 1-edit k-mer probes, overlap filter, keep_non_overlap, adjacency check) of the device programs,
+executed by the host simulator, against the oracle's getSeeds restatement. Exact equality of both anchor lists."""
+from conftest import SIM_LIB
+from oracle import oracle_py as op
+from ratatosk_amd import api
+
+
+def _check(prefix, n, lib_path):
+    fa, rt = prefix + ".index.k31.fasta.gz", prefix + ".index.k31.rtsk"
+    og, pg = op.Graph(fa, rt, 31), api.Graph(fa, rt, 31, device=0, lib_path=lib_path)
+    reads = op.read_fastq(prefix + ".lr.fq")
+    tot_w = 0
+    for name, s, q in reads[:n]:
+        a, b = pg.seeds(s), og.seeds(s)
+        assert a == b, name
+        tot_w += len(a[1])
+    # edge cases: read of length <= k has no seeds at all (src/Graph.cpp:49); all-N read; read with N inside
+    s0 = reads[0][1]
+    for s in ["ACGT" * 7 + "ACG", "N" * 100, s0[:300] + "N" + s0[301:900]]:
+        assert pg.seeds(s) == og.seeds(s)
+    return tot_w
+
+
+def test_sim_seeds_branching(ds_small):
+    assert _check(ds_small, 12, SIM_LIB) > 0  # weak anchors must be exercised
+
+
+def test_sim_seeds_clean(ds_clean):
+    _check(ds_clean, 6, SIM_LIB)
