@@ -36,7 +36,7 @@ extern "C" void rtk_free(void* p) { free(p); }
 // ------------------------------------------------------------------------------------------------ graph object
 struct rtk_graph {
     rtk::FlatGraph host;
-    bool has_host = false, on_device = false;
+    bool has_host = false, on_device = false, unsupported_annotations = false;
     int device = -1;
     void* dbuf[rtk::RTK_N_BUFS];
     uint64_t dbytes[rtk::RTK_N_BUFS];
@@ -62,6 +62,7 @@ extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int
     try { g->host.load(unitig_fasta_gz, rtsk, k, n_threads); }
     catch (const std::exception& e) { return rtk_fail(RTK_ERR_FORMAT, std::string("rtk_graph_load: ") + e.what()); }
     g->has_host = true;
+    for (size_t u = 0; u < g->host.flags.size(); ++u) if (g->host.flags[u] & (RTK_F_SHORT_CYCLE | RTK_F_AMBIGUITY)) g->unsupported_annotations = true;
     rtk_graph_info& i = g->info;
     i.k = k; i.device = -1; i.n_unitigs = g->host.n_unitigs(); i.n_kmers = g->host.n_kmers; i.n_bases = g->host.uoff.back();
     i.n_colour_ids = g->host.col.size() - 1; i.n_global_sets = g->host.n_global; i.table_slots = g->host.ht.size() / 2; i.hbm_bytes = g->host.bytes();
@@ -142,7 +143,7 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
 // ------------------------------------------------------------------------------------------------ per-wave scratch
 struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };
 
-static uint64_t scratch_bytes(const ScratchCfg& c) {
+RTK_HD uint64_t scratch_bytes(const ScratchCfg& c) {
     uint64_t b = 0;
     b += 8ull * 15 * c.w_cap; b += (c.t_cap + 63) / 64 * 64; b += 4ull * c.t_cap; b += 8ull * c.tb_cap_words; b += 8ull * c.r_cap;
     b += 2ull * ((c.mv_cap + 63) / 64 * 64); b += 4 * 5 * 64; b += 64;

@@ -89,7 +89,7 @@ RTK_DEV int rtk_myers_step(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hin, int
 }
 
 // Query profile: peq[cls * W + w], bit i of word w set iff query[64w+i] equals a character of class cls.
-RTK_DEV void rtk_myers_build_peq(const MyersScratch& sc, const MySeq& q, int W, bool iupac) {
+RTK_FN void rtk_myers_build_peq(const MyersScratch& sc, const MySeq& q, int W, bool iupac) {
     for (int w = rtk_lane(); w < W; w += RTK_WAVE) {
         uint64_t acc[15];
         for (int c = 0; c < 15; ++c) acc[c] = 0;
@@ -115,7 +115,7 @@ RTK_DEV uint64_t rtk_myers_eq_word(const MyersScratch& sc, const MySeq& q, int W
 // Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
 // top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
-RTK_DEV void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, int store, uint64_t* fin_pv, uint64_t* fin_mv) {
+RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, int store, uint64_t* fin_pv, uint64_t* fin_mv) {
     const int m = q.n, n = t.n, W = (m + 63) >> 6, last_bit = (m - 1) & 63;
     rtk_myers_build_peq(sc, q, W, iupac);
 #ifdef RTK_SIM
@@ -183,7 +183,7 @@ struct MyersResult { int32_t dist, first, last, nloc; };
 // edlibAlign(..., TASK_DISTANCE): edit distance (or -1 if above a non-negative k), first and largest end location and
 // their number. SHW/HW report target position -1 (score m) when m % 64 != 0, like edlib's padded last block
 // (edlib.cpp:658-692). Optionally lists every end location (locs_out, up to cap).
-RTK_DEV MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, int m, const char* t, int n, int k, int mode, bool iupac,
+RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, int m, const char* t, int n, int k, int mode, bool iupac,
                                         int32_t* locs_out = nullptr, int cap = 0) {
     MyersResult r; r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
     if (m == 0 || n == 0) { // edlib.cpp:161-179
@@ -238,7 +238,7 @@ RTK_DEV MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, in
 
 // Canonical NW traceback over the stored table, preferring up (insert) > left (delete) > diagonal
 // (edlib.cpp:1021-1137). Appends the moves (already in forward order) to sc.moves at *n_moves.
-RTK_DEV void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const MySeq& t, bool iupac, uint32_t* n_moves) {
+RTK_FN void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const MySeq& t, bool iupac, uint32_t* n_moves) {
     const int m = q.n, n = t.n, W = (m + 63) >> 6;
     rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr);
     int cur = sc.colscore[n - 1];
@@ -271,7 +271,7 @@ RTK_DEV void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const M
 }
 
 // D(query rows, last column) after a pass: out[i] = D[i+1][n], from the final vertical delta vectors.
-RTK_DEV void rtk_myers_column(const uint64_t* fin_pv, const uint64_t* fin_mv, int m, int n, int32_t* out) {
+RTK_FN void rtk_myers_column(const uint64_t* fin_pv, const uint64_t* fin_mv, int m, int n, int32_t* out) {
     const int W = (m + 63) >> 6;
     // word prefix: value at the top of word w = n + sum over previous words of (popc(P) - popc(M)) restricted to valid rows
     for (int w0 = 0, base = n; w0 < W; w0 += RTK_WAVE) {
@@ -300,7 +300,7 @@ RTK_DEV void rtk_myers_column(const uint64_t* fin_pv, const uint64_t* fin_mv, in
 // obtainAlignment (edlib.cpp:1164-1216) with the Hirschberg split of edlib.cpp:1234-1399 restated canonically:
 // target halved at n/2; the FIRST query row (ascending) whose left + right scores add up to the optimum, then the
 // row -1 boundary, then the last row. Iterative (explicit stack), emits moves in order into sc.moves.
-RTK_DEV void rtk_myers_alignment(const MyersScratch& sc, const char* q, int m, const char* t, int n, int best, bool iupac, uint32_t* n_moves) {
+RTK_FN void rtk_myers_alignment(const MyersScratch& sc, const char* q, int m, const char* t, int n, int best, bool iupac, uint32_t* n_moves) {
     *n_moves = 0;
     if (static_cast<uint32_t>(m + n) > sc.mv_cap || static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap || static_cast<uint32_t>(m) > sc.r_cap) { *sc.overflow = 1; return; }
     int32_t* st = sc.hstack;

@@ -1,5 +1,1277 @@
-// placeholder: region stage lands next
+// Region stage of the per-read correction on the device: one wavefront owns one weak region of one long read
+// (reference: src/Correction.cpp:159-958 correctSequence and its `correct` lambda :431-753, chooseColors :215-429,
+// extractSemiWeakPaths :3-157; src/GraphTraversal.cpp explorePathsBFS :3-210, explorePathsBFS2 :212-454,
+// exploreSubGraph :456-587, getScorePath :722-772 and :867-909; src/Alignment.cpp selectBest*Alignment :3-147,:967-1015,
+// generateConsensus :309-470; src/Path.hpp; src/ResultCorrection.hpp).
+//
+// The program is wave-uniform: every lane executes the same control flow on the same values; the lanes split up
+// only inside the bulk primitives (2-bit decode of unitig substrings, bit-parallel Myers with one query word per
+// lane, sorted-set algebra with __ballot compaction, copies). Paths live as immutable records in per-wave bump
+// arenas in HBM (three nesting levels: region / BFS call / DFS call); the reference's queue, stack and candidate
+// vectors become small handle lists. Canonical tie rules [D1] (see oracle/oracle_correct.hpp) are applied where the
+// reference depends on heap addresses. Index annotations that our index producer never emits (short cycles, SNP
+// ambiguities) are rejected up front by the host (RTK_ERR_UNSUPPORTED), so fixRepeats / fixAmbiguity are identities.
 #ifndef RTK_REGION_H
 #define RTK_REGION_H
-struct RegionBatch { int dummy; };
+
+#include "rtk_myers.h"
+#include "rtk_seeds.h"
+#include "rtk_sets.h"
+#include "rtk_types.h"
+#include "rtk_wave.h"
+
+// ------------------------------------------------------------------------------------------------ data
+struct RegionDesc { // one entry per output segment of a read, in read order
+    uint32_t read;
+    uint32_t kind;     // RTK_RG_*
+    uint32_t i_solid;  // index of the left solid anchor (interior / tail), unused otherwise
+    uint32_t prev_pos; // where the previous segment stopped in the read
+    uint64_t seg_off;  // out: offset of the segment in the segment pool (sequence bytes, then quality bytes)
+    uint32_t seq_len, qual_len; // out
+    uint32_t status;   // out: non-zero = scratch overflow, redo with a bigger arena
+    uint32_t pad;
+};
+#define RTK_RG_WHOLE_MAX 0   // read returned unchanged, qualities all 'I' (every window solid)
+#define RTK_RG_WHOLE_MIN 1   // read returned unchanged, qualities all '!' (no solid anchor / too short)
+#define RTK_RG_HEAD 2        // before the first solid anchor (reverse-complement correction, src/Correction.cpp:776-797)
+#define RTK_RG_GAP 3         // between two consecutive solid anchors that are not adjacent (:803-935)
+#define RTK_RG_TAIL 4        // after the last solid anchor, corrected forward (:940-950)
+#define RTK_RG_TAIL_COPY 5   // read ends on a solid anchor (:951-955)
+
+struct RegionBatch {
+    RegionDesc* regions; uint64_t regions_cap; unsigned long long* n_regions;
+    uint64_t* r_first; uint32_t* r_count;   // per read: its slice of `regions`
+    char* seq_rc;                           // reverse complement of every read (same offsets as seq)
+    char* seg_pool; uint64_t seg_cap; unsigned long long* seg_top;
+    unsigned long long* next_region;        // dequeue head of the persistent region kernel
+    char* out_pool; uint64_t out_cap; unsigned long long* out_top;
+    uint64_t* out_off; uint32_t* out_seq_len; uint32_t* out_qual_len; // per read
+};
+
+struct RegionScratchCfg { ScratchCfg my; uint32_t set_cap, um_cap, str_cap, list_cap, memo_cap, bm_words; uint64_t arena_cap; };
+
+struct WPath { UMap* ums; char* qual; uint32_t n, l, qlen; }; // mutable working path
+
+struct RegionScratch {
+    MyersScratch my;
+    uint32_t* set[10]; uint32_t set_cap;
+    char* arena[3]; uint64_t arena_cap; uint64_t top[3];   // 0 region level, 1 BFS level, 2 DFS level
+    WPath wp[4]; uint32_t um_cap;
+    char* str[5]; uint32_t str_cap;
+    char* rbuf[8];                                       // result strings: fw seq/qual, bw seq/qual, out seq/qual, 2 temporaries
+    uint64_t* list[6]; uint32_t list_cap;
+    uint32_t* memo_u; uint8_t* memo_v; uint32_t memo_cap; uint32_t memo_n;
+    uint64_t* bm[3]; uint32_t bm_words;
+    uint32_t* overflow;
+    unsigned long long cnt[5]; // expand, colour, pathbase, align, cells
+};
+
+struct RCtx { // everything a region program needs
+    GraphView g; OptsView o; BatchView bv; RegionBatch rb;
+    RegionScratch* sc;
+    int k;
+};
+
+// ------------------------------------------------------------------------------------------------ helpers (src/Common.hpp:410-438)
+RTK_DEV char rtk_get_qual(double score, uint64_t qv_min, uint64_t qv_max) {
+    const char phred_base_std = static_cast<char>(33);
+    const char phred_scale_std = static_cast<char>(qv_max);
+    const double s = score < 1.0 ? score : 1.0;
+    const double qv_score = s * static_cast<double>(static_cast<uint64_t>(phred_scale_std) - qv_min);
+    return static_cast<char>(qv_score + static_cast<double>(phred_base_std) + static_cast<double>(qv_min));
+}
+RTK_DEV void rtk_min_max_len(uint64_t l, double f, uint64_t* mn, uint64_t* mx) {
+    const double lf = static_cast<double>(l);
+    const double a = lf - (lf * f), b = lf + (lf * f);
+    *mn = static_cast<uint64_t>(a > 1.0 ? a : 1.0); *mx = static_cast<uint64_t>(b > 1.0 ? b : 1.0);
+}
+
+RTK_DEV char rtk_comp(char c) {
+    switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+                 case 'M': return 'K'; case 'K': return 'M'; case 'R': return 'Y'; case 'Y': return 'R';
+                 case 'V': return 'B'; case 'B': return 'V'; case 'H': return 'D'; case 'D': return 'H'; default: return c; }
+}
+
+RTK_DEV void rtk_fail_ovf(RegionScratch& s, uint32_t code) { *s.overflow = code; }
+RTK_DEV bool rtk_failed(const RegionScratch& s) { return *s.overflow != 0; }
+
+// anchors of a read in forward or reverse-complement orientation (src/Correction.cpp:196-213)
+struct Anchors { const uint32_t* pos; const uint64_t* hit; const uint64_t* hits_by_pos; uint32_t n, L; int rev; int k; };
+RTK_DEV uint32_t rtk_an_pos(const Anchors& a, uint32_t i) { return a.rev ? (a.L - a.pos[a.n - 1 - i] - static_cast<uint32_t>(a.k)) : a.pos[i]; }
+RTK_DEV UMap rtk_an_um(const Anchors& a, uint32_t i) {
+    const uint32_t j = a.rev ? (a.n - 1 - i) : i;
+    UMap u = rtk_unpack_hit(a.hit ? a.hit[j] : a.hits_by_pos[a.pos[j]]);
+    if (a.rev) u.strand ^= 1u;
+    return u;
+}
+
+// ------------------------------------------------------------------------------------------------ arenas and paths (src/Path.hpp)
+struct PathHdr { uint32_t n, l, qlen, pad; }; // followed by n UMap and qlen quality bytes
+
+RTK_DEV uint64_t rtk_arena_alloc(RegionScratch& s, int lvl, uint64_t bytes) {
+    bytes = (bytes + 15ull) & ~15ull;
+    if (s.top[lvl] + bytes > s.arena_cap) { rtk_fail_ovf(s, 3); return 0; }
+    const uint64_t off = s.top[lvl]; s.top[lvl] += bytes; return off;
+}
+RTK_DEV PathHdr* rtk_path_hdr(const RegionScratch& s, int lvl, uint64_t h) { return reinterpret_cast<PathHdr*>(s.arena[lvl] + h); }
+RTK_DEV UMap* rtk_path_ums(const RegionScratch& s, int lvl, uint64_t h) { return reinterpret_cast<UMap*>(s.arena[lvl] + h + sizeof(PathHdr)); }
+RTK_DEV char* rtk_path_qual(const RegionScratch& s, int lvl, uint64_t h) { const PathHdr* p = rtk_path_hdr(s, lvl, h); return s.arena[lvl] + h + sizeof(PathHdr) + sizeof(UMap) * p->n; }
+// handles carry their level in the top 2 bits
+RTK_DEV uint64_t rtk_mk_handle(int lvl, uint64_t off) { return (static_cast<uint64_t>(lvl) << 62) | off; }
+RTK_DEV int rtk_h_lvl(uint64_t h) { return static_cast<int>(h >> 62); }
+RTK_DEV uint64_t rtk_h_off(uint64_t h) { return h & 0x3FFFFFFFFFFFFFFFull; }
+
+RTK_DEV void rtk_wp_clear(WPath& p) { p.n = 0; p.l = 0; p.qlen = 0; }
+
+RTK_FN uint64_t rtk_wp_commit(RegionScratch& s, const WPath& p, int lvl) { // working path -> immutable record
+    const uint64_t off = rtk_arena_alloc(s, lvl, sizeof(PathHdr) + sizeof(UMap) * p.n + p.qlen);
+    if (rtk_failed(s)) return 0;
+    PathHdr* h = rtk_path_hdr(s, lvl, off);
+    h->n = p.n; h->l = p.l; h->qlen = p.qlen; h->pad = 0;
+    rtk_wcopy(rtk_path_ums(s, lvl, off), p.ums, sizeof(UMap) * p.n);
+    rtk_wcopy(s.arena[lvl] + off + sizeof(PathHdr) + sizeof(UMap) * p.n, p.qual, p.qlen);
+    return rtk_mk_handle(lvl, off);
+}
+
+RTK_FN void rtk_wp_load(RegionScratch& s, WPath& p, uint64_t h) {
+    const int lvl = rtk_h_lvl(h); const uint64_t off = rtk_h_off(h);
+    const PathHdr* hd = rtk_path_hdr(s, lvl, off);
+    if (hd->n > s.um_cap || hd->qlen > s.str_cap) { rtk_fail_ovf(s, 4); rtk_wp_clear(p); return; }
+    p.n = hd->n; p.l = hd->l; p.qlen = hd->qlen;
+    rtk_wcopy(p.ums, rtk_path_ums(s, lvl, off), sizeof(UMap) * hd->n);
+    rtk_wcopy(p.qual, rtk_path_qual(s, lvl, off), hd->qlen);
+}
+
+RTK_DEV uint32_t rtk_rec_n(const RegionScratch& s, uint64_t h) { return rtk_path_hdr(s, rtk_h_lvl(h), rtk_h_off(h))->n; }
+RTK_DEV uint32_t rtk_rec_l(const RegionScratch& s, uint64_t h) { return rtk_path_hdr(s, rtk_h_lvl(h), rtk_h_off(h))->l; }
+RTK_DEV UMap rtk_rec_back(const RegionScratch& s, uint64_t h) { const int lv = rtk_h_lvl(h); const uint64_t o = rtk_h_off(h); return rtk_path_ums(s, lv, o)[rtk_path_hdr(s, lv, o)->n - 1]; }
+
+RTK_DEV void rtk_wp_norm_back(const RCtx& c, WPath& p) { // the former end becomes a whole unitig (Path.hpp:319-323)
+    if (p.n >= 2) { UMap& e = p.ums[p.n - 1]; e.dist = 0; e.len = rtk_nkm(c.g, e.unitig); }
+}
+
+RTK_FN void rtk_wp_extend(const RCtx& c, WPath& p, const UMap& um) { // Path.hpp:308-330
+    RegionScratch& s = *c.sc;
+    if (rtk_um_is_empty(um)) return;
+    if (p.n >= s.um_cap) { rtk_fail_ovf(s, 5); return; }
+    if (p.n == 0) { p.ums[0] = um; p.n = 1; p.l = um.len + static_cast<uint32_t>(c.k) - 1; }
+    else { rtk_wp_norm_back(c, p); p.ums[p.n] = um; ++p.n; p.l += um.len; }
+}
+
+// extend with a quality slice q[0..qn) (Path.hpp:332-363): appended only when its length equals um.len + k - 1
+RTK_FN void rtk_wp_extend_q(const RCtx& c, WPath& p, const UMap& um, const char* q, uint32_t qn) {
+    RegionScratch& s = *c.sc;
+    if (rtk_um_is_empty(um)) return;
+    if (p.n >= s.um_cap) { rtk_fail_ovf(s, 5); return; }
+    const uint32_t want = um.len + static_cast<uint32_t>(c.k) - 1;
+    if (p.n == 0) {
+        p.ums[0] = um; p.n = 1; p.l = want;
+        if (qn == want) { if (qn > s.str_cap) { rtk_fail_ovf(s, 6); return; } rtk_wcopy(p.qual, q, qn); p.qlen = qn; }
+    } else {
+        rtk_wp_norm_back(c, p); p.ums[p.n] = um; ++p.n; p.l += um.len;
+        if (qn == want) {
+            const uint32_t add = qn - (static_cast<uint32_t>(c.k) - 1);
+            if (p.qlen + add > s.str_cap) { rtk_fail_ovf(s, 6); return; }
+            rtk_wcopy(p.qual + p.qlen, q + (c.k - 1), add); p.qlen += add;
+        }
+    }
+}
+
+// fills qual with `ch` for a fresh single-unitig path (string(len + k - 1, getQual(1.0)))
+RTK_FN void rtk_wp_start(const RCtx& c, WPath& p, const UMap& um, char ch) {
+    RegionScratch& s = *c.sc;
+    rtk_wp_clear(p);
+    const uint32_t want = um.len + static_cast<uint32_t>(c.k) - 1;
+    if (want > s.str_cap) { rtk_fail_ovf(s, 6); return; }
+    p.ums[0] = um; p.n = 1; p.l = want;
+    rtk_wfill(p.qual, ch, want); p.qlen = want;
+}
+
+// p.merge(o) where o is a committed record (Path.hpp:366-414)
+RTK_FN void rtk_wp_merge(const RCtx& c, WPath& p, uint64_t ho) {
+    RegionScratch& s = *c.sc;
+    const int lv = rtk_h_lvl(ho); const uint64_t oo = rtk_h_off(ho);
+    const PathHdr* o = rtk_path_hdr(s, lv, oo);
+    const UMap* oums = rtk_path_ums(s, lv, oo);
+    const char* oq = rtk_path_qual(s, lv, oo);
+    if (o->l == 0) return;
+    if (p.l == 0) { rtk_wp_load(s, p, ho); return; }
+    if ((p.qlen == 0) != (o->qlen == 0)) return;
+    const UMap last = p.ums[p.n - 1];
+    if (last.unitig != oums[0].unitig || last.strand != oums[0].strand) return;
+    if (p.n + o->n > s.um_cap) { rtk_fail_ovf(s, 5); return; }
+    if (p.n == 1) {
+        UMap& st = p.ums[0];
+        if (!st.strand) st.dist = oums[0].dist;
+        st.len += oums[0].len - 1;
+        for (uint32_t i = 1; i < o->n; ++i) p.ums[p.n++] = oums[i];
+    } else {
+        UMap& en = p.ums[p.n - 1];
+        if (!en.strand) en.dist = oums[0].dist;
+        en.len += oums[0].len - 1;
+        if (o->n >= 2) { rtk_wp_norm_back(c, p); for (uint32_t i = 1; i < o->n; ++i) p.ums[p.n++] = oums[i]; }
+    }
+    p.l += o->l - static_cast<uint32_t>(c.k);
+    if (o->qlen != 0) {
+        const uint32_t kk = static_cast<uint32_t>(c.k);
+        const uint32_t add = o->qlen > kk ? o->qlen - kk : 0; // o.qual.substr(k)
+        if (p.qlen + add > s.str_cap) { rtk_fail_ovf(s, 6); return; }
+        rtk_wcopy(p.qual + p.qlen, oq + kk, add); p.qlen += add;
+    }
+}
+
+RTK_FN void rtk_wp_prune_prefix(const RCtx& c, WPath& p, uint32_t len) { // Path.hpp:487-571
+    if (p.n == 0 || p.l == 0 || len >= p.l) return;
+    const uint32_t k = static_cast<uint32_t>(c.k);
+    UMap& st = p.ums[0];
+    if (p.n == 1) { if (!st.strand) st.dist += p.l - len; st.len -= p.l - len; }
+    else if (st.len + k - 1 >= len) {
+        p.l = st.len + k - 1; p.n = 1;
+        if (!st.strand) st.dist += p.l - len;
+        st.len -= p.l - len;
+    } else if (p.n == 2 || len > (p.l - p.ums[p.n - 1].len)) {
+        UMap& en = p.ums[p.n - 1];
+        if (!en.strand) en.dist += p.l - len;
+        en.len -= p.l - len;
+    } else {
+        uint32_t acc = st.len + k - 1, w = 1; bool cut = false;
+        const UMap old_end = p.ums[p.n - 1];
+        for (uint32_t i = 1; i + 1 < p.n; ++i) {
+            UMap cur = p.ums[i]; cur.dist = 0; cur.len = rtk_nkm(c.g, cur.unitig);
+            acc += cur.len;
+            if (acc < len) { p.ums[w++] = cur; }
+            else { if (!cur.strand) cur.dist += acc - len; cur.len -= acc - len; p.ums[w++] = cur; cut = true; break; }
+        }
+        if (!cut) p.ums[w++] = old_end;
+        p.n = w;
+    }
+    p.l = len;
+    if (p.qlen != 0 && p.qlen > p.l) p.qlen = p.l;
+}
+
+// mappedSequenceToString of one mapping into dst (lane-parallel 2-bit decode, reverse complement on the fly)
+RTK_DEV void rtk_um_decode(const RCtx& c, const UMap& um, char* dst, uint32_t skip) {
+    const uint32_t n = um.len + static_cast<uint32_t>(c.k) - 1;
+    const uint64_t b0 = c.g.uoff[um.unitig] + um.dist;
+    for (uint32_t i = skip + static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) {
+        const uint32_t code = um.strand ? rtk_base(c.g, b0 + i) : (3u - rtk_base(c.g, b0 + (n - 1 - i)));
+        dst[i - skip] = "ACGT"[code];
+    }
+}
+
+// Path::toString (Path.hpp:449-485) of `n` mappings into dst; returns length (0xFFFFFFFF on overflow)
+RTK_FN uint32_t rtk_ums_to_string(const RCtx& c, const UMap* ums, uint32_t n, char* dst) {
+    RegionScratch& s = *c.sc;
+    uint32_t len = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t skip = i ? static_cast<uint32_t>(c.k) - 1 : 0;
+        const uint32_t add = ums[i].len + static_cast<uint32_t>(c.k) - 1 - skip;
+        if (len + add > s.str_cap) { rtk_fail_ovf(s, 7); return 0xFFFFFFFFu; }
+        rtk_um_decode(c, ums[i], dst + len, skip);
+        len += add;
+    }
+    rtk_sync();
+    s.cnt[2] += len;
+    return len;
+}
+RTK_DEV uint32_t rtk_rec_to_string(const RCtx& c, uint64_t h, char* dst) {
+    const RegionScratch& s = *c.sc;
+    return rtk_ums_to_string(c, rtk_path_ums(s, rtk_h_lvl(h), rtk_h_off(h)), rtk_rec_n(s, h), dst);
+}
+
+RTK_FN MyersResult rtk_align(const RCtx& c, const char* q, uint32_t m, const char* t, uint32_t n, int kk, int mode, bool iupac = true) {
+    RegionScratch& s = *c.sc;
+    s.cnt[3] += 1; s.cnt[4] += static_cast<unsigned long long>((m + 63) / 64) * n;
+    return rtk_myers_distance(s.my, q, static_cast<int>(m), t, static_cast<int>(n), kk, mode, iupac);
+}
+
+// ------------------------------------------------------------------------------------------------ candidate selection (src/Alignment.cpp:3-147, 967-1015)
+// handles[] are committed paths; strings are materialised into str[0].
+RTK_FN void rtk_select_best(const RCtx& c, const uint64_t* handles, uint32_t n, const char* ref, uint32_t ref_len, int mode, double cut, int* best_id, int* best_end) {
+    RegionScratch& s = *c.sc;
+    double best = 0.0; int bid = -1, bend = -1;
+    for (uint32_t i = 0; i < n && !rtk_failed(s); ++i) {
+        const uint32_t sl = rtk_rec_to_string(c, handles[i], s.str[0]);
+        if (sl == 0xFFFFFFFFu) break;
+        const uint32_t norm = (mode == RTK_MODE_NW) ? (sl > ref_len ? sl : ref_len) : sl;
+        if (i == 0) {
+            const MyersResult a = rtk_align(c, s.str[0], sl, ref, ref_len, -1, mode);
+            best = static_cast<double>(a.dist) / static_cast<double>(norm); bend = a.first; bid = 0;
+        } else {
+            const int kk = static_cast<int>(best * static_cast<double>(norm) + 1.0); // G5: double -> int as edlibNewAlignConfig receives it
+            const MyersResult a = rtk_align(c, s.str[0], sl, ref, ref_len, kk, mode);
+            if (a.dist >= 0 && (static_cast<double>(a.dist) / static_cast<double>(norm)) < best) { best = static_cast<double>(a.dist) / static_cast<double>(norm); bend = a.first; bid = static_cast<int>(i); }
+        }
+    }
+    if (mode != RTK_MODE_NW && cut > 0.0 && best > cut) { bid = -1; bend = -1; }
+    *best_id = bid; *best_end = bend;
+}
+
+// ------------------------------------------------------------------------------------------------ scoring (src/GraphTraversal.cpp:867-909, 722-772)
+// path string must already be in str[1] (length sl)
+RTK_FN double rtk_score_path(const RCtx& c, uint32_t sl, const char* ref, uint32_t ref_len, bool terminal) {
+    RegionScratch& s = *c.sc;
+    double score = 0.0;
+    if (sl != 0) {
+        if (terminal) { const MyersResult a = rtk_align(c, s.str[1], sl, ref, ref_len, -1, RTK_MODE_NW); score = 1.0 - (static_cast<double>(a.dist) / static_cast<double>(sl)); }
+        else if (sl >= ref_len) { const MyersResult a = rtk_align(c, ref, ref_len, s.str[1], sl, -1, RTK_MODE_HW); score = 1.0 - (static_cast<double>(a.dist) / static_cast<double>(ref_len)); }
+        else {
+            const uint64_t cap = static_cast<uint64_t>(static_cast<double>(sl) * (1.0 + c.o.weak_region_len_factor));
+            const uint32_t l_ref_len = ref_len < cap ? ref_len : static_cast<uint32_t>(cap);
+            const MyersResult a = rtk_align(c, s.str[1], sl, ref, l_ref_len, -1, RTK_MODE_HW);
+            score = 1.0 - (static_cast<double>(a.dist) / static_cast<double>(sl));
+        }
+        score = score > 0.0 ? score : 0.0; score = score < 1.0 ? score : 1.0;
+    }
+    return score;
+}
+
+// quality string of a path (SHW path alignment against ref) written to qout[0..sl); path string in str[1]
+RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl, const char* ref, uint32_t ref_len, double score_best, double score_second, char* qout) {
+    RegionScratch& s = *c.sc;
+    const double score_comp = score_best * ((score_best == 0.0) ? 0.0 : (1.0 - (score_second / score_best)));
+    const MyersResult a = rtk_align(c, s.str[1], sl, ref, ref_len, -1, RTK_MODE_SHW);
+    uint32_t nm = 0;
+    if (sl > 0 && ref_len > 0) { s.cnt[3] += 1; rtk_myers_alignment(s.my, s.str[1], static_cast<int>(sl), ref, a.first + 1, a.dist, true, &nm); }
+    const char c_best = rtk_get_qual(score_best, 0, static_cast<uint64_t>(c.o.max_qual));
+    rtk_wfill(qout, rtk_get_qual(score_comp, static_cast<uint64_t>(c.o.out_qual), static_cast<uint64_t>(c.o.max_qual)), sl);
+    // walk the moves: a base gets the best-score quality when it sits on an identical reference base in an M run.
+    // query/reference positions of every move come from a prefix count of the moves (chunked wave scan).
+    uint32_t qp = 0, rp = 0;
+    const uint8_t* mv = s.my.moves;
+    for (uint32_t i0 = 0; i0 < nm; i0 += RTK_WAVE) {
+        const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+        const uint8_t m = i < nm ? mv[i] : 255;
+        const bool isq = (m == 0 || m == 3 || m == 1), isr = (m == 0 || m == 3 || m == 2);
+        const uint64_t bq = rtk_ballot(isq), br = rtk_ballot(isr);
+        const uint64_t lt = (1ull << rtk_lane()) - 1ull;
+        const uint32_t myq = qp + static_cast<uint32_t>(rtk_popc(bq & lt)), myr = rp + static_cast<uint32_t>(rtk_popc(br & lt));
+        if ((m == 0 || m == 3) && s.str[1][myq] == ref[myr]) qout[myq] = c_best;
+        qp += static_cast<uint32_t>(rtk_popc(bq)); rp += static_cast<uint32_t>(rtk_popc(br));
+    }
+    rtk_sync();
+}
+
+// ------------------------------------------------------------------------------------------------ colour memo (src/GraphTraversal.cpp:485-487)
+RTK_FN bool rtk_colour_ok(const RCtx& c, uint32_t u, const uint32_t* all_pids, uint32_t n_all) {
+    RegionScratch& s = *c.sc;
+    for (uint32_t i = 0; i < s.memo_n; ++i) if (s.memo_u[i] == u) return s.memo_v[i] != 0;
+    const bool ok = (n_all == 0) || (rtk_shared_with_set(c.g, u, all_pids, n_all, c.o.min_cov_vertices) >= c.o.min_cov_vertices);
+    s.cnt[1] += c.g.card[u] + n_all;
+    if (s.memo_n < s.memo_cap) { s.memo_u[s.memo_n] = u; s.memo_v[s.memo_n] = ok ? 1 : 0; ++s.memo_n; }
+    return ok;
+}
+
+RTK_DEV bool rtk_edge_bit(const GraphView& g, uint32_t u, uint32_t strand, int base) { // UnitigData::getSharedPids (UnitigData.hpp:275-284)
+    const uint32_t idx = 1u << base;
+    return strand ? ((g.flags[u] & (idx << 4)) != 0) : ((g.flags[u] & idx) != 0);
+}
+RTK_DEV int rtk_nb_successors(const GraphView& g, const UMap& um) {
+    const uint32_t* a = g.adj + 8ull * um.unitig + (um.strand ? 0 : 4);
+    int n = 0; for (int b = 0; b < 4; ++b) n += (a[b] != RTK_NONE32) ? 1 : 0; return n;
+}
+
+// ------------------------------------------------------------------------------------------------ DFS (src/GraphTraversal.cpp:456-587)
+// Results: handles of terminal / non-terminal paths (level-2 arena) in list[2] / list[3]; returns counts and best scores.
+struct DfsOut { uint32_t n_t, n_nt; double t1, nt1; };
+
+RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids, uint32_t n_all, const char* ref, uint32_t ref_len, uint32_t max_len_path,
+                                    const UMap& um, const UMap& um_e, uint32_t level) {
+    RegionScratch& s = *c.sc;
+    DfsOut out; out.n_t = 0; out.n_nt = 0; out.t1 = 0.0; out.nt1 = 0.0;
+    double score_t1 = 0.0, score_nt1 = 0.0, score_t2 = 0.0, score_nt2 = 0.0;
+    s.top[2] = 0;
+    uint64_t* T = s.list[2]; uint64_t* NT = s.list[3];
+    uint64_t* stk = s.list[4]; uint32_t sp = 0; // entries: handle (0 = empty path) and level, two words each
+    stk[0] = ~0ull; stk[1] = level; sp = 1;
+    WPath& w = s.wp[2];
+    while (sp > 0 && !rtk_failed(s)) {
+        --sp;
+        const uint64_t hp = stk[2 * sp]; const uint32_t lvl = static_cast<uint32_t>(stk[2 * sp + 1]);
+        const UMap um_start = (hp == ~0ull) ? um : rtk_rec_back(s, hp);
+        const uint32_t* adj = c.g.adj + 8ull * um_start.unitig + (um_start.strand ? 0 : 4);
+        s.cnt[0] += 1;
+        for (int b = 0; b < 4 && !rtk_failed(s); ++b) {
+            if (adj[b] == RTK_NONE32) continue;
+            UMap sc; sc.unitig = adj[b] >> 1; sc.strand = adj[b] & 1u; sc.dist = 0; sc.len = rtk_nkm(c.g, sc.unitig);
+            const bool col_ok = rtk_colour_ok(c, sc.unitig, all_pids, n_all);
+            if (!(rtk_edge_bit(c.g, um_start.unitig, um_start.strand, b) && col_ok)) continue;
+            if (!rtk_um_is_empty(um_e) && sc.unitig == um_e.unitig && um_e.strand == sc.strand) { // terminal
+                if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
+                UMap pref = sc;
+                if (pref.strand) { pref.dist = 0; pref.len = um_e.dist + 1; } else { pref.dist = um_e.dist; pref.len = rtk_nkm(c.g, sc.unitig) - um_e.dist; }
+                rtk_wp_extend(c, w, pref);
+                if (w.l <= max_len_path && !rtk_failed(s)) {
+                    const uint32_t sl = rtk_ums_to_string(c, w.ums, w.n, s.str[1]);
+                    if (sl == 0xFFFFFFFFu) break;
+                    const double sco = rtk_score_path(c, sl, ref, ref_len, true);
+                    if (sco >= score_t1) {
+                        if (sco > score_t1) out.n_t = 0;
+                        if (out.n_t >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
+                        T[out.n_t++] = rtk_wp_commit(s, w, 2);
+                        score_t2 = score_t1; score_t1 = sco;
+                    } else if (sco > score_t2) score_t2 = sco;
+                }
+            }
+            { // non-terminal
+                if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
+                rtk_wp_extend(c, w, sc);
+                if (rtk_failed(s)) break;
+                if (lvl != 0) {
+                    if (2 * (sp + 1) > s.list_cap) { rtk_fail_ovf(s, 8); break; }
+                    stk[2 * sp] = rtk_wp_commit(s, w, 2); stk[2 * sp + 1] = lvl - 1; ++sp;
+                } else if (rtk_nb_successors(c.g, sc) > 0) {
+                    const uint32_t sl = rtk_ums_to_string(c, w.ums, w.n, s.str[1]);
+                    if (sl == 0xFFFFFFFFu) break;
+                    const double sco = rtk_score_path(c, sl, ref, ref_len, false);
+                    if (sco >= score_nt1) {
+                        if (sco > score_nt1) out.n_nt = 0;
+                        if (out.n_nt >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
+                        NT[out.n_nt++] = rtk_wp_commit(s, w, 2);
+                        score_nt2 = score_nt1; score_nt1 = sco;
+                    } else if (sco > score_nt2) score_nt2 = sco;
+                }
+            }
+        }
+    }
+    // qualities (:556-584): re-commit every surviving path with its quality string
+    for (int which = 0; which < 2 && !rtk_failed(s); ++which) {
+        uint64_t* L = which ? NT : T; const uint32_t nL = which ? out.n_nt : out.n_t;
+        for (uint32_t i = 0; i < nL && !rtk_failed(s); ++i) {
+            rtk_wp_load(s, w, L[i]);
+            const uint32_t sl = rtk_ums_to_string(c, w.ums, w.n, s.str[1]);
+            if (sl == 0xFFFFFFFFu || sl > s.str_cap) { rtk_fail_ovf(s, 7); break; }
+            rtk_score_path_qual(c, sl, ref, ref_len, which ? score_nt1 : score_t1, which ? score_nt2 : score_t2, s.str[2]);
+            if (sl == w.l) { rtk_wcopy(w.qual, s.str[2], sl); w.qlen = sl; } // Path::setQuality only accepts q.length() == l
+            L[i] = rtk_wp_commit(s, w, 2);
+        }
+    }
+    out.t1 = score_t1; out.nt1 = score_nt1;
+    return out;
+}
+
+// explore() (src/GraphTraversal.cpp:41-93, 251-304). p = committed path (level 1). Results stay in list[2]/list[3] (level-2 arena).
+RTK_FN void rtk_explore(const RCtx& c, const uint32_t* all_pids, uint32_t n_all, const char* ref, uint32_t ref_len, const UMap& um_e, uint64_t hp, uint32_t max_len_path,
+                         uint32_t* n_t, uint32_t* n_nt) {
+    RegionScratch& s = *c.sc;
+    *n_t = 0; *n_nt = 0;
+    const UMap um = rtk_rec_back(s, hp);
+    const uint32_t path_len = rtk_rec_l(s, hp);
+    const uint32_t k = static_cast<uint32_t>(c.k);
+    const bool non_empty_path = (path_len > (um.len + k - 1)) && !rtk_um_is_empty(um);
+    const uint32_t path_len_prefix = non_empty_path ? (path_len - um.len - k + 1) : 0;
+    uint32_t end_pos_ref = 0;
+    if (non_empty_path) {
+        const uint32_t sl = rtk_rec_to_string(c, hp, s.str[0]);
+        if (sl == 0xFFFFFFFFu) return;
+        const MyersResult a = rtk_align(c, s.str[0], path_len_prefix, ref, ref_len, -1, RTK_MODE_SHW);
+        end_pos_ref = static_cast<uint32_t>(a.first + 1);
+    }
+    if ((ref_len - end_pos_ref) != 0 && path_len < max_len_path) {
+        DfsOut o = rtk_explore_subgraph(c, all_pids, n_all, ref + end_pos_ref, ref_len - end_pos_ref, max_len_path - path_len_prefix, um, um_e, 3);
+        if (rtk_failed(s)) return;
+        if (o.n_t && o.t1 < c.o.min_score) o.n_t = 0;
+        if (o.n_nt && o.nt1 < c.o.min_score) o.n_nt = 0;
+        if (o.n_nt > 1) {
+            int bid, bend;
+            rtk_select_best(c, s.list[3], o.n_nt, ref + end_pos_ref, ref_len - end_pos_ref, RTK_MODE_HW, -1.0, &bid, &bend);
+            s.list[3][0] = s.list[3][bid]; o.n_nt = 1;
+        }
+        *n_t = o.n_t; *n_nt = o.n_nt;
+    }
+}
+
+// P (+) Q: w = copy of p extended by every mapping of sub with its quality slice (src/GraphTraversal.cpp:379-390)
+RTK_FN void rtk_extend_by(const RCtx& c, WPath& w, uint64_t hsub, uint32_t upto /*number of sub mappings to take*/) {
+    RegionScratch& s = *c.sc;
+    const int lv = rtk_h_lvl(hsub); const uint64_t oo = rtk_h_off(hsub);
+    const PathHdr* h = rtk_path_hdr(s, lv, oo); const UMap* ums = rtk_path_ums(s, lv, oo); const char* q = rtk_path_qual(s, lv, oo);
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < h->n && i < upto && !rtk_failed(s); ++i) {
+        const uint32_t want = ums[i].len + static_cast<uint32_t>(c.k) - 1;
+        uint32_t qn = 0;
+        if (j <= h->qlen) qn = (h->qlen - j) < want ? (h->qlen - j) : want; // std::string::substr clamps
+        rtk_wp_extend_q(c, w, ums[i], q + j, qn);
+        j += ums[i].len;
+    }
+}
+
+RTK_FN void rtk_resize_to_best(const RCtx& c, uint64_t* v, uint32_t* n, const char* ref, uint32_t ref_len) { // resizeVector
+    if (*n <= 1) return;
+    int bid, bend;
+    rtk_select_best(c, v, *n, ref, ref_len, RTK_MODE_SHW, -1.0, &bid, &bend);
+    if (rtk_failed(*c.sc)) return;
+    v[0] = v[bid]; *n = 1;
+}
+
+RTK_DEV UMap rtk_start_suffix(const RCtx& c, const UMap& um_s) { // src/GraphTraversal.cpp:113-125, 325-338
+    UMap t = um_s;
+    if (t.strand) { t.dist += t.len - 1; t.len = rtk_nkm(c.g, um_s.unitig) - t.dist; }
+    else { t.len = um_s.dist + 1; t.dist = 0; }
+    return t;
+}
+
+// explorePathsBFS2 / explorePathsBFS. Returns a level-1 handle of the single resulting path, or ~0 if none.
+RTK_FN uint64_t rtk_explore_paths(const RCtx& c, const uint32_t* all_pids, uint32_t n_all, const char* ref, uint32_t ref_len, const UMap& um_s, const UMap& um_e, bool has_end) {
+    RegionScratch& s = *c.sc;
+    const uint32_t k = static_cast<uint32_t>(c.k);
+    s.top[1] = 0; s.memo_n = 0;
+    uint64_t* v = s.list[0]; uint64_t* v_tmp = s.list[1];
+    uint32_t nv = 0, nvt = 0;
+    const char q_max = rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual));
+    const bool ok_start = !rtk_um_is_empty(um_s) && ((c.g.flags[um_s.unitig] & RTK_F_EDGE_MASK) != 0);
+    const bool ok_end = !has_end || (!rtk_um_is_empty(um_e) && ((c.g.flags[um_e.unitig] & RTK_F_EDGE_MASK) != 0));
+    if (ok_start && ok_end) {
+        const uint32_t level = 4;
+        uint64_t mn, mx; rtk_min_max_len(ref_len - k, c.o.weak_region_len_factor, &mn, &mx);
+        const uint32_t min_len_path = static_cast<uint32_t>(mn) + k;
+        const uint32_t max_len_path = static_cast<uint32_t>(mx > 10 ? mx : 10) + k;
+        const uint32_t max_paths = 1024;
+        WPath& w = s.wp[1];
+        const UMap ust = rtk_start_suffix(c, um_s);
+        if (has_end) {
+            if (um_s.unitig == um_e.unitig && um_s.strand == um_e.strand && ust.dist <= um_e.dist) { // :340-358
+                const uint32_t len = (ust.len + k - 1) - (um_e.strand ? (rtk_ulen(c.g, um_e.unitig) - um_e.dist - k) : um_e.dist);
+                if (len >= min_len_path && len <= max_len_path) {
+                    UMap bt = ust;
+                    if (bt.strand) bt.len = um_e.dist - bt.dist + 1; else { bt.dist = um_e.dist; bt.len -= um_e.dist; }
+                    rtk_wp_start(c, w, bt, q_max);
+                    v[nv++] = rtk_wp_commit(s, w, 1);
+                }
+            }
+        } else if ((ust.len + k - 1) >= min_len_path) { // :127-140
+            UMap back = ust;
+            if ((back.len + k - 1) > max_len_path) { if (!back.strand) back.dist = back.len - (max_len_path - k + 1); back.len = max_len_path - k + 1; }
+            rtk_wp_start(c, w, back, q_max);
+            v[nv++] = rtk_wp_commit(s, w, 1);
+        }
+        rtk_wp_start(c, w, ust, q_max);
+        uint64_t qh = rtk_wp_commit(s, w, 1); bool q_has = true; // the queue never holds more than one path (each pop pushes <= 1)
+        while (q_has && !rtk_failed(s)) {
+            const uint64_t hp = qh; q_has = false;
+            if (rtk_rec_l(s, hp) < max_len_path) {
+                uint32_t n_t, n_nt;
+                rtk_explore(c, all_pids, n_all, ref, ref_len, has_end ? um_e : rtk_um_empty(), hp, max_len_path, &n_t, &n_nt);
+                if (rtk_failed(s)) break;
+                if (has_end) {
+                    for (uint32_t i = 0; i < n_t && !rtk_failed(s); ++i) {
+                        rtk_wp_load(s, w, hp); rtk_extend_by(c, w, s.list[2][i], 0xFFFFFFFFu);
+                        if (nvt >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
+                        v_tmp[nvt++] = rtk_wp_commit(s, w, 1);
+                    }
+                    for (uint32_t i = 0; i < n_nt && !rtk_failed(s); ++i) {
+                        if (rtk_rec_n(s, s.list[3][i]) == level) {
+                            rtk_wp_load(s, w, hp); rtk_extend_by(c, w, s.list[3][i], 0xFFFFFFFFu);
+                            qh = rtk_wp_commit(s, w, 1); q_has = true; // queue size 1 < 512: resizeQueue never fires
+                        }
+                    }
+                    if (nvt >= max_paths) {
+                        for (uint32_t i = 0; i < nvt && !rtk_failed(s); ++i) {
+                            const uint32_t l = rtk_rec_l(s, v_tmp[i]);
+                            if (l >= min_len_path && l <= max_len_path) { if (nv + 1 >= max_paths) rtk_resize_to_best(c, v, &nv, ref, ref_len); v[nv++] = v_tmp[i]; }
+                        }
+                        nvt = 0;
+                    }
+                } else { // BFS without end anchor: every extension inside the length window is a candidate (:158-191)
+                    for (uint32_t i = 0; i < n_nt && !rtk_failed(s); ++i) {
+                        const uint64_t hs = s.list[3][i];
+                        const uint32_t nsub = rtk_rec_n(s, hs);
+                        for (uint32_t u = 1; u <= nsub && !rtk_failed(s); ++u) {
+                            rtk_wp_load(s, w, hp); rtk_extend_by(c, w, hs, u);
+                            if (w.l >= min_len_path && w.l <= max_len_path) { if (nvt >= s.list_cap) { rtk_fail_ovf(s, 8); break; } v_tmp[nvt++] = rtk_wp_commit(s, w, 1); }
+                            if (u == nsub && nsub == level) { qh = rtk_wp_commit(s, w, 1); q_has = true; }
+                        }
+                    }
+                    if (nvt >= max_paths) {
+                        for (uint32_t i = 0; i < nvt && !rtk_failed(s); ++i) {
+                            rtk_wp_load(s, w, v_tmp[i]); rtk_wp_prune_prefix(c, w, max_len_path);
+                            if (nv >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
+                            v[nv++] = rtk_wp_commit(s, w, 1);
+                        }
+                        nvt = 0;
+                    }
+                }
+            }
+        }
+        if (!rtk_failed(s)) { // final flush
+            if (has_end) {
+                for (uint32_t i = 0; i < nvt && !rtk_failed(s); ++i) {
+                    const uint32_t l = rtk_rec_l(s, v_tmp[i]);
+                    if (l >= min_len_path && l <= max_len_path) { if (nv + 1 >= max_paths) rtk_resize_to_best(c, v, &nv, ref, ref_len); v[nv++] = v_tmp[i]; }
+                }
+            } else {
+                for (uint32_t i = 0; i < nvt && !rtk_failed(s); ++i) {
+                    rtk_wp_load(s, w, v_tmp[i]); rtk_wp_prune_prefix(c, w, max_len_path);
+                    if (nv >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
+                    v[nv++] = rtk_wp_commit(s, w, 1);
+                }
+            }
+        }
+    }
+    if (rtk_failed(s) || nv == 0) return ~0ull;
+    if (nv > 1) { int bid, bend; rtk_select_best(c, v, nv, ref, ref_len, RTK_MODE_NW, -1.0, &bid, &bend); if (rtk_failed(s)) return ~0ull; v[0] = v[bid]; }
+    return v[0]; // fixRepeats is the identity on an index without short-cycle annotations
+}
+
+// ------------------------------------------------------------------------------------------------ extractSemiWeakPaths (src/Correction.cpp:3-157)
+// BFS results never hold more than one path, so `paths1` is a single running path (level 0). Dead ends are appended to
+// `partial` (list[5]). Returns the complete path handle or ~0.
+RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c, const char* s_read, uint32_t s_len, const uint32_t* all_pids, uint32_t n_all,
+                                       uint32_t start_pos, const UMap& start_um, uint32_t end_pos_in, const UMap& end_um, const Anchors& lvw, uint32_t lvw_lo, uint32_t lvw_hi, uint32_t i_weak,
+                                       uint32_t* n_partial) {
+    RegionScratch& s = *c.sc;
+    const uint32_t k = static_cast<uint32_t>(c.k);
+    const bool no_end = rtk_um_is_empty(end_um);
+    const uint32_t pos2 = no_end ? s_len - k : end_pos_in;
+    const uint32_t max_len_weak_region = c.o.max_len_weak_region1;
+    uint32_t next_weak_pos = 0;
+    bool begin = true, end = false;
+    WPath& w0 = s.wp[0];
+    rtk_wp_start(c, w0, start_um, rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual)));
+    uint64_t cur = rtk_wp_commit(s, w0, 0); uint32_t cur_pos = start_pos; bool have = true;
+    const uint32_t nw = lvw_hi - lvw_lo; // weak anchors of the region are lvw[lvw_lo + i], i in [0, nw)
+    while (i_weak < nw && rtk_an_pos(lvw, lvw_lo + i_weak) < start_pos) ++i_weak;
+    if (i_weak < nw) { const uint32_t wp = rtk_an_pos(lvw, lvw_lo + i_weak); next_weak_pos = wp > start_pos + k ? wp : start_pos + k; }
+    while (have && !end && !rtk_failed(s)) {
+        if (i_weak < nw) { while (i_weak < nw && static_cast<uint64_t>(rtk_an_pos(lvw, lvw_lo + i_weak)) < static_cast<uint64_t>(pos2 - k) && rtk_an_pos(lvw, lvw_lo + i_weak) < next_weak_pos) ++i_weak; }
+        else i_weak = nw;
+        end = (i_weak == nw) || (static_cast<uint64_t>(rtk_an_pos(lvw, lvw_lo + i_weak)) >= static_cast<uint64_t>(pos2 - k));
+        const uint32_t target_pos = end ? pos2 : rtk_an_pos(lvw, lvw_lo + i_weak);
+        const uint32_t l_len = (target_pos - cur_pos) + k;
+        const UMap um_start = begin ? start_um : rtk_rec_back(s, cur);
+        uint64_t res = ~0ull; bool called = false;
+        if (end) {
+            if (no_end) { if (l_len <= (max_len_weak_region / 2)) { res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, rtk_um_empty(), false); called = true; } }
+            else if (l_len <= max_len_weak_region) { res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, end_um, true); called = true; }
+        } else if (l_len <= max_len_weak_region) { res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, rtk_an_um(lvw, lvw_lo + i_weak), true); called = true; }
+        if (rtk_failed(s)) break;
+        if (called && res != ~0ull) {
+            rtk_wp_load(s, w0, cur); rtk_wp_merge(c, w0, res);
+            cur = rtk_wp_commit(s, w0, 0); cur_pos = target_pos;
+        } else {
+            if (*n_partial >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
+            s.list[5][(*n_partial)++] = cur; have = false;
+        }
+        if (!end) next_weak_pos = rtk_an_pos(lvw, lvw_lo + i_weak) + k;
+        begin = false;
+    }
+    return (have && !rtk_failed(s)) ? cur : ~0ull;
+}
+
+// ------------------------------------------------------------------------------------------------ chooseColors (src/Correction.cpp:215-429)
+// anchors of the three sides are given as small (unitig, non-branching) lists, first insertion wins (unordered_map::insert).
+struct SideList { uint32_t* u; uint8_t* nb; uint32_t n, cap; };
+RTK_DEV bool rtk_side_insert(SideList& l, uint32_t u, bool nonbranching) { // returns true when unseen
+    for (uint32_t i = 0; i < l.n; ++i) if (l.u[i] == u) return false;
+    if (l.n < l.cap) { l.u[l.n] = u; l.nb[l.n] = nonbranching ? 1 : 0; ++l.n; }
+    return true;
+}
+
+// set-buffer helpers on RegionScratch: buffers are addressed by index; sizes kept by the caller
+RTK_DEV uint32_t rtk_rs_union(RegionScratch& s, int a, uint32_t na, const uint32_t* b, uint32_t nb, int out) {
+    if (na + nb > s.set_cap) { rtk_fail_ovf(s, 9); return 0; }
+    return rtk_set_union(s.set[a], na, b, nb, s.set[out], s.set[9]);
+}
+
+// Computes all_pids into set[0]; returns its size. Uses set[1..9] as temporaries.
+RTK_FN uint32_t rtk_choose_colors(const RCtx& c, const SideList& side_s, const SideList& side_e, const SideList& side_w) {
+    RegionScratch& s = *c.sc;
+    const GraphView& g = c.g;
+    // a_pid[shift], shift = side index (0 middle, 1 right, 2 left) + 3 * nonbranching: built one after the other into the arena (level 2 is free here)
+    s.top[2] = 0;
+    const SideList* sides[3] = {&side_w, &side_e, &side_s};
+    uint64_t a_off[6]; uint32_t a_n[6];
+    for (int sh = 0; sh < 6 && !rtk_failed(s); ++sh) {
+        const SideList& sl = *sides[sh % 3]; const uint8_t want_nb = sh >= 3 ? 1 : 0;
+        int cur = 1; uint32_t n = 0;
+        for (uint32_t i = 0; i < sl.n && !rtk_failed(s); ++i) {
+            if (sl.nb[i] != want_nb) continue;
+            const uint32_t u = sl.u[i];
+            const int32_t gi = g.gid[u]; // G2: only the global set when there is one
+            const uint32_t* src = gi >= 0 ? g.col + g.goff[gi] : g.col + g.loff[u];
+            const uint32_t ns = gi >= 0 ? static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]) : static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]);
+            s.cnt[1] += ns;
+            n = rtk_rs_union(s, cur, n, src, ns, cur ^ 3); cur ^= 3; // ping-pong between set[1] and set[2]
+        }
+        a_off[sh] = rtk_arena_alloc(s, 2, 4ull * n + 4); a_n[sh] = n;
+        if (!rtk_failed(s)) rtk_wcopy(s.arena[2] + a_off[sh], s.set[cur], 4ull * n);
+    }
+    if (rtk_failed(s)) return 0;
+    auto A = [&](int i) -> const uint32_t* { return reinterpret_cast<const uint32_t*>(s.arena[2] + a_off[i]); };
+    // candidate anchors: cardinality >= min_cov_vertices, ordered by (cardinality, unitig id) [D1]
+    uint64_t* keys = s.list[4]; uint64_t* vals = s.list[3];
+    uint32_t nsp = 0;
+    for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i) {
+        const uint32_t u = sides[sd]->u[i];
+        if (g.card[u] < c.o.min_cov_vertices) continue;
+        bool dup = false; for (uint32_t j = 0; j < nsp; ++j) if (static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull) == u) dup = true;
+        if (dup) continue;
+        if (2 * (nsp + 1) > s.list_cap) { rtk_fail_ovf(s, 8); return 0; }
+        keys[nsp] = (static_cast<uint64_t>(g.card[u]) << 32) | u; vals[nsp] = 0; ++nsp;
+    }
+    rtk_sort_pairs(keys, vals, nsp);
+    const uint32_t cov = 30;
+    for (uint32_t j = 0; j < nsp; ++j) { const uint32_t cd = static_cast<uint32_t>(keys[j] >> 32); vals[j] = cd < cov ? cd : cov; } // remaining quota (p_spid.second)
+    // position unions and their pairwise intersections
+    // set[3] = pos0 = a0|a3, set[4] = pos1 = a1|a4, set[5] = pos2 = a2|a5
+    uint32_t n_pos[3];
+    for (int p = 0; p < 3; ++p) { if (a_n[p] + a_n[p + 3] > s.set_cap) { rtk_fail_ovf(s, 9); return 0; } n_pos[p] = rtk_set_union(A(p), a_n[p], A(p + 3), a_n[p + 3], s.set[3 + p], s.set[9]); }
+    // park a01, a12, a02, nobranch, nobranch_cpy in the arena
+    uint64_t o01, o12, o02, onb, onbc, oi3, oi2, obr; uint32_t n01, n12, n02, nnb, nnbc, ni3 = 0, ni2 = 0, nbr = 0;
+    auto park = [&](const uint32_t* src, uint32_t n, uint64_t* off) { *off = rtk_arena_alloc(s, 2, 4ull * n + 4); if (!rtk_failed(s)) rtk_wcopy(s.arena[2] + *off, src, 4ull * n); };
+    auto P = [&](uint64_t off) -> uint32_t* { return reinterpret_cast<uint32_t*>(s.arena[2] + off); };
+    n01 = rtk_set_inter(s.set[3], n_pos[0], s.set[4], n_pos[1], s.set[6]); park(s.set[6], n01, &o01);
+    n12 = rtk_set_inter(s.set[4], n_pos[1], s.set[5], n_pos[2], s.set[6]); park(s.set[6], n12, &o12);
+    n02 = rtk_set_inter(s.set[3], n_pos[0], s.set[5], n_pos[2], s.set[6]); park(s.set[6], n02, &o02);
+    if (rtk_failed(s)) return 0;
+    { // nobranch = a3|a4|a5
+        if (a_n[3] + a_n[4] + a_n[5] > s.set_cap) { rtk_fail_ovf(s, 9); return 0; }
+        const uint32_t t = rtk_set_union(A(3), a_n[3], A(4), a_n[4], s.set[6], s.set[9]);
+        nnb = rtk_set_union(s.set[6], t, A(5), a_n[5], s.set[7], s.set[9]);
+        park(s.set[7], nnb, &onb); park(s.set[7], nnb, &onbc); nnbc = nnb;
+    }
+    if (rtk_failed(s)) return 0;
+    uint32_t n_all = 0; // all_pids lives in set[0]
+    uint32_t nb_unselected = nsp;
+    uint64_t o_prev2 = 0; uint32_t n_prev2 = 0; // a_pid2 of the previous class
+    for (int i = 5; i >= 0 && !rtk_failed(s); --i) {
+        if (nb_unselected == 0) break;
+        uint32_t n2 = 0; // a_pid2[i] -> set[8]
+        if (i == 5) {
+            ni3 = rtk_set_inter(P(o01), n01, P(o12), n12, s.set[6]); park(s.set[6], ni3, &oi3);
+            n2 = rtk_set_inter(P(onb), nnb, P(oi3), ni3, s.set[8]);
+        } else if (i == 4) {
+            if (n01 + n12 + n02 > s.set_cap) { rtk_fail_ovf(s, 9); break; }
+            const uint32_t t = rtk_set_union(P(o01), n01, P(o12), n12, s.set[6], s.set[9]);
+            ni2 = rtk_set_union(s.set[6], t, P(o02), n02, s.set[7], s.set[9]); park(s.set[7], ni2, &oi2);
+            nnb = rtk_set_diff(P(onb), nnb, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(onb), s.set[6], 4ull * nnb);
+            n2 = rtk_set_inter(P(onb), nnb, P(oi2), ni2, s.set[8]);
+        } else if (i == 3) {
+            nnb = rtk_set_diff(P(onb), nnb, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(onb), s.set[6], 4ull * nnb);
+            n2 = nnb; rtk_wcopy(s.set[8], P(onb), 4ull * nnb);
+        } else if (i == 2) {
+            if (a_n[0] + a_n[1] + a_n[2] > s.set_cap) { rtk_fail_ovf(s, 9); break; }
+            const uint32_t t = rtk_set_union(A(0), a_n[0], A(1), a_n[1], s.set[6], s.set[9]);
+            const uint32_t t2 = rtk_set_union(s.set[6], t, A(2), a_n[2], s.set[7], s.set[9]);
+            nbr = rtk_set_diff(s.set[7], t2, P(onbc), nnbc, s.set[6]); park(s.set[6], nbr, &obr);
+            n2 = rtk_set_inter(P(obr), nbr, P(oi3), ni3, s.set[8]);
+        } else if (i == 1) {
+            nbr = rtk_set_diff(P(obr), nbr, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(obr), s.set[6], 4ull * nbr);
+            n2 = rtk_set_inter(P(obr), nbr, P(oi2), ni2, s.set[8]);
+        } else {
+            nbr = rtk_set_diff(P(obr), nbr, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(obr), s.set[6], 4ull * nbr);
+            n2 = nbr; rtk_wcopy(s.set[8], P(obr), 4ull * nbr);
+        }
+        if (rtk_failed(s)) break;
+        park(s.set[8], n2, &o_prev2); n_prev2 = n2; // a_pid2[i] is needed by the next class
+        if (n2 != 0) {
+            nb_unselected = 0;
+            uint32_t ncur = n2; int curb = 8; // curr_pid in set[8] / set[7] (ping-pong)
+            for (uint32_t j = 0; j < nsp && !rtk_failed(s); ++j) {
+                const uint32_t u = static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull);
+                int quota = static_cast<int>(vals[j]);
+                if (quota > 0 && (i == 0 || rtk_shared_with_set(g, u, s.set[curb], ncur, 1) >= 1)) {
+                    const uint32_t min_cov = g.card[u] < cov ? g.card[u] : cov;
+                    const uint32_t sh = rtk_shared_with_set(g, u, s.set[0], n_all, min_cov);
+                    quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
+                    if (quota > 0) {
+                        const uint32_t all_card = n_all;
+                        // pid = (global & curr) | (local & curr), truncated to its `quota` lowest ids
+                        uint32_t npid = 0;
+                        const int32_t gi = g.gid[u];
+                        uint32_t ng = 0;
+                        if (gi >= 0) ng = rtk_set_inter(g.col + g.goff[gi], static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]), s.set[curb], ncur, s.set[6]);
+                        const uint32_t nl = rtk_set_inter(g.col + g.loff[u], static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]), s.set[curb], ncur, s.set[5]);
+                        if (ng + nl > s.set_cap) { rtk_fail_ovf(s, 9); break; }
+                        npid = rtk_set_union(s.set[6], ng, s.set[5], nl, s.set[4], s.set[9]);
+                        if (npid > static_cast<uint32_t>(quota)) npid = static_cast<uint32_t>(quota);
+                        if (n_all + npid > s.set_cap) { rtk_fail_ovf(s, 9); break; }
+                        const uint32_t nn = rtk_set_union(s.set[0], n_all, s.set[4], npid, s.set[3], s.set[9]);
+                        rtk_wcopy(s.set[0], s.set[3], 4ull * nn); n_all = nn;
+                        const int nb2 = curb == 8 ? 7 : 8;
+                        ncur = rtk_set_diff(s.set[curb], ncur, s.set[4], npid, s.set[nb2]); curb = nb2;
+                        const int gained = static_cast<int>(n_all - all_card);
+                        quota -= gained < quota ? gained : quota;
+                    }
+                }
+                vals[j] = static_cast<uint64_t>(quota);
+                nb_unselected += quota > 0 ? 1u : 0u;
+            }
+        }
+    }
+    return rtk_failed(s) ? 0 : n_all;
+}
+
+// ------------------------------------------------------------------------------------------------ ResultCorrection (src/ResultCorrection.hpp)
+struct ResCorr { char* seq; char* qual; uint32_t seq_len, qual_len; uint64_t* bm; uint32_t old_len; bool is_corrected; uint32_t n_all; int all_set; };
+
+RTK_DEV void rtk_bm_add_range(uint64_t* bm, uint32_t a, uint32_t b) { for (uint32_t i = a; i < b; ++i) bm[i >> 6] |= 1ull << (i & 63); }
+RTK_DEV uint32_t rtk_bm_card(const uint64_t* bm, uint32_t n) { uint32_t c = 0; for (uint32_t w = 0; w < (n + 63) / 64; ++w) c += static_cast<uint32_t>(rtk_popc(bm[w])); return c; }
+RTK_DEV bool rtk_bm_get(const uint64_t* bm, uint32_t i) { return (bm[i >> 6] >> (i & 63)) & 1ull; }
+RTK_DEV uint32_t rtk_rc_len_corrected(const ResCorr& r, uint32_t p) { uint32_t n = p; while (n < r.old_len && rtk_bm_get(r.bm, n)) ++n; return n - p; } // :117-128
+RTK_DEV uint32_t rtk_rc_len_uncorrected(const ResCorr& r, uint32_t p) { if (p >= r.old_len) return 0; uint32_t n = p; while (n < r.old_len && !rtk_bm_get(r.bm, n)) ++n; return n - p; } // :130-142
+
+RTK_FN void rtk_rc_reverse_complement(RegionScratch& s, ResCorr& r, uint64_t* tmp_bm, char* tmp) { // :72-88
+    if (r.seq_len == 0) return;
+    const uint32_t words = (r.old_len + 63) / 64;
+    for (uint32_t w = 0; w < words; ++w) tmp_bm[w] = 0;
+    for (uint32_t i = 0; i < r.old_len; ++i) if (rtk_bm_get(r.bm, i)) { const uint32_t j = r.old_len - i - 1; tmp_bm[j >> 6] |= 1ull << (j & 63); }
+    for (uint32_t w = 0; w < words; ++w) r.bm[w] = tmp_bm[w];
+    for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < r.seq_len; i += RTK_WAVE) tmp[i] = rtk_comp(r.seq[r.seq_len - 1 - i]);
+    rtk_sync(); rtk_wcopy(r.seq, tmp, r.seq_len);
+    for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < r.qual_len; i += RTK_WAVE) tmp[i] = r.qual[r.qual_len - 1 - i];
+    rtk_sync(); rtk_wcopy(r.qual, tmp, r.qual_len);
+    (void)s;
+}
+
+// appenders for the growing corrected strings
+RTK_FN void rtk_app(RegionScratch& s, char* dst, uint32_t* len, const char* src, uint32_t n) { if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wcopy(dst + *len, src, n); *len += n; }
+RTK_FN void rtk_app_fill(RegionScratch& s, char* dst, uint32_t* len, char ch, uint32_t n) { if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wfill(dst + *len, ch, n); *len += n; }
+
+// Bifrost Kmer(const char*) 2-bit code of any character (end k-mer test, src/Correction.cpp:720-724)
+RTK_DEV int rtk_bifrost_code(char ch) { const int x = (ch & 4) >> 1; return x + ((x ^ (ch & 2)) >> 1); }
+
+// ------------------------------------------------------------------------------------------------ the `correct` lambda (src/Correction.cpp:431-753)
+// s_read: read in the orientation of this call; v_s / v_w: anchors in that orientation. Result strings go to res.seq / res.qual.
+RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len, const Anchors& v_s, const Anchors& v_w, uint32_t i_s, uint32_t i_w, const ResCorr* rc, ResCorr& res) {
+    RegionScratch& s = *c.sc;
+    const uint32_t k = static_cast<uint32_t>(c.k);
+    const GraphView& g = c.g;
+    const bool has_end_pt = (i_s + 1) < v_s.n;
+    uint32_t p1 = rtk_an_pos(v_s, i_s); UMap um1 = rtk_an_um(v_s, i_s);
+    const uint32_t p2 = has_end_pt ? rtk_an_pos(v_s, i_s + 1) : (s_len - k);
+    const UMap um2 = has_end_pt ? rtk_an_um(v_s, i_s + 1) : rtk_um_empty();
+    const uint32_t first_pos = p1;
+    uint32_t len_weak_region = p2 - p1 + k;
+    const uint64_t u_min_start = static_cast<uint64_t>(p1) - static_cast<uint64_t>(c.o.insert_sz); // wraps below insert_sz (G1)
+    const uint64_t u_min_end = static_cast<uint64_t>(p2) + static_cast<uint64_t>(c.o.insert_sz);
+    res.old_len = len_weak_region; res.is_corrected = false; res.seq_len = 0; res.qual_len = 0; res.n_all = 0;
+    if ((len_weak_region + 63) / 64 + 1 > s.bm_words) { rtk_fail_ovf(s, 10); return; }
+    for (uint32_t w = 0; w < (len_weak_region + 63) / 64 + 1; ++w) res.bm[w] = 0;
+    const char q_min = rtk_get_qual(0.0, 0, static_cast<uint64_t>(c.o.max_qual));
+    const uint32_t max_len_weak_anchors = c.o.max_len_weak_region1;
+    // weak anchors inside the region: l_v_w = v_w[lw_lo .. lw_hi)
+    uint32_t lw_lo = 0, lw_hi = 0;
+    {
+        const uint32_t v_w_sz = v_w.n;
+        if (v_w_sz) {
+            const uint32_t pos_end = has_end_pt ? p2 : s_len;
+            uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
+            while (x < v_w_sz && rtk_an_pos(v_w, x) < first_pos) ++x;
+            lw_lo = x;
+            while (x < v_w_sz && rtk_an_pos(v_w, x) < pos_end) ++x;
+            lw_hi = x;
+        }
+    }
+    uint32_t n_all = 0;
+    if (rc == nullptr) {
+        // side lists live in list[0..2] memory (u32 unitig + flag bytes)
+        SideList sl, sr, sm;
+        const uint32_t cap = s.list_cap;
+        sl.u = reinterpret_cast<uint32_t*>(s.list[0]); sl.nb = reinterpret_cast<uint8_t*>(s.list[0] + cap / 2); sl.n = 0; sl.cap = cap;
+        sr.u = reinterpret_cast<uint32_t*>(s.list[1]); sr.nb = reinterpret_cast<uint8_t*>(s.list[1] + cap / 2); sr.n = 0; sr.cap = cap;
+        sm.u = reinterpret_cast<uint32_t*>(s.list[2]); sm.nb = reinterpret_cast<uint8_t*>(s.list[2] + cap / 2); sm.n = 0; sm.cap = cap;
+        auto consider = [&](SideList& m, const UMap& um, uint32_t& nb_branching) {
+            const uint32_t u = um.unitig; const bool br = rtk_is_branching(g, u);
+            if (g.kcov[u] < c.o.max_km_cov && (!br || nb_branching < 5)) { const bool unseen = rtk_side_insert(m, u, !br); nb_branching += (unseen && br) ? 1u : 0u; }
+        };
+        { // left (:476-516)
+            uint32_t nbb = 0;
+            for (int64_t x = static_cast<int64_t>(i_s); x >= 0 && static_cast<uint64_t>(rtk_an_pos(v_s, static_cast<uint32_t>(x))) > u_min_start; --x) consider(sl, rtk_an_um(v_s, static_cast<uint32_t>(x)), nbb);
+            const uint32_t v_w_sz = v_w.n;
+            uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
+            while (x > 0 && static_cast<uint64_t>(rtk_an_pos(v_w, x)) > u_min_start) --x;
+            for (; x < v_w_sz && rtk_an_pos(v_w, x) < first_pos; ++x) consider(sl, rtk_an_um(v_w, x), nbb);
+        }
+        if (has_end_pt) { // right (:518-561)
+            uint32_t nbb = 0;
+            for (uint32_t x = i_s + 1; x < v_s.n && static_cast<uint64_t>(rtk_an_pos(v_s, x)) < u_min_end; ++x) consider(sr, rtk_an_um(v_s, x), nbb);
+            const uint32_t v_w_sz = v_w.n;
+            uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
+            while (x < v_w_sz && rtk_an_pos(v_w, x) < p2) ++x;
+            for (; x < v_w_sz && static_cast<uint64_t>(rtk_an_pos(v_w, x)) < u_min_end; ++x) consider(sr, rtk_an_um(v_w, x), nbb);
+        }
+        for (uint32_t x = lw_lo; x < lw_hi; ++x) { const uint32_t u = rtk_an_um(v_w, x).unitig; if (g.kcov[u] < c.o.max_km_cov) rtk_side_insert(sm, u, !rtk_is_branching(g, u)); } // middle (:563-585)
+        if (sl.n >= cap / 2 || sr.n >= cap / 2 || sm.n >= cap / 2) { rtk_fail_ovf(s, 8); return; }
+        n_all = rtk_choose_colors(c, sl, sr, sm);
+        if (rtk_failed(s)) return;
+        // keep all_pids for the reverse-complement call (rc = &fw): set[0] is preserved by everything below
+    } else n_all = rc->n_all;
+    res.n_all = n_all;
+    const uint32_t* all_pids = s.set[0];
+    // ---- paths ----
+    s.top[0] = 0;
+    uint32_t n_partial = 0;
+    uint64_t complete = ~0ull;
+    char* s_corr = res.seq; char* q_corr = res.qual; uint32_t sl_ = 0, ql_ = 0;
+    const Anchors& lvw = v_w;
+    if (n_all >= c.o.min_cov_vertices) complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, 0, &n_partial);
+    if (rtk_failed(s)) return;
+    const uint32_t nlw = lw_hi - lw_lo;
+    auto add_uncorrected = [&](uint32_t pos, uint32_t len, char q) { rtk_app(s, s_corr, &sl_, s_read + pos, (pos + len <= s_len) ? len : (pos < s_len ? s_len - pos : 0)); rtk_app_fill(s, q_corr, &ql_, q, len_weak_region); };
+    if (complete == ~0ull) {
+        uint32_t i_w_s = 0;
+        while (complete == ~0ull && n_partial != 0 && nlw != 0 && n_all >= c.o.min_cov_vertices && !rtk_failed(s)) { // :619-651
+            int aid, aend;
+            rtk_select_best(c, s.list[5], n_partial, s_read + p1, len_weak_region, RTK_MODE_SHW, c.o.weak_region_len_factor, &aid, &aend);
+            if (rtk_failed(s) || aid == -1) break;
+            {
+                const uint32_t next_pos = p1 + static_cast<uint32_t>(aend) + k;
+                while (i_w_s < nlw && rtk_an_pos(lvw, lw_lo + i_w_s) < next_pos) ++i_w_s;
+                if (i_w_s >= nlw || static_cast<uint64_t>(rtk_an_pos(lvw, lw_lo + i_w_s)) >= static_cast<uint64_t>(p2) - k || (rtk_an_pos(lvw, lw_lo + i_w_s) - p1) >= max_len_weak_anchors) break;
+            }
+            const uint64_t hb = s.list[5][aid];
+            const uint32_t wpos = rtk_an_pos(lvw, lw_lo + i_w_s);
+            const uint32_t pl = rtk_rec_to_string(c, hb, s.str[0]); if (pl == 0xFFFFFFFFu) break;
+            rtk_app(s, s_corr, &sl_, s.str[0], pl);
+            rtk_app(s, s_corr, &sl_, s_read + p1 + aend + 1, wpos - p1 - static_cast<uint32_t>(aend) - 1);
+            rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(hb), rtk_h_off(hb)), rtk_path_hdr(s, rtk_h_lvl(hb), rtk_h_off(hb))->qlen);
+            rtk_app_fill(s, q_corr, &ql_, q_min, wpos - p1 - static_cast<uint32_t>(aend) - 1);
+            rtk_bm_add_range(res.bm, p1 - first_pos, p1 + static_cast<uint32_t>(aend) + 1 - first_pos);
+            p1 = wpos; um1 = rtk_an_um(lvw, lw_lo + i_w_s);
+            len_weak_region = p2 - p1 + k;
+            s.top[0] = 0; n_partial = 0; // paths of the previous attempt are dead
+            complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, i_w_s, &n_partial);
+        }
+        if (rtk_failed(s)) return;
+        if (complete != ~0ull) {
+            const uint32_t pl = rtk_rec_to_string(c, complete, s.str[0]); if (pl == 0xFFFFFFFFu) return;
+            rtk_app(s, s_corr, &sl_, s.str[0], pl);
+            rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(complete), rtk_h_off(complete)), rtk_path_hdr(s, rtk_h_lvl(complete), rtk_h_off(complete))->qlen);
+            rtk_bm_add_range(res.bm, p1 - first_pos, p2 - first_pos + k);
+        } else if (n_partial != 0) {
+            int aid, aend;
+            rtk_select_best(c, s.list[5], n_partial, s_read + p1, len_weak_region, RTK_MODE_SHW, c.o.weak_region_len_factor, &aid, &aend);
+            if (rtk_failed(s)) return;
+            if (aid == -1) add_uncorrected(p1, len_weak_region, q_min);
+            else {
+                const uint64_t hb = s.list[5][aid];
+                const uint32_t pl = rtk_rec_to_string(c, hb, s.str[0]); if (pl == 0xFFFFFFFFu) return;
+                rtk_app(s, s_corr, &sl_, s.str[0], pl);
+                const uint32_t rest = len_weak_region - static_cast<uint32_t>(aend) - 1;
+                rtk_app(s, s_corr, &sl_, s_read + p1 + aend + 1, rest);
+                rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(hb), rtk_h_off(hb)), rtk_path_hdr(s, rtk_h_lvl(hb), rtk_h_off(hb))->qlen);
+                rtk_app_fill(s, q_corr, &ql_, q_min, rest);
+                rtk_bm_add_range(res.bm, p1 - first_pos, p1 + static_cast<uint32_t>(aend) + 1 - first_pos);
+            }
+        } else if (sl_ != 0) add_uncorrected(p1, len_weak_region, q_min);
+        else { sl_ = 0; ql_ = 0; add_uncorrected(first_pos, len_weak_region, q_min); } // setUncorrected
+    } else {
+        const uint32_t pl = rtk_rec_to_string(c, complete, s.str[0]); if (pl == 0xFFFFFFFFu) return;
+        sl_ = 0; ql_ = 0;
+        rtk_app(s, s_corr, &sl_, s.str[0], pl);
+        rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(complete), rtk_h_off(complete)), rtk_path_hdr(s, rtk_h_lvl(complete), rtk_h_off(complete))->qlen);
+        rtk_bm_add_range(res.bm, 0, len_weak_region);
+    }
+    if (rtk_failed(s)) return;
+    if (rtk_bm_card(res.bm, res.old_len) == res.old_len) { // :718-725 (G20): last k-mer of the WHOLE read vs last k-mer of the corrected region
+        bool same = sl_ >= k && s_len >= k;
+        for (uint32_t i = 0; same && i < k; ++i) same = rtk_bifrost_code(s_read[s_len - k + i]) == rtk_bifrost_code(s_corr[sl_ - k + i]);
+        if (same) res.is_corrected = true;
+    }
+    if (!res.is_corrected) { // :727-747 trim the corrected string to the largest SHW end location of the raw region
+        const MyersResult a = rtk_align(c, s_read + first_pos, p2 - first_pos + k, s_corr, sl_, -1, RTK_MODE_SHW);
+        if (a.dist >= 0) {
+            const uint32_t keep = (a.first == -1) ? 0u : static_cast<uint32_t>(a.last + 1); // endLocations[0] == -1 wraps to SIZE_MAX in the reference
+            if (keep < sl_) sl_ = keep;
+            if (keep < ql_) ql_ = keep;
+        }
+    }
+    res.seq_len = sl_; res.qual_len = ql_;
+}
+
+// ------------------------------------------------------------------------------------------------ generateConsensus (src/Alignment.cpp:309-470)
+struct CigCur { const uint8_t* mv; uint32_t n, idx, qpos, rpos; }; // op-granular cursor over an alignment (moves 0/3 = M, 1 = I, 2 = D)
+RTK_DEV char rtk_mv_op(uint8_t m) { return (m == 1) ? 'I' : (m == 2 ? 'D' : 'M'); }
+RTK_DEV uint32_t rtk_op_len(const CigCur& cc) { uint32_t j = cc.idx; const char op = rtk_mv_op(cc.mv[cc.idx]); while (j < cc.n && rtk_mv_op(cc.mv[j]) == op) ++j; return j - cc.idx; }
+
+RTK_FN void rtk_move_into_cigar(uint32_t start, uint32_t end, CigCur& cc, uint32_t* rs, uint32_t* re, uint32_t* ref_out) { // moveIntoCIGAR (:354-411)
+    uint32_t read_pos_start = cc.qpos, read_pos_end;
+    while (cc.idx != cc.n && cc.rpos < start) {
+        const uint32_t l = rtk_op_len(cc); const char op = rtk_mv_op(cc.mv[cc.idx]);
+        if (op == 'M') { if (cc.rpos + l > start) { read_pos_start = cc.qpos + (start - cc.rpos); break; } cc.qpos += l; cc.rpos += l; }
+        else if (op == 'I') cc.qpos += l; else cc.rpos += l;
+        cc.idx += l; read_pos_start = cc.qpos;
+    }
+    read_pos_end = read_pos_start;
+    while (cc.idx != cc.n && cc.rpos < end) {
+        const uint32_t l = rtk_op_len(cc); const char op = rtk_mv_op(cc.mv[cc.idx]);
+        if (op == 'M') { if (cc.rpos + l > end) { *rs = read_pos_start; *re = cc.qpos + (end - cc.rpos); *ref_out = end; return; } cc.qpos += l; cc.rpos += l; }
+        else if (op == 'I') cc.qpos += l; else cc.rpos += l;
+        cc.idx += l; read_pos_end = cc.qpos;
+    }
+    *rs = read_pos_start; *re = read_pos_end; *ref_out = cc.rpos;
+}
+
+// writes the consensus into out_s/out_q; returns false when the result is "empty" (caller falls back to the raw region)
+RTK_FN bool rtk_generate_consensus(const RCtx& c, const ResCorr* fw, const ResCorr* bw, const char* ref, uint32_t ref_len, double max_norm,
+                                    char* out_s, uint32_t* out_sl, char* out_q, uint32_t* out_ql) {
+    RegionScratch& s = *c.sc;
+    *out_sl = 0; *out_ql = 0;
+    const uint32_t nfw = rtk_bm_card(fw->bm, fw->old_len), nbw = rtk_bm_card(bw->bm, bw->old_len);
+    auto take = [&](const ResCorr* r) { rtk_app(s, out_s, out_sl, r->seq, r->seq_len); rtk_app(s, out_q, out_ql, r->qual, r->qual_len); return true; };
+    if (nbw == 0 && nfw != 0) return take(fw);
+    else if (nfw == 0 && nbw != 0) return take(bw);
+    else if (nfw + nbw == 0) return false;
+    if (nbw > nfw) { const ResCorr* t = fw; fw = bw; bw = t; }
+    // NW path alignments of both corrections against the raw region; the moves are parked in str[3] (fw) and str[4] (bw)
+    const MyersResult afw = rtk_align(c, fw->seq, fw->seq_len, ref, ref_len, -1, RTK_MODE_NW);
+    uint32_t nm_fw = 0, nm_bw = 0;
+    if (fw->seq_len && ref_len) rtk_myers_alignment(s.my, fw->seq, static_cast<int>(fw->seq_len), ref, static_cast<int>(ref_len), afw.dist, true, &nm_fw);
+    if (rtk_failed(s) || nm_fw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
+    rtk_wcopy(s.str[3], s.my.moves, nm_fw);
+    const MyersResult abw = rtk_align(c, bw->seq, bw->seq_len, ref, ref_len, -1, RTK_MODE_NW);
+    if (bw->seq_len && ref_len) rtk_myers_alignment(s.my, bw->seq, static_cast<int>(bw->seq_len), ref, static_cast<int>(ref_len), abw.dist, true, &nm_bw);
+    if (rtk_failed(s) || nm_bw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
+    rtk_wcopy(s.str[4], s.my.moves, nm_bw);
+    const double n_fw = static_cast<double>(afw.dist) / static_cast<double>(fw->seq_len > ref_len ? fw->seq_len : ref_len);
+    const double n_bw = static_cast<double>(abw.dist) / static_cast<double>(bw->seq_len > ref_len ? bw->seq_len : ref_len);
+    if (max_norm > 0.0 && (n_fw > max_norm || n_bw > max_norm)) {
+        if (n_fw > max_norm && n_bw > max_norm) return false;
+        if (n_fw > max_norm) return take(bw);
+        return take(fw);
+    }
+    CigCur cf, cb;
+    cf.mv = reinterpret_cast<const uint8_t*>(s.str[3]); cf.n = nm_fw; cf.idx = 0; cf.qpos = 0; cf.rpos = 0;
+    cb.mv = reinterpret_cast<const uint8_t*>(s.str[4]); cb.n = nm_bw; cb.idx = 0; cb.qpos = 0; cb.rpos = 0;
+    uint32_t i = 0;
+    while (i < ref_len && !rtk_failed(s)) {
+        int64_t len_fw = rtk_rc_len_corrected(*fw, i), len_bw = rtk_rc_len_corrected(*bw, i);
+        if ((len_fw + len_bw) <= 0) {
+            len_fw = rtk_rc_len_uncorrected(*fw, i); len_bw = rtk_rc_len_uncorrected(*bw, i);
+            if (len_fw > len_bw || len_fw <= 0) len_fw = -1; else len_bw = -1;
+        }
+        uint32_t rs, re, rout;
+        if (len_fw >= len_bw) {
+            rtk_move_into_cigar(i, static_cast<uint32_t>(static_cast<int64_t>(i) + len_fw), cf, &rs, &re, &rout);
+            if (re > rs) { rtk_app(s, out_s, out_sl, fw->seq + rs, (rs < fw->seq_len) ? ((re - rs) < (fw->seq_len - rs) ? (re - rs) : (fw->seq_len - rs)) : 0);
+                           rtk_app(s, out_q, out_ql, fw->qual + rs, (rs < fw->qual_len) ? ((re - rs) < (fw->qual_len - rs) ? (re - rs) : (fw->qual_len - rs)) : 0); }
+        } else {
+            rtk_move_into_cigar(i, static_cast<uint32_t>(static_cast<int64_t>(i) + len_bw), cb, &rs, &re, &rout);
+            if (re > rs) { rtk_app(s, out_s, out_sl, bw->seq + rs, (rs < bw->seq_len) ? ((re - rs) < (bw->seq_len - rs) ? (re - rs) : (bw->seq_len - rs)) : 0);
+                           rtk_app(s, out_q, out_ql, bw->qual + rs, (rs < bw->qual_len) ? ((re - rs) < (bw->qual_len - rs) ? (re - rs) : (bw->qual_len - rs)) : 0); }
+        }
+        if (rout == i) { rtk_fail_ovf(s, 11); return false; } // no progress: would loop forever in the reference as well
+        i = rout;
+    }
+    if (max_norm > 0.0 && !rtk_failed(s)) {
+        const MyersResult a = rtk_align(c, out_s, *out_sl, ref, ref_len, -1, RTK_MODE_NW, /*iupac=*/false); // edlibDefaultAlignConfig (:460)
+        const double n = static_cast<double>(a.dist) / static_cast<double>(*out_sl > ref_len ? *out_sl : ref_len);
+        if (n > max_norm) { *out_sl = 0; *out_ql = 0; return take(fw); }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ scratch layout
+RTK_HD uint64_t region_scratch_bytes(const RegionScratchCfg& c) {
+    uint64_t b = scratch_bytes(c.my);
+    b += 10ull * 4 * c.set_cap + 3ull * c.arena_cap + 4ull * (sizeof(UMap) * c.um_cap + c.str_cap) + (5ull + 8ull) * c.str_cap;
+    b += 6ull * 8 * c.list_cap + 5ull * c.memo_cap + 3ull * 8 * c.bm_words + sizeof(RegionScratch) + 1024;
+    return (b + 255) / 256 * 256;
+}
+
+// the RegionScratch header itself lives at the start of the slab so that its mutable fields (arena tops, counters) are per wave
+RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& c) {
+    RegionScratch* s = reinterpret_cast<RegionScratch*>(base);
+    char* p = base + ((sizeof(RegionScratch) + 255) / 256 * 256);
+    RegionScratch t;
+    t.my = scratch_carve(p, c.my); p += scratch_bytes(c.my);
+    for (int i = 0; i < 3; ++i) { t.arena[i] = p; p += c.arena_cap; t.top[i] = 0; }
+    t.arena_cap = c.arena_cap;
+    for (int i = 0; i < 6; ++i) { t.list[i] = reinterpret_cast<uint64_t*>(p); p += 8ull * c.list_cap; }
+    t.list_cap = c.list_cap;
+    for (int i = 0; i < 3; ++i) { t.bm[i] = reinterpret_cast<uint64_t*>(p); p += 8ull * c.bm_words; }
+    t.bm_words = c.bm_words;
+    for (int i = 0; i < 4; ++i) { t.wp[i].ums = reinterpret_cast<UMap*>(p); p += sizeof(UMap) * c.um_cap; t.wp[i].n = 0; t.wp[i].l = 0; t.wp[i].qlen = 0; }
+    t.um_cap = c.um_cap;
+    for (int i = 0; i < 10; ++i) { t.set[i] = reinterpret_cast<uint32_t*>(p); p += 4ull * c.set_cap; }
+    t.set_cap = c.set_cap;
+    t.memo_u = reinterpret_cast<uint32_t*>(p); p += 4ull * c.memo_cap; t.memo_cap = c.memo_cap; t.memo_n = 0;
+    for (int i = 0; i < 4; ++i) { t.wp[i].qual = p; p += c.str_cap; }
+    for (int i = 0; i < 5; ++i) { t.str[i] = p; p += c.str_cap; }
+    for (int i = 0; i < 8; ++i) { t.rbuf[i] = p; p += c.str_cap; }
+    t.str_cap = c.str_cap;
+    t.memo_v = reinterpret_cast<uint8_t*>(p); p += c.memo_cap;
+    t.overflow = t.my.overflow;
+    for (int i = 0; i < 5; ++i) t.cnt[i] = 0;
+    *s = t; // every lane stores the same header
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ region driver (src/Correction.cpp:776-957)
+RTK_FN void rtk_emit_segment(const RCtx& c, RegionDesc* rd, const char* sq, uint32_t sl, const char* ql, uint32_t qll) {
+    unsigned long long off = 0;
+    if (rtk_lane() == 0) off = rtk_atomic_add(c.rb.seg_top, static_cast<unsigned long long>(sl) + qll);
+    off = rtk_shfl(off, 0);
+    if (off + sl + qll > c.rb.seg_cap) { rtk_fail_ovf(*c.sc, 12); return; }
+    rtk_wcopy(c.rb.seg_pool + off, sq, sl);
+    rtk_wcopy(c.rb.seg_pool + off + sl, ql, qll);
+    rd->seg_off = off; rd->seq_len = sl; rd->qual_len = qll;
+}
+
+RTK_FN void rtk_region_program(const RCtx& c, RegionDesc* rd) {
+    RegionScratch& s = *c.sc;
+    const uint32_t r = rd->read, k = static_cast<uint32_t>(c.k);
+    const uint64_t base = c.bv.roff[r];
+    const uint32_t L = static_cast<uint32_t>(c.bv.roff[r + 1] - base);
+    const char* s_fw = c.bv.seq + base; const char* s_bw = c.rb.seq_rc + base;
+    const char q_min = rtk_get_qual(0.0, 0, static_cast<uint64_t>(c.o.max_qual)), q_max = rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual));
+    char* out_s = s.rbuf[4]; char* out_q = s.rbuf[5]; uint32_t osl = 0, oql = 0;
+    Anchors so; so.pos = c.bv.s_pos + base; so.hit = nullptr; so.hits_by_pos = c.bv.hits + base; so.n = c.bv.n_solid[r]; so.L = L; so.rev = 0; so.k = c.k;
+    Anchors we; we.pos = c.bv.wk_pos + c.bv.w_off[r]; we.hit = c.bv.wk_hit + c.bv.w_off[r]; we.hits_by_pos = nullptr; we.n = c.bv.w_cnt[r]; we.L = L; we.rev = 0; we.k = c.k;
+    Anchors so_r = so; so_r.rev = 1; Anchors we_r = we; we_r.rev = 1;
+    ResCorr fw, bw;
+    fw.seq = s.rbuf[0]; fw.qual = s.rbuf[1]; fw.bm = s.bm[0]; bw.seq = s.rbuf[2]; bw.qual = s.rbuf[3]; bw.bm = s.bm[1];
+    if (L + 64 > s.str_cap) { rtk_fail_ovf(s, 7); return; }
+    const uint32_t kind = rd->kind;
+    if (kind == RTK_RG_WHOLE_MAX || kind == RTK_RG_WHOLE_MIN) { // :165-171
+        rtk_app(s, out_s, &osl, s_fw, L); rtk_app_fill(s, out_q, &oql, kind == RTK_RG_WHOLE_MAX ? q_max : q_min, L);
+    } else if (kind == RTK_RG_HEAD) { // :776-797
+        const uint32_t i_solid_rev = so.n - 1;
+        uint32_t i_weak_rev = we.n;
+        while (i_weak_rev > 0 && rtk_an_pos(we_r, i_weak_rev - 1) > rtk_an_pos(so_r, i_solid_rev)) --i_weak_rev;
+        rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_rev, i_weak_rev, nullptr, bw);
+        if (rtk_failed(s)) return;
+        rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
+        rtk_app(s, out_s, &osl, bw.seq, bw.seq_len >= k ? bw.seq_len - k : bw.seq_len); // substr(0, length - k): wraps to "everything" below k
+        rtk_app(s, out_q, &oql, bw.qual, bw.qual_len >= k ? bw.qual_len - k : bw.qual_len);
+    } else if (kind == RTK_RG_GAP) { // :803-935
+        const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
+        const uint32_t pa = so.pos[i], pb = so.pos[i + 1];
+        const UMap ua = rtk_an_um(so, i), ub = rtk_an_um(so, i + 1);
+        uint32_t i_weak = 0; // first weak anchor at or after the left solid anchor (:801), found by binary search
+        { uint32_t lo = 0, hi = we.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (we.pos[mid] < pa) lo = mid + 1; else hi = mid; } i_weak = lo; }
+        bool isUncorrected = false;
+        bool sameUnitig = (ua.unitig == ub.unitig) && (ua.strand == ub.strand);
+        if (sameUnitig && !(c.g.flags[ua.unitig] & RTK_F_SHORT_CYCLE)) { // same-unitig shortcut (:814-858)
+            const uint32_t min_pos = ua.dist < ub.dist ? ua.dist : ub.dist, max_pos = ua.dist < ub.dist ? ub.dist : ua.dist;
+            const uint32_t len_query_km = pb - pa, len_unitig_km = max_pos - min_pos;
+            uint64_t mn, mx; rtk_min_max_len(len_unitig_km, c.o.weak_region_len_factor, &mn, &mx);
+            sameUnitig = sameUnitig && ((ua.strand && (ua.dist < ub.dist)) || (!ua.strand && (ua.dist > ub.dist)));
+            sameUnitig = sameUnitig && (len_query_km >= mn) && (len_query_km <= mx);
+            if (sameUnitig) {
+                UMap sub = ua; sub.dist = min_pos; sub.len = len_unitig_km + 1;
+                const uint32_t sl = rtk_ums_to_string(c, &sub, 1, s.str[0]); if (sl == 0xFFFFFFFFu) return;
+                rtk_app(s, out_s, &osl, s_fw + prev_pos, pa - prev_pos);
+                rtk_app(s, out_s, &osl, s.str[0], sl >= k ? sl - k : sl);
+                rtk_app_fill(s, out_q, &oql, q_max, (pa - prev_pos) + (sl - k));
+            } else isUncorrected = true;
+        } else if (pb >= pa + k) {
+            rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw);
+            if (rtk_failed(s)) return;
+            const uint32_t l_solid = pa - prev_pos;
+            auto emit_minus_k = [&](const char* seq, uint32_t sl, const char* q, uint32_t ql) { // (prefix + x).substr(0, len - k)
+                const uint32_t ts = l_solid + sl, tq = l_solid + ql;
+                const uint32_t ks = ts >= k ? ts - k : ts, kq = tq >= k ? tq - k : tq;
+                rtk_app(s, out_s, &osl, s_fw + prev_pos, ks < l_solid ? ks : l_solid); if (ks > l_solid) rtk_app(s, out_s, &osl, seq, ks - l_solid);
+                rtk_app_fill(s, out_q, &oql, q_max, kq < l_solid ? kq : l_solid); if (kq > l_solid) rtk_app(s, out_q, &oql, q, kq - l_solid);
+            };
+            if (fw.is_corrected) emit_minus_k(fw.seq, fw.seq_len, fw.qual, fw.qual_len);
+            else {
+                const uint32_t i_solid_bw = so.n - i - 2;
+                uint32_t i_weak_bw = we.n - i_weak;
+                while (i_weak_bw > 0 && rtk_an_pos(we_r, i_weak_bw - 1) > rtk_an_pos(so_r, i_solid_bw)) --i_weak_bw;
+                rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_bw, i_weak_bw, &fw, bw);
+                if (rtk_failed(s)) return;
+                rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
+                if (bw.is_corrected) {
+                    // l_solid = (|s_bw| - rev_pos(i_solid_bw + 1) - k) - prev_pos == pa - prev_pos
+                    emit_minus_k(bw.seq, bw.seq_len, bw.qual, bw.qual_len);
+                } else {
+                    const uint32_t ref_len = pb - pa + k;
+                    uint32_t csl = 0, cql = 0;
+                    const bool ok = rtk_generate_consensus(c, &fw, &bw, s_fw + pa, ref_len, c.o.weak_region_len_factor, s.rbuf[6], &csl, s.rbuf[7], &cql);
+                    if (rtk_failed(s)) return;
+                    if (!ok || csl == 0) { // raw region, k solid qualities then minimum quality (:898-904)
+                        csl = 0; cql = 0;
+                        rtk_app(s, s.rbuf[6], &csl, s_fw + pa, ref_len);
+                        rtk_app_fill(s, s.rbuf[7], &cql, q_max, k); rtk_app_fill(s, s.rbuf[7], &cql, q_min, pb - pa);
+                    }
+                    emit_minus_k(s.rbuf[6], csl, s.rbuf[7], cql);
+                }
+            }
+        } else isUncorrected = true;
+        if (isUncorrected) { // :920-932
+            rtk_app(s, out_s, &osl, s_fw + prev_pos, pb - prev_pos);
+            rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos);
+            if (pb < pa + k) rtk_app_fill(s, out_q, &oql, q_max, pb - pa);
+            else { rtk_app_fill(s, out_q, &oql, q_max, k); rtk_app_fill(s, out_q, &oql, q_min, pb - pa - k); }
+        }
+    } else if (kind == RTK_RG_TAIL) { // :940-950
+        const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
+        const uint32_t pa = so.pos[i];
+        uint32_t i_weak = 0;
+        { uint32_t lo = 0, hi = we.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (we.pos[mid] < pa) lo = mid + 1; else hi = mid; } i_weak = lo; }
+        rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw);
+        if (rtk_failed(s)) return;
+        const uint32_t l_solid = pa - prev_pos;
+        rtk_app(s, out_s, &osl, s_fw + prev_pos, l_solid); rtk_app(s, out_s, &osl, fw.seq, fw.seq_len);
+        rtk_app_fill(s, out_q, &oql, q_max, l_solid); rtk_app(s, out_q, &oql, fw.qual, fw.qual_len);
+    } else { // RTK_RG_TAIL_COPY (:951-955)
+        const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
+        const uint32_t pa = so.pos[i];
+        rtk_app(s, out_s, &osl, s_fw + prev_pos, L - prev_pos);
+        rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos + k); rtk_app_fill(s, out_q, &oql, q_min, L - pa - k);
+    }
+    if (rtk_failed(s)) return;
+    rtk_emit_segment(c, rd, out_s, osl, out_q, oql);
+}
+
+// ------------------------------------------------------------------------------------------------ region enumeration (one wave per read)
+RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const RegionBatch& rb, uint32_t r) {
+    const uint32_t k = static_cast<uint32_t>(g.k);
+    const uint64_t base = bv.roff[r];
+    const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
+    const uint32_t* sp = bv.s_pos + base; const uint32_t ns = bv.n_solid[r];
+    // reverse complement of the read (used by the head and backward corrections, src/Correction.cpp:175)
+    for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < L; i += RTK_WAVE) rb.seq_rc[base + i] = rtk_comp(bv.seq[base + (L - 1 - i)]);
+    uint32_t n_gaps = 0;
+    const bool whole = (L <= k) || ns == 0 || (ns == L - k + 1);
+    if (!whole) for (uint32_t c0 = 0; c0 + 1 < ns; c0 += RTK_WAVE) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); n_gaps += static_cast<uint32_t>(rtk_popc(rtk_ballot(i + 1 < ns && sp[i] != sp[i + 1] - 1))); }
+    const uint32_t total = whole ? 1u : ((sp[0] != 0 ? 1u : 0u) + n_gaps + 1u);
+    unsigned long long first = 0;
+    if (rtk_lane() == 0) first = rtk_atomic_add(rb.n_regions, static_cast<unsigned long long>(total));
+    first = rtk_shfl(first, 0);
+    rb.r_first[r] = first; rb.r_count[r] = total;
+    if (first + total > rb.regions_cap) return; // host notices n_regions > cap and retries with a bigger list
+    RegionDesc* out = rb.regions + first;
+    uint32_t w = 0;
+    auto put = [&](uint32_t kind, uint32_t i_solid, uint32_t prev_pos) {
+        RegionDesc d; d.read = r; d.kind = kind; d.i_solid = i_solid; d.prev_pos = prev_pos; d.seg_off = 0; d.seq_len = 0; d.qual_len = 0; d.status = 0; d.pad = 0;
+        out[w++] = d;
+    };
+    if (whole) { put((L > k && ns != 0 && ns == L - k + 1) ? RTK_RG_WHOLE_MAX : RTK_RG_WHOLE_MIN, 0, 0); rtk_sync(); return; }
+    if (sp[0] != 0) put(RTK_RG_HEAD, 0, 0);
+    uint32_t prev_pos = sp[0];
+    for (uint32_t c0 = 0; c0 + 1 < ns; c0 += 64) {
+        uint64_t bal;
+#ifdef RTK_SIM
+        bal = 0; for (uint32_t j = 0; j < 64 && c0 + j + 1 < ns; ++j) if (sp[c0 + j] != sp[c0 + j + 1] - 1) bal |= 1ull << j;
+#else
+        { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); bal = rtk_ballot(i + 1 < ns && sp[i] != sp[i + 1] - 1); }
+#endif
+        while (bal) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u; bal &= bal - 1ull; put(RTK_RG_GAP, i, prev_pos); prev_pos = sp[i + 1]; }
+    }
+    put(sp[ns - 1] < L - k ? RTK_RG_TAIL : RTK_RG_TAIL_COPY, ns - 1, prev_pos);
+    rtk_sync();
+}
+
+// ------------------------------------------------------------------------------------------------ stitch (one wave per read)
+RTK_FN void rtk_stitch_read(const BatchView& bv, const RegionBatch& rb, uint32_t r) {
+    const RegionDesc* rg = rb.regions + rb.r_first[r]; const uint32_t n = rb.r_count[r];
+    uint64_t ts = 0, tq = 0;
+    for (uint32_t i = 0; i < n; ++i) { ts += rg[i].seq_len; tq += rg[i].qual_len; }
+    unsigned long long off = 0;
+    if (rtk_lane() == 0) off = rtk_atomic_add(rb.out_top, static_cast<unsigned long long>(ts + tq));
+    off = rtk_shfl(off, 0);
+    rb.out_off[r] = off; rb.out_seq_len[r] = static_cast<uint32_t>(ts); rb.out_qual_len[r] = static_cast<uint32_t>(tq);
+    if (off + ts + tq > rb.out_cap) return;
+    uint64_t ws = off, wq = off + ts;
+    for (uint32_t i = 0; i < n; ++i) {
+        rtk_wcopy(rb.out_pool + ws, rb.seg_pool + rg[i].seg_off, rg[i].seq_len); ws += rg[i].seq_len;
+        rtk_wcopy(rb.out_pool + wq, rb.seg_pool + rg[i].seg_off + rg[i].seq_len, rg[i].qual_len); wq += rg[i].qual_len;
+    }
+    (void)bv;
+}
+
 #endif

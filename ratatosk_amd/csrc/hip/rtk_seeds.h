@@ -96,7 +96,7 @@ RTK_DEV bool rtk_is_branching(const GraphView& g, uint32_t u) { return (g.flags[
 
 
 // min(|colours(u) & set|, cap)  (getNumberSharedPairID(SharedPairID, PairID), src/Common.cpp:73-83)
-RTK_DEV uint32_t rtk_shared_with_set(const GraphView& g, uint32_t u, const uint32_t* set, uint32_t n, uint32_t cap) {
+RTK_FN uint32_t rtk_shared_with_set(const GraphView& g, uint32_t u, const uint32_t* set, uint32_t n, uint32_t cap) {
     uint32_t shared = 0;
     const int32_t gi = g.gid[u];
     if (gi >= 0) shared = rtk_set_inter_count(g.col + g.goff[gi], static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]), set, n, cap);
@@ -106,7 +106,7 @@ RTK_DEV uint32_t rtk_shared_with_set(const GraphView& g, uint32_t u, const uint3
 
 // min(|colours(u) & colours(v)|, cap)  (getNumberSharedPairID(SharedPairID, SharedPairID), src/Common.cpp:51-71);
 // global and local parts of one unitig are disjoint, so the four partial intersections add up
-RTK_DEV uint32_t rtk_shared_unitigs(const GraphView& g, uint32_t u, uint32_t v, uint32_t cap) {
+RTK_FN uint32_t rtk_shared_unitigs(const GraphView& g, uint32_t u, uint32_t v, uint32_t cap) {
     const int32_t gu = g.gid[u], gv = g.gid[v];
     const uint32_t* lv = g.col + g.loff[v]; const uint32_t nlv = static_cast<uint32_t>(g.loff[v + 1] - g.loff[v]);
     if (gu >= 0 && gu == gv) {
@@ -121,7 +121,7 @@ RTK_DEV uint32_t rtk_shared_unitigs(const GraphView& g, uint32_t u, uint32_t v, 
 }
 
 // colours(u) = global | local, merged into the running union held in sc.set[cur]; returns new size (0xFFFFFFFF on overflow)
-RTK_DEV uint32_t rtk_union_unitig(const GraphView& g, const SeedScratch& sc, int& cur, uint32_t n_cur, uint32_t u) {
+RTK_FN uint32_t rtk_union_unitig(const GraphView& g, const SeedScratch& sc, int& cur, uint32_t n_cur, uint32_t u) {
     const int32_t gi = g.gid[u];
     if (gi >= 0) {
         const uint32_t ng = static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]);
@@ -139,7 +139,7 @@ RTK_DEV uint32_t rtk_union_unitig(const GraphView& g, const SeedScratch& sc, int
 }
 
 // ---------------------------------------------------------------------------------------------- mask (src/Graph.cpp:102-191)
-RTK_DEV void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
+RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
     const uint64_t base = bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
     const uint32_t k = static_cast<uint32_t>(g.k);
@@ -210,7 +210,7 @@ RTK_DEV void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchVie
 // One tile = 64 consecutive base positions; every candidate window of the tile is expanded by the whole wave into its
 // 93 substitution + 124 "insertion" + 29 "deletion" variants (one variant per lane per round), each probed in the k-mer table.
 #define RTK_N_VARIANTS 246
-RTK_DEV void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile) {
+RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile) {
     const int k = g.k;
     const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
 #ifdef RTK_SIM
@@ -321,7 +321,7 @@ RTK_DEV void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t 
 RTK_DEV bool rtk_char_eq_base(char c, uint32_t b) { return rtk_cls(static_cast<unsigned char>(c)) == static_cast<int>(b); }
 
 // classification of one weak hit (src/Alignment.cpp:1049-1072): returns key or 0 when the hit is dropped
-RTK_DEV uint64_t rtk_weak_key(const char* ref, uint32_t pos, uint64_t code, int k) {
+RTK_FN uint64_t rtk_weak_key(const char* ref, uint32_t pos, uint64_t code, int k) {
     auto qb = [&](int i) -> uint32_t { return static_cast<uint32_t>((code >> (2 * (k - 1 - i))) & 3ull); };
     int l = 0;
     while (l < k && rtk_char_eq_base(ref[pos + l], qb(l))) ++l;
@@ -334,7 +334,7 @@ RTK_DEV uint64_t rtk_weak_key(const char* ref, uint32_t pos, uint64_t code, int 
     return (static_cast<uint64_t>(pos + static_cast<uint32_t>(l)) << 16) | (static_cast<uint64_t>(mis) << 8) | static_cast<uint64_t>(type_var);
 }
 
-RTK_DEV void rtk_finalize_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
+RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
     const uint64_t base = bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
     const uint32_t k = static_cast<uint32_t>(g.k);

@@ -19,7 +19,7 @@
 #ifdef RTK_SIM
 
 #define RTK_DEV inline
-#define RTK_DEVNOINL
+#define RTK_FN inline
 #define RTK_WAVE 1
 inline int rtk_lane() { return 0; }
 inline uint64_t rtk_ballot(bool p) { return p ? 1ull : 0ull; }
@@ -35,7 +35,7 @@ template <class T> inline T rtk_atomic_add(T* p, T v) { return __atomic_fetch_ad
 #include <hip/hip_runtime.h>
 
 #define RTK_DEV __device__ __forceinline__
-#define RTK_DEVNOINL __device__ __noinline__
+#define RTK_FN __device__ __noinline__ // large device functions are real calls: keeps hipcc compile time and code size bounded
 #define RTK_WAVE 64
 __device__ __forceinline__ int rtk_lane() { return static_cast<int>(threadIdx.x) & 63; }
 __device__ __forceinline__ uint64_t rtk_ballot(bool p) { return __ballot(p ? 1 : 0); }
@@ -74,13 +74,13 @@ RTK_DEV int rtk_wave_excl_scan(int v, int* total) { // exclusive prefix sum acro
 }
 
 // bulk copy / fill (lane-strided); publishes
-RTK_DEV void rtk_wcopy(void* dst, const void* src, uint64_t n) {
+RTK_FN void rtk_wcopy(void* dst, const void* src, uint64_t n) {
     char* d = static_cast<char*>(dst); const char* s = static_cast<const char*>(src);
     for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = s[i];
     rtk_sync();
 }
 
-RTK_DEV void rtk_wfill(void* dst, int c, uint64_t n) {
+RTK_FN void rtk_wfill(void* dst, int c, uint64_t n) {
     char* d = static_cast<char*>(dst);
     for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = static_cast<char>(c);
     rtk_sync();

@@ -1,0 +1,36 @@
+"""Whole per-read correction (seeds -> regions -> stitch) of the device programs, executed by the host simulator,
+against the oracle: corrected sequence AND quality strings must be byte-identical for every read."""
+from conftest import SIM_LIB
+from oracle import oracle_py as op
+from ratatosk_amd import api
+
+
+def _check(prefix, n, lib_path, extra_reads=()):
+    fa, rt = prefix + ".index.k31.fasta.gz", prefix + ".index.k31.rtsk"
+    og, pg = op.Graph(fa, rt, 31), api.Graph(fa, rt, 31, device=0, lib_path=lib_path)
+    reads = op.read_fastq(prefix + ".lr.fq")[:n]
+    seqs = [r[1] for r in reads] + list(extra_reads)
+    quals = [r[2] for r in reads] + ["I" * len(s) for s in extra_reads]
+    b = api.Batch(pg, seqs, quals)
+    b.run()
+    got = b.fetch()
+    st = b.stats()
+    want, cnt = og.correct_batch(seqs, quals, threads=4)
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        assert g_[0] == w_[0], "sequence of read %d differs" % i
+        assert g_[1] == w_[1], "quality of read %d differs" % i
+    assert st["n_expand"] == cnt["n_expand"] and st["n_colour_elem"] == cnt["n_colour_elem"]
+    return st, got, seqs
+
+
+def test_sim_correct_branching(ds_small):
+    s0 = op.read_fastq(ds_small + ".lr.fq")[0][1]
+    # edge cases of correctSequence (src/Correction.cpp:165-171): too short, no solid anchor, lower case, N runs
+    extra = ["ACGT" * 5, "A" * 31, "N" * 200, s0[:500].lower(), s0[:400] + "N" * 40 + s0[440:1200]]
+    st, got, seqs = _check(ds_small, 12, SIM_LIB, extra)
+    assert st["n_expand"] > 0 and st["n_regions"] > len(seqs)
+    assert got[len(seqs) - 5][0] == "ACGT" * 5 and set(got[len(seqs) - 5][1]) == {"!"}
+
+
+def test_sim_correct_clean(ds_clean):
+    _check(ds_clean, 8, SIM_LIB)
