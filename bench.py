@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- corrected long-read bases/sec of the MI355X-native `Ratatosk correct -1` hot path.
+
+A "step" is one pass of the whole hot path (exact k-mer scan -> mask -> 1-edit k-mer scan -> anchor filters -> region
+enumeration -> colour-guided BFS/DFS + Myers scoring -> stitch) over one batch of synthetic long reads that is already
+resident in HBM when the timed region starts (rtk_batch_create is outside, rtk_batch_run inside). Workload = BASELINE.json
+configs[1]: 5 Mb random reference, 30x PE 150 bp short reads (0.5 % substitutions), 30x ONT-R9.4-profile long reads,
+k = 31 first pass; the index is built on the CPU by the repo's own index producer, correction runs on the GPU.
+
+N > 1 (torch.distributed.run, one rank per GPU, RCCL): rank 0 loads the flat graph and broadcasts its buffers once; long
+reads are sharded by batch ticket (rank r takes batches r, r+N, ...), no collective on the data path -> weak scaling.
+
+Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the dominant kernel (algorithmic bytes /
+HIP-event duration measured here) and `cpu_baseline` (the oracle, multithreaded, on a bounded sample; N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ref-len", type=int, default=5_000_000)
+    ap.add_argument("--batch-bases", type=int, default=16_000_000, help="long-read bases per step (per GPU)")
+    ap.add_argument("--cpu-sample-bases", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workdir", default=None)
+    ap.add_argument("--sim", action="store_true", help="CPU-only developer simulator + gloo (tests of the N>1 plumbing); never a benchmark")
+    return ap.parse_args()
+
+
+def make_dataset(workdir, ref_len, lr_bases):
+    """Seeded synthetic inputs + index in the reference's file formats."""
+    bin_dir = os.path.join(ROOT, "ratatosk_amd", "bin")
+    pre = os.path.join(workdir, "c2")
+    lr_cov = max(1.0, float(lr_bases) / ref_len)
+    subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "2", "--ref-len", str(ref_len), "--sr-cov", "30",
+                           "--sr-err", "0.005", "--lr-cov", "%.3f" % lr_cov, "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07"], stderr=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(bin_dir, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre], stderr=subprocess.DEVNULL)
+    return pre
+
+
+def read_long_reads(path, max_bases):
+    seqs, quals, tot = [], [], 0
+    with open(path) as f:
+        while tot < max_bases:
+            h = f.readline()
+            if not h:
+                break
+            s = f.readline().rstrip("\n"); f.readline(); q = f.readline().rstrip("\n")
+            seqs.append(s); quals.append(q); tot += len(s)
+    return seqs, quals
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from ratatosk_amd import api, dist as rdist
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    lib_path = os.path.join(ROOT, "tests", "hostsim", "librtk_hostsim.so") if a.sim else None
+    if not a.sim and not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible (the hot path has no CPU fallback)")
+    device = 0 if a.sim else local_rank
+    if not a.sim:
+        torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group(backend="gloo" if a.sim else "nccl")
+    api.load_library(lib_path)
+
+    # ---- inputs (untimed): rank 0 generates, everyone reads its shard of the long reads ----
+    n_batches = a.steps + a.warmup
+    need_bases = a.batch_bases * n_batches * world
+    if rank == 0:
+        workdir = a.workdir or tempfile.mkdtemp(prefix="rtk_bench_")
+        t0 = time.time()
+        pre = make_dataset(workdir, a.ref_len, min(need_bases, 30 * a.ref_len))
+        t_data = time.time() - t0
+    else:
+        pre, t_data = None, 0.0
+    if world > 1:
+        box = [pre]
+        dist.broadcast_object_list(box, src=0)
+        pre = box[0]
+    fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
+    t0 = time.time()
+    graph = rdist.load_graph_replicated(fa, rt, 31, rank, world, device, lib_path=lib_path)
+    t_graph = time.time() - t0
+    info = graph.info()
+    seqs, quals = read_long_reads(pre + ".lr.fq", need_bases)
+    # batches by ticket: consecutive reads until >= batch_bases; rank r owns tickets r, r+N, ...
+    tickets, cur_s, cur_q, cur = [], [], [], 0
+    for s, q in zip(seqs, quals):
+        cur_s.append(s); cur_q.append(q); cur += len(s)
+        if cur >= a.batch_bases:
+            tickets.append((cur_s, cur_q)); cur_s, cur_q, cur = [], [], 0
+    if cur_s and not tickets:
+        tickets.append((cur_s, cur_q))
+    mine = [t for i, t in enumerate(tickets) if i % world == rank]
+    if not mine:
+        mine = [tickets[rank % len(tickets)]]
+    opts = graph.opts()
+    batches = [api.Batch(graph, *mine[i % len(mine)]) for i in range(min(n_batches, len(mine)))]  # resident in HBM before timing
+
+    def sync():
+        if not a.sim:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for w in range(a.warmup):
+        batches[w % len(batches)].run(opts)
+    sync()
+    t0 = time.time()
+    done_bases, stats = 0, []
+    for st in range(a.steps):
+        b = batches[(a.warmup + st) % len(batches)]
+        b.run(opts)
+        done_bases += b.in_bases
+        stats.append(b.stats())
+    sync()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt, float(done_bases)], dtype=torch.float64, device="cpu" if a.sim else "cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_all, bases_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_all, bases_all = dt, float(done_bases)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, from the HIP-event times of this very run ----
+        kern = {"k_lookup_exact": "ms_lookup_exact", "k_mask": "ms_mask", "k_inexact": "ms_lookup_inexact", "k_finalize": "ms_seeds", "k_regions": "ms_correct", "k_stitch": "ms_stitch"}
+        tot = {k_: sum(s[v] for s in stats) for k_, v in kern.items()}
+        dom = max(tot, key=tot.get)
+        n_l = max(1, len(stats))
+        avg_ms = tot[dom] / n_l
+        S = lambda key: sum(s[key] for s in stats) / n_l  # per-launch averages
+        # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md): 16-byte table slot per probe, 40 B per expanded unitig
+        # (8 neighbour slots + flag word), 4 B per colour id streamed, 0.25 B per path base materialised, 4 B per read base in/out.
+        alg = {
+            "k_lookup_exact": 16.0 * S("n_probes_exact") + 1.0 * S("in_bases") + 8.0 * S("in_bases"),
+            "k_inexact": 16.0 * S("n_probes_inexact") + 1.0 * S("in_bases") + 16.0 * S("n_hits_inexact"),
+            "k_regions": 40.0 * S("n_expand") + 4.0 * S("n_colour_elem") + 0.25 * S("n_path_base") + 4.0 * S("in_bases"),
+            "k_mask": 9.0 * S("in_bases"), "k_finalize": 12.0 * S("in_bases") + 16.0 * S("n_hits_inexact"), "k_stitch": 4.0 * S("out_bases"),
+        }
+        achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": None, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
+                    "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()}}
+        whole_alg = (16.0 * (S("n_probes_exact") + S("n_probes_inexact")) + 40.0 * S("n_expand") + 4.0 * S("n_colour_elem") + 0.25 * S("n_path_base") + 4.0 * S("in_bases")) / max(1.0, S("in_bases"))
+        out = {
+            "metric": "corrected long-read bases/sec", "value": bases_all / dt_all if dt_all > 0 else 0.0, "unit": "bases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt_all / max(1, a.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: k=31 first-pass correct, %.1f Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU" % (a.ref_len / 1e6, a.batch_bases),
+                       "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated" % world,
+                       "alg_bytes_per_base": round(whole_alg, 1), "setup_s": {"data+index": round(t_data, 1), "graph_load+upload": round(t_graph, 1)}},
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            # ---- CPU baseline: the oracle (restatement of the reference path) on a bounded sample of the same workload ----
+            from oracle import oracle_py as op
+            og = op.Graph(fa, rt, 31)
+            ss, qq, tot_b = [], [], 0
+            for s, q in zip(*mine[0]):
+                ss.append(s); qq.append(q); tot_b += len(s)
+                if tot_b >= a.cpu_sample_bases:
+                    break
+            cores = os.cpu_count() or 1
+            t1 = time.time()
+            want, _ = og.correct_batch(ss, qq, threads=cores)
+            dt_cpu = time.time() - t1
+            # parity spot check on the same sample (the oracle is the checker here, not the thing measured above)
+            chk = api.Batch(graph, ss, qq); chk.run(opts); got = chk.fetch(); chk.close()
+            out["cpu_baseline"] = {"value": tot_b / dt_cpu, "unit": "bases/s", "cores": cores, "kind": "port",
+                                   "sample": "%d reads / %d bases of step 0, oracle (C++ restatement) with %d threads" % (len(ss), tot_b, cores),
+                                   "parity_on_sample": got == want}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

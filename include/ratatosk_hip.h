@@ -77,6 +77,9 @@ int rtk_graph_n_buffers(const rtk_graph* g);
 int rtk_graph_buffer(rtk_graph* g, int idx, void** dev_ptr, uint64_t* bytes);
 int rtk_graph_alloc_buffers(rtk_graph* g, int device, const uint64_t* bytes, int n, const rtk_graph_info* info);
 int rtk_graph_adopt_device(rtk_graph* g);
+/* Same with caller-owned HBM buffers (e.g. torch tensors that torch.distributed broadcasts into); never freed by the library. */
+int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* dev_ptrs, const uint64_t* bytes, int n, const rtk_graph_info* info);
+int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n);
 
 int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info);
 void rtk_graph_free(rtk_graph* g);

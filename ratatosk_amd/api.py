@@ -57,6 +57,7 @@ def load_library(path=None):
     L.rtk_graph_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.rtk_graph_alloc_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(RtkGraphInfo)]
     L.rtk_graph_adopt_device.argtypes = [C.c_void_p]
+    L.rtk_graph_buffer_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
     L.rtk_graph_get_info.argtypes = [C.c_void_p, C.POINTER(RtkGraphInfo)]
     L.rtk_graph_free.argtypes = [C.c_void_p]
     L.rtk_opts_default.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]

@@ -36,7 +36,7 @@ extern "C" void rtk_free(void* p) { free(p); }
 // ------------------------------------------------------------------------------------------------ graph object
 struct rtk_graph {
     rtk::FlatGraph host;
-    bool has_host = false, on_device = false, unsupported_annotations = false;
+    bool has_host = false, on_device = false, unsupported_annotations = false, owns_buffers = true;
     int device = -1;
     void* dbuf[rtk::RTK_N_BUFS];
     uint64_t dbytes[rtk::RTK_N_BUFS];
@@ -96,6 +96,25 @@ extern "C" int rtk_graph_alloc_buffers(rtk_graph* g, int device, const uint64_t*
     return RTK_OK;
 }
 
+extern "C" int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* dev_ptrs, const uint64_t* bytes, int n, const rtk_graph_info* info) {
+    if (!g || !dev_ptrs || !bytes || !info || n != rtk::RTK_N_BUFS) return rtk_fail(RTK_ERR_ARG, "rtk_graph_attach_buffers: bad argument");
+    int rc = require_device(device); if (rc) return rc;
+    for (int i = 0; i < n; ++i) { if (g->dbuf[i] && g->owns_buffers) rtk_dfree(g->dbuf[i]); g->dbuf[i] = dev_ptrs[i]; g->dbytes[i] = bytes[i]; }
+    g->owns_buffers = false;
+    const bool had_host = g->has_host;
+    if (!had_host) g->info = *info;
+    g->info.device = device; g->device = device;
+    return RTK_OK;
+}
+
+extern "C" int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n) {
+    if (!g || !bytes || n != rtk::RTK_N_BUFS || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer_bytes: needs a loaded graph");
+    const rtk::FlatGraph& h = g->host;
+    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size() };
+    for (int i = 0; i < n; ++i) bytes[i] = b[i];
+    return RTK_OK;
+}
+
 extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
     if (!g || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: graph has no host image");
     int rc = require_device(device); if (rc) return rc;
@@ -128,7 +147,7 @@ extern "C" int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info) { if
 
 extern "C" void rtk_graph_free(rtk_graph* g) {
     if (!g) return;
-    for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
+    if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
     delete g;
 }
 

@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing: one process per GPU; the read-only flat graph is loaded once by rank 0 and replicated with one
+`torch.distributed.broadcast` (RCCL over xGMI) per flat buffer; long reads are sharded by batch ticket with no collective
+on the data path. This is the MI355X counterpart of the reference's only distribution scheme -- a replicated index and
+chunked long reads (reference: Ratatosk_nf/Ratatosk.nf:277-299; threads + tickets inside a node, src/Ratatosk.cpp:727-906).
+"""
+import ctypes as C
+
+from . import api
+
+
+def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None):
+    """Returns an api.Graph whose HBM image is valid on `device` of every rank."""
+    if world <= 1:
+        return api.Graph(fasta_gz, rtsk, k, device=device, lib_path=lib_path)
+    import torch
+    import torch.distributed as dist
+    L = api.load_library(lib_path)
+    sim = lib_path is not None
+    n_buf = L.rtk_graph_n_buffers(None)
+    sizes = (C.c_uint64 * n_buf)()
+    info = api.RtkGraphInfo()
+    g = api.Graph.__new__(api.Graph)
+    g.L, g.k, g.h = L, k, C.c_void_p()
+    if rank == 0:
+        g._check(L.rtk_graph_load(api._b(fasta_gz), api._b(rtsk), k, 1, C.byref(g.h)))
+        g._check(L.rtk_graph_buffer_bytes(g.h, sizes, n_buf))
+        g._check(L.rtk_graph_get_info(g.h, C.byref(info)))
+        meta = [[int(sizes[i]) for i in range(n_buf)], bytes(info)]
+    else:
+        g._check(L.rtk_graph_shell(k, C.byref(g.h)))
+        meta = [None, None]
+    dist.broadcast_object_list(meta, src=0)
+    for i in range(n_buf):
+        sizes[i] = meta[0][i]
+    C.memmove(C.byref(info), meta[1], C.sizeof(info))
+    dev = torch.device("cpu") if sim else torch.device("cuda", device)
+    tensors = [torch.empty(max(8, int(sizes[i])), dtype=torch.uint8, device=dev) for i in range(n_buf)]
+    ptrs = (C.c_void_p * n_buf)(*[t.data_ptr() for t in tensors])
+    L.rtk_graph_attach_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.POINTER(api.RtkGraphInfo)]
+    g._check(L.rtk_graph_attach_buffers(g.h, device, ptrs, sizes, n_buf, C.byref(info)))
+    if rank == 0:
+        g._check(L.rtk_graph_upload(g.h, device))  # host image -> the attached buffers
+    for t in tensors:  # one large contiguous broadcast per buffer; ring/tree over xGMI is per-link bound
+        dist.broadcast(t, src=0)
+    if not sim:
+        torch.cuda.synchronize()
+    if rank != 0:
+        g._check(L.rtk_graph_adopt_device(g.h))
+    g._tensors = tensors  # keep the HBM buffers alive as long as the graph
+    return g
+
+
+def shard_tickets(n_tickets, rank, world):
+    """Batch tickets owned by `rank` (round-robin, like the reference's ticket dispenser: src/Ratatosk.cpp:755)."""
+    return [i for i in range(n_tickets) if i % world == rank]
