@@ -42,6 +42,7 @@ struct rtk_graph {
     uint64_t dbytes[rtk::RTK_N_BUFS];
     GraphView dview;
     rtk_graph_info info;
+    void* scratch = nullptr; uint64_t scratch_bytes_ = 0; // per-wave work areas, kept across batches (one batch runs at a time per graph)
     rtk_graph() { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { dbuf[i] = nullptr; dbytes[i] = 0; } memset(&dview, 0, sizeof(dview)); memset(&info, 0, sizeof(info)); }
 };
 
@@ -148,6 +149,7 @@ extern "C" int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info) { if
 extern "C" void rtk_graph_free(rtk_graph* g) {
     if (!g) return;
     if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
+    rtk_dfree(g->scratch);
     delete g;
 }
 
@@ -160,6 +162,11 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
 }
 
 // ------------------------------------------------------------------------------------------------ per-wave scratch
+static char* graph_scratch(rtk_graph* g, uint64_t bytes) { // grows monotonically; hipMalloc/hipFree of tens of GB per batch would dominate a step
+    if (bytes > g->scratch_bytes_) { rtk_dfree(g->scratch); g->scratch = nullptr; g->scratch_bytes_ = 0; g->scratch = rtk_dmalloc(bytes); g->scratch_bytes_ = bytes; }
+    return static_cast<char*>(g->scratch);
+}
+
 struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };
 
 RTK_HD uint64_t scratch_bytes(const ScratchCfg& c) {

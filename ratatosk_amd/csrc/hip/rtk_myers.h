@@ -148,27 +148,45 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& 
         const bool is_last_word = has_word && (w == W - 1);
         const bool is_block_tail = (lane == nw - 1);
         const int bit = is_last_word ? last_bit : 63;
+        // this lane's profile words for A, C, G, T stay in registers for the whole pass; other classes are fetched on demand
+        uint64_t eqA = 0, eqC = 0, eqG = 0, eqT = 0;
+        if (has_word) { eqA = sc.peq[w]; eqC = sc.peq[static_cast<uint64_t>(W) + w]; eqG = sc.peq[2ull * W + w]; eqT = sc.peq[3ull * W + w]; }
         uint64_t Pv = ~0ull, Mv = 0ull;
-        int hout_prev = 0;
+        int hout_prev = 0; unsigned tc_prev = 0;
         int score = m;
         const int steps = n + nw - 1;
-        for (int s = 0; s < steps; ++s) {
-            const int col = s - lane;
-            const bool active = has_word && col >= 0 && col < n;
-            int lane0_in = top_h;
-            if (w0 != 0 && lane == 0 && s < n) lane0_in = static_cast<int>(sc.carry[s]);
-            const int hin = rtk_shfl_up1(hout_prev, lane0_in);
-            if (active) {
-                const unsigned char tc = rtk_seq_at(t, col);
-                const uint64_t Eq = rtk_myers_eq_word(sc, q, W, w, tc);
-                uint64_t Ph, Mh;
-                const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
-                if (store) { uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
-                if (is_block_tail) {
-                    if (w0 + nw < W) sc.carry[col] = static_cast<int8_t>(hout);
-                    else { score += hout; sc.colscore[col] = score; }
+        // The target character of a column enters at lane 0 and then rides down the lanes together with the horizontal
+        // delta (one packed __shfl_up per step): no memory access on the step-to-step dependency chain.
+        for (int c0 = 0; c0 < steps; c0 += 64) {
+            const int cj = c0 + lane;
+            const int my_t = (cj < n) ? static_cast<int>(rtk_seq_at(t, cj)) : 0;          // lane j holds t[c0 + j] ...
+            const int my_c = (w0 != 0 && cj < n) ? static_cast<int>(sc.carry[cj]) : top_h; // ... and the delta entering row block w0
+            const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
+            for (int j = 0; j < lim; ++j) {
+                const int s = c0 + j;
+                const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
+                const int in_c = __builtin_amdgcn_readlane(my_c, j);
+                const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+                unsigned got = __shfl_up(mine, 1, 64);
+                if (lane == 0) got = static_cast<unsigned>(in_c + 1) | (in_t << 8);
+                const int hin = static_cast<int>(got & 0xFFu) - 1;
+                const unsigned tc = got >> 8;
+                const int col = s - lane;
+                const bool active = has_word && col >= 0 && col < n;
+                if (active) {
+                    uint64_t Eq;
+                    if (tc == 'A') Eq = eqA; else if (tc == 'C') Eq = eqC; else if (tc == 'G') Eq = eqG; else if (tc == 'T') Eq = eqT;
+                    else Eq = rtk_myers_eq_word(sc, q, W, w, static_cast<unsigned char>(tc));
+                    uint64_t Ph, Mh;
+                    const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
+                    if (store) { uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
+                    if (is_block_tail) {
+                        if (w0 + nw < W) sc.carry[col] = static_cast<int8_t>(hout);
+                        else { score += hout; sc.colscore[col] = score; }
+                    }
+                    hout_prev = hout;
                 }
-                hout_prev = hout;
+                tc_prev = tc;
             }
         }
         if (fin_pv && has_word) { fin_pv[w] = Pv; fin_mv[w] = Mv; }

@@ -44,6 +44,7 @@ struct RegionBatch {
     char* seq_rc;                           // reverse complement of every read (same offsets as seq)
     char* seg_pool; uint64_t seg_cap; unsigned long long* seg_top;
     unsigned long long* next_region;        // dequeue head of the persistent region kernel
+    unsigned long long* n_overflow;         // regions that ran out of scratch in the last launch
     char* out_pool; uint64_t out_cap; unsigned long long* out_top;
     uint64_t* out_off; uint32_t* out_seq_len; uint32_t* out_qual_len; // per read
 };
