@@ -106,9 +106,12 @@ class Graph:
         self.n_unitigs, self.n_kmers, self.max_km_cov_top = a.value, b.value, c.value
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_graph_free(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().orc_graph_free(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     def opts(self, **kw):
         o = default_opts(max(self.max_km_cov_top, 128))  # src/Ratatosk.cpp:625

@@ -1,0 +1,42 @@
+"""`Ratatosk correct -1` CLI surface of the build (reference: src/Ratatosk.cpp:145-301,1029-1037): option handling without a GPU,
+and on the GPU the written OUT.2.fastq must equal the oracle's records, in input order."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import BIN
+from oracle import oracle_py as op
+
+EXE = os.path.join(BIN, "Ratatosk")
+
+
+def test_cli_usage_and_scope_messages():
+    assert subprocess.run([EXE, "--help"], capture_output=True).returncode == 0
+    r = subprocess.run([EXE, "index", "-s", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "not in scope" in r.stderr
+    r = subprocess.run([EXE, "correct", "-2", "-g", "a", "-d", "b", "-l", "c", "-o", "d"], capture_output=True, text=True)
+    assert r.returncode == 1 and "first pass" in r.stderr
+
+
+def test_cli_fails_loudly_without_gpu(ds_small, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([EXE, "correct", "-1", "-g", ds_small + ".index.k31.fasta.gz", "-d", ds_small + ".index.k31.rtsk", "-l", ds_small + ".lr.fq",
+                        "-o", str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_correct_matches_oracle(ds_small, tmp_path):
+    fa, rt = ds_small + ".index.k31.fasta.gz", ds_small + ".index.k31.rtsk"
+    out = str(tmp_path / "out")
+    # small batches so that the ticket reorder path is exercised
+    r = subprocess.run([EXE, "correct", "-1", "-v", "-c", "1", "-B", "12000", "-g", fa, "-d", rt, "-l", ds_small + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = op.read_fastq(out + ".2.fastq")
+    reads = op.read_fastq(ds_small + ".lr.fq")
+    want, _ = op.Graph(fa, rt, 31).correct_batch([x[1] for x in reads], [x[2] for x in reads], threads=4)
+    assert [g[0] for g in got] == [x[0] for x in reads]
+    assert [(g[1], g[2]) for g in got] == want
