@@ -59,6 +59,9 @@ typedef struct rtk_stats {
     uint64_t n_windows, n_probes_exact, n_probes_inexact, n_hits_inexact, n_regions, n_region_items, n_arena_overflow;
     uint64_t n_expand, n_colour_elem, n_path_base, n_align, n_align_cells;
     uint64_t in_bases, out_bases;
+    /* wave-cycles (s_memtime ticks summed over all waves) spent by k_regions per phase: colour selection, graph traversal incl.
+     * its alignments, consensus + trimming alignments, everything else; and inside those, Myers passes and set algebra */
+    uint64_t cyc_colour, cyc_paths, cyc_consensus, cyc_total, cyc_myers, cyc_sets /* path record commit+load */, cyc_tostring, cyc_pathqual;
 } rtk_stats;
 
 /* dbg.read(G.fasta.gz) + readGraphData(G.rtsk) (reference: src/Ratatosk.cpp:1087-1089; src/Graph.cpp:722-784).

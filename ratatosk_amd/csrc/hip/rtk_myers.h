@@ -112,13 +112,64 @@ RTK_DEV uint64_t rtk_myers_eq_word(const MyersScratch& sc, const MySeq& q, int W
     return e;
 }
 
+#ifndef RTK_SIM
+// Branch-free anti-diagonal sweep for the common case: query <= 64 words (one row block), target made of A/C/G/T only.
+// Scalar branches are expensive on CDNA (instruction-fetch restart), so everything per step is predicated with
+// v_cndmask; the only branch left is the once-per-64-columns flush of the score buffer.
+template <int STORE>
+__device__ __forceinline__ void rtk_myers_sweep_acgt(int m, int n, int W, int top_h, int last_bit, const char* __restrict__ tp, int trev,
+                                                     uint64_t eqA, uint64_t eqC, uint64_t eqG, uint64_t eqT,
+                                                     int32_t* __restrict__ colscore, uint64_t* __restrict__ tb, uint64_t& Pv_out, uint64_t& Mv_out) {
+    const int lane = rtk_lane();
+    const int w = lane;
+    const bool has_word = lane < W;
+    const int bit = (w == W - 1) ? last_bit : 63;
+    uint64_t Pv = ~0ull, Mv = 0ull;
+    int hout_prev = 0; unsigned tc_prev = 0;
+    int score = m, sbuf = 0;
+    const int steps = n + W - 1;
+    for (int c0 = 0; c0 < steps; c0 += 64) {
+        const int cj = c0 + lane;
+        int my_t = (cj < n) ? static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj])) : 0;
+        asm volatile("" : "+v"(my_t));
+        const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
+        for (int j = 0; j < lim; ++j) {
+            const int s = c0 + j;
+            const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
+            const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+            const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(top_h + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
+            const int hin = static_cast<int>(got & 0xFFu) - 1;
+            const unsigned tc = got >> 8;
+            const unsigned sel = (tc >> 1) & 3u; // 'A' -> 0, 'C' -> 1, 'T' -> 2, 'G' -> 3
+            const uint64_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
+            uint64_t nPv = Pv, nMv = Mv, Ph, Mh;
+            const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
+            const int col = s - lane;
+            const bool active = has_word && col >= 0 && col < n;
+            if (STORE) { if (active) { uint64_t* e = tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
+            Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
+            hout_prev = active ? hout : hout_prev;
+            score += (active && lane == W - 1) ? hout : 0;
+            tc_prev = tc;
+            const int tcol = s - (W - 1);
+            if (tcol >= 0) { // uniform
+                const int sv = __builtin_amdgcn_readlane(score, W - 1);
+                sbuf = (lane == (tcol & 63)) ? sv : sbuf;
+                if ((tcol & 63) == 63 || tcol == n - 1) { const int cc = (tcol & ~63) + lane; if (cc <= tcol) colscore[cc] = sbuf; }
+            }
+        }
+    }
+    Pv_out = Pv; Mv_out = Mv;
+}
+#endif
+
 // Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
 // top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
 RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, int store, uint64_t* fin_pv, uint64_t* fin_mv) {
     const int m = q.n, n = t.n, W = (m + 63) >> 6, last_bit = (m - 1) & 63;
-    rtk_myers_build_peq(sc, q, W, iupac);
 #ifdef RTK_SIM
+    rtk_myers_build_peq(sc, q, W, iupac);
     int score = m;
     // the simulator walks the matrix column by column; per-word state lives in fin arrays or a local buffer
     uint64_t* Pv = fin_pv; uint64_t* Mv = fin_mv;
@@ -141,6 +192,11 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& 
     delete[] heapPv; delete[] heapMv;
 #else
     const int lane = rtk_lane();
+    // local copies: the scratch descriptor lives in private memory and its fields could alias the stores below,
+    // which would force a (slow) reload of every pointer on every step
+    int8_t* __restrict__ const carry = sc.carry; int32_t* __restrict__ const colscore = sc.colscore; uint64_t* __restrict__ const tb = sc.tb;
+    const char* __restrict__ const tp = t.p; const int trev = t.rev;
+    const char* __restrict__ const qp = q.p; const int qrev = q.rev;
     for (int w0 = 0; w0 < W; w0 += 64) {
         const int nw = (W - w0) < 64 ? (W - w0) : 64;
         const int w = w0 + lane;
@@ -150,25 +206,52 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& 
         const int bit = is_last_word ? last_bit : 63;
         // this lane's profile words for A, C, G, T stay in registers for the whole pass; other classes are fetched on demand
         uint64_t eqA = 0, eqC = 0, eqG = 0, eqT = 0;
-        if (has_word) { eqA = sc.peq[w]; eqC = sc.peq[static_cast<uint64_t>(W) + w]; eqG = sc.peq[2ull * W + w]; eqT = sc.peq[3ull * W + w]; }
+        if (has_word) { // built straight from the query characters of this word (no profile table in memory on the device)
+            const int lim = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+            for (int i = 0; i < lim; ++i) {
+                const unsigned char qc = static_cast<unsigned char>(qrev ? qp[m - 1 - (64 * w + i)] : qp[64 * w + i]);
+                const uint32_t bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu; // bases this query character equals
+                eqA |= static_cast<uint64_t>(bm & 1u) << i; eqC |= static_cast<uint64_t>((bm >> 1) & 1u) << i;
+                eqG |= static_cast<uint64_t>((bm >> 2) & 1u) << i; eqT |= static_cast<uint64_t>((bm >> 3) & 1u) << i;
+            }
+        }
         uint64_t Pv = ~0ull, Mv = 0ull;
+        if (W <= 64) { // single row block: is the target plain A/C/G/T? then take the branch-free sweep
+            bool plain = true;
+            for (int c0 = 0; c0 < n && plain; c0 += 64) {
+                const int cj = c0 + lane;
+                bool okc = true;
+                if (cj < n) { const unsigned char ch = static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj]); okc = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+                plain = (rtk_ballot(!okc) == 0ull);
+            }
+            if (plain) {
+                if (store) rtk_myers_sweep_acgt<1>(m, n, W, top_h, last_bit, tp, trev, eqA, eqC, eqG, eqT, colscore, tb, Pv, Mv);
+                else rtk_myers_sweep_acgt<0>(m, n, W, top_h, last_bit, tp, trev, eqA, eqC, eqG, eqT, colscore, tb, Pv, Mv);
+                if (fin_pv && has_word) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
+                rtk_sync();
+                continue;
+            }
+        }
         int hout_prev = 0; unsigned tc_prev = 0;
         int score = m;
         const int steps = n + nw - 1;
         // The target character of a column enters at lane 0 and then rides down the lanes together with the horizontal
         // delta (one packed __shfl_up per step): no memory access on the step-to-step dependency chain.
+        const bool last_block = (w0 + nw >= W);
+        int sbuf = 0;       // last-row scores of up to 64 columns, one per lane (lane = column & 63), flushed with one coalesced store
         for (int c0 = 0; c0 < steps; c0 += 64) {
             const int cj = c0 + lane;
-            const int my_t = (cj < n) ? static_cast<int>(rtk_seq_at(t, cj)) : 0;          // lane j holds t[c0 + j] ...
-            const int my_c = (w0 != 0 && cj < n) ? static_cast<int>(sc.carry[cj]) : top_h; // ... and the delta entering row block w0
+            int my_t = (cj < n) ? static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj])) : 0; // lane j holds t[c0 + j] ...
+            int my_c = (w0 != 0 && cj < n) ? static_cast<int>(carry[cj]) : top_h; // ... and the delta entering row block w0
+            asm volatile("" : "+v"(my_t), "+v"(my_c)); // the loads are complete here, so the step loop below carries no memory wait
             const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
             for (int j = 0; j < lim; ++j) {
                 const int s = c0 + j;
                 const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
                 const int in_c = __builtin_amdgcn_readlane(my_c, j);
                 const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
-                unsigned got = __shfl_up(mine, 1, 64);
-                if (lane == 0) got = static_cast<unsigned>(in_c + 1) | (in_t << 8);
+                // wave_shr:1 (DPP): lane l receives lane l-1's value, lane 0 keeps `old` = the values entering the block
+                const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(in_c + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
                 const int hin = static_cast<int>(got & 0xFFu) - 1;
                 const unsigned tc = got >> 8;
                 const int col = s - lane;
@@ -176,17 +259,25 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& 
                 if (active) {
                     uint64_t Eq;
                     if (tc == 'A') Eq = eqA; else if (tc == 'C') Eq = eqC; else if (tc == 'G') Eq = eqG; else if (tc == 'T') Eq = eqT;
-                    else Eq = rtk_myers_eq_word(sc, q, W, w, static_cast<unsigned char>(tc));
+                    else { // rare: IUPAC code, N or foreign byte in the target -> compare the 64 query characters of this word directly
+                        Eq = 0; const int lim2 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                        for (int i = 0; i < lim2; ++i) Eq |= static_cast<uint64_t>(rtk_chars_equal(static_cast<unsigned char>(qrev ? qp[m - 1 - (64 * w + i)] : qp[64 * w + i]), static_cast<unsigned char>(tc), iupac)) << i;
+                    }
                     uint64_t Ph, Mh;
                     const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
-                    if (store) { uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
-                    if (is_block_tail) {
-                        if (w0 + nw < W) sc.carry[col] = static_cast<int8_t>(hout);
-                        else { score += hout; sc.colscore[col] = score; }
-                    }
+                    if (store) { uint64_t* e = tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
+                    if (is_block_tail) { if (!last_block) carry[col] = static_cast<int8_t>(hout); else score += hout; }
                     hout_prev = hout;
                 }
                 tc_prev = tc;
+                if (last_block) { // park the tail lane's score of column (s - nw + 1) in lane (column & 63); store 64 of them at once
+                    const int tcol = s - (nw - 1);
+                    if (tcol >= 0 && tcol < n) {
+                        const int sv = __builtin_amdgcn_readlane(score, nw - 1);
+                        if (lane == (tcol & 63)) sbuf = sv;
+                        if ((tcol & 63) == 63 || tcol == n - 1) { const int cc = (tcol & ~63) + lane; if (cc <= tcol) colscore[cc] = sbuf; }
+                    }
+                }
             }
         }
         if (fin_pv && has_word) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
@@ -264,11 +355,33 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const My
     uint32_t nt = 0; // moves are produced backwards into moves_tmp, from its end
     uint8_t* tmp = sc.moves_tmp;
     const uint32_t cap = sc.mv_cap;
+#ifndef RTK_SIM
+    // The wave keeps, for the current query word, the four delta words of 64 consecutive columns in registers
+    // (lane l <-> column c_hi - l); a traceback step is then scalar (v_readlane), with one table reload per ~60 moves.
+    const int lane = rtk_lane();
+    int w_cur = -1, c_hi = -1;
+    uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+#define RTK_RL64(v, l) ((static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>((v) >> 32), (l)))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>((v) & 0xFFFFFFFFull), (l))))
+#endif
     while (i > 0 && j > 0) {
         const int r = i - 1, c = j - 1, w = r >> 6, b = r & 63;
+#ifdef RTK_SIM
         const uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(c) * W + w);
-        const int vd = static_cast<int>((e[0] >> b) & 1ull) - static_cast<int>((e[1] >> b) & 1ull);
-        const int hd = static_cast<int>((e[2] >> b) & 1ull) - static_cast<int>((e[3] >> b) & 1ull);
+        const uint64_t a0 = e[0], a1 = e[1], a2 = e[2], a3 = e[3];
+        uint64_t l0 = 0, l1 = 0;
+        if (c > 0) { const uint64_t* el = sc.tb + 4ull * (static_cast<uint64_t>(c - 1) * W + w); l0 = el[0]; l1 = el[1]; }
+#else
+        if (w != w_cur || c > c_hi || c_hi - c > 62) {
+            c_hi = c; w_cur = w;
+            const int col = c - lane;
+            if (col >= 0) { const uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(col) * W + w); e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3]; }
+        }
+        const int li = c_hi - c;
+        const uint64_t a0 = RTK_RL64(e0, li), a1 = RTK_RL64(e1, li), a2 = RTK_RL64(e2, li), a3 = RTK_RL64(e3, li);
+        const uint64_t l0 = RTK_RL64(e0, li + 1), l1 = RTK_RL64(e1, li + 1); // column c-1 (unused when c == 0)
+#endif
+        const int vd = static_cast<int>((a0 >> b) & 1ull) - static_cast<int>((a1 >> b) & 1ull);
+        const int hd = static_cast<int>((a2 >> b) & 1ull) - static_cast<int>((a3 >> b) & 1ull);
         uint8_t mv;
         if (vd == 1) { mv = 1; --i; cur -= 1; }
         else if (hd == 1) { mv = 2; --j; cur -= 1; }
@@ -276,14 +389,15 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const My
             const int left = cur - hd;
             int diag;
             if (c == 0) diag = i - 1;
-            else { const uint64_t* el = sc.tb + 4ull * (static_cast<uint64_t>(c - 1) * W + w); diag = left - (static_cast<int>((el[0] >> b) & 1ull) - static_cast<int>((el[1] >> b) & 1ull)); }
+            else diag = left - (static_cast<int>((l0 >> b) & 1ull) - static_cast<int>((l1 >> b) & 1ull));
             mv = (diag == cur) ? 0 : 3;
             --i; --j; cur = diag;
         }
         ++nt; tmp[cap - nt] = mv;
     }
-    while (i > 0) { ++nt; tmp[cap - nt] = 1; --i; }
-    while (j > 0) { ++nt; tmp[cap - nt] = 2; --j; }
+    // whatever is left is a run of inserts (query only) or deletes (target only)
+    if (i > 0) { rtk_wfill(tmp + (cap - nt - static_cast<uint32_t>(i)), 1, static_cast<uint64_t>(i)); nt += static_cast<uint32_t>(i); i = 0; }
+    if (j > 0) { rtk_wfill(tmp + (cap - nt - static_cast<uint32_t>(j)), 2, static_cast<uint64_t>(j)); nt += static_cast<uint32_t>(j); j = 0; }
     rtk_wcopy(sc.moves + *n_moves, tmp + (cap - nt), nt);
     *n_moves += nt;
 }

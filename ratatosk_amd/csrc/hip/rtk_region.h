@@ -64,7 +64,7 @@ struct RegionScratch {
     uint32_t* memo_u; uint8_t* memo_v; uint32_t memo_cap; uint32_t memo_n;
     uint64_t* bm[3]; uint32_t bm_words;
     uint32_t* overflow;
-    unsigned long long cnt[5]; // expand, colour, pathbase, align, cells
+    unsigned long long cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
 };
 
 struct RCtx { // everything a region program needs
@@ -125,12 +125,14 @@ RTK_DEV uint64_t rtk_h_off(uint64_t h) { return h & 0x3FFFFFFFFFFFFFFFull; }
 RTK_DEV void rtk_wp_clear(WPath& p) { p.n = 0; p.l = 0; p.qlen = 0; }
 
 RTK_FN uint64_t rtk_wp_commit(RegionScratch& s, const WPath& p, int lvl) { // working path -> immutable record
+    const unsigned long long tc0 = rtk_clock();
     const uint64_t off = rtk_arena_alloc(s, lvl, sizeof(PathHdr) + sizeof(UMap) * p.n + p.qlen);
     if (rtk_failed(s)) return 0;
     PathHdr* h = rtk_path_hdr(s, lvl, off);
     h->n = p.n; h->l = p.l; h->qlen = p.qlen; h->pad = 0;
     rtk_wcopy(rtk_path_ums(s, lvl, off), p.ums, sizeof(UMap) * p.n);
     rtk_wcopy(s.arena[lvl] + off + sizeof(PathHdr) + sizeof(UMap) * p.n, p.qual, p.qlen);
+    s.cnt[11] += rtk_clock() - tc0;
     return rtk_mk_handle(lvl, off);
 }
 
@@ -138,9 +140,11 @@ RTK_FN void rtk_wp_load(RegionScratch& s, WPath& p, uint64_t h) {
     const int lvl = rtk_h_lvl(h); const uint64_t off = rtk_h_off(h);
     const PathHdr* hd = rtk_path_hdr(s, lvl, off);
     if (hd->n > s.um_cap || hd->qlen > s.str_cap) { rtk_fail_ovf(s, 4); rtk_wp_clear(p); return; }
+    const unsigned long long tc0 = rtk_clock();
     p.n = hd->n; p.l = hd->l; p.qlen = hd->qlen;
     rtk_wcopy(p.ums, rtk_path_ums(s, lvl, off), sizeof(UMap) * hd->n);
     rtk_wcopy(p.qual, rtk_path_qual(s, lvl, off), hd->qlen);
+    s.cnt[11] += rtk_clock() - tc0;
 }
 
 RTK_DEV uint32_t rtk_rec_n(const RegionScratch& s, uint64_t h) { return rtk_path_hdr(s, rtk_h_lvl(h), rtk_h_off(h))->n; }
@@ -263,6 +267,7 @@ RTK_DEV void rtk_um_decode(const RCtx& c, const UMap& um, char* dst, uint32_t sk
 // Path::toString (Path.hpp:449-485) of `n` mappings into dst; returns length (0xFFFFFFFF on overflow)
 RTK_FN uint32_t rtk_ums_to_string(const RCtx& c, const UMap* ums, uint32_t n, char* dst) {
     RegionScratch& s = *c.sc;
+    const unsigned long long tc0 = rtk_clock();
     uint32_t len = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t skip = i ? static_cast<uint32_t>(c.k) - 1 : 0;
@@ -273,6 +278,7 @@ RTK_FN uint32_t rtk_ums_to_string(const RCtx& c, const UMap* ums, uint32_t n, ch
     }
     rtk_sync();
     s.cnt[2] += len;
+    s.cnt[12] += rtk_clock() - tc0;
     return len;
 }
 RTK_DEV uint32_t rtk_rec_to_string(const RCtx& c, uint64_t h, char* dst) {
@@ -283,7 +289,10 @@ RTK_DEV uint32_t rtk_rec_to_string(const RCtx& c, uint64_t h, char* dst) {
 RTK_FN MyersResult rtk_align(const RCtx& c, const char* q, uint32_t m, const char* t, uint32_t n, int kk, int mode, bool iupac = true) {
     RegionScratch& s = *c.sc;
     s.cnt[3] += 1; s.cnt[4] += static_cast<unsigned long long>((m + 63) / 64) * n;
-    return rtk_myers_distance(s.my, q, static_cast<int>(m), t, static_cast<int>(n), kk, mode, iupac);
+    const unsigned long long t0 = rtk_clock();
+    const MyersResult r = rtk_myers_distance(s.my, q, static_cast<int>(m), t, static_cast<int>(n), kk, mode, iupac);
+    s.cnt[9] += rtk_clock() - t0;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------ candidate selection (src/Alignment.cpp:3-147, 967-1015)
@@ -330,6 +339,7 @@ RTK_FN double rtk_score_path(const RCtx& c, uint32_t sl, const char* ref, uint32
 // quality string of a path (SHW path alignment against ref) written to qout[0..sl); path string in str[1]
 RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl, const char* ref, uint32_t ref_len, double score_best, double score_second, char* qout) {
     RegionScratch& s = *c.sc;
+    const unsigned long long tq0 = rtk_clock();
     const double score_comp = score_best * ((score_best == 0.0) ? 0.0 : (1.0 - (score_second / score_best)));
     const MyersResult a = rtk_align(c, s.str[1], sl, ref, ref_len, -1, RTK_MODE_SHW);
     uint32_t nm = 0;
@@ -351,6 +361,7 @@ RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl, const char* ref, uin
         qp += static_cast<uint32_t>(rtk_popc(bq)); rp += static_cast<uint32_t>(rtk_popc(br));
     }
     rtk_sync();
+    s.cnt[13] += rtk_clock() - tq0;
 }
 
 // ------------------------------------------------------------------------------------------------ colour memo (src/GraphTraversal.cpp:485-487)
@@ -894,7 +905,7 @@ RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len
         }
         for (uint32_t x = lw_lo; x < lw_hi; ++x) { const uint32_t u = rtk_an_um(v_w, x).unitig; if (g.kcov[u] < c.o.max_km_cov) rtk_side_insert(sm, u, !rtk_is_branching(g, u)); } // middle (:563-585)
         if (sl.n >= cap / 2 || sr.n >= cap / 2 || sm.n >= cap / 2) { rtk_fail_ovf(s, 8); return; }
-        n_all = rtk_choose_colors(c, sl, sr, sm);
+        { const unsigned long long t0 = rtk_clock(); n_all = rtk_choose_colors(c, sl, sr, sm); s.cnt[5] += rtk_clock() - t0; }
         if (rtk_failed(s)) return;
         // keep all_pids for the reverse-complement call (rc = &fw): set[0] is preserved by everything below
     } else n_all = rc->n_all;
@@ -906,7 +917,7 @@ RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len
     uint64_t complete = ~0ull;
     char* s_corr = res.seq; char* q_corr = res.qual; uint32_t sl_ = 0, ql_ = 0;
     const Anchors& lvw = v_w;
-    if (n_all >= c.o.min_cov_vertices) complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, 0, &n_partial);
+    { const unsigned long long t0 = rtk_clock(); if (n_all >= c.o.min_cov_vertices) complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, 0, &n_partial); s.cnt[6] += rtk_clock() - t0; }
     if (rtk_failed(s)) return;
     const uint32_t nlw = lw_hi - lw_lo;
     auto add_uncorrected = [&](uint32_t pos, uint32_t len, char q) { rtk_app(s, s_corr, &sl_, s_read + pos, (pos + len <= s_len) ? len : (pos < s_len ? s_len - pos : 0)); rtk_app_fill(s, q_corr, &ql_, q, len_weak_region); };
@@ -932,7 +943,7 @@ RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len
             p1 = wpos; um1 = rtk_an_um(lvw, lw_lo + i_w_s);
             len_weak_region = p2 - p1 + k;
             s.top[0] = 0; n_partial = 0; // paths of the previous attempt are dead
-            complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, i_w_s, &n_partial);
+            { const unsigned long long t0 = rtk_clock(); complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, i_w_s, &n_partial); s.cnt[6] += rtk_clock() - t0; }
         }
         if (rtk_failed(s)) return;
         if (complete != ~0ull) {
@@ -1094,7 +1105,7 @@ RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& 
     t.str_cap = c.str_cap;
     t.memo_v = reinterpret_cast<uint8_t*>(p); p += c.memo_cap;
     t.overflow = t.my.overflow;
-    for (int i = 0; i < 5; ++i) t.cnt[i] = 0;
+    for (int i = 0; i < 16; ++i) t.cnt[i] = 0;
     *s = t; // every lane stores the same header
     return s;
 }
@@ -1181,7 +1192,9 @@ RTK_FN void rtk_region_program(const RCtx& c, RegionDesc* rd) {
                 } else {
                     const uint32_t ref_len = pb - pa + k;
                     uint32_t csl = 0, cql = 0;
+                    const unsigned long long tc0 = rtk_clock();
                     const bool ok = rtk_generate_consensus(c, &fw, &bw, s_fw + pa, ref_len, c.o.weak_region_len_factor, s.rbuf[6], &csl, s.rbuf[7], &cql);
+                    s.cnt[7] += rtk_clock() - tc0;
                     if (rtk_failed(s)) return;
                     if (!ok || csl == 0) { // raw region, k solid qualities then minimum quality (:898-904)
                         csl = 0; cql = 0;

@@ -210,9 +210,22 @@ RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView
 // One tile = 64 consecutive base positions; every candidate window of the tile is expanded by the whole wave into its
 // 93 substitution + 124 "insertion" + 29 "deletion" variants (one variant per lane per round), each probed in the k-mer table.
 #define RTK_N_VARIANTS 246
-RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile) {
+struct PoolChunk { unsigned long long base; uint32_t left; }; // wave-private slice of the raw-hit pool (one device atomic per 4096 entries)
+#define RTK_POOL_CHUNK 4096u
+
+RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_hits, PoolChunk* chunk) {
     const int k = g.k;
     const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
+#ifndef RTK_SIM
+    // LDS staging of the tile's 64 + k + 1 characters of the masked read: one coalesced load, then every lane slides over its own window
+    __shared__ unsigned char tile_chars[128];
+    {
+        const uint64_t a0 = tile * 64 + static_cast<uint64_t>(rtk_lane()), a1 = a0 + 64;
+        tile_chars[rtk_lane()] = (a0 < bv.n_bases) ? static_cast<unsigned char>(bv.masked[a0]) : 'N';
+        tile_chars[64 + rtk_lane()] = (a1 < bv.n_bases) ? static_cast<unsigned char>(bv.masked[a1]) : 'N';
+        __syncthreads();
+    }
+#endif
 #ifdef RTK_SIM
     const int n_sub = 64;
 #else
@@ -232,11 +245,16 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
             const uint64_t rend = bv.roff[lo + 1];
             if (bb + static_cast<uint64_t>(k) <= rend && rend - bv.roff[lo] > static_cast<uint64_t>(k)) {
                 bool ok = true;
-                for (int i = 0; i < k - 1; ++i) { const int c = rtk_cls(static_cast<unsigned char>(bv.masked[bb + i])); if (c > 3) { ok = false; break; } c_k1 = (c_k1 << 2) | static_cast<uint64_t>(c); }
+#ifdef RTK_SIM
+                const unsigned char* wc = reinterpret_cast<const unsigned char*>(bv.masked) + bb;
+#else
+                const unsigned char* wc = tile_chars + rtk_lane(); // k + 1 <= 64: the window and its two look-ahead characters are inside the staged 128 bytes
+#endif
+                for (int i = 0; i < k - 1; ++i) { const int c = rtk_cls(wc[i]); if (c > 3) { ok = false; break; } c_k1 = (c_k1 << 2) | static_cast<uint64_t>(c); }
                 if (ok) {
                     cand = true;
-                    const int c = rtk_cls(static_cast<unsigned char>(bv.masked[bb + k - 1]));
-                    if (c <= 3) { ck = static_cast<uint32_t>(c); if (bb + static_cast<uint64_t>(k) + 1 <= rend) { const int c2 = rtk_cls(static_cast<unsigned char>(bv.masked[bb + k])); if (c2 <= 3) ck1 = static_cast<uint32_t>(c2); } }
+                    const int c = rtk_cls(wc[k - 1]);
+                    if (c <= 3) { ck = static_cast<uint32_t>(c); if (bb + static_cast<uint64_t>(k) + 1 <= rend) { const int c2 = rtk_cls(wc[k]); if (c2 <= 3) ck1 = static_cast<uint32_t>(c2); } }
                 }
             }
         }
@@ -298,9 +316,13 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
             }
 #endif
             if (total > 0) {
-                unsigned long long pbase = 0;
-                if (rtk_lane() == 0) pbase = rtk_atomic_add(bv.ipool_top, static_cast<unsigned long long>(total));
-                pbase = rtk_shfl(pbase, 0);
+                if (chunk->left < static_cast<uint32_t>(total)) { // refill the wave's private slice (the tail of the old slice is abandoned)
+                    unsigned long long nb = 0;
+                    if (rtk_lane() == 0) nb = rtk_atomic_add(bv.ipool_top, static_cast<unsigned long long>(RTK_POOL_CHUNK));
+                    chunk->base = rtk_shfl(nb, 0); chunk->left = RTK_POOL_CHUNK;
+                }
+                const unsigned long long pbase = chunk->base;
+                chunk->base += static_cast<unsigned long long>(total); chunk->left -= static_cast<uint32_t>(total);
                 if (pbase + static_cast<unsigned long long>(total) <= bv.ipool_cap) {
 #ifdef RTK_SIM
                     for (int i = 0; i < total; ++i) { bv.ipool[2 * (pbase + i)] = sim_code[i]; bv.ipool[2 * (pbase + i) + 1] = sim_hit[i]; }
@@ -311,8 +333,8 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
                     if (rtk_lane() == 0) bv.wdesc[w_b] = (static_cast<uint64_t>(pbase) << 24) | static_cast<uint64_t>(total);
                 } else if (rtk_lane() == 0) rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
             }
-            const int ptot = rtk_wave_sum(static_cast<int>(probes));
-            if (rtk_lane() == 0) { rtk_atomic_add(bv.counters + RTK_CNT_PROBES_INEXACT, static_cast<unsigned long long>(ptot)); if (total) rtk_atomic_add(bv.counters + RTK_CNT_HITS_INEXACT, static_cast<unsigned long long>(total)); }
+            *acc_probes += probes; // per-lane tallies, reduced once per wave at kernel end (a device-wide atomic per window saturates one L2 word)
+            if (rtk_lane() == 0) *acc_hits += static_cast<unsigned long long>(total);
         }
     }
 }

@@ -29,6 +29,7 @@ inline void rtk_sync() {}
 inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
 template <class T> inline T rtk_atomic_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long rtk_clock() { return 0; }
 
 #else
 
@@ -47,6 +48,7 @@ __device__ __forceinline__ void rtk_sync() { __syncthreads(); }
 __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
 template <class T> __device__ __forceinline__ T rtk_atomic_add(T* p, T v) { return atomicAdd(p, v); }
+__device__ __forceinline__ unsigned long long rtk_clock() { return static_cast<unsigned long long>(clock64()); }
 
 #endif
 
