@@ -163,6 +163,77 @@ __device__ __forceinline__ void rtk_myers_sweep_acgt(int m, int n, int W, int to
 }
 #endif
 
+#ifndef RTK_SIM
+// Self-contained fast path for forward sequences with <= 64 query words: profile words built from 8 wide loads per lane,
+// branch-free sweep, running minimum kept in scalar registers (no per-column score array), A/C/G/T check folded into the
+// per-64-column target load. Returns plain == false (and no result) when the target holds another character.
+struct SweepStat { int final_score, best, first, last, cnt; bool plain; };
+template <int STORE>
+__device__ __forceinline__ SweepStat rtk_myers_fast(const char* __restrict__ qp, int m, const char* __restrict__ tp, int n, int top_h, bool iupac, uint64_t* __restrict__ tb) {
+    SweepStat st; st.final_score = m; st.best = 0x7fffffff; st.first = -1; st.last = -1; st.cnt = 0; st.plain = true;
+    const int lane = rtk_lane();
+    const int W = (m + 63) >> 6, last_bit = (m - 1) & 63;
+    const int w = lane;
+    const bool has_word = lane < W;
+    uint64_t eqA = 0, eqC = 0, eqG = 0, eqT = 0;
+    if (has_word) {
+        const int lim = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+        uint64_t qw[8];
+        for (int j = 0; j < 8; ++j) { uint64_t x = 0; if (8 * j < lim) __builtin_memcpy(&x, qp + 64 * w + 8 * j, 8); qw[j] = x; } // may read up to 7 bytes past the query inside its padded buffer
+        for (int i = 0; i < lim; ++i) {
+            const unsigned char qc = static_cast<unsigned char>((qw[i >> 3] >> (8 * (i & 7))) & 0xFFull);
+            uint32_t bm;
+            if (qc == 'A') bm = 1u; else if (qc == 'C') bm = 2u; else if (qc == 'G') bm = 4u; else if (qc == 'T') bm = 8u;
+            else bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu;
+            eqA |= static_cast<uint64_t>(bm & 1u) << i; eqC |= static_cast<uint64_t>((bm >> 1) & 1u) << i;
+            eqG |= static_cast<uint64_t>((bm >> 2) & 1u) << i; eqT |= static_cast<uint64_t>((bm >> 3) & 1u) << i;
+        }
+    }
+    const int bit = (w == W - 1) ? last_bit : 63;
+    uint64_t Pv = ~0ull, Mv = 0ull;
+    int hout_prev = 0; unsigned tc_prev = 0;
+    int score = m;
+    int best = 0x7fffffff, first = -1, last = -1, cnt = 0, fin = m;
+    const int steps = n + W - 1;
+    for (int c0 = 0; c0 < steps; c0 += 64) {
+        const int cj = c0 + lane;
+        int my_t = 'A';
+        if (cj < n) my_t = static_cast<int>(static_cast<unsigned char>(tp[cj]));
+        if (rtk_ballot(!(my_t == 'A' || my_t == 'C' || my_t == 'G' || my_t == 'T')) != 0ull) { st.plain = false; return st; }
+        asm volatile("" : "+v"(my_t));
+        const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
+        for (int j = 0; j < lim; ++j) {
+            const int s = c0 + j;
+            const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
+            const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+            const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(top_h + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
+            const int hin = static_cast<int>(got & 0xFFu) - 1;
+            const unsigned tc = got >> 8;
+            const unsigned sel = (tc >> 1) & 3u; // 'A' -> 0, 'C' -> 1, 'T' -> 2, 'G' -> 3
+            const uint64_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
+            uint64_t nPv = Pv, nMv = Mv, Ph, Mh;
+            const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
+            const int col = s - lane;
+            const bool active = has_word && col >= 0 && col < n;
+            if (STORE) { if (active) { uint64_t* e = tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
+            Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
+            hout_prev = active ? hout : hout_prev;
+            score += (active && lane == W - 1) ? hout : 0;
+            tc_prev = tc;
+            const int tcol = s - (W - 1);
+            if (tcol >= 0) { // wave-uniform: last-row score of column tcol, tracked in scalar registers
+                const int sv = __builtin_amdgcn_readlane(score, W - 1);
+                fin = sv;
+                if (sv < best) { best = sv; first = tcol; last = tcol; cnt = 1; }
+                else if (sv == best) { last = tcol; ++cnt; }
+            }
+        }
+    }
+    st.final_score = fin; st.best = best; st.first = first; st.last = last; st.cnt = cnt;
+    return st;
+}
+#endif
+
 // Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
 // top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
@@ -304,6 +375,21 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, int
     }
     if (mode == RTK_MODE_NW && k >= 0 && k < (n > m ? n - m : m - n)) return r; // edlib.cpp:744-747
     if (static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap) { *sc.overflow = 1; return r; }
+#ifndef RTK_SIM
+    if (m <= 4096 && !locs_out) {
+        const SweepStat st = rtk_myers_fast<0>(q, m, t, n, mode == RTK_MODE_HW ? 0 : 1, iupac, nullptr);
+        if (st.plain) {
+            if (mode == RTK_MODE_NW) { if (k >= 0 && st.final_score > k) return r; r.dist = st.final_score; r.first = r.last = n - 1; r.nloc = 1; return r; }
+            int best = st.best; const bool pseudo = (m & 63) != 0;
+            if (pseudo && m < best) best = m;
+            if (k >= 0 && best > k) return r;
+            r.dist = best;
+            if (pseudo && m == best) { r.first = -1; r.last = (st.best == best) ? st.last : -1; r.nloc = 1 + ((st.best == best) ? st.cnt : 0); }
+            else { r.first = st.first; r.last = st.last; r.nloc = st.cnt; }
+            return r;
+        }
+    }
+#endif
     rtk_myers_pass(sc, rtk_seq(q, m), rtk_seq(t, n), mode == RTK_MODE_HW ? 0 : 1, iupac, 0, nullptr, nullptr);
     if (mode == RTK_MODE_NW) {
         const int d = sc.colscore[n - 1];
@@ -349,8 +435,14 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, int
 // (edlib.cpp:1021-1137). Appends the moves (already in forward order) to sc.moves at *n_moves.
 RTK_FN void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const MySeq& t, bool iupac, uint32_t* n_moves) {
     const int m = q.n, n = t.n, W = (m + 63) >> 6;
-    rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr);
-    int cur = sc.colscore[n - 1];
+    int cur;
+#ifndef RTK_SIM
+    SweepStat fst; fst.plain = false;
+    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast<1>(q.p, m, t.p, n, 1, iupac, sc.tb);
+    if (fst.plain) { cur = fst.final_score; rtk_sync(); }
+    else
+#endif
+    { rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr); cur = sc.colscore[n - 1]; }
     int i = m, j = n;
     uint32_t nt = 0; // moves are produced backwards into moves_tmp, from its end
     uint8_t* tmp = sc.moves_tmp;
