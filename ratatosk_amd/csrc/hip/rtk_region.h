@@ -548,7 +548,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c, const uint32_t* all_pids, uint3
                     UMap bt = ust;
                     if (bt.strand) bt.len = um_e.dist - bt.dist + 1; else { bt.dist = um_e.dist; bt.len -= um_e.dist; }
                     rtk_wp_start(c, w, bt, q_max);
-                    v[nv++] = rtk_wp_commit(s, w, 1);
+                    if (nv < s.list_cap) v[nv++] = rtk_wp_commit(s, w, 1); else rtk_fail_ovf(s, 8);
                 }
             }
         } else if ((ust.len + k - 1) >= min_len_path) { // :127-140
@@ -580,7 +580,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c, const uint32_t* all_pids, uint3
                     if (nvt >= max_paths) {
                         for (uint32_t i = 0; i < nvt && !rtk_failed(s); ++i) {
                             const uint32_t l = rtk_rec_l(s, v_tmp[i]);
-                            if (l >= min_len_path && l <= max_len_path) { if (nv + 1 >= max_paths) rtk_resize_to_best(c, v, &nv, ref, ref_len); v[nv++] = v_tmp[i]; }
+                            if (l >= min_len_path && l <= max_len_path) { if (nv + 1 >= max_paths) rtk_resize_to_best(c, v, &nv, ref, ref_len); if (nv >= s.list_cap) { rtk_fail_ovf(s, 8); break; } v[nv++] = v_tmp[i]; }
                         }
                         nvt = 0;
                     }
@@ -609,7 +609,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c, const uint32_t* all_pids, uint3
             if (has_end) {
                 for (uint32_t i = 0; i < nvt && !rtk_failed(s); ++i) {
                     const uint32_t l = rtk_rec_l(s, v_tmp[i]);
-                    if (l >= min_len_path && l <= max_len_path) { if (nv + 1 >= max_paths) rtk_resize_to_best(c, v, &nv, ref, ref_len); v[nv++] = v_tmp[i]; }
+                    if (l >= min_len_path && l <= max_len_path) { if (nv + 1 >= max_paths) rtk_resize_to_best(c, v, &nv, ref, ref_len); if (nv >= s.list_cap) { rtk_fail_ovf(s, 8); break; } v[nv++] = v_tmp[i]; }
                 }
             } else {
                 for (uint32_t i = 0; i < nvt && !rtk_failed(s); ++i) {

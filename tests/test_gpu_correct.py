@@ -17,3 +17,9 @@ def test_gpu_correct_branching(ds_small):
 
 def test_gpu_correct_clean(ds_clean):
     _check(ds_clean, 10, None)
+
+
+def test_gpu_scratch_overflow_is_redone_on_device(ds_small, monkeypatch):
+    monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
+    st, got, seqs = _check(ds_small, 12, None, counters_must_match=False)
+    assert st["n_arena_overflow"] > 0
