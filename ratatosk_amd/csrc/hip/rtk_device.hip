@@ -55,6 +55,7 @@ static void graph_set_view(rtk_graph* g) {
     v.loff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_LOFF]); v.gid = static_cast<const int32_t*>(g->dbuf[rtk::RTK_BUF_GID]);
     v.goff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_GOFF]); v.col = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_COL]);
     v.ht = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HT]);
+    v.bf = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_BF]); v.bf_mask = g->dbytes[rtk::RTK_BUF_BF] / 8 - 1;
 }
 
 extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out) {
@@ -111,7 +112,7 @@ extern "C" int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* d
 extern "C" int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n) {
     if (!g || !bytes || n != rtk::RTK_N_BUFS || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer_bytes: needs a loaded graph");
     const rtk::FlatGraph& h = g->host;
-    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size() };
+    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size() };
     for (int i = 0; i < n; ++i) bytes[i] = b[i];
     return RTK_OK;
 }
@@ -120,8 +121,8 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
     if (!g || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: graph has no host image");
     int rc = require_device(device); if (rc) return rc;
     const rtk::FlatGraph& h = g->host;
-    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data() };
-    const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size() };
+    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data(), h.bf.data() };
+    const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size() };
     try {
         rtk_set_device(device);
         for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { if (!g->dbuf[i]) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; } rtk_h2d(g->dbuf[i], src[i], bytes[i]); }
@@ -194,7 +195,7 @@ RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
 // by their base position in the concatenated read buffer. hits[b] = packed (unitig, dist, strand) or RTK_NO_HIT.
 RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* roff, uint32_t n_reads, uint64_t n_bases, int grid, uint64_t* hits, uint64_t* n_probes_out) {
     const uint64_t n_tiles = (n_bases + RTK_WAVE - 1) / RTK_WAVE;
-    uint32_t probes = 0;
+    uint32_t probes = 0, slots = 0;
     for (uint64_t tile = static_cast<uint64_t>(RTK_BLOCK_ID); tile < n_tiles; tile += static_cast<uint64_t>(grid)) {
         const uint64_t b = tile * RTK_WAVE + static_cast<uint64_t>(rtk_lane());
         if (b >= n_bases) continue;
@@ -209,11 +210,14 @@ RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* rof
                 if (c > 3) { ok = false; break; }
                 fw = (fw << 2) | static_cast<uint64_t>(c);
             }
-            if (ok) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += np; }
+            if (ok) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += 1; slots += np; }
         }
         hits[b] = h;
     }
-    if (n_probes_out) { const int tot = rtk_wave_sum(static_cast<int>(probes)); if (rtk_lane() == 0 && tot) rtk_atomic_add(reinterpret_cast<unsigned long long*>(n_probes_out), static_cast<unsigned long long>(tot)); }
+    if (n_probes_out) { // n_probes_out[0] += k-mer queries, n_probes_out[11] += 16-byte table slots visited (RTK_CNT_PROBES_EXACT -> RTK_CNT_SLOTS_EXACT)
+        const int tot = rtk_wave_sum(static_cast<int>(probes)), tots = rtk_wave_sum(static_cast<int>(slots));
+        if (rtk_lane() == 0) { if (tot) rtk_atomic_add(reinterpret_cast<unsigned long long*>(n_probes_out), static_cast<unsigned long long>(tot)); if (tots) rtk_atomic_add(reinterpret_cast<unsigned long long*>(n_probes_out) + 11, static_cast<unsigned long long>(tots)); }
+    }
 }
 
 static int default_grid() {

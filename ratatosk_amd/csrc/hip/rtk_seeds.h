@@ -90,6 +90,8 @@ RTK_HD SeedScratch seed_scratch_carve(char* base, const SeedScratchCfg& c) {
 #define RTK_CNT_PATHBASE 9
 #define RTK_CNT_ALIGN 10
 #define RTK_CNT_CELLS 11
+#define RTK_CNT_SLOTS_EXACT 12
+#define RTK_CNT_SLOTS_INEXACT 13
 
 RTK_DEV uint32_t rtk_hit_unitig(uint64_t h) { return static_cast<uint32_t>(h >> 33); }
 RTK_DEV bool rtk_is_branching(const GraphView& g, uint32_t u) { return (g.flags[u] & RTK_F_BRANCHING) != 0; }
@@ -210,10 +212,42 @@ RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView
 // One tile = 64 consecutive base positions; every candidate window of the tile is expanded by the whole wave into its
 // 93 substitution + 124 "insertion" + 29 "deletion" variants (one variant per lane per round), each probed in the k-mer table.
 #define RTK_N_VARIANTS 246
+
+// variant v (0..245) of the window whose first k-1 / k / k+1 characters are (w_k1, w_ck, w_ck1): 2-bit code of the graph k-mer to look for
+RTK_DEV bool rtk_variant_code(int v, int k, uint64_t w_k1, uint32_t w_ck, uint32_t w_ck1, uint64_t* code_out) {
+    uint64_t code = 0; bool valid = false;
+    if (v < 93) { // substitution: needs k characters
+        if (w_ck <= 3) {
+            const int oo = v / 3, j = v % 3;
+            const uint64_t full = (w_k1 << 2) | w_ck;
+            const int sh = 2 * (k - 1 - oo);
+            const uint32_t orig = static_cast<uint32_t>((full >> sh) & 3ull);
+            const uint32_t nb = static_cast<uint32_t>(j) + (static_cast<uint32_t>(j) >= orig ? 1u : 0u);
+            code = (full & ~(3ull << sh)) | (static_cast<uint64_t>(nb) << sh); valid = true;
+        }
+    } else if (v < 217) { // graph k-mer has one extra base: k-1 read characters + an inserted one
+        const int vv = v - 93, oo = vv / 4; const uint64_t nb = static_cast<uint64_t>(vv % 4);
+        const int rest = k - 1 - oo; // characters after the inserted base
+        const uint64_t lo_mask = rest ? ((1ull << (2 * rest)) - 1ull) : 0ull;
+        code = ((w_k1 >> (2 * rest)) << (2 * rest + 2)) | (nb << (2 * rest)) | (w_k1 & lo_mask); valid = true;
+    } else if (v < RTK_N_VARIANTS) { // graph k-mer lacks one interior read base: k+1 read characters
+        if (w_ck <= 3 && w_ck1 <= 3) {
+            const int oo = v - 217 + 1; // deleted offset in [1, k-2]
+            const uint64_t full2 = (w_k1 << 4) | (static_cast<uint64_t>(w_ck) << 2) | static_cast<uint64_t>(w_ck1); // k+1 characters (exactly 64 bits for k = 31)
+            const int keep_lo = k - oo; // characters after the deleted one
+            const uint64_t lo_mask = (1ull << (2 * keep_lo)) - 1ull;
+            const uint64_t hi = (2 * (keep_lo + 1) >= 64) ? 0ull : (full2 >> (2 * (keep_lo + 1)));
+            code = (hi << (2 * keep_lo)) | (full2 & lo_mask); valid = true;
+        }
+    }
+    *code_out = code & ((k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull));
+    return valid;
+}
+
 struct PoolChunk { unsigned long long base; uint32_t left; }; // wave-private slice of the raw-hit pool (one device atomic per 4096 entries)
 #define RTK_POOL_CHUNK 4096u
 
-RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_hits, PoolChunk* chunk) {
+RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk) {
     const int k = g.k;
     const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
 #ifndef RTK_SIM
@@ -269,49 +303,30 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
 #else
             const uint64_t w_b = tile * 64 + static_cast<uint64_t>(sl);
 #endif
-            uint64_t my_code[4]; uint64_t my_hit[4]; int my_n = 0; uint32_t probes = 0;
+            uint64_t my_code[4]; uint64_t my_hit[4]; int my_n = 0; uint32_t probes = 0, slots = 0;
             int total = 0;
 #ifdef RTK_SIM
             // simulator: one lane walks all variants; hits are appended straight to the pool below
             uint64_t sim_code[RTK_N_VARIANTS], sim_hit[RTK_N_VARIANTS];
             for (int v = 0; v < RTK_N_VARIANTS; ++v) {
-#else
-            for (int v = rtk_lane(); v < RTK_N_VARIANTS + 63 - ((RTK_N_VARIANTS + 63) % 64); v += 64) {
-#endif
-                uint64_t code = 0; bool valid = false;
-                if (v < 93) { // substitution: needs k characters
-                    if (w_ck <= 3) {
-                        const int oo = v / 3, j = v % 3;
-                        const uint64_t full = (w_k1 << 2) | w_ck;
-                        const int sh = 2 * (k - 1 - oo);
-                        const uint32_t orig = static_cast<uint32_t>((full >> sh) & 3ull);
-                        const uint32_t nb = static_cast<uint32_t>(j) + (static_cast<uint32_t>(j) >= orig ? 1u : 0u);
-                        code = (full & ~(3ull << sh)) | (static_cast<uint64_t>(nb) << sh); valid = true;
-                    }
-                } else if (v < 217) { // graph k-mer has one extra base: k-1 read characters + an inserted one
-                    const int vv = v - 93, oo = vv / 4; const uint64_t nb = static_cast<uint64_t>(vv % 4);
-                    const int rest = k - 1 - oo; // characters after the inserted base
-                    const uint64_t lo_mask = rest ? ((1ull << (2 * rest)) - 1ull) : 0ull;
-                    code = ((w_k1 >> (2 * rest)) << (2 * rest + 2)) | (nb << (2 * rest)) | (w_k1 & lo_mask); valid = true;
-                } else if (v < RTK_N_VARIANTS) { // graph k-mer lacks one interior read base: k+1 read characters
-                    if (w_ck <= 3 && w_ck1 <= 3) {
-                        const int oo = v - 217 + 1; // deleted offset in [1, k-2]
-                        // full2 = k+1 characters; for k = 31 that is exactly 64 bits
-                        const uint64_t full2 = (w_k1 << 4) | (static_cast<uint64_t>(w_ck) << 2) | static_cast<uint64_t>(w_ck1);
-                        const int keep_lo = k - oo; // characters after the deleted one
-                        const uint64_t lo_mask = (1ull << (2 * keep_lo)) - 1ull;
-                        const uint64_t hi = (2 * (keep_lo + 1) >= 64) ? 0ull : (full2 >> (2 * (keep_lo + 1)));
-                        code = (hi << (2 * keep_lo)) | (full2 & lo_mask); valid = true;
-                    }
-                }
-                uint64_t hit = RTK_NO_HIT;
-                if (valid) { uint32_t np; hit = rtk_find_kmer(g, code & ((k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull)), &np); probes += np; }
-#ifdef RTK_SIM
+                uint64_t code; uint64_t hit = RTK_NO_HIT;
+                if (rtk_variant_code(v, k, w_k1, w_ck, w_ck1, &code)) { uint32_t np; hit = rtk_find_kmer(g, code, &np); probes += 1; slots += np; }
                 if (hit != RTK_NO_HIT) { sim_code[total] = code; sim_hit[total] = hit; ++total; }
             }
 #else
+            // four rounds of 64 variants: all four pre-filter words are requested before any is looked at (memory-level parallelism),
+            // the table is only touched by the ~1 % of variants that pass the filter
+            uint64_t vcode[4], vcan[4], vhh[4], vword[4]; uint32_t vq[4]; bool vvalid[4];
+            for (int rr = 0; rr < 4; ++rr) {
+                vvalid[rr] = rtk_variant_code(rtk_lane() + 64 * rr, k, w_k1, w_ck, w_ck1, &vcode[rr]);
+                rtk_kmer_prepare(vcode[rr], k, &vcan[rr], &vhh[rr], &vq[rr]);
+            }
+            for (int rr = 0; rr < 4; ++rr) vword[rr] = vvalid[rr] ? g.bf[(vhh[rr] >> 32) & g.bf_mask] : 0ull;
+            for (int rr = 0; rr < 4; ++rr) {
+                uint64_t hit = RTK_NO_HIT;
+                if (vvalid[rr]) { probes += 1; if (rtk_filter_pass(vword[rr], vhh[rr])) { uint32_t np; hit = rtk_table_lookup(g, vcan[rr], vhh[rr], vq[rr], &np); slots += np; } }
                 const uint64_t hb = rtk_ballot(hit != RTK_NO_HIT);
-                if (hit != RTK_NO_HIT) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; }
+                if (hit != RTK_NO_HIT) { my_code[my_n] = vcode[rr]; my_hit[my_n] = hit; ++my_n; }
                 total += rtk_popc(hb);
             }
 #endif
@@ -333,6 +348,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
                     if (rtk_lane() == 0) bv.wdesc[w_b] = (static_cast<uint64_t>(pbase) << 24) | static_cast<uint64_t>(total);
                 } else if (rtk_lane() == 0) rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
             }
+            *acc_slots += slots;
             *acc_probes += probes; // per-lane tallies, reduced once per wave at kernel end (a device-wide atomic per window saturates one L2 word)
             if (rtk_lane() == 0) *acc_hits += static_cast<unsigned long long>(total);
         }

@@ -40,6 +40,8 @@ struct GraphView {
     const uint64_t* goff;      // [n_global+1] global set g = col[goff[g] .. goff[g+1])
     const uint32_t* col;       // sorted u32 pair ids
     const uint64_t* ht;        // [2*slots] {canonical k-mer, unitig<<32 | dist<<1 | stored_is_canonical}, empty key = RTK_EMPTY_KEY
+    const uint64_t* bf;        // [bf_mask+1] blocked Bloom filter over the canonical k-mers (2 bits of one 64-bit word per k-mer)
+    uint64_t bf_mask;
 };
 
 RTK_HD uint32_t rtk_ulen(const GraphView& g, uint32_t u) { return static_cast<uint32_t>(g.uoff[u + 1] - g.uoff[u]); }
@@ -80,11 +82,17 @@ RTK_HD bool rtk_um_eq(const UMap& a, const UMap& b) { return a.unitig == b.uniti
 RTK_HD uint64_t rtk_pack_hit(uint32_t unitig, uint32_t dist, uint32_t strand) { return (static_cast<uint64_t>(unitig) << 33) | (static_cast<uint64_t>(dist) << 1) | (strand & 1u); }
 RTK_HD UMap rtk_unpack_hit(uint64_t h) { UMap u; u.unitig = static_cast<uint32_t>(h >> 33); u.dist = static_cast<uint32_t>((h >> 1) & 0xFFFFFFFFull); u.len = 1; u.strand = static_cast<uint32_t>(h & 1ull); return u; }
 
-// Exact k-mer lookup (Bifrost find(km,false) [A1]): fw = k-mer code in read orientation.
+// Exact k-mer lookup (Bifrost find(km,false) [A1]): fw = k-mer code in read orientation. *n_probes = 16-byte table slots visited
+// (0 when the pre-filter already answered).
 RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probes) {
     const uint64_t rc = rtk_revcomp(fw, g.k);
     const uint64_t can = fw < rc ? fw : rc;
-    uint64_t i = rtk_hash64(can) & g.ht_mask;
+    const uint64_t hh = rtk_hash64(can);
+    { // pre-filter: absent k-mers (the bulk of the 1-edit variants) stop here after one 8-byte read
+        const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63));
+        if ((g.bf[(hh >> 32) & g.bf_mask] & bits) != bits) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; }
+    }
+    uint64_t i = hh & g.ht_mask;
     uint32_t np = 0;
     while (true) {
         const uint64_t key = g.ht[2 * i];
@@ -96,6 +104,23 @@ RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probe
             return rtk_pack_hit(static_cast<uint32_t>(v >> 32), static_cast<uint32_t>((v & 0xFFFFFFFFull) >> 1), stored_is_can == query_is_can ? 1u : 0u);
         }
         if (key == RTK_EMPTY_KEY) { if (n_probes) *n_probes = np; return RTK_NO_HIT; }
+        i = (i + 1) & g.ht_mask;
+    }
+}
+
+
+// Split form of rtk_find_kmer for callers that want several filter reads in flight before any of them is consumed.
+RTK_HD void rtk_kmer_prepare(uint64_t fw, int k, uint64_t* can, uint64_t* hh, uint32_t* query_is_can) {
+    const uint64_t rc = rtk_revcomp(fw, k);
+    *can = fw < rc ? fw : rc; *query_is_can = (fw <= rc) ? 1u : 0u; *hh = rtk_hash64(*can);
+}
+RTK_HD bool rtk_filter_pass(uint64_t word, uint64_t hh) { const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)); return (word & bits) == bits; }
+RTK_HD uint64_t rtk_table_lookup(const GraphView& g, uint64_t can, uint64_t hh, uint32_t query_is_can, uint32_t* n_slots) {
+    uint64_t i = hh & g.ht_mask; uint32_t np = 0;
+    while (true) {
+        const uint64_t key = g.ht[2 * i]; ++np;
+        if (key == can) { const uint64_t v = g.ht[2 * i + 1]; *n_slots = np; return rtk_pack_hit(static_cast<uint32_t>(v >> 32), static_cast<uint32_t>((v & 0xFFFFFFFFull) >> 1), (static_cast<uint32_t>(v & 1ull) == query_is_can) ? 1u : 0u); }
+        if (key == RTK_EMPTY_KEY) { *n_slots = np; return RTK_NO_HIT; }
         i = (i + 1) & g.ht_mask;
     }
 }

@@ -8,6 +8,7 @@
 #include <fstream>
 #include <map>
 #include <stdexcept>
+#include <cstdlib>
 
 #include "../common/fastx.hpp"
 #include "../common/kmer.hpp"
@@ -19,12 +20,12 @@ GraphView FlatGraph::view() const {
     GraphView v;
     v.k = k; v.n_unitigs = n_unitigs(); v.n_kmers = n_kmers; v.ht_mask = ht.size() / 2 - 1;
     v.useq = useq.data(); v.uoff = uoff.data(); v.adj = adj.data(); v.flags = flags.data(); v.kcov = kcov.data(); v.card = card.data();
-    v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data();
+    v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data(); v.bf = bf.data(); v.bf_mask = bf.size() - 1;
     return v;
 }
 
 uint64_t FlatGraph::bytes() const {
-    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
+    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
 void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int /*n_threads*/) {
@@ -65,6 +66,10 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     ht.assign(2 * slots, 0);
     for (uint64_t i = 0; i < slots; ++i) ht[2 * i] = RTK_EMPTY_KEY;
     const uint64_t hmask = slots - 1, kmask = kmer_mask(k);
+    // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer, >= 16 bits per key.
+    // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
+    uint64_t bf_words = 16; { const char* e = getenv("RTK_BF_KEYS_PER_WORD"); const uint64_t kpw = e ? strtoull(e, nullptr, 10) : 4; while (bf_words * kpw < n_kmers) bf_words <<= 1; }
+    bf.assign(bf_words, 0);
     for (size_t u = 0; u < n; ++u) {
         const std::string& s = seqs[u];
         uint64_t fw = 0;
@@ -78,10 +83,11 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                 h = (h + 1) & hmask;
             }
             ht[2 * h] = can;
+            { const uint64_t hh = rtk_hash64(can); bf[(hh >> 32) & (bf_words - 1)] |= (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)); }
             ht[2 * h + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
         }
     }
-    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; return v; }();
+    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; v.bf = bf.data(); v.bf_mask = bf_words - 1; return v; }();
     // ---- unitig data (.rtsk) ----
     flags.assign(n, 0); kcov.assign(n, 0); card.assign(n, 0); gid.assign(n, -1); loff.assign(n + 1, 0);
     std::vector<std::vector<uint32_t> > locals(n);

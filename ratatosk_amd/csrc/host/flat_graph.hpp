@@ -14,7 +14,7 @@ namespace rtk {
 struct FlatGraph {
     int k = 31;
     uint64_t n_kmers = 0, n_global = 0;
-    std::vector<uint64_t> useq, uoff, loff, goff, ht;
+    std::vector<uint64_t> useq, uoff, loff, goff, ht, bf;
     std::vector<uint32_t> adj, flags, kcov, card, col;
     std::vector<int32_t> gid;
     uint64_t max_km_cov_top = 0; // getMaxKmerCoverage(dbg, 0.001) (reference: src/Graph.cpp:825-841)
@@ -26,8 +26,8 @@ struct FlatGraph {
     void load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads);
 };
 
-// the 12 flat buffers in a fixed order (upload / RCCL broadcast order)
-enum { RTK_BUF_USEQ = 0, RTK_BUF_UOFF, RTK_BUF_ADJ, RTK_BUF_FLAGS, RTK_BUF_KCOV, RTK_BUF_CARD, RTK_BUF_LOFF, RTK_BUF_GID, RTK_BUF_GOFF, RTK_BUF_COL, RTK_BUF_HT, RTK_N_BUFS };
+// the flat buffers in a fixed order (upload / RCCL broadcast order)
+enum { RTK_BUF_USEQ = 0, RTK_BUF_UOFF, RTK_BUF_ADJ, RTK_BUF_FLAGS, RTK_BUF_KCOV, RTK_BUF_CARD, RTK_BUF_LOFF, RTK_BUF_GID, RTK_BUF_GOFF, RTK_BUF_COL, RTK_BUF_HT, RTK_BUF_BF, RTK_N_BUFS };
 
 } // namespace rtk
 
