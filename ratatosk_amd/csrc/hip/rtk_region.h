@@ -843,6 +843,33 @@ RTK_FN void rtk_app_fill(RegionScratch& s, char* dst, uint32_t* len, char ch, ui
 // Bifrost Kmer(const char*) 2-bit code of any character (end k-mer test, src/Correction.cpp:720-724)
 RTK_DEV int rtk_bifrost_code(char ch) { const int x = (ch & 4) >> 1; return x + ((x ^ (ch & 2)) >> 1); }
 
+
+// Visits anchors x = start, start+step, ... while `in_range(pos)` holds (positions are sorted, so the condition is a prefix
+// property), calling fn(um) once per RUN of consecutive anchors on the same unitig. Repeated visits of one unitig are no-ops for
+// the side lists (first insertion wins, the branching quota only grows), so skipping them is exact. Lanes fetch 64 anchors at a time.
+template <class Cond, class Fn>
+RTK_DEV void rtk_scan_anchor_runs(const Anchors& a, int64_t start, int step, Cond in_range, Fn fn) {
+    uint32_t prev_unitig = RTK_NONE32; bool first = true;
+    for (int64_t b = 0;; b += RTK_WAVE) {
+        const int64_t x = start + static_cast<int64_t>(step) * (b + rtk_lane());
+        bool ok = false; UMap um = rtk_um_empty();
+        if (x >= 0 && x < static_cast<int64_t>(a.n)) { ok = in_range(rtk_an_pos(a, static_cast<uint32_t>(x))); if (ok) um = rtk_an_um(a, static_cast<uint32_t>(x)); }
+        const uint64_t okm = rtk_ballot(ok);
+        const int lead = (~okm == 0ull) ? RTK_WAVE : (rtk_ffs(~okm) - 1); // anchors of this chunk that are visited
+        if (lead == 0) break;
+        uint32_t left_unitig = rtk_shfl_up1(um.unitig, prev_unitig);
+        const bool run_start = ok && rtk_lane() < lead && (um.unitig != left_unitig || (first && rtk_lane() == 0));
+        uint64_t rs = rtk_ballot(run_start);
+        while (rs) {
+            const int l = rtk_ffs(rs) - 1; rs &= rs - 1ull;
+            UMap u; u.unitig = rtk_shfl(um.unitig, l); u.dist = rtk_shfl(um.dist, l); u.len = 1; u.strand = rtk_shfl(um.strand, l);
+            fn(u);
+        }
+        prev_unitig = rtk_shfl(um.unitig, lead - 1); first = false;
+        if (lead < RTK_WAVE) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ the `correct` lambda (src/Correction.cpp:431-753)
 // s_read: read in the orientation of this call; v_s / v_w: anchors in that orientation. Result strings go to res.seq / res.qual.
 RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len, const Anchors& v_s, const Anchors& v_w, uint32_t i_s, uint32_t i_w, const ResCorr* rc, ResCorr& res) {
@@ -889,7 +916,7 @@ RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len
         };
         { // left (:476-516)
             uint32_t nbb = 0;
-            for (int64_t x = static_cast<int64_t>(i_s); x >= 0 && static_cast<uint64_t>(rtk_an_pos(v_s, static_cast<uint32_t>(x))) > u_min_start; --x) consider(sl, rtk_an_um(v_s, static_cast<uint32_t>(x)), nbb);
+            rtk_scan_anchor_runs(v_s, static_cast<int64_t>(i_s), -1, [&](uint32_t p) { return static_cast<uint64_t>(p) > u_min_start; }, [&](const UMap& um) { consider(sl, um, nbb); });
             const uint32_t v_w_sz = v_w.n;
             uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
             while (x > 0 && static_cast<uint64_t>(rtk_an_pos(v_w, x)) > u_min_start) --x;
@@ -897,7 +924,7 @@ RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len
         }
         if (has_end_pt) { // right (:518-561)
             uint32_t nbb = 0;
-            for (uint32_t x = i_s + 1; x < v_s.n && static_cast<uint64_t>(rtk_an_pos(v_s, x)) < u_min_end; ++x) consider(sr, rtk_an_um(v_s, x), nbb);
+            rtk_scan_anchor_runs(v_s, static_cast<int64_t>(i_s) + 1, +1, [&](uint32_t p) { return static_cast<uint64_t>(p) < u_min_end; }, [&](const UMap& um) { consider(sr, um, nbb); });
             const uint32_t v_w_sz = v_w.n;
             uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
             while (x < v_w_sz && rtk_an_pos(v_w, x) < p2) ++x;
