@@ -237,7 +237,10 @@ __device__ __forceinline__ SweepStat rtk_myers_fast(const char* __restrict__ qp,
 // Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
 // top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
-RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, int store, uint64_t* fin_pv, uint64_t* fin_mv) {
+RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq& t_, int top_h_, bool iupac_, int store_, uint64_t* fin_pv_, uint64_t* fin_mv_) {
+    const MyersScratch& sc = *rtk_u(&sc_);
+    MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
+    const int top_h = rtk_u(top_h_), store = rtk_u(store_); const bool iupac = rtk_u(iupac_); uint64_t* fin_pv = rtk_u(fin_pv_); uint64_t* fin_mv = rtk_u(fin_mv_);
     const int m = q.n, n = t.n, W = (m + 63) >> 6, last_bit = (m - 1) & 63;
 #ifdef RTK_SIM
     rtk_myers_build_peq(sc, q, W, iupac);
@@ -265,7 +268,7 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc, const MySeq& q, const MySeq& 
     const int lane = rtk_lane();
     // local copies: the scratch descriptor lives in private memory and its fields could alias the stores below,
     // which would force a (slow) reload of every pointer on every step
-    int8_t* __restrict__ const carry = sc.carry; int32_t* __restrict__ const colscore = sc.colscore; uint64_t* __restrict__ const tb = sc.tb;
+    int8_t* __restrict__ const carry = rtk_u(sc.carry); int32_t* __restrict__ const colscore = rtk_u(sc.colscore); uint64_t* __restrict__ const tb = rtk_u(sc.tb);
     const char* __restrict__ const tp = t.p; const int trev = t.rev;
     const char* __restrict__ const qp = q.p; const int qrev = q.rev;
     for (int w0 = 0; w0 < W; w0 += 64) {
@@ -363,8 +366,10 @@ struct MyersResult { int32_t dist, first, last, nloc; };
 // edlibAlign(..., TASK_DISTANCE): edit distance (or -1 if above a non-negative k), first and largest end location and
 // their number. SHW/HW report target position -1 (score m) when m % 64 != 0, like edlib's padded last block
 // (edlib.cpp:658-692). Optionally lists every end location (locs_out, up to cap).
-RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, int m, const char* t, int n, int k, int mode, bool iupac,
-                                        int32_t* locs_out = nullptr, int cap = 0) {
+RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int k_, int mode_, bool iupac_,
+                                        int32_t* locs_out_ = nullptr, int cap_ = 0) {
+    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), k = rtk_u(k_), mode = rtk_u(mode_), cap = rtk_u(cap_);
+    const bool iupac = rtk_u(iupac_); int32_t* locs_out = rtk_u(locs_out_);
     MyersResult r; r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
     if (m == 0 || n == 0) { // edlib.cpp:161-179
         if (mode == RTK_MODE_NW) { r.dist = m > n ? m : n; r.first = r.last = n - 1; }
@@ -433,20 +438,23 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc, const char* q, int
 
 // Canonical NW traceback over the stored table, preferring up (insert) > left (delete) > diagonal
 // (edlib.cpp:1021-1137). Appends the moves (already in forward order) to sc.moves at *n_moves.
-RTK_FN void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const MySeq& t, bool iupac, uint32_t* n_moves) {
+RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const MySeq& t_, bool iupac_, uint32_t* n_moves_) {
+    const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_); const bool iupac = rtk_u(iupac_);
+    MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
     const int m = q.n, n = t.n, W = (m + 63) >> 6;
     int cur;
 #ifndef RTK_SIM
     SweepStat fst; fst.plain = false;
-    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast<1>(q.p, m, t.p, n, 1, iupac, sc.tb);
+    uint64_t* const tbp = rtk_ld(&sc.tb);
+    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast<1>(q.p, m, t.p, n, 1, iupac, tbp);
     if (fst.plain) { cur = fst.final_score; rtk_sync(); }
     else
 #endif
-    { rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr); cur = sc.colscore[n - 1]; }
+    { rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr); cur = rtk_ld(rtk_ld(&sc.colscore) + (n - 1)); }
     int i = m, j = n;
     uint32_t nt = 0; // moves are produced backwards into moves_tmp, from its end
-    uint8_t* tmp = sc.moves_tmp;
-    const uint32_t cap = sc.mv_cap;
+    uint8_t* tmp = rtk_ld(&sc.moves_tmp);
+    const uint32_t cap = rtk_ld(&sc.mv_cap);
 #ifndef RTK_SIM
     // The wave keeps, for the current query word, the four delta words of 64 consecutive columns in registers
     // (lane l <-> column c_hi - l); a traceback step is then scalar (v_readlane), with one table reload per ~60 moves.
@@ -466,7 +474,7 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const My
         if (w != w_cur || c > c_hi || c_hi - c > 62) {
             c_hi = c; w_cur = w;
             const int col = c - lane;
-            if (col >= 0) { const uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(col) * W + w); e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3]; }
+            if (col >= 0) { const uint64_t* e = tbp + 4ull * (static_cast<uint64_t>(col) * W + w); e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3]; }
         }
         const int li = c_hi - c;
         const uint64_t a0 = RTK_RL64(e0, li), a1 = RTK_RL64(e1, li), a2 = RTK_RL64(e2, li), a3 = RTK_RL64(e3, li);
@@ -495,7 +503,8 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc, const MySeq& q, const My
 }
 
 // D(query rows, last column) after a pass: out[i] = D[i+1][n], from the final vertical delta vectors.
-RTK_FN void rtk_myers_column(const uint64_t* fin_pv, const uint64_t* fin_mv, int m, int n, int32_t* out) {
+RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, int m_, int n_, int32_t* out_) {
+    const uint64_t* fin_pv = rtk_u(fin_pv_); const uint64_t* fin_mv = rtk_u(fin_mv_); const int m = rtk_u(m_), n = rtk_u(n_); int32_t* out = rtk_u(out_);
     const int W = (m + 63) >> 6;
     // word prefix: value at the top of word w = n + sum over previous words of (popc(P) - popc(M)) restricted to valid rows
     for (int w0 = 0, base = n; w0 < W; w0 += RTK_WAVE) {
@@ -524,7 +533,9 @@ RTK_FN void rtk_myers_column(const uint64_t* fin_pv, const uint64_t* fin_mv, int
 // obtainAlignment (edlib.cpp:1164-1216) with the Hirschberg split of edlib.cpp:1234-1399 restated canonically:
 // target halved at n/2; the FIRST query row (ascending) whose left + right scores add up to the optimum, then the
 // row -1 boundary, then the last row. Iterative (explicit stack), emits moves in order into sc.moves.
-RTK_FN void rtk_myers_alignment(const MyersScratch& sc, const char* q, int m, const char* t, int n, int best, bool iupac, uint32_t* n_moves) {
+RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int best_, bool iupac_, uint32_t* n_moves_) {
+    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), best = rtk_u(best_);
+    const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_);
     *n_moves = 0;
     if (static_cast<uint32_t>(m + n) > sc.mv_cap || static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap || static_cast<uint32_t>(m) > sc.r_cap) { *sc.overflow = 1; return; }
     int32_t* st = sc.hstack;

@@ -73,6 +73,10 @@ struct RCtx { // everything a region program needs
     int k;
 };
 
+#ifndef RTK_SIM
+RTK_DEV UMap rtk_u(const UMap& m) { UMap r; r.unitig = rtk_u(m.unitig); r.dist = rtk_u(m.dist); r.len = rtk_u(m.len); r.strand = rtk_u(m.strand); return r; }
+#endif
+
 // ------------------------------------------------------------------------------------------------ helpers (src/Common.hpp:410-438)
 RTK_DEV char rtk_get_qual(double score, uint64_t qv_min, uint64_t qv_max) {
     const char phred_base_std = static_cast<char>(33);
@@ -94,7 +98,7 @@ RTK_DEV char rtk_comp(char c) {
 }
 
 RTK_DEV void rtk_fail_ovf(RegionScratch& s, uint32_t code) { *s.overflow = code; }
-RTK_DEV bool rtk_failed(const RegionScratch& s) { return *s.overflow != 0; }
+RTK_DEV bool rtk_failed(const RegionScratch& s) { return rtk_ld(rtk_ld(&s.overflow)) != 0; }
 
 // anchors of a read in forward or reverse-complement orientation (src/Correction.cpp:196-213)
 struct Anchors { const uint32_t* pos; const uint64_t* hit; const uint64_t* hits_by_pos; uint32_t n, L; int rev; int k; };
@@ -111,12 +115,13 @@ struct PathHdr { uint32_t n, l, qlen, pad; }; // followed by n UMap and qlen qua
 
 RTK_DEV uint64_t rtk_arena_alloc(RegionScratch& s, int lvl, uint64_t bytes) {
     bytes = (bytes + 15ull) & ~15ull;
-    if (s.top[lvl] + bytes > s.arena_cap) { rtk_fail_ovf(s, 3); return 0; }
-    const uint64_t off = s.top[lvl]; s.top[lvl] += bytes; return off;
+    const uint64_t off = rtk_ld(&s.top[lvl]);
+    if (off + bytes > rtk_ld(&s.arena_cap)) { rtk_fail_ovf(s, 3); return 0; }
+    s.top[lvl] = off + bytes; return off;
 }
-RTK_DEV PathHdr* rtk_path_hdr(const RegionScratch& s, int lvl, uint64_t h) { return reinterpret_cast<PathHdr*>(s.arena[lvl] + h); }
-RTK_DEV UMap* rtk_path_ums(const RegionScratch& s, int lvl, uint64_t h) { return reinterpret_cast<UMap*>(s.arena[lvl] + h + sizeof(PathHdr)); }
-RTK_DEV char* rtk_path_qual(const RegionScratch& s, int lvl, uint64_t h) { const PathHdr* p = rtk_path_hdr(s, lvl, h); return s.arena[lvl] + h + sizeof(PathHdr) + sizeof(UMap) * p->n; }
+RTK_DEV PathHdr* rtk_path_hdr(const RegionScratch& s, int lvl, uint64_t h) { return reinterpret_cast<PathHdr*>(rtk_ld(&s.arena[lvl]) + h); }
+RTK_DEV UMap* rtk_path_ums(const RegionScratch& s, int lvl, uint64_t h) { return reinterpret_cast<UMap*>(rtk_ld(&s.arena[lvl]) + h + sizeof(PathHdr)); }
+RTK_DEV char* rtk_path_qual(const RegionScratch& s, int lvl, uint64_t h) { const PathHdr* p = rtk_path_hdr(s, lvl, h); return reinterpret_cast<char*>(const_cast<PathHdr*>(p)) + sizeof(PathHdr) + sizeof(UMap) * rtk_ld(&p->n); }
 // handles carry their level in the top 2 bits
 RTK_DEV uint64_t rtk_mk_handle(int lvl, uint64_t off) { return (static_cast<uint64_t>(lvl) << 62) | off; }
 RTK_DEV int rtk_h_lvl(uint64_t h) { return static_cast<int>(h >> 62); }
@@ -124,43 +129,54 @@ RTK_DEV uint64_t rtk_h_off(uint64_t h) { return h & 0x3FFFFFFFFFFFFFFFull; }
 
 RTK_DEV void rtk_wp_clear(WPath& p) { p.n = 0; p.l = 0; p.qlen = 0; }
 
-RTK_FN uint64_t rtk_wp_commit(RegionScratch& s, const WPath& p, int lvl) { // working path -> immutable record
+RTK_FN uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_) { // working path -> immutable record
+    RegionScratch& s = *rtk_u(&s_); const WPath& p = *rtk_u(&p_); const int lvl = rtk_u(lvl_);
     const unsigned long long tc0 = rtk_clock();
-    const uint64_t off = rtk_arena_alloc(s, lvl, sizeof(PathHdr) + sizeof(UMap) * p.n + p.qlen);
+    const uint32_t pn = rtk_ld(&p.n), pl = rtk_ld(&p.l), pq = rtk_ld(&p.qlen);
+    const uint64_t off = rtk_arena_alloc(s, lvl, sizeof(PathHdr) + sizeof(UMap) * pn + pq);
     if (rtk_failed(s)) return 0;
-    PathHdr* h = rtk_path_hdr(s, lvl, off);
-    h->n = p.n; h->l = p.l; h->qlen = p.qlen; h->pad = 0;
-    rtk_wcopy(rtk_path_ums(s, lvl, off), p.ums, sizeof(UMap) * p.n);
-    rtk_wcopy(s.arena[lvl] + off + sizeof(PathHdr) + sizeof(UMap) * p.n, p.qual, p.qlen);
+    char* rec = rtk_ld(&s.arena[lvl]) + off;
+    PathHdr* h = reinterpret_cast<PathHdr*>(rec);
+    h->n = pn; h->l = pl; h->qlen = pq; h->pad = 0;
+    rtk_wcopy2(rec + sizeof(PathHdr), rtk_ld(&p.ums), sizeof(UMap) * pn, rec + sizeof(PathHdr) + sizeof(UMap) * pn, rtk_ld(&p.qual), pq);
     s.cnt[11] += rtk_clock() - tc0;
     return rtk_mk_handle(lvl, off);
 }
 
-RTK_FN void rtk_wp_load(RegionScratch& s, WPath& p, uint64_t h) {
+RTK_FN void rtk_wp_load(RegionScratch& s_, WPath& p_, uint64_t h_) {
+    RegionScratch& s = *rtk_u(&s_); WPath& p = *rtk_u(&p_); const uint64_t h = rtk_u(h_);
     const int lvl = rtk_h_lvl(h); const uint64_t off = rtk_h_off(h);
-    const PathHdr* hd = rtk_path_hdr(s, lvl, off);
-    if (hd->n > s.um_cap || hd->qlen > s.str_cap) { rtk_fail_ovf(s, 4); rtk_wp_clear(p); return; }
+    const char* rec = rtk_ld(&s.arena[lvl]) + off;
+    const PathHdr* hd = reinterpret_cast<const PathHdr*>(rec);
+    const uint32_t hn = rtk_ld(&hd->n), hl = rtk_ld(&hd->l), hq = rtk_ld(&hd->qlen);
+    if (hn > rtk_ld(&s.um_cap) || hq > rtk_ld(&s.str_cap)) { rtk_fail_ovf(s, 4); rtk_wp_clear(p); return; }
     const unsigned long long tc0 = rtk_clock();
-    p.n = hd->n; p.l = hd->l; p.qlen = hd->qlen;
-    rtk_wcopy(p.ums, rtk_path_ums(s, lvl, off), sizeof(UMap) * hd->n);
-    rtk_wcopy(p.qual, rtk_path_qual(s, lvl, off), hd->qlen);
+    p.n = hn; p.l = hl; p.qlen = hq;
+    rtk_wcopy2(rtk_ld(&p.ums), rec + sizeof(PathHdr), sizeof(UMap) * hn, rtk_ld(&p.qual), rec + sizeof(PathHdr) + sizeof(UMap) * hn, hq);
     s.cnt[11] += rtk_clock() - tc0;
 }
 
-RTK_DEV uint32_t rtk_rec_n(const RegionScratch& s, uint64_t h) { return rtk_path_hdr(s, rtk_h_lvl(h), rtk_h_off(h))->n; }
-RTK_DEV uint32_t rtk_rec_l(const RegionScratch& s, uint64_t h) { return rtk_path_hdr(s, rtk_h_lvl(h), rtk_h_off(h))->l; }
-RTK_DEV UMap rtk_rec_back(const RegionScratch& s, uint64_t h) { const int lv = rtk_h_lvl(h); const uint64_t o = rtk_h_off(h); return rtk_path_ums(s, lv, o)[rtk_path_hdr(s, lv, o)->n - 1]; }
+RTK_DEV uint32_t rtk_rec_n(const RegionScratch& s, uint64_t h) { return rtk_ld(&rtk_path_hdr(s, rtk_h_lvl(h), rtk_h_off(h))->n); }
+RTK_DEV uint32_t rtk_rec_l(const RegionScratch& s, uint64_t h) { return rtk_ld(&rtk_path_hdr(s, rtk_h_lvl(h), rtk_h_off(h))->l); }
+RTK_DEV UMap rtk_rec_back(const RegionScratch& s, uint64_t h) { const int lv = rtk_h_lvl(h); const uint64_t o = rtk_h_off(h); const char* rec = rtk_ld(&s.arena[lv]) + o; return rtk_u(reinterpret_cast<const UMap*>(rec + sizeof(PathHdr))[rtk_ld(&reinterpret_cast<const PathHdr*>(rec)->n) - 1]); }
 
+RTK_DEV uint32_t rtk_nkm_u(const RCtx& c, uint32_t u) { // k-mers of unitig u, uniform
+    const uint64_t* uo = rtk_u(c.g.uoff) + u;
+    return static_cast<uint32_t>(rtk_ld(uo + 1) - rtk_ld(uo)) - static_cast<uint32_t>(rtk_u(c.k)) + 1u;
+}
 RTK_DEV void rtk_wp_norm_back(const RCtx& c, WPath& p) { // the former end becomes a whole unitig (Path.hpp:319-323)
-    if (p.n >= 2) { UMap& e = p.ums[p.n - 1]; e.dist = 0; e.len = rtk_nkm(c.g, e.unitig); }
+    const uint32_t pn = rtk_ld(&p.n);
+    if (pn >= 2) { UMap* e = rtk_ld(&p.ums) + (pn - 1); e->dist = 0; e->len = rtk_nkm_u(c, rtk_ld(&e->unitig)); }
 }
 
-RTK_FN void rtk_wp_extend(const RCtx& c, WPath& p, const UMap& um) { // Path.hpp:308-330
-    RegionScratch& s = *c.sc;
+RTK_FN void rtk_wp_extend(const RCtx& c, WPath& p_, const UMap& um_) { // Path.hpp:308-330
+    RegionScratch& s = *rtk_u(c.sc); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_);
     if (rtk_um_is_empty(um)) return;
-    if (p.n >= s.um_cap) { rtk_fail_ovf(s, 5); return; }
-    if (p.n == 0) { p.ums[0] = um; p.n = 1; p.l = um.len + static_cast<uint32_t>(c.k) - 1; }
-    else { rtk_wp_norm_back(c, p); p.ums[p.n] = um; ++p.n; p.l += um.len; }
+    const uint32_t pn = rtk_ld(&p.n);
+    if (pn >= rtk_ld(&s.um_cap)) { rtk_fail_ovf(s, 5); return; }
+    UMap* ums = rtk_ld(&p.ums);
+    if (pn == 0) { ums[0] = um; p.n = 1; p.l = um.len + static_cast<uint32_t>(rtk_u(c.k)) - 1; }
+    else { rtk_wp_norm_back(c, p); ums[pn] = um; p.n = pn + 1; p.l = rtk_ld(&p.l) + um.len; }
 }
 
 // extend with a quality slice q[0..qn) (Path.hpp:332-363): appended only when its length equals um.len + k - 1
@@ -256,24 +272,29 @@ RTK_FN void rtk_wp_prune_prefix(const RCtx& c, WPath& p, uint32_t len) { // Path
 
 // mappedSequenceToString of one mapping into dst (lane-parallel 2-bit decode, reverse complement on the fly)
 RTK_DEV void rtk_um_decode(const RCtx& c, const UMap& um, char* dst, uint32_t skip) {
-    const uint32_t n = um.len + static_cast<uint32_t>(c.k) - 1;
-    const uint64_t b0 = c.g.uoff[um.unitig] + um.dist;
+    const uint32_t n = um.len + static_cast<uint32_t>(rtk_u(c.k)) - 1;
+    const uint64_t b0 = rtk_ld(rtk_u(c.g.uoff) + um.unitig) + um.dist;
+    const uint64_t* useq = rtk_u(c.g.useq);
     for (uint32_t i = skip + static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) {
-        const uint32_t code = um.strand ? rtk_base(c.g, b0 + i) : (3u - rtk_base(c.g, b0 + (n - 1 - i)));
-        dst[i - skip] = "ACGT"[code];
+        const uint64_t pos = um.strand ? (b0 + i) : (b0 + (n - 1 - i));
+        const uint32_t b = static_cast<uint32_t>((useq[pos >> 5] >> (2 * (pos & 31))) & 3ull);
+        const uint32_t code = um.strand ? b : (3u - b);
+        dst[i - skip] = static_cast<char>((0x54474341u >> (8 * code)) & 0xFFu); // "ACGT"
     }
 }
 
 // Path::toString (Path.hpp:449-485) of `n` mappings into dst; returns length (0xFFFFFFFF on overflow)
-RTK_FN uint32_t rtk_ums_to_string(const RCtx& c, const UMap* ums, uint32_t n, char* dst) {
-    RegionScratch& s = *c.sc;
+RTK_FN uint32_t rtk_ums_to_string(const RCtx& c, const UMap* ums_, uint32_t n_, char* dst_) {
+    RegionScratch& s = *rtk_u(c.sc); const UMap* ums = rtk_u(ums_); const uint32_t n = rtk_u(n_); char* dst = rtk_u(dst_);
     const unsigned long long tc0 = rtk_clock();
     uint32_t len = 0;
+    const uint32_t k1 = static_cast<uint32_t>(rtk_u(c.k)) - 1, str_cap = rtk_ld(&s.str_cap);
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t skip = i ? static_cast<uint32_t>(c.k) - 1 : 0;
-        const uint32_t add = ums[i].len + static_cast<uint32_t>(c.k) - 1 - skip;
-        if (len + add > s.str_cap) { rtk_fail_ovf(s, 7); return 0xFFFFFFFFu; }
-        rtk_um_decode(c, ums[i], dst + len, skip);
+        const UMap um = rtk_u(ums[i]);
+        const uint32_t skip = i ? k1 : 0;
+        const uint32_t add = um.len + k1 - skip;
+        if (len + add > str_cap) { rtk_fail_ovf(s, 7); return 0xFFFFFFFFu; }
+        rtk_um_decode(c, um, dst + len, skip);
         len += add;
     }
     rtk_sync();
@@ -282,12 +303,13 @@ RTK_FN uint32_t rtk_ums_to_string(const RCtx& c, const UMap* ums, uint32_t n, ch
     return len;
 }
 RTK_DEV uint32_t rtk_rec_to_string(const RCtx& c, uint64_t h, char* dst) {
-    const RegionScratch& s = *c.sc;
+    const RegionScratch& s = *rtk_u(c.sc);
     return rtk_ums_to_string(c, rtk_path_ums(s, rtk_h_lvl(h), rtk_h_off(h)), rtk_rec_n(s, h), dst);
 }
 
-RTK_FN MyersResult rtk_align(const RCtx& c, const char* q, uint32_t m, const char* t, uint32_t n, int kk, int mode, bool iupac = true) {
-    RegionScratch& s = *c.sc;
+RTK_FN MyersResult rtk_align(const RCtx& c, const char* q_, uint32_t m_, const char* t_, uint32_t n_, int kk_, int mode_, bool iupac_ = true) {
+    RegionScratch& s = *rtk_u(c.sc); const char* q = rtk_u(q_); const char* t = rtk_u(t_);
+    const uint32_t m = rtk_u(m_), n = rtk_u(n_); const int kk = rtk_u(kk_), mode = rtk_u(mode_); const bool iupac = rtk_u(iupac_);
     s.cnt[3] += 1; s.cnt[4] += static_cast<unsigned long long>((m + 63) / 64) * n;
     const unsigned long long t0 = rtk_clock();
     const MyersResult r = rtk_myers_distance(s.my, q, static_cast<int>(m), t, static_cast<int>(n), kk, mode, iupac);
@@ -297,20 +319,23 @@ RTK_FN MyersResult rtk_align(const RCtx& c, const char* q, uint32_t m, const cha
 
 // ------------------------------------------------------------------------------------------------ candidate selection (src/Alignment.cpp:3-147, 967-1015)
 // handles[] are committed paths; strings are materialised into str[0].
-RTK_FN void rtk_select_best(const RCtx& c, const uint64_t* handles, uint32_t n, const char* ref, uint32_t ref_len, int mode, double cut, int* best_id, int* best_end) {
-    RegionScratch& s = *c.sc;
+RTK_FN void rtk_select_best(const RCtx& c, const uint64_t* handles_, uint32_t n_, const char* ref_, uint32_t ref_len_, int mode_, double cut_, int* best_id, int* best_end) {
+    RegionScratch& s = *rtk_u(c.sc); const uint64_t* handles = rtk_u(handles_); const uint32_t n = rtk_u(n_), ref_len = rtk_u(ref_len_); const char* ref = rtk_u(ref_);
+    const int mode = rtk_u(mode_); const double cut = rtk_u(cut_);
     double best = 0.0; int bid = -1, bend = -1;
+    char* const str0 = rtk_ld(&s.str[0]);
     for (uint32_t i = 0; i < n && !rtk_failed(s); ++i) {
-        const uint32_t sl = rtk_rec_to_string(c, handles[i], s.str[0]);
+        const uint32_t sl = rtk_rec_to_string(c, rtk_ld(handles + i), str0);
         if (sl == 0xFFFFFFFFu) break;
         const uint32_t norm = (mode == RTK_MODE_NW) ? (sl > ref_len ? sl : ref_len) : sl;
         if (i == 0) {
-            const MyersResult a = rtk_align(c, s.str[0], sl, ref, ref_len, -1, mode);
-            best = static_cast<double>(a.dist) / static_cast<double>(norm); bend = a.first; bid = 0;
+            const MyersResult a = rtk_align(c, str0, sl, ref, ref_len, -1, mode);
+            best = static_cast<double>(rtk_u(a.dist)) / static_cast<double>(norm); bend = rtk_u(a.first); bid = 0;
         } else {
             const int kk = static_cast<int>(best * static_cast<double>(norm) + 1.0); // G5: double -> int as edlibNewAlignConfig receives it
-            const MyersResult a = rtk_align(c, s.str[0], sl, ref, ref_len, kk, mode);
-            if (a.dist >= 0 && (static_cast<double>(a.dist) / static_cast<double>(norm)) < best) { best = static_cast<double>(a.dist) / static_cast<double>(norm); bend = a.first; bid = static_cast<int>(i); }
+            const MyersResult a = rtk_align(c, str0, sl, ref, ref_len, kk, mode);
+            const int ad = rtk_u(a.dist);
+            if (ad >= 0 && (static_cast<double>(ad) / static_cast<double>(norm)) < best) { best = static_cast<double>(ad) / static_cast<double>(norm); bend = rtk_u(a.first); bid = static_cast<int>(i); }
         }
     }
     if (mode != RTK_MODE_NW && cut > 0.0 && best > cut) { bid = -1; bend = -1; }
@@ -319,17 +344,18 @@ RTK_FN void rtk_select_best(const RCtx& c, const uint64_t* handles, uint32_t n, 
 
 // ------------------------------------------------------------------------------------------------ scoring (src/GraphTraversal.cpp:867-909, 722-772)
 // path string must already be in str[1] (length sl)
-RTK_FN double rtk_score_path(const RCtx& c, uint32_t sl, const char* ref, uint32_t ref_len, bool terminal) {
-    RegionScratch& s = *c.sc;
+RTK_FN double rtk_score_path(const RCtx& c, uint32_t sl_, const char* ref_, uint32_t ref_len_, bool terminal_) {
+    RegionScratch& s = *rtk_u(c.sc); const uint32_t sl = rtk_u(sl_), ref_len = rtk_u(ref_len_); const char* ref = rtk_u(ref_); const bool terminal = rtk_u(terminal_);
     double score = 0.0;
     if (sl != 0) {
-        if (terminal) { const MyersResult a = rtk_align(c, s.str[1], sl, ref, ref_len, -1, RTK_MODE_NW); score = 1.0 - (static_cast<double>(a.dist) / static_cast<double>(sl)); }
-        else if (sl >= ref_len) { const MyersResult a = rtk_align(c, ref, ref_len, s.str[1], sl, -1, RTK_MODE_HW); score = 1.0 - (static_cast<double>(a.dist) / static_cast<double>(ref_len)); }
+        const char* const str1 = rtk_ld(&s.str[1]);
+        if (terminal) { const MyersResult a = rtk_align(c, str1, sl, ref, ref_len, -1, RTK_MODE_NW); score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(sl)); }
+        else if (sl >= ref_len) { const MyersResult a = rtk_align(c, ref, ref_len, str1, sl, -1, RTK_MODE_HW); score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(ref_len)); }
         else {
-            const uint64_t cap = static_cast<uint64_t>(static_cast<double>(sl) * (1.0 + c.o.weak_region_len_factor));
+            const uint64_t cap = static_cast<uint64_t>(static_cast<double>(sl) * (1.0 + rtk_u(c.o.weak_region_len_factor)));
             const uint32_t l_ref_len = ref_len < cap ? ref_len : static_cast<uint32_t>(cap);
-            const MyersResult a = rtk_align(c, s.str[1], sl, ref, l_ref_len, -1, RTK_MODE_HW);
-            score = 1.0 - (static_cast<double>(a.dist) / static_cast<double>(sl));
+            const MyersResult a = rtk_align(c, str1, sl, ref, l_ref_len, -1, RTK_MODE_HW);
+            score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(sl));
         }
         score = score > 0.0 ? score : 0.0; score = score < 1.0 ? score : 1.0;
     }
@@ -337,19 +363,21 @@ RTK_FN double rtk_score_path(const RCtx& c, uint32_t sl, const char* ref, uint32
 }
 
 // quality string of a path (SHW path alignment against ref) written to qout[0..sl); path string in str[1]
-RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl, const char* ref, uint32_t ref_len, double score_best, double score_second, char* qout) {
-    RegionScratch& s = *c.sc;
+RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl_, const char* ref_, uint32_t ref_len_, double score_best_, double score_second_, char* qout_) {
+    RegionScratch& s = *rtk_u(c.sc); const uint32_t sl = rtk_u(sl_), ref_len = rtk_u(ref_len_); const char* ref = rtk_u(ref_); char* qout = rtk_u(qout_);
+    const double score_best = rtk_u(score_best_), score_second = rtk_u(score_second_);
     const unsigned long long tq0 = rtk_clock();
     const double score_comp = score_best * ((score_best == 0.0) ? 0.0 : (1.0 - (score_second / score_best)));
-    const MyersResult a = rtk_align(c, s.str[1], sl, ref, ref_len, -1, RTK_MODE_SHW);
+    const char* const str1 = rtk_ld(&s.str[1]);
+    const MyersResult a = rtk_align(c, str1, sl, ref, ref_len, -1, RTK_MODE_SHW);
     uint32_t nm = 0;
-    if (sl > 0 && ref_len > 0) { s.cnt[3] += 1; rtk_myers_alignment(s.my, s.str[1], static_cast<int>(sl), ref, a.first + 1, a.dist, true, &nm); }
-    const char c_best = rtk_get_qual(score_best, 0, static_cast<uint64_t>(c.o.max_qual));
-    rtk_wfill(qout, rtk_get_qual(score_comp, static_cast<uint64_t>(c.o.out_qual), static_cast<uint64_t>(c.o.max_qual)), sl);
+    if (sl > 0 && ref_len > 0) { s.cnt[3] += 1; rtk_myers_alignment(s.my, str1, static_cast<int>(sl), ref, rtk_u(a.first) + 1, rtk_u(a.dist), true, &nm); nm = rtk_u(nm); }
+    const char c_best = rtk_get_qual(score_best, 0, static_cast<uint64_t>(rtk_u(c.o.max_qual)));
+    rtk_wfill(qout, rtk_get_qual(score_comp, static_cast<uint64_t>(rtk_u(c.o.out_qual)), static_cast<uint64_t>(rtk_u(c.o.max_qual))), sl);
     // walk the moves: a base gets the best-score quality when it sits on an identical reference base in an M run.
     // query/reference positions of every move come from a prefix count of the moves (chunked wave scan).
     uint32_t qp = 0, rp = 0;
-    const uint8_t* mv = s.my.moves;
+    const uint8_t* mv = rtk_ld(&s.my.moves);
     for (uint32_t i0 = 0; i0 < nm; i0 += RTK_WAVE) {
         const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
         const uint8_t m = i < nm ? mv[i] : 255;
@@ -357,7 +385,7 @@ RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl, const char* ref, uin
         const uint64_t bq = rtk_ballot(isq), br = rtk_ballot(isr);
         const uint64_t lt = (1ull << rtk_lane()) - 1ull;
         const uint32_t myq = qp + static_cast<uint32_t>(rtk_popc(bq & lt)), myr = rp + static_cast<uint32_t>(rtk_popc(br & lt));
-        if ((m == 0 || m == 3) && s.str[1][myq] == ref[myr]) qout[myq] = c_best;
+        if ((m == 0 || m == 3) && str1[myq] == ref[myr]) qout[myq] = c_best;
         qp += static_cast<uint32_t>(rtk_popc(bq)); rp += static_cast<uint32_t>(rtk_popc(br));
     }
     rtk_sync();
@@ -365,12 +393,18 @@ RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl, const char* ref, uin
 }
 
 // ------------------------------------------------------------------------------------------------ colour memo (src/GraphTraversal.cpp:485-487)
-RTK_FN bool rtk_colour_ok(const RCtx& c, uint32_t u, const uint32_t* all_pids, uint32_t n_all) {
-    RegionScratch& s = *c.sc;
-    for (uint32_t i = 0; i < s.memo_n; ++i) if (s.memo_u[i] == u) return s.memo_v[i] != 0;
-    const bool ok = (n_all == 0) || (rtk_shared_with_set(c.g, u, all_pids, n_all, c.o.min_cov_vertices) >= c.o.min_cov_vertices);
-    s.cnt[1] += c.g.card[u] + n_all;
-    if (s.memo_n < s.memo_cap) { s.memo_u[s.memo_n] = u; s.memo_v[s.memo_n] = ok ? 1 : 0; ++s.memo_n; }
+RTK_FN bool rtk_colour_ok(const RCtx& c, uint32_t u_, const uint32_t* all_pids_, uint32_t n_all_) {
+    RegionScratch& s = *rtk_u(c.sc); const uint32_t u = rtk_u(u_), n_all = rtk_u(n_all_); const uint32_t* all_pids = rtk_u(all_pids_);
+    const uint32_t mn = rtk_ld(&s.memo_n); const uint32_t* mu = rtk_ld(&s.memo_u); uint8_t* mvv = rtk_ld(&s.memo_v);
+    for (uint32_t i0 = 0; i0 < mn; i0 += RTK_WAVE) { // 64 memo entries per step
+        const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+        const uint64_t hit = rtk_ballot(i < mn && mu[i] == u);
+        if (hit) return rtk_ld(mvv + i0 + static_cast<uint32_t>(rtk_ffs(hit) - 1)) != 0;
+    }
+    const uint32_t mcv = static_cast<uint32_t>(rtk_u(c.o.min_cov_vertices));
+    const bool ok = (n_all == 0) || (rtk_u(rtk_shared_with_set(c.g, u, all_pids, n_all, mcv)) >= mcv);
+    s.cnt[1] += rtk_ld(rtk_u(c.g.card) + u) + n_all;
+    if (mn < rtk_ld(&s.memo_cap)) { const_cast<uint32_t*>(mu)[mn] = u; mvv[mn] = ok ? 1 : 0; s.memo_n = mn + 1; rtk_sync(); }
     return ok;
 }
 
@@ -379,48 +413,61 @@ RTK_DEV bool rtk_edge_bit(const GraphView& g, uint32_t u, uint32_t strand, int b
     return strand ? ((g.flags[u] & (idx << 4)) != 0) : ((g.flags[u] & idx) != 0);
 }
 RTK_DEV int rtk_nb_successors(const GraphView& g, const UMap& um) {
-    const uint32_t* a = g.adj + 8ull * um.unitig + (um.strand ? 0 : 4);
-    int n = 0; for (int b = 0; b < 4; ++b) n += (a[b] != RTK_NONE32) ? 1 : 0; return n;
+    const uint32_t* a = rtk_u(g.adj) + 8ull * um.unitig + (um.strand ? 0 : 4);
+    int n = 0; for (int b = 0; b < 4; ++b) n += (rtk_ld(a + b) != RTK_NONE32) ? 1 : 0; return n;
 }
 
 // ------------------------------------------------------------------------------------------------ DFS (src/GraphTraversal.cpp:456-587)
 // Results: handles of terminal / non-terminal paths (level-2 arena) in list[2] / list[3]; returns counts and best scores.
 struct DfsOut { uint32_t n_t, n_nt; double t1, nt1; };
 
-RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids, uint32_t n_all, const char* ref, uint32_t ref_len, uint32_t max_len_path,
-                                    const UMap& um, const UMap& um_e, uint32_t level) {
-    RegionScratch& s = *c.sc;
+RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, uint32_t max_len_path_,
+                                    const UMap& um_, const UMap& um_e_, uint32_t level_) {
+    RegionScratch& s = *rtk_u(c.sc);
+    const uint32_t* all_pids = rtk_u(all_pids_); const char* ref = rtk_u(ref_);
+    const uint32_t n_all = rtk_u(n_all_), ref_len = rtk_u(ref_len_), max_len_path = rtk_u(max_len_path_), level = rtk_u(level_);
+    const UMap um = rtk_u(um_), um_e = rtk_u(um_e_);
     DfsOut out; out.n_t = 0; out.n_nt = 0; out.t1 = 0.0; out.nt1 = 0.0;
     double score_t1 = 0.0, score_nt1 = 0.0, score_t2 = 0.0, score_nt2 = 0.0;
+    uint32_t n_t = 0, n_nt = 0;
     s.top[2] = 0;
-    uint64_t* T = s.list[2]; uint64_t* NT = s.list[3];
-    uint64_t* stk = s.list[4]; uint32_t sp = 0; // entries: handle (0 = empty path) and level, two words each
+    uint64_t* T = rtk_ld(&s.list[2]); uint64_t* NT = rtk_ld(&s.list[3]);
+    uint64_t* stk = rtk_ld(&s.list[4]); uint32_t sp = 0; // entries: handle (0 = empty path) and level, two words each
+    const uint32_t list_cap = rtk_ld(&s.list_cap);
+    char* const str1 = rtk_ld(&s.str[1]); char* const str2 = rtk_ld(&s.str[2]);
+    const uint32_t* const g_adj = rtk_u(c.g.adj); const uint32_t* const g_flags = rtk_u(c.g.flags);
     stk[0] = ~0ull; stk[1] = level; sp = 1;
     WPath& w = s.wp[2];
+    const bool has_end = !rtk_um_is_empty(um_e);
+    unsigned long long n_exp = 0;
     while (sp > 0 && !rtk_failed(s)) {
         --sp;
-        const uint64_t hp = stk[2 * sp]; const uint32_t lvl = static_cast<uint32_t>(stk[2 * sp + 1]);
+        const uint64_t hp = rtk_ld(stk + 2 * sp); const uint32_t lvl = static_cast<uint32_t>(rtk_ld(stk + 2 * sp + 1));
         const UMap um_start = (hp == ~0ull) ? um : rtk_rec_back(s, hp);
-        const uint32_t* adj = c.g.adj + 8ull * um_start.unitig + (um_start.strand ? 0 : 4);
-        s.cnt[0] += 1;
+        const uint32_t* adj = g_adj + 8ull * um_start.unitig + (um_start.strand ? 0 : 4);
+        ++n_exp;
+        // the four neighbour slots and the edge bits of this unitig, fetched together
+        const uint32_t a4[4] = { rtk_ld(adj), rtk_ld(adj + 1), rtk_ld(adj + 2), rtk_ld(adj + 3) };
+        const uint32_t eb = (rtk_ld(g_flags + um_start.unitig) >> (um_start.strand ? 4 : 0)) & 0xFu; // UnitigData::getSharedPids (UnitigData.hpp:275-284)
         for (int b = 0; b < 4 && !rtk_failed(s); ++b) {
-            if (adj[b] == RTK_NONE32) continue;
-            UMap sc; sc.unitig = adj[b] >> 1; sc.strand = adj[b] & 1u; sc.dist = 0; sc.len = rtk_nkm(c.g, sc.unitig);
-            const bool col_ok = rtk_colour_ok(c, sc.unitig, all_pids, n_all);
-            if (!(rtk_edge_bit(c.g, um_start.unitig, um_start.strand, b) && col_ok)) continue;
-            if (!rtk_um_is_empty(um_e) && sc.unitig == um_e.unitig && um_e.strand == sc.strand) { // terminal
+            const uint32_t ab = a4[b];
+            if (ab == RTK_NONE32) continue;
+            UMap sc; sc.unitig = ab >> 1; sc.strand = ab & 1u; sc.dist = 0; sc.len = rtk_nkm_u(c, sc.unitig);
+            const bool col_ok = rtk_u(rtk_colour_ok(c, sc.unitig, all_pids, n_all));
+            if (!(((eb >> b) & 1u) && col_ok)) continue;
+            if (has_end && sc.unitig == um_e.unitig && um_e.strand == sc.strand) { // terminal
                 if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
                 UMap pref = sc;
-                if (pref.strand) { pref.dist = 0; pref.len = um_e.dist + 1; } else { pref.dist = um_e.dist; pref.len = rtk_nkm(c.g, sc.unitig) - um_e.dist; }
+                if (pref.strand) { pref.dist = 0; pref.len = um_e.dist + 1; } else { pref.dist = um_e.dist; pref.len = sc.len - um_e.dist; }
                 rtk_wp_extend(c, w, pref);
-                if (w.l <= max_len_path && !rtk_failed(s)) {
-                    const uint32_t sl = rtk_ums_to_string(c, w.ums, w.n, s.str[1]);
+                if (rtk_ld(&w.l) <= max_len_path && !rtk_failed(s)) {
+                    const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
                     if (sl == 0xFFFFFFFFu) break;
-                    const double sco = rtk_score_path(c, sl, ref, ref_len, true);
+                    const double sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, true));
                     if (sco >= score_t1) {
-                        if (sco > score_t1) out.n_t = 0;
-                        if (out.n_t >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
-                        T[out.n_t++] = rtk_wp_commit(s, w, 2);
+                        if (sco > score_t1) n_t = 0;
+                        if (n_t >= list_cap) { rtk_fail_ovf(s, 8); break; }
+                        T[n_t++] = rtk_wp_commit(s, w, 2);
                         score_t2 = score_t1; score_t1 = sco;
                     } else if (sco > score_t2) score_t2 = sco;
                 }
@@ -430,35 +477,36 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids, uint
                 rtk_wp_extend(c, w, sc);
                 if (rtk_failed(s)) break;
                 if (lvl != 0) {
-                    if (2 * (sp + 1) > s.list_cap) { rtk_fail_ovf(s, 8); break; }
+                    if (2 * (sp + 1) > list_cap) { rtk_fail_ovf(s, 8); break; }
                     stk[2 * sp] = rtk_wp_commit(s, w, 2); stk[2 * sp + 1] = lvl - 1; ++sp;
                 } else if (rtk_nb_successors(c.g, sc) > 0) {
-                    const uint32_t sl = rtk_ums_to_string(c, w.ums, w.n, s.str[1]);
+                    const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
                     if (sl == 0xFFFFFFFFu) break;
-                    const double sco = rtk_score_path(c, sl, ref, ref_len, false);
+                    const double sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, false));
                     if (sco >= score_nt1) {
-                        if (sco > score_nt1) out.n_nt = 0;
-                        if (out.n_nt >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
-                        NT[out.n_nt++] = rtk_wp_commit(s, w, 2);
+                        if (sco > score_nt1) n_nt = 0;
+                        if (n_nt >= list_cap) { rtk_fail_ovf(s, 8); break; }
+                        NT[n_nt++] = rtk_wp_commit(s, w, 2);
                         score_nt2 = score_nt1; score_nt1 = sco;
                     } else if (sco > score_nt2) score_nt2 = sco;
                 }
             }
         }
     }
+    s.cnt[0] += n_exp;
     // qualities (:556-584): re-commit every surviving path with its quality string
     for (int which = 0; which < 2 && !rtk_failed(s); ++which) {
-        uint64_t* L = which ? NT : T; const uint32_t nL = which ? out.n_nt : out.n_t;
+        uint64_t* L = which ? NT : T; const uint32_t nL = which ? n_nt : n_t;
         for (uint32_t i = 0; i < nL && !rtk_failed(s); ++i) {
-            rtk_wp_load(s, w, L[i]);
-            const uint32_t sl = rtk_ums_to_string(c, w.ums, w.n, s.str[1]);
-            if (sl == 0xFFFFFFFFu || sl > s.str_cap) { rtk_fail_ovf(s, 7); break; }
-            rtk_score_path_qual(c, sl, ref, ref_len, which ? score_nt1 : score_t1, which ? score_nt2 : score_t2, s.str[2]);
-            if (sl == w.l) { rtk_wcopy(w.qual, s.str[2], sl); w.qlen = sl; } // Path::setQuality only accepts q.length() == l
+            rtk_wp_load(s, w, rtk_ld(L + i));
+            const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
+            if (sl == 0xFFFFFFFFu || sl > rtk_ld(&s.str_cap)) { rtk_fail_ovf(s, 7); break; }
+            rtk_score_path_qual(c, sl, ref, ref_len, which ? score_nt1 : score_t1, which ? score_nt2 : score_t2, str2);
+            if (sl == rtk_ld(&w.l)) { rtk_wcopy(rtk_ld(&w.qual), str2, sl); w.qlen = sl; } // Path::setQuality only accepts q.length() == l
             L[i] = rtk_wp_commit(s, w, 2);
         }
     }
-    out.t1 = score_t1; out.nt1 = score_nt1;
+    out.n_t = n_t; out.n_nt = n_nt; out.t1 = score_t1; out.nt1 = score_nt1;
     return out;
 }
 

@@ -30,6 +30,8 @@ inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
 template <class T> inline T rtk_atomic_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long rtk_clock() { return 0; }
+// rtk_u(v): "v is the same in every lane" (identity on the value)
+template <class T> inline T rtk_u(T v) { return v; }
 
 #else
 
@@ -49,6 +51,21 @@ __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
 template <class T> __device__ __forceinline__ T rtk_atomic_add(T* p, T v) { return atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long rtk_clock() { return static_cast<unsigned long long>(clock64()); }
+// rtk_u(v): "v is the same in every lane". Identity on the value; tells the compiler to keep it in scalar registers, so the region
+// program's control state, pointers and loop counters live in SGPRs (scalar ALU, scalar branches, spills into VGPR lanes instead of
+// 64-wide stores to the stack). Only ever applied to values that are wave-uniform by construction.
+__device__ __forceinline__ uint32_t rtk_u(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+__device__ __forceinline__ int32_t rtk_u(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool rtk_u(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
+__device__ __forceinline__ unsigned long long rtk_u(unsigned long long v) {
+    const uint32_t lo = rtk_u(static_cast<uint32_t>(v)), hi = rtk_u(static_cast<uint32_t>(v >> 32));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+__device__ __forceinline__ unsigned long rtk_u(unsigned long v) { return static_cast<unsigned long>(rtk_u(static_cast<unsigned long long>(v))); }
+__device__ __forceinline__ long rtk_u(long v) { return static_cast<long>(rtk_u(static_cast<unsigned long long>(v))); }
+__device__ __forceinline__ long long rtk_u(long long v) { return static_cast<long long>(rtk_u(static_cast<unsigned long long>(v))); }
+__device__ __forceinline__ double rtk_u(double v) { return __longlong_as_double(rtk_u(__double_as_longlong(v))); }
+template <class T> __device__ __forceinline__ T* rtk_u(T* p) { return reinterpret_cast<T*>(rtk_u(reinterpret_cast<unsigned long long>(p))); }
 
 #endif
 
@@ -75,15 +92,34 @@ RTK_DEV int rtk_wave_excl_scan(int v, int* total) { // exclusive prefix sum acro
 #endif
 }
 
-// bulk copy / fill (lane-strided); publishes
-RTK_FN void rtk_wcopy(void* dst, const void* src, uint64_t n) {
+// uniform load: *p for a p that is the same in every lane
+template <class T> RTK_DEV T rtk_ld(const T* p) { return rtk_u(*p); }
+
+// bulk copy / fill (lane-strided); publishes. 16 bytes per lane and step when both sides are 16-byte aligned.
+struct alignas(16) RtkV16 { uint64_t a, b; };
+RTK_DEV void rtk_copy_lanes(void* dst, const void* src, uint64_t n) {
     char* d = static_cast<char*>(dst); const char* s = static_cast<const char*>(src);
-    for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = s[i];
+    uint64_t done = 0;
+    if (((reinterpret_cast<uint64_t>(d) | reinterpret_cast<uint64_t>(s)) & 15ull) == 0) {
+        const uint64_t n16 = n >> 4;
+        for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n16; i += RTK_WAVE) reinterpret_cast<RtkV16*>(d)[i] = reinterpret_cast<const RtkV16*>(s)[i];
+        done = n16 << 4;
+    }
+    for (uint64_t i = done + static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = s[i];
+}
+RTK_FN void rtk_wcopy(void* dst, const void* src, uint64_t n) {
+    rtk_copy_lanes(rtk_u(dst), rtk_u(src), rtk_u(n));
+    rtk_sync();
+}
+// two copies, one publish
+RTK_FN void rtk_wcopy2(void* dst0, const void* src0, uint64_t n0, void* dst1, const void* src1, uint64_t n1) {
+    rtk_copy_lanes(rtk_u(dst0), rtk_u(src0), rtk_u(n0));
+    rtk_copy_lanes(rtk_u(dst1), rtk_u(src1), rtk_u(n1));
     rtk_sync();
 }
 
 RTK_FN void rtk_wfill(void* dst, int c, uint64_t n) {
-    char* d = static_cast<char*>(dst);
+    char* d = static_cast<char*>(rtk_u(dst)); n = rtk_u(n); c = rtk_u(c);
     for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = static_cast<char>(c);
     rtk_sync();
 }
