@@ -19,21 +19,21 @@
 #define RTK_MODE_HW 2
 
 struct MyersScratch {
-    uint64_t* peq;       // [15 * w_cap]
-    uint32_t w_cap;      // max query words
-    int8_t* carry;       // [t_cap]
-    int32_t* colscore;   // [t_cap] last-row score of every column
-    uint32_t t_cap;      // max target columns
-    uint64_t* tb;        // [tb_cap_words] traceback table, 4 words per (column, query word): Pv, Mv, Ph, Mh
-    uint64_t tb_cap_words;
-    int32_t* rowL;       // [r_cap] Hirschberg: D(left half)[row]
-    int32_t* rowR;       // [r_cap]
-    uint32_t r_cap;
-    uint8_t* moves;      // [mv_cap] alignment moves: 0 match, 1 insert (query only), 2 delete (target only), 3 mismatch
-    uint8_t* moves_tmp;  // [mv_cap]
-    uint32_t mv_cap;
-    int32_t* hstack;     // [5 * 64] explicit Hirschberg stack
-    uint32_t* overflow;  // set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
+    U<uint64_t*> peq;       // [15 * w_cap]
+    U<uint32_t> w_cap;      // max query words
+    U<int8_t*> carry;       // [t_cap]
+    U<int32_t*> colscore;   // [t_cap] last-row score of every column
+    U<uint32_t> t_cap;      // max target columns
+    U<uint64_t*> tb;        // [tb_cap_words] traceback table, 4 words per (column, query word): Pv, Mv, Ph, Mh
+    U<uint64_t> tb_cap_words;
+    U<int32_t*> rowL;       // [r_cap] Hirschberg: D(left half)[row]
+    U<int32_t*> rowR;       // [r_cap]
+    U<uint32_t> r_cap;
+    U<uint8_t*> moves;      // [mv_cap] alignment moves: 0 match, 1 insert (query only), 2 delete (target only), 3 mismatch
+    U<uint8_t*> moves_tmp;  // [mv_cap]
+    U<uint32_t> mv_cap;
+    U<int32_t*> hstack;     // [5 * 64] explicit Hirschberg stack
+    U<uint32_t*> overflow;  // set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
 };
 
 struct MySeq { // a character sequence read forwards or backwards (Hirschberg aligns reversed halves, edlib.cpp:1259-1263)

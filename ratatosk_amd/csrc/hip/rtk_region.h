@@ -39,38 +39,38 @@ struct RegionDesc { // one entry per output segment of a read, in read order
 #define RTK_RG_TAIL_COPY 5   // read ends on a solid anchor (:951-955)
 
 struct RegionBatch {
-    RegionDesc* regions; uint64_t regions_cap; unsigned long long* n_regions;
-    uint64_t* r_first; uint32_t* r_count;   // per read: its slice of `regions`
-    char* seq_rc;                           // reverse complement of every read (same offsets as seq)
-    char* seg_pool; uint64_t seg_cap; unsigned long long* seg_top;
-    unsigned long long* next_region;        // dequeue head of the persistent region kernel
-    unsigned long long* n_overflow;         // regions that ran out of scratch in the last launch
-    char* out_pool; uint64_t out_cap; unsigned long long* out_top;
-    uint64_t* out_off; uint32_t* out_seq_len; uint32_t* out_qual_len; // per read
+    U<RegionDesc*> regions; U<uint64_t> regions_cap; U<unsigned long long*> n_regions;
+    U<uint64_t*> r_first; U<uint32_t*> r_count;   // per read: its slice of `regions`
+    U<char*> seq_rc;                           // reverse complement of every read (same offsets as seq)
+    U<char*> seg_pool; U<uint64_t> seg_cap; U<unsigned long long*> seg_top;
+    U<unsigned long long*> next_region;        // dequeue head of the persistent region kernel
+    U<unsigned long long*> n_overflow;         // regions that ran out of scratch in the last launch
+    U<char*> out_pool; U<uint64_t> out_cap; U<unsigned long long*> out_top;
+    U<uint64_t*> out_off; U<uint32_t*> out_seq_len; U<uint32_t*> out_qual_len; // per read
 };
 
 struct RegionScratchCfg { ScratchCfg my; uint32_t set_cap, um_cap, str_cap, list_cap, memo_cap, bm_words; uint64_t arena_cap; };
 
-struct WPath { UMap* ums; char* qual; uint32_t n, l, qlen; }; // mutable working path
+struct WPath { U<UMap*> ums; U<char*> qual; U<uint32_t> n, l, qlen; }; // mutable working path
 
 struct RegionScratch {
     MyersScratch my;
-    uint32_t* set[10]; uint32_t set_cap;
-    char* arena[3]; uint64_t arena_cap; uint64_t top[3];   // 0 region level, 1 BFS level, 2 DFS level
-    WPath wp[4]; uint32_t um_cap;
-    char* str[5]; uint32_t str_cap;
-    char* rbuf[8];                                       // result strings: fw seq/qual, bw seq/qual, out seq/qual, 2 temporaries
-    uint64_t* list[6]; uint32_t list_cap;
-    uint32_t* memo_u; uint8_t* memo_v; uint32_t memo_cap; uint32_t memo_n;
-    uint64_t* bm[3]; uint32_t bm_words;
-    uint32_t* overflow;
-    unsigned long long cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
+    U<uint32_t*> set[10]; U<uint32_t> set_cap;
+    U<char*> arena[3]; U<uint64_t> arena_cap; U<uint64_t> top[3];   // 0 region level, 1 BFS level, 2 DFS level
+    WPath wp[4]; U<uint32_t> um_cap;
+    U<char*> str[5]; U<uint32_t> str_cap;
+    U<char*> rbuf[8];                                       // result strings: fw seq/qual, bw seq/qual, out seq/qual, 2 temporaries
+    U<uint64_t*> list[6]; U<uint32_t> list_cap;
+    U<uint32_t*> memo_u; U<uint8_t*> memo_v; U<uint32_t> memo_cap; U<uint32_t> memo_n;
+    U<uint64_t*> bm[3]; U<uint32_t> bm_words;
+    U<uint32_t*> overflow;
+    U<unsigned long long> cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
 };
 
 struct RCtx { // everything a region program needs
     GraphView g; OptsView o; BatchView bv; RegionBatch rb;
-    RegionScratch* sc;
-    int k;
+    U<RegionScratch*> sc;
+    U<int> k;
 };
 
 #ifndef RTK_SIM
@@ -101,7 +101,7 @@ RTK_DEV void rtk_fail_ovf(RegionScratch& s, uint32_t code) { *s.overflow = code;
 RTK_DEV bool rtk_failed(const RegionScratch& s) { return rtk_ld(rtk_ld(&s.overflow)) != 0; }
 
 // anchors of a read in forward or reverse-complement orientation (src/Correction.cpp:196-213)
-struct Anchors { const uint32_t* pos; const uint64_t* hit; const uint64_t* hits_by_pos; uint32_t n, L; int rev; int k; };
+struct Anchors { U<const uint32_t*> pos; U<const uint64_t*> hit; U<const uint64_t*> hits_by_pos; U<uint32_t> n, L; U<int> rev; U<int> k; };
 RTK_DEV uint32_t rtk_an_pos(const Anchors& a, uint32_t i) { return a.rev ? (a.L - a.pos[a.n - 1 - i] - static_cast<uint32_t>(a.k)) : a.pos[i]; }
 RTK_DEV UMap rtk_an_um(const Anchors& a, uint32_t i) {
     const uint32_t j = a.rev ? (a.n - 1 - i) : i;
@@ -111,7 +111,7 @@ RTK_DEV UMap rtk_an_um(const Anchors& a, uint32_t i) {
 }
 
 // ------------------------------------------------------------------------------------------------ arenas and paths (src/Path.hpp)
-struct PathHdr { uint32_t n, l, qlen, pad; }; // followed by n UMap and qlen quality bytes
+struct PathHdr { U<uint32_t> n, l, qlen, pad; }; // followed by n UMap and qlen quality bytes
 
 RTK_DEV uint64_t rtk_arena_alloc(RegionScratch& s, int lvl, uint64_t bytes) {
     bytes = (bytes + 15ull) & ~15ull;
@@ -955,9 +955,9 @@ RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len
         // side lists live in list[0..2] memory (u32 unitig + flag bytes)
         SideList sl, sr, sm;
         const uint32_t cap = s.list_cap;
-        sl.u = reinterpret_cast<uint32_t*>(s.list[0]); sl.nb = reinterpret_cast<uint8_t*>(s.list[0] + cap / 2); sl.n = 0; sl.cap = cap;
-        sr.u = reinterpret_cast<uint32_t*>(s.list[1]); sr.nb = reinterpret_cast<uint8_t*>(s.list[1] + cap / 2); sr.n = 0; sr.cap = cap;
-        sm.u = reinterpret_cast<uint32_t*>(s.list[2]); sm.nb = reinterpret_cast<uint8_t*>(s.list[2] + cap / 2); sm.n = 0; sm.cap = cap;
+        sl.u = reinterpret_cast<uint32_t*>(s.list[0].get()); sl.nb = reinterpret_cast<uint8_t*>(s.list[0].get() + cap / 2); sl.n = 0; sl.cap = cap;
+        sr.u = reinterpret_cast<uint32_t*>(s.list[1].get()); sr.nb = reinterpret_cast<uint8_t*>(s.list[1].get() + cap / 2); sr.n = 0; sr.cap = cap;
+        sm.u = reinterpret_cast<uint32_t*>(s.list[2].get()); sm.nb = reinterpret_cast<uint8_t*>(s.list[2].get() + cap / 2); sm.n = 0; sm.cap = cap;
         auto consider = [&](SideList& m, const UMap& um, uint32_t& nb_branching) {
             const uint32_t u = um.unitig; const bool br = rtk_is_branching(g, u);
             if (g.kcov[u] < c.o.max_km_cov && (!br || nb_branching < 5)) { const bool unseen = rtk_side_insert(m, u, !br); nb_branching += (unseen && br) ? 1u : 0u; }
@@ -1119,8 +1119,8 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c, const ResCorr* fw, const ResCo
         return take(fw);
     }
     CigCur cf, cb;
-    cf.mv = reinterpret_cast<const uint8_t*>(s.str[3]); cf.n = nm_fw; cf.idx = 0; cf.qpos = 0; cf.rpos = 0;
-    cb.mv = reinterpret_cast<const uint8_t*>(s.str[4]); cb.n = nm_bw; cb.idx = 0; cb.qpos = 0; cb.rpos = 0;
+    cf.mv = reinterpret_cast<const uint8_t*>(s.str[3].get()); cf.n = nm_fw; cf.idx = 0; cf.qpos = 0; cf.rpos = 0;
+    cb.mv = reinterpret_cast<const uint8_t*>(s.str[4].get()); cb.n = nm_bw; cb.idx = 0; cb.qpos = 0; cb.rpos = 0;
     uint32_t i = 0;
     while (i < ref_len && !rtk_failed(s)) {
         int64_t len_fw = rtk_rc_len_corrected(*fw, i), len_bw = rtk_rc_len_corrected(*bw, i);

@@ -12,40 +12,40 @@
 #include "rtk_wave.h"
 
 struct OptsView {
-    uint32_t insert_sz, min_cov_vertices, max_len_weak_region1, max_km_cov;
-    double weak_region_len_factor, large_k_factor, min_score;
-    int32_t max_qual, out_qual;
+    U<uint32_t> insert_sz, min_cov_vertices, max_len_weak_region1, max_km_cov;
+    U<double> weak_region_len_factor, large_k_factor, min_score;
+    U<int32_t> max_qual, out_qual;
 };
 
 struct BatchView {
-    uint32_t n_reads;
-    uint64_t n_bases;
-    const char* seq;          // upper-cased reads, concatenated
-    const uint64_t* roff;     // [n_reads+1]
-    uint64_t* hits;           // [n_bases] exact hit of the window starting at each base (packed, RTK_NO_HIT if none)
-    char* masked;             // [n_bases] the 'N'-masked copy searched inexactly (src/Graph.cpp:102)
-    uint64_t* wdesc;          // [n_bases] group of raw inexact hits of the window: pool offset << 24 | count
-    uint64_t* ipool;          // raw inexact hits {k-mer code in read orientation, packed hit}
-    uint64_t ipool_cap;       // entries
-    unsigned long long* ipool_top;
-    uint32_t* s_pos;          // solid anchor positions of read r at [roff[r], roff[r] + n_solid[r])
-    uint32_t* n_solid;        // [n_reads]
-    uint32_t* wk_pos;         // weak anchors (all reads), read r at [w_off[r], w_off[r] + w_cnt[r])
-    uint64_t* wk_hit;
-    uint64_t wk_cap;
-    unsigned long long* wk_top;
-    uint64_t* w_off;          // [n_reads]
-    uint32_t* w_cnt;          // [n_reads]
-    uint32_t* status;         // [n_reads] non-zero: a scratch capacity was exceeded for this read
-    unsigned long long* counters; // [16] event counters (see rtk_pipeline.inc)
+    U<uint32_t> n_reads;
+    U<uint64_t> n_bases;
+    U<const char*> seq;          // upper-cased reads, concatenated
+    U<const uint64_t*> roff;     // [n_reads+1]
+    U<uint64_t*> hits;           // [n_bases] exact hit of the window starting at each base (packed, RTK_NO_HIT if none)
+    U<char*> masked;             // [n_bases] the 'N'-masked copy searched inexactly (src/Graph.cpp:102)
+    U<uint64_t*> wdesc;          // [n_bases] group of raw inexact hits of the window: pool offset << 24 | count
+    U<uint64_t*> ipool;          // raw inexact hits {k-mer code in read orientation, packed hit}
+    U<uint64_t> ipool_cap;       // entries
+    U<unsigned long long*> ipool_top;
+    U<uint32_t*> s_pos;          // solid anchor positions of read r at [roff[r], roff[r] + n_solid[r])
+    U<uint32_t*> n_solid;        // [n_reads]
+    U<uint32_t*> wk_pos;         // weak anchors (all reads), read r at [w_off[r], w_off[r] + w_cnt[r])
+    U<uint64_t*> wk_hit;
+    U<uint64_t> wk_cap;
+    U<unsigned long long*> wk_top;
+    U<uint64_t*> w_off;          // [n_reads]
+    U<uint32_t*> w_cnt;          // [n_reads]
+    U<uint32_t*> status;         // [n_reads] non-zero: a scratch capacity was exceeded for this read
+    U<unsigned long long*> counters; // [16] event counters (see rtk_pipeline.inc)
 };
 
 struct SeedScratch {
-    uint32_t* set[6]; uint32_t set_cap;           // sorted-id buffers
-    uint32_t* vpos; uint64_t* vcode; uint64_t* vhit; uint64_t* vkey; uint64_t* vidx; uint32_t v_cap; // weak-hit work lists (vkey/vidx hold 2*v_cap)
-    uint32_t* gstart; uint32_t* gcnt; uint32_t* gps; uint32_t* gpe; uint8_t* gkeep; uint8_t* vflag; // variant groups
-    uint8_t* sflag;                               // per solid candidate
-    uint32_t* overflow;
+    U<uint32_t*> set[6]; U<uint32_t> set_cap;           // sorted-id buffers
+    U<uint32_t*> vpos; U<uint64_t*> vcode; U<uint64_t*> vhit; U<uint64_t*> vkey; U<uint64_t*> vidx; U<uint32_t> v_cap; // weak-hit work lists (vkey/vidx hold 2*v_cap)
+    U<uint32_t*> gstart; U<uint32_t*> gcnt; U<uint32_t*> gps; U<uint32_t*> gpe; U<uint8_t*> gkeep; U<uint8_t*> vflag; // variant groups
+    U<uint8_t*> sflag;                               // per solid candidate
+    U<uint32_t*> overflow;
 };
 
 
@@ -280,7 +280,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
             if (bb + static_cast<uint64_t>(k) <= rend && rend - bv.roff[lo] > static_cast<uint64_t>(k)) {
                 bool ok = true;
 #ifdef RTK_SIM
-                const unsigned char* wc = reinterpret_cast<const unsigned char*>(bv.masked) + bb;
+                const unsigned char* wc = reinterpret_cast<const unsigned char*>(bv.masked.get()) + bb;
 #else
                 const unsigned char* wc = tile_chars + rtk_lane(); // k + 1 <= 64: the window and its two look-ahead characters are inside the staged 128 bytes
 #endif

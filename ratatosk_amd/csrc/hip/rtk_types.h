@@ -15,6 +15,49 @@
 #define RTK_HD inline
 #endif
 
+// ---- wave-uniform values -------------------------------------------------------------------------------------------------
+// rtk_u(v): "v is the same in every lane". Identity on the value; on the device it moves the value to scalar registers, so that
+// the wave-level programs keep their control state, pointers and loop counters in SGPRs (scalar ALU and branches, spills into
+// VGPR lanes instead of 64-wide stores to the stack). Only ever applied to values that are wave-uniform by construction.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RTK_SIM)
+template <class T> __device__ __forceinline__ T rtk_u(T v) {
+    static_assert(sizeof(T) <= 8, "rtk_u: scalar types only");
+    if (sizeof(T) <= 4) {
+        uint32_t x = 0; __builtin_memcpy(&x, &v, sizeof(T));
+        x = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x)));
+        T r; __builtin_memcpy(&r, &x, sizeof(T)); return r;
+    } else {
+        uint64_t x = 0; __builtin_memcpy(&x, &v, sizeof(T));
+        const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x & 0xFFFFFFFFull)));
+        const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x >> 32)));
+        x = (static_cast<uint64_t>(hi) << 32) | lo;
+        T r; __builtin_memcpy(&r, &x, sizeof(T)); return r;
+    }
+}
+#else
+template <class T> RTK_HD T rtk_u(T v) { return v; }
+#endif
+
+// U<T>: a struct field that holds a wave-uniform value (all the view / scratch descriptors below are per wave or per launch).
+// Reads go through rtk_u, so every use site gets the scalar form without being written differently. Same layout as T.
+template <class T> struct U {
+    T v;
+    RTK_HD operator T() const { return rtk_u(v); }
+    RTK_HD T get() const { return rtk_u(v); }
+    RTK_HD U& operator=(T x) { v = x; return *this; }
+    template <class X> RTK_HD U& operator+=(X x) { v = static_cast<T>(rtk_u(v) + x); return *this; }
+    template <class X> RTK_HD U& operator-=(X x) { v = static_cast<T>(rtk_u(v) - x); return *this; }
+    template <class X> RTK_HD U& operator*=(X x) { v = static_cast<T>(rtk_u(v) * x); return *this; }
+    template <class X> RTK_HD U& operator|=(X x) { v = static_cast<T>(rtk_u(v) | x); return *this; }
+    RTK_HD U& operator++() { v = rtk_u(v) + 1; return *this; }
+    RTK_HD U& operator--() { v = rtk_u(v) - 1; return *this; }
+    RTK_HD T operator++(int) { const T o = rtk_u(v); v = o + 1; return o; }
+    RTK_HD T operator--(int) { const T o = rtk_u(v); v = o - 1; return o; }
+    RTK_HD T operator->() const { return rtk_u(v); }
+    RTK_HD decltype(auto) operator*() const { return *rtk_u(v); }
+    template <class I> RTK_HD decltype(auto) operator[](I i) const { return rtk_u(v)[i]; }
+};
+
 #define RTK_NONE32 0xFFFFFFFFu
 #define RTK_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
@@ -25,23 +68,23 @@
 #define RTK_F_AMBIGUITY (1u << 10)  // UnitigData.hpp:483-486
 
 struct GraphView {
-    int32_t k;
-    uint32_t n_unitigs;
-    uint64_t n_kmers;
-    uint64_t ht_mask;          // slots - 1 (power of two)
-    const uint64_t* useq;      // unitig bases, 2 bits each, base i of the pool at bits [2*(i&31), +1] of word i>>5
-    const uint64_t* uoff;      // [n+1] first base of unitig u in the pool
-    const uint32_t* adj;       // [n*8] fw A,C,G,T then reverse-strand A,C,G,T: neighbour unitig<<1|strand or RTK_NONE32
-    const uint32_t* flags;     // [n]
-    const uint32_t* kcov;      // [n] round(cov/(size-k+1)) (UnitigData.hpp:396-399), precomputed in double on the host
-    const uint32_t* card;      // [n] |global| + |local|
-    const uint64_t* loff;      // [n+1] local colour set of u = col[loff[u] .. loff[u+1])
-    const int32_t* gid;        // [n] global colour set id or -1
-    const uint64_t* goff;      // [n_global+1] global set g = col[goff[g] .. goff[g+1])
-    const uint32_t* col;       // sorted u32 pair ids
-    const uint64_t* ht;        // [2*slots] {canonical k-mer, unitig<<32 | dist<<1 | stored_is_canonical}, empty key = RTK_EMPTY_KEY
-    const uint64_t* bf;        // [bf_mask+1] blocked Bloom filter over the canonical k-mers (2 bits of one 64-bit word per k-mer)
-    uint64_t bf_mask;
+    U<int32_t> k;
+    U<uint32_t> n_unitigs;
+    U<uint64_t> n_kmers;
+    U<uint64_t> ht_mask;          // slots - 1 (power of two)
+    U<const uint64_t*> useq;      // unitig bases, 2 bits each, base i of the pool at bits [2*(i&31), +1] of word i>>5
+    U<const uint64_t*> uoff;      // [n+1] first base of unitig u in the pool
+    U<const uint32_t*> adj;       // [n*8] fw A,C,G,T then reverse-strand A,C,G,T: neighbour unitig<<1|strand or RTK_NONE32
+    U<const uint32_t*> flags;     // [n]
+    U<const uint32_t*> kcov;      // [n] round(cov/(size-k+1)) (UnitigData.hpp:396-399), precomputed in double on the host
+    U<const uint32_t*> card;      // [n] |global| + |local|
+    U<const uint64_t*> loff;      // [n+1] local colour set of u = col[loff[u] .. loff[u+1])
+    U<const int32_t*> gid;        // [n] global colour set id or -1
+    U<const uint64_t*> goff;      // [n_global+1] global set g = col[goff[g] .. goff[g+1])
+    U<const uint32_t*> col;       // sorted u32 pair ids
+    U<const uint64_t*> ht;        // [2*slots] {canonical k-mer, unitig<<32 | dist<<1 | stored_is_canonical}, empty key = RTK_EMPTY_KEY
+    U<const uint64_t*> bf;        // [bf_mask+1] blocked Bloom filter over the canonical k-mers (2 bits of one 64-bit word per k-mer)
+    U<uint64_t> bf_mask;
 };
 
 RTK_HD uint32_t rtk_ulen(const GraphView& g, uint32_t u) { return static_cast<uint32_t>(g.uoff[u + 1] - g.uoff[u]); }

@@ -16,6 +16,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "rtk_types.h"
+
 #ifdef RTK_SIM
 
 #define RTK_DEV inline
@@ -28,10 +30,8 @@ template <class T> inline T rtk_shfl_up1(T v, T lane0_value) { (void)v; return l
 inline void rtk_sync() {}
 inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
-template <class T> inline T rtk_atomic_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T rtk_atomic_add_raw(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long rtk_clock() { return 0; }
-// rtk_u(v): "v is the same in every lane" (identity on the value)
-template <class T> inline T rtk_u(T v) { return v; }
 
 #else
 
@@ -49,23 +49,8 @@ template <class T> __device__ __forceinline__ T rtk_shfl_up1(T v, T lane0_value)
 __device__ __forceinline__ void rtk_sync() { __syncthreads(); }
 __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
-template <class T> __device__ __forceinline__ T rtk_atomic_add(T* p, T v) { return atomicAdd(p, v); }
+template <class T> __device__ __forceinline__ T rtk_atomic_add_raw(T* p, T v) { return atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long rtk_clock() { return static_cast<unsigned long long>(clock64()); }
-// rtk_u(v): "v is the same in every lane". Identity on the value; tells the compiler to keep it in scalar registers, so the region
-// program's control state, pointers and loop counters live in SGPRs (scalar ALU, scalar branches, spills into VGPR lanes instead of
-// 64-wide stores to the stack). Only ever applied to values that are wave-uniform by construction.
-__device__ __forceinline__ uint32_t rtk_u(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
-__device__ __forceinline__ int32_t rtk_u(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ bool rtk_u(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
-__device__ __forceinline__ unsigned long long rtk_u(unsigned long long v) {
-    const uint32_t lo = rtk_u(static_cast<uint32_t>(v)), hi = rtk_u(static_cast<uint32_t>(v >> 32));
-    return (static_cast<unsigned long long>(hi) << 32) | lo;
-}
-__device__ __forceinline__ unsigned long rtk_u(unsigned long v) { return static_cast<unsigned long>(rtk_u(static_cast<unsigned long long>(v))); }
-__device__ __forceinline__ long rtk_u(long v) { return static_cast<long>(rtk_u(static_cast<unsigned long long>(v))); }
-__device__ __forceinline__ long long rtk_u(long long v) { return static_cast<long long>(rtk_u(static_cast<unsigned long long>(v))); }
-__device__ __forceinline__ double rtk_u(double v) { return __longlong_as_double(rtk_u(__double_as_longlong(v))); }
-template <class T> __device__ __forceinline__ T* rtk_u(T* p) { return reinterpret_cast<T*>(rtk_u(reinterpret_cast<unsigned long long>(p))); }
 
 #endif
 
@@ -92,8 +77,12 @@ RTK_DEV int rtk_wave_excl_scan(int v, int* total) { // exclusive prefix sum acro
 #endif
 }
 
+template <class T, class V> RTK_DEV T rtk_atomic_add(T* p, V v) { return rtk_atomic_add_raw(p, static_cast<T>(v)); }
+template <class T, class V> RTK_DEV T rtk_atomic_add(const U<T*>& p, V v) { return rtk_atomic_add_raw(p.get(), static_cast<T>(v)); }
+
 // uniform load: *p for a p that is the same in every lane
 template <class T> RTK_DEV T rtk_ld(const T* p) { return rtk_u(*p); }
+template <class T> RTK_DEV T rtk_ld(const U<T>* p) { return p->get(); }
 
 // bulk copy / fill (lane-strided); publishes. 16 bytes per lane and step when both sides are 16-byte aligned.
 struct alignas(16) RtkV16 { uint64_t a, b; };
