@@ -180,7 +180,8 @@ RTK_FN void rtk_wp_extend(const RCtx& c, WPath& p_, const UMap& um_) { // Path.h
 }
 
 // extend with a quality slice q[0..qn) (Path.hpp:332-363): appended only when its length equals um.len + k - 1
-RTK_FN void rtk_wp_extend_q(const RCtx& c, WPath& p, const UMap& um, const char* q, uint32_t qn) {
+RTK_FN void rtk_wp_extend_q(const RCtx& c_, WPath& p_, const UMap& um_, const char* q_, uint32_t qn_) {
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_); const char* q = rtk_u(q_); uint32_t qn = rtk_u(qn_);
     RegionScratch& s = *c.sc;
     if (rtk_um_is_empty(um)) return;
     if (p.n >= s.um_cap) { rtk_fail_ovf(s, 5); return; }
@@ -199,7 +200,8 @@ RTK_FN void rtk_wp_extend_q(const RCtx& c, WPath& p, const UMap& um, const char*
 }
 
 // fills qual with `ch` for a fresh single-unitig path (string(len + k - 1, getQual(1.0)))
-RTK_FN void rtk_wp_start(const RCtx& c, WPath& p, const UMap& um, char ch) {
+RTK_FN void rtk_wp_start(const RCtx& c_, WPath& p_, const UMap& um_, char ch_) {
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_); char ch = rtk_u(ch_);
     RegionScratch& s = *c.sc;
     rtk_wp_clear(p);
     const uint32_t want = um.len + static_cast<uint32_t>(c.k) - 1;
@@ -209,7 +211,8 @@ RTK_FN void rtk_wp_start(const RCtx& c, WPath& p, const UMap& um, char ch) {
 }
 
 // p.merge(o) where o is a committed record (Path.hpp:366-414)
-RTK_FN void rtk_wp_merge(const RCtx& c, WPath& p, uint64_t ho) {
+RTK_FN void rtk_wp_merge(const RCtx& c_, WPath& p_, uint64_t ho_) {
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); uint64_t ho = rtk_u(ho_);
     RegionScratch& s = *c.sc;
     const int lv = rtk_h_lvl(ho); const uint64_t oo = rtk_h_off(ho);
     const PathHdr* o = rtk_path_hdr(s, lv, oo);
@@ -241,7 +244,8 @@ RTK_FN void rtk_wp_merge(const RCtx& c, WPath& p, uint64_t ho) {
     }
 }
 
-RTK_FN void rtk_wp_prune_prefix(const RCtx& c, WPath& p, uint32_t len) { // Path.hpp:487-571
+RTK_FN void rtk_wp_prune_prefix(const RCtx& c_, WPath& p_, uint32_t len_) {
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); uint32_t len = rtk_u(len_); // Path.hpp:487-571
     if (p.n == 0 || p.l == 0 || len >= p.l) return;
     const uint32_t k = static_cast<uint32_t>(c.k);
     UMap& st = p.ums[0];
@@ -511,8 +515,8 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
 }
 
 // explore() (src/GraphTraversal.cpp:41-93, 251-304). p = committed path (level 1). Results stay in list[2]/list[3] (level-2 arena).
-RTK_FN void rtk_explore(const RCtx& c, const uint32_t* all_pids, uint32_t n_all, const char* ref, uint32_t ref_len, const UMap& um_e, uint64_t hp, uint32_t max_len_path,
-                         uint32_t* n_t, uint32_t* n_nt) {
+RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_e_, uint64_t hp_, uint32_t max_len_path_, uint32_t* n_t_, uint32_t* n_nt_) {
+    const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_e = rtk_u(um_e_); uint64_t hp = rtk_u(hp_); uint32_t max_len_path = rtk_u(max_len_path_); uint32_t* n_t = rtk_u(n_t_); uint32_t* n_nt = rtk_u(n_nt_);
     RegionScratch& s = *c.sc;
     *n_t = 0; *n_nt = 0;
     const UMap um = rtk_rec_back(s, hp);
@@ -542,7 +546,8 @@ RTK_FN void rtk_explore(const RCtx& c, const uint32_t* all_pids, uint32_t n_all,
 }
 
 // P (+) Q: w = copy of p extended by every mapping of sub with its quality slice (src/GraphTraversal.cpp:379-390)
-RTK_FN void rtk_extend_by(const RCtx& c, WPath& w, uint64_t hsub, uint32_t upto /*number of sub mappings to take*/) {
+RTK_FN void rtk_extend_by(const RCtx& c_, WPath& w_, uint64_t hsub_, uint32_t upto_) {
+    const RCtx& c = *rtk_u(&c_); WPath& w = *rtk_u(&w_); uint64_t hsub = rtk_u(hsub_); uint32_t upto = rtk_u(upto_);
     RegionScratch& s = *c.sc;
     const int lv = rtk_h_lvl(hsub); const uint64_t oo = rtk_h_off(hsub);
     const PathHdr* h = rtk_path_hdr(s, lv, oo); const UMap* ums = rtk_path_ums(s, lv, oo); const char* q = rtk_path_qual(s, lv, oo);
@@ -556,7 +561,8 @@ RTK_FN void rtk_extend_by(const RCtx& c, WPath& w, uint64_t hsub, uint32_t upto 
     }
 }
 
-RTK_FN void rtk_resize_to_best(const RCtx& c, uint64_t* v, uint32_t* n, const char* ref, uint32_t ref_len) { // resizeVector
+RTK_FN void rtk_resize_to_best(const RCtx& c_, uint64_t* v_, uint32_t* n_, const char* ref_, uint32_t ref_len_) {
+    const RCtx& c = *rtk_u(&c_); uint64_t* v = rtk_u(v_); uint32_t* n = rtk_u(n_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); // resizeVector
     if (*n <= 1) return;
     int bid, bend;
     rtk_select_best(c, v, *n, ref, ref_len, RTK_MODE_SHW, -1.0, &bid, &bend);
@@ -572,7 +578,8 @@ RTK_DEV UMap rtk_start_suffix(const RCtx& c, const UMap& um_s) { // src/GraphTra
 }
 
 // explorePathsBFS2 / explorePathsBFS. Returns a level-1 handle of the single resulting path, or ~0 if none.
-RTK_FN uint64_t rtk_explore_paths(const RCtx& c, const uint32_t* all_pids, uint32_t n_all, const char* ref, uint32_t ref_len, const UMap& um_s, const UMap& um_e, bool has_end) {
+RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_s_, const UMap& um_e_, bool has_end_) {
+    const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_s = rtk_u(um_s_); const UMap um_e = rtk_u(um_e_); bool has_end = rtk_u(has_end_);
     RegionScratch& s = *c.sc;
     const uint32_t k = static_cast<uint32_t>(c.k);
     s.top[1] = 0; s.memo_n = 0;
@@ -676,9 +683,8 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c, const uint32_t* all_pids, uint3
 // ------------------------------------------------------------------------------------------------ extractSemiWeakPaths (src/Correction.cpp:3-157)
 // BFS results never hold more than one path, so `paths1` is a single running path (level 0). Dead ends are appended to
 // `partial` (list[5]). Returns the complete path handle or ~0.
-RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c, const char* s_read, uint32_t s_len, const uint32_t* all_pids, uint32_t n_all,
-                                       uint32_t start_pos, const UMap& start_um, uint32_t end_pos_in, const UMap& end_um, const Anchors& lvw, uint32_t lvw_lo, uint32_t lvw_hi, uint32_t i_weak,
-                                       uint32_t* n_partial) {
+RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint32_t s_len_, const uint32_t* all_pids_, uint32_t n_all_, uint32_t start_pos_, const UMap& start_um_, uint32_t end_pos_in_, const UMap& end_um_, const Anchors& lvw_, uint32_t lvw_lo_, uint32_t lvw_hi_, uint32_t i_weak_, uint32_t* n_partial_) {
+    const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); uint32_t s_len = rtk_u(s_len_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); uint32_t start_pos = rtk_u(start_pos_); const UMap start_um = rtk_u(start_um_); uint32_t end_pos_in = rtk_u(end_pos_in_); const UMap end_um = rtk_u(end_um_); const Anchors& lvw = *rtk_u(&lvw_); uint32_t lvw_lo = rtk_u(lvw_lo_); uint32_t lvw_hi = rtk_u(lvw_hi_); uint32_t i_weak = rtk_u(i_weak_); uint32_t* n_partial = rtk_u(n_partial_);
     RegionScratch& s = *c.sc;
     const uint32_t k = static_cast<uint32_t>(c.k);
     const bool no_end = rtk_um_is_empty(end_um);
@@ -734,7 +740,8 @@ RTK_DEV uint32_t rtk_rs_union(RegionScratch& s, int a, uint32_t na, const uint32
 }
 
 // Computes all_pids into set[0]; returns its size. Uses set[1..9] as temporaries.
-RTK_FN uint32_t rtk_choose_colors(const RCtx& c, const SideList& side_s, const SideList& side_e, const SideList& side_w) {
+RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
+    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
     RegionScratch& s = *c.sc;
     const GraphView& g = c.g;
     // a_pid[shift], shift = side index (0 middle, 1 right, 2 left) + 3 * nonbranching: built one after the other into the arena (level 2 is free here)
@@ -871,7 +878,8 @@ RTK_DEV bool rtk_bm_get(const uint64_t* bm, uint32_t i) { return (bm[i >> 6] >> 
 RTK_DEV uint32_t rtk_rc_len_corrected(const ResCorr& r, uint32_t p) { uint32_t n = p; while (n < r.old_len && rtk_bm_get(r.bm, n)) ++n; return n - p; } // :117-128
 RTK_DEV uint32_t rtk_rc_len_uncorrected(const ResCorr& r, uint32_t p) { if (p >= r.old_len) return 0; uint32_t n = p; while (n < r.old_len && !rtk_bm_get(r.bm, n)) ++n; return n - p; } // :130-142
 
-RTK_FN void rtk_rc_reverse_complement(RegionScratch& s, ResCorr& r, uint64_t* tmp_bm, char* tmp) { // :72-88
+RTK_FN void rtk_rc_reverse_complement(RegionScratch& s_, ResCorr& r_, uint64_t* tmp_bm_, char* tmp_) {
+    RegionScratch& s = *rtk_u(&s_); ResCorr& r = *rtk_u(&r_); uint64_t* tmp_bm = rtk_u(tmp_bm_); char* tmp = rtk_u(tmp_); // :72-88
     if (r.seq_len == 0) return;
     const uint32_t words = (r.old_len + 63) / 64;
     for (uint32_t w = 0; w < words; ++w) tmp_bm[w] = 0;
@@ -885,8 +893,10 @@ RTK_FN void rtk_rc_reverse_complement(RegionScratch& s, ResCorr& r, uint64_t* tm
 }
 
 // appenders for the growing corrected strings
-RTK_FN void rtk_app(RegionScratch& s, char* dst, uint32_t* len, const char* src, uint32_t n) { if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wcopy(dst + *len, src, n); *len += n; }
-RTK_FN void rtk_app_fill(RegionScratch& s, char* dst, uint32_t* len, char ch, uint32_t n) { if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wfill(dst + *len, ch, n); *len += n; }
+RTK_FN void rtk_app(RegionScratch& s_, char* dst_, uint32_t* len_, const char* src_, uint32_t n_) {
+    RegionScratch& s = *rtk_u(&s_); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); const char* src = rtk_u(src_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wcopy(dst + *len, src, n); *len += n; }
+RTK_FN void rtk_app_fill(RegionScratch& s_, char* dst_, uint32_t* len_, char ch_, uint32_t n_) {
+    RegionScratch& s = *rtk_u(&s_); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); char ch = rtk_u(ch_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wfill(dst + *len, ch, n); *len += n; }
 
 // Bifrost Kmer(const char*) 2-bit code of any character (end k-mer test, src/Correction.cpp:720-724)
 RTK_DEV int rtk_bifrost_code(char ch) { const int x = (ch & 4) >> 1; return x + ((x ^ (ch & 2)) >> 1); }
@@ -920,7 +930,8 @@ RTK_DEV void rtk_scan_anchor_runs(const Anchors& a, int64_t start, int step, Con
 
 // ------------------------------------------------------------------------------------------------ the `correct` lambda (src/Correction.cpp:431-753)
 // s_read: read in the orientation of this call; v_s / v_w: anchors in that orientation. Result strings go to res.seq / res.qual.
-RTK_FN void rtk_correct_region(const RCtx& c, const char* s_read, uint32_t s_len, const Anchors& v_s, const Anchors& v_w, uint32_t i_s, uint32_t i_w, const ResCorr* rc, ResCorr& res) {
+RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_len_, const Anchors& v_s_, const Anchors& v_w_, uint32_t i_s_, uint32_t i_w_, const ResCorr* rc_, ResCorr& res_) {
+    const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); uint32_t s_len = rtk_u(s_len_); const Anchors& v_s = *rtk_u(&v_s_); const Anchors& v_w = *rtk_u(&v_w_); uint32_t i_s = rtk_u(i_s_); uint32_t i_w = rtk_u(i_w_); const ResCorr* rc = rtk_u(rc_); ResCorr& res = *rtk_u(&res_);
     RegionScratch& s = *c.sc;
     const uint32_t k = static_cast<uint32_t>(c.k);
     const GraphView& g = c.g;
@@ -1072,7 +1083,8 @@ struct CigCur { const uint8_t* mv; uint32_t n, idx, qpos, rpos; }; // op-granula
 RTK_DEV char rtk_mv_op(uint8_t m) { return (m == 1) ? 'I' : (m == 2 ? 'D' : 'M'); }
 RTK_DEV uint32_t rtk_op_len(const CigCur& cc) { uint32_t j = cc.idx; const char op = rtk_mv_op(cc.mv[cc.idx]); while (j < cc.n && rtk_mv_op(cc.mv[j]) == op) ++j; return j - cc.idx; }
 
-RTK_FN void rtk_move_into_cigar(uint32_t start, uint32_t end, CigCur& cc, uint32_t* rs, uint32_t* re, uint32_t* ref_out) { // moveIntoCIGAR (:354-411)
+RTK_FN void rtk_move_into_cigar(uint32_t start_, uint32_t end_, CigCur& cc_, uint32_t* rs_, uint32_t* re_, uint32_t* ref_out_) {
+    uint32_t start = rtk_u(start_); uint32_t end = rtk_u(end_); CigCur& cc = *rtk_u(&cc_); uint32_t* rs = rtk_u(rs_); uint32_t* re = rtk_u(re_); uint32_t* ref_out = rtk_u(ref_out_); // moveIntoCIGAR (:354-411)
     uint32_t read_pos_start = cc.qpos, read_pos_end;
     while (cc.idx != cc.n && cc.rpos < start) {
         const uint32_t l = rtk_op_len(cc); const char op = rtk_mv_op(cc.mv[cc.idx]);
@@ -1091,8 +1103,8 @@ RTK_FN void rtk_move_into_cigar(uint32_t start, uint32_t end, CigCur& cc, uint32
 }
 
 // writes the consensus into out_s/out_q; returns false when the result is "empty" (caller falls back to the raw region)
-RTK_FN bool rtk_generate_consensus(const RCtx& c, const ResCorr* fw, const ResCorr* bw, const char* ref, uint32_t ref_len, double max_norm,
-                                    char* out_s, uint32_t* out_sl, char* out_q, uint32_t* out_ql) {
+RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const ResCorr* bw_, const char* ref_, uint32_t ref_len_, double max_norm_, char* out_s_, uint32_t* out_sl_, char* out_q_, uint32_t* out_ql_) {
+    const RCtx& c = *rtk_u(&c_); const ResCorr* fw = rtk_u(fw_); const ResCorr* bw = rtk_u(bw_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); double max_norm = rtk_u(max_norm_); char* out_s = rtk_u(out_s_); uint32_t* out_sl = rtk_u(out_sl_); char* out_q = rtk_u(out_q_); uint32_t* out_ql = rtk_u(out_ql_);
     RegionScratch& s = *c.sc;
     *out_sl = 0; *out_ql = 0;
     const uint32_t nfw = rtk_bm_card(fw->bm, fw->old_len), nbw = rtk_bm_card(bw->bm, bw->old_len);
@@ -1186,7 +1198,8 @@ RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& 
 }
 
 // ------------------------------------------------------------------------------------------------ region driver (src/Correction.cpp:776-957)
-RTK_FN void rtk_emit_segment(const RCtx& c, RegionDesc* rd, const char* sq, uint32_t sl, const char* ql, uint32_t qll) {
+RTK_FN void rtk_emit_segment(const RCtx& c_, RegionDesc* rd_, const char* sq_, uint32_t sl_, const char* ql_, uint32_t qll_) {
+    const RCtx& c = *rtk_u(&c_); RegionDesc* rd = rtk_u(rd_); const char* sq = rtk_u(sq_); uint32_t sl = rtk_u(sl_); const char* ql = rtk_u(ql_); uint32_t qll = rtk_u(qll_);
     unsigned long long off = 0;
     if (rtk_lane() == 0) off = rtk_atomic_add(c.rb.seg_top, static_cast<unsigned long long>(sl) + qll);
     off = rtk_shfl(off, 0);
@@ -1196,7 +1209,8 @@ RTK_FN void rtk_emit_segment(const RCtx& c, RegionDesc* rd, const char* sq, uint
     rd->seg_off = off; rd->seq_len = sl; rd->qual_len = qll;
 }
 
-RTK_FN void rtk_region_program(const RCtx& c, RegionDesc* rd) {
+RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
+    const RCtx& c = *rtk_u(&c_); RegionDesc* rd = rtk_u(rd_);
     RegionScratch& s = *c.sc;
     const uint32_t r = rd->read, k = static_cast<uint32_t>(c.k);
     const uint64_t base = c.bv.roff[r];

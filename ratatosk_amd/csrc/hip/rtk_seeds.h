@@ -98,7 +98,8 @@ RTK_DEV bool rtk_is_branching(const GraphView& g, uint32_t u) { return (g.flags[
 
 
 // min(|colours(u) & set|, cap)  (getNumberSharedPairID(SharedPairID, PairID), src/Common.cpp:73-83)
-RTK_FN uint32_t rtk_shared_with_set(const GraphView& g, uint32_t u, const uint32_t* set, uint32_t n, uint32_t cap) {
+RTK_FN uint32_t rtk_shared_with_set(const GraphView& g_, uint32_t u_, const uint32_t* set_, uint32_t n_, uint32_t cap_) {
+    const GraphView& g = *rtk_u(&g_); uint32_t u = rtk_u(u_); const uint32_t* set = rtk_u(set_); uint32_t n = rtk_u(n_); uint32_t cap = rtk_u(cap_);
     uint32_t shared = 0;
     const int32_t gi = g.gid[u];
     if (gi >= 0) shared = rtk_set_inter_count(g.col + g.goff[gi], static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]), set, n, cap);
@@ -108,7 +109,8 @@ RTK_FN uint32_t rtk_shared_with_set(const GraphView& g, uint32_t u, const uint32
 
 // min(|colours(u) & colours(v)|, cap)  (getNumberSharedPairID(SharedPairID, SharedPairID), src/Common.cpp:51-71);
 // global and local parts of one unitig are disjoint, so the four partial intersections add up
-RTK_FN uint32_t rtk_shared_unitigs(const GraphView& g, uint32_t u, uint32_t v, uint32_t cap) {
+RTK_FN uint32_t rtk_shared_unitigs(const GraphView& g_, uint32_t u_, uint32_t v_, uint32_t cap_) {
+    const GraphView& g = *rtk_u(&g_); uint32_t u = rtk_u(u_); uint32_t v = rtk_u(v_); uint32_t cap = rtk_u(cap_);
     const int32_t gu = g.gid[u], gv = g.gid[v];
     const uint32_t* lv = g.col + g.loff[v]; const uint32_t nlv = static_cast<uint32_t>(g.loff[v + 1] - g.loff[v]);
     if (gu >= 0 && gu == gv) {
@@ -123,7 +125,8 @@ RTK_FN uint32_t rtk_shared_unitigs(const GraphView& g, uint32_t u, uint32_t v, u
 }
 
 // colours(u) = global | local, merged into the running union held in sc.set[cur]; returns new size (0xFFFFFFFF on overflow)
-RTK_FN uint32_t rtk_union_unitig(const GraphView& g, const SeedScratch& sc, int& cur, uint32_t n_cur, uint32_t u) {
+RTK_FN uint32_t rtk_union_unitig(const GraphView& g_, const SeedScratch& sc_, int& cur_, uint32_t n_cur_, uint32_t u_) {
+    const GraphView& g = *rtk_u(&g_); const SeedScratch& sc = *rtk_u(&sc_); int& cur = *rtk_u(&cur_); uint32_t n_cur = rtk_u(n_cur_); uint32_t u = rtk_u(u_);
     const int32_t gi = g.gid[u];
     if (gi >= 0) {
         const uint32_t ng = static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]);

@@ -16,7 +16,8 @@ RTK_DEV uint32_t rtk_lower_bound(const uint32_t* a, uint32_t n, uint32_t x) { //
 RTK_DEV bool rtk_set_contains(const uint32_t* a, uint32_t n, uint32_t x) { const uint32_t i = rtk_lower_bound(a, n, x); return i < n && a[i] == x; }
 
 // out = { x in a : (x in b) == want_in_b }
-RTK_FN uint32_t rtk_set_filter(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, bool want_in_b, uint32_t* out) {
+RTK_FN uint32_t rtk_set_filter(const uint32_t* a_, uint32_t na_, const uint32_t* b_, uint32_t nb_, bool want_in_b_, uint32_t* out_) {
+    const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); bool want_in_b = rtk_u(want_in_b_); uint32_t* out = rtk_u(out_);
     uint32_t base = 0;
     for (uint32_t i0 = 0; i0 < na; i0 += RTK_WAVE) {
         const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
@@ -34,7 +35,8 @@ RTK_DEV uint32_t rtk_set_inter(const uint32_t* a, uint32_t na, const uint32_t* b
 RTK_DEV uint32_t rtk_set_diff(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t* out) { return rtk_set_filter(a, na, b, nb, false, out); }
 
 // |a & b|, stops counting once `cap` is reached (callers only compare against the cap)
-RTK_FN uint32_t rtk_set_inter_count(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t cap) {
+RTK_FN uint32_t rtk_set_inter_count(const uint32_t* a_, uint32_t na_, const uint32_t* b_, uint32_t nb_, uint32_t cap_) {
+    const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); uint32_t cap = rtk_u(cap_);
     if (na > nb) { const uint32_t* t = a; a = b; b = t; const uint32_t tn = na; na = nb; nb = tn; }
     uint32_t cnt = 0;
     for (uint32_t i0 = 0; i0 < na && cnt < cap; i0 += RTK_WAVE) {
@@ -46,7 +48,8 @@ RTK_FN uint32_t rtk_set_inter_count(const uint32_t* a, uint32_t na, const uint32
 }
 
 // out = a | b ; tmp holds b \ a (capacity >= nb)
-RTK_FN uint32_t rtk_set_union(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t* out, uint32_t* tmp) {
+RTK_FN uint32_t rtk_set_union(const uint32_t* a_, uint32_t na_, const uint32_t* b_, uint32_t nb_, uint32_t* out_, uint32_t* tmp_) {
+    const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); uint32_t* out = rtk_u(out_); uint32_t* tmp = rtk_u(tmp_);
     const uint32_t nd = rtk_set_diff(b, nb, a, na, tmp);
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < na; i += RTK_WAVE) out[i + rtk_lower_bound(tmp, nd, a[i])] = a[i];
     for (uint32_t j = static_cast<uint32_t>(rtk_lane()); j < nd; j += RTK_WAVE) out[j + rtk_lower_bound(a, na, tmp[j])] = tmp[j];
@@ -56,7 +59,8 @@ RTK_FN uint32_t rtk_set_union(const uint32_t* a, uint32_t na, const uint32_t* b,
 
 // In-place bitonic sort of n (key, value) pairs by (key, value) ascending. Arrays must have room for the next power of two
 // of n (padded with all-ones keys).
-RTK_FN void rtk_sort_pairs(uint64_t* key, uint64_t* val, uint32_t n) {
+RTK_FN void rtk_sort_pairs(uint64_t* key_, uint64_t* val_, uint32_t n_) {
+    uint64_t* key = rtk_u(key_); uint64_t* val = rtk_u(val_); uint32_t n = rtk_u(n_);
     if (n < 2) return;
     uint32_t p = 1; while (p < n) p <<= 1;
     for (uint32_t i = n + static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) { key[i] = ~0ull; val[i] = ~0ull; }
