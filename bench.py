@@ -31,8 +31,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--serial", action="store_true", help="run the two stages of every step back to back (no overlap between steps)")
     ap.add_argument("--ref-len", type=int, default=5_000_000)
     ap.add_argument("--batch-bases", type=int, default=16_000_000, help="long-read bases per step (per GPU)")
     ap.add_argument("--cpu-sample-bases", type=int, default=16_000_000)
@@ -114,7 +115,8 @@ def main():
     if not mine:
         mine = [tickets[rank % len(tickets)]]
     opts = graph.opts()
-    batches = [api.Batch(graph, *mine[i % len(mine)]) for i in range(min(n_batches, len(mine)))]  # resident in HBM before timing
+    # resident in HBM before timing; at least two batch objects so that consecutive steps can overlap (stage A of step s+1 with stage B of step s)
+    batches = [api.Batch(graph, *mine[i % len(mine)]) for i in range(max(2, min(n_batches, len(mine))))]
 
     def sync():
         if not a.sim:
@@ -122,18 +124,23 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for w in range(a.warmup):
-        batches[w % len(batches)].run(opts)
+    # a step = one batch through both stages. Consecutive steps are software-pipelined on two HIP streams: while the region kernels of
+    # step s run, the (latency-bound) seed kernels of step s+1 run beside them. All K steps are complete before the clock stops.
+    api.run_pipelined([batches[w % len(batches)] for w in range(a.warmup)], opts)
     sync()
     t0 = time.time()
+    seq_b = [batches[(a.warmup + st) % len(batches)] for st in range(a.steps)]
     done_bases, stats = 0, []
-    for st in range(a.steps):
-        b = batches[(a.warmup + st) % len(batches)]
-        b.run(opts)
-        done_bases += b.in_bases
-        stats.append(b.stats())
+    if a.serial:
+        for b in seq_b:
+            b.run(opts)
+    else:
+        api.run_pipelined(seq_b, opts)
     sync()
     dt = time.time() - t0
+    for b in seq_b:
+        done_bases += b.in_bases
+        stats.append(b.stats())
     if world > 1:
         t = torch.tensor([dt, float(done_bases)], dtype=torch.float64, device="cpu" if a.sim else "cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

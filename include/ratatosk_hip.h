@@ -102,6 +102,12 @@ int rtk_correct_batch(rtk_graph* g, const rtk_opts* opts, uint32_t n, const char
  * create = pack + H2D copy, run = kernels only (synchronous), fetch = D2H + unpack. */
 int rtk_batch_create(rtk_graph* g, uint32_t n, const char* const* seq, const char* const* qual, const uint32_t* len, rtk_batch** out);
 int rtk_batch_run(rtk_batch* b, const rtk_opts* opts);
+/* rtk_batch_run = rtk_batch_run_seeds (getSeeds of every read: src/Graph.cpp:3-482) followed by rtk_batch_run_regions (correctSequence
+ * of every read: src/Correction.cpp:159-958). Every batch owns a HIP stream, and each call only waits for that stream: calling the
+ * two stages of DIFFERENT batches from two host threads overlaps them on the device (the seed stage is latency-bound and leaves the
+ * vector ALUs to the region stage of the previous batch), the way the reference overlaps its worker threads (src/Ratatosk.cpp:727). */
+int rtk_batch_run_seeds(rtk_batch* b, const rtk_opts* opts);
+int rtk_batch_run_regions(rtk_batch* b, const rtk_opts* opts);
 int rtk_batch_fetch(rtk_batch* b, char** out_seq, char** out_qual, uint32_t* out_len);
 int rtk_batch_get_stats(const rtk_batch* b, rtk_stats* stats);
 void rtk_batch_free(rtk_batch* b);

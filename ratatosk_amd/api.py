@@ -66,6 +66,8 @@ def load_library(path=None):
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
     L.rtk_batch_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]
     L.rtk_batch_run.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
+    L.rtk_batch_run_seeds.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
+    L.rtk_batch_run_regions.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
     L.rtk_batch_fetch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
     L.rtk_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(RtkStats)]
     L.rtk_batch_free.argtypes = [C.c_void_p]
@@ -172,6 +174,16 @@ class Batch:
         o = opts or self.g.opts()
         self.g._check(self.L.rtk_batch_run(self.h, C.byref(o)))
 
+    def run_seeds(self, opts=None):
+        """Stage A (anchors). May run on another host thread while run_regions of a different batch is in flight."""
+        o = opts or self.g.opts()
+        self.g._check(self.L.rtk_batch_run_seeds(self.h, C.byref(o)))
+
+    def run_regions(self, opts=None):
+        """Stage B (region correction + stitching); needs run_seeds of this batch."""
+        o = opts or self.g.opts()
+        self.g._check(self.L.rtk_batch_run_regions(self.h, C.byref(o)))
+
     def fetch(self):
         n = self.n
         os_, oq = (C.c_void_p * n)(), (C.c_void_p * n)()
@@ -225,3 +237,28 @@ def myers_batch(queries, targets, ks=None, modes=None, want_path=False, use_iupa
             c = cig.raw[i * cap_cig:(i + 1) * cap_cig].split(b"\0", 1)[0].decode()
         out.append((dist[i], el, c))
     return out
+
+
+def run_pipelined(batches, opts=None):
+    """Runs the batches in order with the seed stage of batch i+1 overlapping the region stage of batch i (two host threads,
+    one HIP stream per batch). Results are the same as calling run() on each batch."""
+    import threading
+    prev, err = None, []
+
+    def seeds(b):
+        try:
+            b.run_seeds(opts)
+        except Exception as e:  # surfaced on the calling thread
+            err.append(e)
+
+    for b in batches:
+        t = threading.Thread(target=seeds, args=(b,))
+        t.start()
+        if prev is not None:
+            prev.run_regions(opts)
+        t.join()
+        if err:
+            raise err[0]
+        prev = b
+    if prev is not None:
+        prev.run_regions(opts)

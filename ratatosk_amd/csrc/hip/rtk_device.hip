@@ -1,6 +1,7 @@
 // libratatosk_hip.so: HIP kernels for gfx950 + the C ABI of include/ratatosk_hip.h.
 // (Compiled a second time with -DRTK_SIM by tests/hostsim into a developer simulator; see rtk_wave.h.)
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -42,7 +43,9 @@ struct rtk_graph {
     uint64_t dbytes[rtk::RTK_N_BUFS];
     GraphView dview;
     rtk_graph_info info;
-    void* scratch = nullptr; uint64_t scratch_bytes_ = 0; // per-wave work areas, kept across batches (one batch runs at a time per graph)
+    // per-wave work areas, kept across batches: slot 0 for the seed stage, slot 1 for the region stage. A stage holds its slot's lock
+    // while it runs, so the seed stage of one batch and the region stage of another overlap, two stages of one kind queue up.
+    void* scratch[2] = {nullptr, nullptr}; uint64_t scratch_bytes_[2] = {0, 0}; std::mutex scratch_lock[2];
     rtk_graph() { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { dbuf[i] = nullptr; dbytes[i] = 0; } memset(&dview, 0, sizeof(dview)); memset(&info, 0, sizeof(info)); }
 };
 
@@ -150,7 +153,7 @@ extern "C" int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info) { if
 extern "C" void rtk_graph_free(rtk_graph* g) {
     if (!g) return;
     if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
-    rtk_dfree(g->scratch);
+    rtk_dfree(g->scratch[0]); rtk_dfree(g->scratch[1]);
     delete g;
 }
 
@@ -163,9 +166,9 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
 }
 
 // ------------------------------------------------------------------------------------------------ per-wave scratch
-static char* graph_scratch(rtk_graph* g, uint64_t bytes) { // grows monotonically; hipMalloc/hipFree of tens of GB per batch would dominate a step
-    if (bytes > g->scratch_bytes_) { rtk_dfree(g->scratch); g->scratch = nullptr; g->scratch_bytes_ = 0; g->scratch = rtk_dmalloc(bytes); g->scratch_bytes_ = bytes; }
-    return static_cast<char*>(g->scratch);
+static char* graph_scratch(rtk_graph* g, int slot, uint64_t bytes) { // grows monotonically; hipMalloc/hipFree of tens of GB per batch would dominate a step
+    if (bytes > g->scratch_bytes_[slot]) { rtk_dfree(g->scratch[slot]); g->scratch[slot] = nullptr; g->scratch_bytes_[slot] = 0; g->scratch[slot] = rtk_dmalloc(bytes); g->scratch_bytes_[slot] = bytes; }
+    return static_cast<char*>(g->scratch[slot]);
 }
 
 struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };

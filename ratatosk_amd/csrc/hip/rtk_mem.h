@@ -26,6 +26,11 @@ inline void rtk_h2d(void* d, const void* h, uint64_t n) { if (n) memcpy(d, h, n)
 inline void rtk_d2h(void* h, const void* d, uint64_t n) { if (n) memcpy(h, d, n); }
 inline void rtk_dzero(void* d, uint64_t n) { if (n) memset(d, 0, n); }
 inline void rtk_dsync() {}
+inline rtk_stream_t rtk_stream_create() { return 0; }
+inline void rtk_stream_destroy(rtk_stream_t) {}
+inline void rtk_ssync(rtk_stream_t) {}
+inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t) { if (n) memcpy(h, d, n); }
+inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t) { if (n) memset(d, 0, n); }
 inline int rtk_device_count() { return 1; }
 inline void rtk_set_device(int) {}
 
@@ -58,6 +63,13 @@ inline void rtk_h2d(void* d, const void* h, uint64_t n) { if (n) rtk_check(hipMe
 inline void rtk_d2h(void* h, const void* d, uint64_t n) { if (n) rtk_check(hipMemcpy(h, d, n, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
 inline void rtk_dzero(void* d, uint64_t n) { if (n) rtk_check(hipMemset(d, 0, n), "hipMemset"); }
 inline void rtk_dsync() { rtk_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+// every batch owns a non-blocking stream: its kernels, clears, read-backs and timers are ordered on it and only it is waited for,
+// so the stages of different batches overlap on the device
+inline rtk_stream_t rtk_stream_create() { hipStream_t s = nullptr; rtk_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); return s; }
+inline void rtk_stream_destroy(rtk_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+inline void rtk_ssync(rtk_stream_t s) { rtk_check(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t s) { if (n) { rtk_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "hipMemcpyAsync D2H"); rtk_ssync(s); } }
+inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemsetAsync(d, 0, n, s), "hipMemsetAsync"); }
 inline int rtk_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline void rtk_set_device(int d) { rtk_check(hipSetDevice(d), "hipSetDevice"); }
 
