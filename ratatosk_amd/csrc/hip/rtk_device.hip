@@ -268,6 +268,10 @@ RTK_GLOBAL void k_myers_batch(const MyersProb* probs, uint32_t n, const char* po
         dist[i] = r.dist; n_loc[i] = r.nloc;
         uint32_t nm = 0;
         if (want_path && r.dist >= 0 && p.qlen > 0 && p.tlen > 0) { // edlib.cpp:271-284 (zero-length inputs return before any path is built)
+            if (p.k < 0 && p.mode != RTK_MODE_HW) { // the single-sweep route the region program takes for NW / SHW paths
+                const MyersResult r2 = rtk_myers_path(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.mode, use_iupac != 0, &nm);
+                if (r2.dist != r.dist || r2.first != r.first) *sc.overflow = 3; // must agree with the distance pass
+            } else
             rtk_myers_alignment(sc, q, static_cast<int>(p.qlen), t, r.first + 1, r.dist, use_iupac != 0, &nm);
             if (nm <= cap_moves) rtk_wcopy(moves_out + static_cast<uint64_t>(i) * cap_moves, sc.moves, nm);
         }

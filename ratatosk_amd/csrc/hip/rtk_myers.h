@@ -438,23 +438,16 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, i
 
 // Canonical NW traceback over the stored table, preferring up (insert) > left (delete) > diagonal
 // (edlib.cpp:1021-1137). Appends the moves (already in forward order) to sc.moves at *n_moves.
-RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const MySeq& t_, bool iupac_, uint32_t* n_moves_) {
-    const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_); const bool iupac = rtk_u(iupac_);
-    MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
-    const int m = q.n, n = t.n, W = (m + 63) >> 6;
-    int cur;
-#ifndef RTK_SIM
-    SweepStat fst; fst.plain = false;
-    uint64_t* const tbp = rtk_ld(&sc.tb);
-    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast<1>(q.p, m, t.p, n, 1, iupac, tbp);
-    if (fst.plain) { cur = fst.final_score; rtk_sync(); }
-    else
-#endif
-    { rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr); cur = rtk_ld(rtk_ld(&sc.colscore) + (n - 1)); }
+// Walks the stored table from cell (m, n) back to the origin; `cur` = D[m][n]. Appends the moves to sc.moves (after *n_moves).
+RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int cur_, uint32_t* n_moves_) {
+    const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_);
+    const int m = rtk_u(m_), n = rtk_u(n_), W = (m + 63) >> 6;
+    int cur = rtk_u(cur_);
     int i = m, j = n;
     uint32_t nt = 0; // moves are produced backwards into moves_tmp, from its end
     uint8_t* tmp = rtk_ld(&sc.moves_tmp);
     const uint32_t cap = rtk_ld(&sc.mv_cap);
+    uint64_t* const tbp = rtk_ld(&sc.tb);
 #ifndef RTK_SIM
     // The wave keeps, for the current query word, the four delta words of 64 consecutive columns in registers
     // (lane l <-> column c_hi - l); a traceback step is then scalar (v_readlane), with one table reload per ~60 moves.
@@ -466,10 +459,10 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const 
     while (i > 0 && j > 0) {
         const int r = i - 1, c = j - 1, w = r >> 6, b = r & 63;
 #ifdef RTK_SIM
-        const uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(c) * W + w);
+        const uint64_t* e = tbp + 4ull * (static_cast<uint64_t>(c) * W + w);
         const uint64_t a0 = e[0], a1 = e[1], a2 = e[2], a3 = e[3];
         uint64_t l0 = 0, l1 = 0;
-        if (c > 0) { const uint64_t* el = sc.tb + 4ull * (static_cast<uint64_t>(c - 1) * W + w); l0 = el[0]; l1 = el[1]; }
+        if (c > 0) { const uint64_t* el = tbp + 4ull * (static_cast<uint64_t>(c - 1) * W + w); l0 = el[0]; l1 = el[1]; }
 #else
         if (w != w_cur || c > c_hi || c_hi - c > 62) {
             c_hi = c; w_cur = w;
@@ -498,11 +491,24 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const 
     // whatever is left is a run of inserts (query only) or deletes (target only)
     if (i > 0) { rtk_wfill(tmp + (cap - nt - static_cast<uint32_t>(i)), 1, static_cast<uint64_t>(i)); nt += static_cast<uint32_t>(i); i = 0; }
     if (j > 0) { rtk_wfill(tmp + (cap - nt - static_cast<uint32_t>(j)), 2, static_cast<uint64_t>(j)); nt += static_cast<uint32_t>(j); j = 0; }
-    rtk_wcopy(sc.moves + *n_moves, tmp + (cap - nt), nt);
+    rtk_wcopy(rtk_ld(&sc.moves) + *n_moves, tmp + (cap - nt), nt);
     *n_moves += nt;
 }
 
-// D(query rows, last column) after a pass: out[i] = D[i+1][n], from the final vertical delta vectors.
+RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const MySeq& t_, bool iupac_, uint32_t* n_moves_) {
+    const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_); const bool iupac = rtk_u(iupac_);
+    MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
+    const int m = q.n, n = t.n;
+    int cur;
+#ifndef RTK_SIM
+    SweepStat fst; fst.plain = false;
+    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast<1>(q.p, m, t.p, n, 1, iupac, rtk_ld(&sc.tb));
+    if (fst.plain) { cur = fst.final_score; rtk_sync(); }
+    else
+#endif
+    { rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr); cur = rtk_ld(rtk_ld(&sc.colscore) + (n - 1)); }
+    rtk_myers_walk(sc, m, n, cur, n_moves);
+}
 RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, int m_, int n_, int32_t* out_) {
     const uint64_t* fin_pv = rtk_u(fin_pv_); const uint64_t* fin_mv = rtk_u(fin_mv_); const int m = rtk_u(m_), n = rtk_u(n_); int32_t* out = rtk_u(out_);
     const int W = (m + 63) >> 6;
@@ -580,6 +586,43 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
         st[5 * sp] = q0 + ul; st[5 * sp + 1] = qm - ul; st[5 * sp + 2] = t0 + lh; st[5 * sp + 3] = rh; st[5 * sp + 4] = rs; ++sp;
         st[5 * sp] = q0; st[5 * sp + 1] = ul; st[5 * sp + 2] = t0; st[5 * sp + 3] = lh; st[5 * sp + 4] = ls; ++sp;
     }
+}
+
+// edlibAlign(..., k = -1, NW or SHW, TASK_PATH): result and moves. When the whole table fits the in-memory traceback branch of
+// obtainAlignment (edlib.cpp:1191-1193) ONE stored sweep serves both the distance and the traceback: an SHW matrix restricted to
+// columns [0, end] IS the NW matrix of the truncated target edlib re-aligns (same top row, same left column), so the table
+// entries, the walk and the moves are the same. Anything else (IUPAC/N in the target, long queries, Hirschberg-sized tables)
+// takes the two-pass route.
+RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int mode_, bool iupac_, uint32_t* n_moves_) {
+    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), mode = rtk_u(mode_);
+    const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_);
+    *n_moves = 0;
+    MyersResult r; bool have = false;
+#ifndef RTK_SIM
+    const long long W = (m + 63) >> 6;
+    if (m > 0 && n > 0 && m <= 4096 && static_cast<uint64_t>(4 * W * n) <= sc.tb_cap_words && static_cast<uint32_t>(m + n) <= sc.mv_cap && static_cast<uint32_t>(n) <= sc.t_cap &&
+        static_cast<uint32_t>(m) <= sc.r_cap && static_cast<uint32_t>(W) <= sc.w_cap) {
+        const SweepStat st = rtk_myers_fast<1>(q, m, t, n, 1, iupac, rtk_ld(&sc.tb));
+        rtk_sync();
+        if (st.plain) {
+            r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
+            if (mode == RTK_MODE_NW) { r.dist = st.final_score; r.first = r.last = n - 1; r.nloc = 1; }
+            else { // same bookkeeping as rtk_myers_distance
+                int best = st.best; const bool pseudo = (m & 63) != 0;
+                if (pseudo && m < best) best = m;
+                r.dist = best;
+                if (pseudo && m == best) { r.first = -1; r.last = (st.best == best) ? st.last : -1; r.nloc = 1 + ((st.best == best) ? st.cnt : 0); }
+                else { r.first = st.first; r.last = st.last; r.nloc = st.cnt; }
+            }
+            have = true;
+            const long long tn = (mode == RTK_MODE_NW) ? n : (r.first + 1);
+            if (tn > 0 && (2LL * 8 + 4) * W * tn + 8LL * tn < 1024 * 1024) { rtk_myers_walk(sc, m, static_cast<int>(tn), r.dist, n_moves); return r; }
+        }
+    }
+#endif
+    if (!have) r = rtk_myers_distance(sc, q, m, t, n, -1, mode, iupac);
+    if (m > 0 && n > 0) rtk_myers_alignment(sc, q, m, t, (mode == RTK_MODE_NW) ? n : (r.first + 1), r.dist, iupac, n_moves);
+    return r;
 }
 
 #endif

@@ -321,6 +321,17 @@ RTK_FN MyersResult rtk_align(const RCtx& c, const char* q_, uint32_t m_, const c
     return r;
 }
 
+// alignment with its moves (left in s.my.moves); counted like the distance call + path call pair it replaces
+RTK_FN MyersResult rtk_align_path(const RCtx& c_, const char* q_, uint32_t m_, const char* t_, uint32_t n_, int mode_, uint32_t* n_moves_) {
+    const RCtx& c = *rtk_u(&c_); RegionScratch& s = *c.sc; const char* q = rtk_u(q_); const char* t = rtk_u(t_);
+    const uint32_t m = rtk_u(m_), n = rtk_u(n_); const int mode = rtk_u(mode_); uint32_t* n_moves = rtk_u(n_moves_);
+    s.cnt[3] += (m > 0 && n > 0) ? 2 : 1; s.cnt[4] += static_cast<unsigned long long>((m + 63) / 64) * n;
+    const unsigned long long t0 = rtk_clock();
+    const MyersResult r = rtk_myers_path(s.my, q, static_cast<int>(m), t, static_cast<int>(n), mode, true, n_moves);
+    s.cnt[9] += rtk_clock() - t0;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------ candidate selection (src/Alignment.cpp:3-147, 967-1015)
 // handles[] are committed paths; strings are materialised into str[0].
 RTK_FN void rtk_select_best(const RCtx& c, const uint64_t* handles_, uint32_t n_, const char* ref_, uint32_t ref_len_, int mode_, double cut_, int* best_id, int* best_end) {
@@ -373,9 +384,8 @@ RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl_, const char* ref_, u
     const unsigned long long tq0 = rtk_clock();
     const double score_comp = score_best * ((score_best == 0.0) ? 0.0 : (1.0 - (score_second / score_best)));
     const char* const str1 = rtk_ld(&s.str[1]);
-    const MyersResult a = rtk_align(c, str1, sl, ref, ref_len, -1, RTK_MODE_SHW);
     uint32_t nm = 0;
-    if (sl > 0 && ref_len > 0) { s.cnt[3] += 1; rtk_myers_alignment(s.my, str1, static_cast<int>(sl), ref, rtk_u(a.first) + 1, rtk_u(a.dist), true, &nm); nm = rtk_u(nm); }
+    rtk_align_path(c, str1, sl, ref, ref_len, RTK_MODE_SHW, &nm); nm = rtk_u(nm);
     const char c_best = rtk_get_qual(score_best, 0, static_cast<uint64_t>(rtk_u(c.o.max_qual)));
     rtk_wfill(qout, rtk_get_qual(score_comp, static_cast<uint64_t>(rtk_u(c.o.out_qual)), static_cast<uint64_t>(rtk_u(c.o.max_qual))), sl);
     // walk the moves: a base gets the best-score quality when it sits on an identical reference base in an M run.
@@ -1114,13 +1124,11 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
     else if (nfw + nbw == 0) return false;
     if (nbw > nfw) { const ResCorr* t = fw; fw = bw; bw = t; }
     // NW path alignments of both corrections against the raw region; the moves are parked in str[3] (fw) and str[4] (bw)
-    const MyersResult afw = rtk_align(c, fw->seq, fw->seq_len, ref, ref_len, -1, RTK_MODE_NW);
     uint32_t nm_fw = 0, nm_bw = 0;
-    if (fw->seq_len && ref_len) rtk_myers_alignment(s.my, fw->seq, static_cast<int>(fw->seq_len), ref, static_cast<int>(ref_len), afw.dist, true, &nm_fw);
+    const MyersResult afw = rtk_align_path(c, fw->seq, fw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_fw);
     if (rtk_failed(s) || nm_fw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
     rtk_wcopy(s.str[3], s.my.moves, nm_fw);
-    const MyersResult abw = rtk_align(c, bw->seq, bw->seq_len, ref, ref_len, -1, RTK_MODE_NW);
-    if (bw->seq_len && ref_len) rtk_myers_alignment(s.my, bw->seq, static_cast<int>(bw->seq_len), ref, static_cast<int>(ref_len), abw.dist, true, &nm_bw);
+    const MyersResult abw = rtk_align_path(c, bw->seq, bw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_bw);
     if (rtk_failed(s) || nm_bw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
     rtk_wcopy(s.str[4], s.my.moves, nm_bw);
     const double n_fw = static_cast<double>(afw.dist) / static_cast<double>(fw->seq_len > ref_len ? fw->seq_len : ref_len);
