@@ -233,6 +233,99 @@ __device__ __forceinline__ SweepStat rtk_myers_fast(const char* __restrict__ qp,
     return st;
 }
 #endif
+#ifndef RTK_SIM
+// The same sweep on 32-bit words (queries up to 2048 characters = 64 lanes): every bit-vector operation is one VALU instruction
+// instead of two, and twice as many lanes work per step. The deltas are properties of the DP matrix, not of the word size, so the
+// results - and the traceback table, written as the two halves of the 64-bit entries rtk_myers_walk reads - are the same.
+RTK_DEV int rtk_myers_step32(uint32_t& Pv, uint32_t& Mv, uint32_t Eq, int hin, int bit, uint32_t& Ph_out, uint32_t& Mh_out) {
+    const uint32_t pv = Pv, mv = Mv;
+    const uint32_t Xv = Eq | mv;
+    Eq |= static_cast<uint32_t>(hin) >> 31; // hin < 0
+    const uint32_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+    uint32_t Ph = mv | ~(Xh | pv);
+    uint32_t Mh = pv & Xh;
+    Ph_out = Ph; Mh_out = Mh;
+    const int hout = static_cast<int>((Ph >> bit) & 1u) - static_cast<int>((Mh >> bit) & 1u);
+    Ph = (Ph << 1) | (hin > 0 ? 1u : 0u); Mh = (Mh << 1) | (static_cast<uint32_t>(hin) >> 31);
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+    return hout;
+}
+
+template <int STORE>
+__device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ qp, int m, const char* __restrict__ tp, int n, int top_h, bool iupac, uint64_t* __restrict__ tb) {
+    SweepStat st; st.final_score = m; st.best = 0x7fffffff; st.first = -1; st.last = -1; st.cnt = 0; st.plain = true;
+    const int lane = rtk_lane();
+    const int W = (m + 31) >> 5, W64 = (m + 63) >> 6, last_bit = (m - 1) & 31;
+    const int w = lane;
+    const bool has_word = lane < W;
+    uint32_t eqA = 0, eqC = 0, eqG = 0, eqT = 0;
+    if (has_word) {
+        const int lim = (m - 32 * w) < 32 ? (m - 32 * w) : 32;
+        uint64_t qw[4];
+        for (int j = 0; j < 4; ++j) { uint64_t x = 0; if (8 * j < lim) __builtin_memcpy(&x, qp + 32 * w + 8 * j, 8); qw[j] = x; } // may read up to 7 bytes past the query inside its padded buffer
+        for (int i = 0; i < lim; ++i) {
+            const unsigned char qc = static_cast<unsigned char>((qw[i >> 3] >> (8 * (i & 7))) & 0xFFull);
+            uint32_t bm;
+            if (qc == 'A') bm = 1u; else if (qc == 'C') bm = 2u; else if (qc == 'G') bm = 4u; else if (qc == 'T') bm = 8u;
+            else bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu;
+            eqA |= (bm & 1u) << i; eqC |= ((bm >> 1) & 1u) << i; eqG |= ((bm >> 2) & 1u) << i; eqT |= ((bm >> 3) & 1u) << i;
+        }
+    }
+    const int bit = (w == W - 1) ? last_bit : 31;
+    uint32_t Pv = ~0u, Mv = 0u;
+    int hout_prev = 0; unsigned tc_prev = 0;
+    int score = m;
+    int best = 0x7fffffff, first = -1, last = -1, cnt = 0, fin = m;
+    const int steps = n + W - 1;
+    // table entry of (column, 64-bit word) = 4 x u64 {Pv, Mv, Ph, Mh}; this lane owns the low or high half of each
+    uint32_t* const tb32 = reinterpret_cast<uint32_t*>(tb) + 8ull * (w >> 1) + (w & 1);
+    for (int c0 = 0; c0 < steps; c0 += 64) {
+        const int cj = c0 + lane;
+        int my_t = 'A';
+        if (cj < n) my_t = static_cast<int>(static_cast<unsigned char>(tp[cj]));
+        if (rtk_ballot(!(my_t == 'A' || my_t == 'C' || my_t == 'G' || my_t == 'T')) != 0ull) { st.plain = false; return st; }
+        asm volatile("" : "+v"(my_t));
+        const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
+        for (int j = 0; j < lim; ++j) {
+            const int s = c0 + j;
+            const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
+            const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+            const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(top_h + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
+            const int hin = static_cast<int>(got & 0xFFu) - 1;
+            const unsigned tc = got >> 8;
+            const unsigned sel = (tc >> 1) & 3u; // 'A' -> 0, 'C' -> 1, 'T' -> 2, 'G' -> 3
+            const uint32_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
+            uint32_t nPv = Pv, nMv = Mv, Ph, Mh;
+            const int hout = rtk_myers_step32(nPv, nMv, Eq, hin, bit, Ph, Mh);
+            const int col = s - lane;
+            const bool active = has_word && col >= 0 && col < n;
+            if (STORE) { if (active) { uint32_t* e = tb32 + 8ull * (static_cast<uint64_t>(col) * W64); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } }
+            Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
+            hout_prev = active ? hout : hout_prev;
+            score += (active && lane == W - 1) ? hout : 0;
+            tc_prev = tc;
+            const int tcol = s - (W - 1);
+            if (tcol >= 0) { // wave-uniform: last-row score of column tcol, tracked in scalar registers
+                const int sv = __builtin_amdgcn_readlane(score, W - 1);
+                fin = sv;
+                if (sv < best) { best = sv; first = tcol; last = tcol; cnt = 1; }
+                else if (sv == best) { last = tcol; ++cnt; }
+            }
+        }
+    }
+    st.final_score = fin; st.best = best; st.first = first; st.last = last; st.cnt = cnt;
+    return st;
+}
+
+// dispatcher: 32-bit words up to 2048 query characters, 64-bit words beyond
+template <int STORE>
+__device__ __forceinline__ SweepStat rtk_myers_fast_any(const char* __restrict__ qp, int m, const char* __restrict__ tp, int n, int top_h, bool iupac, uint64_t* __restrict__ tb) {
+    if (m <= 2048) return rtk_myers_fast32<STORE>(qp, m, tp, n, top_h, iupac, tb);
+    return rtk_myers_fast<STORE>(qp, m, tp, n, top_h, iupac, tb);
+}
+#endif
+
 
 // Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
@@ -382,7 +475,7 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, i
     if (static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap) { *sc.overflow = 1; return r; }
 #ifndef RTK_SIM
     if (m <= 4096 && !locs_out) {
-        const SweepStat st = rtk_myers_fast<0>(q, m, t, n, mode == RTK_MODE_HW ? 0 : 1, iupac, nullptr);
+        const SweepStat st = rtk_myers_fast_any<0>(q, m, t, n, mode == RTK_MODE_HW ? 0 : 1, iupac, nullptr);
         if (st.plain) {
             if (mode == RTK_MODE_NW) { if (k >= 0 && st.final_score > k) return r; r.dist = st.final_score; r.first = r.last = n - 1; r.nloc = 1; return r; }
             int best = st.best; const bool pseudo = (m & 63) != 0;
@@ -502,7 +595,7 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const 
     int cur;
 #ifndef RTK_SIM
     SweepStat fst; fst.plain = false;
-    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast<1>(q.p, m, t.p, n, 1, iupac, rtk_ld(&sc.tb));
+    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast_any<1>(q.p, m, t.p, n, 1, iupac, rtk_ld(&sc.tb));
     if (fst.plain) { cur = fst.final_score; rtk_sync(); }
     else
 #endif
@@ -602,7 +695,7 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
     const long long W = (m + 63) >> 6;
     if (m > 0 && n > 0 && m <= 4096 && static_cast<uint64_t>(4 * W * n) <= sc.tb_cap_words && static_cast<uint32_t>(m + n) <= sc.mv_cap && static_cast<uint32_t>(n) <= sc.t_cap &&
         static_cast<uint32_t>(m) <= sc.r_cap && static_cast<uint32_t>(W) <= sc.w_cap) {
-        const SweepStat st = rtk_myers_fast<1>(q, m, t, n, 1, iupac, rtk_ld(&sc.tb));
+        const SweepStat st = rtk_myers_fast_any<1>(q, m, t, n, 1, iupac, rtk_ld(&sc.tb));
         rtk_sync();
         if (st.plain) {
             r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
