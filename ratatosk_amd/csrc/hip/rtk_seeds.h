@@ -22,6 +22,7 @@ struct BatchView {
     U<uint64_t> n_bases;
     U<const char*> seq;          // upper-cased reads, concatenated
     U<const uint64_t*> roff;     // [n_reads+1]
+    U<const uint32_t*> order;    // [n_reads] read indices, longest first (per-read kernels start their longest items first)
     U<uint64_t*> hits;           // [n_bases] exact hit of the window starting at each base (packed, RTK_NO_HIT if none)
     U<char*> masked;             // [n_bases] the 'N'-masked copy searched inexactly (src/Graph.cpp:102)
     U<uint64_t*> wdesc;          // [n_bases] group of raw inexact hits of the window: pool offset << 24 | count
@@ -382,29 +383,43 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
     if (rtk_lane() == 0) { bv.n_solid[r] = 0; bv.w_cnt[r] = 0; bv.w_off[r] = 0; }
     if (L <= k) { rtk_sync(); return; }
     const uint32_t nwin = L - k + 1;
+    unsigned long long tph[8]; int iph = 0; const unsigned long long tstart = rtk_clock(); unsigned long long tlast = tstart;
+#define RTK_PHASE() { const unsigned long long tn_ = rtk_clock(); tph[iph++] = tn_ - tlast; tlast = tn_; }
     const uint64_t* hits = bv.hits + base;
     uint32_t* s_pos = bv.s_pos + base;
     // ---- solid = exact hits minus runs that overlap the next run by less than k (src/Graph.cpp:221-239) ----
     // hit x (run end e, next hit nx after the gap) is dropped iff nx < x + k.
+    // In bits: with b = presence of the k-1 windows after x (bit 0 = x+1), x is dropped iff b has a one above its first zero,
+    // i.e. iff b & (b + 1) != 0. One ballot per 64 windows gives the presence bits; each lane looks at its own and the next block's.
     uint32_t n1 = 0;
-    for (uint32_t c0 = 0; c0 < nwin; c0 += RTK_WAVE) {
-        const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane());
-        bool keep = false;
-        if (x < nwin && hits[x] != RTK_NO_HIT) {
-            keep = true;
-            uint32_t j = x + 1;
-            while (j < nwin && j < x + k && hits[j] != RTK_NO_HIT) ++j; // j = first non-hit after the run (or limit)
-            if (j < nwin && j < x + k) { // run ended at j-1 < x+k-1: look for the next hit before x+k
-                uint32_t nx = j + 1;
-                while (nx < nwin && nx < x + k && hits[nx] == RTK_NO_HIT) ++nx;
-                if (nx < nwin && nx < x + k) keep = false;
-            }
-        }
-        const uint64_t bal = rtk_ballot(keep);
-        if (keep) s_pos[n1 + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)))] = x;
-        n1 += static_cast<uint32_t>(rtk_popc(bal));
+#ifdef RTK_SIM
+    for (uint32_t x = 0; x < nwin; ++x) {
+        if (hits[x] == RTK_NO_HIT) continue;
+        uint64_t b = 0;
+        for (uint32_t j = 1; j < k; ++j) if (x + j < nwin && hits[x + j] != RTK_NO_HIT) b |= 1ull << (j - 1);
+        if ((b & (b + 1ull)) == 0) s_pos[n1++] = x;
     }
+#else
+    {
+        const uint32_t lane = static_cast<uint32_t>(rtk_lane());
+        uint64_t cur = rtk_ballot(lane < nwin && hits[lane] != RTK_NO_HIT);
+        for (uint32_t c0 = 0; c0 < nwin; c0 += RTK_WAVE) {
+            const uint32_t xn = c0 + RTK_WAVE + lane;
+            const uint64_t nxt = rtk_ballot(xn < nwin && hits[xn] != RTK_NO_HIT);
+            const uint32_t x = c0 + lane;
+            // bits x+1 .. x+k-1 of the 128-bit presence string (k - 1 <= 62)
+            const uint64_t after = (lane == 63) ? nxt : ((cur >> (lane + 1)) | (nxt << (63 - lane)));
+            const uint64_t b = after & ((1ull << (k - 1)) - 1ull);
+            const bool keep = ((cur >> lane) & 1ull) && ((b & (b + 1ull)) == 0);
+            const uint64_t bal = rtk_ballot(keep);
+            if (keep) s_pos[n1 + static_cast<uint32_t>(rtk_popc(bal & ((1ull << lane) - 1ull)))] = x;
+            n1 += static_cast<uint32_t>(rtk_popc(bal));
+            cur = nxt;
+        }
+    }
+#endif
     rtk_sync();
+    RTK_PHASE();
     // ---- adjacent solid anchors on different unitigs must be graph neighbours sharing >= min_cov colours (:329-372) ----
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n1; i += RTK_WAVE) sc.sflag[i] = 0; // 1 = emptied
     rtk_sync();
@@ -446,33 +461,66 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
     }
     rtk_sync();
     if (rtk_lane() == 0) bv.n_solid[r] = n2;
+    RTK_PHASE();
     // ---- weak = raw inexact hits sorted by (pos, mapped k-mer), deduplicated (src/Graph.cpp:201-216) ----
+    // 64 windows per step. Windows holding several raw hits are first sorted by k-mer and stripped of duplicates in place (one
+    // window at a time, the whole wave on it); then every lane appends the hits of its own window at its prefix-sum offset.
     uint32_t nv = 0; bool ovf = false;
-    for (uint32_t c0 = 0; c0 < nwin && !ovf; c0 += 64) {
-        uint64_t bal;
-#ifdef RTK_SIM
-        bal = 0; for (uint32_t j = 0; j < 64 && c0 + j < nwin; ++j) if (bv.wdesc[base + c0 + j]) bal |= 1ull << j;
-#else
-        { const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane()); bal = rtk_ballot(x < nwin && bv.wdesc[base + x] != 0); }
-#endif
-        while (bal && !ovf) {
-            const uint32_t p = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u;
-            bal &= bal - 1ull;
-            const uint64_t d = bv.wdesc[base + p];
-            const uint64_t off = d >> 24; const uint32_t cnt = static_cast<uint32_t>(d & 0xFFFFFFull);
-            // sort the group by k-mer code in scratch (vkey/vidx), then append unique codes
-            for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < cnt; i += RTK_WAVE) { sc.vkey[i] = bv.ipool[2 * (off + i)]; sc.vidx[i] = bv.ipool[2 * (off + i) + 1]; }
-            rtk_sync();
-            rtk_sort_pairs(sc.vkey, sc.vidx, cnt);
-            for (uint32_t i = 0; i < cnt && !ovf; ++i) {
-                if (i > 0 && sc.vkey[i] == sc.vkey[i - 1]) continue;
-                if (nv >= sc.v_cap) { ovf = true; break; }
-                sc.vpos[nv] = p; sc.vcode[nv] = sc.vkey[i]; sc.vhit[nv] = sc.vidx[i]; ++nv;
+    for (uint32_t c0 = 0; c0 < nwin && !ovf; c0 += RTK_WAVE) {
+        const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane());
+        const uint64_t d = (x < nwin) ? bv.wdesc[base + x] : 0ull;
+        const uint64_t off = d >> 24; const uint32_t cnt = static_cast<uint32_t>(d & 0xFFFFFFull);
+        uint32_t ucnt = cnt ? 1u : 0u;
+        uint64_t multi = rtk_ballot(cnt >= 2);
+        while (multi) {
+            const int sl = rtk_ffs(multi) - 1;
+            multi &= multi - 1ull;
+            const uint64_t w_off = rtk_u(rtk_shfl(off, sl)); const uint32_t w_cnt = rtk_u(rtk_shfl(cnt, sl));
+#ifndef RTK_SIM
+            if (w_cnt <= 64) { // the usual case: the group fits one element per lane -> rank by all-pairs comparison in registers, no scratch, no barrier
+                const uint32_t li = static_cast<uint32_t>(rtk_lane());
+                uint64_t key = ~0ull, val = ~0ull;
+                if (li < w_cnt) { key = bv.ipool[2 * (w_off + li)]; val = bv.ipool[2 * (w_off + li) + 1]; }
+                bool dup = false;
+                for (uint32_t j = 0; j < w_cnt; ++j) { // is an equal k-mer ordered before mine? ((k-mer, hit, index) ascending, like the sort + first-of-run rule)
+                    const uint64_t kj = rtk_shfl(key, static_cast<int>(j)), vj = rtk_shfl(val, static_cast<int>(j));
+                    dup = dup || (kj == key && (vj < val || (vj == val && j < li)));
+                }
+                const bool uq = li < w_cnt && !dup;
+                uint64_t ub = rtk_ballot(uq);
+                const uint32_t nu = static_cast<uint32_t>(rtk_popc(ub));
+                uint32_t pos = 0;
+                while (ub) { const int j = rtk_ffs(ub) - 1; ub &= ub - 1ull; pos += (rtk_shfl(key, j) < key) ? 1u : 0u; }
+                if (uq) { bv.ipool[2 * (w_off + pos)] = key; bv.ipool[2 * (w_off + pos) + 1] = val; }
+                if (static_cast<int>(li) == sl) ucnt = nu;
+                continue;
             }
+#endif
+            if (2ull * w_cnt > 2ull * sc.v_cap + 512ull) { ovf = true; break; } // vkey / vidx hold 2 * v_cap + 512 entries, the sort pads to a power of two
+            for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < w_cnt; i += RTK_WAVE) { sc.vkey[i] = bv.ipool[2 * (w_off + i)]; sc.vidx[i] = bv.ipool[2 * (w_off + i) + 1]; }
+            rtk_sync();
+            rtk_sort_pairs(sc.vkey, sc.vidx, w_cnt);
+            uint32_t nu = 0; // first entry of every run of equal k-mers goes back to the front of the group
+            for (uint32_t i0 = 0; i0 < w_cnt; i0 += RTK_WAVE) {
+                const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+                const bool uq = i < w_cnt && (i == 0 || sc.vkey[i] != sc.vkey[i - 1]);
+                const uint64_t ub = rtk_ballot(uq);
+                if (uq) { const uint64_t dst = w_off + nu + static_cast<uint32_t>(rtk_popc(ub & ((1ull << rtk_lane()) - 1ull))); bv.ipool[2 * dst] = sc.vkey[i]; bv.ipool[2 * dst + 1] = sc.vidx[i]; }
+                nu += static_cast<uint32_t>(rtk_popc(ub));
+            }
+            rtk_sync();
+            if (rtk_lane() == sl) ucnt = nu;
         }
+        if (ovf) break;
+        rtk_sync(); // compacted groups are read back by their window's lane
+        int tot = 0; const uint32_t my_off = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(ucnt), &tot));
+        if (nv + static_cast<uint32_t>(tot) > sc.v_cap) { ovf = true; break; }
+        for (uint32_t i = 0; i < ucnt; ++i) { const uint32_t o = nv + my_off + i; sc.vpos[o] = x; sc.vcode[o] = bv.ipool[2 * (off + i)]; sc.vhit[o] = bv.ipool[2 * (off + i) + 1]; }
+        nv += static_cast<uint32_t>(tot);
     }
     if (ovf) { *sc.overflow = 1; nv = 0; }
     rtk_sync();
+    RTK_PHASE();
     // ---- keep_non_overlap (src/Alignment.cpp:1017-1199) ----
     // NB: an inexact hit is never "solid": its mapped k-mer differs from the read window by construction.
     uint32_t n_keep = 0;
@@ -488,15 +536,25 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
         { // number of classified hits = first index with an all-ones key
             uint32_t lo = 0, hi = nv; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.vkey[mid] == ~0ull) hi = mid; else lo = mid + 1; } nvalid = lo;
         }
+        RTK_PHASE();
         // groups of equal key
         uint32_t ng = 0;
-        for (uint32_t i = 0; i < nvalid;) {
-            uint32_t j = i; uint32_t ps = 0xFFFFFFFFu, pe = 0;
-            while (j < nvalid && sc.vkey[j] == sc.vkey[i]) { const uint32_t pp = sc.vpos[sc.vidx[j]]; ps = pp < ps ? pp : ps; pe = (pp + k) > pe ? (pp + k) : pe; ++j; }
-            sc.gstart[ng] = i; sc.gcnt[ng] = j - i; sc.gps[ng] = ps; sc.gpe[ng] = pe; sc.gkeep[ng] = 1; ++ng;
-            i = j;
+        for (uint32_t i0 = 0; i0 < nvalid; i0 += RTK_WAVE) { // group starts, compacted in order
+            const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+            const bool st = i < nvalid && (i == 0 || sc.vkey[i] != sc.vkey[i - 1]);
+            const uint64_t sb = rtk_ballot(st);
+            if (st) sc.gstart[ng + static_cast<uint32_t>(rtk_popc(sb & ((1ull << rtk_lane()) - 1ull)))] = i;
+            ng += static_cast<uint32_t>(rtk_popc(sb));
         }
         rtk_sync();
+        for (uint32_t gi = static_cast<uint32_t>(rtk_lane()); gi < ng; gi += RTK_WAVE) { // one group per lane: extent and position span
+            const uint32_t a = sc.gstart[gi], e = (gi + 1 < ng) ? sc.gstart[gi + 1] : nvalid;
+            uint32_t ps = 0xFFFFFFFFu, pe = 0;
+            for (uint32_t j = a; j < e; ++j) { const uint32_t pp = sc.vpos[sc.vidx[j]]; ps = pp < ps ? pp : ps; pe = (pp + k) > pe ? (pp + k) : pe; }
+            sc.gcnt[gi] = e - a; sc.gps[gi] = ps; sc.gpe[gi] = pe; sc.gkeep[gi] = 1;
+        }
+        rtk_sync();
+        RTK_PHASE();
         // a variant is dropped iff another variant overlaps it within k without sharing a unitig (order independent)
         for (uint32_t gi = static_cast<uint32_t>(rtk_lane()); gi < ng; gi += RTK_WAVE) {
             const uint64_t k1 = sc.vkey[sc.gstart[gi]]; const uint32_t p1 = static_cast<uint32_t>(k1 >> 16);
@@ -528,6 +586,7 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
         rtk_sync();
         for (uint32_t gi = static_cast<uint32_t>(rtk_lane()); gi < ng; gi += RTK_WAVE) if (sc.gkeep[gi]) for (uint32_t a = 0; a < sc.gcnt[gi]; ++a) sc.vflag[sc.vidx[sc.gstart[gi] + a]] = 1;
         rtk_sync();
+        RTK_PHASE();
         // count, reserve space in the weak pool, write in original order
         for (uint32_t c0 = 0; c0 < nv; c0 += RTK_WAVE) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); n_keep += static_cast<uint32_t>(rtk_popc(rtk_ballot(i < nv && sc.vflag[i]))); }
         if (n_keep) {
@@ -548,6 +607,14 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
             }
         }
     }
+    RTK_PHASE();
+    if (rtk_lane() == 0) { // phase profile of the stage (wave cycles), read back under RTK_TRACE
+        for (int i = 0; i < iph && i < 7; ++i) rtk_atomic_add(bv.counters + 24 + i, tph[i]);
+#ifndef RTK_SIM
+        atomicMax(bv.counters.get() + 31, rtk_clock() - tstart);
+#endif
+    }
+#undef RTK_PHASE
     rtk_sync();
 }
 
