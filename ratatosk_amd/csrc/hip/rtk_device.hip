@@ -196,26 +196,36 @@ RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
 // ------------------------------------------------------------------------------------------------ K1: exact k-mer lookup
 // dbg.searchSequence(s, exact) (reference: src/Graph.cpp:97 [A1]). One lane per k-mer window; windows are addressed
 // by their base position in the concatenated read buffer. hits[b] = packed (unitig, dist, strand) or RTK_NO_HIT.
-RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* roff, uint32_t n_reads, uint64_t n_bases, int grid, uint64_t* hits, uint64_t* n_probes_out) {
+RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* roff, uint32_t n_reads, uint64_t n_bases, int grid, uint64_t* hits, uint64_t* hitmap, uint64_t* n_probes_out) {
     const uint64_t n_tiles = (n_bases + RTK_WAVE - 1) / RTK_WAVE;
     uint32_t probes = 0, slots = 0;
     for (uint64_t tile = static_cast<uint64_t>(RTK_BLOCK_ID); tile < n_tiles; tile += static_cast<uint64_t>(grid)) {
         const uint64_t b = tile * RTK_WAVE + static_cast<uint64_t>(rtk_lane());
-        if (b >= n_bases) continue;
-        // owning read: largest r with roff[r] <= b
-        uint32_t lo = 0, hi = n_reads;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (roff[mid] <= b) lo = mid; else hi = mid; }
         uint64_t h = RTK_NO_HIT;
-        if (b + static_cast<uint64_t>(g.k) <= roff[lo + 1]) {
-            uint64_t fw = 0; bool ok = true;
-            for (int i = 0; i < g.k; ++i) {
-                const int c = rtk_cls(static_cast<unsigned char>(seq[b + i]));
-                if (c > 3) { ok = false; break; }
-                fw = (fw << 2) | static_cast<uint64_t>(c);
+        if (b < n_bases) {
+            // owning read: largest r with roff[r] <= b
+            uint32_t lo = 0, hi = n_reads;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (roff[mid] <= b) lo = mid; else hi = mid; }
+            if (b + static_cast<uint64_t>(g.k) <= roff[lo + 1]) {
+                uint64_t fw = 0; bool ok = true;
+                for (int i = 0; i < g.k; ++i) {
+                    const int c = rtk_cls(static_cast<unsigned char>(seq[b + i]));
+                    if (c > 3) { ok = false; break; }
+                    fw = (fw << 2) | static_cast<uint64_t>(c);
+                }
+                if (ok) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += 1; slots += np; }
             }
-            if (ok) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += 1; slots += np; }
+            hits[b] = h;
         }
-        hits[b] = h;
+        // presence bit of every window (bit b & 63 of word b >> 6): the per-read programs scan 64 windows per word instead of 64 hits
+        if (hitmap) {
+#ifdef RTK_SIM
+            if (h != RTK_NO_HIT) __atomic_fetch_or(hitmap + (b >> 6), 1ull << (b & 63), __ATOMIC_RELAXED);
+#else
+            const uint64_t bal = rtk_ballot(h != RTK_NO_HIT);
+            if (rtk_lane() == 0) hitmap[tile] = bal;
+#endif
+        }
     }
     if (n_probes_out) { // n_probes_out[0] += k-mer queries, n_probes_out[11] += 16-byte table slots visited (RTK_CNT_PROBES_EXACT -> RTK_CNT_SLOTS_EXACT)
         const int tot = rtk_wave_sum(static_cast<int>(probes)), tots = rtk_wave_sum(static_cast<int>(slots));
@@ -243,7 +253,7 @@ extern "C" int rtk_lookup_exact(rtk_graph* g, const char* seq, uint32_t len, int
         uint64_t* dhits = static_cast<uint64_t*>(rtk_dmalloc(8ull * (len + 1)));
         const uint64_t roff[2] = {0, len};
         rtk_h2d(dseq, up.data(), len); rtk_h2d(droff, roff, 16);
-        rtk_launch(k_lookup_exact, default_grid(), 0, g->dview, static_cast<const char*>(dseq), static_cast<const uint64_t*>(droff), 1u, static_cast<uint64_t>(len), default_grid(), dhits, static_cast<uint64_t*>(nullptr));
+        rtk_launch(k_lookup_exact, default_grid(), 0, g->dview, static_cast<const char*>(dseq), static_cast<const uint64_t*>(droff), 1u, static_cast<uint64_t>(len), default_grid(), dhits, static_cast<uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr));
         rtk_dsync();
         std::vector<uint64_t> h(len + 1);
         rtk_d2h(h.data(), dhits, 8ull * len);

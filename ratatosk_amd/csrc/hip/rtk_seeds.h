@@ -24,6 +24,7 @@ struct BatchView {
     U<const uint64_t*> roff;     // [n_reads+1]
     U<const uint32_t*> order;    // [n_reads] read indices, longest first (per-read kernels start their longest items first)
     U<uint64_t*> hits;           // [n_bases] exact hit of the window starting at each base (packed, RTK_NO_HIT if none)
+    U<uint64_t*> hitmap;         // [n_bases/64 + 2] bit b&63 of word b>>6: window b has an exact hit
     U<char*> masked;             // [n_bases] the 'N'-masked copy searched inexactly (src/Graph.cpp:102)
     U<uint64_t*> wdesc;          // [n_bases] group of raw inexact hits of the window: pool offset << 24 | count
     U<uint64_t*> ipool;          // raw inexact hits {k-mer code in read orientation, packed hit}
@@ -145,6 +146,43 @@ RTK_FN uint32_t rtk_union_unitig(const GraphView& g_, const SeedScratch& sc_, in
 }
 
 // ---------------------------------------------------------------------------------------------- mask (src/Graph.cpp:102-191)
+// presence bits of the 64 windows starting at global position g0 (bit j = window g0 + j), limited to the first n_valid of them
+RTK_DEV uint64_t rtk_hit_bits(const uint64_t* map, uint64_t g0, uint64_t n_valid) {
+    if (n_valid == 0) return 0ull;
+    const uint64_t w0 = map[g0 >> 6], sh = g0 & 63ull;
+    uint64_t bits = w0 >> sh;
+    if (sh) bits |= map[(g0 >> 6) + 1] << (64ull - sh);
+    return n_valid >= 64 ? bits : (bits & ((1ull << n_valid) - 1ull));
+}
+
+// Visits the exact hits at windows lo .. hi (inclusive, read coordinates) in ascending (dir > 0) or descending order and calls
+// fn(unitig) at every change of unitig (src/Graph.cpp:127-183 walks the hits one by one and reacts to unitig changes only).
+// 64 windows per step: presence bits from the bitmap, the hits of the set bits fetched by their lanes, changes found with a ballot.
+template <class Fn>
+RTK_DEV void rtk_scan_hit_runs(const uint64_t* hits, const uint64_t* hmap, uint64_t base, uint32_t nwin, int64_t lo, int64_t hi, int dir, Fn fn) {
+    uint32_t prev_u = RTK_NONE32;
+    if (hi >= static_cast<int64_t>(nwin)) hi = static_cast<int64_t>(nwin) - 1;
+    if (lo < 0) lo = 0;
+    for (int64_t done = 0; lo + done <= hi; done += RTK_WAVE) {
+        const int64_t x = dir > 0 ? (lo + done + rtk_lane()) : (hi - done - rtk_lane());
+        bool valid = x >= lo && x <= hi;
+        if (valid) { const uint64_t g = base + static_cast<uint64_t>(x); valid = (hmap[g >> 6] >> (g & 63ull)) & 1ull; }
+        uint32_t u = RTK_NONE32;
+        if (valid) u = rtk_hit_unitig(hits[x]);
+        const uint64_t m = rtk_ballot(valid);
+        if (!m) continue;
+        const uint64_t pm = m & ((1ull << rtk_lane()) - 1ull);
+        const uint32_t up = rtk_shfl(u, pm ? (63 - __builtin_clzll(pm)) : 0);
+        const uint32_t u_before = pm ? up : prev_u;
+        uint64_t st = rtk_ballot(valid && (u_before == RTK_NONE32 || u != u_before));
+        while (st) {
+            const int l = rtk_ffs(st) - 1; st &= st - 1ull;
+            if (!fn(rtk_u(rtk_shfl(u, l)))) return;
+        }
+        prev_u = rtk_u(rtk_shfl(u, 63 - __builtin_clzll(m)));
+    }
+}
+
 RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
     const uint64_t base = bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
@@ -154,19 +192,27 @@ RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView
     const uint32_t nwin = L - k + 1;
     const uint64_t* hits = bv.hits + base;
     int64_t prev = -1, first = -1;
-    for (uint32_t c0 = 0; c0 < nwin; c0 += 64) {
-        uint64_t bal;
-#ifdef RTK_SIM
-        bal = 0; for (uint32_t j = 0; j < 64 && c0 + j < nwin; ++j) if (hits[c0 + j] != RTK_NO_HIT) bal |= 1ull << j;
-#else
-        { const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane()); bal = rtk_ballot(x < nwin && hits[x] != RTK_NO_HIT); }
-#endif
+    const uint64_t* hmap = bv.hitmap;
+    for (uint32_t cc = 0; cc < nwin; cc += 64 * RTK_WAVE) { // every lane fetches the presence bits of one 64-window block, then the blocks are visited in order
+        const uint32_t my_c0 = cc + 64u * static_cast<uint32_t>(rtk_lane());
+        const uint64_t my_bits = (my_c0 < nwin) ? rtk_hit_bits(hmap, base + my_c0, nwin - my_c0) : 0ull;
+      for (int bl = 0; bl < RTK_WAVE; ++bl) {
+        const uint32_t c0 = cc + 64u * static_cast<uint32_t>(bl);
+        if (c0 >= nwin) break;
+        uint64_t bal = rtk_u(rtk_shfl(my_bits, bl));
         if (bal == ~0ull && prev == static_cast<int64_t>(c0) - 1) { if (first < 0) first = c0; prev = c0 + 63; continue; } // inside a run: no gap
-        while (bal) {
-            const uint32_t p = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u;
-            bal &= bal - 1ull;
-            if (prev >= 0 && static_cast<int64_t>(p) != prev + 1) {
-                const uint32_t pv = static_cast<uint32_t>(prev);
+        // only the first hit of a run can close a gap: visit run starts, with `prev` = the last hit before each of them
+        const uint64_t all_hits = bal; const int64_t prev_in = prev;
+        uint64_t starts = bal & ~((bal << 1) | ((prev_in >= 0 && prev_in == static_cast<int64_t>(c0) - 1) ? 1ull : 0ull));
+        if (all_hits) prev = static_cast<int64_t>(c0) + 63 - __builtin_clzll(all_hits);
+        while (starts) {
+            const int bit = rtk_ffs(starts) - 1;
+            const uint32_t p = c0 + static_cast<uint32_t>(bit);
+            starts &= starts - 1ull;
+            const uint64_t below = all_hits & ((1ull << bit) - 1ull);
+            const int64_t prev_hit = below ? (static_cast<int64_t>(c0) + 63 - __builtin_clzll(below)) : prev_in;
+            if (prev_hit >= 0) {
+                const uint32_t pv = static_cast<uint32_t>(prev_hit);
                 const uint32_t diff = p - pv;
                 bool unmask = false;
                 if (diff >= o.insert_sz) unmask = true;
@@ -174,37 +220,26 @@ RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView
                     const uint32_t ssl = o.insert_sz - diff;
                     const uint32_t min_pos_left = (pv < ssl) ? 0u : (pv - ssl);
                     const uint64_t max_pos_right = static_cast<uint64_t>(p) + ssl;
-                    int cur = 0; uint32_t nL = 0, nR = 0; uint32_t prev_u = RTK_NONE32; bool ovf = false;
-                    for (int64_t x = pv; x > static_cast<int64_t>(min_pos_left) && !ovf; --x) { // G13: index 0 is never visited
-                        const uint64_t h = hits[x];
-                        if (h == RTK_NO_HIT) continue;
-                        if (x == first) break;
-                        const uint32_t u = rtk_hit_unitig(h);
-                        if (prev_u == RTK_NONE32 || u != prev_u) {
-                            if (!rtk_is_branching(g, u)) { nL = rtk_union_unitig(g, sc, cur, nL, u); if (nL == 0xFFFFFFFFu) ovf = true; }
-                            prev_u = u;
-                        }
-                    }
+                    int cur = 0; uint32_t nL = 0, nR = 0; bool ovf = false;
+                    // left of the gap: hits at pv, pv-1, ... above min_pos_left, stopping before the read's first hit (G13: index 0 is never visited)
+                    const int64_t lb = (first > static_cast<int64_t>(min_pos_left)) ? first : static_cast<int64_t>(min_pos_left);
+                    rtk_scan_hit_runs(hits, hmap, base, nwin, lb + 1, static_cast<int64_t>(pv), -1, [&](uint32_t u) {
+                        if (!rtk_is_branching(g, u)) { nL = rtk_union_unitig(g, sc, cur, nL, u); if (nL == 0xFFFFFFFFu) { ovf = true; return false; } }
+                        return true; });
                     if (!ovf) { // park the left union in set[3]
                         if (nL > sc.set_cap) ovf = true; else rtk_wcopy(sc.set[3], sc.set[cur], 4ull * nL);
                     }
-                    cur = 0; prev_u = RTK_NONE32;
-                    for (uint64_t x = p; x < max_pos_right && x < nwin && !ovf; ++x) {
-                        const uint64_t h = hits[x];
-                        if (h == RTK_NO_HIT) continue;
-                        const uint32_t u = rtk_hit_unitig(h);
-                        if (prev_u == RTK_NONE32 || u != prev_u) {
-                            if (!rtk_is_branching(g, u)) { nR = rtk_union_unitig(g, sc, cur, nR, u); if (nR == 0xFFFFFFFFu) ovf = true; }
-                            prev_u = u;
-                        }
-                    }
+                    cur = 0;
+                    if (!ovf) rtk_scan_hit_runs(hits, hmap, base, nwin, static_cast<int64_t>(p), static_cast<int64_t>(max_pos_right) - 1, +1, [&](uint32_t u) {
+                        if (!rtk_is_branching(g, u)) { nR = rtk_union_unitig(g, sc, cur, nR, u); if (nR == 0xFFFFFFFFu) { ovf = true; return false; } }
+                        return true; });
                     if (!ovf) unmask = rtk_set_inter_count(sc.set[3], nL, sc.set[cur], nR, o.min_cov_vertices) < o.min_cov_vertices;
                 }
                 if (unmask) rtk_wcopy(bv.masked + base + pv + k, bv.seq + base + pv + k, diff - k);
             }
             if (first < 0) first = p;
-            prev = p;
         }
+      }
     }
     if (first >= 0) {
         if (static_cast<uint64_t>(first) >= o.insert_sz / 2) rtk_wcopy(bv.masked + base, bv.seq + base, static_cast<uint64_t>(first) + k - 1);
@@ -392,32 +427,38 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
     // In bits: with b = presence of the k-1 windows after x (bit 0 = x+1), x is dropped iff b has a one above its first zero,
     // i.e. iff b & (b + 1) != 0. One ballot per 64 windows gives the presence bits; each lane looks at its own and the next block's.
     uint32_t n1 = 0;
-#ifdef RTK_SIM
-    for (uint32_t x = 0; x < nwin; ++x) {
-        if (hits[x] == RTK_NO_HIT) continue;
-        uint64_t b = 0;
-        for (uint32_t j = 1; j < k; ++j) if (x + j < nwin && hits[x + j] != RTK_NO_HIT) b |= 1ull << (j - 1);
-        if ((b & (b + 1ull)) == 0) s_pos[n1++] = x;
-    }
-#else
     {
+        const uint64_t* hmap = bv.hitmap;
         const uint32_t lane = static_cast<uint32_t>(rtk_lane());
-        uint64_t cur = rtk_ballot(lane < nwin && hits[lane] != RTK_NO_HIT);
-        for (uint32_t c0 = 0; c0 < nwin; c0 += RTK_WAVE) {
-            const uint32_t xn = c0 + RTK_WAVE + lane;
-            const uint64_t nxt = rtk_ballot(xn < nwin && hits[xn] != RTK_NO_HIT);
-            const uint32_t x = c0 + lane;
-            // bits x+1 .. x+k-1 of the 128-bit presence string (k - 1 <= 62)
-            const uint64_t after = (lane == 63) ? nxt : ((cur >> (lane + 1)) | (nxt << (63 - lane)));
-            const uint64_t b = after & ((1ull << (k - 1)) - 1ull);
-            const bool keep = ((cur >> lane) & 1ull) && ((b & (b + 1ull)) == 0);
-            const uint64_t bal = rtk_ballot(keep);
-            if (keep) s_pos[n1 + static_cast<uint32_t>(rtk_popc(bal & ((1ull << lane) - 1ull)))] = x;
-            n1 += static_cast<uint32_t>(rtk_popc(bal));
-            cur = nxt;
+        const uint64_t kmask = (1ull << (k - 1)) - 1ull;
+        for (uint32_t cc = 0; cc < nwin; cc += 64 * RTK_WAVE) { // one 64-window block (and its successor) per lane, fetched together
+            const uint32_t my_c0 = cc + 64u * lane;
+            const uint64_t my_cur = (my_c0 < nwin) ? rtk_hit_bits(hmap, base + my_c0, nwin - my_c0) : 0ull;
+            const uint64_t my_nxt = (my_c0 + 64 < nwin) ? rtk_hit_bits(hmap, base + my_c0 + 64, nwin - my_c0 - 64) : 0ull;
+            for (int bl = 0; bl < RTK_WAVE; ++bl) {
+                const uint32_t c0 = cc + 64u * static_cast<uint32_t>(bl);
+                if (c0 >= nwin) break;
+                const uint64_t cur = rtk_u(rtk_shfl(my_cur, bl)), nxt = rtk_u(rtk_shfl(my_nxt, bl));
+                if (cur == 0) continue;
+#ifdef RTK_SIM
+                for (uint32_t j = 0; j < 64; ++j) { // the 1-lane simulator walks the 64 windows of the block
+                    if (!((cur >> j) & 1ull)) continue;
+                    const uint64_t after = (j == 63) ? nxt : ((cur >> (j + 1)) | (nxt << (63 - j)));
+                    const uint64_t b = after & kmask;
+                    if ((b & (b + 1ull)) == 0) s_pos[n1++] = c0 + j;
+                }
+#else
+                // bits x+1 .. x+k-1 of the 128-bit presence string (k - 1 <= 62)
+                const uint64_t after = (lane == 63) ? nxt : ((cur >> (lane + 1)) | (nxt << (63 - lane)));
+                const uint64_t b = after & kmask;
+                const bool keep = ((cur >> lane) & 1ull) && ((b & (b + 1ull)) == 0);
+                const uint64_t bal = rtk_ballot(keep);
+                if (keep) s_pos[n1 + static_cast<uint32_t>(rtk_popc(bal & ((1ull << lane) - 1ull)))] = c0 + lane;
+                n1 += static_cast<uint32_t>(rtk_popc(bal));
+#endif
+            }
         }
     }
-#endif
     rtk_sync();
     RTK_PHASE();
     // ---- adjacent solid anchors on different unitigs must be graph neighbours sharing >= min_cov colours (:329-372) ----
