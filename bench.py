@@ -66,6 +66,26 @@ def read_long_reads(path, max_bases):
     return seqs, quals
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload (profiles/rNN_pmc_summary.json,
+    written by profiles/scripts/profile_round.sh): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 B, MI355X_MICROARCH.md)
+    + WRITE_SIZE, both reported in KB. None when no profile has been collected for the current code."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")):
+        m = re.search(r"r(\d+)_pmc_summary", f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, None
+    try:
+        k = json.load(open(best[1]))["kernels"][kernel]
+        return int(2.0 * k["fetch_bytes_per_launch_raw"] + k["write_bytes_per_launch_raw"]), os.path.relpath(best[1], ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
     a = parse()
     import torch
@@ -166,8 +186,9 @@ def main():
             "k_mask": 9.0 * S("in_bases"), "k_finalize": 12.0 * S("in_bases") + 16.0 * S("n_hits_inexact"), "k_stitch": 4.0 * S("out_bases"),
         }
         achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
+                    "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
                     "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()}, "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")), "probes_inexact_per_step": int(S("n_probes_inexact")), "table_slots_inexact_per_step": int(S("n_slots_inexact")), "k_regions_wave_cycle_share": {kk: round(S(kk) / max(1.0, S("cyc_total")), 3) for kk in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual")}, "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
         whole_alg = (8.0 * (S("n_probes_exact") + S("n_probes_inexact")) + 16.0 * (S("n_slots_exact") + S("n_slots_inexact")) + 40.0 * S("n_expand") + 4.0 * S("n_colour_elem") + 0.25 * S("n_path_base") + 4.0 * S("in_bases")) / max(1.0, S("in_bases"))
         out = {

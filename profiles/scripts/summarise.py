@@ -14,7 +14,7 @@ def short(name):
     for k in ("k_lookup_exact", "k_mask", "k_inexact", "k_finalize", "k_regions", "k_stitch", "k_enum", "k_myers_batch"):
         if k in name:
             return k
-    if "index" in name.lower() or "gather" in name.lower():
+    if "index_elementwise" in name or "gather" in name.lower():
         return "torch_index"
     if "copy" in name.lower() or "Copy" in name:
         return "torch_copy"
@@ -31,7 +31,7 @@ def pmc(d, pat):
         res[short(r["Kernel_Name"])][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     o = {}
     for k, cs in res.items():
-        o[k] = {c: {"launches": len(v), "mean_per_launch": sum(v.values()) / len(v)} for c, v in cs.items()}
+        o[k] = {c: {"launches": len(v), "mean_per_launch": sum(v.values()) / len(v), "max_per_launch": max(v.values())} for c, v in cs.items()}
     return o
 
 
@@ -59,18 +59,18 @@ res["kernels"] = kern
 N = 1 << 26
 cal = {"accesses": N}
 if "torch_index" in cf and "FETCH_SIZE" in cf["torch_index"]:
-    b = cf["torch_index"]["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+    b = cf["torch_index"]["FETCH_SIZE"]["max_per_launch"] * 1024.0
     cal["gather_fetch_bytes_raw"] = b
-    cal["gather_fetch_bytes_per_random_8B_read_raw"] = (b - 0.0) / N  # includes the 8 B/elem coalesced index stream
+    cal["gather_fetch_raw_bytes_per_element"] = b / N  # one random 8-byte read + 8 bytes of the coalesced index stream per element
 if "torch_copy" in cf and "FETCH_SIZE" in cf["torch_copy"]:
-    b = cf["torch_copy"]["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+    b = cf["torch_copy"]["FETCH_SIZE"]["max_per_launch"] * 1024.0
     cal["copy_fetch_bytes_raw"] = b
     cal["copy_fetch_raw_over_true"] = b / (8.0 * N)
 if "torch_index" in cw and "WRITE_SIZE" in cw["torch_index"]:
-    cal["gather_write_raw_over_true"] = cw["torch_index"]["WRITE_SIZE"]["mean_per_launch"] * 1024.0 / (8.0 * N)
+    cal["gather_write_raw_over_true"] = cw["torch_index"]["WRITE_SIZE"]["max_per_launch"] * 1024.0 / (8.0 * N)
 if "torch_copy" in cw and "WRITE_SIZE" in cw["torch_copy"]:
-    cal["copy_write_raw_over_true"] = cw["torch_copy"]["WRITE_SIZE"]["mean_per_launch"] * 1024.0 / (8.0 * N)
-cal["all_calib_kernels"] = {k: {c: v for c, v in cs.items()} for k, cs in list(cf.items()) + list(cw.items())}
+    cal["copy_write_raw_over_true"] = cw["torch_copy"]["WRITE_SIZE"]["max_per_launch"] * 1024.0 / (8.0 * N)
+cal["reading"] = "coalesced 16 B/lane reads: FETCH_SIZE x 2 = bytes; random 8-byte reads: 64 B tallied per read; WRITE_SIZE = bytes for coalesced writes"
 res["calibration"] = cal
 json.dump(res, open(os.path.join(summ, rnd + "_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res["kernels"], indent=1)[:3000])

@@ -1,7 +1,7 @@
 // `Ratatosk` host driver for the in-scope branch of the reference CLI: `Ratatosk correct -1 -g G -d D -l reads -o OUT`
 // (reference: src/Ratatosk.cpp:145-301 option table, :303-508 validation, :618-1000 search(), :1029-1037 file names,
 // :1083-1095/:1145-1149 pass-1 branch). C++11 host orchestration over the C ABI of libratatosk_hip.so: one worker thread
-// per GPU pulls read batches by ticket, corrects them on its device, and the writer emits blocks in ticket order (pass-1
+// per GPU (two, so that consecutive batches overlap) pulls read batches by ticket, corrects them on its device, and the writer emits blocks in ticket order (pass-1
 // output is always in input order: src/Ratatosk.cpp:919). Everything else (`index`, `-2`, `-u`, `-p/-P`) is out of scope.
 #include <getopt.h>
 
@@ -74,9 +74,11 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < opt.in_long.size(); ++i) { const std::vector<std::string> v = rtk::expand_input_list(opt.in_long[i]); files.insert(files.end(), v.begin(), v.end()); }
 
     if (opt.verbose) printf("Ratatosk::Ratatosk(): Reading graph.\n");
-    const int n_workers = opt.cores;
-    std::vector<rtk_graph*> graphs(n_workers, nullptr);
-    for (int w = 0; w < n_workers; ++w) {
+    // -c N = N GPUs. Two host workers per GPU share its graph: while one batch is in its region stage the next one runs its seed
+    // stage on its own stream (rtk_correct_batch = create + seeds + regions + fetch; the stages of different batches overlap).
+    const int n_gpus = opt.cores, n_workers = 2 * opt.cores;
+    std::vector<rtk_graph*> graphs(n_gpus, nullptr);
+    for (int w = 0; w < n_gpus; ++w) {
         if (rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, 1, &graphs[w]) != RTK_OK || rtk_graph_upload(graphs[w], w) != RTK_OK) {
             fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error());
             exit(1);
@@ -116,7 +118,7 @@ int main(int argc, char** argv) {
                 const uint32_t n = static_cast<uint32_t>(seqs.size());
                 std::vector<const char*> ps(n), pq(n); std::vector<uint32_t> len(n), olen(n); std::vector<char*> os(n, nullptr), oq(n, nullptr);
                 for (uint32_t i = 0; i < n; ++i) { ps[i] = seqs[i].c_str(); pq[i] = quals[i].empty() ? nullptr : quals[i].c_str(); len[i] = static_cast<uint32_t>(seqs[i].size()); }
-                if (rtk_correct_batch(graphs[w], &ro, n, ps.data(), pq.data(), len.data(), os.data(), oq.data(), olen.data()) != RTK_OK) {
+                if (rtk_correct_batch(graphs[w % n_gpus], &ro, n, ps.data(), pq.data(), len.data(), os.data(), oq.data(), olen.data()) != RTK_OK) {
                     fprintf(stderr, "Ratatosk::correct(): %s\n", rtk_last_error()); failed = true;
                 } else {
                     for (uint32_t i = 0; i < n; ++i) { // writeCorrectedOutput, trim == 0 (src/Ratatosk.cpp:516-520)
@@ -138,7 +140,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < th.size(); ++i) th[i].join();
     for (std::map<size_t, std::string>::iterator it = done.begin(); it != done.end(); ++it) fwrite(it->second.data(), 1, it->second.size(), fout);
     fclose(fout);
-    for (int w = 0; w < n_workers; ++w) rtk_graph_free(graphs[w]);
+    for (int w = 0; w < n_gpus; ++w) rtk_graph_free(graphs[w]);
     if (failed) exit(1);
     return 0;
 }
