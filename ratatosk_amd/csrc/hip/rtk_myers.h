@@ -252,7 +252,8 @@ RTK_DEV int rtk_myers_step32(uint32_t& Pv, uint32_t& Mv, uint32_t Eq, int hin, i
     return hout;
 }
 
-template <int STORE>
+// TRACK = 0: only the final score is wanted (NW); 1: minimum of the last row with its first / last position and count (SHW, HW).
+template <int STORE, int TRACK>
 __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ qp, int m, const char* __restrict__ tp, int n, int top_h, bool iupac, uint64_t* __restrict__ tb) {
     SweepStat st; st.final_score = m; st.best = 0x7fffffff; st.first = -1; st.last = -1; st.cnt = 0; st.plain = true;
     const int lane = rtk_lane();
@@ -276,10 +277,48 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
     uint32_t Pv = ~0u, Mv = 0u;
     int hout_prev = 0; unsigned tc_prev = 0;
     int score = m;
-    int best = 0x7fffffff, first = -1, last = -1, cnt = 0, fin = m;
+    int best = 0x7fffffff, first = -1, last = -1, cnt = 0;
     const int steps = n + W - 1;
     // table entry of (column, 64-bit word) = 4 x u64 {Pv, Mv, Ph, Mh}; this lane owns the low or high half of each
     uint32_t* const tb32 = reinterpret_cast<uint32_t*>(tb) + 8ull * (w >> 1) + (w & 1);
+    // one step of the anti-diagonal pipeline. MASKED = 1 while the pipeline fills or drains (some words have no column yet / any
+    // more); in between every word has one and the activity test, the column range checks and the conditional updates fall away.
+#define RTK_STEP32(MASKED)                                                                                                                   \
+    {                                                                                                                                        \
+        const int s = c0 + j;                                                                                                                \
+        const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));                                                     \
+        const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);                                                         \
+        const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(top_h + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false)); \
+        const int hin = static_cast<int>(got & 0xFFu) - 1;                                                                                   \
+        const unsigned tc = got >> 8;                                                                                                        \
+        /* 'A' 0x41, 'C' 0x43, 'G' 0x47, 'T' 0x54: bit 1 picks C/G over A/T, bit 2 picks T/G over A/C; bitwise selects, no condition code */ \
+        const uint32_t m1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(got), 9, 1));                                       \
+        const uint32_t m2 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(got), 10, 1));                                      \
+        const uint32_t lo_ = (eqC & m1) | (eqA & ~m1), hi_ = (eqG & m1) | (eqT & ~m1);                                                       \
+        const uint32_t Eq = (hi_ & m2) | (lo_ & ~m2);                                                                                        \
+        uint32_t nPv = Pv, nMv = Mv, Ph, Mh;                                                                                                 \
+        const int hout = rtk_myers_step32(nPv, nMv, Eq, hin, bit, Ph, Mh);                                                                   \
+        const int col = s - lane;                                                                                                            \
+        if (MASKED) {                                                                                                                        \
+            const bool active = has_word && col >= 0 && col < n;                                                                             \
+            if (STORE) { if (active) { uint32_t* e = tb32 + 8ull * (static_cast<uint64_t>(col) * W64); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
+            Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;                                                                                  \
+            hout_prev = active ? hout : hout_prev;                                                                                           \
+            score += active ? hout : 0;                                                                                                      \
+        } else {                                                                                                                             \
+            if (STORE) { if (has_word) { uint32_t* e = tb32 + 8ull * (static_cast<uint64_t>(col) * W64); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
+            Pv = nPv; Mv = nMv; hout_prev = hout; score += hout;                                                                             \
+        }                                                                                                                                    \
+        tc_prev = tc;                                                                                                                        \
+        if (TRACK) {                                                                                                                         \
+            const int tcol = s - (W - 1);                                                                                                    \
+            if (!(MASKED) || tcol >= 0) { /* wave-uniform: last-row score of column tcol, tracked in scalar registers */                    \
+                const int sv = __builtin_amdgcn_readlane(score, W - 1);                                                                      \
+                if (sv < best) { best = sv; first = tcol; last = tcol; cnt = 1; }                                                            \
+                else if (sv == best) { last = tcol; ++cnt; }                                                                                 \
+            }                                                                                                                                \
+        }                                                                                                                                    \
+    }
     for (int c0 = 0; c0 < steps; c0 += 64) {
         const int cj = c0 + lane;
         int my_t = 'A';
@@ -287,41 +326,23 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
         if (rtk_ballot(!(my_t == 'A' || my_t == 'C' || my_t == 'G' || my_t == 'T')) != 0ull) { st.plain = false; return st; }
         asm volatile("" : "+v"(my_t));
         const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
-        for (int j = 0; j < lim; ++j) {
-            const int s = c0 + j;
-            const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
-            const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
-            const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(top_h + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
-            const int hin = static_cast<int>(got & 0xFFu) - 1;
-            const unsigned tc = got >> 8;
-            const unsigned sel = (tc >> 1) & 3u; // 'A' -> 0, 'C' -> 1, 'T' -> 2, 'G' -> 3
-            const uint32_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
-            uint32_t nPv = Pv, nMv = Mv, Ph, Mh;
-            const int hout = rtk_myers_step32(nPv, nMv, Eq, hin, bit, Ph, Mh);
-            const int col = s - lane;
-            const bool active = has_word && col >= 0 && col < n;
-            if (STORE) { if (active) { uint32_t* e = tb32 + 8ull * (static_cast<uint64_t>(col) * W64); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } }
-            Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
-            hout_prev = active ? hout : hout_prev;
-            score += (active && lane == W - 1) ? hout : 0;
-            tc_prev = tc;
-            const int tcol = s - (W - 1);
-            if (tcol >= 0) { // wave-uniform: last-row score of column tcol, tracked in scalar registers
-                const int sv = __builtin_amdgcn_readlane(score, W - 1);
-                fin = sv;
-                if (sv < best) { best = sv; first = tcol; last = tcol; cnt = 1; }
-                else if (sv == best) { last = tcol; ++cnt; }
-            }
-        }
+        // steps [0, W-1) fill the pipeline, [W-1, n) run it full, [n, n+W-1) drain it
+        int j_fill = (W - 1) - c0; j_fill = j_fill < 0 ? 0 : (j_fill > lim ? lim : j_fill);
+        int j_full = n - c0; j_full = j_full < j_fill ? j_fill : (j_full > lim ? lim : j_full);
+        int j = 0;
+        for (; j < j_fill; ++j) RTK_STEP32(1)
+        for (; j < j_full; ++j) RTK_STEP32(0)
+        for (; j < lim; ++j) RTK_STEP32(1)
     }
-    st.final_score = fin; st.best = best; st.first = first; st.last = last; st.cnt = cnt;
+#undef RTK_STEP32
+    st.final_score = __builtin_amdgcn_readlane(score, W - 1); st.best = best; st.first = first; st.last = last; st.cnt = cnt;
     return st;
 }
 
 // dispatcher: 32-bit words up to 2048 query characters, 64-bit words beyond
-template <int STORE>
+template <int STORE, int TRACK>
 __device__ __forceinline__ SweepStat rtk_myers_fast_any(const char* __restrict__ qp, int m, const char* __restrict__ tp, int n, int top_h, bool iupac, uint64_t* __restrict__ tb) {
-    if (m <= 2048) return rtk_myers_fast32<STORE>(qp, m, tp, n, top_h, iupac, tb);
+    if (m <= 2048) return rtk_myers_fast32<STORE, TRACK>(qp, m, tp, n, top_h, iupac, tb);
     return rtk_myers_fast<STORE>(qp, m, tp, n, top_h, iupac, tb);
 }
 #endif
@@ -475,7 +496,7 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, i
     if (static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap) { *sc.overflow = 1; return r; }
 #ifndef RTK_SIM
     if (m <= 4096 && !locs_out) {
-        const SweepStat st = rtk_myers_fast_any<0>(q, m, t, n, mode == RTK_MODE_HW ? 0 : 1, iupac, nullptr);
+        const SweepStat st = (mode == RTK_MODE_NW) ? rtk_myers_fast_any<0, 0>(q, m, t, n, 1, iupac, nullptr) : rtk_myers_fast_any<0, 1>(q, m, t, n, mode == RTK_MODE_HW ? 0 : 1, iupac, nullptr);
         if (st.plain) {
             if (mode == RTK_MODE_NW) { if (k >= 0 && st.final_score > k) return r; r.dist = st.final_score; r.first = r.last = n - 1; r.nloc = 1; return r; }
             int best = st.best; const bool pseudo = (m & 63) != 0;
@@ -595,7 +616,7 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const 
     int cur;
 #ifndef RTK_SIM
     SweepStat fst; fst.plain = false;
-    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast_any<1>(q.p, m, t.p, n, 1, iupac, rtk_ld(&sc.tb));
+    if (m <= 4096 && !q.rev && !t.rev) fst = rtk_myers_fast_any<1, 0>(q.p, m, t.p, n, 1, iupac, rtk_ld(&sc.tb));
     if (fst.plain) { cur = fst.final_score; rtk_sync(); }
     else
 #endif
@@ -695,7 +716,7 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
     const long long W = (m + 63) >> 6;
     if (m > 0 && n > 0 && m <= 4096 && static_cast<uint64_t>(4 * W * n) <= sc.tb_cap_words && static_cast<uint32_t>(m + n) <= sc.mv_cap && static_cast<uint32_t>(n) <= sc.t_cap &&
         static_cast<uint32_t>(m) <= sc.r_cap && static_cast<uint32_t>(W) <= sc.w_cap) {
-        const SweepStat st = rtk_myers_fast_any<1>(q, m, t, n, 1, iupac, rtk_ld(&sc.tb));
+        const SweepStat st = (mode == RTK_MODE_NW) ? rtk_myers_fast_any<1, 0>(q, m, t, n, 1, iupac, rtk_ld(&sc.tb)) : rtk_myers_fast_any<1, 1>(q, m, t, n, 1, iupac, rtk_ld(&sc.tb));
         rtk_sync();
         if (st.plain) {
             r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
