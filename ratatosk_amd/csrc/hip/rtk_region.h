@@ -882,19 +882,63 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
 // ------------------------------------------------------------------------------------------------ ResultCorrection (src/ResultCorrection.hpp)
 struct ResCorr { char* seq; char* qual; uint32_t seq_len, qual_len; uint64_t* bm; uint32_t old_len; bool is_corrected; uint32_t n_all; int all_set; };
 
-RTK_DEV void rtk_bm_add_range(uint64_t* bm, uint32_t a, uint32_t b) { for (uint32_t i = a; i < b; ++i) bm[i >> 6] |= 1ull << (i & 63); }
-RTK_DEV uint32_t rtk_bm_card(const uint64_t* bm, uint32_t n) { uint32_t c = 0; for (uint32_t w = 0; w < (n + 63) / 64; ++w) c += static_cast<uint32_t>(rtk_popc(bm[w])); return c; }
+// position bitmaps (ResultCorrection's Roaring set of corrected old positions): word-wise, one word per lane
+RTK_DEV void rtk_bm_add_range(uint64_t* bm, uint32_t a, uint32_t b) { // [a, b)
+    if (b <= a) return;
+    const uint32_t w0 = a >> 6, w1 = (b - 1) >> 6;
+    for (uint32_t w = w0 + static_cast<uint32_t>(rtk_lane()); w <= w1; w += RTK_WAVE) {
+        const uint32_t lo = (w == w0) ? (a & 63u) : 0u, hi = (w == w1) ? ((b - 1) & 63u) : 63u;
+        const uint64_t mask = ((hi == 63u) ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+        bm[w] |= mask;
+    }
+    rtk_sync();
+}
+RTK_DEV uint32_t rtk_bm_card(const uint64_t* bm, uint32_t n) {
+    int c = 0;
+    for (uint32_t w = static_cast<uint32_t>(rtk_lane()); w < (n + 63) / 64; w += RTK_WAVE) c += rtk_popc(bm[w]);
+    return static_cast<uint32_t>(rtk_u(rtk_wave_sum(c)));
+}
 RTK_DEV bool rtk_bm_get(const uint64_t* bm, uint32_t i) { return (bm[i >> 6] >> (i & 63)) & 1ull; }
-RTK_DEV uint32_t rtk_rc_len_corrected(const ResCorr& r, uint32_t p) { uint32_t n = p; while (n < r.old_len && rtk_bm_get(r.bm, n)) ++n; return n - p; } // :117-128
-RTK_DEV uint32_t rtk_rc_len_uncorrected(const ResCorr& r, uint32_t p) { if (p >= r.old_len) return 0; uint32_t n = p; while (n < r.old_len && !rtk_bm_get(r.bm, n)) ++n; return n - p; } // :130-142
+// first position >= p (capped at n) whose bit equals `want`
+RTK_DEV uint32_t rtk_bm_next(const uint64_t* bm, uint32_t n, uint32_t p, bool want) {
+    if (p >= n) return n;
+    const uint32_t words = (n + 63) / 64;
+    for (uint32_t w0 = p >> 6; w0 < words; w0 += RTK_WAVE) {
+        const uint32_t w = w0 + static_cast<uint32_t>(rtk_lane());
+        uint64_t x = 0;
+        if (w < words) { x = want ? bm[w] : ~bm[w]; if (w == (p >> 6)) x &= ~((1ull << (p & 63u)) - 1ull); }
+        const uint64_t bal = rtk_ballot(x != 0);
+        if (bal) {
+            const int l = rtk_ffs(bal) - 1;
+            const uint32_t pos = 64u * (w0 + static_cast<uint32_t>(l)) + static_cast<uint32_t>(rtk_ffs(rtk_shfl(x, l)) - 1);
+            return rtk_u(pos < n ? pos : n);
+        }
+    }
+    return n;
+}
+RTK_DEV uint32_t rtk_rc_len_corrected(const ResCorr& r, uint32_t p) { return rtk_bm_next(r.bm, r.old_len, p, false) - (p < r.old_len ? p : r.old_len); } // :117-128
+RTK_DEV uint32_t rtk_rc_len_uncorrected(const ResCorr& r, uint32_t p) { return rtk_bm_next(r.bm, r.old_len, p, true) - (p < r.old_len ? p : r.old_len); } // :130-142
+// 64 bits of the bitmap starting at bit `lo` (may be negative; bits outside the words read as 0)
+RTK_DEV uint64_t rtk_bm_window(const uint64_t* bm, uint32_t words, int64_t lo) {
+    if (lo <= -64) return 0ull;
+    if (lo < 0) return words ? (bm[0] << static_cast<uint32_t>(-lo)) : 0ull;
+    const uint32_t w = static_cast<uint32_t>(lo >> 6), sh = static_cast<uint32_t>(lo & 63);
+    uint64_t x = 0;
+    if (w < words) x = bm[w] >> sh;
+    if (sh && w + 1 < words) x |= bm[w + 1] << (64u - sh);
+    return x;
+}
 
 RTK_FN void rtk_rc_reverse_complement(RegionScratch& s_, ResCorr& r_, uint64_t* tmp_bm_, char* tmp_) {
     RegionScratch& s = *rtk_u(&s_); ResCorr& r = *rtk_u(&r_); uint64_t* tmp_bm = rtk_u(tmp_bm_); char* tmp = rtk_u(tmp_); // :72-88
     if (r.seq_len == 0) return;
     const uint32_t words = (r.old_len + 63) / 64;
-    for (uint32_t w = 0; w < words; ++w) tmp_bm[w] = 0;
-    for (uint32_t i = 0; i < r.old_len; ++i) if (rtk_bm_get(r.bm, i)) { const uint32_t j = r.old_len - i - 1; tmp_bm[j >> 6] |= 1ull << (j & 63); }
-    for (uint32_t w = 0; w < words; ++w) r.bm[w] = tmp_bm[w];
+    // new bit j = old bit old_len-1-j: output word ow is the bit reversal of the 64 old bits ending at old_len-1-64*ow
+    for (uint32_t ow = static_cast<uint32_t>(rtk_lane()); ow < words; ow += RTK_WAVE)
+        tmp_bm[ow] = rtk_brev64(rtk_bm_window(r.bm, words, static_cast<int64_t>(r.old_len) - 1 - 64ll * ow - 63));
+    rtk_sync();
+    for (uint32_t w = static_cast<uint32_t>(rtk_lane()); w < words; w += RTK_WAVE) r.bm[w] = tmp_bm[w];
+    rtk_sync();
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < r.seq_len; i += RTK_WAVE) tmp[i] = rtk_comp(r.seq[r.seq_len - 1 - i]);
     rtk_sync(); rtk_wcopy(r.seq, tmp, r.seq_len);
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < r.qual_len; i += RTK_WAVE) tmp[i] = r.qual[r.qual_len - 1 - i];
@@ -955,7 +999,8 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     const uint64_t u_min_end = static_cast<uint64_t>(p2) + static_cast<uint64_t>(c.o.insert_sz);
     res.old_len = len_weak_region; res.is_corrected = false; res.seq_len = 0; res.qual_len = 0; res.n_all = 0;
     if ((len_weak_region + 63) / 64 + 1 > s.bm_words) { rtk_fail_ovf(s, 10); return; }
-    for (uint32_t w = 0; w < (len_weak_region + 63) / 64 + 1; ++w) res.bm[w] = 0;
+    for (uint32_t w = static_cast<uint32_t>(rtk_lane()); w < (len_weak_region + 63) / 64 + 1; w += RTK_WAVE) res.bm[w] = 0;
+    rtk_sync();
     const char q_min = rtk_get_qual(0.0, 0, static_cast<uint64_t>(c.o.max_qual));
     const uint32_t max_len_weak_anchors = c.o.max_len_weak_region1;
     // weak anchors inside the region: l_v_w = v_w[lw_lo .. lw_hi)

@@ -32,6 +32,7 @@ inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
 template <class T> inline T rtk_atomic_add_raw(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long rtk_clock() { return 0; }
+inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1ull); x >>= 1; } return r; }
 
 #else
 
@@ -51,6 +52,7 @@ __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
 template <class T> __device__ __forceinline__ T rtk_atomic_add_raw(T* p, T v) { return atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long rtk_clock() { return static_cast<unsigned long long>(clock64()); }
+__device__ __forceinline__ uint64_t rtk_brev64(uint64_t x) { return __builtin_bitreverse64(x); }
 
 #endif
 
