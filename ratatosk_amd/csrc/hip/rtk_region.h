@@ -110,6 +110,16 @@ RTK_DEV UMap rtk_an_um(const Anchors& a, uint32_t i) {
     return u;
 }
 
+// positions are ascending in the anchor index: binary searches replace the reference's linear walks over the lists
+RTK_DEV uint32_t rtk_an_first_ge(const Anchors& a, uint32_t lo, uint32_t hi, uint64_t key) { // first x in [lo, hi) with pos(x) >= key, else hi
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (static_cast<uint64_t>(rtk_u(rtk_an_pos(a, mid))) < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+RTK_DEV uint32_t rtk_an_first_gt(const Anchors& a, uint32_t lo, uint32_t hi, uint64_t key) { // first x in [lo, hi) with pos(x) > key, else hi
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (static_cast<uint64_t>(rtk_u(rtk_an_pos(a, mid))) <= key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 // ------------------------------------------------------------------------------------------------ arenas and paths (src/Path.hpp)
 struct PathHdr { U<uint32_t> n, l, qlen, pad; }; // followed by n UMap and qlen quality bytes
 
@@ -738,8 +748,12 @@ RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint3
 // anchors of the three sides are given as small (unitig, non-branching) lists, first insertion wins (unordered_map::insert).
 struct SideList { uint32_t* u; uint8_t* nb; uint32_t n, cap; };
 RTK_DEV bool rtk_side_insert(SideList& l, uint32_t u, bool nonbranching) { // returns true when unseen
-    for (uint32_t i = 0; i < l.n; ++i) if (l.u[i] == u) return false;
-    if (l.n < l.cap) { l.u[l.n] = u; l.nb[l.n] = nonbranching ? 1 : 0; ++l.n; }
+    const uint32_t n = rtk_u(l.n); const uint32_t* lu = rtk_u(l.u);
+    for (uint32_t i0 = 0; i0 < n; i0 += RTK_WAVE) { // 64 entries per step
+        const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+        if (rtk_ballot(i < n && lu[i] == u)) return false;
+    }
+    if (n < rtk_u(l.cap)) { l.u[n] = u; l.nb[n] = nonbranching ? 1 : 0; l.n = n + 1; rtk_sync(); }
     return true;
 }
 
@@ -1009,11 +1023,9 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
         const uint32_t v_w_sz = v_w.n;
         if (v_w_sz) {
             const uint32_t pos_end = has_end_pt ? p2 : s_len;
-            uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
-            while (x < v_w_sz && rtk_an_pos(v_w, x) < first_pos) ++x;
-            lw_lo = x;
-            while (x < v_w_sz && rtk_an_pos(v_w, x) < pos_end) ++x;
-            lw_hi = x;
+            const uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
+            lw_lo = rtk_an_first_ge(v_w, x, v_w_sz, first_pos);
+            lw_hi = rtk_an_first_ge(v_w, lw_lo, v_w_sz, pos_end);
         }
     }
     uint32_t n_all = 0;
@@ -1032,19 +1044,28 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
             uint32_t nbb = 0;
             rtk_scan_anchor_runs(v_s, static_cast<int64_t>(i_s), -1, [&](uint32_t p) { return static_cast<uint64_t>(p) > u_min_start; }, [&](const UMap& um) { consider(sl, um, nbb); });
             const uint32_t v_w_sz = v_w.n;
-            uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
-            while (x > 0 && static_cast<uint64_t>(rtk_an_pos(v_w, x)) > u_min_start) --x;
-            for (; x < v_w_sz && rtk_an_pos(v_w, x) < first_pos; ++x) consider(sl, rtk_an_um(v_w, x), nbb);
+            if (v_w_sz) {
+                const uint32_t x0 = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
+                // the reference walks back while pos > u_min_start and index > 0: it lands on the last anchor at or below u_min_start (or on 0)
+                const uint32_t f = rtk_an_first_gt(v_w, 0, x0 + 1, u_min_start);
+                const uint32_t x = f > 0 ? f - 1 : 0;
+                rtk_scan_anchor_runs(v_w, static_cast<int64_t>(x), +1, [&](uint32_t p) { return p < first_pos; }, [&](const UMap& um) { consider(sl, um, nbb); });
+            }
         }
         if (has_end_pt) { // right (:518-561)
             uint32_t nbb = 0;
             rtk_scan_anchor_runs(v_s, static_cast<int64_t>(i_s) + 1, +1, [&](uint32_t p) { return static_cast<uint64_t>(p) < u_min_end; }, [&](const UMap& um) { consider(sr, um, nbb); });
             const uint32_t v_w_sz = v_w.n;
-            uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
-            while (x < v_w_sz && rtk_an_pos(v_w, x) < p2) ++x;
-            for (; x < v_w_sz && static_cast<uint64_t>(rtk_an_pos(v_w, x)) < u_min_end; ++x) consider(sr, rtk_an_um(v_w, x), nbb);
+            if (v_w_sz) {
+                const uint32_t x0 = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
+                const uint32_t x = rtk_an_first_ge(v_w, x0, v_w_sz, p2);
+                rtk_scan_anchor_runs(v_w, static_cast<int64_t>(x), +1, [&](uint32_t p) { return static_cast<uint64_t>(p) < u_min_end; }, [&](const UMap& um) { consider(sr, um, nbb); });
+            }
         }
-        for (uint32_t x = lw_lo; x < lw_hi; ++x) { const uint32_t u = rtk_an_um(v_w, x).unitig; if (g.kcov[u] < c.o.max_km_cov) rtk_side_insert(sm, u, !rtk_is_branching(g, u)); } // middle (:563-585)
+        if (lw_hi > lw_lo) { // middle (:563-585)
+            const uint32_t pos_end_m = has_end_pt ? p2 : s_len;
+            rtk_scan_anchor_runs(v_w, static_cast<int64_t>(lw_lo), +1, [&](uint32_t p) { return p < pos_end_m; }, [&](const UMap& um) { const uint32_t u = um.unitig; if (g.kcov[u] < c.o.max_km_cov) rtk_side_insert(sm, u, !rtk_is_branching(g, u)); });
+        }
         if (sl.n >= cap / 2 || sr.n >= cap / 2 || sm.n >= cap / 2) { rtk_fail_ovf(s, 8); return; }
         { const unsigned long long t0 = rtk_clock(); n_all = rtk_choose_colors(c, sl, sr, sm); s.cnt[5] += rtk_clock() - t0; }
         if (rtk_failed(s)) return;
@@ -1136,7 +1157,16 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
 // ------------------------------------------------------------------------------------------------ generateConsensus (src/Alignment.cpp:309-470)
 struct CigCur { const uint8_t* mv; uint32_t n, idx, qpos, rpos; }; // op-granular cursor over an alignment (moves 0/3 = M, 1 = I, 2 = D)
 RTK_DEV char rtk_mv_op(uint8_t m) { return (m == 1) ? 'I' : (m == 2 ? 'D' : 'M'); }
-RTK_DEV uint32_t rtk_op_len(const CigCur& cc) { uint32_t j = cc.idx; const char op = rtk_mv_op(cc.mv[cc.idx]); while (j < cc.n && rtk_mv_op(cc.mv[j]) == op) ++j; return j - cc.idx; }
+RTK_DEV uint32_t rtk_op_len(const CigCur& cc) { // length of the run of equal ops at the cursor; 64 moves per step
+    const uint8_t* mv = rtk_u(cc.mv); const uint32_t n = rtk_u(cc.n), idx = rtk_u(cc.idx);
+    const char op = rtk_mv_op(rtk_ld(mv + idx));
+    for (uint32_t j0 = idx; j0 < n; j0 += RTK_WAVE) {
+        const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane());
+        const uint64_t diff = rtk_ballot(j < n && rtk_mv_op(mv[j]) != op);
+        if (diff) return j0 + static_cast<uint32_t>(rtk_ffs(diff) - 1) - idx;
+    }
+    return n - idx;
+}
 
 RTK_FN void rtk_move_into_cigar(uint32_t start_, uint32_t end_, CigCur& cc_, uint32_t* rs_, uint32_t* re_, uint32_t* ref_out_) {
     uint32_t start = rtk_u(start_); uint32_t end = rtk_u(end_); CigCur& cc = *rtk_u(&cc_); uint32_t* rs = rtk_u(rs_); uint32_t* re = rtk_u(re_); uint32_t* ref_out = rtk_u(ref_out_); // moveIntoCIGAR (:354-411)
