@@ -64,6 +64,8 @@ typedef struct rtk_stats {
     uint64_t cyc_colour, cyc_paths, cyc_consensus, cyc_total, cyc_myers, cyc_sets /* path record commit+load */, cyc_tostring, cyc_pathqual;
     /* n_probes_* = k-mer queries (one 8-byte pre-filter word each); n_slots_* = 16-byte table slots visited behind the filter */
     uint64_t n_slots_exact, n_slots_inexact;
+    /* traceback walks inside cyc_myers: wave-cycles and alignment moves produced */
+    uint64_t cyc_walk, n_moves;
 } rtk_stats;
 
 /* dbg.read(G.fasta.gz) + readGraphData(G.rtsk) (reference: src/Ratatosk.cpp:1087-1089; src/Graph.cpp:722-784).

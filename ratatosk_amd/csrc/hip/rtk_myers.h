@@ -34,6 +34,7 @@ struct MyersScratch {
     U<uint32_t> mv_cap;
     U<int32_t*> hstack;     // [5 * 64] explicit Hirschberg stack
     U<uint32_t*> overflow;  // set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
+    U<unsigned long long> walk_cycles, walk_moves, walk_reloads, walk_scalar, walk_calls, walk_tail_cycles; // profile of the traceback walks
 };
 
 struct MySeq { // a character sequence read forwards or backwards (Hirschberg aligns reversed halves, edlib.cpp:1259-1263)
@@ -557,6 +558,7 @@ RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int cur_, ui
     const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_);
     const int m = rtk_u(m_), n = rtk_u(n_), W = (m + 63) >> 6;
     int cur = rtk_u(cur_);
+    const unsigned long long tw0 = rtk_clock(); unsigned n_rel = 0, n_sc = 0;
     int i = m, j = n;
     uint32_t nt = 0; // moves are produced backwards into moves_tmp, from its end
     uint8_t* tmp = rtk_ld(&sc.moves_tmp);
@@ -579,11 +581,59 @@ RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int cur_, ui
         if (c > 0) { const uint64_t* el = tbp + 4ull * (static_cast<uint64_t>(c - 1) * W + w); l0 = el[0]; l1 = el[1]; }
 #else
         if (w != w_cur || c > c_hi || c_hi - c > 62) {
-            c_hi = c; w_cur = w;
+            c_hi = c; w_cur = w; ++n_rel;
             const int col = c - lane;
             if (col >= 0) { const uint64_t* e = tbp + 4ull * (static_cast<uint64_t>(col) * W + w); e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3]; }
         }
         const int li = c_hi - c;
+        { // run of inserts (moves up column c): consecutive rows from r downwards whose vertical delta is +1 = ones of Pv & ~Mv below bit b
+            const uint64_t up = RTK_RL64(e0, li) & ~RTK_RL64(e1, li);
+            if ((up >> b) & 1ull) {
+                const uint64_t nup = ~(up << (63 - b));
+                const int run = nup ? __builtin_clzll(nup) : 64; // >= 1, stays inside this 64-row word
+                if (lane < run) tmp[cap - (nt + 1u + static_cast<uint32_t>(lane))] = 1;
+                i -= run; cur -= run; nt += static_cast<uint32_t>(run);
+                continue;
+            }
+        }
+        { // run of deletes (moves left along row r): leading columns whose cell has no +1 vertical delta but a +1 horizontal one
+            const int l = lane - li;
+            const int vd_ = static_cast<int>((e0 >> b) & 1ull) - static_cast<int>((e1 >> b) & 1ull);
+            const int hd_ = static_cast<int>((e2 >> b) & 1ull) - static_cast<int>((e3 >> b) & 1ull);
+            const bool isleft = l >= 0 && (c - l) >= 0 && vd_ != 1 && hd_ == 1;
+            const uint64_t nleft = ~(rtk_ballot(isleft) >> li);
+            const int run = nleft ? __builtin_ctzll(nleft) : 64;
+            if (run > 0) {
+                if (l >= 0 && l < run) tmp[cap - (nt + 1u + static_cast<uint32_t>(l))] = 2;
+                j -= run; cur -= run; nt += static_cast<uint32_t>(run);
+                continue;
+            }
+        }
+        { // Runs of diagonal moves, up to 62 at a time: the move out of a cell only depends on the deltas stored around it, so the lane
+          // holding column c - l looks at cell (r - l, c - l) of the diagonal through (r, c); the leading lanes that see neither an
+          // insert nor a delete form one run of match / mismatch moves, written out together.
+            const int l = lane - li;
+            const int rl = r - l;
+            const bool valid = l >= 0 && lane <= 62 && rl >= 64 * w && (c - l) >= 1;
+            const int bb = rl & 63, bn = (bb + 1) & 63;
+            const int vd_ = static_cast<int>((e0 >> bb) & 1ull) - static_cast<int>((e1 >> bb) & 1ull);
+            const int hd_ = static_cast<int>((e2 >> bb) & 1ull) - static_cast<int>((e3 >> bb) & 1ull);
+            const int vdn = static_cast<int>((e0 >> bn) & 1ull) - static_cast<int>((e1 >> bn) & 1ull); // my column, one row further down: what lane - 1 needs
+            const int vdl = __shfl_down(vdn, 1, 64);
+            const bool isdiag = valid && vd_ != 1 && hd_ != 1;
+            const uint64_t dm = rtk_ballot(isdiag) >> li;
+            const uint64_t ndm = ~dm;
+            const int run = ndm ? __builtin_ctzll(ndm) : 64;
+            if (run > 0) {
+                const bool mine = l >= 0 && l < run;
+                const bool mism = (hd_ + vdl) != 0;
+                const uint64_t mm = rtk_ballot(mine && mism);
+                if (mine) tmp[cap - (nt + 1u + static_cast<uint32_t>(l))] = mism ? 3 : 0;
+                cur -= rtk_popc(mm); i -= run; j -= run; nt += static_cast<uint32_t>(run);
+                continue;
+            }
+        }
+        ++n_sc;
         const uint64_t a0 = RTK_RL64(e0, li), a1 = RTK_RL64(e1, li), a2 = RTK_RL64(e2, li), a3 = RTK_RL64(e3, li);
         const uint64_t l0 = RTK_RL64(e0, li + 1), l1 = RTK_RL64(e1, li + 1); // column c-1 (unused when c == 0)
 #endif
@@ -602,11 +652,14 @@ RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int cur_, ui
         }
         ++nt; tmp[cap - nt] = mv;
     }
+    const unsigned long long tw1 = rtk_clock();
     // whatever is left is a run of inserts (query only) or deletes (target only)
     if (i > 0) { rtk_wfill(tmp + (cap - nt - static_cast<uint32_t>(i)), 1, static_cast<uint64_t>(i)); nt += static_cast<uint32_t>(i); i = 0; }
     if (j > 0) { rtk_wfill(tmp + (cap - nt - static_cast<uint32_t>(j)), 2, static_cast<uint64_t>(j)); nt += static_cast<uint32_t>(j); j = 0; }
+    rtk_sync(); // runs were written by their lanes
     rtk_wcopy(rtk_ld(&sc.moves) + *n_moves, tmp + (cap - nt), nt);
     *n_moves += nt;
+    { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.walk_cycles += rtk_clock() - tw0; msc.walk_moves += nt; msc.walk_reloads += n_rel; msc.walk_scalar += n_sc; msc.walk_calls += 1; msc.walk_tail_cycles += rtk_clock() - tw1; }
 }
 
 RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const MySeq& t_, bool iupac_, uint32_t* n_moves_) {

@@ -795,10 +795,10 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
     for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i) {
         const uint32_t u = sides[sd]->u[i];
         if (g.card[u] < c.o.min_cov_vertices) continue;
-        bool dup = false; for (uint32_t j = 0; j < nsp; ++j) if (static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull) == u) dup = true;
+        bool dup = false; for (uint32_t j0 = 0; j0 < nsp && !dup; j0 += RTK_WAVE) { const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane()); dup = rtk_ballot(j < nsp && static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull) == u) != 0ull; }
         if (dup) continue;
         if (2 * (nsp + 1) > s.list_cap) { rtk_fail_ovf(s, 8); return 0; }
-        keys[nsp] = (static_cast<uint64_t>(g.card[u]) << 32) | u; vals[nsp] = 0; ++nsp;
+        keys[nsp] = (static_cast<uint64_t>(g.card[u]) << 32) | u; vals[nsp] = 0; ++nsp; rtk_sync();
     }
     rtk_sort_pairs(keys, vals, nsp);
     const uint32_t cov = 30;
