@@ -15,13 +15,33 @@ RTK_DEV uint32_t rtk_lower_bound(const uint32_t* a, uint32_t n, uint32_t x) { //
 
 RTK_DEV bool rtk_set_contains(const uint32_t* a, uint32_t n, uint32_t x) { const uint32_t i = rtk_lower_bound(a, n, x); return i < n && a[i] == x; }
 
+#ifndef RTK_SIM
+// The set that is searched is staged in LDS when it fits: a binary search is a chain of dependent reads, and an LDS read returns
+// several times sooner than one from L2. One wave per workgroup, so the buffer is private to the wave.
+#define RTK_LDS_SET_CAP 2048
+__device__ __forceinline__ uint32_t* rtk_lds_set_buf() { __shared__ uint32_t buf[RTK_LDS_SET_CAP]; return buf; } // ONE 8 KB buffer per wave for every user
+RTK_DEV bool rtk_lds_contains(const uint32_t* lds, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lds[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo < n && lds[lo] == x;
+}
+#endif
+
 // out = { x in a : (x in b) == want_in_b }
 RTK_FN uint32_t rtk_set_filter(const uint32_t* a_, uint32_t na_, const uint32_t* b_, uint32_t nb_, bool want_in_b_, uint32_t* out_) {
     const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); bool want_in_b = rtk_u(want_in_b_); uint32_t* out = rtk_u(out_);
     uint32_t base = 0;
+#ifndef RTK_SIM
+    uint32_t* const lds_b = rtk_lds_set_buf();
+    const bool staged = nb <= RTK_LDS_SET_CAP && na >= 16;
+    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nb; i += RTK_WAVE) lds_b[i] = b[i]; __syncthreads(); }
+#endif
     for (uint32_t i0 = 0; i0 < na; i0 += RTK_WAVE) {
         const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
         uint32_t x = 0; bool keep = false;
+#ifndef RTK_SIM
+        if (staged) { if (i < na) { x = a[i]; keep = (rtk_lds_contains(lds_b, nb, x) == want_in_b); } } else
+#endif
         if (i < na) { x = a[i]; keep = (rtk_set_contains(b, nb, x) == want_in_b); }
         const uint64_t bal = rtk_ballot(keep);
         if (keep) out[base + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)))] = x;
@@ -39,9 +59,18 @@ RTK_FN uint32_t rtk_set_inter_count(const uint32_t* a_, uint32_t na_, const uint
     const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); uint32_t cap = rtk_u(cap_);
     if (na > nb) { const uint32_t* t = a; a = b; b = t; const uint32_t tn = na; na = nb; nb = tn; }
     uint32_t cnt = 0;
+#ifndef RTK_SIM
+    uint32_t* const lds_b = rtk_lds_set_buf();
+    const bool staged = nb <= RTK_LDS_SET_CAP && na >= 16;
+    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nb; i += RTK_WAVE) lds_b[i] = b[i]; __syncthreads(); }
+#endif
     for (uint32_t i0 = 0; i0 < na && cnt < cap; i0 += RTK_WAVE) {
         const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+#ifndef RTK_SIM
+        const bool in = (i < na) && (staged ? rtk_lds_contains(lds_b, nb, a[i]) : rtk_set_contains(b, nb, a[i]));
+#else
         const bool in = (i < na) && rtk_set_contains(b, nb, a[i]);
+#endif
         cnt += static_cast<uint32_t>(rtk_popc(rtk_ballot(in)));
     }
     return cnt;
