@@ -361,9 +361,22 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
                 rtk_kmer_prepare(vcode[rr], k, &vcan[rr], &vhh[rr], &vq[rr]);
             }
             for (int rr = 0; rr < 4; ++rr) vword[rr] = vvalid[rr] ? g.bf[(vhh[rr] >> 32) & g.bf_mask] : 0ull;
+            // ... and the first table slot (key and value, one 16-byte read) of every variant that passes is requested before any is compared
+            uint64_t skey[4], sval[4]; bool vpass[4];
+            const uint64_t* const ht = g.ht; const uint64_t ht_mask = g.ht_mask;
+            for (int rr = 0; rr < 4; ++rr) {
+                vpass[rr] = vvalid[rr] && rtk_filter_pass(vword[rr], vhh[rr]);
+                skey[rr] = RTK_EMPTY_KEY; sval[rr] = 0;
+                if (vpass[rr]) { const uint64_t* sp = ht + 2 * (vhh[rr] & ht_mask); skey[rr] = sp[0]; sval[rr] = sp[1]; }
+            }
             for (int rr = 0; rr < 4; ++rr) {
                 uint64_t hit = RTK_NO_HIT;
-                if (vvalid[rr]) { probes += 1; if (rtk_filter_pass(vword[rr], vhh[rr])) { uint32_t np; hit = rtk_table_lookup(g, vcan[rr], vhh[rr], vq[rr], &np); slots += np; } }
+                if (vvalid[rr]) probes += 1;
+                if (vpass[rr]) {
+                    slots += 1;
+                    if (skey[rr] == vcan[rr]) hit = rtk_pack_hit(static_cast<uint32_t>(sval[rr] >> 32), static_cast<uint32_t>((sval[rr] & 0xFFFFFFFFull) >> 1), (static_cast<uint32_t>(sval[rr] & 1ull) == vq[rr]) ? 1u : 0u);
+                    else if (skey[rr] != RTK_EMPTY_KEY) { uint32_t np; hit = rtk_table_lookup(g, vcan[rr], vhh[rr] + 1, vq[rr], &np); slots += np; } // collision: keep probing from the next slot
+                }
                 const uint64_t hb = rtk_ballot(hit != RTK_NO_HIT);
                 if (hit != RTK_NO_HIT) { my_code[my_n] = vcode[rr]; my_hit[my_n] = hit; ++my_n; }
                 total += rtk_popc(hb);
