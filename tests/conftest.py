@@ -49,6 +49,21 @@ def ds_clean(tmp_path_factory):
     return make_dataset(d, "clean", ["--seed", 1, "--ref-len", 50000, "--sr-cov", 30, "--sr-err", 0.002, "--lr-n", 10, "--lr-len", 5000, "--lr-err", 0.10])
 
 
+@pytest.fixture(scope="session")
+def ds_k25(tmp_path_factory):
+    """k = 25 graph (the reference accepts any odd k1 <= 31 for pass 1, src/Ratatosk.cpp:213)."""
+    d = tmp_path_factory.mktemp("ds_k25")
+    return make_dataset(d, "k25", ["--seed", 5, "--ref-len", 20000, "--het", 0.003, "--sr-cov", 40, "--sr-err", 0.005, "--lr-n", 6, "--lr-len", 2500, "--lr-profile", "ont", "--lr-err", 0.08], ["-k", 25])
+
+
+@pytest.fixture(scope="session")
+def ds_medium(tmp_path_factory):
+    """GPU-tier set: 400 kb diploid reference with repeats, 160 ONT-profile reads (~1.3 Mb): every branch of the region program at volume."""
+    d = tmp_path_factory.mktemp("ds_medium")
+    return make_dataset(d, "medium", ["--seed", 7, "--ref-len", 400000, "--het", 0.002, "--repeat-frac", 0.05, "--sr-cov", 30, "--sr-err", 0.005,
+                                      "--lr-n", 160, "--lr-len", 8000, "--lr-profile", "ont", "--lr-err", 0.07], ["--global-cov-factor", 1.5])
+
+
 def golden_rows():
     path = os.path.join(ROOT, "tests", "golden", "edlib_golden.tsv")
     rows = []

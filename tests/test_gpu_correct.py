@@ -23,3 +23,20 @@ def test_gpu_scratch_overflow_is_redone_on_device(ds_small, monkeypatch):
     monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
     st, got, seqs = _check(ds_small, 12, None, counters_must_match=False)
     assert st["n_arena_overflow"] > 0
+
+
+def test_gpu_correct_other_options(ds_small):
+    _check(ds_small, 12, None, opts=dict(insert_sz=300, max_len_weak_region1=300, max_qual=30))
+
+
+def test_gpu_correct_k25(ds_k25):
+    s0 = op.read_fastq(ds_k25 + ".lr.fq")[0][1]
+    extra = [s0[:300] + "R" + s0[301:700] + "YN" + s0[702:1500], s0[:25], s0[:26]]
+    _check(ds_k25, 6, None, extra, k=25)
+
+
+def test_gpu_correct_volume(ds_medium):
+    """1.3 Mb of ONT-profile reads on a repeat-bearing diploid graph, oracle on all host threads."""
+    import os
+    st, got, seqs = _check(ds_medium, 160, None, threads=os.cpu_count() or 4)
+    assert st["n_regions"] > 5000

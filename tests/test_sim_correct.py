@@ -5,17 +5,18 @@ from oracle import oracle_py as op
 from ratatosk_amd import api
 
 
-def _check(prefix, n, lib_path, extra_reads=(), counters_must_match=True):
-    fa, rt = prefix + ".index.k31.fasta.gz", prefix + ".index.k31.rtsk"
-    og, pg = op.Graph(fa, rt, 31), api.Graph(fa, rt, 31, device=0, lib_path=lib_path)
+def _check(prefix, n, lib_path, extra_reads=(), counters_must_match=True, k=31, opts=None, threads=4):
+    """opts: overrides of the Correct_Opt fields (same names in the oracle's and the library's option structs)."""
+    fa, rt = prefix + ".index.k%d.fasta.gz" % k, prefix + ".index.k%d.rtsk" % k
+    og, pg = op.Graph(fa, rt, k), api.Graph(fa, rt, k, device=0, lib_path=lib_path)
     reads = op.read_fastq(prefix + ".lr.fq")[:n]
     seqs = [r[1] for r in reads] + list(extra_reads)
     quals = [r[2] for r in reads] + ["I" * len(s) for s in extra_reads]
     b = api.Batch(pg, seqs, quals)
-    b.run()
+    b.run(pg.opts(**(opts or {})))
     got = b.fetch()
     st = b.stats()
-    want, cnt = og.correct_batch(seqs, quals, threads=4)
+    want, cnt = og.correct_batch(seqs, quals, opts=og.opts(**(opts or {})), threads=threads)
     for i, (g_, w_) in enumerate(zip(got, want)):
         assert g_[0] == w_[0], "sequence of read %d differs" % i
         assert g_[1] == w_[1], "quality of read %d differs" % i
@@ -42,3 +43,16 @@ def test_sim_scratch_overflow_is_redone_on_device(ds_small, monkeypatch):
     monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
     st, got, seqs = _check(ds_small, 12, SIM_LIB, counters_must_match=False)
     assert st["n_arena_overflow"] > 0
+
+
+def test_sim_correct_other_options(ds_small):
+    """-i / -w / -Q away from their defaults (src/Ratatosk.cpp:145-301): shorter insert size changes masking and colour windows,
+    a short maximum weak-region length leaves long regions uncorrected (src/Correction.cpp:74), other quality scale."""
+    _check(ds_small, 8, SIM_LIB, opts=dict(insert_sz=300, max_len_weak_region1=300, max_qual=30))
+
+
+def test_sim_correct_k25(ds_k25):
+    s0 = op.read_fastq(ds_k25 + ".lr.fq")[0][1]
+    # IUPAC codes and N inside reads: windows over them are never looked up, alignments use the 28-pair table (src/Common.hpp:262-276)
+    extra = [s0[:300] + "R" + s0[301:700] + "YN" + s0[702:1500], s0[:25], s0[:26]]
+    _check(ds_k25, 6, SIM_LIB, extra, k=25)
