@@ -30,6 +30,13 @@ RTK_DEV bool rtk_lds_contains(const uint32_t* lds, uint32_t n, uint32_t x) {
 // out = { x in a : (x in b) == want_in_b }
 RTK_FN uint32_t rtk_set_filter(const uint32_t* a_, uint32_t na_, const uint32_t* b_, uint32_t nb_, bool want_in_b_, uint32_t* out_) {
     const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); bool want_in_b = rtk_u(want_in_b_); uint32_t* out = rtk_u(out_);
+    if (na == 0) return 0;
+    if (nb == 0) { // nothing to search in: all of a, or none of it
+        if (want_in_b) return 0;
+        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < na; i += RTK_WAVE) out[i] = a[i];
+        rtk_sync();
+        return na;
+    }
     uint32_t base = 0;
 #ifndef RTK_SIM
     uint32_t* const lds_b = rtk_lds_set_buf();
@@ -58,6 +65,7 @@ RTK_DEV uint32_t rtk_set_diff(const uint32_t* a, uint32_t na, const uint32_t* b,
 RTK_FN uint32_t rtk_set_inter_count(const uint32_t* a_, uint32_t na_, const uint32_t* b_, uint32_t nb_, uint32_t cap_) {
     const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); uint32_t cap = rtk_u(cap_);
     if (na > nb) { const uint32_t* t = a; a = b; b = t; const uint32_t tn = na; na = nb; nb = tn; }
+    if (na == 0 || cap == 0) return 0;
     uint32_t cnt = 0;
 #ifndef RTK_SIM
     uint32_t* const lds_b = rtk_lds_set_buf();
@@ -79,6 +87,12 @@ RTK_FN uint32_t rtk_set_inter_count(const uint32_t* a_, uint32_t na_, const uint
 // out = a | b ; tmp holds b \ a (capacity >= nb)
 RTK_FN uint32_t rtk_set_union(const uint32_t* a_, uint32_t na_, const uint32_t* b_, uint32_t nb_, uint32_t* out_, uint32_t* tmp_) {
     const uint32_t* a = rtk_u(a_); uint32_t na = rtk_u(na_); const uint32_t* b = rtk_u(b_); uint32_t nb = rtk_u(nb_); uint32_t* out = rtk_u(out_); uint32_t* tmp = rtk_u(tmp_);
+    if (nb == 0 || na == 0) { // union with the empty set: a copy
+        const uint32_t* src = nb == 0 ? a : b; const uint32_t n = nb == 0 ? na : nb;
+        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) out[i] = src[i];
+        rtk_sync();
+        return n;
+    }
     const uint32_t nd = rtk_set_diff(b, nb, a, na, tmp);
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < na; i += RTK_WAVE) out[i + rtk_lower_bound(tmp, nd, a[i])] = a[i];
     for (uint32_t j = static_cast<uint32_t>(rtk_lane()); j < nd; j += RTK_WAVE) out[j + rtk_lower_bound(a, na, tmp[j])] = tmp[j];
