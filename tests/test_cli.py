@@ -40,3 +40,18 @@ def test_cli_correct_matches_oracle(ds_small, tmp_path):
     want, _ = op.Graph(fa, rt, 31).correct_batch([x[1] for x in reads], [x[2] for x in reads], threads=4)
     assert [g[0] for g in got] == [x[0] for x in reads]
     assert [(g[1], g[2]) for g in got] == want
+
+
+@pytest.mark.gpu
+def test_cli_two_workers_many_tickets(ds_medium, tmp_path):
+    """Seven tickets through the two overlapping workers of one GPU (seed stage of one, region stage of the other): records still
+    come out in input order and equal the oracle's."""
+    fa, rt = ds_medium + ".index.k31.fasta.gz", ds_medium + ".index.k31.rtsk"
+    out = str(tmp_path / "out")
+    r = subprocess.run([EXE, "correct", "-1", "-c", "1", "-B", "200000", "-g", fa, "-d", rt, "-l", ds_medium + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = op.read_fastq(out + ".2.fastq")
+    reads = op.read_fastq(ds_medium + ".lr.fq")
+    want, _ = op.Graph(fa, rt, 31).correct_batch([x[1] for x in reads], [x[2] for x in reads], threads=os.cpu_count() or 4)
+    assert [g[0] for g in got] == [x[0] for x in reads]
+    assert [(g[1], g[2]) for g in got] == want
