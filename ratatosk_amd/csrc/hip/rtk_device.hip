@@ -203,10 +203,13 @@ RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* rof
     for (uint64_t tile = static_cast<uint64_t>(RTK_BLOCK_ID); tile < n_tiles; tile += static_cast<uint64_t>(grid)) {
         const uint64_t b = tile * RTK_WAVE + static_cast<uint64_t>(rtk_lane());
         uint64_t h = RTK_NO_HIT;
+        // owning read: largest r with roff[r] <= b. One scalar search for the tile's first base; the other lanes step forward from it
+        // (a tile rarely spans more than one read boundary).
+        uint32_t lo0 = 0;
+        { uint32_t hi = n_reads; const uint64_t b0 = tile * RTK_WAVE; while (hi - lo0 > 1) { const uint32_t mid = (lo0 + hi) >> 1; if (rtk_ld(roff + mid) <= b0) lo0 = mid; else hi = mid; } }
         if (b < n_bases) {
-            // owning read: largest r with roff[r] <= b
-            uint32_t lo = 0, hi = n_reads;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (roff[mid] <= b) lo = mid; else hi = mid; }
+            uint32_t lo = lo0;
+            while (lo + 1 < n_reads && roff[lo + 1] <= b) ++lo;
             if (b + static_cast<uint64_t>(g.k) <= roff[lo + 1]) {
                 uint64_t fw = 0; bool ok = true;
                 for (int i = 0; i < g.k; ++i) {
