@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -46,6 +47,22 @@ struct rtk_graph {
     // per-wave work areas, kept across batches: slot 0 for the seed stage, slot 1 for the region stage. A stage holds its slot's lock
     // while it runs, so the seed stage of one batch and the region stage of another overlap, two stages of one kind queue up.
     void* scratch[2] = {nullptr, nullptr}; uint64_t scratch_bytes_[2] = {0, 0}; std::mutex scratch_lock[2];
+    // device buffers of finished batches, by size: a ticket's ~25 buffers are taken from here instead of hipMalloc / hipFree, which
+    // cost milliseconds each and (hipFree) wait for the whole device, i.e. for the other batch's kernels
+    std::mutex pool_lock; std::multimap<uint64_t, void*> pool; uint64_t pool_bytes = 0;
+    void* pool_take(uint64_t bytes, uint64_t* got) {
+        bytes = (bytes + 4095) / 4096 * 4096;
+        { std::lock_guard<std::mutex> h(pool_lock);
+          std::multimap<uint64_t, void*>::iterator it = pool.lower_bound(bytes);
+          if (it != pool.end() && it->first <= bytes + bytes / 4 + (1u << 20)) { void* p = it->second; *got = it->first; pool_bytes -= it->first; pool.erase(it); return p; } }
+        *got = bytes; return rtk_dmalloc(bytes);
+    }
+    void pool_give(void* p, uint64_t bytes) {
+        std::lock_guard<std::mutex> h(pool_lock);
+        if (pool_bytes + bytes > (24ull << 30)) { rtk_dfree(p); return; } // keep at most 24 GB parked
+        pool.insert(std::make_pair(bytes, p)); pool_bytes += bytes;
+    }
+    void pool_clear() { std::lock_guard<std::mutex> h(pool_lock); for (std::multimap<uint64_t, void*>::iterator it = pool.begin(); it != pool.end(); ++it) rtk_dfree(it->second); pool.clear(); pool_bytes = 0; }
     rtk_graph() { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { dbuf[i] = nullptr; dbytes[i] = 0; } memset(&dview, 0, sizeof(dview)); memset(&info, 0, sizeof(info)); }
 };
 
@@ -153,7 +170,7 @@ extern "C" int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info) { if
 extern "C" void rtk_graph_free(rtk_graph* g) {
     if (!g) return;
     if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
-    rtk_dfree(g->scratch[0]); rtk_dfree(g->scratch[1]);
+    rtk_dfree(g->scratch[0]); rtk_dfree(g->scratch[1]); g->pool_clear();
     delete g;
 }
 

@@ -5,6 +5,8 @@
 // output is always in input order: src/Ratatosk.cpp:919). Everything else (`index`, `-2`, `-u`, `-p/-P`) is out of scope.
 #include <getopt.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -97,6 +99,9 @@ int main(int argc, char** argv) {
     size_t ticket_dispenser = 0, next_to_write = 0, n_reads = 0;
     std::map<size_t, std::string> done; // ticket -> formatted FASTQ block
     bool failed = false;
+    std::atomic<long long> us_parse(0), us_correct(0), us_format(0);
+    auto now_us = []() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const long long t_begin = now_us();
 
     auto worker = [&](int w) {
         while (true) {
@@ -104,6 +109,7 @@ int main(int argc, char** argv) {
             {
                 std::lock_guard<std::mutex> lk(m_in);
                 if (stop) return;
+                const long long tp0 = now_us();
                 ticket = ticket_dispenser++;
                 std::string n, s, q;
                 while (bases < opt.batch_bases) {
@@ -112,13 +118,18 @@ int main(int argc, char** argv) {
                     bases += s.size(); names.push_back(n); seqs.push_back(s); quals.push_back(q);
                     if (opt.verbose && (++n_reads % 1000 == 0)) printf("Ratatosk::correct(): Processed %zu reads \n", n_reads);
                 }
+                us_parse += now_us() - tp0;
             }
             std::string block;
             if (!seqs.empty()) {
                 const uint32_t n = static_cast<uint32_t>(seqs.size());
                 std::vector<const char*> ps(n), pq(n); std::vector<uint32_t> len(n), olen(n); std::vector<char*> os(n, nullptr), oq(n, nullptr);
                 for (uint32_t i = 0; i < n; ++i) { ps[i] = seqs[i].c_str(); pq[i] = quals[i].empty() ? nullptr : quals[i].c_str(); len[i] = static_cast<uint32_t>(seqs[i].size()); }
-                if (rtk_correct_batch(graphs[w % n_gpus], &ro, n, ps.data(), pq.data(), len.data(), os.data(), oq.data(), olen.data()) != RTK_OK) {
+                const long long tc0 = now_us();
+                const int rc_ = rtk_correct_batch(graphs[w % n_gpus], &ro, n, ps.data(), pq.data(), len.data(), os.data(), oq.data(), olen.data());
+                us_correct += now_us() - tc0;
+                const long long tf0 = now_us();
+                if (rc_ != RTK_OK) {
                     fprintf(stderr, "Ratatosk::correct(): %s\n", rtk_last_error()); failed = true;
                 } else {
                     for (uint32_t i = 0; i < n; ++i) { // writeCorrectedOutput, trim == 0 (src/Ratatosk.cpp:516-520)
@@ -126,6 +137,7 @@ int main(int argc, char** argv) {
                         rtk_free(os[i]); rtk_free(oq[i]);
                     }
                 }
+                us_format += now_us() - tf0;
             }
             {
                 std::unique_lock<std::mutex> lk(m_out);
@@ -140,6 +152,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < th.size(); ++i) th[i].join();
     for (std::map<size_t, std::string>::iterator it = done.begin(); it != done.end(); ++it) fwrite(it->second.data(), 1, it->second.size(), fout);
     fclose(fout);
+    if (opt.verbose) printf("Ratatosk::correct(): correction phase %.2f s wall; summed over workers: parse %.2f s, correct (pack + GPU + unpack) %.2f s, format %.2f s\n",
+                            1e-6 * (now_us() - t_begin), 1e-6 * us_parse.load(), 1e-6 * us_correct.load(), 1e-6 * us_format.load());
     for (int w = 0; w < n_gpus; ++w) rtk_graph_free(graphs[w]);
     if (failed) exit(1);
     return 0;
