@@ -269,6 +269,9 @@ RTK_DEV bool rtk_variant_code(int v, int k, uint64_t w_k1, uint32_t w_ck, uint32
         const int rest = k - 1 - oo; // characters after the inserted base
         const uint64_t lo_mask = rest ? ((1ull << (2 * rest)) - 1ull) : 0ull;
         code = ((w_k1 >> (2 * rest)) << (2 * rest + 2)) | (nb << (2 * rest)) | (w_k1 & lo_mask); valid = true;
+        // inserting b in front of a b spells the same k-mer as inserting it behind that b: only the last offset of such a run is probed
+        // (the hits of a window are reduced to distinct k-mers anyway, src/Graph.cpp:201-216)
+        if (rest >= 1 && ((w_k1 >> (2 * (rest - 1))) & 3ull) == nb) valid = false;
     } else if (v < RTK_N_VARIANTS) { // graph k-mer lacks one interior read base: k+1 read characters
         if (w_ck <= 3 && w_ck1 <= 3) {
             const int oo = v - 217 + 1; // deleted offset in [1, k-2]
@@ -277,6 +280,8 @@ RTK_DEV bool rtk_variant_code(int v, int k, uint64_t w_k1, uint32_t w_ck, uint32
             const uint64_t lo_mask = (1ull << (2 * keep_lo)) - 1ull;
             const uint64_t hi = (2 * (keep_lo + 1) >= 64) ? 0ull : (full2 >> (2 * (keep_lo + 1)));
             code = (hi << (2 * keep_lo)) | (full2 & lo_mask); valid = true;
+            // deleting either of two equal neighbours spells the same k-mer: only the last offset of a run is probed
+            if (oo <= k - 3 && ((full2 >> (2 * (k - oo))) & 3ull) == ((full2 >> (2 * (k - oo - 1))) & 3ull)) valid = false;
         }
     }
     *code_out = code & ((k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull));
