@@ -309,6 +309,9 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
 #else
     const int n_sub = 1;
 #endif
+    const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
+    uint32_t lo_tile = 0; // one scalar search per tile: largest r with roff[r] <= first base of the tile
+    { uint32_t hi = n_reads; const uint64_t b0 = tile * 64; while (hi - lo_tile > 1) { const uint32_t mid = (lo_tile + hi) >> 1; if (rtk_ld(roff + mid) <= b0) lo_tile = mid; else hi = mid; } }
     for (int sub = 0; sub < n_sub; ++sub) { // the 1-lane simulator visits the 64 positions of the tile one after the other
 #ifdef RTK_SIM
         const uint64_t bb = tile * 64 + static_cast<uint64_t>(sub);
@@ -318,10 +321,10 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
         // per-lane: is the window starting at bb a candidate? how many usable characters follow (k-1, k or k+1)?
         bool cand = false; uint64_t c_k1 = 0; uint32_t ck = 4, ck1 = 4;
         if (bb < bv.n_bases) {
-            uint32_t lo = 0, hi = bv.n_reads;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (bv.roff[mid] <= bb) lo = mid; else hi = mid; }
-            const uint64_t rend = bv.roff[lo + 1];
-            if (bb + static_cast<uint64_t>(k) <= rend && rend - bv.roff[lo] > static_cast<uint64_t>(k)) {
+            uint32_t lo = lo_tile; // owning read: steps forward from the read of the tile's first base
+            while (lo + 1 < n_reads && roff[lo + 1] <= bb) ++lo;
+            const uint64_t rend = roff[lo + 1];
+            if (bb + static_cast<uint64_t>(k) <= rend && rend - roff[lo] > static_cast<uint64_t>(k)) {
                 bool ok = true;
 #ifdef RTK_SIM
                 const unsigned char* wc = reinterpret_cast<const unsigned char*>(bv.masked.get()) + bb;
