@@ -66,6 +66,8 @@ def load_library(path=None):
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
     L.rtk_batch_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]
     L.rtk_batch_run.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
+    L.rtk_graph_strip_annotations.restype = C.c_longlong
+    L.rtk_graph_strip_annotations.argtypes = [C.c_void_p]
     L.rtk_batch_run_seeds.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
     L.rtk_batch_run_regions.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
     L.rtk_batch_fetch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]

@@ -167,6 +167,15 @@ extern "C" int rtk_graph_adopt_device(rtk_graph* g) {
 
 extern "C" int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info) { if (!g || !info) return rtk_fail(RTK_ERR_ARG, "rtk_graph_get_info: null"); *info = g->info; return RTK_OK; }
 
+extern "C" long long rtk_graph_strip_annotations(rtk_graph* g) {
+    if (!g) return rtk_fail(RTK_ERR_ARG, "rtk_graph_strip_annotations: null");
+    if (!g->has_host || g->on_device) return rtk_fail(RTK_ERR_ARG, "rtk_graph_strip_annotations: call it on a loaded graph before rtk_graph_upload");
+    long long n = 0;
+    for (size_t u = 0; u < g->host.flags.size(); ++u) if (g->host.flags[u] & (RTK_F_SHORT_CYCLE | RTK_F_AMBIGUITY)) { g->host.flags[u] &= ~static_cast<uint32_t>(RTK_F_SHORT_CYCLE | RTK_F_AMBIGUITY); ++n; }
+    g->unsupported_annotations = false;
+    return n;
+}
+
 extern "C" void rtk_graph_free(rtk_graph* g) {
     if (!g) return;
     if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);

@@ -25,14 +25,14 @@ struct Opt {
     std::string out, graph, udata;
     int cores = 1, k1 = 31, max_qual = 40;
     size_t insert_sz = 500, w1 = 1000, batch_bases = 32u << 20;
-    bool pass1 = false, pass2 = false, verbose = false, correct = false;
+    bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false;
 };
 
 static void usage() {
     fprintf(stderr, "Ratatosk (MI355X hot-path build)\n\nUsage: Ratatosk correct -1 -g <graph.fasta.gz> -d <unitig_data.rtsk> -l <long_reads> -o <out_prefix> [options]\n"
                     "  -c, --cores           number of GPUs/worker threads to use (default 1)\n  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
-                    "  -Q, --max-base-qual   maximum base quality (default 40)\n  -v, --verbose\n"
+                    "  -Q, --max-base-qual   maximum base quality (default 40)\n  -v, --verbose\n      --strip-annotations  accept an index with short-cycle / SNP annotations by dropping them (results then differ from the reference there)\n"
                     "Writes <out_prefix>.2.fastq (plain FASTQ, input order). Only the `correct -1` step with a pre-built index is in scope.\n");
 }
 
@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     static struct option lo[] = {{"in-long", required_argument, 0, 'l'}, {"out-long", required_argument, 0, 'o'}, {"cores", required_argument, 0, 'c'},
         {"in-graph", required_argument, 0, 'g'}, {"in-unitig-data", required_argument, 0, 'd'}, {"insert-sz", required_argument, 0, 'i'}, {"k1", required_argument, 0, 'k'},
         {"max-len-weak1", required_argument, 0, 'w'}, {"max-base-qual", required_argument, 0, 'Q'}, {"1st-pass-only", no_argument, 0, '1'}, {"2nd-pass-only", no_argument, 0, '2'},
-        {"batch-bases", required_argument, 0, 'B'}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
+        {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
     int c, idx = 0;
     while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:B:12v", lo, &idx)) != -1) {
         switch (c) {
@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
             case '1': opt.pass1 = true; break;
             case '2': opt.pass2 = true; break;
             case 'v': opt.verbose = true; break;
+            case 1001: opt.strip = true; break;
             case 's': fprintf(stderr, "Ratatosk::correct: short reads are only needed by `index` (not in scope); ignored\n"); break;
             default: usage(); return 0; // the reference returns 0 on option errors too (src/Ratatosk.cpp:1018)
         }
@@ -81,7 +82,9 @@ int main(int argc, char** argv) {
     const int n_gpus = opt.cores, n_workers = 2 * opt.cores;
     std::vector<rtk_graph*> graphs(n_gpus, nullptr);
     for (int w = 0; w < n_gpus; ++w) {
-        if (rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, 1, &graphs[w]) != RTK_OK || rtk_graph_upload(graphs[w], w) != RTK_OK) {
+        bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, 1, &graphs[w]) == RTK_OK;
+        if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[w]); if (w == 0 && ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs (fixRepeats / fixAmbiguity are not built)\n", ns); }
+        if (!ok || rtk_graph_upload(graphs[w], w) != RTK_OK) {
             fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error());
             exit(1);
         }

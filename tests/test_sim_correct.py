@@ -56,3 +56,40 @@ def test_sim_correct_k25(ds_k25):
     # IUPAC codes and N inside reads: windows over them are never looked up, alignments use the 28-pair table (src/Common.hpp:262-276)
     extra = [s0[:300] + "R" + s0[301:700] + "YN" + s0[702:1500], s0[:25], s0[:26]]
     _check(ds_k25, 6, SIM_LIB, extra, k=25)
+
+
+def test_annotated_index_is_refused_then_stripped(ds_clean, tmp_path):
+    """An index whose unitig data carries a short-cycle flag (what the reference's `index` step writes, src/Graph.cpp:4660) is refused
+    loudly by the run entry points; rtk_graph_strip_annotations makes it equal to the unannotated index."""
+    import ctypes as C
+    import shutil
+    import pytest
+    fa, rt = ds_clean + ".index.k31.fasta.gz", ds_clean + ".index.k31.rtsk"
+    rt2 = str(tmp_path / "annot.rtsk")
+    shutil.copy(rt, rt2)
+    with open(rt2, "r+b") as f:  # first record: 16-byte head k-mer, u64 coverage word, u64 shared word (bit 8 = short cycle)
+        f.seek(16 + 8 + 1)
+        b = f.read(1)
+        f.seek(16 + 8 + 1)
+        f.write(bytes([b[0] | 0x01]))
+    reads = op.read_fastq(ds_clean + ".lr.fq")[:3]
+    seqs, quals = [r[1] for r in reads], [r[2] for r in reads]
+    pg = api.Graph(fa, rt2, 31, device=0, lib_path=SIM_LIB)
+    with pytest.raises(api.RtkError) as e:
+        api.Batch(pg, seqs, quals).run()
+    assert "annotations" in str(e.value)
+    # same files, annotations dropped before the upload: results of the plain index
+    L = api.load_library(SIM_LIB)
+    h = C.c_void_p()
+    assert L.rtk_graph_load(fa.encode(), rt2.encode(), 31, 1, C.byref(h)) == 0
+    assert L.rtk_graph_strip_annotations(h) == 1
+    assert L.rtk_graph_upload(h, 0) == 0
+    o = api.RtkOpts(); assert L.rtk_opts_default(h, C.byref(o)) == 0
+    want = api.Graph(fa, rt, 31, device=0, lib_path=SIM_LIB).correct_batch(seqs, quals)
+    n = len(seqs)
+    sa = (C.c_char_p * n)(*[s.encode() for s in seqs]); qa = (C.c_char_p * n)(*[q.encode() for q in quals]); la = (C.c_uint32 * n)(*[len(s) for s in seqs])
+    os_, oq, ol = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_uint32 * n)()
+    assert L.rtk_correct_batch(h, C.byref(o), n, sa, qa, la, os_, oq, ol) == 0
+    got = [(C.string_at(os_[i], ol[i]).decode(), C.string_at(oq[i], ol[i]).decode()) for i in range(n)]
+    assert got == want
+    L.rtk_graph_free(h)
