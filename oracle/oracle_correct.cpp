@@ -151,13 +151,82 @@ std::string pathToString(const Ctx& c, const Path& p) { // Path.hpp:449-485
     return s;
 }
 
-void requireUnannotated(const Ctx& c, const Path& p) { // fixRepeats / getAmbiguityVector are identity without index annotations
+void requireUnannotated(const Ctx& c, const Path& p) { // getAmbiguityVector / fixAmbiguity are identity without SNP annotations
     for (size_t i = 0; i < p.ums.size(); ++i) {
-        if (c.g.isShortCycle(p.ums[i].unitig) || c.g.info[p.ums[i].unitig].has_ambiguity) {
-            fprintf(stderr, "oracle: unitig %d carries short-cycle / SNP annotations; fixRepeats/fixAmbiguity are not restated (SURVEY.md §8f-3)\n", p.ums[i].unitig);
+        if (c.g.info[p.ums[i].unitig].has_ambiguity) {
+            fprintf(stderr, "oracle: unitig %d carries SNP annotations; fixAmbiguity is not restated (SURVEY.md 8f-3)\n", p.ums[i].unitig);
             abort();
         }
     }
+}
+
+// ---------------------------------------------------------------- fixRepeats (src/GraphTraversal.cpp:1149-1334)
+// Path(um_start, ext, um_end) (Path.hpp:109-152): um_start, then one whole unitig per character of ext (the successor reached by
+// that base), then um_end. Empty when a base has no successor.
+Path pathFromCompact(const Ctx& c, const UM& um_start, const std::string& ext, const UM& um_end) {
+    Path p;
+    UM curr = um_start;
+    std::vector<UM> mid;
+    for (size_t i = 0; i < ext.size(); ++i) {
+        UM out[4]; char base[4]; int n = 0; c.g.successors(curr, out, base, n);
+        int f = -1; for (int j = 0; j < n; ++j) if (base[j] == ext[i]) f = j;
+        if (f < 0) return Path();
+        curr = out[f]; mid.push_back(curr);
+    }
+    p.ums.push_back(um_start); p.l = um_start.len + c.k - 1;
+    for (size_t i = 0; i < mid.size(); ++i) { p.ums.push_back(mid[i]); p.l += mid[i].len; }
+    p.ums.push_back(um_end); p.l += um_end.len;
+    return p;
+}
+
+Path pathRevComp(const Path& p) { // Path.hpp:208-262
+    Path o; o.l = p.l; o.qual = std::string(p.qual.rbegin(), p.qual.rend());
+    for (size_t i = p.ums.size(); i-- > 0;) { UM u = p.ums[i]; u.strand = !u.strand; o.ums.push_back(u); }
+    return o;
+}
+
+Path fixRepeats(const Ctx& c, const Path& path_in, const char* ref, const size_t ref_len) {
+    Path path = path_in;
+    std::vector<UM> v = path.ums;
+    std::string s_qual = path.qual;
+    const char q_max = getQual(1.0, 0, c.opt.max_qual);
+    int64_t editDistance;
+    { const std::string s = pathToString(c, path); editDistance = c.align(s.c_str(), s.length(), ref, ref_len, -1, MODE_NW, false).editDistance; }
+    for (size_t i = 0; i < v.size(); ++i) {
+        const UM um_path = v[i];
+        if (!c.g.isShortCycle(um_path.unitig)) continue;
+        Path best;
+        // the unitig from the mapped start to its end, and from its beginning to the mapped end, both forward (:1213-1224)
+        UM um_start = um_path, um_end = um_path;
+        um_start.len = c.g.nkm(um_path.unitig) - um_path.dist; um_start.strand = true;
+        um_end.dist = 0; um_end.len = um_path.dist + um_path.len; um_end.strand = true;
+        const std::vector<std::string>& cyc = c.g.info[um_path.unitig].cycles;
+        for (size_t ci = 0; ci < cyc.size(); ++ci) {
+            Path rep = pathFromCompact(c, um_start, cyc[ci], um_end);
+            if (!um_path.strand) rep = pathRevComp(rep);
+            // evaluatePath (:1167-1201): prefix + repeat + suffix, qualities of the replaced unitig set to the maximum
+            Path ext; size_t len_prefix = 0;
+            for (size_t j = 0; j < i; ++j) { pathExtend(c, ext, v[j]); len_prefix += v[j].len; }
+            for (size_t j = 0; j < rep.ums.size(); ++j) pathExtend(c, ext, rep.ums[j]);
+            for (size_t j = i + 1; j < v.size(); ++j) pathExtend(c, ext, v[j]);
+            std::string lq = s_qual;
+            if (len_prefix > lq.size()) { fprintf(stderr, "oracle: fixRepeats on a path without qualities (std::string::replace would throw in the reference)\n"); abort(); }
+            lq.replace(len_prefix, um_path.len + c.k - 1, std::string(rep.l, q_max));
+            if (lq.length() == ext.l) ext.qual = lq; // Path::setQuality
+            const std::string s = pathToString(c, ext);
+            const int64_t d = c.align(s.c_str(), s.length(), ref, ref_len, static_cast<int>(editDistance), MODE_NW, false).editDistance;
+            if (d >= 0 && d < editDistance) { editDistance = d; best = ext; }
+        }
+        if (getenv("ORC_TRACE_REPEATS")) fprintf(stderr, "[orc] fixRepeats unitig %d cycles %zu improved %d\n", um_path.unitig, cyc.size(), best.l != 0 ? 1 : 0);
+        if (best.l != 0) { // a better aligning path: continue behind the inserted unitigs (:1283-1292)
+            const size_t diff = best.size() - path.size();
+            path = best; v = path.ums; s_qual = path.qual;
+            i += diff - 1;
+        } else {
+            for (size_t j = i + 1; j < v.size(); ++j) { if (v[j].unitig == um_path.unitig) ++i; else break; }
+        }
+    }
+    return path;
 }
 
 // ---------------------------------------------------------------- candidate selection (src/Alignment.cpp)
@@ -380,7 +449,7 @@ std::vector<Path> explorePathsBFS2(const Ctx& c, const IdSet& all_pids, const ch
     }
     if (!v.empty()) {
         if (v.size() > 1) { const int b = selectBest(c, v, ref, ref_len, MODE_NW).first; std::vector<Path> one(1, v[b]); v.swap(one); }
-        requireUnannotated(c, v[0]); // fixRepeats == identity on an index without short-cycle annotations
+        v[0] = fixRepeats(c, v[0], ref, ref_len); requireUnannotated(c, v[0]);
     }
     return v;
 }
@@ -438,7 +507,7 @@ std::vector<Path> explorePathsBFS(const Ctx& c, const IdSet& all_pids, const cha
     }
     if (!v.empty()) {
         if (v.size() > 1) { const int b = selectBest(c, v, ref, ref_len, MODE_NW).first; std::vector<Path> one(1, v[b]); v.swap(one); }
-        requireUnannotated(c, v[0]);
+        v[0] = fixRepeats(c, v[0], ref, ref_len); requireUnannotated(c, v[0]);
     }
     return v;
 }

@@ -11,9 +11,11 @@
 // address-dependent orders:
 //   [D1] chooseColors anchor order = (colour-set cardinality asc, unitig id asc)   (src/Correction.cpp:286-293)
 //   [D2] extractSemiWeakPaths path grouping = STABLE sort by mapped string of the last unitig (src/Correction.cpp:52)
+// fixRepeats on short-cycle unitigs (src/GraphTraversal.cpp:1149-1334) is restated; its inputs come from the restatement of
+// detectShortCycles in ratatosk_amd/csrc/tools/build_index.cpp.
 // Not restated (index annotations our index producer never emits; aborts loudly if present):
-//   fixRepeats on short-cycle unitigs (src/GraphTraversal.cpp:1149-1334), fixAmbiguity/getAmbiguityVector on
-//   SNP-annotated unitigs (src/Alignment.cpp:527-844, src/GraphTraversal.cpp:966-1055), pass 2 (long_read_correct).
+//   fixAmbiguity/getAmbiguityVector on SNP-annotated unitigs (src/Alignment.cpp:527-844, src/GraphTraversal.cpp:966-1055),
+//   pass 2 (long_read_correct).
 #ifndef RTK_ORACLE_CORRECT_HPP
 #define RTK_ORACLE_CORRECT_HPP
 

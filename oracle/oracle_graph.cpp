@@ -165,6 +165,7 @@ void Graph::load(const std::string& fasta_gz, const std::string& rtsk, int k_) {
         ui.has_ambiguity = !amb.empty();
         const uint64_t ncyc = r.u64();
         if (r.p + ncyc > bytes.size()) throw std::runtime_error("oracle: truncated cycles");
+        for (uint64_t a = 0; a < ncyc;) { const size_t l = strnlen(reinterpret_cast<const char*>(&bytes[r.p + a]), ncyc - a); ui.cycles.push_back(std::string(reinterpret_cast<const char*>(&bytes[r.p + a]), l)); a += l + 1; }
         r.p += ncyc;
     }
     for (size_t u = 0; u < seen.size(); ++u) if (!seen[u]) throw std::runtime_error("oracle: unitig without .rtsk record");

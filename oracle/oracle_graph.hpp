@@ -47,6 +47,7 @@ struct UnitigInfo { // restatement of the read side of src/UnitigData.hpp:258-49
     int32_t global_id; // index into Graph::globals or -1 (SharedPairID global pointer)
     IdSet local;
     bool has_ambiguity;
+    std::vector<std::string> cycles; // getCompactCycles() (UnitigData.hpp:312-327): successor-base strings of the short cycles through the unitig
     UnitigInfo() : kmcov(0), shared(0), global_id(-1), has_ambiguity(false) {}
 };
 

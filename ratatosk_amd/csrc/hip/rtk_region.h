@@ -598,6 +598,99 @@ RTK_DEV UMap rtk_start_suffix(const RCtx& c, const UMap& um_s) { // src/GraphTra
 }
 
 // explorePathsBFS2 / explorePathsBFS. Returns a level-1 handle of the single resulting path, or ~0 if none.
+// ------------------------------------------------------------------------------------------------ fixRepeats (src/GraphTraversal.cpp:1149-1334)
+// For every unitig of the path that lies on a short cycle (micro / mini-satellite motif) the stored compact cycles are tried as one
+// more turn through it: prefix + [unitig to its end, cycle unitigs, unitig from its start] + suffix; a turn is kept when it lowers the
+// NW distance to the read window (bounded by the distance so far). Identity when no unitig of the path is flagged.
+RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, uint32_t ref_len_) {
+    const RCtx& c = *rtk_u(&c_); const uint64_t hp = rtk_u(hp_); const char* ref = rtk_u(ref_); const uint32_t ref_len = rtk_u(ref_len_);
+    RegionScratch& s = *c.sc;
+    const GraphView& g = c.g;
+    const uint32_t k = static_cast<uint32_t>(c.k);
+    { // fast way out: no flagged unitig on the path
+        const int lv = rtk_h_lvl(hp); const uint64_t oo = rtk_h_off(hp);
+        const UMap* pu = rtk_path_ums(s, lv, oo); const uint32_t pn = rtk_rec_n(s, hp);
+        bool any = false;
+        for (uint32_t i0 = 0; i0 < pn && !any; i0 += RTK_WAVE) { const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane()); any = rtk_ballot(i < pn && (g.flags[pu[i].unitig] & RTK_F_SHORT_CYCLE)) != 0ull; }
+        if (!any) return hp;
+    }
+    WPath& P = s.wp[1]; WPath& E = s.wp[2]; UMap* R = s.wp[3].ums;
+    rtk_wp_load(s, P, hp);
+    if (rtk_failed(s)) return ~0ull;
+    const char q_max = rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual));
+    int ed;
+    { const uint32_t sl = rtk_ums_to_string(c, P.ums, P.n, s.str[0]); if (sl == 0xFFFFFFFFu) return ~0ull; ed = rtk_u(rtk_align(c, s.str[0], sl, ref, ref_len, -1, RTK_MODE_NW).dist); }
+    for (uint32_t i = 0; i < P.n && !rtk_failed(s); ++i) {
+        const UMap um_path = rtk_u(P.ums[i]);
+        if (!(g.flags[um_path.unitig] & RTK_F_SHORT_CYCLE)) continue;
+        uint64_t best_h = ~0ull;
+        UMap um_start = um_path, um_end = um_path; // the unitig from the mapped start to its end / from its beginning to the mapped end, both forward (:1213-1224)
+        um_start.len = rtk_nkm(g, um_path.unitig) - um_path.dist; um_start.strand = 1;
+        um_end.dist = 0; um_end.len = um_path.dist + um_path.len; um_end.strand = 1;
+        const char* cyc = g.cyc; const uint64_t c_lo = g.cycoff[um_path.unitig], c_hi = g.cycoff[um_path.unitig + 1];
+        for (uint64_t a = c_lo; a < c_hi && !rtk_failed(s);) {
+            // Path(um_start, cycle, um_end) (Path.hpp:109-152) as an explicit unitig list R
+            uint32_t nR = 0, rep_l = um_start.len + k - 1; bool ok = true;
+            if (s.um_cap < 4) { rtk_fail_ovf(s, 5); break; }
+            R[nR++] = um_start;
+            UMap curr = um_start;
+            uint64_t e = a;
+            for (; e < c_hi; ++e) {
+                const char ch = rtk_ld(cyc + e);
+                if (ch == 0) break;
+                const uint32_t nb = rtk_ld(g.adj + 8ull * curr.unitig + (curr.strand ? 0 : 4) + ((static_cast<uint32_t>(ch) >> 1) & 3u ^ (((static_cast<uint32_t>(ch) >> 1) & 3u) >> 1))); // A,C,G,T -> 0..3
+                if (nb == RTK_NONE32) { ok = false; continue; }
+                if (!ok) continue;
+                curr.unitig = nb >> 1; curr.strand = nb & 1u; curr.dist = 0; curr.len = rtk_nkm(g, curr.unitig);
+                if (nR + 2 > s.um_cap) { rtk_fail_ovf(s, 5); break; }
+                R[nR++] = curr; rep_l += curr.len;
+            }
+            a = e + 1;
+            if (rtk_failed(s)) break;
+            if (ok) { R[nR++] = um_end; rep_l += um_end.len; } else { nR = 0; rep_l = 0; }
+            rtk_sync();
+            if (!um_path.strand) { // rev_comp (Path.hpp:208-262): reversed order, flipped strands
+                for (uint32_t x = 0; x < nR / 2; ++x) { const UMap t = rtk_u(R[x]); R[x] = R[nR - 1 - x]; R[nR - 1 - x] = t; }
+                rtk_sync();
+                for (uint32_t x = static_cast<uint32_t>(rtk_lane()); x < nR; x += RTK_WAVE) R[x].strand ^= 1u;
+                rtk_sync();
+            }
+            // evaluatePath (:1167-1201)
+            rtk_wp_clear(E);
+            uint32_t len_prefix = 0;
+            for (uint32_t j = 0; j < i; ++j) { const UMap u = rtk_u(P.ums[j]); rtk_wp_extend(c, E, u); len_prefix += u.len; }
+            for (uint32_t x = 0; x < nR; ++x) { const UMap u = rtk_u(R[x]); rtk_wp_extend(c, E, u); }
+            for (uint32_t j = i + 1; j < P.n; ++j) { const UMap u = rtk_u(P.ums[j]); rtk_wp_extend(c, E, u); }
+            if (rtk_failed(s)) break;
+            const uint32_t qn = P.qlen;
+            if (len_prefix > qn) { rtk_fail_ovf(s, 14); break; } // std::string::replace would throw in the reference: a path without qualities never gets here
+            const uint32_t cut = (um_path.len + k - 1) < (qn - len_prefix) ? (um_path.len + k - 1) : (qn - len_prefix);
+            const uint32_t new_len = qn - cut + rep_l;
+            E.qlen = 0;
+            if (new_len == E.l) { // Path::setQuality
+                if (new_len > s.str_cap) { rtk_fail_ovf(s, 6); break; }
+                rtk_wcopy(E.qual, P.qual, len_prefix);
+                rtk_wfill(E.qual + len_prefix, q_max, rep_l);
+                rtk_wcopy(E.qual + len_prefix + rep_l, P.qual + len_prefix + cut, qn - len_prefix - cut);
+                E.qlen = new_len;
+            }
+            const uint32_t sl = rtk_ums_to_string(c, E.ums, E.n, s.str[0]); if (sl == 0xFFFFFFFFu) break;
+            const int d = rtk_u(rtk_align(c, s.str[0], sl, ref, ref_len, ed, RTK_MODE_NW).dist);
+            if (d >= 0 && d < ed) { ed = d; best_h = rtk_wp_commit(s, E, 1); }
+        }
+        if (rtk_failed(s)) break;
+        if (best_h != ~0ull) { // a better aligning path: go on behind the inserted unitigs (:1283-1292)
+            const uint32_t diff = rtk_rec_n(s, best_h) - P.n;
+            rtk_wp_load(s, P, best_h);
+            i += diff - 1;
+        } else {
+            while (i + 1 < P.n && rtk_u(P.ums[i + 1]).unitig == um_path.unitig) ++i;
+        }
+    }
+    if (rtk_failed(s)) return ~0ull;
+    return rtk_wp_commit(s, P, 1);
+}
+
 RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_s_, const UMap& um_e_, bool has_end_) {
     const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_s = rtk_u(um_s_); const UMap um_e = rtk_u(um_e_); bool has_end = rtk_u(has_end_);
     RegionScratch& s = *c.sc;
@@ -697,7 +790,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
     }
     if (rtk_failed(s) || nv == 0) return ~0ull;
     if (nv > 1) { int bid, bend; rtk_select_best(c, v, nv, ref, ref_len, RTK_MODE_NW, -1.0, &bid, &bend); if (rtk_failed(s)) return ~0ull; v[0] = v[bid]; }
-    return v[0]; // fixRepeats is the identity on an index without short-cycle annotations
+    return rtk_fix_repeats(c, v[0], ref, ref_len);
 }
 
 // ------------------------------------------------------------------------------------------------ extractSemiWeakPaths (src/Correction.cpp:3-157)

@@ -85,6 +85,8 @@ struct GraphView {
     U<const uint64_t*> ht;        // [2*slots] {canonical k-mer, unitig<<32 | dist<<1 | stored_is_canonical}, empty key = RTK_EMPTY_KEY
     U<const uint64_t*> bf;        // [bf_mask+1] blocked Bloom filter over the canonical k-mers (2 bits of one 64-bit word per k-mer)
     U<uint64_t> bf_mask;
+    U<const uint64_t*> cycoff;    // [n+1] compact cycles of unitig u = cyc[cycoff[u] .. cycoff[u+1]) (NUL-terminated strings of successor bases)
+    U<const char*> cyc;
 };
 
 RTK_HD uint32_t rtk_ulen(const GraphView& g, uint32_t u) { return static_cast<uint32_t>(g.uoff[u + 1] - g.uoff[u]); }

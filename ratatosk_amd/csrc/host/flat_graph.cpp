@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <stdexcept>
@@ -21,11 +22,12 @@ GraphView FlatGraph::view() const {
     v.k = k; v.n_unitigs = n_unitigs(); v.n_kmers = n_kmers; v.ht_mask = ht.size() / 2 - 1;
     v.useq = useq.data(); v.uoff = uoff.data(); v.adj = adj.data(); v.flags = flags.data(); v.kcov = kcov.data(); v.card = card.data();
     v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data(); v.bf = bf.data(); v.bf_mask = bf.size() - 1;
+    v.cycoff = cycoff.data(); v.cyc = reinterpret_cast<const char*>(cyc.data());
     return v;
 }
 
 uint64_t FlatGraph::bytes() const {
-    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
+    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + cycoff.size() + cyc.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
 void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int /*n_threads*/) {
@@ -97,6 +99,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     std::vector<std::vector<uint32_t> > globals;
     std::map<std::vector<uint32_t>, int32_t> gdedup; // identical global sets share one id (reference: src/Graph.cpp:748-771)
     std::vector<char> seen(n, 0);
+    std::vector<std::string> cycles(n); // compact cycles of short-cycle unitigs (UnitigData.hpp:307-327): NUL-terminated strings, concatenated
     {
         std::ifstream in(rtsk.c_str(), std::ios::binary);
         if (!in.good()) throw std::runtime_error("cannot open unitig data file " + rtsk);
@@ -115,6 +118,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             seen[u] = 1;
             uint32_t f = static_cast<uint32_t>(r.shared & 0xFFull);
             if (r.shared & 0x100ull) f |= RTK_F_SHORT_CYCLE;
+            cycles[u] = r.cycles;
             if (r.kmcov >> 63) f |= RTK_F_BRANCHING;
             if (!r.ambiguity_ids.empty()) f |= RTK_F_AMBIGUITY;
             flags[u] = f;
@@ -138,6 +142,11 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     col.assign(goff[globals.size()] + 1, 0);
     for (size_t u = 0; u < n; ++u) std::copy(locals[u].begin(), locals[u].end(), col.begin() + loff[u]);
     for (size_t g = 0; g < globals.size(); ++g) std::copy(globals[g].begin(), globals[g].end(), col.begin() + goff[g]);
+    // ---- compact cycles ----
+    cycoff.assign(n + 1, 0);
+    for (size_t u = 0; u < n; ++u) cycoff[u + 1] = cycoff[u] + cycles[u].size();
+    cyc.assign(cycoff[n] / 8 + 2, 0);
+    for (size_t u = 0; u < n; ++u) if (!cycles[u].empty()) memcpy(reinterpret_cast<char*>(cyc.data()) + cycoff[u], cycles[u].data(), cycles[u].size());
     // ---- adjacency ([A3]: neighbours of the unitig end in walk direction, A,C,G,T) ----
     adj.assign(n * 8, RTK_NONE32);
     for (size_t u = 0; u < n; ++u) {

@@ -12,8 +12,8 @@
 //   * branching bit  = >1 predecessors or >1 successors            (reference: src/Graph.cpp:1997)
 //   * edge bits      = neighbour shares >= min_cov_vertices colours (reference: src/Graph.cpp:1999-2017)
 //   * global/local   = simplified form of the colour compaction of src/Graph.cpp:2874-2985
-//   * SNP-ambiguity, haplotype and short-cycle annotations are left empty (their producers
-//     `detectSNPs`/`detectShortCycles` are index-time code outside the scope).
+//   * short cycles   = restatement of detectShortCycles (src/Graph.cpp:4660-4735), so that fixRepeats has inputs
+//   * SNP-ambiguity and haplotype annotations are left empty (`detectSNPs` is index-time code outside the scope).
 #include <zlib.h>
 
 #include <algorithm>
@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
     unsigned min_count = 2;
     size_t min_cov_vertices = 2;
     double global_cov_factor = 3.0, min_color_sharing = 0.5;
+    bool detect_cycles = true;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char* n) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "rtk_build_index: missing value for %s\n", n); exit(2); } return argv[++i]; };
@@ -71,6 +72,7 @@ int main(int argc, char** argv) {
         else if (a == "-k") k = atoi(need("-k"));
         else if (a == "--min-count") min_count = static_cast<unsigned>(atoi(need("--min-count")));
         else if (a == "--global-cov-factor") global_cov_factor = atof(need("--global-cov-factor"));
+        else if (a == "--no-short-cycles") detect_cycles = false;
         else { fprintf(stderr, "rtk_build_index: unknown option %s\n", a.c_str()); return 2; }
     }
     if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=31)] [--min-count 2] [--global-cov-factor 3.0]\n"); return 2; }
@@ -209,6 +211,55 @@ int main(int argc, char** argv) {
         kmcov[u] = (cov << 31) | ((deg[0] > 1 || deg[1] > 1) ? (1ULL << 63) : 0ULL);
     }
 
+    // ---- short cycles (restatement of detectShortCycles, src/Graph.cpp:4660-4735): for every unitig U in forward direction, breadth
+    // first over paths U -> X1 .. Xm -> U whose interior spans fewer than k + 1 k-mers, following only edges carrying an edge bit and
+    // unitigs sharing >= min_cov colours with U; a cycle counts when its interior unitigs are distinct and U's colours intersected
+    // with theirs keep >= min_cov ids. Stored per unitig as the entering bases of X1..Xm (Path::getMiddleCompactedPath), NUL-terminated.
+    std::vector<std::string> cycles(n);
+    if (detect_cycles) {
+        std::vector<uint64_t> headk(n);
+        for (size_t u = 0; u < n; ++u) kmer_encode(U[u].seq.c_str(), k, headk[u]);
+        auto n_km = [&](size_t u) { return U[u].seq.size() - static_cast<size_t>(k) + 1; };
+        struct Step { size_t u; bool fw; char base; };
+        size_t n_cyc_unitigs = 0;
+        for (size_t u0 = 0; u0 < n; ++u0) {
+            std::queue<std::vector<Step> > q;
+            { std::vector<Step> p0; Step s0; s0.u = u0; s0.fw = true; s0.base = 0; p0.push_back(s0); q.push(p0); }
+            while (!q.empty()) {
+                const std::vector<Step> path = q.front(); q.pop();
+                const Step cur = path.back();
+                const std::string& cs = U[cur.u].seq;
+                uint64_t tail, head;
+                kmer_encode(cs.c_str() + cs.size() - k, k, tail); kmer_encode(cs.c_str(), k, head);
+                const uint64_t endk = cur.fw ? tail : kmer_revcomp(head, k);
+                for (uint64_t b = 0; b < 4; ++b) {
+                    const int64_t w = adj[cur.u].u[cur.fw ? 0 : 1][b];
+                    if (w < 0) continue;
+                    const uint64_t bit = cur.fw ? ((1ULL << b) << 4) : (1ULL << b);
+                    if (!(shared[cur.u] & bit)) continue;                                                       // edge seen in enough reads
+                    if (shared_count(U[cur.u].colours, U[u0].colours) < min_cov_vertices) continue;            // still read-compatible with the start
+                    const uint64_t y = ((endk << 2) | b) & mask;
+                    const bool w_fw = (y == headk[static_cast<size_t>(w)]);
+                    if (static_cast<size_t>(w) == u0 && w_fw) { // came back to the start unitig, same strand
+                        bool distinct = true;
+                        for (size_t i = 1; i < path.size() && distinct; ++i) for (size_t j = i + 1; j < path.size() && distinct; ++j) if (path[i].u == path[j].u && path[i].fw == path[j].fw) distinct = false;
+                        if (!distinct) continue;
+                        std::vector<uint32_t> pid = U[u0].colours;
+                        for (size_t i = 1; i < path.size() && pid.size() >= min_cov_vertices; ++i) { std::vector<uint32_t> t; std::set_intersection(pid.begin(), pid.end(), U[path[i].u].colours.begin(), U[path[i].u].colours.end(), std::back_inserter(t)); pid.swap(t); }
+                        if (pid.size() >= min_cov_vertices) { std::string c; for (size_t i = 1; i < path.size(); ++i) c.push_back(path[i].base); cycles[u0] += c; cycles[u0].push_back('\0'); }
+                    } else {
+                        size_t interior = 0; for (size_t i = 1; i < path.size(); ++i) interior += n_km(path[i].u);
+                        if (interior + static_cast<size_t>(k) - 1 < 2 * static_cast<size_t>(k)) { // path.length() - um_start.len < 2k
+                            std::vector<Step> nx = path; Step st; st.u = static_cast<size_t>(w); st.fw = w_fw; st.base = "ACGT"[b]; nx.push_back(st); q.push(nx);
+                        }
+                    }
+                }
+            }
+            if (!cycles[u0].empty()) { shared[u0] |= 0x100ULL; ++n_cyc_unitigs; }
+        }
+        fprintf(stderr, "rtk_build_index: %zu unitigs in short cycles\n", n_cyc_unitigs);
+    }
+
     // ---- global / local colour split (simplified restatement of src/Graph.cpp:2874-2985) ----
     std::vector<std::vector<uint32_t> > global_ids(n), local_ids(n);
     {
@@ -267,7 +318,7 @@ int main(int argc, char** argv) {
             RtskRecord r;
             disk_kmer_from_string(U[u].seq.c_str(), k, r.head);
             r.kmcov = kmcov[u]; r.shared = shared[u];
-            r.global_ids = global_ids[u]; r.local_ids = local_ids[u];
+            r.global_ids = global_ids[u]; r.local_ids = local_ids[u]; r.cycles = cycles[u];
             rtsk_write_record(out, r);
         }
     }

@@ -6,6 +6,7 @@
 //         PREFIX.lr.fq    long reads, 4-line FASTQ
 // There is no counterpart in the reference (it ships no data and no generator); everything is
 // derived from one 64-bit seed so every box regenerates identical inputs.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,7 @@ struct Opt {
     double lr_err = 0.10;
     std::string lr_profile = "uniform"; // uniform: sub:ins:del = 4:3:3 ; ont: 35:25:40, log-normal length, homopolymer-biased indels
     double repeat_frac = 0.0;  // fraction of the reference made of two-copy repeats (config 5)
+    size_t tandem = 0;         // number of tandem-repeat blocks (unit 7..45 bp, spanning > 2k): short cycles in the graph
 };
 
 static double gauss(Rng& r) {
@@ -83,6 +85,7 @@ int main(int argc, char** argv) {
         else if (a == "--lr-err") o.lr_err = atof(need("--lr-err"));
         else if (a == "--lr-profile") o.lr_profile = need("--lr-profile");
         else if (a == "--repeat-frac") o.repeat_frac = atof(need("--repeat-frac"));
+        else if (a == "--tandem") o.tandem = strtoull(need("--tandem"), nullptr, 10);
         else { fprintf(stderr, "rtk_simulate: unknown option %s\n", a.c_str()); return 2; }
     }
     Rng rng(o.seed);
@@ -98,10 +101,20 @@ int main(int argc, char** argv) {
             if (a + rep_len <= b || b + rep_len <= a) hap0.replace(b, rep_len, hap0, a, rep_len);
         }
     }
+    std::vector<std::pair<size_t, size_t> > tandems; // (position, unit length)
+    for (size_t t = 0; t < o.tandem && o.ref_len > 2000; ++t) {
+        const size_t unit = 7 + rng.below(39), copies = 3 + (62 + unit - 1) / unit, span = unit * copies;
+        const size_t pos = 500 + rng.below(o.ref_len - span - 1000);
+        for (size_t i = unit; i < span; ++i) hap0[pos + i] = hap0[pos + i - unit];
+        tandems.push_back(std::make_pair(pos, unit));
+    }
     std::vector<std::string> haps(1, hap0);
     if (o.het > 0.0) {
         std::string h1 = hap0;
         for (size_t i = 0; i < h1.size(); ++i) if (rng.uniform() < o.het) { char c; do { c = bits2base(static_cast<int>(rng.below(4))); } while (c == h1[i]); h1[i] = c; }
+        // the second haplotype loses one unit of every other tandem block: reads and graph paths then disagree in copy number
+        std::vector<std::pair<size_t, size_t> > td = tandems; std::sort(td.begin(), td.end());
+        for (size_t t = td.size(); t-- > 0;) if (t % 2 == 0) h1.erase(td[t].first, td[t].second);
         haps.push_back(h1);
     }
     {

@@ -64,6 +64,14 @@ def ds_medium(tmp_path_factory):
                                       "--lr-n", 160, "--lr-len", 8000, "--lr-profile", "ont", "--lr-err", 0.07], ["--global-cov-factor", 1.5])
 
 
+@pytest.fixture(scope="session")
+def ds_tandem(tmp_path_factory):
+    """Tandem repeats (unit 7..45 bp spanning > 2k, one haplotype a unit short): unitigs on short cycles, fixRepeats has work."""
+    d = tmp_path_factory.mktemp("ds_tandem")
+    return make_dataset(d, "tandem", ["--seed", 21, "--ref-len", 60000, "--het", 0.003, "--tandem", 30, "--sr-cov", 40, "--sr-err", 0.005,
+                                      "--lr-n", 40, "--lr-len", 3000, "--lr-profile", "ont", "--lr-err", 0.07])
+
+
 def golden_rows():
     path = os.path.join(ROOT, "tests", "golden", "edlib_golden.tsv")
     rows = []

@@ -56,3 +56,7 @@ def test_gpu_overlapped_stages_give_the_same_records(ds_medium):
     for p, b in zip(parts, batches):
         want, _ = og.correct_batch([r[1] for r in p], [r[2] for r in p], threads=os.cpu_count() or 4)
         assert b.fetch() == want
+
+
+def test_gpu_correct_short_cycles(ds_tandem):
+    _check(ds_tandem, 40, None)

@@ -59,19 +59,22 @@ def test_sim_correct_k25(ds_k25):
 
 
 def test_annotated_index_is_refused_then_stripped(ds_clean, tmp_path):
-    """An index whose unitig data carries a short-cycle flag (what the reference's `index` step writes, src/Graph.cpp:4660) is refused
-    loudly by the run entry points; rtk_graph_strip_annotations makes it equal to the unannotated index."""
+    """An index whose unitig data carries SNP-ambiguity annotations (what the reference's `index` step writes unless -F,
+    src/Graph.cpp:484) is refused loudly by the run entry points; rtk_graph_strip_annotations makes it equal to the unannotated index."""
     import ctypes as C
     import shutil
+    import struct
     import pytest
     fa, rt = ds_clean + ".index.k31.fasta.gz", ds_clean + ".index.k31.rtsk"
     rt2 = str(tmp_path / "annot.rtsk")
     shutil.copy(rt, rt2)
-    with open(rt2, "r+b") as f:  # first record: 16-byte head k-mer, u64 coverage word, u64 shared word (bit 8 = short cycle)
-        f.seek(16 + 8 + 1)
-        b = f.read(1)
-        f.seek(16 + 8 + 1)
-        f.write(bytes([b[0] | 0x01]))
+    with open(rt2, "r+b") as f:  # first record: 16-byte head k-mer, u64 coverage, u64 shared, then the PairID streams global, local, ambiguity, ...
+        off = 32
+        for _ in range(2):  # skip the global and the local colour sets
+            f.seek(off); (w,) = struct.unpack("<Q", f.read(8)); off += 8 + ((w >> 3) if (w & 7) == 3 else 0)
+        f.seek(off); (w,) = struct.unpack("<Q", f.read(8))
+        assert w == 1  # empty ambiguity set
+        f.seek(off); f.write(struct.pack("<Q", ((1 << 5) << 3) | 1))  # bit-vector form holding id 5
     reads = op.read_fastq(ds_clean + ".lr.fq")[:3]
     seqs, quals = [r[1] for r in reads], [r[2] for r in reads]
     pg = api.Graph(fa, rt2, 31, device=0, lib_path=SIM_LIB)
@@ -93,3 +96,9 @@ def test_annotated_index_is_refused_then_stripped(ds_clean, tmp_path):
     got = [(C.string_at(os_[i], ol[i]).decode(), C.string_at(oq[i], ol[i]).decode()) for i in range(n)]
     assert got == want
     L.rtk_graph_free(h)
+
+
+def test_sim_correct_short_cycles(ds_tandem):
+    """Index with short-cycle annotations (detectShortCycles restated in rtk_build_index): fixRepeats (src/GraphTraversal.cpp:1149-1334)
+    on the device equals the oracle's."""
+    _check(ds_tandem, 40, SIM_LIB)
