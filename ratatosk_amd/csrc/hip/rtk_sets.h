@@ -102,10 +102,41 @@ RTK_FN uint32_t rtk_set_union(const uint32_t* a_, uint32_t na_, const uint32_t* 
 
 // In-place bitonic sort of n (key, value) pairs by (key, value) ascending. Arrays must have room for the next power of two
 // of n (padded with all-ones keys).
+#ifndef RTK_SIM
+// the same network run in LDS for up to RTK_LDS_SORT_CAP pairs, in the 8 KB buffer of the set searches (one LDS allocation per wave: the
+// region kernel keeps 16 waves per CU)
+#define RTK_LDS_SORT_CAP (RTK_LDS_SET_CAP / 4)
+RTK_DEV uint64_t* rtk_lds_sort_buf() { return reinterpret_cast<uint64_t*>(rtk_lds_set_buf()); }
+#endif
+
 RTK_FN void rtk_sort_pairs(uint64_t* key_, uint64_t* val_, uint32_t n_) {
     uint64_t* key = rtk_u(key_); uint64_t* val = rtk_u(val_); uint32_t n = rtk_u(n_);
     if (n < 2) return;
     uint32_t p = 1; while (p < n) p <<= 1;
+#ifndef RTK_SIM
+    if (p <= RTK_LDS_SORT_CAP) {
+        uint64_t* const lk = rtk_lds_sort_buf(); uint64_t* const lv = lk + RTK_LDS_SORT_CAP;
+        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) { lk[i] = i < n ? key[i] : ~0ull; lv[i] = i < n ? val[i] : ~0ull; }
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= p; kk <<= 1) {
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const uint64_t ki = lk[i], kl = lk[l], vi = lv[i], vl = lv[l];
+                        const bool gt = (ki > kl) || (ki == kl && vi > vl);
+                        const bool up = ((i & kk) == 0);
+                        if (gt == up) { lk[i] = kl; lk[l] = ki; lv[i] = vl; lv[l] = vi; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) { key[i] = lk[i]; val[i] = lv[i]; }
+        rtk_sync();
+        return;
+    }
+#endif
     for (uint32_t i = n + static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) { key[i] = ~0ull; val[i] = ~0ull; }
     rtk_sync();
     for (uint32_t kk = 2; kk <= p; kk <<= 1) {
