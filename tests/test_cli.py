@@ -55,3 +55,30 @@ def test_cli_two_workers_many_tickets(ds_medium, tmp_path):
     want, _ = op.Graph(fa, rt, 31).correct_batch([x[1] for x in reads], [x[2] for x in reads], threads=os.cpu_count() or 4)
     assert [g[0] for g in got] == [x[0] for x in reads]
     assert [(g[1], g[2]) for g in got] == want
+
+
+@pytest.mark.gpu
+def test_cli_fasta_input_through_a_list_file(ds_small, tmp_path):
+    """Inputs may be FASTA (no qualities; pass 1 writes synthetic ones anyway, src/Correction.cpp:184-185) and may be given as a text
+    file listing one path per line (src/Common.cpp:412-446), here two files whose reads must come out concatenated in order."""
+    fa, rt = ds_small + ".index.k31.fasta.gz", ds_small + ".index.k31.rtsk"
+    reads = op.read_fastq(ds_small + ".lr.fq")
+    f1, f2, lst = str(tmp_path / "a.fa"), str(tmp_path / "b.fasta"), str(tmp_path / "inputs.txt")
+    half = len(reads) // 2
+    with open(f1, "w") as f:
+        for n, s, _ in reads[:half]:
+            f.write(">%s some description\n" % n)
+            for i in range(0, len(s), 70):  # multi-line FASTA
+                f.write(s[i:i + 70] + "\n")
+    with open(f2, "w") as f:
+        for n, s, _ in reads[half:]:
+            f.write(">%s\n%s\n" % (n, s.lower()))
+    with open(lst, "w") as f:
+        f.write(f1 + "\n" + f2 + "\n")
+    out = str(tmp_path / "out")
+    r = subprocess.run([EXE, "correct", "-1", "-c", "1", "-B", "9000", "-g", fa, "-d", rt, "-l", lst, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = op.read_fastq(out + ".2.fastq")
+    want, _ = op.Graph(fa, rt, 31).correct_batch([x[1] for x in reads], None, threads=4)
+    assert [g[0] for g in got] == [x[0] for x in reads]
+    assert [(g[1], g[2]) for g in got] == want
