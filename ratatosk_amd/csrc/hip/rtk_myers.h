@@ -320,10 +320,11 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
             }                                                                                                                                \
         }                                                                                                                                    \
     }
+    int nxt_t = 'A'; // target characters of the NEXT 64 columns: requested one block ahead, so their latency hides behind 64 steps
+    if (lane < n) nxt_t = static_cast<int>(static_cast<unsigned char>(tp[lane]));
     for (int c0 = 0; c0 < steps; c0 += 64) {
-        const int cj = c0 + lane;
-        int my_t = 'A';
-        if (cj < n) my_t = static_cast<int>(static_cast<unsigned char>(tp[cj]));
+        int my_t = nxt_t;
+        { const int cn = c0 + 64 + lane; nxt_t = 'A'; if (cn < n) nxt_t = static_cast<int>(static_cast<unsigned char>(tp[cn])); }
         if (rtk_ballot(!(my_t == 'A' || my_t == 'C' || my_t == 'G' || my_t == 'T')) != 0ull) { st.plain = false; return st; }
         asm volatile("" : "+v"(my_t));
         const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
