@@ -418,17 +418,18 @@ RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl_, const char* ref_, u
 
 // ------------------------------------------------------------------------------------------------ colour memo (src/GraphTraversal.cpp:485-487)
 RTK_FN bool rtk_colour_ok(const RCtx& c, uint32_t u_, const uint32_t* all_pids_, uint32_t n_all_) {
-    RegionScratch& s = *rtk_u(c.sc); const uint32_t u = rtk_u(u_), n_all = rtk_u(n_all_); const uint32_t* all_pids = rtk_u(all_pids_);
+    RegionScratch& s = *rtk_u(c.sc); const unsigned long long tk0 = rtk_clock(); const uint32_t u = rtk_u(u_), n_all = rtk_u(n_all_); const uint32_t* all_pids = rtk_u(all_pids_);
     const uint32_t mn = rtk_ld(&s.memo_n); const uint32_t* mu = rtk_ld(&s.memo_u); uint8_t* mvv = rtk_ld(&s.memo_v);
     for (uint32_t i0 = 0; i0 < mn; i0 += RTK_WAVE) { // 64 memo entries per step
         const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
         const uint64_t hit = rtk_ballot(i < mn && mu[i] == u);
-        if (hit) return rtk_ld(mvv + i0 + static_cast<uint32_t>(rtk_ffs(hit) - 1)) != 0;
+        if (hit) { s.cnt[15] += rtk_clock() - tk0; return rtk_ld(mvv + i0 + static_cast<uint32_t>(rtk_ffs(hit) - 1)) != 0; }
     }
     const uint32_t mcv = static_cast<uint32_t>(rtk_u(c.o.min_cov_vertices));
     const bool ok = (n_all == 0) || (rtk_u(rtk_shared_with_set(c.g, u, all_pids, n_all, mcv)) >= mcv);
     s.cnt[1] += rtk_ld(rtk_u(c.g.card) + u) + n_all;
     if (mn < rtk_ld(&s.memo_cap)) { const_cast<uint32_t*>(mu)[mn] = u; mvv[mn] = ok ? 1 : 0; s.memo_n = mn + 1; rtk_sync(); }
+    s.cnt[15] += rtk_clock() - tk0;
     return ok;
 }
 
@@ -464,6 +465,7 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
     WPath& w = s.wp[2];
     const bool has_end = !rtk_um_is_empty(um_e);
     unsigned long long n_exp = 0;
+    const unsigned long long td0 = rtk_clock(); const unsigned long long my0 = s.cnt[9];
     while (sp > 0 && !rtk_failed(s)) {
         --sp;
         const uint64_t hp = rtk_ld(stk + 2 * sp); const uint32_t lvl = static_cast<uint32_t>(rtk_ld(stk + 2 * sp + 1));
@@ -518,6 +520,7 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
         }
     }
     s.cnt[0] += n_exp;
+    s.cnt[14] += (rtk_clock() - td0) - (s.cnt[9] - my0); // DFS bookkeeping: loop time minus the alignments inside it
     // qualities (:556-584): re-commit every surviving path with its quality string
     for (int which = 0; which < 2 && !rtk_failed(s); ++which) {
         uint64_t* L = which ? NT : T; const uint32_t nL = which ? n_nt : n_t;
