@@ -6,9 +6,18 @@ import bench
 from ratatosk_amd import api
 from oracle import oracle_py as op
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ref_len = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000     # 60000000 + het 0.001 = configs[2]'s graph
+het = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 api.load_library(None)
 wd = tempfile.mkdtemp(prefix="rtk_pv_")
-pre = bench.make_dataset(wd, 5_000_000, 150_000_000)
+if het > 0.0:
+    import subprocess
+    bin_dir = os.path.join(ROOT, "ratatosk_amd", "bin"); pre = os.path.join(wd, "c")
+    subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "3", "--ref-len", str(ref_len), "--het", str(het), "--sr-cov", "30", "--sr-err", "0.005",
+                           "--lr-cov", "%.3f" % ((mb + 20) * 1e6 / ref_len), "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07"], stderr=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(bin_dir, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre], stderr=subprocess.DEVNULL)
+else:
+    pre = bench.make_dataset(wd, ref_len, 150_000_000)
 fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
 g, og = api.Graph(fa, rt, 31, device=0), op.Graph(fa, rt, 31)
 seqs, quals = bench.read_long_reads(pre + ".lr.fq", 150_000_000)
