@@ -379,24 +379,28 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
         // A window in flight is remembered by its three scalar words; the k-mers of the few variants that pass the filter are spelled
         // again when their slot arrives, so that only the slot contents wait in vector registers.
         struct Win { uint64_t w_b, w_k1; uint32_t w_ck, w_ck1; };
-        const uint64_t* const ht = g.ht; const uint64_t ht_mask = g.ht_mask; const uint64_t* const bf = g.bf; const uint64_t bf_mask = g.bf_mask;
+        const uint64_t* const ht = g.ht; const uint64_t ht_mask = g.ht_mask; const uint64_t* const bf = g.bf; const uint64_t bf_mask = g.bf_mask; const uint64_t* const bf1 = g.bf1; const uint64_t bf1_mask = g.bf1_mask;
         auto stage_probe = [&](Win& wn, uint32_t& pass, uint64_t* skey, uint64_t* sval) { // takes the next candidate off `bal`
             const int sl = rtk_ffs(bal) - 1;
             bal &= bal - 1ull;
             wn.w_k1 = rtk_u(rtk_shfl(c_k1, sl)); wn.w_ck = rtk_u(rtk_shfl(ck, sl)); wn.w_ck1 = rtk_u(rtk_shfl(ck1, sl));
             wn.w_b = tile * 64 + static_cast<uint64_t>(sl);
-            uint64_t hh[4], word[4]; bool valid[4]; uint32_t probes = 0;
+            uint64_t hh[4], word[4]; bool valid[4], valid1[4]; uint32_t probes = 0;
             for (int rr = 0; rr < 4; ++rr) {
                 uint64_t code, can; uint32_t q;
                 valid[rr] = rtk_variant_code(rtk_lane() + 64 * rr, k, wn.w_k1, wn.w_ck, wn.w_ck1, &code);
                 rtk_kmer_prepare(code, k, &can, &hh[rr], &q);
                 probes += valid[rr] ? 1u : 0u;
             }
-            for (int rr = 0; rr < 4; ++rr) word[rr] = valid[rr] ? bf[(hh[rr] >> 32) & bf_mask] : 0ull;
+            // first-level bit (L2 resident), then the filter word only for the variants whose bit is set
+            uint64_t w1[4];
+            for (int rr = 0; rr < 4; ++rr) w1[rr] = valid[rr] ? bf1[((hh[rr] >> 12) & bf1_mask) >> 6] : 0ull;
+            for (int rr = 0; rr < 4; ++rr) valid1[rr] = valid[rr] && rtk_filter1_pass(w1[rr], hh[rr], bf1_mask);
+            for (int rr = 0; rr < 4; ++rr) word[rr] = valid1[rr] ? bf[(hh[rr] >> 32) & bf_mask] : 0ull;
             *acc_probes += probes; // per-lane tallies, reduced once per wave at kernel end (a device-wide atomic per window saturates one L2 word)
             pass = 0;
             for (int rr = 0; rr < 4; ++rr) {
-                const bool ps = valid[rr] && rtk_filter_pass(word[rr], hh[rr]);
+                const bool ps = valid1[rr] && rtk_filter_pass(word[rr], hh[rr]);
                 skey[rr] = RTK_EMPTY_KEY; sval[rr] = 0;
                 if (ps) { pass |= 1u << rr; const uint64_t* sp = ht + 2 * (hh[rr] & ht_mask); skey[rr] = sp[0]; sval[rr] = sp[1]; }
             }

@@ -85,6 +85,8 @@ struct GraphView {
     U<const uint64_t*> ht;        // [2*slots] {canonical k-mer, unitig<<32 | dist<<1 | stored_is_canonical}, empty key = RTK_EMPTY_KEY
     U<const uint64_t*> bf;        // [bf_mask+1] blocked Bloom filter over the canonical k-mers (2 bits of one 64-bit word per k-mer)
     U<uint64_t> bf_mask;
+    U<const uint64_t*> bf1;       // cache-sized first-level filter in front of `bf`: one bit per k-mer in a bit array of bf1_mask + 1 bits (a single all-ones word when disabled)
+    U<uint64_t> bf1_mask;
     U<const uint64_t*> cycoff;    // [n+1] compact cycles of unitig u = cyc[cycoff[u] .. cycoff[u+1]) (NUL-terminated strings of successor bases)
     U<const char*> cyc;
 };
@@ -133,6 +135,10 @@ RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probe
     const uint64_t rc = rtk_revcomp(fw, g.k);
     const uint64_t can = fw < rc ? fw : rc;
     const uint64_t hh = rtk_hash64(can);
+    { // first level: one bit in an array small enough to stay in L2
+        const uint64_t b1 = (hh >> 12) & g.bf1_mask;
+        if (!((g.bf1[b1 >> 6] >> (b1 & 63ull)) & 1ull)) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; }
+    }
     { // pre-filter: absent k-mers (the bulk of the 1-edit variants) stop here after one 8-byte read
         const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63));
         if ((g.bf[(hh >> 32) & g.bf_mask] & bits) != bits) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; }
@@ -159,6 +165,7 @@ RTK_HD void rtk_kmer_prepare(uint64_t fw, int k, uint64_t* can, uint64_t* hh, ui
     const uint64_t rc = rtk_revcomp(fw, k);
     *can = fw < rc ? fw : rc; *query_is_can = (fw <= rc) ? 1u : 0u; *hh = rtk_hash64(*can);
 }
+RTK_HD bool rtk_filter1_pass(uint64_t word1, uint64_t hh, uint64_t bf1_mask) { const uint64_t b1 = (hh >> 12) & bf1_mask; return (word1 >> (b1 & 63ull)) & 1ull; }
 RTK_HD bool rtk_filter_pass(uint64_t word, uint64_t hh) { const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)); return (word & bits) == bits; }
 RTK_HD uint64_t rtk_table_lookup(const GraphView& g, uint64_t can, uint64_t hh, uint32_t query_is_can, uint32_t* n_slots) {
     uint64_t i = hh & g.ht_mask; uint32_t np = 0;

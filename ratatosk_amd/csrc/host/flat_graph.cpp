@@ -22,12 +22,13 @@ GraphView FlatGraph::view() const {
     v.k = k; v.n_unitigs = n_unitigs(); v.n_kmers = n_kmers; v.ht_mask = ht.size() / 2 - 1;
     v.useq = useq.data(); v.uoff = uoff.data(); v.adj = adj.data(); v.flags = flags.data(); v.kcov = kcov.data(); v.card = card.data();
     v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data(); v.bf = bf.data(); v.bf_mask = bf.size() - 1;
+    v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1;
     v.cycoff = cycoff.data(); v.cyc = reinterpret_cast<const char*>(cyc.data());
     return v;
 }
 
 uint64_t FlatGraph::bytes() const {
-    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + cycoff.size() + cyc.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
+    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
 void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int /*n_threads*/) {
@@ -70,11 +71,16 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     const uint64_t hmask = slots - 1, kmask = kmer_mask(k);
     // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer.
     // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
-    // Density: 4 k-mers per word (>= 16 bits per key, 1.3 % false positives) for graphs whose filter lives in HBM anyway; small graphs
-    // take 8 per word (>= 8 bits per key, 4 %): half the footprint, more of it stays in the 8 x 4 MB of L2 (measured 17.4 vs 19.5 ms
-    // per 32 Mb on the 5 Mb configuration, 16 per word 18.9 ms).
-    uint64_t bf_words = 16; { const char* e = getenv("RTK_BF_KEYS_PER_WORD"); const uint64_t kpw = e ? strtoull(e, nullptr, 10) : (n_kmers <= (1ull << 24) ? 8 : 4); while (bf_words * kpw < n_kmers) bf_words <<= 1; }
+    // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.
+    uint64_t bf_words = 16; { const char* e = getenv("RTK_BF_KEYS_PER_WORD"); const uint64_t kpw = e ? strtoull(e, nullptr, 10) : 4; while (bf_words * kpw < n_kmers) bf_words <<= 1; }
     bf.assign(bf_words, 0);
+    // First level in front of it: ONE bit per k-mer in at most 2 MB (>= 3 bits per key, ~27 % false positives), meant to stay resident in
+    // the 4 MB of L2 next to each XCD so that most absent k-mers never cross the fabric (k_inexact 18.3 -> 12.8 ms per 32 Mb on the 5 Mb
+    // configuration; 1 MB / 4 MB arrays measured 14.8 / 13.6 ms). Graphs too large for that get a single all-ones word (every query passes).
+    { uint64_t bits = 64; const char* e0 = getenv("RTK_BF1_LOG2BITS"); const uint64_t cap_bits = 1ull << (e0 ? atoi(e0) : 24); while (bits < 3 * n_kmers && bits < cap_bits) bits <<= 1;
+      if (e0) { bits = cap_bits; }
+      const char* e1 = getenv("RTK_BF1_OFF");
+      if (3 * n_kmers > 2 * cap_bits || (e1 && e1[0] == '1')) bf1.assign(1, ~0ull); else bf1.assign(bits / 64, 0); }
     for (size_t u = 0; u < n; ++u) {
         const std::string& s = seqs[u];
         uint64_t fw = 0;
@@ -88,11 +94,12 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                 h = (h + 1) & hmask;
             }
             ht[2 * h] = can;
-            { const uint64_t hh = rtk_hash64(can); bf[(hh >> 32) & (bf_words - 1)] |= (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)); }
+            { const uint64_t hh = rtk_hash64(can); bf[(hh >> 32) & (bf_words - 1)] |= (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63));
+              const uint64_t b1 = (hh >> 12) & (bf1.size() * 64 - 1); bf1[b1 >> 6] |= 1ull << (b1 & 63ull); }
             ht[2 * h + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
         }
     }
-    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; v.bf = bf.data(); v.bf_mask = bf_words - 1; return v; }();
+    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; return v; }();
     // ---- unitig data (.rtsk) ----
     flags.assign(n, 0); kcov.assign(n, 0); card.assign(n, 0); gid.assign(n, -1); loff.assign(n + 1, 0);
     std::vector<std::vector<uint32_t> > locals(n);
