@@ -1,6 +1,7 @@
 // libratatosk_hip.so: HIP kernels for gfx950 + the C ABI of include/ratatosk_hip.h.
 // (Compiled a second time with -DRTK_SIM by tests/hostsim into a developer simulator; see rtk_wave.h.)
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -50,6 +51,7 @@ struct rtk_graph {
     // device buffers of finished batches, by size: a ticket's ~25 buffers are taken from here instead of hipMalloc / hipFree, which
     // cost milliseconds each and (hipFree) wait for the whole device, i.e. for the other batch's kernels
     std::mutex pool_lock; std::multimap<uint64_t, void*> pool; uint64_t pool_bytes = 0;
+    std::atomic<int> refs{1}; // the caller's handle + one per live batch
     void* pool_take(uint64_t bytes, uint64_t* got) {
         bytes = (bytes + 4095) / 4096 * 4096;
         { std::lock_guard<std::mutex> h(pool_lock);
@@ -178,12 +180,15 @@ extern "C" long long rtk_graph_strip_annotations(rtk_graph* g) {
     return n;
 }
 
-extern "C" void rtk_graph_free(rtk_graph* g) {
-    if (!g) return;
+// A graph is shared by its batches (buffer pool, scratch slots): it is destroyed when the caller has released it AND its last batch
+// is gone, whichever comes last (callers with garbage collectors free the two in any order).
+static void graph_release(rtk_graph* g) {
+    if (g->refs.fetch_sub(1) != 1) return;
     if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
     rtk_dfree(g->scratch[0]); rtk_dfree(g->scratch[1]); g->pool_clear();
     delete g;
 }
+extern "C" void rtk_graph_free(rtk_graph* g) { if (g) graph_release(g); }
 
 extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
     if (!o) return rtk_fail(RTK_ERR_ARG, "rtk_opts_default: null");
