@@ -74,13 +74,13 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.
     uint64_t bf_words = 16; { const char* e = getenv("RTK_BF_KEYS_PER_WORD"); const uint64_t kpw = e ? strtoull(e, nullptr, 10) : 4; while (bf_words * kpw < n_kmers) bf_words <<= 1; }
     bf.assign(bf_words, 0);
-    // First level in front of it: ONE bit per k-mer in at most 2 MB (>= 3 bits per key, ~27 % false positives), meant to stay resident in
+    // First level in front of it: ONE bit per k-mer in 2 MB (>= 3 bits per key, ~27 % false positives; 4 MB for graphs of 5 to 33 M k-mers), meant to stay resident in
     // the 4 MB of L2 next to each XCD so that most absent k-mers never cross the fabric (k_inexact 18.3 -> 12.8 ms per 32 Mb on the 5 Mb
     // configuration; 1 MB / 4 MB arrays measured 14.8 / 13.6 ms). Graphs too large for that get a single all-ones word (every query passes).
-    { uint64_t bits = 64; const char* e0 = getenv("RTK_BF1_LOG2BITS"); const uint64_t cap_bits = 1ull << (e0 ? atoi(e0) : 24); while (bits < 3 * n_kmers && bits < cap_bits) bits <<= 1;
+    { uint64_t bits = 64; const char* e0 = getenv("RTK_BF1_LOG2BITS"); const uint64_t cap_bits = 1ull << (e0 ? atoi(e0) : (3 * n_kmers > (1ull << 24) ? 25 : 24)); while (bits < 3 * n_kmers && bits < cap_bits) bits <<= 1;
       if (e0) { bits = cap_bits; }
       const char* e1 = getenv("RTK_BF1_OFF");
-      if (3 * n_kmers > 2 * cap_bits || (e1 && e1[0] == '1')) bf1.assign(1, ~0ull); else bf1.assign(bits / 64, 0); }
+      if (n_kmers > cap_bits || (e1 && e1[0] == '1')) bf1.assign(1, ~0ull); else bf1.assign(bits / 64, 0); } // below one bit per key the array stops paying for itself
     for (size_t u = 0; u < n; ++u) {
         const std::string& s = seqs[u];
         uint64_t fw = 0;
