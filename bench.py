@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--serial", action="store_true", help="run the two stages of every step back to back (no overlap between steps)")
     ap.add_argument("--ref-len", type=int, default=5_000_000)
-    ap.add_argument("--batch-bases", type=int, default=32_000_000, help="long-read bases per step (per GPU)")
+    ap.add_argument("--batch-bases", type=int, default=64_000_000, help="long-read bases per step (per GPU)")
     ap.add_argument("--cpu-sample-bases", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=None)

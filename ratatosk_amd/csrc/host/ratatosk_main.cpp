@@ -24,7 +24,7 @@ struct Opt {
     std::vector<std::string> in_long;
     std::string out, graph, udata;
     int cores = 1, k1 = 31, max_qual = 40;
-    size_t insert_sz = 500, w1 = 1000, batch_bases = 32u << 20;
+    size_t insert_sz = 500, w1 = 1000, batch_bases = 64u << 20;
     bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false;
 };
 
