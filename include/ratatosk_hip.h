@@ -44,6 +44,7 @@ typedef struct rtk_opts {
     double min_score;               /* 0.0 with one correction round, src/Ratatosk.cpp:847 */
     int32_t max_qual;               /* -Q, 40   */
     int32_t out_qual;               /* 1        */
+    double min_confidence_snp_corr; /* -m, 0.9 (src/Common.hpp:147): below this confidence a SNP-annotated base is re-decided against the read */
 } rtk_opts;
 
 typedef struct rtk_graph_info {

@@ -19,12 +19,13 @@ struct orc_opts { // mirrors the pass-1 fields of Correct_Opt (reference: src/Co
     uint64_t insert_sz, min_cov_vertices, max_len_weak_region1, max_km_cov;
     double weak_region_len_factor, large_k_factor, min_score;
     int32_t max_qual, out_qual;
+    double min_confidence_snp_corr;
 };
 
 static Opt toOpt(const orc_opts* o) {
     Opt r;
     if (o) { r.insert_sz = o->insert_sz; r.min_cov_vertices = o->min_cov_vertices; r.max_len_weak_region1 = o->max_len_weak_region1; r.max_km_cov = o->max_km_cov;
-             r.weak_region_len_factor = o->weak_region_len_factor; r.large_k_factor = o->large_k_factor; r.min_score = o->min_score; r.max_qual = o->max_qual; r.out_qual = o->out_qual; }
+             r.weak_region_len_factor = o->weak_region_len_factor; r.large_k_factor = o->large_k_factor; r.min_score = o->min_score; r.max_qual = o->max_qual; r.out_qual = o->out_qual; r.min_confidence_snp_corr = o->min_confidence_snp_corr; }
     return r;
 }
 

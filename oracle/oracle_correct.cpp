@@ -151,13 +151,139 @@ std::string pathToString(const Ctx& c, const Path& p) { // Path.hpp:449-485
     return s;
 }
 
-void requireUnannotated(const Ctx& c, const Path& p) { // getAmbiguityVector / fixAmbiguity are identity without SNP annotations
-    for (size_t i = 0; i < p.ums.size(); ++i) {
-        if (c.g.info[p.ums[i].unitig].has_ambiguity) {
-            fprintf(stderr, "oracle: unitig %d carries SNP annotations; fixAmbiguity is not restated (SURVEY.md 8f-3)\n", p.ums[i].unitig);
-            abort();
+typedef std::vector<std::pair<size_t, char> > AmbVec;
+
+inline char iupacUnion(char a, char b) { return iupacChar(static_cast<uint8_t>(iupacIndex(a) | iupacIndex(b))); } // getAmbiguityRev + getAmbiguity (src/Common.hpp:351-400)
+inline bool iupacOverlap(char a, char b) { return (iupacIndex(a) & iupacIndex(b)) != 0; }
+
+// src/GraphTraversal.cpp:966-1036: SNP annotations of the path's unitigs in path-string coordinates; annotations in the k-1
+// characters two consecutive unitigs share are merged (union of the alleles)
+AmbVec getAmbiguityVector(const Ctx& c, const Path& p) {
+    AmbVec v_amb;
+    const size_t k = c.k;
+    size_t prev_l = 0, pos_prev_l = 0;
+    for (size_t x = 0; x < p.ums.size(); ++x) {
+        const UM& um = p.ums[x];
+        const AmbVec v_amb_um = c.g.ambiguityChars(um);
+        AmbVec v_amb_tmp;
+        size_t it_prev = pos_prev_l, it_curr = 0;
+        while (it_prev != v_amb.size() && it_curr != v_amb_um.size() && v_amb_um[it_curr].first < k - 1) {
+            const size_t it_curr_pos = v_amb_um[it_curr].first + prev_l;
+            if (v_amb[it_prev].first < it_curr_pos) { v_amb_tmp.push_back(v_amb[it_prev]); ++it_prev; }
+            else if (v_amb[it_prev].first > it_curr_pos) { v_amb_tmp.push_back(std::make_pair(it_curr_pos, v_amb_um[it_curr].second)); ++it_curr; }
+            else { v_amb_tmp.push_back(std::make_pair(v_amb[it_prev].first, iupacUnion(v_amb[it_prev].second, v_amb_um[it_curr].second))); ++it_prev; ++it_curr; }
+        }
+        for (; it_prev != v_amb.size(); ++it_prev) v_amb_tmp.push_back(v_amb[it_prev]);
+        for (; it_curr != v_amb_um.size(); ++it_curr) v_amb_tmp.push_back(std::make_pair(v_amb_um[it_curr].first + prev_l, v_amb_um[it_curr].second));
+        prev_l += um.len;
+        v_amb.erase(v_amb.begin() + static_cast<long>(pos_prev_l), v_amb.end());
+        for (size_t i = 0; i < v_amb_tmp.size(); ++i) { v_amb.push_back(v_amb_tmp[i]); pos_prev_l += static_cast<size_t>(v_amb.back().first < prev_l); }
+    }
+    return v_amb;
+}
+
+// [A6] positions of the all-ACGT windows of s
+std::vector<size_t> kmerWindows(const std::string& s, size_t k) {
+    std::vector<size_t> v; size_t run = 0;
+    for (size_t i = 0; i < s.length(); ++i) { run = isDNA(s[i]) ? run + 1 : 0; if (run >= k) v.push_back(i + 1 - k); }
+    return v;
+}
+
+// src/Alignment.cpp:527-844 with hap_id undetermined (no phasing input: every isValidHap test is short-circuited, :741,:801)
+void fixAmbiguity(const Ctx& c, std::string& query, std::string& quality, const char* ref_seq, const size_t ref_len, const AmbVec& v_ambiguity) {
+    if (v_ambiguity.empty()) return;
+    const size_t query_len = query.length();
+    const size_t k = c.k;
+    if (quality.length() < query_len) { fprintf(stderr, "oracle: fixAmbiguity with a quality string shorter than the sequence\n"); abort(); }
+    const char q_max_corr = getQual(1.0, c.opt.out_qual, c.opt.max_qual);
+    const char q_min_corr = getQual(0.0, c.opt.out_qual, c.opt.max_qual);
+    const char q_min_conf_corr = getQual(c.opt.min_confidence_snp_corr, 0, c.opt.max_qual);
+    const char c_noCorrect = 'X';
+    std::string query_tmp = query;
+    std::map<size_t, char> m_safe, m_all; // the reference's hash maps are only ever used key by key
+    for (size_t i = 0; i < v_ambiguity.size(); ++i) {
+        const std::pair<size_t, char>& p = v_ambiguity[i];
+        if (quality[p.first] < q_min_conf_corr) { m_safe.insert(p); query_tmp[p.first] = p.second; }
+    }
+    m_all = m_safe;
+    const AlignResult align = c.align(query_tmp.c_str(), query_len, ref_seq, ref_len, -1, MODE_SHW, true);
+    { // walk of the CIGAR (:612-706), op by op
+        size_t q_pos = 0, t_pos = 0; // SHW: startLocations[0] == 0
+        for (size_t a = 0; a < align.alignment.size(); ++a) {
+            const unsigned char op = align.alignment[a];
+            if (op == 0 || op == 3) { // 'M'
+                if (!isDNA(query_tmp[q_pos])) {
+                    if (!isDNA(ref_seq[t_pos])) { std::map<size_t, char>::iterator it = m_safe.find(q_pos); if (it != m_safe.end()) it->second = c_noCorrect; }
+                    else if (quality[q_pos] >= q_min_corr) {
+                        if (iupacOverlap(query_tmp[q_pos], ref_seq[t_pos])) { std::map<size_t, char>::iterator it = m_safe.find(q_pos); if (it != m_safe.end()) it->second = ref_seq[t_pos]; }
+                    }
+                    std::map<size_t, char>::iterator it = m_all.find(q_pos);
+                    if (it != m_all.end()) it->second = ref_seq[t_pos];
+                } else if (!isDNA(ref_seq[t_pos])) {
+                    if (quality[q_pos] < q_min_conf_corr || !iupacOverlap(query_tmp[q_pos], ref_seq[t_pos])) {
+                        m_safe.insert(std::make_pair(q_pos, c_noCorrect));
+                        m_all.insert(std::make_pair(q_pos, ref_seq[t_pos]));
+                    }
+                }
+                ++q_pos; ++t_pos;
+            } else if (op == 1) { // 'I'
+                if (!isDNA(query_tmp[q_pos])) {
+                    std::map<size_t, char>::iterator it_s = m_safe.find(q_pos), it_a = m_all.find(q_pos);
+                    if (it_s != m_safe.end() && it_a != m_all.end()) { it_a->second = it_s->second; it_s->second = c_noCorrect; }
+                }
+                ++q_pos;
+            } else ++t_pos; // 'D'
         }
     }
+    std::set<std::pair<size_t, char> > s_ambiguity;
+    for (std::map<size_t, char>::const_iterator p = m_safe.begin(); p != m_safe.end(); ++p) { // :713-768 linked SNPs of the same unitig
+        if (!isDNA(p->second)) continue;
+        const size_t pos_buff = (p->first < (k - 1)) ? 0 : (p->first - k + 1);
+        const size_t len_buff = std::min(p->first + k, query_len) - pos_buff;
+        const size_t pos_snp_buff = p->first - pos_buff;
+        std::string q_sub = query.substr(pos_buff, len_buff);
+        q_sub[pos_snp_buff] = p->second;
+        const std::vector<size_t> w = kmerWindows(q_sub, k);
+        for (size_t wi = 0; wi < w.size(); ++wi) {
+            const UM um = c.g.findUnitig(q_sub.c_str(), w[wi], q_sub.length());
+            if (um.isEmpty()) continue;
+            const UM um_tmp(um.unitig, 0, c.g.nkm(um.unitig), um.strand);
+            const std::string unitig_seq = c.g.mapped(um_tmp);
+            const AmbVec v_amb = c.g.ambiguityChars(um_tmp);
+            size_t pos_snp_unitig = (pos_snp_buff - w[wi]) + um.dist;
+            if (!um.strand) pos_snp_unitig = c.g.usize(um.unitig) - pos_snp_unitig - 1;
+            for (size_t a = 0; a < v_amb.size(); ++a) {
+                int64_t pos = static_cast<int64_t>(v_amb[a].first);
+                if (static_cast<size_t>(pos) <= pos_snp_unitig) pos = static_cast<int64_t>(p->first) - static_cast<int64_t>(pos_snp_unitig - static_cast<size_t>(pos));
+                else pos = static_cast<int64_t>(p->first) + static_cast<int64_t>(static_cast<size_t>(pos) - pos_snp_unitig);
+                if (pos >= 0 && static_cast<size_t>(pos) < query_len && static_cast<size_t>(pos) != p->first) {
+                    const std::map<size_t, char>::const_iterator it = m_safe.find(static_cast<size_t>(pos));
+                    if (it != m_safe.end() && !isDNA(it->second)) s_ambiguity.insert(std::make_pair(static_cast<size_t>(pos), unitig_seq[v_amb[a].first]));
+                }
+            }
+            const size_t next_pos = w[wi] + (um.len - 1); // it_km += um.len - 1 [A6]
+            while (wi < w.size() && w[wi] < next_pos) ++wi;
+            if (wi >= w.size()) break;
+        }
+    }
+    {
+        const AmbVec v(s_ambiguity.begin(), s_ambiguity.end());
+        for (size_t i = 0; i < v.size(); ++i) {
+            if ((i == 0 || v[i].first != v[i - 1].first) && (i + 1 == v.size() || v[i].first != v[i + 1].first)) {
+                std::map<size_t, char>::iterator it_s = m_safe.find(v[i].first);
+                if (it_s != m_safe.end() && iupacOverlap(v[i].second, it_s->second)) it_s->second = v[i].second;
+            }
+        }
+    }
+    for (std::map<size_t, char>::const_iterator p = m_safe.begin(); p != m_safe.end(); ++p) { // :792-838
+        if (p->second == c_noCorrect || quality[p->first] < q_min_corr) {
+            const std::map<size_t, char>::const_iterator it_a = m_all.find(p->first);
+            if (it_a != m_all.end()) { query_tmp[p->first] = it_a->second; quality[p->first] = q_max_corr; } // validHap is always true with an undetermined haplotype
+        }
+        else if (!isDNA(p->second)) query_tmp[p->first] = query[p->first];
+        else query_tmp[p->first] = p->second;
+    }
+    query = query_tmp;
 }
 
 // ---------------------------------------------------------------- fixRepeats (src/GraphTraversal.cpp:1149-1334)
@@ -337,8 +463,8 @@ void exploreSubGraph(const Ctx& c, const IdSet& all_pids, const char* ref, const
             }
         }
     }
-    for (size_t i = 0; i < out.terminal.size(); ++i) { Path& p = out.terminal[i]; const std::string q = getScorePathQual(c, p, ref, ref_len, score_t1, score_t2); if (q.length() == p.l) p.qual = q; requireUnannotated(c, p); }
-    for (size_t i = 0; i < out.non_terminal.size(); ++i) { Path& p = out.non_terminal[i]; const std::string q = getScorePathQual(c, p, ref, ref_len, score_nt1, score_nt2); if (q.length() == p.l) p.qual = q; requireUnannotated(c, p); }
+    for (size_t i = 0; i < out.terminal.size(); ++i) { Path& p = out.terminal[i]; const std::string q = getScorePathQual(c, p, ref, ref_len, score_t1, score_t2); if (q.length() == p.l) p.qual = q; }
+    for (size_t i = 0; i < out.non_terminal.size(); ++i) { Path& p = out.non_terminal[i]; const std::string q = getScorePathQual(c, p, ref, ref_len, score_nt1, score_nt2); if (q.length() == p.l) p.qual = q; }
     out.t1 = score_t1; out.nt1 = score_nt1;
 }
 
@@ -449,7 +575,7 @@ std::vector<Path> explorePathsBFS2(const Ctx& c, const IdSet& all_pids, const ch
     }
     if (!v.empty()) {
         if (v.size() > 1) { const int b = selectBest(c, v, ref, ref_len, MODE_NW).first; std::vector<Path> one(1, v[b]); v.swap(one); }
-        v[0] = fixRepeats(c, v[0], ref, ref_len); requireUnannotated(c, v[0]);
+        v[0] = fixRepeats(c, v[0], ref, ref_len);
     }
     return v;
 }
@@ -507,7 +633,7 @@ std::vector<Path> explorePathsBFS(const Ctx& c, const IdSet& all_pids, const cha
     }
     if (!v.empty()) {
         if (v.size() > 1) { const int b = selectBest(c, v, ref, ref_len, MODE_NW).first; std::vector<Path> one(1, v[b]); v.swap(one); }
-        v[0] = fixRepeats(c, v[0], ref, ref_len); requireUnannotated(c, v[0]);
+        v[0] = fixRepeats(c, v[0], ref, ref_len);
     }
     return v;
 }
@@ -821,6 +947,8 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
         } else { middle(nullptr); all_pids = rc->all_pids; res.all_pids = all_pids; }
 
         const size_t card_pids = all_pids.size();
+        AmbVec v_ambiguity; // :635-637,:657-659,:677-679,:703-705
+        auto addAmbiguity = [&](const Path& path, size_t offset) { const AmbVec v = getAmbiguityVector(c, path); for (size_t i = 0; i < v.size(); ++i) v_ambiguity.push_back(std::make_pair(offset + v[i].first, v[i].second)); };
         SemiWeak paths1;
         if (card_pids >= opt.min_cov_vertices) paths1 = extractSemiWeakPaths(c, s, all_pids, um_solid1, um_solid2, l_v_w, 0);
         if (paths1.complete.empty()) {
@@ -834,7 +962,7 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
                     if (i_w_s >= l_v_w.size() || l_v_w[i_w_s].first >= um_solid2.first - k || (l_v_w[i_w_s].first - um_solid1.first) >= max_len_weak_anchors) break;
                 }
                 const Path& best = paths1.partial[align.first];
-                requireUnannotated(c, best);
+                addAmbiguity(best, s_corrected.length());
                 s_corrected += pathToString(c, best) + s.substr(um_solid1.first + align.second + 1, l_v_w[i_w_s].first - um_solid1.first - align.second - 1);
                 q_corrected += best.qual;
                 q_corrected += std::string(l_v_w[i_w_s].first - um_solid1.first - align.second - 1, q_min);
@@ -846,7 +974,7 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
             if (!paths1.complete.empty()) {
                 const std::pair<int, int> p_align = selectBest(c, paths1.complete, s.c_str() + um_solid1.first, len_weak_region, MODE_NW);
                 const Path& best = paths1.complete[p_align.first];
-                requireUnannotated(c, best);
+                addAmbiguity(best, s_corrected.length());
                 s_corrected += pathToString(c, best); q_corrected += best.qual;
                 res.addRange(um_solid1.first - v_s[i_s].first, um_solid2.first - v_s[i_s].first + k);
             } else if (!paths1.partial.empty()) {
@@ -854,7 +982,7 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
                 if (align.first == -1) addUncorrected(um_solid1.first, len_weak_region, q_min);
                 else {
                     const Path& best = paths1.partial[align.first];
-                    requireUnannotated(c, best);
+                    addAmbiguity(best, s_corrected.length());
                     s_corrected += pathToString(c, best) + s.substr(um_solid1.first + align.second + 1, len_weak_region - align.second - 1);
                     q_corrected += best.qual;
                     q_corrected += std::string(len_weak_region - align.second - 1, q_min);
@@ -865,11 +993,11 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
         } else {
             const std::pair<int, int> p_align = selectBest(c, paths1.complete, s.c_str() + um_solid1.first, len_weak_region, MODE_NW);
             const Path& best = paths1.complete[p_align.first];
-            requireUnannotated(c, best);
+            addAmbiguity(best, 0);
             s_corrected = pathToString(c, best); q_corrected = best.qual;
             res.addRange(0, len_weak_region);
         }
-        // fixAmbiguity (:716) is a no-op without SNP annotations (src/Alignment.cpp:532)
+        fixAmbiguity(c, s_corrected, q_corrected, s_start, res.old_seq_len, v_ambiguity); // :716
         if (res.pos.size() == res.old_seq_len) { // :718-725 (G20)
             bool same = s_corrected.length() >= k && s.length() >= k;
             for (size_t i = 0; same && i < k; ++i) same = bifrostCode(s[s.length() - k + i]) == bifrostCode(s_corrected[s_corrected.length() - k + i]);

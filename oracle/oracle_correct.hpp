@@ -13,9 +13,10 @@
 //   [D2] extractSemiWeakPaths path grouping = STABLE sort by mapped string of the last unitig (src/Correction.cpp:52)
 // fixRepeats on short-cycle unitigs (src/GraphTraversal.cpp:1149-1334) is restated; its inputs come from the restatement of
 // detectShortCycles in ratatosk_amd/csrc/tools/build_index.cpp.
-// Not restated (index annotations our index producer never emits; aborts loudly if present):
-//   fixAmbiguity/getAmbiguityVector on SNP-annotated unitigs (src/Alignment.cpp:527-844, src/GraphTraversal.cpp:966-1055),
-//   pass 2 (long_read_correct).
+// fixAmbiguity/getAmbiguityVector on SNP-annotated unitigs (src/Alignment.cpp:527-844, src/GraphTraversal.cpp:966-1036) are
+// restated for an undetermined haplotype (no phasing input); they lean on Bifrost's findUnitig and KmerIterator, assumptions
+// [A6]/[A7] of oracle_graph.hpp. Test inputs come from `build_index --snps` (a simplified stand-in for detectSNPs).
+// Not restated: pass 2 (long_read_correct), phasing (hap ids).
 #ifndef RTK_ORACLE_CORRECT_HPP
 #define RTK_ORACLE_CORRECT_HPP
 
@@ -36,9 +37,10 @@ struct Opt { // the Correct_Opt fields the pass-1 hot path reads (src/Common.hpp
     double min_score;
     int max_qual;
     int out_qual;
+    double min_confidence_snp_corr; // -m (src/Common.hpp:147)
     size_t max_km_cov; // = max(getMaxKmerCoverage(dbg, 0.001), 128) (src/Ratatosk.cpp:625)
     Opt() : insert_sz(500), min_cov_vertices(2), max_len_weak_region1(1000), weak_region_len_factor(0.25), large_k_factor(1.5),
-            min_score(0.0), max_qual(40), out_qual(1), max_km_cov(128) {}
+            min_score(0.0), max_qual(40), out_qual(1), min_confidence_snp_corr(0.9), max_km_cov(128) {}
 };
 
 struct Counters { // event counts feeding the algorithmic-bytes model of SURVEY.md §8(d)

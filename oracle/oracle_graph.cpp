@@ -163,6 +163,8 @@ void Graph::load(const std::string& fasta_gz, const std::string& rtsk, int k_) {
             ui.global_id = it->second;
         }
         ui.has_ambiguity = !amb.empty();
+        for (size_t a = 0; a < amb.size(); ++a) ui.amb.push_back(std::make_pair(amb[a] >> 4, iupacChar(static_cast<uint8_t>(amb[a] & 0xF)))); // UnitigData.hpp:448-451,565-574
+        std::sort(ui.amb.begin(), ui.amb.end());
         const uint64_t ncyc = r.u64();
         if (r.p + ncyc > bytes.size()) throw std::runtime_error("oracle: truncated cycles");
         for (uint64_t a = 0; a < ncyc;) { const size_t l = strnlen(reinterpret_cast<const char*>(&bytes[r.p + a]), ncyc - a); ui.cycles.push_back(std::string(reinterpret_cast<const char*>(&bytes[r.p + a]), l)); a += l + 1; }
@@ -179,6 +181,37 @@ UM Graph::findKmerCode(uint64_t fw) const {
     const bool stored_is_can = it->second & 1ULL;
     const bool query_is_can = (fw <= rc);
     return UM(static_cast<int32_t>(it->second >> 32), static_cast<uint32_t>((it->second & 0xFFFFFFFFULL) >> 1), 1, stored_is_can == query_is_can);
+}
+
+static const char kIupac[17] = ".ACMGRSVTWYHKDBN";
+char iupacChar(uint8_t idx) { return kIupac[idx & 15]; }
+uint8_t iupacIndex(char c) { const char u = static_cast<char>(c & 0xDF); for (uint8_t i = 1; i < 16; ++i) if (u == kIupac[i]) return i; return 0; }
+char iupacComplement(char c) {
+    const uint8_t i = iupacIndex(c);
+    if (i == 0) return c;
+    return kIupac[((i & 1) << 3) | ((i & 8) >> 3) | ((i & 2) << 1) | ((i & 4) >> 1)];
+}
+
+UM Graph::findUnitig(const char* s, size_t pos, size_t len) const { // [A7]
+    if (pos + static_cast<size_t>(k) > len) return UM();
+    UM um = findKmer(s + pos);
+    if (um.isEmpty()) return um;
+    const std::string& u = seq[um.unitig];
+    size_t j = pos + k; uint32_t n = 1;
+    if (um.strand) { size_t up = um.dist + k; while (j < len && up < u.size() && s[j] == u[up]) { ++j; ++up; ++n; } }
+    else { int64_t up = static_cast<int64_t>(um.dist) - 1; while (j < len && up >= 0 && s[j] == iupacComplement(u[static_cast<size_t>(up)])) { ++j; --up; ++n; } um.dist -= (n - 1); }
+    um.len = n;
+    return um;
+}
+
+std::vector<std::pair<size_t, char> > Graph::ambiguityChars(const UM& um) const {
+    std::vector<std::pair<size_t, char> > v;
+    if (um.isEmpty()) return v;
+    const std::vector<std::pair<uint32_t, char> >& a = info[um.unitig].amb;
+    const size_t sz = um.len + k - 1, end = um.dist + sz;
+    if (um.strand) { for (size_t i = 0; i < a.size(); ++i) if (a[i].first >= um.dist && a[i].first < end) v.push_back(std::make_pair(a[i].first - um.dist, a[i].second)); }
+    else for (size_t i = a.size(); i-- > 0;) if (a[i].first >= um.dist && a[i].first < end) v.push_back(std::make_pair(sz - (a[i].first - um.dist) - 1, iupacComplement(a[i].second)));
+    return v;
 }
 
 UM Graph::findKmer(const char* s) const {

@@ -15,6 +15,11 @@
 //        as whole-unitig mappings (dist=0, len=size-k+1).
 //   [A4] on-disk Kmer = 2 x u64, 2 bits/base (A0 C1 G2 T3), first base in the MSBs of word 0.
 //   [A5] FASTA/FASTQ records: name = header up to the first whitespace.
+//   [A6] KmerIterator visits the all-ACGT windows of a string in order; `it += n` moves to the first such window at or after
+//        position(it) + n (src/Alignment.cpp:565,741,813 `it_km += um.len - 1`).
+//   [A7] findUnitig(s, pos, len) = find(k-mer at s+pos) extended along the unitig while s keeps agreeing: forward strand
+//        {dist = d, len = 1 + agreeing characters}; reverse strand the match runs towards the unitig head and
+//        {dist = d - (len - 1)} (the mapping always starts at its lowest forward offset).
 // "Parity unpinned" for everything that depends on [A1]-[A3]: the reference has no tests and its binary
 // cannot be built here.
 #ifndef RTK_ORACLE_GRAPH_HPP
@@ -47,6 +52,7 @@ struct UnitigInfo { // restatement of the read side of src/UnitigData.hpp:258-49
     int32_t global_id; // index into Graph::globals or -1 (SharedPairID global pointer)
     IdSet local;
     bool has_ambiguity;
+    std::vector<std::pair<uint32_t, char> > amb; // get_ambiguity_char() (UnitigData.hpp:565-574): (position on the forward unitig, IUPAC code), sorted
     std::vector<std::string> cycles; // getCompactCycles() (UnitigData.hpp:312-327): successor-base strings of the short cycles through the unitig
     UnitigInfo() : kmcov(0), shared(0), global_id(-1), has_ambiguity(false) {}
 };
@@ -67,6 +73,11 @@ struct Graph {
     // Bifrost find(km, extremities_only=false) on a k-mer given as text; empty UM if absent / non-ACGT. [A1]
     UM findKmer(const char* s) const;
     UM findKmerCode(uint64_t fw_code) const;
+
+    // Bifrost findUnitig(s, pos, len): the k-mer at s+pos, extended along its unitig while the following characters of s agree. [A7]
+    UM findUnitig(const char* s, size_t pos, size_t len) const;
+    // UnitigData::get_ambiguity_char(um) (UnitigData.hpp:458-481): annotations inside the mapping, in mapping coordinates and orientation
+    std::vector<std::pair<size_t, char> > ambiguityChars(const UM& um) const;
 
     std::string mapped(const UM& um) const;                 // const_UnitigMap::mappedSequenceToString
     bool sameUnitig(const UM& a, const UM& b) const { return a.unitig == b.unitig; } // isSameReferenceUnitig
@@ -95,6 +106,12 @@ IdSet set_diff(const IdSet& a, const IdSet& b);
 size_t set_inter_card(const IdSet& a, const IdSet& b);
 
 std::string revcomp(const std::string& s);
+
+// IUPAC helpers (src/Common.hpp:260,351-400; Bifrost isDNA / reverse_complement(char))
+uint8_t iupacIndex(char c);   // bit0 A, bit1 C, bit2 G, bit3 T; 0 for anything outside the table
+char iupacChar(uint8_t idx);  // ".ACMGRSVTWYHKDBN"[idx]
+char iupacComplement(char c);
+inline bool isDNA(char c) { const char u = static_cast<char>(c & 0xDF); return u == 'A' || u == 'C' || u == 'G' || u == 'T'; }
 
 } // namespace orc
 

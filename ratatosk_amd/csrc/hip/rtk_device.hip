@@ -80,6 +80,7 @@ static void graph_set_view(rtk_graph* g) {
     v.bf = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_BF]); v.bf_mask = g->dbytes[rtk::RTK_BUF_BF] / 8 - 1;
     v.bf1 = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_BF1]); v.bf1_mask = g->dbytes[rtk::RTK_BUF_BF1] * 8 - 1;
     v.cycoff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_CYCOFF]); v.cyc = static_cast<const char*>(g->dbuf[rtk::RTK_BUF_CYC]);
+    v.amb = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_AMB]); v.n_amb = g->dbytes[rtk::RTK_BUF_AMB] / 8 - (static_cast<uint64_t>(v.n_unitigs) + 1);
 }
 
 extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out) {
@@ -88,7 +89,6 @@ extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int
     try { g->host.load(unitig_fasta_gz, rtsk, k, n_threads); }
     catch (const std::exception& e) { return rtk_fail(RTK_ERR_FORMAT, std::string("rtk_graph_load: ") + e.what()); }
     g->has_host = true;
-    for (size_t u = 0; u < g->host.flags.size(); ++u) if (g->host.flags[u] & RTK_F_AMBIGUITY) g->unsupported_annotations = true; // short cycles are handled (fixRepeats)
     rtk_graph_info& i = g->info;
     i.k = k; i.device = -1; i.n_unitigs = g->host.n_unitigs(); i.n_kmers = g->host.n_kmers; i.n_bases = g->host.uoff.back();
     i.n_colour_ids = g->host.col.size() - 1; i.n_global_sets = g->host.n_global; i.table_slots = g->host.ht.size() / 2; i.hbm_bytes = g->host.bytes();
@@ -136,7 +136,7 @@ extern "C" int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* d
 extern "C" int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n) {
     if (!g || !bytes || n != rtk::RTK_N_BUFS || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer_bytes: needs a loaded graph");
     const rtk::FlatGraph& h = g->host;
-    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size() };
+    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size() };
     for (int i = 0; i < n; ++i) bytes[i] = b[i];
     return RTK_OK;
 }
@@ -145,8 +145,8 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
     if (!g || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: graph has no host image");
     int rc = require_device(device); if (rc) return rc;
     const rtk::FlatGraph& h = g->host;
-    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data(), h.bf.data(), h.cycoff.data(), h.cyc.data(), h.bf1.data() };
-    const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size() };
+    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data(), h.bf.data(), h.cycoff.data(), h.cyc.data(), h.bf1.data(), h.amb.data() };
+    const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size() };
     try {
         rtk_set_device(device);
         for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { if (!g->dbuf[i]) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; } rtk_h2d(g->dbuf[i], src[i], bytes[i]); }
@@ -176,6 +176,7 @@ extern "C" long long rtk_graph_strip_annotations(rtk_graph* g) {
     if (!g->has_host || g->on_device) return rtk_fail(RTK_ERR_ARG, "rtk_graph_strip_annotations: call it on a loaded graph before rtk_graph_upload");
     long long n = 0;
     for (size_t u = 0; u < g->host.flags.size(); ++u) if (g->host.flags[u] & (RTK_F_SHORT_CYCLE | RTK_F_AMBIGUITY)) { g->host.flags[u] &= ~static_cast<uint32_t>(RTK_F_SHORT_CYCLE | RTK_F_AMBIGUITY); ++n; }
+    g->host.amb.assign(g->host.flags.size() + 1, 0);
     g->unsupported_annotations = false;
     return n;
 }
@@ -194,7 +195,7 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
     if (!o) return rtk_fail(RTK_ERR_ARG, "rtk_opts_default: null");
     o->insert_sz = 500; o->min_cov_vertices = 2; o->max_len_weak_region1 = 1000;
     o->max_km_cov = 128; if (g && g->info.max_km_cov_top > 128) o->max_km_cov = g->info.max_km_cov_top; // src/Ratatosk.cpp:625
-    o->weak_region_len_factor = 0.25; o->large_k_factor = 1.5; o->min_score = 0.0; o->max_qual = 40; o->out_qual = 1;
+    o->weak_region_len_factor = 0.25; o->large_k_factor = 1.5; o->min_score = 0.0; o->max_qual = 40; o->out_qual = 1; o->min_confidence_snp_corr = 0.9;
     return RTK_OK;
 }
 

@@ -10,7 +10,7 @@
 // arenas in HBM (three nesting levels: region / BFS call / DFS call); the reference's queue, stack and candidate
 // vectors become small handle lists. Canonical tie rules [D1] (see oracle/oracle_correct.hpp) are applied where the
 // reference depends on heap addresses. Index annotations that our index producer never emits (short cycles, SNP
-// ambiguities) are rejected up front by the host (RTK_ERR_UNSUPPORTED), so fixRepeats / fixAmbiguity are identities.
+// ambiguities) are handled by rtk_fix_repeats and rtk_ambiguity.h.
 #ifndef RTK_REGION_H
 #define RTK_REGION_H
 
@@ -60,7 +60,7 @@ struct RegionScratch {
     WPath wp[4]; U<uint32_t> um_cap;
     U<char*> str[5]; U<uint32_t> str_cap;
     U<char*> rbuf[8];                                       // result strings: fw seq/qual, bw seq/qual, out seq/qual, 2 temporaries
-    U<uint64_t*> list[6]; U<uint32_t> list_cap;
+    U<uint64_t*> list[11]; U<uint32_t> list_cap;                // 6..10: SNP-annotation sets (rtk_ambiguity.h)
     U<uint32_t*> memo_u; U<uint8_t*> memo_v; U<uint32_t> memo_cap; U<uint32_t> memo_n;
     U<uint64_t*> bm[3]; U<uint32_t> bm_words;
     U<uint32_t*> overflow;
@@ -341,6 +341,8 @@ RTK_FN MyersResult rtk_align_path(const RCtx& c_, const char* q_, uint32_t m_, c
     s.cnt[9] += rtk_clock() - t0;
     return r;
 }
+
+#include "rtk_ambiguity.h"
 
 // ------------------------------------------------------------------------------------------------ candidate selection (src/Alignment.cpp:3-147, 967-1015)
 // handles[] are committed paths; strings are materialised into str[0].
@@ -1171,7 +1173,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     const uint32_t* all_pids = s.set[0];
     // ---- paths ----
     s.top[0] = 0;
-    uint32_t n_partial = 0;
+    uint32_t n_partial = 0, n_amb = 0; // n_amb: size of v_ambiguity (list[RTK_L_AMB])
     uint64_t complete = ~0ull;
     char* s_corr = res.seq; char* q_corr = res.qual; uint32_t sl_ = 0, ql_ = 0;
     const Anchors& lvw = v_w;
@@ -1193,6 +1195,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
             const uint64_t hb = s.list[5][aid];
             const uint32_t wpos = rtk_an_pos(lvw, lw_lo + i_w_s);
             const uint32_t pl = rtk_rec_to_string(c, hb, s.str[0]); if (pl == 0xFFFFFFFFu) break;
+            n_amb = rtk_amb_collect(c, hb, sl_, n_amb);
             rtk_app(s, s_corr, &sl_, s.str[0], pl);
             rtk_app(s, s_corr, &sl_, s_read + p1 + aend + 1, wpos - p1 - static_cast<uint32_t>(aend) - 1);
             rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(hb), rtk_h_off(hb)), rtk_path_hdr(s, rtk_h_lvl(hb), rtk_h_off(hb))->qlen);
@@ -1206,6 +1209,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
         if (rtk_failed(s)) return;
         if (complete != ~0ull) {
             const uint32_t pl = rtk_rec_to_string(c, complete, s.str[0]); if (pl == 0xFFFFFFFFu) return;
+            n_amb = rtk_amb_collect(c, complete, sl_, n_amb);
             rtk_app(s, s_corr, &sl_, s.str[0], pl);
             rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(complete), rtk_h_off(complete)), rtk_path_hdr(s, rtk_h_lvl(complete), rtk_h_off(complete))->qlen);
             rtk_bm_add_range(res.bm, p1 - first_pos, p2 - first_pos + k);
@@ -1217,6 +1221,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
             else {
                 const uint64_t hb = s.list[5][aid];
                 const uint32_t pl = rtk_rec_to_string(c, hb, s.str[0]); if (pl == 0xFFFFFFFFu) return;
+                n_amb = rtk_amb_collect(c, hb, sl_, n_amb);
                 rtk_app(s, s_corr, &sl_, s.str[0], pl);
                 const uint32_t rest = len_weak_region - static_cast<uint32_t>(aend) - 1;
                 rtk_app(s, s_corr, &sl_, s_read + p1 + aend + 1, rest);
@@ -1229,11 +1234,13 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     } else {
         const uint32_t pl = rtk_rec_to_string(c, complete, s.str[0]); if (pl == 0xFFFFFFFFu) return;
         sl_ = 0; ql_ = 0;
+        n_amb = rtk_amb_collect(c, complete, 0, n_amb);
         rtk_app(s, s_corr, &sl_, s.str[0], pl);
         rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(complete), rtk_h_off(complete)), rtk_path_hdr(s, rtk_h_lvl(complete), rtk_h_off(complete))->qlen);
         rtk_bm_add_range(res.bm, 0, len_weak_region);
     }
     if (rtk_failed(s)) return;
+    if (n_amb != 0) { rtk_fix_ambiguity(c, s_corr, sl_, q_corr, ql_, s_read + first_pos, res.old_len, n_amb); if (rtk_failed(s)) return; } // :716
     if (rtk_bm_card(res.bm, res.old_len) == res.old_len) { // :718-725 (G20): last k-mer of the WHOLE read vs last k-mer of the corrected region
         bool same = sl_ >= k && s_len >= k;
         for (uint32_t i = 0; same && i < k; ++i) same = rtk_bifrost_code(s_read[s_len - k + i]) == rtk_bifrost_code(s_corr[sl_ - k + i]);
@@ -1344,7 +1351,7 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
 RTK_HD uint64_t region_scratch_bytes(const RegionScratchCfg& c) {
     uint64_t b = scratch_bytes(c.my);
     b += 10ull * 4 * c.set_cap + 3ull * c.arena_cap + 4ull * (sizeof(UMap) * c.um_cap + c.str_cap) + (5ull + 8ull) * c.str_cap;
-    b += 6ull * 8 * c.list_cap + 5ull * c.memo_cap + 3ull * 8 * c.bm_words + sizeof(RegionScratch) + 1024;
+    b += 11ull * 8 * c.list_cap + 5ull * c.memo_cap + 3ull * 8 * c.bm_words + sizeof(RegionScratch) + 1024;
     return (b + 255) / 256 * 256;
 }
 
@@ -1356,7 +1363,7 @@ RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& 
     t.my = scratch_carve(p, c.my); p += scratch_bytes(c.my);
     for (int i = 0; i < 3; ++i) { t.arena[i] = p; p += c.arena_cap; t.top[i] = 0; }
     t.arena_cap = c.arena_cap;
-    for (int i = 0; i < 6; ++i) { t.list[i] = reinterpret_cast<uint64_t*>(p); p += 8ull * c.list_cap; }
+    for (int i = 0; i < 11; ++i) { t.list[i] = reinterpret_cast<uint64_t*>(p); p += 8ull * c.list_cap; }
     t.list_cap = c.list_cap;
     for (int i = 0; i < 3; ++i) { t.bm[i] = reinterpret_cast<uint64_t*>(p); p += 8ull * c.bm_words; }
     t.bm_words = c.bm_words;

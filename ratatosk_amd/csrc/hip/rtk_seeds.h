@@ -15,6 +15,7 @@ struct OptsView {
     U<uint32_t> insert_sz, min_cov_vertices, max_len_weak_region1, max_km_cov;
     U<double> weak_region_len_factor, large_k_factor, min_score;
     U<int32_t> max_qual, out_qual;
+    U<double> min_confidence_snp_corr;
 };
 
 struct BatchView {

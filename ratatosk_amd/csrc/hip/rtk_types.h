@@ -89,6 +89,8 @@ struct GraphView {
     U<uint64_t> bf1_mask;
     U<const uint64_t*> cycoff;    // [n+1] compact cycles of unitig u = cyc[cycoff[u] .. cycoff[u+1]) (NUL-terminated strings of successor bases)
     U<const char*> cyc;
+    U<const uint64_t*> amb;       // SNP annotations: amb[u]..amb[u+1] index the entries of unitig u, entry j = amb[n_unitigs + 1 + j] = position<<4 | IUPAC index, by (position, code)
+    U<uint64_t> n_amb;            // number of annotation entries (0: getAmbiguityVector / fixAmbiguity are identities)
 };
 
 RTK_HD uint32_t rtk_ulen(const GraphView& g, uint32_t u) { return static_cast<uint32_t>(g.uoff[u + 1] - g.uoff[u]); }

@@ -24,11 +24,12 @@ GraphView FlatGraph::view() const {
     v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data(); v.bf = bf.data(); v.bf_mask = bf.size() - 1;
     v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1;
     v.cycoff = cycoff.data(); v.cyc = reinterpret_cast<const char*>(cyc.data());
+    v.amb = amb.data(); v.n_amb = amb.size() - (static_cast<uint64_t>(n_unitigs()) + 1);
     return v;
 }
 
 uint64_t FlatGraph::bytes() const {
-    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
+    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
 void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int /*n_threads*/) {
@@ -106,6 +107,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     std::vector<std::vector<uint32_t> > globals;
     std::map<std::vector<uint32_t>, int32_t> gdedup; // identical global sets share one id (reference: src/Graph.cpp:748-771)
     std::vector<char> seen(n, 0);
+    std::vector<std::vector<uint32_t> > ambs(n); // SNP annotation ids of each unitig (pos<<4 | IUPAC index)
     std::vector<std::string> cycles(n); // compact cycles of short-cycle unitigs (UnitigData.hpp:307-327): NUL-terminated strings, concatenated
     {
         std::ifstream in(rtsk.c_str(), std::ios::binary);
@@ -127,7 +129,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             if (r.shared & 0x100ull) f |= RTK_F_SHORT_CYCLE;
             cycles[u] = r.cycles;
             if (r.kmcov >> 63) f |= RTK_F_BRANCHING;
-            if (!r.ambiguity_ids.empty()) f |= RTK_F_AMBIGUITY;
+            if (!r.ambiguity_ids.empty()) { f |= RTK_F_AMBIGUITY; ambs[u].swap(r.ambiguity_ids); }
             flags[u] = f;
             const uint64_t cov = (r.kmcov & 0x7fffffffull) + ((r.kmcov >> 31) & 0x7fffffffull); // phased + unphased (UnitigData.hpp:371-384)
             kcov[u] = static_cast<uint32_t>(std::round(static_cast<double>(cov) / static_cast<double>(nk)));
@@ -149,6 +151,17 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     col.assign(goff[globals.size()] + 1, 0);
     for (size_t u = 0; u < n; ++u) std::copy(locals[u].begin(), locals[u].end(), col.begin() + loff[u]);
     for (size_t g = 0; g < globals.size(); ++g) std::copy(globals[g].begin(), globals[g].end(), col.begin() + goff[g]);
+    // ---- SNP annotations: get_ambiguity_char() order = (position, IUPAC character) (UnitigData.hpp:557-574) ----
+    {
+        amb.assign(n + 1, 0);
+        static const char codes[17] = ".ACMGRSVTWYHKDBN"; // src/Common.hpp:260
+        for (size_t u = 0; u < n; ++u) {
+            std::vector<uint32_t>& a = ambs[u];
+            std::sort(a.begin(), a.end(), [](uint32_t x, uint32_t y) { return (x >> 4) != (y >> 4) ? (x >> 4) < (y >> 4) : codes[x & 15] < codes[y & 15]; });
+            amb[u + 1] = amb[u] + a.size();
+        }
+        for (size_t u = 0; u < n; ++u) for (size_t i = 0; i < ambs[u].size(); ++i) amb.push_back(ambs[u][i]);
+    }
     // ---- compact cycles ----
     cycoff.assign(n + 1, 0);
     for (size_t u = 0; u < n; ++u) cycoff[u + 1] = cycoff[u] + cycles[u].size();

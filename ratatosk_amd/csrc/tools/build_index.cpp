@@ -13,7 +13,10 @@
 //   * edge bits      = neighbour shares >= min_cov_vertices colours (reference: src/Graph.cpp:1999-2017)
 //   * global/local   = simplified form of the colour compaction of src/Graph.cpp:2874-2985
 //   * short cycles   = restatement of detectShortCycles (src/Graph.cpp:4660-4735), so that fixRepeats has inputs
-//   * SNP-ambiguity and haplotype annotations are left empty (`detectSNPs` is index-time code outside the scope).
+//   * SNP annotations (--snps only) = simplified stand-in for detectSNPs (src/Graph.cpp:484-720): a position is annotated with the
+//     IUPAC union of its base and the substituted base when the k-mer with that substitution lies on ANOTHER unitig and one
+//     neighbour on each side shares >= min_cov colours with both (one-step form of isValidSNPcandidate,
+//     src/GraphTraversal.cpp:1057-1147). Gives fixAmbiguity/getAmbiguityVector inputs; haplotype ids stay empty (no phasing).
 #include <zlib.h>
 
 #include <algorithm>
@@ -63,7 +66,7 @@ int main(int argc, char** argv) {
     unsigned min_count = 2;
     size_t min_cov_vertices = 2;
     double global_cov_factor = 3.0, min_color_sharing = 0.5;
-    bool detect_cycles = true;
+    bool detect_cycles = true, detect_snps = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char* n) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "rtk_build_index: missing value for %s\n", n); exit(2); } return argv[++i]; };
@@ -73,9 +76,10 @@ int main(int argc, char** argv) {
         else if (a == "--min-count") min_count = static_cast<unsigned>(atoi(need("--min-count")));
         else if (a == "--global-cov-factor") global_cov_factor = atof(need("--global-cov-factor"));
         else if (a == "--no-short-cycles") detect_cycles = false;
+        else if (a == "--snps") detect_snps = true;
         else { fprintf(stderr, "rtk_build_index: unknown option %s\n", a.c_str()); return 2; }
     }
-    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=31)] [--min-count 2] [--global-cov-factor 3.0]\n"); return 2; }
+    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=31)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps]\n"); return 2; }
     const uint64_t mask = kmer_mask(k);
 
     // ---- pass 1: count canonical k-mers ----
@@ -260,6 +264,50 @@ int main(int argc, char** argv) {
         fprintf(stderr, "rtk_build_index: %zu unitigs in short cycles\n", n_cyc_unitigs);
     }
 
+    // ---- SNP annotations (simplified stand-in for detectSNPs, see the header) ----
+    std::vector<std::vector<uint32_t> > ambiguity(n);
+    if (detect_snps) {
+        size_t n_amb = 0, n_amb_unitigs = 0;
+        for (size_t u = 0; u < n; ++u) {
+            if (!(shared[u] & 0xffULL)) continue; // hasSharedPids (src/Graph.cpp:500)
+            const std::string& s = U[u].seq;
+            std::vector<uint8_t> fin(s.size(), 0);
+            std::set<size_t> ok, bad;
+            auto flank = [&](size_t w, int d) {
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t x = adj[u].u[d][b];
+                    if (x < 0 || !(shared[u] & (d == 0 ? ((1ULL << b) << 4) : (1ULL << b)))) continue;
+                    if (shared_count(U[static_cast<size_t>(x)].colours, U[u].colours) >= min_cov_vertices && shared_count(U[static_cast<size_t>(x)].colours, U[w].colours) >= min_cov_vertices) return true;
+                }
+                return false;
+            };
+            uint64_t fw = 0;
+            for (size_t i = 0; i < s.size(); ++i) {
+                fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & mask;
+                if (i + 1 < static_cast<size_t>(k)) continue;
+                const size_t p = i + 1 - static_cast<size_t>(k);
+                for (int j = 0; j < k; ++j) {
+                    const int sh = 2 * (k - 1 - j);
+                    const uint64_t cur = (fw >> sh) & 3ULL;
+                    for (uint64_t alt = 0; alt < 4; ++alt) {
+                        if (alt == cur) continue;
+                        const uint64_t y = (fw & ~(3ULL << sh)) | (alt << sh);
+                        const uint64_t* v = km.slot(kmer_canonical(y, k), false);
+                        if (!v) continue;
+                        const size_t w = (*v >> 32) - 1;
+                        if (w == u) continue; // a SNP candidate cannot be on the same unitig (src/Graph.cpp:523)
+                        if (bad.count(w)) continue;
+                        if (!ok.count(w)) { if (U[u].colours.size() >= min_cov_vertices && U[w].colours.size() >= min_cov_vertices && flank(w, 0) && flank(w, 1)) ok.insert(w); else { bad.insert(w); continue; } }
+                        fin[p + static_cast<size_t>(j)] |= static_cast<uint8_t>((1u << cur) | (1u << alt)); // bit0 A, bit1 C, bit2 G, bit3 T (src/Common.hpp:260,351)
+                    }
+                }
+            }
+            for (size_t i = 0; i < fin.size(); ++i) if (fin[i]) { ambiguity[u].push_back(static_cast<uint32_t>((i << 4) + fin[i])); ++n_amb; } // UnitigData.hpp:448-451
+            if (!ambiguity[u].empty()) ++n_amb_unitigs;
+        }
+        fprintf(stderr, "rtk_build_index: %zu SNP annotations on %zu unitigs\n", n_amb, n_amb_unitigs);
+    }
+
     // ---- global / local colour split (simplified restatement of src/Graph.cpp:2874-2985) ----
     std::vector<std::vector<uint32_t> > global_ids(n), local_ids(n);
     {
@@ -318,7 +366,7 @@ int main(int argc, char** argv) {
             RtskRecord r;
             disk_kmer_from_string(U[u].seq.c_str(), k, r.head);
             r.kmcov = kmcov[u]; r.shared = shared[u];
-            r.global_ids = global_ids[u]; r.local_ids = local_ids[u]; r.cycles = cycles[u];
+            r.global_ids = global_ids[u]; r.local_ids = local_ids[u]; r.ambiguity_ids = ambiguity[u]; r.cycles = cycles[u];
             rtsk_write_record(out, r);
         }
     }

@@ -72,6 +72,17 @@ def ds_tandem(tmp_path_factory):
                                       "--lr-n", 40, "--lr-len", 3000, "--lr-profile", "ont", "--lr-err", 0.07])
 
 
+@pytest.fixture(scope="session")
+def ds_snps(tmp_path_factory):
+    """Diploid set whose index carries SNP annotations (`rtk_build_index --snps`): getAmbiguityVector / fixAmbiguity have work.
+    PREFIX_plain.index.* is the same graph without the annotations."""
+    d = tmp_path_factory.mktemp("ds_snps")
+    pre = make_dataset(d, "snps", ["--seed", 31, "--ref-len", 60000, "--het", 0.004, "--sr-cov", 40, "--sr-err", 0.005,
+                                   "--lr-n", 40, "--lr-len", 3000, "--lr-profile", "ont", "--lr-err", 0.07], ["--snps"])
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre + "_plain"], stderr=subprocess.DEVNULL)
+    return pre
+
+
 def golden_rows():
     path = os.path.join(ROOT, "tests", "golden", "edlib_golden.tsv")
     rows = []

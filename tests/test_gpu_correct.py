@@ -60,3 +60,9 @@ def test_gpu_overlapped_stages_give_the_same_records(ds_medium):
 
 def test_gpu_correct_short_cycles(ds_tandem):
     _check(ds_tandem, 40, None)
+
+
+def test_gpu_correct_snp_annotations(ds_snps):
+    """SNP-annotated index: getAmbiguityVector / fixAmbiguity on the GPU equal the oracle's."""
+    _check(ds_snps, 40, None)
+    _check(ds_snps, 12, None, opts=dict(min_confidence_snp_corr=0.5, out_qual=3, max_qual=30))

@@ -58,37 +58,31 @@ def test_sim_correct_k25(ds_k25):
     _check(ds_k25, 6, SIM_LIB, extra, k=25)
 
 
-def test_annotated_index_is_refused_then_stripped(ds_clean, tmp_path):
-    """An index whose unitig data carries SNP-ambiguity annotations (what the reference's `index` step writes unless -F,
-    src/Graph.cpp:484) is refused loudly by the run entry points; rtk_graph_strip_annotations makes it equal to the unannotated index."""
+def test_sim_correct_snp_annotations(ds_snps):
+    """Index with SNP annotations (what the reference's `index` step writes unless -F, src/Graph.cpp:484): getAmbiguityVector
+    (src/GraphTraversal.cpp:966-1036) and fixAmbiguity (src/Alignment.cpp:527-844) on the device equal the oracle's, also with
+    another confidence threshold (-m) and quality range; and they do change results."""
+    _, got, seqs = _check(ds_snps, 40, SIM_LIB)
+    _check(ds_snps, 12, SIM_LIB, opts=dict(min_confidence_snp_corr=0.5, out_qual=3, max_qual=30))
+    plain = api.Graph(ds_snps + "_plain.index.k31.fasta.gz", ds_snps + "_plain.index.k31.rtsk", 31, device=0, lib_path=SIM_LIB).correct_batch(seqs, ["I" * len(x) for x in seqs])
+    assert sum(1 for a, b in zip(got, plain) if a != b) >= 5
+    assert all(len(a[0]) == len(a[1]) for a in got)
+
+
+def test_strip_annotations_gives_the_plain_index(ds_snps):
+    """rtk_graph_strip_annotations (CLI --strip-annotations) drops the SNP / short-cycle annotations before the upload: same results
+    as the index built without them."""
     import ctypes as C
-    import shutil
-    import struct
-    import pytest
-    fa, rt = ds_clean + ".index.k31.fasta.gz", ds_clean + ".index.k31.rtsk"
-    rt2 = str(tmp_path / "annot.rtsk")
-    shutil.copy(rt, rt2)
-    with open(rt2, "r+b") as f:  # first record: 16-byte head k-mer, u64 coverage, u64 shared, then the PairID streams global, local, ambiguity, ...
-        off = 32
-        for _ in range(2):  # skip the global and the local colour sets
-            f.seek(off); (w,) = struct.unpack("<Q", f.read(8)); off += 8 + ((w >> 3) if (w & 7) == 3 else 0)
-        f.seek(off); (w,) = struct.unpack("<Q", f.read(8))
-        assert w == 1  # empty ambiguity set
-        f.seek(off); f.write(struct.pack("<Q", ((1 << 5) << 3) | 1))  # bit-vector form holding id 5
-    reads = op.read_fastq(ds_clean + ".lr.fq")[:3]
+    fa, rt = ds_snps + ".index.k31.fasta.gz", ds_snps + ".index.k31.rtsk"
+    reads = op.read_fastq(ds_snps + ".lr.fq")[:6]
     seqs, quals = [r[1] for r in reads], [r[2] for r in reads]
-    pg = api.Graph(fa, rt2, 31, device=0, lib_path=SIM_LIB)
-    with pytest.raises(api.RtkError) as e:
-        api.Batch(pg, seqs, quals).run()
-    assert "annotations" in str(e.value)
-    # same files, annotations dropped before the upload: results of the plain index
     L = api.load_library(SIM_LIB)
     h = C.c_void_p()
-    assert L.rtk_graph_load(fa.encode(), rt2.encode(), 31, 1, C.byref(h)) == 0
-    assert L.rtk_graph_strip_annotations(h) == 1
+    assert L.rtk_graph_load(fa.encode(), rt.encode(), 31, 1, C.byref(h)) == 0
+    assert L.rtk_graph_strip_annotations(h) > 100
     assert L.rtk_graph_upload(h, 0) == 0
     o = api.RtkOpts(); assert L.rtk_opts_default(h, C.byref(o)) == 0
-    want = api.Graph(fa, rt, 31, device=0, lib_path=SIM_LIB).correct_batch(seqs, quals)
+    want = api.Graph(ds_snps + "_plain.index.k31.fasta.gz", ds_snps + "_plain.index.k31.rtsk", 31, device=0, lib_path=SIM_LIB).correct_batch(seqs, quals)
     n = len(seqs)
     sa = (C.c_char_p * n)(*[s.encode() for s in seqs]); qa = (C.c_char_p * n)(*[q.encode() for q in quals]); la = (C.c_uint32 * n)(*[len(s) for s in seqs])
     os_, oq, ol = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_uint32 * n)()
