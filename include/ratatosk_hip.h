@@ -91,12 +91,10 @@ int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n);
 
 int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info);
 void rtk_graph_free(rtk_graph* g);
-/* Indexes written by the reference carry short-cycle annotations (detectShortCycles, src/Graph.cpp:4660, always; consumed by the
- * built fixRepeats) and SNP-ambiguity annotations (detectSNPs, src/Graph.cpp:484, unless -F); the consumer of the latter, fixAmbiguity
- * (SURVEY.md 8a a14), is not built yet and such an index is refused at run time (RTK_ERR_UNSUPPORTED). This call drops BOTH kinds of
- * annotation from a loaded graph BEFORE
- * rtk_graph_upload, which makes the graph identical to one whose index was written without them: corrections then differ from the
- * reference's wherever a path crosses an annotated unitig. Returns the number of unitigs that carried an annotation, < 0 on error. */
+/* Indexes written by the reference carry short-cycle annotations (detectShortCycles, src/Graph.cpp:4660, always) and SNP-ambiguity
+ * annotations (detectSNPs, src/Graph.cpp:484, unless -F); both are consumed (fixRepeats, fixAmbiguity). This call drops BOTH kinds
+ * from a loaded graph BEFORE rtk_graph_upload, which makes the graph identical to one whose index was written without them.
+ * Returns the number of unitigs that carried an annotation, < 0 on error. */
 long long rtk_graph_strip_annotations(rtk_graph* g);
 
 /* Correct_Opt defaults + max_km_cov derived from the graph (reference: src/Common.hpp:101-156, src/Ratatosk.cpp:625). */

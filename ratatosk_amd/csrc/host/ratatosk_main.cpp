@@ -24,6 +24,7 @@ struct Opt {
     std::vector<std::string> in_long;
     std::string out, graph, udata;
     int cores = 1, k1 = 31, max_qual = 40;
+    double min_conf_snp = 0.9;
     size_t insert_sz = 500, w1 = 1000, batch_bases = 64u << 20;
     bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false;
 };
@@ -32,7 +33,8 @@ static void usage() {
     fprintf(stderr, "Ratatosk (MI355X hot-path build)\n\nUsage: Ratatosk correct -1 -g <graph.fasta.gz> -d <unitig_data.rtsk> -l <long_reads> -o <out_prefix> [options]\n"
                     "  -c, --cores           number of GPUs/worker threads to use (default 1)\n  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
-                    "  -Q, --max-base-qual   maximum base quality (default 40)\n  -v, --verbose\n      --strip-annotations  accept an index with short-cycle / SNP annotations by dropping them (results then differ from the reference there)\n"
+                    "  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
+                    "      --strip-annotations  drop the short-cycle / SNP annotations of the index before correcting (fixRepeats / fixAmbiguity then have nothing to do)\n"
                     "Writes <out_prefix>.2.fastq (plain FASTQ, input order). Only the `correct -1` step with a pre-built index is in scope.\n");
 }
 
@@ -45,10 +47,10 @@ int main(int argc, char** argv) {
     else { usage(); return 0; }
     static struct option lo[] = {{"in-long", required_argument, 0, 'l'}, {"out-long", required_argument, 0, 'o'}, {"cores", required_argument, 0, 'c'},
         {"in-graph", required_argument, 0, 'g'}, {"in-unitig-data", required_argument, 0, 'd'}, {"insert-sz", required_argument, 0, 'i'}, {"k1", required_argument, 0, 'k'},
-        {"max-len-weak1", required_argument, 0, 'w'}, {"max-base-qual", required_argument, 0, 'Q'}, {"1st-pass-only", no_argument, 0, '1'}, {"2nd-pass-only", no_argument, 0, '2'},
+        {"max-len-weak1", required_argument, 0, 'w'}, {"max-base-qual", required_argument, 0, 'Q'}, {"min-conf-snp-corr", required_argument, 0, 'm'}, {"1st-pass-only", no_argument, 0, '1'}, {"2nd-pass-only", no_argument, 0, '2'},
         {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
     int c, idx = 0;
-    while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:B:12v", lo, &idx)) != -1) {
+    while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:12v", lo, &idx)) != -1) {
         switch (c) {
             case 'l': opt.in_long.push_back(optarg); break;
             case 'o': opt.out = optarg; break;
@@ -59,6 +61,7 @@ int main(int argc, char** argv) {
             case 'k': opt.k1 = atoi(optarg); break;
             case 'w': opt.w1 = strtoull(optarg, nullptr, 10); break;
             case 'Q': opt.max_qual = atoi(optarg); break;
+            case 'm': opt.min_conf_snp = atof(optarg); break;
             case 'B': opt.batch_bases = strtoull(optarg, nullptr, 10); break;
             case '1': opt.pass1 = true; break;
             case '2': opt.pass2 = true; break;
@@ -71,6 +74,7 @@ int main(int argc, char** argv) {
     if (opt.pass2 || !opt.pass1) { fprintf(stderr, "Ratatosk::correct: only the first pass (-1) with a pre-built index (-g, -d) is in scope of this build\n"); return 1; }
     if (opt.graph.empty() || opt.udata.empty() || opt.in_long.empty() || opt.out.empty()) { fprintf(stderr, "Ratatosk::correct: -g, -d, -l and -o are required\n"); return 0; }
     if (opt.cores < 1) opt.cores = 1;
+    if (opt.min_conf_snp < 0.0 || opt.min_conf_snp > 1.0) { fprintf(stderr, "Ratatosk::Ratatosk(): Minimum confidence threshold to correct a SNP must be in [0.0, 1.0].\n"); return 0; } // src/Ratatosk.cpp:366-376
 
     // input files (a text file lists one path per line: src/Common.cpp:428-446)
     std::vector<std::string> files;
@@ -83,14 +87,14 @@ int main(int argc, char** argv) {
     std::vector<rtk_graph*> graphs(n_gpus, nullptr);
     for (int w = 0; w < n_gpus; ++w) {
         bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, 1, &graphs[w]) == RTK_OK;
-        if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[w]); if (w == 0 && ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs (fixRepeats / fixAmbiguity are not built)\n", ns); }
+        if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[w]); if (w == 0 && ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs\n", ns); }
         if (!ok || rtk_graph_upload(graphs[w], w) != RTK_OK) {
             fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error());
             exit(1);
         }
     }
     rtk_opts ro; rtk_opts_default(graphs[0], &ro);
-    ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_qual = opt.max_qual;
+    ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_qual = opt.max_qual; ro.min_confidence_snp_corr = opt.min_conf_snp;
 
     const std::string fn_out = opt.out + ".2.fastq"; // opt_pass1.filename_long_out += ".2" (src/Ratatosk.cpp:1079) + ".fastq" (:622)
     FILE* fout = fopen(fn_out.c_str(), "w");

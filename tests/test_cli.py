@@ -82,3 +82,22 @@ def test_cli_fasta_input_through_a_list_file(ds_small, tmp_path):
     want, _ = op.Graph(fa, rt, 31).correct_batch([x[1] for x in reads], None, threads=4)
     assert [g[0] for g in got] == [x[0] for x in reads]
     assert [(g[1], g[2]) for g in got] == want
+
+
+@pytest.mark.gpu
+def test_cli_snp_annotated_index_and_min_conf_option(ds_snps, tmp_path):
+    """-m / --min-conf-snp-corr (src/Ratatosk.cpp:240) reaches fixAmbiguity; --strip-annotations gives the plain index."""
+    fa, rt = ds_snps + ".index.k31.fasta.gz", ds_snps + ".index.k31.rtsk"
+    reads = op.read_fastq(ds_snps + ".lr.fq")
+    seqs, quals = [x[1] for x in reads], [x[2] for x in reads]
+    out = str(tmp_path / "out")
+    r = subprocess.run([EXE, "correct", "-1", "-c", "1", "-m", "0.5", "-g", fa, "-d", rt, "-l", ds_snps + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    og = op.Graph(fa, rt, 31)
+    want, _ = og.correct_batch(seqs, quals, opts=og.opts(min_confidence_snp_corr=0.5), threads=4)
+    assert [(g[1], g[2]) for g in op.read_fastq(out + ".2.fastq")] == want
+    r = subprocess.run([EXE, "correct", "-1", "-c", "1", "--strip-annotations", "-g", fa, "-d", rt, "-l", ds_snps + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0 and "dropped" in r.stderr, r.stderr
+    plain, _ = op.Graph(ds_snps + "_plain.index.k31.fasta.gz", ds_snps + "_plain.index.k31.rtsk", 31).correct_batch(seqs, quals, threads=4)
+    assert [(g[1], g[2]) for g in op.read_fastq(out + ".2.fastq")] == plain
+    assert want != plain
