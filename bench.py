@@ -39,18 +39,23 @@ def parse():
     ap.add_argument("--cpu-sample-bases", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--plain-index", action="store_true", help="index without SNP annotations (like the reference's `index -F`); for A/B measurements only")
     ap.add_argument("--sim", action="store_true", help="CPU-only developer simulator + gloo (tests of the N>1 plumbing); never a benchmark")
     return ap.parse_args()
 
 
-def make_dataset(workdir, ref_len, lr_bases):
+def make_dataset(workdir, ref_len, lr_bases, snps=True):
     """Seeded synthetic inputs + index in the reference's file formats."""
     bin_dir = os.path.join(ROOT, "ratatosk_amd", "bin")
     pre = os.path.join(workdir, "c2")
     lr_cov = max(1.0, float(lr_bases) / ref_len)
     subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "2", "--ref-len", str(ref_len), "--sr-cov", "30",
                            "--sr-err", "0.005", "--lr-cov", "%.3f" % lr_cov, "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07"], stderr=subprocess.DEVNULL)
-    subprocess.check_call([os.path.join(bin_dir, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre], stderr=subprocess.DEVNULL)
+    # --snps: SNP annotations like the reference's default `index` step (detectSNPs runs unless -F, src/Ratatosk.cpp:1120-1127)
+    r = subprocess.run([os.path.join(bin_dir, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + (["--snps"] if snps else []), stderr=subprocess.PIPE, text=True, check=True)
+    for line in r.stderr.splitlines():
+        if "SNP annotations" in line:
+            sys.stderr.write(line + "\n")
     return pre
 
 
@@ -109,7 +114,7 @@ def main():
     if rank == 0:
         workdir = a.workdir or tempfile.mkdtemp(prefix="rtk_bench_")
         t0 = time.time()
-        pre = make_dataset(workdir, a.ref_len, min(need_bases, 30 * a.ref_len))
+        pre = make_dataset(workdir, a.ref_len, min(need_bases, 30 * a.ref_len), snps=not a.plain_index)
         t_data = time.time() - t0
     else:
         pre, t_data = None, 0.0

@@ -134,12 +134,24 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
     const uint64_t* v = s.list[RTK_L_AMB];
     uint64_t* ms = s.list[RTK_L_AMB + 1]; uint64_t* ma = s.list[RTK_L_AMB + 2]; uint64_t* vu = s.list[RTK_L_AMB + 3]; uint64_t* sa = s.list[RTK_L_AMB + 4];
     uint32_t nms = 0, nma = 0, nsa = 0;
+    for (uint32_t i = 0; i < n_amb; ++i) {
+        const uint32_t p = rtk_amb_pos(v[i]);
+        if (quality[p] < q_min_conf_corr && rtk_amb_find(ms, nms, p) < 0) ms[nms++] = v[i]; // n_amb <= cap
+    }
+    if (nms == 0) {
+        // every annotated base is confident: nothing enters the sets unless the alignment meets a non-ACGT character of the
+        // corrected or the raw region (:630-678), and with both clean the whole call leaves query and quality as they are
+        bool odd = false;
+        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < query_len; i += RTK_WAVE) odd |= !rtk_is_dna(query[i]);
+        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < ref_len; i += RTK_WAVE) odd |= !rtk_is_dna(ref[i]);
+        if (rtk_ballot(odd) == 0) return;
+    }
     char* qt = s.str[0]; // query_tmp
     rtk_wcopy(qt, query, query_len);
     rtk_sync();
     for (uint32_t i = 0; i < n_amb; ++i) {
         const uint32_t p = rtk_amb_pos(v[i]);
-        if (quality[p] < q_min_conf_corr) { if (rtk_amb_find(ms, nms, p) < 0) ms[nms++] = v[i]; qt[p] = rtk_amb_chr(v[i]); } // n_amb <= cap
+        if (quality[p] < q_min_conf_corr) qt[p] = rtk_amb_chr(v[i]);
     }
     for (uint32_t i = 0; i < nms; ++i) ma[i] = ms[i];
     nma = nms;

@@ -27,6 +27,7 @@
 #include <queue>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../common/fastx.hpp"
@@ -267,9 +268,8 @@ int main(int argc, char** argv) {
     // ---- SNP annotations (simplified stand-in for detectSNPs, see the header) ----
     std::vector<std::vector<uint32_t> > ambiguity(n);
     if (detect_snps) {
-        size_t n_amb = 0, n_amb_unitigs = 0;
-        for (size_t u = 0; u < n; ++u) {
-            if (!(shared[u] & 0xffULL)) continue; // hasSharedPids (src/Graph.cpp:500)
+        auto annotate = [&](size_t u) {
+            if (!(shared[u] & 0xffULL)) return; // hasSharedPids (src/Graph.cpp:500)
             const std::string& s = U[u].seq;
             std::vector<uint8_t> fin(s.size(), 0);
             std::set<size_t> ok, bad;
@@ -302,9 +302,16 @@ int main(int argc, char** argv) {
                     }
                 }
             }
-            for (size_t i = 0; i < fin.size(); ++i) if (fin[i]) { ambiguity[u].push_back(static_cast<uint32_t>((i << 4) + fin[i])); ++n_amb; } // UnitigData.hpp:448-451
-            if (!ambiguity[u].empty()) ++n_amb_unitigs;
+            for (size_t i = 0; i < fin.size(); ++i) if (fin[i]) ambiguity[u].push_back(static_cast<uint32_t>((i << 4) + fin[i])); // UnitigData.hpp:448-451
+        };
+        { // unitigs are independent and the k-mer table is only read: one strided slice per thread
+            unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64;
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (size_t u = t; u < n; u += nt) annotate(u); });
+            for (size_t t = 0; t < th.size(); ++t) th[t].join();
         }
+        size_t n_amb = 0, n_amb_unitigs = 0;
+        for (size_t u = 0; u < n; ++u) { n_amb += ambiguity[u].size(); n_amb_unitigs += ambiguity[u].empty() ? 0 : 1; }
         fprintf(stderr, "rtk_build_index: %zu SNP annotations on %zu unitigs\n", n_amb, n_amb_unitigs);
     }
 
