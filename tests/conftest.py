@@ -83,6 +83,15 @@ def ds_snps(tmp_path_factory):
     return pre
 
 
+@pytest.fixture(scope="session")
+def ds_snps_rich(tmp_path_factory):
+    """Everything at once: diploid (0.6 % SNPs), two-copy repeats, tandem repeats, global colour sets, index with SNP AND short-cycle
+    annotations."""
+    d = tmp_path_factory.mktemp("ds_snps_rich")
+    return make_dataset(d, "rich", ["--seed", 41, "--ref-len", 200000, "--het", 0.006, "--repeat-frac", 0.05, "--tandem", 10, "--sr-cov", 35, "--sr-err", 0.005,
+                                    "--lr-n", 80, "--lr-len", 5000, "--lr-profile", "ont", "--lr-err", 0.07], ["--snps", "--global-cov-factor", 1.5])
+
+
 def golden_rows():
     path = os.path.join(ROOT, "tests", "golden", "edlib_golden.tsv")
     rows = []

@@ -1,5 +1,7 @@
 """End-to-end parity of the HIP path (all kernels, through the C ABI) with the oracle: corrected FASTQ records must be
 byte-identical (sequence and quality) on seeded synthetic inputs, including the edge cases the reference handles."""
+import os
+
 import pytest
 
 from oracle import oracle_py as op
@@ -37,7 +39,6 @@ def test_gpu_correct_k25(ds_k25):
 
 def test_gpu_correct_volume(ds_medium):
     """1.3 Mb of ONT-profile reads on a repeat-bearing diploid graph, oracle on all host threads."""
-    import os
     st, got, seqs = _check(ds_medium, 160, None, threads=os.cpu_count() or 4)
     assert st["n_regions"] > 5000
 
@@ -45,7 +46,6 @@ def test_gpu_correct_volume(ds_medium):
 def test_gpu_overlapped_stages_give_the_same_records(ds_medium):
     """Three batches through api.run_pipelined (seed stage of batch i+1 beside the region stage of batch i, one stream each, shared
     cached scratch slots): every batch must still equal the oracle."""
-    import os
     from ratatosk_amd import api
     fa, rt = ds_medium + ".index.k31.fasta.gz", ds_medium + ".index.k31.rtsk"
     og, pg = op.Graph(fa, rt, 31), api.Graph(fa, rt, 31, device=0)
@@ -66,3 +66,10 @@ def test_gpu_correct_snp_annotations(ds_snps):
     """SNP-annotated index: getAmbiguityVector / fixAmbiguity on the GPU equal the oracle's."""
     _check(ds_snps, 40, None)
     _check(ds_snps, 12, None, opts=dict(min_confidence_snp_corr=0.5, out_qual=3, max_qual=30))
+
+
+def test_gpu_snp_annotations_with_repeats_cycles_and_tiny_scratch(ds_snps_rich, ds_snps, monkeypatch):
+    _check(ds_snps_rich, 80, None, threads=os.cpu_count() or 4)
+    monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
+    st, _, _ = _check(ds_snps, 20, None, counters_must_match=False)
+    assert st["n_arena_overflow"] > 0

@@ -69,6 +69,15 @@ def test_sim_correct_snp_annotations(ds_snps):
     assert all(len(a[0]) == len(a[1]) for a in got)
 
 
+def test_sim_snp_annotations_with_repeats_cycles_and_tiny_scratch(ds_snps_rich, ds_snps, monkeypatch):
+    """SNP annotations together with short cycles, repeats and global colour sets; and with work areas that overflow (the sets of
+    rtk_ambiguity.h live in the region scratch lists: affected regions are redone with bigger ones)."""
+    _check(ds_snps_rich, 16, SIM_LIB)
+    monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
+    st, _, _ = _check(ds_snps, 10, SIM_LIB, counters_must_match=False)
+    assert st["n_arena_overflow"] > 0
+
+
 def test_strip_annotations_gives_the_plain_index(ds_snps):
     """rtk_graph_strip_annotations (CLI --strip-annotations) drops the SNP / short-cycle annotations before the upload: same results
     as the index built without them."""
