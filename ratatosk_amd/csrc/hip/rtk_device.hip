@@ -39,7 +39,7 @@ extern "C" void rtk_free(void* p) { free(p); }
 // ------------------------------------------------------------------------------------------------ graph object
 struct rtk_graph {
     rtk::FlatGraph host;
-    bool has_host = false, on_device = false, unsupported_annotations = false, owns_buffers = true;
+    bool has_host = false, on_device = false, owns_buffers = true;
     int device = -1;
     void* dbuf[rtk::RTK_N_BUFS];
     uint64_t dbytes[rtk::RTK_N_BUFS];
@@ -177,7 +177,6 @@ extern "C" long long rtk_graph_strip_annotations(rtk_graph* g) {
     long long n = 0;
     for (size_t u = 0; u < g->host.flags.size(); ++u) if (g->host.flags[u] & (RTK_F_SHORT_CYCLE | RTK_F_AMBIGUITY)) { g->host.flags[u] &= ~static_cast<uint32_t>(RTK_F_SHORT_CYCLE | RTK_F_AMBIGUITY); ++n; }
     g->host.amb.assign(g->host.flags.size() + 1, 0);
-    g->unsupported_annotations = false;
     return n;
 }
 
