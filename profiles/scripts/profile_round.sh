@@ -13,6 +13,8 @@ SERIAL="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial"   # cou
 timeout 900 python bench.py > $SUM/${R}_bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats of the same command
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $SUM/${R}_bench_under_rocprof.json 2> $OUT/stats.err
+# 2b. the same with the steps back to back (per-kernel durations undisturbed by the next step's seed kernels)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o stats -- python bench.py --no-cpu-baseline --serial > /dev/null 2> $OUT/stats_serial.err
 # 3. PMC passes, each on its own (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $SERIAL > /dev/null 2> $OUT/fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $SERIAL > /dev/null 2> $OUT/write.err

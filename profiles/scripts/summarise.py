@@ -41,6 +41,11 @@ if f:
     rows = list(csv.reader(open(f)))
     with open(os.path.join(summ, rnd + "_kernel_stats.csv"), "w") as g:
         csv.writer(g).writerows(rows)
+f = find("stats_serial", "*kernel_stats.csv")
+if f:
+    rows = list(csv.reader(open(f)))
+    with open(os.path.join(summ, rnd + "_kernel_stats_serial.csv"), "w") as g:
+        csv.writer(g).writerows(rows)
 res = {"units": "FETCH_SIZE / WRITE_SIZE are KB as reported by rocprofv3; *_bytes fields are converted (x1024)"}
 fe, wr, sq = pmc("fetch", "*counter_collection.csv"), pmc("write", "*counter_collection.csv"), pmc("sq", "*counter_collection.csv")
 cf, cw = pmc("calib_fetch", "*counter_collection.csv"), pmc("calib_write", "*counter_collection.csv")
