@@ -440,6 +440,157 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 1-edit search by half-k-mer seeds ([A2], same hit sets as above)
+// A graph k-mer G one edit away from a read window keeps its first h or its last h characters (h = (k-1)/2, the middle character
+// belongs to neither half): the edit cannot touch both. So instead of spelling the ~246 variants of a window and probing each, a lane
+// looks up the read h-mers that would be G's first half (1 key) or G's last half (3 keys: substitution, graph-has-extra-base, graph-
+// lacks-a-base shift the second half by 0 / -1 / +1) in the index of all unitig h-mers (GraphView::hx), in both orientations, and
+// checks the k-mers those h-mers belong to with three XOR / count-leading-zero tests. One lane per window.
+
+RTK_DEV uint64_t rtk_rev2(uint64_t x, int n) { // reverses the order of the n 2-bit groups held in the low 2n bits
+    uint64_t y = rtk_brev64(x);
+    y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+    return (n >= 32) ? y : (y >> (64 - 2 * n));
+}
+RTK_DEV uint64_t rtk_pool_kmer(const GraphView& g, uint64_t gp, int k) { // 2-bit code (first base in the high bits) of the k bases of the unitig pool at gp
+    const uint64_t w0 = g.useq[gp >> 5], w1 = g.useq[(gp >> 5) + 1];
+    const int sh = static_cast<int>(2 * (gp & 31ull));
+    uint64_t lsb = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+    if (k < 32) lsb &= (1ull << (2 * k)) - 1ull;
+    return rtk_rev2(lsb, k);
+}
+RTK_DEV int rtk_clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+RTK_DEV int rtk_ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
+
+// is G one of the 1-edit variants of the window whose first k-1 characters are w_k1 (and ck, ck1 the next two, 4 = unusable)? (oracle: searchInexact)
+RTK_DEV bool rtk_one_edit(uint64_t G, int k, uint64_t w_k1, uint32_t ck, uint32_t ck1) {
+    const uint64_t mk = (k < 32) ? ((1ull << (2 * k)) - 1ull) : ~0ull, mk1 = (1ull << (2 * (k - 1))) - 1ull;
+    if (ck <= 3) { // substitution: exactly one differing character
+        const uint64_t x = (G ^ ((w_k1 << 2) | static_cast<uint64_t>(ck))) & mk;
+        if (rtk_popc((x | (x >> 1)) & 0x5555555555555555ull) == 1) return true;
+    }
+    { // G = the k-1 read characters with one base inserted anywhere: common prefix + common suffix cover the k-1 characters
+        const uint64_t xp = ((G >> 2) ^ w_k1) & mk1, xs = (G ^ w_k1) & mk1;
+        const int lcp = xp ? (rtk_clz64(xp) - (64 - 2 * (k - 1))) / 2 : k - 1, lcs = xs ? rtk_ctz64(xs) / 2 : k - 1;
+        if (lcp + lcs >= k - 1) return true;
+    }
+    if (ck <= 3 && ck1 <= 3) { // G = the k+1 read characters without one interior character (offset 1..k-2)
+        const uint64_t S = (w_k1 << 4) | (static_cast<uint64_t>(ck) << 2) | static_cast<uint64_t>(ck1);
+        const uint64_t xp = (G ^ (S >> 2)) & mk, xs = (G ^ S) & mk;
+        const int lcp = xp ? (rtk_clz64(xp) - (64 - 2 * k)) / 2 : k, lcs = xs ? rtk_ctz64(xs) / 2 : k;
+        const int lo = (k - lcs) > 1 ? (k - lcs) : 1, hi = lcp < (k - 2) ? lcp : (k - 2);
+        if (lo <= hi) return true;
+    }
+    return false;
+}
+
+// visits (code, hit) of every graph k-mer that is a 1-edit variant of the window and contains one of its seed h-mers; a k-mer reached
+// through two seeds is visited twice (the hits of a window are reduced to distinct k-mers downstream, src/Graph.cpp:201-216)
+template <class V>
+RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_t ck, uint32_t ck1, uint32_t* n_lookups, uint32_t* n_slots, V visit) {
+    const int h = (k - 1) / 2;
+    const uint64_t hm = (1ull << (2 * h)) - 1ull;
+    const uint64_t* const hx = g.hx; const uint64_t hx_mask = g.hx_mask; const uint64_t* const hxl = g.hxl; const uint64_t* const uoff = g.uoff;
+    // the window's characters as one code: k-1, k or k+1 of them
+    uint64_t key[4]; bool first_half[4]; int nkeys = 0;
+    key[nkeys] = (w_k1 >> (2 * (k - 1 - h))) & hm; first_half[nkeys++] = true;                       // m[p .. p+h)
+    key[nkeys] = w_k1 & hm; first_half[nkeys++] = false;                                              // m[p+k-1-h .. p+k-1): last half when the graph k-mer has an extra base
+    if (ck <= 3) { key[nkeys] = ((w_k1 << 2) | static_cast<uint64_t>(ck)) & hm; first_half[nkeys++] = false; } // m[p+k-h .. p+k): substitution
+    if (ck <= 3 && ck1 <= 3) { key[nkeys] = ((w_k1 << 4) | (static_cast<uint64_t>(ck) << 2) | static_cast<uint64_t>(ck1)) & hm; first_half[nkeys++] = false; } // m[p+k+1-h .. p+k+1): a read base missing in the graph
+    for (int q = 0; q < nkeys; ++q) {
+        for (int ori = 0; ori < 2; ++ori) {
+            const uint64_t x = ori ? rtk_revcomp(key[q], h) : key[q];
+            *n_lookups += 1;
+            uint64_t i = rtk_hash64(x) & hx_mask, val = 0; bool found = false;
+            while (true) { const uint64_t kk = hx[2 * i]; *n_slots += 1; if (kk == x) { val = hx[2 * i + 1]; found = true; break; } if (kk == RTK_EMPTY_KEY) break; i = (i + 1) & hx_mask; }
+            if (!found) continue;
+            const uint64_t first = val >> 24; const uint32_t cnt = static_cast<uint32_t>(val & 0xFFFFFFull);
+            // the unitig h-mer is the first half of the forward k-mer F starting there, or the last half of the one starting h+1 earlier;
+            // read-oriented G = F when the read h-mer itself was found, its reverse complement when the reverse-complemented key was
+            const bool at_start = (first_half[q] != (ori != 0));
+            for (uint32_t e = 0; e < cnt; ++e) {
+                const uint64_t ent = hxl[first + e];
+                const uint32_t u = static_cast<uint32_t>(ent >> 32), pos = static_cast<uint32_t>(ent & 0xFFFFFFFFull);
+                const uint64_t u0 = uoff[u], ulen = uoff[u + 1] - u0;
+                int64_t t = static_cast<int64_t>(pos) - (at_start ? 0 : (h + 1));
+                if (t < 0 || static_cast<uint64_t>(t) + static_cast<uint64_t>(k) > ulen) continue;
+                const uint64_t F = rtk_pool_kmer(g, u0 + static_cast<uint64_t>(t), k);
+                const uint64_t G = ori ? rtk_revcomp(F, k) : F;
+                if (rtk_one_edit(G, k, w_k1, ck, ck1)) visit(G, rtk_pack_hit(u, static_cast<uint32_t>(t), ori ? 0u : 1u));
+            }
+        }
+    }
+}
+
+RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk) {
+    const int k = g.k;
+    const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
+    uint32_t lo_tile = 0; // one scalar search per tile: largest r with roff[r] <= first base of the tile
+    { uint32_t hi = n_reads; const uint64_t b0 = tile * 64; while (hi - lo_tile > 1) { const uint32_t mid = (lo_tile + hi) >> 1; if (rtk_ld(roff + mid) <= b0) lo_tile = mid; else hi = mid; } }
+#ifdef RTK_SIM
+    const int n_sub = 64;
+#else
+    const int n_sub = 1;
+#endif
+    for (int sub = 0; sub < n_sub; ++sub) { // the 1-lane simulator visits the 64 positions of the tile one after the other
+#ifdef RTK_SIM
+        const uint64_t bb = tile * 64 + static_cast<uint64_t>(sub);
+#else
+        const uint64_t bb = tile * 64 + static_cast<uint64_t>(rtk_lane());
+#endif
+        bool cand = false; uint64_t c_k1 = 0; uint32_t ck = 4, ck1 = 4;
+        if (bb < bv.n_bases) {
+            uint32_t lo = lo_tile;
+            while (lo + 1 < n_reads && roff[lo + 1] <= bb) ++lo;
+            const uint64_t rend = roff[lo + 1];
+            if (bb + static_cast<uint64_t>(k) <= rend && rend - roff[lo] > static_cast<uint64_t>(k)) {
+                bool ok = true;
+                const unsigned char* wc = reinterpret_cast<const unsigned char*>(bv.masked.get()) + bb;
+                for (int i = 0; i < k - 1; ++i) { const int c = rtk_cls(wc[i]); if (c > 3) { ok = false; break; } c_k1 = (c_k1 << 2) | static_cast<uint64_t>(c); }
+                if (ok) {
+                    cand = true;
+                    const int c = rtk_cls(wc[k - 1]);
+                    if (c <= 3) { ck = static_cast<uint32_t>(c); if (bb + static_cast<uint64_t>(k) + 1 <= rend) { const int c2 = rtk_cls(wc[k]); if (c2 <= 3) ck1 = static_cast<uint32_t>(c2); } }
+                }
+            }
+        }
+        // pass 1: up to four distinct hits of the lane's window stay in registers
+        uint64_t my_code[4], my_hit[4]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
+        if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, [&](uint64_t code, uint64_t hit) {
+            for (int i = 0; i < my_n; ++i) if (my_hit[i] == hit) return;
+            if (my_n < 4) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; } else more = true;
+        });
+        *acc_probes += lookups; *acc_slots += slots;
+        if (more) { // a window inside a repeat: count every visit, take a private slice of the pool, write them all
+            uint32_t n_all = 0, l2 = 0, s2 = 0;
+            rtk_seeded_window(g, k, c_k1, ck, ck1, &l2, &s2, [&](uint64_t, uint64_t) { ++n_all; });
+            const unsigned long long pb = rtk_atomic_add(bv.ipool_top, static_cast<unsigned long long>(n_all));
+            if (pb + n_all <= bv.ipool_cap && n_all < (1u << 24)) {
+                uint32_t w = 0;
+                rtk_seeded_window(g, k, c_k1, ck, ck1, &l2, &s2, [&](uint64_t code, uint64_t hit) { bv.ipool[2 * (pb + w)] = code; bv.ipool[2 * (pb + w) + 1] = hit; ++w; });
+                bv.wdesc[bb] = (static_cast<uint64_t>(pb) << 24) | static_cast<uint64_t>(n_all);
+                rtk_atomic_add(bv.counters + RTK_CNT_HITS_INEXACT, static_cast<unsigned long long>(n_all));
+            } else rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
+            my_n = 0;
+        }
+        int total; const int off = rtk_wave_excl_scan(my_n, &total);
+        if (total > 0) {
+            if (chunk->left < static_cast<uint32_t>(total)) { // refill the wave's private slice (the tail of the old slice is abandoned)
+                unsigned long long nb = 0;
+                if (rtk_lane() == 0) nb = rtk_atomic_add(bv.ipool_top, static_cast<unsigned long long>(RTK_POOL_CHUNK));
+                chunk->base = rtk_shfl(nb, 0); chunk->left = RTK_POOL_CHUNK;
+            }
+            const unsigned long long pbase = chunk->base;
+            chunk->base += static_cast<unsigned long long>(total); chunk->left -= static_cast<uint32_t>(total);
+            if (pbase + static_cast<unsigned long long>(total) <= bv.ipool_cap) {
+                for (int i = 0; i < my_n; ++i) { bv.ipool[2 * (pbase + off + i)] = my_code[i]; bv.ipool[2 * (pbase + off + i) + 1] = my_hit[i]; }
+                if (my_n) bv.wdesc[bb] = (static_cast<uint64_t>(pbase + off) << 24) | static_cast<uint64_t>(my_n);
+            } else if (rtk_lane() == 0) rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
+            if (rtk_lane() == 0) *acc_hits += static_cast<unsigned long long>(total);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- finalize (src/Graph.cpp:201-372)
 RTK_DEV bool rtk_char_eq_base(char c, uint32_t b) { return rtk_cls(static_cast<unsigned char>(c)) == static_cast<int>(b); }
 

@@ -25,11 +25,12 @@ GraphView FlatGraph::view() const {
     v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1;
     v.cycoff = cycoff.data(); v.cyc = reinterpret_cast<const char*>(cyc.data());
     v.amb = amb.data(); v.n_amb = amb.size() - (static_cast<uint64_t>(n_unitigs()) + 1);
+    v.hx = hx.data(); v.hx_mask = hx.size() / 2 - 1; v.hxl = hxl.data();
     return v;
 }
 
 uint64_t FlatGraph::bytes() const {
-    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
+    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size() + hx.size() + hxl.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
 void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int /*n_threads*/) {
@@ -63,6 +64,41 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             const uint64_t p = uoff[u] + i;
             useq[p >> 5] |= static_cast<uint64_t>(b) << (2 * (p & 31));
         }
+    }
+    // ---- half-k-mer index: every h-mer (h = (k-1)/2) of the forward unitig sequences -> the places it starts. A graph k-mer one edit
+    // away from a read window shares its first or its last h characters with the read (the edit cannot be in both), so the 1-edit search
+    // looks up read h-mers here and verifies the few k-mers they belong to instead of spelling every variant of the window.
+    {
+        const int h = (k - 1) / 2;
+        std::vector<std::pair<uint64_t, uint64_t> > pairs;
+        pairs.reserve(uoff[n]);
+        const uint64_t hm = (1ull << (2 * h)) - 1ull;
+        for (size_t u = 0; u < n; ++u) {
+            const std::string& s = seqs[u];
+            uint64_t fw = 0;
+            for (size_t i = 0; i < s.size(); ++i) {
+                fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & hm;
+                if (i + 1 >= static_cast<size_t>(h)) pairs.push_back(std::make_pair(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h)));
+            }
+        }
+        std::sort(pairs.begin(), pairs.end());
+        uint64_t uniq = 0;
+        for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].first != pairs[i - 1].first) ++uniq;
+        uint64_t hslots = 16;
+        while (hslots < 2 * uniq) hslots <<= 1;
+        hx.assign(2 * hslots, 0);
+        for (uint64_t i = 0; i < hslots; ++i) hx[2 * i] = RTK_EMPTY_KEY;
+        hxl.resize(pairs.size() + 1);
+        for (size_t i = 0; i < pairs.size();) {
+            size_t j = i;
+            while (j < pairs.size() && pairs[j].first == pairs[i].first) { hxl[j] = pairs[j].second; ++j; }
+            if (j - i >= (1ull << 24)) throw std::runtime_error("an h-mer occurs more than 2^24 times in the unitigs: the half-k-mer index cannot hold it");
+            uint64_t q = rtk_hash64(pairs[i].first) & (hslots - 1);
+            while (hx[2 * q] != RTK_EMPTY_KEY) q = (q + 1) & (hslots - 1);
+            hx[2 * q] = pairs[i].first; hx[2 * q + 1] = (static_cast<uint64_t>(i) << 24) | static_cast<uint64_t>(j - i);
+            i = j;
+        }
+        hxl[pairs.size()] = 0;
     }
     // ---- k-mer -> (unitig, offset, orientation) table, load factor <= 0.5 ----
     uint64_t slots = 16;
