@@ -510,6 +510,7 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
             const bool at_start = (first_half[q] != (ori != 0));
             for (uint32_t e = 0; e < cnt; ++e) {
                 const uint64_t ent = hxl[first + e];
+                *n_slots += 2; // a candidate costs its list entry, the unitig bounds and 16 bytes of unitig sequence
                 const uint32_t u = static_cast<uint32_t>(ent >> 32), pos = static_cast<uint32_t>(ent & 0xFFFFFFFFull);
                 const uint64_t u0 = uoff[u], ulen = uoff[u + 1] - u0;
                 int64_t t = static_cast<int64_t>(pos) - (at_start ? 0 : (h + 1));
@@ -522,6 +523,9 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
     }
 }
 
+#ifndef RTK_SEED_REGS
+#define RTK_SEED_REGS 4 // distinct hits of a window kept in registers; windows with more take the counted slow path
+#endif
 RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk) {
     const int k = g.k;
     const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
@@ -555,10 +559,10 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
             }
         }
         // pass 1: up to four distinct hits of the lane's window stay in registers
-        uint64_t my_code[4], my_hit[4]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
+        uint64_t my_code[RTK_SEED_REGS], my_hit[RTK_SEED_REGS]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
         if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, [&](uint64_t code, uint64_t hit) {
             for (int i = 0; i < my_n; ++i) if (my_hit[i] == hit) return;
-            if (my_n < 4) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; } else more = true;
+            if (my_n < RTK_SEED_REGS) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; } else more = true;
         });
         *acc_probes += lookups; *acc_slots += slots;
         if (more) { // a window inside a repeat: count every visit, take a private slice of the pool, write them all

@@ -13,3 +13,10 @@ def test_gpu_seeds_branching(ds_small):
 
 def test_gpu_seeds_clean(ds_clean):
     _check(ds_clean, 10, None)
+
+
+def test_gpu_seeds_variant_enumeration_agrees(ds_small, ds_tandem, ds_k25, monkeypatch):
+    assert _check(ds_tandem, 40, None) > 0
+    monkeypatch.setenv("RTK_INEXACT_ENUM", "1")
+    assert _check(ds_small, 12, None) > 0
+    assert _check(ds_tandem, 40, None) > 0

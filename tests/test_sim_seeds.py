@@ -27,3 +27,12 @@ def test_sim_seeds_branching(ds_small):
 
 def test_sim_seeds_clean(ds_clean):
     _check(ds_clean, 6, SIM_LIB)
+
+
+def test_sim_seeds_variant_enumeration_agrees(ds_small, ds_tandem, monkeypatch):
+    """The 1-edit search runs on half-k-mer seeds + verification; spelling and probing every variant (RTK_INEXACT_ENUM=1, the first
+    implementation) must give the same anchors - also where h-mers repeat (tandem repeats: more than four hits per window)."""
+    assert _check(ds_tandem, 10, SIM_LIB) > 0
+    monkeypatch.setenv("RTK_INEXACT_ENUM", "1")
+    assert _check(ds_small, 6, SIM_LIB) > 0
+    assert _check(ds_tandem, 10, SIM_LIB) > 0
