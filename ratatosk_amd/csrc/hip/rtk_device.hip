@@ -81,7 +81,7 @@ static void graph_set_view(rtk_graph* g) {
     v.bf1 = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_BF1]); v.bf1_mask = g->dbytes[rtk::RTK_BUF_BF1] * 8 - 1;
     v.cycoff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_CYCOFF]); v.cyc = static_cast<const char*>(g->dbuf[rtk::RTK_BUF_CYC]);
     v.amb = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_AMB]); v.n_amb = g->dbytes[rtk::RTK_BUF_AMB] / 8 - (static_cast<uint64_t>(v.n_unitigs) + 1);
-    v.hx = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HX]); v.hx_mask = g->dbytes[rtk::RTK_BUF_HX] / 16 - 1; v.hxl = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HXL]);
+    v.hx = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HX]); v.hx_mask = g->dbytes[rtk::RTK_BUF_HX] / 8 - 1; v.hxl = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HXL]);
 }
 
 extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out) {

@@ -501,10 +501,10 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
         for (int ori = 0; ori < 2; ++ori) {
             const uint64_t x = ori ? rtk_revcomp(key[q], h) : key[q];
             *n_lookups += 1;
-            uint64_t i = rtk_hash64(x) & hx_mask, val = 0; bool found = false;
-            while (true) { const uint64_t kk = hx[2 * i]; *n_slots += 1; if (kk == x) { val = hx[2 * i + 1]; found = true; break; } if (kk == RTK_EMPTY_KEY) break; i = (i + 1) & hx_mask; }
+            uint64_t i = rtk_hash64(x) & hx_mask, first = 0; bool found = false;
+            while (true) { const uint64_t sv = hx[i]; *n_slots += 1; if (sv == RTK_EMPTY_KEY) break; if ((sv >> 34) == x) { first = sv & 0x3FFFFFFFFull; found = true; break; } i = (i + 1) & hx_mask; }
             if (!found) continue;
-            const uint64_t first = val >> 24; const uint32_t cnt = static_cast<uint32_t>(val & 0xFFFFFFull);
+            const uint32_t cnt = static_cast<uint32_t>(hxl[first]); ++first;
             // the unitig h-mer is the first half of the forward k-mer F starting there, or the last half of the one starting h+1 earlier;
             // read-oriented G = F when the read h-mer itself was found, its reverse complement when the reverse-complemented key was
             const bool at_start = (first_half[q] != (ori != 0));

@@ -91,9 +91,9 @@ struct GraphView {
     U<const char*> cyc;
     U<const uint64_t*> amb;       // SNP annotations: amb[u]..amb[u+1] index the entries of unitig u, entry j = amb[n_unitigs + 1 + j] = position<<4 | IUPAC index, by (position, code)
     U<uint64_t> n_amb;            // number of annotation entries (0: getAmbiguityVector / fixAmbiguity are identities)
-    U<const uint64_t*> hx;        // [2*(hx_mask+1)] half-k-mer index for the 1-edit search: {h-mer of the forward unitig sequences (h = (k-1)/2), first<<24 | count}
-    U<uint64_t> hx_mask;          //   -> hxl[first .. first+count): every place that h-mer starts, as unitig<<32 | offset; empty key = RTK_EMPTY_KEY
-    U<const uint64_t*> hxl;
+    U<const uint64_t*> hx;        // [hx_mask+1] half-k-mer index for the 1-edit search: slot = h-mer << 34 | first (h = (k-1)/2, h-mers of the forward unitig
+    U<uint64_t> hx_mask;          //   sequences), empty = RTK_EMPTY_KEY; hxl[first] = number of places the h-mer starts, then the places as unitig<<32 | offset.
+    U<const uint64_t*> hxl;       //   hx_mask == 0: no index (the search spells the variants instead)
 };
 
 RTK_HD uint32_t rtk_ulen(const GraphView& g, uint32_t u) { return static_cast<uint32_t>(g.uoff[u + 1] - g.uoff[u]); }

@@ -25,7 +25,7 @@ GraphView FlatGraph::view() const {
     v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1;
     v.cycoff = cycoff.data(); v.cyc = reinterpret_cast<const char*>(cyc.data());
     v.amb = amb.data(); v.n_amb = amb.size() - (static_cast<uint64_t>(n_unitigs()) + 1);
-    v.hx = hx.data(); v.hx_mask = hx.size() / 2 - 1; v.hxl = hxl.data();
+    v.hx = hx.data(); v.hx_mask = hx.size() - 1; v.hxl = hxl.data();
     return v;
 }
 
@@ -68,37 +68,46 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     // ---- half-k-mer index: every h-mer (h = (k-1)/2) of the forward unitig sequences -> the places it starts. A graph k-mer one edit
     // away from a read window shares its first or its last h characters with the read (the edit cannot be in both), so the 1-edit search
     // looks up read h-mers here and verifies the few k-mers they belong to instead of spelling every variant of the window.
+    // hx: one word per slot, h-mer << 34 | first; hxl[first] = number of places, then the places (unitig << 32 | offset).
+    // Not built (a single empty slot; the search then spells the variants) with RTK_INEXACT_ENUM=1 or above RTK_HX_MAX_GB (default 96).
     {
         const int h = (k - 1) / 2;
-        std::vector<std::pair<uint64_t, uint64_t> > pairs;
-        pairs.reserve(uoff[n]);
-        const uint64_t hm = (1ull << (2 * h)) - 1ull;
-        for (size_t u = 0; u < n; ++u) {
-            const std::string& s = seqs[u];
-            uint64_t fw = 0;
-            for (size_t i = 0; i < s.size(); ++i) {
-                fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & hm;
-                if (i + 1 >= static_cast<size_t>(h)) pairs.push_back(std::make_pair(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h)));
+        const char* e_enum = getenv("RTK_INEXACT_ENUM"); const char* e_gb = getenv("RTK_HX_MAX_GB");
+        const double max_gb = e_gb ? atof(e_gb) : 96.0;
+        const double est_gb = static_cast<double>(uoff[n]) * (8.0 * 4.0 + 8.0 * 1.5) / 1e9; // slots at load 0.25..0.5 + list words
+        if ((e_enum && e_enum[0] == '1') || est_gb > max_gb) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); }
+        else {
+            std::vector<std::pair<uint64_t, uint64_t> > pairs;
+            pairs.reserve(uoff[n]);
+            const uint64_t hm = (1ull << (2 * h)) - 1ull;
+            for (size_t u = 0; u < n; ++u) {
+                const std::string& s = seqs[u];
+                uint64_t fw = 0;
+                for (size_t i = 0; i < s.size(); ++i) {
+                    fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & hm;
+                    if (i + 1 >= static_cast<size_t>(h)) pairs.push_back(std::make_pair(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h)));
+                }
             }
+            std::sort(pairs.begin(), pairs.end());
+            uint64_t uniq = 0;
+            for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].first != pairs[i - 1].first) ++uniq;
+            if (pairs.size() + uniq >= (1ull << 34)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
+            uint64_t hslots = 16;
+            while (hslots < 2 * uniq) hslots <<= 1;
+            hx.assign(hslots, RTK_EMPTY_KEY);
+            hxl.clear(); hxl.reserve(pairs.size() + uniq + 1);
+            for (size_t i = 0; i < pairs.size();) {
+                size_t j = i;
+                while (j < pairs.size() && pairs[j].first == pairs[i].first) ++j;
+                uint64_t q = rtk_hash64(pairs[i].first) & (hslots - 1);
+                while (hx[q] != RTK_EMPTY_KEY) q = (q + 1) & (hslots - 1);
+                hx[q] = (pairs[i].first << 34) | static_cast<uint64_t>(hxl.size());
+                hxl.push_back(static_cast<uint64_t>(j - i));
+                for (size_t t = i; t < j; ++t) hxl.push_back(pairs[t].second);
+                i = j;
+            }
+            hxl.push_back(0);
         }
-        std::sort(pairs.begin(), pairs.end());
-        uint64_t uniq = 0;
-        for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].first != pairs[i - 1].first) ++uniq;
-        uint64_t hslots = 16;
-        while (hslots < 2 * uniq) hslots <<= 1;
-        hx.assign(2 * hslots, 0);
-        for (uint64_t i = 0; i < hslots; ++i) hx[2 * i] = RTK_EMPTY_KEY;
-        hxl.resize(pairs.size() + 1);
-        for (size_t i = 0; i < pairs.size();) {
-            size_t j = i;
-            while (j < pairs.size() && pairs[j].first == pairs[i].first) { hxl[j] = pairs[j].second; ++j; }
-            if (j - i >= (1ull << 24)) throw std::runtime_error("an h-mer occurs more than 2^24 times in the unitigs: the half-k-mer index cannot hold it");
-            uint64_t q = rtk_hash64(pairs[i].first) & (hslots - 1);
-            while (hx[2 * q] != RTK_EMPTY_KEY) q = (q + 1) & (hslots - 1);
-            hx[2 * q] = pairs[i].first; hx[2 * q + 1] = (static_cast<uint64_t>(i) << 24) | static_cast<uint64_t>(j - i);
-            i = j;
-        }
-        hxl[pairs.size()] = 0;
     }
     // ---- k-mer -> (unitig, offset, orientation) table, load factor <= 0.5 ----
     uint64_t slots = 16;
