@@ -266,12 +266,31 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
         const int lim = (m - 32 * w) < 32 ? (m - 32 * w) : 32;
         uint64_t qw[4];
         for (int j = 0; j < 4; ++j) { uint64_t x = 0; if (8 * j < lim) __builtin_memcpy(&x, qp + 32 * w + 8 * j, 8); qw[j] = x; } // may read up to 7 bytes past the query inside its padded buffer
-        for (int i = 0; i < lim; ++i) {
-            const unsigned char qc = static_cast<unsigned char>((qw[i >> 3] >> (8 * (i & 7))) & 0xFFull);
-            uint32_t bm;
-            if (qc == 'A') bm = 1u; else if (qc == 'C') bm = 2u; else if (qc == 'G') bm = 4u; else if (qc == 'T') bm = 8u;
-            else bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu;
-            eqA |= (bm & 1u) << i; eqC |= ((bm >> 1) & 1u) << i; eqG |= ((bm >> 2) & 1u) << i; eqT |= ((bm >> 3) & 1u) << i;
+        // four characters at a time: bits 1 and 2 of 'A' 0x41, 'C' 0x43, 'T' 0x54, 'G' 0x47 are a 2-bit code (0, 1, 2, 3); the two bit
+        // planes are gathered into 32-bit masks and the four profile words are their boolean combinations. A word holding anything
+        // else than A/C/G/T (IUPAC codes, N, the bytes past the query) is left to the character-by-character loop below.
+        uint32_t p1 = 0, p2 = 0, done = 0;
+        for (int j = 0; j < 8; ++j) {
+            if (4 * j >= lim) break;
+            const uint32_t x = static_cast<uint32_t>(qw[j >> 1] >> (32 * (j & 1)));
+            const uint32_t b1 = (x >> 1) & 0x01010101u, b2 = (x >> 2) & 0x01010101u;
+            const uint32_t b12 = b1 & b2, b2n = b2 & ~b1;
+            const uint32_t recon = 0x41414141u + (b1 << 1) + (b12 << 2) + (b2n << 4) + (b2n << 1) + b2n; // 0x41 + 2*b1 + 4*b1*b2 + 0x13*(b2 & !b1), per byte
+            if (x != recon || 4 * j + 4 > lim) continue;
+            const uint32_t n1 = (b1 & 1u) | ((b1 >> 7) & 2u) | ((b1 >> 14) & 4u) | ((b1 >> 21) & 8u);
+            const uint32_t n2 = (b2 & 1u) | ((b2 >> 7) & 2u) | ((b2 >> 14) & 4u) | ((b2 >> 21) & 8u);
+            p1 |= n1 << (4 * j); p2 |= n2 << (4 * j); done |= 0xFu << (4 * j);
+        }
+        eqA = ~p1 & ~p2 & done; eqC = p1 & ~p2 & done; eqT = ~p1 & p2 & done; eqG = p1 & p2 & done;
+        if (done != ((lim >= 32) ? ~0u : ((1u << lim) - 1u))) {
+            for (int i = 0; i < lim; ++i) {
+                if ((done >> i) & 1u) continue;
+                const unsigned char qc = static_cast<unsigned char>((qw[i >> 3] >> (8 * (i & 7))) & 0xFFull);
+                uint32_t bm;
+                if (qc == 'A') bm = 1u; else if (qc == 'C') bm = 2u; else if (qc == 'G') bm = 4u; else if (qc == 'T') bm = 8u;
+                else bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu;
+                eqA |= (bm & 1u) << i; eqC |= ((bm >> 1) & 1u) << i; eqG |= ((bm >> 2) & 1u) << i; eqT |= ((bm >> 3) & 1u) << i;
+            }
         }
     }
     const int bit = (w == W - 1) ? last_bit : 31;
