@@ -37,6 +37,10 @@ struct MyersScratch {
     U<unsigned long long> walk_cycles, walk_moves, walk_reloads, walk_scalar, walk_calls, walk_tail_cycles; // profile of the traceback walks
 };
 
+// traceback table entry of (column, 64-bit query word): word-major, so that the walk's window of 64 consecutive columns of one word is
+// one contiguous 2 KB run (16 cache lines) instead of 64 entries a table row apart. `ncols` = number of columns of the sweep that stored it.
+#define RTK_TB(col, w, ncols) (static_cast<uint64_t>(w) * static_cast<uint64_t>(ncols) + static_cast<uint64_t>(col))
+
 struct MySeq { // a character sequence read forwards or backwards (Hirschberg aligns reversed halves, edlib.cpp:1259-1263)
     const char* p; int32_t n; int32_t rev;
 };
@@ -147,7 +151,7 @@ __device__ __forceinline__ void rtk_myers_sweep_acgt(int m, int n, int W, int to
             const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
             const int col = s - lane;
             const bool active = has_word && col >= 0 && col < n;
-            if (STORE) { if (active) { uint64_t* e = tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
+            if (STORE) { if (active) { uint64_t* e = tb + 4ull * RTK_TB(col, w, n); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
             Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
             hout_prev = active ? hout : hout_prev;
             score += (active && lane == W - 1) ? hout : 0;
@@ -216,7 +220,7 @@ __device__ __forceinline__ SweepStat rtk_myers_fast(const char* __restrict__ qp,
             const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
             const int col = s - lane;
             const bool active = has_word && col >= 0 && col < n;
-            if (STORE) { if (active) { uint64_t* e = tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
+            if (STORE) { if (active) { uint64_t* e = tb + 4ull * RTK_TB(col, w, n); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
             Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
             hout_prev = active ? hout : hout_prev;
             score += (active && lane == W - 1) ? hout : 0;
@@ -300,7 +304,7 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
     int best = 0x7fffffff, first = -1, last = -1, cnt = 0;
     const int steps = n + W - 1;
     // table entry of (column, 64-bit word) = 4 x u64 {Pv, Mv, Ph, Mh}; this lane owns the low or high half of each
-    uint32_t* const tb32 = reinterpret_cast<uint32_t*>(tb) + 8ull * (w >> 1) + (w & 1);
+    uint32_t* const tb32 = reinterpret_cast<uint32_t*>(tb) + 8ull * RTK_TB(0, w >> 1, n) + (w & 1);
     // one step of the anti-diagonal pipeline. MASKED = 1 while the pipeline fills or drains (some words have no column yet / any
     // more); in between every word has one and the activity test, the column range checks and the conditional updates fall away.
 #define RTK_STEP32(MASKED)                                                                                                                   \
@@ -321,12 +325,12 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
         const int col = s - lane;                                                                                                            \
         if (MASKED) {                                                                                                                        \
             const bool active = has_word && col >= 0 && col < n;                                                                             \
-            if (STORE) { if (active) { uint32_t* e = tb32 + 8ull * (static_cast<uint64_t>(col) * W64); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
+            if (STORE) { if (active) { uint32_t* e = tb32 + 8ull * static_cast<uint64_t>(col); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
             Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;                                                                                  \
             hout_prev = active ? hout : hout_prev;                                                                                           \
             score += active ? hout : 0;                                                                                                      \
         } else {                                                                                                                             \
-            if (STORE) { if (has_word) { uint32_t* e = tb32 + 8ull * (static_cast<uint64_t>(col) * W64); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
+            if (STORE) { if (has_word) { uint32_t* e = tb32 + 8ull * static_cast<uint64_t>(col); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
             Pv = nPv; Mv = nMv; hout_prev = hout; score += hout;                                                                             \
         }                                                                                                                                    \
         tc_prev = tc;                                                                                                                        \
@@ -393,7 +397,7 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq
             uint64_t Ph, Mh;
             const uint64_t Eq = rtk_myers_eq_word(sc, q, W, w, tc);
             hin = rtk_myers_step(Pv[w], Mv[w], Eq, hin, (w == W - 1) ? last_bit : 63, Ph, Mh);
-            if (store) { uint64_t* e = sc.tb + 4ull * (static_cast<uint64_t>(j) * W + w); e[0] = Pv[w]; e[1] = Mv[w]; e[2] = Ph; e[3] = Mh; }
+            if (store) { uint64_t* e = sc.tb + 4ull * RTK_TB(j, w, n); e[0] = Pv[w]; e[1] = Mv[w]; e[2] = Ph; e[3] = Mh; }
         }
         score += hin;
         sc.colscore[j] = score;
@@ -474,7 +478,7 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq
                     }
                     uint64_t Ph, Mh;
                     const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
-                    if (store) { uint64_t* e = tb + 4ull * (static_cast<uint64_t>(col) * W + w); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
+                    if (store) { uint64_t* e = tb + 4ull * RTK_TB(col, w, n); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
                     if (is_block_tail) { if (!last_block) carry[col] = static_cast<int8_t>(hout); else score += hout; }
                     hout_prev = hout;
                 }
@@ -574,9 +578,9 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, i
 // Canonical NW traceback over the stored table, preferring up (insert) > left (delete) > diagonal
 // (edlib.cpp:1021-1137). Appends the moves (already in forward order) to sc.moves at *n_moves.
 // Walks the stored table from cell (m, n) back to the origin; `cur` = D[m][n]. Appends the moves to sc.moves (after *n_moves).
-RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int cur_, uint32_t* n_moves_) {
+RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int ncols_, int cur_, uint32_t* n_moves_) { // ncols: columns of the sweep that stored the table (>= n)
     const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_);
-    const int m = rtk_u(m_), n = rtk_u(n_), W = (m + 63) >> 6;
+    const int m = rtk_u(m_), n = rtk_u(n_), ncols = rtk_u(ncols_);
     int cur = rtk_u(cur_);
     const unsigned long long tw0 = rtk_clock(); unsigned n_rel = 0, n_sc = 0;
     int i = m, j = n;
@@ -595,15 +599,15 @@ RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int cur_, ui
     while (i > 0 && j > 0) {
         const int r = i - 1, c = j - 1, w = r >> 6, b = r & 63;
 #ifdef RTK_SIM
-        const uint64_t* e = tbp + 4ull * (static_cast<uint64_t>(c) * W + w);
+        const uint64_t* e = tbp + 4ull * RTK_TB(c, w, ncols);
         const uint64_t a0 = e[0], a1 = e[1], a2 = e[2], a3 = e[3];
         uint64_t l0 = 0, l1 = 0;
-        if (c > 0) { const uint64_t* el = tbp + 4ull * (static_cast<uint64_t>(c - 1) * W + w); l0 = el[0]; l1 = el[1]; }
+        if (c > 0) { const uint64_t* el = tbp + 4ull * RTK_TB(c - 1, w, ncols); l0 = el[0]; l1 = el[1]; }
 #else
         if (w != w_cur || c > c_hi || c_hi - c > 62) {
             c_hi = c; w_cur = w; ++n_rel;
             const int col = c - lane;
-            if (col >= 0) { const uint64_t* e = tbp + 4ull * (static_cast<uint64_t>(col) * W + w); e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3]; }
+            if (col >= 0) { const uint64_t* e = tbp + 4ull * RTK_TB(col, w, ncols); e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3]; }
         }
         const int li = c_hi - c;
         { // run of inserts (moves up column c): consecutive rows from r downwards whose vertical delta is +1 = ones of Pv & ~Mv below bit b
@@ -694,7 +698,7 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const 
     else
 #endif
     { rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr); cur = rtk_ld(rtk_ld(&sc.colscore) + (n - 1)); }
-    rtk_myers_walk(sc, m, n, cur, n_moves);
+    rtk_myers_walk(sc, m, n, n, cur, n_moves);
 }
 RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, int m_, int n_, int32_t* out_) {
     const uint64_t* fin_pv = rtk_u(fin_pv_); const uint64_t* fin_mv = rtk_u(fin_mv_); const int m = rtk_u(m_), n = rtk_u(n_); int32_t* out = rtk_u(out_);
@@ -803,7 +807,7 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
             }
             have = true;
             const long long tn = (mode == RTK_MODE_NW) ? n : (r.first + 1);
-            if (tn > 0 && (2LL * 8 + 4) * W * tn + 8LL * tn < 1024 * 1024) { rtk_myers_walk(sc, m, static_cast<int>(tn), r.dist, n_moves); return r; }
+            if (tn > 0 && (2LL * 8 + 4) * W * tn + 8LL * tn < 1024 * 1024) { rtk_myers_walk(sc, m, static_cast<int>(tn), n, r.dist, n_moves); return r; }
         }
     }
 #endif
