@@ -920,7 +920,7 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
         park(s.set[7], nnb, &onb); park(s.set[7], nnb, &onbc); nnbc = nnb;
     }
     if (rtk_failed(s)) return 0;
-    uint32_t n_all = 0; // all_pids lives in set[0]
+    uint32_t n_all = 0; int allb = 0; // all_pids lives in set[0] (while it is being built: in set[allb])
     uint32_t nb_unselected = nsp;
     uint64_t o_prev2 = 0; uint32_t n_prev2 = 0; // a_pid2 of the previous class
     for (int i = 5; i >= 0 && !rtk_failed(s); --i) {
@@ -961,7 +961,7 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
                 int quota = static_cast<int>(vals[j]);
                 if (quota > 0 && (i == 0 || rtk_shared_with_set(g, u, s.set[curb], ncur, 1) >= 1)) {
                     const uint32_t min_cov = g.card[u] < cov ? g.card[u] : cov;
-                    const uint32_t sh = rtk_shared_with_set(g, u, s.set[0], n_all, min_cov);
+                    const uint32_t sh = rtk_shared_with_set(g, u, s.set[allb], n_all, min_cov);
                     quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
                     if (quota > 0) {
                         const uint32_t all_card = n_all;
@@ -975,8 +975,8 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
                         npid = rtk_set_union(s.set[6], ng, s.set[5], nl, s.set[4], s.set[9]);
                         if (npid > static_cast<uint32_t>(quota)) npid = static_cast<uint32_t>(quota);
                         if (n_all + npid > s.set_cap) { rtk_fail_ovf(s, 9); break; }
-                        const uint32_t nn = rtk_set_union(s.set[0], n_all, s.set[4], npid, s.set[3], s.set[9]);
-                        rtk_wcopy(s.set[0], s.set[3], 4ull * nn); n_all = nn;
+                        const uint32_t nn = rtk_set_union(s.set[allb], n_all, s.set[4], npid, s.set[allb ^ 3], s.set[9]);
+                        allb ^= 3; n_all = nn; // all_pids alternates between set[0] and set[3]; it is moved to set[0] once, at the end
                         const int nb2 = curb == 8 ? 7 : 8;
                         ncur = rtk_set_diff(s.set[curb], ncur, s.set[4], npid, s.set[nb2]); curb = nb2;
                         const int gained = static_cast<int>(n_all - all_card);
@@ -988,6 +988,7 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
             }
         }
     }
+    if (allb != 0 && !rtk_failed(s)) rtk_wcopy(s.set[0], s.set[3], 4ull * n_all);
     return rtk_failed(s) ? 0 : n_all;
 }
 
