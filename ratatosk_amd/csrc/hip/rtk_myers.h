@@ -299,7 +299,7 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
     }
     const int bit = (w == W - 1) ? last_bit : 31;
     uint32_t Pv = ~0u, Mv = 0u;
-    int hout_prev = 0; unsigned tc_prev = 0;
+    int hout_prev = 0; uint32_t m1_prev = 0, m2_prev = 0;
     int score = m;
     int best = 0x7fffffff, first = -1, last = -1, cnt = 0;
     const int steps = n + W - 1;
@@ -310,14 +310,12 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
 #define RTK_STEP32(MASKED)                                                                                                                   \
     {                                                                                                                                        \
         const int s = c0 + j;                                                                                                                \
-        const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));                                                     \
-        const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);                                                         \
-        const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(top_h + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false)); \
-        const int hin = static_cast<int>(got & 0xFFu) - 1;                                                                                   \
-        const unsigned tc = got >> 8;                                                                                                        \
-        /* 'A' 0x41, 'C' 0x43, 'G' 0x47, 'T' 0x54: bit 1 picks C/G over A/T, bit 2 picks T/G over A/C; bitwise selects, no condition code */ \
-        const uint32_t m1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(got), 9, 1));                                       \
-        const uint32_t m2 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(got), 10, 1));                                      \
+        const int in_t = __builtin_amdgcn_readlane(my_t, j);                                                                                 \
+        /* 'A' 0x41, 'C' 0x43, 'G' 0x47, 'T' 0x54: bit 1 picks C/G over A/T, bit 2 picks T/G over A/C. The two choices travel down the  */ \
+        /* lanes as full-width masks next to the horizontal delta (three DPP moves), so that the profile word is three bitwise selects.  */ \
+        const int hin = __builtin_amdgcn_update_dpp(top_h, hout_prev, 0x138, 0xF, 0xF, false);                                              \
+        const uint32_t m1 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(__builtin_amdgcn_sbfe(in_t, 1, 1), static_cast<int>(m1_prev), 0x138, 0xF, 0xF, false)); \
+        const uint32_t m2 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(__builtin_amdgcn_sbfe(in_t, 2, 1), static_cast<int>(m2_prev), 0x138, 0xF, 0xF, false)); \
         const uint32_t lo_ = (eqC & m1) | (eqA & ~m1), hi_ = (eqG & m1) | (eqT & ~m1);                                                       \
         const uint32_t Eq = (hi_ & m2) | (lo_ & ~m2);                                                                                        \
         uint32_t nPv = Pv, nMv = Mv, Ph, Mh;                                                                                                 \
@@ -333,7 +331,7 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
             if (STORE) { if (has_word) { uint32_t* e = tb32 + 8ull * static_cast<uint64_t>(col); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
             Pv = nPv; Mv = nMv; hout_prev = hout; score += hout;                                                                             \
         }                                                                                                                                    \
-        tc_prev = tc;                                                                                                                        \
+        m1_prev = m1; m2_prev = m2;                                                                                                          \
         if (TRACK) {                                                                                                                         \
             const int tcol = s - (W - 1);                                                                                                    \
             if (!(MASKED) || tcol >= 0) { /* wave-uniform: last-row score of column tcol, tracked in scalar registers */                    \
