@@ -294,8 +294,8 @@ struct PoolChunk { unsigned long long base; uint32_t left; }; // wave-private sl
 
 RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk) {
     const int k = g.k;
-    const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
 #ifndef RTK_SIM
+    const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
     // LDS staging of the tile's 64 + k + 1 characters of the masked read: one coalesced load, then every lane slides over its own window
     __shared__ unsigned char tile_chars[128];
     {
