@@ -643,7 +643,7 @@ RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, 
             for (; e < c_hi; ++e) {
                 const char ch = rtk_ld(cyc + e);
                 if (ch == 0) break;
-                const uint32_t nb = rtk_ld(g.adj + 8ull * curr.unitig + (curr.strand ? 0 : 4) + ((static_cast<uint32_t>(ch) >> 1) & 3u ^ (((static_cast<uint32_t>(ch) >> 1) & 3u) >> 1))); // A,C,G,T -> 0..3
+                const uint32_t nb = rtk_ld(g.adj + 8ull * curr.unitig + (curr.strand ? 0 : 4) + (((static_cast<uint32_t>(ch) >> 1) & 3u) ^ (((static_cast<uint32_t>(ch) >> 1) & 3u) >> 1))); // A,C,G,T -> 0..3
                 if (nb == RTK_NONE32) { ok = false; continue; }
                 if (!ok) continue;
                 curr.unitig = nb >> 1; curr.strand = nb & 1u; curr.dist = 0; curr.len = rtk_nkm(g, curr.unitig);
