@@ -57,6 +57,14 @@ def ds_k25(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def ds_k21(tmp_path_factory):
+    """k = 21: half-k-mers of 10 bases, so the 1-edit search sees many chance candidates per lookup; SNP annotations on."""
+    d = tmp_path_factory.mktemp("ds_k21")
+    return make_dataset(d, "k21", ["--seed", 9, "--ref-len", 60000, "--het", 0.004, "--repeat-frac", 0.05, "--sr-cov", 40, "--sr-err", 0.005,
+                                   "--lr-n", 16, "--lr-len", 3000, "--lr-profile", "ont", "--lr-err", 0.08], ["-k", 21, "--snps"])
+
+
+@pytest.fixture(scope="session")
 def ds_medium(tmp_path_factory):
     """GPU-tier set: 400 kb diploid reference with repeats, 160 ONT-profile reads (~1.3 Mb): every branch of the region program at volume."""
     d = tmp_path_factory.mktemp("ds_medium")

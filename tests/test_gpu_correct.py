@@ -73,3 +73,7 @@ def test_gpu_snp_annotations_with_repeats_cycles_and_tiny_scratch(ds_snps_rich, 
     monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
     st, _, _ = _check(ds_snps, 20, None, counters_must_match=False)
     assert st["n_arena_overflow"] > 0
+
+
+def test_gpu_correct_k21(ds_k21):
+    _check(ds_k21, 16, None, k=21)

@@ -58,6 +58,10 @@ def test_sim_correct_k25(ds_k25):
     _check(ds_k25, 6, SIM_LIB, extra, k=25)
 
 
+def test_sim_correct_k21(ds_k21):
+    _check(ds_k21, 8, SIM_LIB, k=21)
+
+
 def test_sim_correct_snp_annotations(ds_snps):
     """Index with SNP annotations (what the reference's `index` step writes unless -F, src/Graph.cpp:484): getAmbiguityVector
     (src/GraphTraversal.cpp:966-1036) and fixAmbiguity (src/Alignment.cpp:527-844) on the device equal the oracle's, also with
