@@ -40,6 +40,20 @@ struct MyersScratch {
 // traceback table entry of (column, 64-bit query word): word-major, so that the walk's window of 64 consecutive columns of one word is
 // one contiguous 2 KB run (16 cache lines) instead of 64 entries a table row apart. `ncols` = number of columns of the sweep that stored it.
 #define RTK_TB(col, w, ncols) (static_cast<uint64_t>(w) * static_cast<uint64_t>(ncols) + static_cast<uint64_t>(col))
+// An entry is 32 bytes: the low 32-bit halves of {Pv, Mv, Ph, Mh}, then their high halves, so that each of the two lanes that share a
+// 64-bit word in the 32-bit sweep writes its four words with ONE 16-byte store.
+struct RtkTbHalf { uint32_t pv, mv, ph, mh; };
+RTK_DEV void rtk_tb_put(uint64_t* e, uint64_t Pv, uint64_t Mv, uint64_t Ph, uint64_t Mh) {
+    RtkTbHalf lo, hi;
+    lo.pv = static_cast<uint32_t>(Pv); lo.mv = static_cast<uint32_t>(Mv); lo.ph = static_cast<uint32_t>(Ph); lo.mh = static_cast<uint32_t>(Mh);
+    hi.pv = static_cast<uint32_t>(Pv >> 32); hi.mv = static_cast<uint32_t>(Mv >> 32); hi.ph = static_cast<uint32_t>(Ph >> 32); hi.mh = static_cast<uint32_t>(Mh >> 32);
+    reinterpret_cast<RtkTbHalf*>(e)[0] = lo; reinterpret_cast<RtkTbHalf*>(e)[1] = hi;
+}
+RTK_DEV void rtk_tb_get(const uint64_t* e, uint64_t& Pv, uint64_t& Mv, uint64_t& Ph, uint64_t& Mh) {
+    const RtkTbHalf lo = reinterpret_cast<const RtkTbHalf*>(e)[0], hi = reinterpret_cast<const RtkTbHalf*>(e)[1];
+    Pv = static_cast<uint64_t>(lo.pv) | (static_cast<uint64_t>(hi.pv) << 32); Mv = static_cast<uint64_t>(lo.mv) | (static_cast<uint64_t>(hi.mv) << 32);
+    Ph = static_cast<uint64_t>(lo.ph) | (static_cast<uint64_t>(hi.ph) << 32); Mh = static_cast<uint64_t>(lo.mh) | (static_cast<uint64_t>(hi.mh) << 32);
+}
 
 struct MySeq { // a character sequence read forwards or backwards (Hirschberg aligns reversed halves, edlib.cpp:1259-1263)
     const char* p; int32_t n; int32_t rev;
@@ -151,7 +165,7 @@ __device__ __forceinline__ void rtk_myers_sweep_acgt(int m, int n, int W, int to
             const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
             const int col = s - lane;
             const bool active = has_word && col >= 0 && col < n;
-            if (STORE) { if (active) { uint64_t* e = tb + 4ull * RTK_TB(col, w, n); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
+            if (STORE) { if (active) { rtk_tb_put(tb + 4ull * RTK_TB(col, w, n), nPv, nMv, Ph, Mh); } }
             Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
             hout_prev = active ? hout : hout_prev;
             score += (active && lane == W - 1) ? hout : 0;
@@ -220,7 +234,7 @@ __device__ __forceinline__ SweepStat rtk_myers_fast(const char* __restrict__ qp,
             const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
             const int col = s - lane;
             const bool active = has_word && col >= 0 && col < n;
-            if (STORE) { if (active) { uint64_t* e = tb + 4ull * RTK_TB(col, w, n); e[0] = nPv; e[1] = nMv; e[2] = Ph; e[3] = Mh; } }
+            if (STORE) { if (active) { rtk_tb_put(tb + 4ull * RTK_TB(col, w, n), nPv, nMv, Ph, Mh); } }
             Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;
             hout_prev = active ? hout : hout_prev;
             score += (active && lane == W - 1) ? hout : 0;
@@ -303,8 +317,8 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
     int score = m;
     int best = 0x7fffffff, first = -1, last = -1, cnt = 0;
     const int steps = n + W - 1;
-    // table entry of (column, 64-bit word) = 4 x u64 {Pv, Mv, Ph, Mh}; this lane owns the low or high half of each
-    uint32_t* const tb32 = reinterpret_cast<uint32_t*>(tb) + 8ull * RTK_TB(0, w >> 1, n) + (w & 1);
+    // table entry of (column, 64-bit word) = two RtkTbHalf (low halves, high halves of Pv, Mv, Ph, Mh); this lane owns one of them
+    RtkTbHalf* const tbh = reinterpret_cast<RtkTbHalf*>(tb) + 2ull * RTK_TB(0, w >> 1, n) + (w & 1); // this lane's half of the entries of its 64-bit word
     // one step of the anti-diagonal pipeline. MASKED = 1 while the pipeline fills or drains (some words have no column yet / any
     // more); in between every word has one and the activity test, the column range checks and the conditional updates fall away.
 #define RTK_STEP32(MASKED)                                                                                                                   \
@@ -323,12 +337,12 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
         const int col = s - lane;                                                                                                            \
         if (MASKED) {                                                                                                                        \
             const bool active = has_word && col >= 0 && col < n;                                                                             \
-            if (STORE) { if (active) { uint32_t* e = tb32 + 8ull * static_cast<uint64_t>(col); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
+            if (STORE) { if (active) { RtkTbHalf hv; hv.pv = nPv; hv.mv = nMv; hv.ph = Ph; hv.mh = Mh; tbh[2ull * static_cast<uint64_t>(col)] = hv; } } \
             Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;                                                                                  \
             hout_prev = active ? hout : hout_prev;                                                                                           \
             score += active ? hout : 0;                                                                                                      \
         } else {                                                                                                                             \
-            if (STORE) { if (has_word) { uint32_t* e = tb32 + 8ull * static_cast<uint64_t>(col); e[0] = nPv; e[2] = nMv; e[4] = Ph; e[6] = Mh; } } \
+            if (STORE) { if (has_word) { RtkTbHalf hv; hv.pv = nPv; hv.mv = nMv; hv.ph = Ph; hv.mh = Mh; tbh[2ull * static_cast<uint64_t>(col)] = hv; } } \
             Pv = nPv; Mv = nMv; hout_prev = hout; score += hout;                                                                             \
         }                                                                                                                                    \
         m1_prev = m1; m2_prev = m2;                                                                                                          \
@@ -395,7 +409,7 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq
             uint64_t Ph, Mh;
             const uint64_t Eq = rtk_myers_eq_word(sc, q, W, w, tc);
             hin = rtk_myers_step(Pv[w], Mv[w], Eq, hin, (w == W - 1) ? last_bit : 63, Ph, Mh);
-            if (store) { uint64_t* e = sc.tb + 4ull * RTK_TB(j, w, n); e[0] = Pv[w]; e[1] = Mv[w]; e[2] = Ph; e[3] = Mh; }
+            if (store) { rtk_tb_put(sc.tb + 4ull * RTK_TB(j, w, n), Pv[w], Mv[w], Ph, Mh); }
         }
         score += hin;
         sc.colscore[j] = score;
@@ -476,7 +490,7 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq
                     }
                     uint64_t Ph, Mh;
                     const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
-                    if (store) { uint64_t* e = tb + 4ull * RTK_TB(col, w, n); e[0] = Pv; e[1] = Mv; e[2] = Ph; e[3] = Mh; }
+                    if (store) { rtk_tb_put(tb + 4ull * RTK_TB(col, w, n), Pv, Mv, Ph, Mh); }
                     if (is_block_tail) { if (!last_block) carry[col] = static_cast<int8_t>(hout); else score += hout; }
                     hout_prev = hout;
                 }
@@ -597,15 +611,14 @@ RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int ncols_, 
     while (i > 0 && j > 0) {
         const int r = i - 1, c = j - 1, w = r >> 6, b = r & 63;
 #ifdef RTK_SIM
-        const uint64_t* e = tbp + 4ull * RTK_TB(c, w, ncols);
-        const uint64_t a0 = e[0], a1 = e[1], a2 = e[2], a3 = e[3];
+        uint64_t a0, a1, a2, a3; rtk_tb_get(tbp + 4ull * RTK_TB(c, w, ncols), a0, a1, a2, a3);
         uint64_t l0 = 0, l1 = 0;
-        if (c > 0) { const uint64_t* el = tbp + 4ull * RTK_TB(c - 1, w, ncols); l0 = el[0]; l1 = el[1]; }
+        if (c > 0) { uint64_t l2, l3; rtk_tb_get(tbp + 4ull * RTK_TB(c - 1, w, ncols), l0, l1, l2, l3); }
 #else
         if (w != w_cur || c > c_hi || c_hi - c > 62) {
             c_hi = c; w_cur = w; ++n_rel;
             const int col = c - lane;
-            if (col >= 0) { const uint64_t* e = tbp + 4ull * RTK_TB(col, w, ncols); e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3]; }
+            if (col >= 0) rtk_tb_get(tbp + 4ull * RTK_TB(col, w, ncols), e0, e1, e2, e3);
         }
         const int li = c_hi - c;
         { // run of inserts (moves up column c): consecutive rows from r downwards whose vertical delta is +1 = ones of Pv & ~Mv below bit b
