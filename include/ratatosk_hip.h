@@ -97,6 +97,11 @@ void rtk_graph_free(rtk_graph* g);
  * Returns the number of unitigs that carried an annotation, < 0 on error. */
 long long rtk_graph_strip_annotations(rtk_graph* g);
 
+/* Optional: allocate the per-wave scratch slabs of the seed and region stages (tens of GB, seconds of hipMalloc) for reads up to
+ * max_read_len on `device` ahead of time, e.g. from a helper thread while rtk_graph_load parses the index. The first graph uploaded
+ * to that device adopts them. Not part of the reference's seam; there is nothing to release. */
+int rtk_reserve_scratch(int device, uint32_t max_read_len);
+
 /* Correct_Opt defaults + max_km_cov derived from the graph (reference: src/Common.hpp:101-156, src/Ratatosk.cpp:625). */
 int rtk_opts_default(const rtk_graph* g, rtk_opts* opts);
 

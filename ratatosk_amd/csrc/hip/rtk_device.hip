@@ -200,8 +200,23 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
 }
 
 // ------------------------------------------------------------------------------------------------ per-wave scratch
+// Slabs reserved ahead of any graph (rtk_reserve_scratch): the first hipMalloc of a tens-of-GB slab takes seconds, a caller can have
+// it done while the graph files are still being parsed. A graph that needs a slab takes the smallest reserved one that is large enough.
+struct ReservedSlab { int device; void* p; uint64_t bytes; };
+static std::mutex g_reserved_lock;
+static std::vector<ReservedSlab> g_reserved;
+
 static char* graph_scratch(rtk_graph* g, int slot, uint64_t bytes) { // grows monotonically; hipMalloc/hipFree of tens of GB per batch would dominate a step
-    if (bytes > g->scratch_bytes_[slot]) { rtk_dfree(g->scratch[slot]); g->scratch[slot] = nullptr; g->scratch_bytes_[slot] = 0; g->scratch[slot] = rtk_dmalloc(bytes); g->scratch_bytes_[slot] = bytes; }
+    if (bytes > g->scratch_bytes_[slot]) {
+        rtk_dfree(g->scratch[slot]); g->scratch[slot] = nullptr; g->scratch_bytes_[slot] = 0;
+        {
+            std::lock_guard<std::mutex> lk(g_reserved_lock);
+            int best = -1;
+            for (size_t i = 0; i < g_reserved.size(); ++i) if (g_reserved[i].device == g->device && g_reserved[i].bytes >= bytes && (best < 0 || g_reserved[i].bytes < g_reserved[static_cast<size_t>(best)].bytes)) best = static_cast<int>(i);
+            if (best >= 0) { g->scratch[slot] = g_reserved[static_cast<size_t>(best)].p; g->scratch_bytes_[slot] = g_reserved[static_cast<size_t>(best)].bytes; g_reserved.erase(g_reserved.begin() + best); }
+        }
+        if (!g->scratch[slot]) { g->scratch[slot] = rtk_dmalloc(bytes); g->scratch_bytes_[slot] = bytes; }
+    }
     return static_cast<char*>(g->scratch[slot]);
 }
 

@@ -85,6 +85,9 @@ int main(int argc, char** argv) {
     // stage on its own stream (rtk_correct_batch = create + seeds + regions + fetch; the stages of different batches overlap).
     const int n_gpus = opt.cores, n_workers = 2 * opt.cores;
     std::vector<rtk_graph*> graphs(n_gpus, nullptr);
+    // the per-wave scratch slabs (tens of GB per GPU, seconds of hipMalloc) are reserved while the index files are parsed
+    std::vector<std::thread> reservers;
+    for (int w = 0; w < n_gpus; ++w) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
     for (int w = 0; w < n_gpus; ++w) {
         bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, 1, &graphs[w]) == RTK_OK;
         if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[w]); if (w == 0 && ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs\n", ns); }
@@ -93,6 +96,7 @@ int main(int argc, char** argv) {
             exit(1);
         }
     }
+    for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join();
     rtk_opts ro; rtk_opts_default(graphs[0], &ro);
     ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_qual = opt.max_qual; ro.min_confidence_snp_corr = opt.min_conf_snp;
 
