@@ -260,13 +260,8 @@ RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* rof
             uint32_t lo = lo0;
             while (lo + 1 < n_reads && roff[lo + 1] <= b) ++lo;
             if (b + static_cast<uint64_t>(g.k) <= roff[lo + 1]) {
-                uint64_t fw = 0; bool ok = true;
-                for (int i = 0; i < g.k; ++i) {
-                    const int c = rtk_cls(static_cast<unsigned char>(seq[b + i]));
-                    if (c > 3) { ok = false; break; }
-                    fw = (fw << 2) | static_cast<uint64_t>(c);
-                }
-                if (ok) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += 1; slots += np; }
+                int n_ok; const uint64_t fw = rtk_pack_acgt(reinterpret_cast<const unsigned char*>(seq) + b, g.k, &n_ok); // the read buffer is padded by 64 bytes
+                if (n_ok == g.k) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += 1; slots += np; }
             }
             hits[b] = h;
         }

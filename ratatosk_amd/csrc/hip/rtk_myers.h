@@ -71,6 +71,34 @@ RTK_DEV int rtk_cls(unsigned char c) {
     }
 }
 
+// Branch-free 2-bit packing of up to 32 characters (A 0, C 1, G 2, T 3; first character in the high bits of the result, `want`
+// characters in total, unaligned source with at least 32 readable bytes). *n_ok = number of leading characters that are A/C/G/T
+// (upper case), capped at `want`; the code is only meaningful for those. Bits 1-2 of 'A' 0x41, 'C' 0x43, 'T' 0x54, 'G' 0x47 are a
+// 2-bit code; a character is valid iff rebuilding it from that code gives it back. No per-character branches: the per-lane switch
+// of rtk_cls costs ~50 scalar instructions per character in exec-mask bookkeeping.
+RTK_DEV uint64_t rtk_pack_acgt(const unsigned char* p, int want, int* n_ok) {
+    uint64_t code = 0; int ok = 0; bool open = true;
+    for (int j = 0; j < 4; ++j) {
+        uint64_t x; __builtin_memcpy(&x, p + 8 * j, 8);
+        const uint64_t b1 = (x >> 1) & 0x0101010101010101ull, b2 = (x >> 2) & 0x0101010101010101ull;
+        const uint64_t b12 = b1 & b2, b2n = b2 & ~b1;
+        const uint64_t recon = 0x4141414141414141ull + (b1 << 1) + (b12 << 2) + (b2n << 4) + (b2n << 1) + b2n;
+        const uint64_t bad = x ^ recon;
+        const int good = bad ? (__builtin_ctzll(bad) >> 3) : 8; // leading valid characters of this word
+        // gather the two bit planes, first character first: byte i -> bit 7 - i
+        const uint64_t hi = (b2 * 0x8040201008040201ull) >> 56, lo = ((b1 ^ b2) * 0x8040201008040201ull) >> 56;
+        uint64_t h = hi, l = lo; // interleave: hi bits to odd positions, lo bits to even positions of a 16-bit group
+        h = (h | (h << 4)) & 0x0F0Full; h = (h | (h << 2)) & 0x3333ull; h = (h | (h << 1)) & 0x5555ull;
+        l = (l | (l << 4)) & 0x0F0Full; l = (l | (l << 2)) & 0x3333ull; l = (l | (l << 1)) & 0x5555ull;
+        code = (code << 16) | (h << 1) | l;
+        if (open) { ok += good; open = good == 8; }
+    }
+    // 32 characters packed; keep the first `want`
+    if (want < 32) code >>= 2 * (32 - want);
+    *n_ok = ok < want ? ok : want;
+    return code;
+}
+
 // 15-bit set of classes a character of class c is equal to (identity + the 28 (code, base) pairs of Common.hpp:262-274)
 RTK_DEV uint32_t rtk_eq_classes(int c, bool iupac) {
     if (c >= 15) return 0u;

@@ -548,13 +548,11 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
             while (lo + 1 < n_reads && roff[lo + 1] <= bb) ++lo;
             const uint64_t rend = roff[lo + 1];
             if (bb + static_cast<uint64_t>(k) <= rend && rend - roff[lo] > static_cast<uint64_t>(k)) {
-                bool ok = true;
-                const unsigned char* wc = reinterpret_cast<const unsigned char*>(bv.masked.get()) + bb;
-                for (int i = 0; i < k - 1; ++i) { const int c = rtk_cls(wc[i]); if (c > 3) { ok = false; break; } c_k1 = (c_k1 << 2) | static_cast<uint64_t>(c); }
-                if (ok) {
-                    cand = true;
-                    const int c = rtk_cls(wc[k - 1]);
-                    if (c <= 3) { ck = static_cast<uint32_t>(c); if (bb + static_cast<uint64_t>(k) + 1 <= rend) { const int c2 = rtk_cls(wc[k]); if (c2 <= 3) ck1 = static_cast<uint32_t>(c2); } }
+                // k + 1 characters packed without per-character branches (the masked copy is padded by 64 bytes)
+                int n_ok; const uint64_t S = rtk_pack_acgt(reinterpret_cast<const unsigned char*>(bv.masked.get()) + bb, k + 1, &n_ok);
+                if (n_ok >= k - 1) {
+                    cand = true; c_k1 = S >> 4;
+                    if (n_ok >= k) { ck = static_cast<uint32_t>((S >> 2) & 3ull); if (n_ok >= k + 1 && bb + static_cast<uint64_t>(k) + 1 <= rend) ck1 = static_cast<uint32_t>(S & 3ull); }
                 }
             }
         }
