@@ -76,8 +76,10 @@ RTK_DEV int rtk_cls(unsigned char c) {
 // (upper case), capped at `want`; the code is only meaningful for those. Bits 1-2 of 'A' 0x41, 'C' 0x43, 'T' 0x54, 'G' 0x47 are a
 // 2-bit code; a character is valid iff rebuilding it from that code gives it back. No per-character branches: the per-lane switch
 // of rtk_cls costs ~50 scalar instructions per character in exec-mask bookkeeping.
-RTK_DEV uint64_t rtk_pack_acgt(const unsigned char* p, int want, int* n_ok) {
-    uint64_t code = 0; int ok = 0; bool open = true;
+RTK_DEV uint64_t rtk_spread8(uint64_t v) { v = (v | (v << 4)) & 0x0F0Full; v = (v | (v << 2)) & 0x3333ull; return (v | (v << 1)) & 0x5555ull; } // bit i of a byte -> bit 2i
+// inv2 (optional): bit 2(want-1-i) set iff character i is not A/C/G/T (same layout as the low code bits)
+RTK_DEV uint64_t rtk_pack_acgt(const unsigned char* p, int want, int* n_ok, uint64_t* inv2 = nullptr) {
+    uint64_t code = 0, inv = 0; int ok = 0; bool open = true;
     for (int j = 0; j < 4; ++j) {
         uint64_t x; __builtin_memcpy(&x, p + 8 * j, 8);
         const uint64_t b1 = (x >> 1) & 0x0101010101010101ull, b2 = (x >> 2) & 0x0101010101010101ull;
@@ -85,16 +87,18 @@ RTK_DEV uint64_t rtk_pack_acgt(const unsigned char* p, int want, int* n_ok) {
         const uint64_t recon = 0x4141414141414141ull + (b1 << 1) + (b12 << 2) + (b2n << 4) + (b2n << 1) + b2n;
         const uint64_t bad = x ^ recon;
         const int good = bad ? (__builtin_ctzll(bad) >> 3) : 8; // leading valid characters of this word
-        // gather the two bit planes, first character first: byte i -> bit 7 - i
+        // gather the bit planes, first character first: byte i -> bit 7 - i
         const uint64_t hi = (b2 * 0x8040201008040201ull) >> 56, lo = ((b1 ^ b2) * 0x8040201008040201ull) >> 56;
-        uint64_t h = hi, l = lo; // interleave: hi bits to odd positions, lo bits to even positions of a 16-bit group
-        h = (h | (h << 4)) & 0x0F0Full; h = (h | (h << 2)) & 0x3333ull; h = (h | (h << 1)) & 0x5555ull;
-        l = (l | (l << 4)) & 0x0F0Full; l = (l | (l << 2)) & 0x3333ull; l = (l | (l << 1)) & 0x5555ull;
-        code = (code << 16) | (h << 1) | l;
+        code = (code << 16) | (rtk_spread8(hi) << 1) | rtk_spread8(lo);
+        if (inv2) {
+            const uint64_t nz = ((((bad & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | bad) >> 7) & 0x0101010101010101ull; // 1 per non-zero byte
+            inv = (inv << 16) | rtk_spread8((nz * 0x8040201008040201ull) >> 56);
+        }
         if (open) { ok += good; open = good == 8; }
     }
     // 32 characters packed; keep the first `want`
-    if (want < 32) code >>= 2 * (32 - want);
+    if (want < 32) { code >>= 2 * (32 - want); inv >>= 2 * (32 - want); }
+    if (inv2) *inv2 = inv;
     *n_ok = ok < want ? ok : want;
     return code;
 }

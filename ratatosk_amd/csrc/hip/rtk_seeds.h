@@ -598,14 +598,30 @@ RTK_DEV bool rtk_char_eq_base(char c, uint32_t b) { return rtk_cls(static_cast<u
 
 // classification of one weak hit (src/Alignment.cpp:1049-1072): returns key or 0 when the hit is dropped
 RTK_FN uint64_t rtk_weak_key(const char* ref, uint32_t pos, uint64_t code, int k) {
-    auto qb = [&](int i) -> uint32_t { return static_cast<uint32_t>((code >> (2 * (k - 1 - i))) & 3ull); };
-    int l = 0;
-    while (l < k && rtk_char_eq_base(ref[pos + l], qb(l))) ++l;
+    // the k read characters as 2-bit codes next to the graph k-mer `code`; a character that is not A/C/G/T equals nothing (inv)
+    int n_ok; uint64_t inv;
+    const uint64_t R = rtk_pack_acgt(reinterpret_cast<const unsigned char*>(ref) + pos, k, &n_ok, &inv);
+    const uint64_t even = 0x5555555555555555ull;
+    const uint64_t mk = (k < 32) ? ((1ull << (2 * k)) - 1ull) : ~0ull, mk1 = (1ull << (2 * (k - 1))) - 1ull;
+    auto neq = [&](uint64_t x) -> uint64_t { return (x | (x >> 1)) & even; }; // one bit (the low one of its pair) per differing character
+    // character i sits at bits [2(k-1-i), 2(k-1-i)+1]
+    const uint64_t d0 = (neq(code ^ R) | inv) & mk;                 // read[i] != kmer[i]
+    const int l = d0 ? (__builtin_clzll(d0) - (64 - 2 * k)) / 2 : k; // first differing position
     if (l >= k) return 0;
+    const uint64_t below = (l + 1 < k) ? ((1ull << (2 * (k - 1 - l))) - 1ull) : 0ull; // characters after position l (k-character layout)
     int type_var = 0; uint32_t mis = 0;
-    { bool ok = true; for (int i = l + 1; i < k && ok; ++i) ok = rtk_char_eq_base(ref[pos + i], qb(i)); if (ok) { type_var = 1; mis = 1u << qb(l); } }
-    if (!type_var) { bool ok = true; for (int i = 0; i < k - l - 1 && ok; ++i) ok = rtk_char_eq_base(ref[pos + l + i], qb(l + 1 + i)); if (ok) { type_var = 2; mis = 1u << qb(l); } }
-    if (!type_var) { bool ok = true; for (int i = 0; i < k - l - 1 && ok; ++i) ok = rtk_char_eq_base(ref[pos + l + 1 + i], qb(l + i)); if (ok) type_var = 3; }
+    const uint32_t ql = static_cast<uint32_t>((code >> (2 * (k - 1 - l))) & 3ull);
+    if ((d0 & below) == 0) { type_var = 1; mis = 1u << ql; }        // read[i] == kmer[i] for every i > l
+    if (!type_var) { // read[l + i] == kmer[l + 1 + i]: the read without the k-mer's character l; compare kmer[1..k) with read[0..k-1) from position l on
+        const uint64_t d = (neq((code & mk1) ^ (R >> 2)) | (inv >> 2)) & mk1; // (k-1)-character layout: index j <-> read[j] vs kmer[j+1], bits 2(k-2-j)
+        const uint64_t from_l = (l < k - 1) ? ((1ull << (2 * (k - 1 - l))) - 1ull) : 0ull; // indices j >= l
+        if ((d & from_l) == 0) { type_var = 2; mis = 1u << ql; }
+    }
+    if (!type_var) { // read[l + 1 + i] == kmer[l + i]: compare kmer[0..k-1) with read[1..k) from position l on
+        const uint64_t d = (neq((code >> 2) ^ (R & mk1)) | (inv & mk1)) & mk1; // index j <-> kmer[j] vs read[j+1], bits 2(k-2-j)
+        const uint64_t from_l = (l < k - 1) ? ((1ull << (2 * (k - 1 - l))) - 1ull) : 0ull;
+        if ((d & from_l) == 0) type_var = 3;
+    }
     if (type_var == 0 || l == 0 || l == k - 1) return 0;
     return (static_cast<uint64_t>(pos + static_cast<uint32_t>(l)) << 16) | (static_cast<uint64_t>(mis) << 8) | static_cast<uint64_t>(type_var);
 }
