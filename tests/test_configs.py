@@ -1,0 +1,123 @@
+"""Parity at the sizes BASELINE.json's configs name, not only on the small seeded sets of the other tests:
+
+  configs[0]  50 kb random ref, 1 000 x 2x150 bp pairs (6x), 100 x 10 kb long reads with 10 % errors -- oracle AND HIP path must
+              reproduce the corrected FASTQ frozen in tests/golden/config0.json (byte-identical: sha256 + per-read CRCs);
+  configs[1]  5 Mb ref, 30x PE150 at 0.5 %, ONT-profile long reads (>= 16 Mb of them), SNP-annotated index as bench.py builds it;
+  configs[2]  graph of the chr20-scale set: 60 Mb diploid reference with 0.1 % heterozygous SNPs, 30x short reads; a bounded
+              long-read sample so that the oracle leg stays below two minutes.
+
+The HIP path runs through the C ABI (ratatosk_amd.api -> libratatosk_hip.so); the oracle is the checker."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+import zlib
+
+import pytest
+
+from conftest import BIN, ROOT, SIM_LIB
+from oracle import oracle_py as op
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import gen_config0_golden as g0  # noqa: E402
+
+GOLD0 = json.load(open(os.path.join(ROOT, "tests", "golden", "config0.json")))
+
+
+@pytest.fixture(scope="module")
+def config0(tmp_path_factory):
+    pre = g0.make(str(tmp_path_factory.mktemp("config0")))
+    assert g0.input_sums(pre) == GOLD0["inputs"], "rtk_simulate / rtk_build_index no longer write the frozen configs[0] inputs: regenerate tests/golden/config0.json deliberately"
+    return pre
+
+
+def _check_config0(recs, names):
+    assert len(recs) == GOLD0["n_reads"]
+    bad = [i for i, w in enumerate(recs) if zlib.crc32((w[0] + "\n" + w[1]).encode()) != GOLD0["read_crc32"][i]]
+    assert not bad, "corrected records differ from the frozen configs[0] output at reads %s" % bad[:10]
+    assert hashlib.sha256(g0.fastq_bytes(names, recs)).hexdigest() == GOLD0["fastq_sha256"]
+
+
+def test_config0_oracle_reproduces_frozen_fastq(config0):
+    reads = op.read_fastq(config0 + ".lr.fq")
+    og = op.Graph(config0 + ".index.k31.fasta.gz", config0 + ".index.k31.rtsk", 31)
+    want, _ = og.correct_batch([r[1] for r in reads], [r[2] for r in reads], threads=4)
+    _check_config0(want, [r[0] for r in reads])
+
+
+def test_config0_device_program_on_simulator(config0):
+    """The device programs (host simulator build) on the first reads of configs[0]: same records as frozen."""
+    from ratatosk_amd import api
+    reads = op.read_fastq(config0 + ".lr.fq")[:6]
+    pg = api.Graph(config0 + ".index.k31.fasta.gz", config0 + ".index.k31.rtsk", 31, device=0, lib_path=SIM_LIB)
+    got = pg.correct_batch([r[1] for r in reads], [r[2] for r in reads])
+    for i, w in enumerate(got):
+        assert zlib.crc32((w[0] + "\n" + w[1]).encode()) == GOLD0["read_crc32"][i], "read %d" % i
+
+
+@pytest.mark.gpu
+def test_gpu_config0_frozen_fastq_through_the_cli(config0, tmp_path):
+    """`Ratatosk correct -1 -c 4` at configs[0]'s stated parameters: OUT.2.fastq must be the frozen file byte for byte."""
+    out = str(tmp_path / "out")
+    r = subprocess.run([os.path.join(BIN, "Ratatosk"), "correct", "-1", "-c", "4", "-g", config0 + ".index.k31.fasta.gz", "-d", config0 + ".index.k31.rtsk",
+                        "-l", config0 + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert hashlib.sha256(open(out + ".2.fastq", "rb").read()).hexdigest() == GOLD0["fastq_sha256"]
+    got = op.read_fastq(out + ".2.fastq")
+    _check_config0([(g[1], g[2]) for g in got], [g[0] for g in got])
+
+
+def _sized(tmp, name, sim_args, index_args, sample_bases, skip_bases=0):
+    t0 = time.time()
+    pre = os.path.join(str(tmp), name)
+    subprocess.check_call([os.path.join(BIN, "rtk_simulate"), "--prefix", pre] + [str(a) for a in sim_args], stderr=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + list(index_args), stderr=subprocess.DEVNULL)
+    os.remove(pre + ".sr.fq")
+    t_data = time.time() - t0
+    reads = op.read_fastq(pre + ".lr.fq")
+    seqs, quals, tot, skipped = [], [], 0, 0
+    for _, s, q in reads:
+        if skipped < skip_bases:
+            skipped += len(s); continue
+        seqs.append(s); quals.append(q); tot += len(s)
+        if tot >= sample_bases:
+            break
+    return pre, seqs, quals, tot, t_data
+
+
+def _parity(pre, seqs, quals):
+    from ratatosk_amd import api
+    fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
+    pg = api.Graph(fa, rt, 31, device=0)
+    t0 = time.time(); got = pg.correct_batch(seqs, quals); t_gpu = time.time() - t0
+    og = op.Graph(fa, rt, 31)
+    t0 = time.time(); want, _ = og.correct_batch(seqs, quals, threads=os.cpu_count() or 4); t_cpu = time.time() - t0
+    bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b]
+    assert not bad, "%d of %d reads differ from the oracle (first: %s)" % (len(bad), len(seqs), bad[:5])
+    assert sum(1 for s, w in zip(seqs, want) if s != w[0]) > len(seqs) // 2  # the correction did something
+    return pg.info(), t_gpu, t_cpu
+
+
+@pytest.mark.gpu
+def test_gpu_config1_size(tmp_path_factory):
+    """configs[1]: 5 Mb reference, 30x PE150 (0.5 % substitutions), >= 16 Mb of ONT-profile long reads, index with SNP annotations."""
+    pre, seqs, quals, tot, t_data = _sized(tmp_path_factory.mktemp("config1"), "c1",
+                                           ["--seed", 2, "--ref-len", 5_000_000, "--sr-cov", 30, "--sr-err", 0.005, "--lr-cov", 4, "--lr-len", 8000, "--lr-profile", "ont", "--lr-err", 0.07],
+                                           ["--snps"], 16_000_000)
+    assert tot >= 16_000_000
+    info, t_gpu, t_cpu = _parity(pre, seqs, quals)
+    assert info.n_kmers > 5_000_000
+    print("configs[1]: %d reads / %d bases, data %.0f s, HIP (host-inclusive) %.1f s, oracle %.1f s" % (len(seqs), tot, t_data, t_gpu, t_cpu))
+
+
+@pytest.mark.gpu
+def test_gpu_config2_graph_size(tmp_path_factory):
+    """configs[2]'s graph: 60 Mb diploid reference (0.1 % heterozygous SNPs), 30x short reads; 8 Mb of its long reads."""
+    pre, seqs, quals, tot, t_data = _sized(tmp_path_factory.mktemp("config2"), "c2",
+                                           ["--seed", 3, "--ref-len", 60_000_000, "--het", 0.001, "--sr-cov", 30, "--sr-err", 0.005, "--lr-cov", 0.15, "--lr-len", 8000, "--lr-profile", "ont", "--lr-err", 0.07],
+                                           [], 8_000_000)
+    info, t_gpu, t_cpu = _parity(pre, seqs, quals)
+    assert info.n_kmers > 60_000_000
+    print("configs[2] graph: %d reads / %d bases, data %.0f s, HIP (host-inclusive) %.1f s, oracle %.1f s" % (len(seqs), tot, t_data, t_gpu, t_cpu))

@@ -1,0 +1,176 @@
+""".rtsk PairID streams as the REFERENCE writes them (src/PairID.cpp:1137-1174): stored Roaring sets are `runOptimize`d before they are
+written (src/Common.cpp:517,546), so real indexes hold cookie-12347 payloads with RUN containers, which the repo's own index producer
+never emits (it writes cookie 12346). Here an index is re-encoded by an independent Python encoder of the RoaringFormatSpec -- run /
+array / bitset containers mixed, with and without the offset header (>= 4 containers), colour ids spread over many 16-bit keys by
+an order-preserving renaming -- and loaded by the product loader and by the oracle's loader: same sets, same corrected reads as
+with the original file (an order-preserving renaming of the pair ids cannot change any decision of the correction)."""
+import gzip
+import struct
+
+from conftest import SIM_LIB
+from oracle import oracle_py as op
+from ratatosk_amd import api
+
+
+def _decode_12346(buf):
+    cookie, n = struct.unpack_from("<II", buf, 0)
+    assert cookie == 12346
+    keys = [struct.unpack_from("<HH", buf, 8 + 4 * i) for i in range(n)]
+    off = 8 + 8 * n
+    out = []
+    for key, cm1 in keys:
+        card = cm1 + 1
+        if card <= 4096:
+            out += [(key << 16) | v for v in struct.unpack_from("<%dH" % card, buf, off)]
+            off += 2 * card
+        else:
+            words = struct.unpack_from("<1024Q", buf, off)
+            out += [(key << 16) | (64 * w + b) for w in range(1024) for b in range(64) if (words[w] >> b) & 1]
+            off += 8192
+    return out
+
+
+def _encode_12347(ids, force_run):
+    """RoaringFormatSpec with run containers: cookie 12347 | (n-1) << 16, run bitmap, (key, card-1) pairs, offsets iff n >= 4,
+    then per container: run = u16 n_runs + (start, length-1) pairs; array = u16 values; bitset = 1024 u64."""
+    conts = {}
+    for v in ids:
+        conts.setdefault(v >> 16, []).append(v & 0xFFFF)
+    keys = sorted(conts)
+    n = len(keys)
+    bodies, is_run = [], []
+    for ci, key in enumerate(keys):
+        vals = conts[key]
+        runs = []
+        for v in vals:
+            if runs and runs[-1][0] + runs[-1][1] + 1 == v:
+                runs[-1][1] += 1
+            else:
+                runs.append([v, 0])
+        as_run = force_run(ci) or (2 + 4 * len(runs) < min(2 * len(vals), 8192))
+        if as_run:
+            bodies.append(struct.pack("<H", len(runs)) + b"".join(struct.pack("<HH", s, l) for s, l in runs))
+        elif len(vals) <= 4096:
+            bodies.append(struct.pack("<%dH" % len(vals), *vals))
+        else:
+            words = [0] * 1024
+            for v in vals:
+                words[v >> 6] |= 1 << (v & 63)
+            bodies.append(struct.pack("<1024Q", *words))
+        is_run.append(as_run)
+    out = struct.pack("<I", 12347 | ((n - 1) << 16))
+    bm = bytearray((n + 7) // 8)
+    for i, r in enumerate(is_run):
+        if r:
+            bm[i // 8] |= 1 << (i % 8)
+    out += bytes(bm)
+    out += b"".join(struct.pack("<HH", k, len(conts[k]) - 1) for k in keys)
+    if n >= 4:
+        off = len(out) + 4 * n
+        for b in bodies:
+            out += struct.pack("<I", off)
+            off += len(b)
+    return out + b"".join(bodies), sum(is_run), n
+
+
+def _rewrite(src, dst, remap):
+    """Copies an .rtsk file, renaming the colour ids of the global and local sets with `remap` and writing every set that needs a
+    Roaring payload in the run-container layout. Returns (payloads, run containers, containers, payloads with >= 4 containers)."""
+    data = open(src, "rb").read()
+    out = bytearray()
+    p = 0
+    st = [0, 0, 0, 0]
+
+    def read_pid():
+        nonlocal p
+        (w,) = struct.unpack_from("<Q", data, p); p += 8
+        f = w & 7
+        if f == 1:
+            return [b for b in range(61) if (w >> (3 + b)) & 1]
+        if f == 2:
+            return [w >> 3]
+        assert f == 3
+        n = w >> 3
+        ids = _decode_12346(data[p:p + n]); p += n
+        return ids
+
+    def write_pid(ids, colour):
+        if colour:
+            ids = [remap(v) for v in ids]
+        if not ids:
+            out.extend(struct.pack("<Q", 1)); return
+        if ids[-1] < 61:
+            out.extend(struct.pack("<Q", (sum(1 << v for v in ids) << 3) | 1)); return
+        if len(ids) == 1:
+            out.extend(struct.pack("<Q", (ids[0] << 3) | 2)); return
+        payload, n_run, n_cont = _encode_12347(ids, (lambda ci: ci % 3 == 0) if colour else (lambda ci: False))
+        st[0] += 1; st[1] += n_run; st[2] += n_cont; st[3] += 1 if n_cont >= 4 else 0
+        out.extend(struct.pack("<Q", (len(payload) << 3) | 3)); out.extend(payload)
+
+    while p < len(data):
+        out.extend(data[p:p + 32]); p += 32  # head k-mer, kmCov_cardBranches, shared_pids
+        for colour in (True, True, False, False):  # global, local, ambiguity, hap
+            write_pid(read_pid(), colour)
+        (n,) = struct.unpack_from("<Q", data, p)
+        out.extend(data[p:p + 8 + n]); p += 8 + n
+    open(dst, "wb").write(bytes(out))
+    return st
+
+
+def _flat_colours(pg):
+    """Colour sets as the PRODUCT loader flattened them (buffers RTK_BUF_LOFF/GID/GOFF/COL of csrc/host/flat_graph.hpp; with the
+    simulator library "device" memory is host memory, so the buffers can be read back through the C ABI)."""
+    import ctypes as C
+
+    def buf(idx, ctype):
+        p, n = C.c_void_p(), C.c_uint64()
+        assert pg.L.rtk_graph_buffer(pg.h, idx, C.byref(p), C.byref(n)) == 0
+        return C.cast(p, C.POINTER(ctype)), n.value // C.sizeof(ctype)
+    (loff, _), (gid, _), (goff, _), (col, _) = buf(6, C.c_uint64), buf(7, C.c_int32), buf(8, C.c_uint64), buf(9, C.c_uint32)
+    return {"local": lambda u: [col[i] for i in range(loff[u], loff[u + 1])],
+            "global": lambda u: [] if gid[u] < 0 else [col[i] for i in range(goff[gid[u]], goff[gid[u] + 1])]}
+
+
+def test_run_container_payloads_load_like_the_plain_ones(ds_snps_rich, tmp_path):
+    fa, rt = ds_snps_rich + ".index.k31.fasta.gz", ds_snps_rich + ".index.k31.rtsk"
+    rt2 = str(tmp_path / "runs.rtsk")
+    remap = lambda v: v + (v // 48) * 70001  # order preserving; spreads the ids over many 16-bit keys, keeps short runs
+    n_payload, n_run, n_cont, n_off = _rewrite(rt, rt2, remap)
+    assert n_payload > 100 and n_run > 100 and n_off > 50 and n_cont > n_run  # run AND array containers, with and without offset header
+    og1, og2 = op.Graph(fa, rt, 31), op.Graph(fa, rt2, 31)
+    pg1, pg2 = api.Graph(fa, rt, 31, device=0, lib_path=SIM_LIB), api.Graph(fa, rt2, 31, device=0, lib_path=SIM_LIB)
+    i1, i2 = pg1.info(), pg2.info()
+    assert (i1.n_unitigs, i1.n_colour_ids, i1.n_global_sets) == (i2.n_unitigs, i2.n_colour_ids, i2.n_global_sets)
+    # the decoded sets themselves: product loader (flat colour pool) against the oracle's independent decoder, unitig by unitig
+    flat = _flat_colours(pg2)
+    n_glob = 0
+    for u in range(0, og2.n_unitigs, 3):
+        a, b = og1.unitig(u), og2.unitig(u)
+        assert [remap(v) for v in a["local"]] == b["local"]
+        assert flat["local"](u) == b["local"]
+        if b["global_id"] >= 0:
+            n_glob += 1
+            assert flat["global"](u) == og2.global_set(b["global_id"]) == [remap(v) for v in og1.global_set(a["global_id"])]
+        else:
+            assert flat["global"](u) == []
+    assert n_glob > 10
+    reads = op.read_fastq(ds_snps_rich + ".lr.fq")[:8]
+    seqs, quals = [r[1] for r in reads], [r[2] for r in reads]
+    want, _ = og1.correct_batch(seqs, quals, threads=4)
+    assert og2.correct_batch(seqs, quals, threads=4)[0] == want
+    assert pg2.correct_batch(seqs, quals) == want
+
+
+def test_tinybitmap_stream_is_refused_loudly(ds_small, tmp_path):
+    """PairID flag 0 = Bifrost TinyBitmap::write payload (src/PairID.cpp:1158-1167): layout unverifiable without Bifrost. The loader
+    must name the problem instead of mis-parsing the rest of the file."""
+    rt = ds_small + ".index.k31.rtsk"
+    data = bytearray(open(rt, "rb").read())
+    data[32:40] = struct.pack("<Q", 0)  # first record's global PairID word -> flag 0
+    bad = str(tmp_path / "flag0.rtsk")
+    open(bad, "wb").write(bytes(data))
+    try:
+        api.Graph(ds_small + ".index.k31.fasta.gz", bad, 31, upload=False)
+        assert False, "flag-0 stream accepted"
+    except api.RtkError as e:
+        assert "TinyBitmap" in str(e)
