@@ -89,6 +89,12 @@ int rtk_graph_adopt_device(rtk_graph* g);
 int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* dev_ptrs, const uint64_t* bytes, int n, const rtk_graph_info* info);
 int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n);
 
+/* Single-process multi-GPU (the C++ `Ratatosk correct` driver): the index is parsed and flattened ONCE, uploaded to one GPU and
+ * replicated to the others device-to-device (xGMI peer copies, one per flat buffer) -- the reference's worker threads likewise
+ * share one graph (src/Ratatosk.cpp:618,727). The clone has no host image; release it with rtk_graph_free. */
+int rtk_n_devices(void); /* HIP devices visible to the process (0: every compute call fails with RTK_ERR_NO_DEVICE) */
+int rtk_graph_clone_to_device(const rtk_graph* src, int device, rtk_graph** out);
+
 int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info);
 void rtk_graph_free(rtk_graph* g);
 /* Indexes written by the reference carry short-cycle annotations (detectShortCycles, src/Graph.cpp:4660, always) and SNP-ambiguity
@@ -122,6 +128,10 @@ int rtk_batch_run(rtk_batch* b, const rtk_opts* opts);
 int rtk_batch_run_seeds(rtk_batch* b, const rtk_opts* opts);
 int rtk_batch_run_regions(rtk_batch* b, const rtk_opts* opts);
 int rtk_batch_fetch(rtk_batch* b, char** out_seq, char** out_qual, uint32_t* out_len);
+/* rtk_batch_fetch without the per-read allocations: the corrected records stay packed in (pinned) host memory owned by the batch --
+ * read i is pool[off[i] .. +len[i]) followed by its quality string pool[off[i]+len[i] .. +len[i]) -- valid until the batch is freed
+ * or run again. What a writer that formats FASTQ blocks needs (reference: writeCorrectedOutput, src/Ratatosk.cpp:510-520). */
+int rtk_batch_fetch_view(rtk_batch* b, const char** pool, const uint64_t** off, const uint32_t** len);
 int rtk_batch_get_stats(const rtk_batch* b, rtk_stats* stats);
 void rtk_batch_free(rtk_batch* b);
 

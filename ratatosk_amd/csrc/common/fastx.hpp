@@ -9,12 +9,37 @@
 
 #include <zlib.h>
 
+#include <cctype>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
 namespace rtk {
+
+// A batch of reads in ONE buffer (names, sequences and, on request, qualities back to back) + offsets: what a ticket of the host
+// driver carries from the reader thread to a GPU worker without per-record strings.
+class PackedReads {
+public:
+    explicit PackedReads(bool keep_qual = false) : keep_qual_(keep_qual), n_bases_(0) {}
+    void reserve(size_t bytes) { buf_.reserve(bytes); }
+    size_t size() const { return rec_.size(); }
+    size_t n_bases() const { return n_bases_; }
+    bool keeps_qual() const { return keep_qual_; }
+    const char* name(size_t i) const { return buf_.data() + rec_[i].name_off; }
+    uint32_t name_len(size_t i) const { return rec_[i].name_len; }
+    const char* seq(size_t i) const { return buf_.data() + rec_[i].seq_off; }
+    uint32_t seq_len(size_t i) const { return rec_[i].seq_len; }
+    const char* qual(size_t i) const { return rec_[i].has_qual ? buf_.data() + rec_[i].seq_off + rec_[i].seq_len : nullptr; } // seq_len characters
+private:
+    friend class FastxReader;
+    struct Rec { size_t name_off, seq_off; uint32_t name_len, seq_len; bool has_qual; };
+    std::vector<char> buf_;
+    std::vector<Rec> rec_;
+    bool keep_qual_;
+    size_t n_bases_;
+};
 
 class FastxReader {
 public:
@@ -60,7 +85,65 @@ public:
         return true;
     }
 
+    // Same record conventions as next(), appended to `out` (sequence lines of a multi-line FASTA record are concatenated in place).
+    bool next_packed(PackedReads& out) {
+        std::vector<char>& b = out.buf_;
+        size_t h0;
+        while (true) { // header
+            h0 = b.size();
+            if (!getline_append(b)) return false;
+            if (b.size() > h0 && (b[h0] == '>' || b[h0] == '@')) break;
+            b.resize(h0);
+        }
+        const bool fastq = (b[h0] == '@');
+        size_t e = h0 + 1;
+        while (e < b.size() && !isspace(static_cast<unsigned char>(b[e]))) ++e;
+        memmove(&b[h0], &b[h0 + 1], e - (h0 + 1)); // drop the marker, keep the name
+        PackedReads::Rec r; r.name_off = h0; r.name_len = static_cast<uint32_t>(e - (h0 + 1)); r.has_qual = false;
+        b.resize(h0 + r.name_len);
+        r.seq_off = b.size();
+        if (fastq) {
+            if (!getline_append(b)) { b.resize(h0); return false; }
+            r.seq_len = static_cast<uint32_t>(b.size() - r.seq_off);
+            const size_t p0 = b.size();
+            if (!getline_append(b)) { b.resize(h0); return false; } // '+'
+            b.resize(p0);
+            if (!getline_append(b)) { b.resize(h0); return false; }
+            if (out.keep_qual_ && b.size() - p0 == r.seq_len) r.has_qual = true; else b.resize(p0);
+        } else {
+            while (true) {
+                const size_t p0 = b.size();
+                if (!getline_append(b)) break;
+                if (b.size() > p0 && (b[p0] == '>' || b[p0] == '@')) { peek_.assign(&b[p0], b.size() - p0); has_peek_ = true; b.resize(p0); break; }
+            }
+            r.seq_len = static_cast<uint32_t>(b.size() - r.seq_off);
+        }
+        out.rec_.push_back(r); out.n_bases_ += r.seq_len;
+        return true;
+    }
+
 private:
+    bool getline_append(std::vector<char>& out) {
+        if (has_peek_) { out.insert(out.end(), peek_.begin(), peek_.end()); has_peek_ = false; return true; }
+        const size_t start = out.size();
+        bool got = false;
+        while (true) {
+            if (pos_ == end_) {
+                if (eof_) break;
+                const int n = gzread(fp_, buf_, sizeof(buf_));
+                if (n <= 0) { eof_ = true; break; }
+                pos_ = 0; end_ = static_cast<size_t>(n);
+            }
+            const char* p = static_cast<const char*>(memchr(buf_ + pos_, '\n', end_ - pos_));
+            got = true;
+            if (p) { out.insert(out.end(), static_cast<const char*>(buf_ + pos_), p); pos_ = static_cast<size_t>(p - buf_) + 1; break; }
+            out.insert(out.end(), buf_ + pos_, buf_ + end_);
+            pos_ = end_;
+        }
+        if (out.size() > start && out.back() == '\r') out.pop_back();
+        return got;
+    }
+
     bool getline(std::string& out) {
         if (has_peek_) { out.swap(peek_); has_peek_ = false; return true; }
         out.clear();
@@ -87,7 +170,7 @@ private:
     }
 
     gzFile fp_;
-    char buf_[1 << 16];
+    char buf_[1 << 18];
     size_t pos_, end_;
     bool eof_;
     std::string peek_;

@@ -64,7 +64,22 @@ struct rtk_graph {
         if (pool_bytes + bytes > (24ull << 30)) { rtk_dfree(p); return; } // keep at most 24 GB parked
         pool.insert(std::make_pair(bytes, p)); pool_bytes += bytes;
     }
-    void pool_clear() { std::lock_guard<std::mutex> h(pool_lock); for (std::multimap<uint64_t, void*>::iterator it = pool.begin(); it != pool.end(); ++it) rtk_dfree(it->second); pool.clear(); pool_bytes = 0; }
+    void pool_clear() { std::lock_guard<std::mutex> h(pool_lock); for (std::multimap<uint64_t, void*>::iterator it = pool.begin(); it != pool.end(); ++it) rtk_dfree(it->second); pool.clear(); pool_bytes = 0;
+                        for (std::multimap<uint64_t, void*>::iterator it = hpool.begin(); it != hpool.end(); ++it) rtk_hfree_pinned(it->second); hpool.clear(); hpool_bytes = 0; }
+    // pinned host staging buffers of finished batches (packed reads in, packed records out): hipHostMalloc costs milliseconds per call
+    std::multimap<uint64_t, void*> hpool; uint64_t hpool_bytes = 0;
+    void* stage_take(uint64_t bytes, uint64_t* got) {
+        bytes = (bytes + (1u << 20) - 1) >> 20 << 20;
+        { std::lock_guard<std::mutex> h(pool_lock);
+          std::multimap<uint64_t, void*>::iterator it = hpool.lower_bound(bytes);
+          if (it != hpool.end() && it->first <= 2 * bytes + (4u << 20)) { void* p = it->second; *got = it->first; hpool_bytes -= it->first; hpool.erase(it); return p; } }
+        *got = bytes; return rtk_hmalloc_pinned(bytes);
+    }
+    void stage_give(void* p, uint64_t bytes) {
+        std::lock_guard<std::mutex> h(pool_lock);
+        if (hpool_bytes + bytes > (8ull << 30)) { rtk_hfree_pinned(p); return; }
+        hpool.insert(std::make_pair(bytes, p)); hpool_bytes += bytes;
+    }
     rtk_graph() { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { dbuf[i] = nullptr; dbytes[i] = 0; } memset(&dview, 0, sizeof(dview)); memset(&info, 0, sizeof(info)); }
 };
 
@@ -154,6 +169,26 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
     g->device = device; g->info.device = device; g->on_device = true;
     graph_set_view(g);
+    return RTK_OK;
+}
+
+extern "C" int rtk_n_devices(void) { return rtk_device_count(); }
+
+// One more replica of a resident graph on another GPU of the same process: the flat buffers go device to device (xGMI peers), the host
+// image is neither parsed again nor copied (reference counterpart: ONE graph shared by all worker threads, src/Ratatosk.cpp:618,727).
+extern "C" int rtk_graph_clone_to_device(const rtk_graph* src, int device, rtk_graph** out) {
+    if (!src || !out) return rtk_fail(RTK_ERR_ARG, "rtk_graph_clone_to_device: null argument");
+    if (!src->on_device) return rtk_fail(RTK_ERR_ARG, "rtk_graph_clone_to_device: the source graph is not resident on a device");
+    int rc = require_device(device); if (rc) return rc;
+    std::unique_ptr<rtk_graph> g(new rtk_graph());
+    try {
+        rtk_set_device(device);
+        for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { g->dbuf[i] = rtk_dmalloc(src->dbytes[i]); g->dbytes[i] = src->dbytes[i]; rtk_d2d_peer(g->dbuf[i], device, src->dbuf[i], src->device, src->dbytes[i]); }
+        rtk_dsync();
+    } catch (const std::exception& e) { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]); return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_graph_clone_to_device: ") + e.what()); }
+    g->info = src->info; g->info.device = device; g->device = device; g->on_device = true;
+    graph_set_view(g.get());
+    *out = g.release();
     return RTK_OK;
 }
 

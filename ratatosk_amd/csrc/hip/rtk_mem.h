@@ -31,8 +31,13 @@ inline void rtk_stream_destroy(rtk_stream_t) {}
 inline void rtk_ssync(rtk_stream_t) {}
 inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t) { if (n) memcpy(h, d, n); }
 inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t) { if (n) memset(d, 0, n); }
-inline int rtk_device_count() { return 1; }
+inline int rtk_device_count() { const char* e = getenv("RTK_SIM_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; } // pretend GPUs: the multi-GPU host plumbing runs on CPU
 inline void rtk_set_device(int) {}
+inline void rtk_d2d_peer(void* d, int, const void* s, int, uint64_t n) { if (n) memcpy(d, s, n); }
+inline void* rtk_hmalloc_pinned(uint64_t bytes) { void* p = malloc(bytes ? bytes : 1); if (!p) throw std::runtime_error("sim: out of memory"); return p; }
+inline void rtk_hfree_pinned(void* p) { free(p); }
+inline void rtk_h2d_s(void* d, const void* h, uint64_t n, rtk_stream_t) { if (n) memcpy(d, h, n); }
+inline void rtk_check_async_d2h(void* h, const void* d, uint64_t n, rtk_stream_t) { if (n) memcpy(h, d, n); }
 
 template <class F, class... A>
 inline void rtk_launch(F f, int grid, rtk_stream_t, A... a) {
@@ -72,6 +77,13 @@ inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t s) { if (
 inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemsetAsync(d, 0, n, s), "hipMemsetAsync"); }
 inline int rtk_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline void rtk_set_device(int d) { rtk_check(hipSetDevice(d), "hipSetDevice"); }
+// GPU -> GPU copy of a flat graph buffer (xGMI when the two devices are peers; the runtime stages through the host otherwise)
+inline void rtk_d2d_peer(void* d, int ddev, const void* s, int sdev, uint64_t n) { if (n) rtk_check(hipMemcpyPeer(d, ddev, s, sdev, n), "hipMemcpyPeer"); }
+// pinned host staging memory: H2D / D2H copies from it run at PCIe speed and asynchronously on the batch's stream
+inline void* rtk_hmalloc_pinned(uint64_t bytes) { void* p = nullptr; rtk_check(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc"); return p; }
+inline void rtk_hfree_pinned(void* p) { if (p) (void)hipHostFree(p); }
+inline void rtk_h2d_s(void* d, const void* h, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s), "hipMemcpyAsync H2D"); }
+inline void rtk_check_async_d2h(void* h, const void* d, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "hipMemcpyAsync D2H"); } // completed by the next rtk_d2h_s / rtk_ssync
 
 template <class F, class... A>
 inline void rtk_launch(F f, int grid, rtk_stream_t s, A... a) {

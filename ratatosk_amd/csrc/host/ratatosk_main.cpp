@@ -1,8 +1,18 @@
 // `Ratatosk` host driver for the in-scope branch of the reference CLI: `Ratatosk correct -1 -g G -d D -l reads -o OUT`
 // (reference: src/Ratatosk.cpp:145-301 option table, :303-508 validation, :618-1000 search(), :1029-1037 file names,
-// :1083-1095/:1145-1149 pass-1 branch). C++11 host orchestration over the C ABI of libratatosk_hip.so: one worker thread
-// per GPU (two, so that consecutive batches overlap) pulls read batches by ticket, corrects them on its device, and the writer emits blocks in ticket order (pass-1
-// output is always in input order: src/Ratatosk.cpp:919). Everything else (`index`, `-2`, `-u`, `-p/-P`) is out of scope.
+// :1083-1095/:1145-1149 pass-1 branch). C++11 host orchestration over the C ABI of libratatosk_hip.so.
+//
+// Shape of the pipeline (the reference: N threads, each under a spin-lock reads a >= 1 MiB batch + takes a ticket, corrects it,
+// under a second lock appends its block; blocks are re-ordered by ticket at the end, src/Ratatosk.cpp:727-999):
+//   reader thread   parses FASTA/FASTQ(.gz) into packed ticket batches (one buffer per batch, no per-record strings), bounded queue;
+//   GPU workers     `--workers-per-gpu` (3) threads per GPU: pack + H2D, kernels, D2H of one ticket each through the C ABI; the
+//                   library overlaps the stages of different tickets on the device, the host work of one hides behind the kernels of
+//                   the others; formatting of the FASTQ block happens here too, straight from the pinned fetch view;
+//   ordered writer  whoever completes the next ticket in line writes it and every consecutive finished one (input order is
+//                   guaranteed for pass 1: src/Ratatosk.cpp:919); workers that run too far ahead of the writer wait.
+// The index is parsed and flattened ONCE (-c threads), uploaded to the first GPU and replicated device-to-device to the others.
+// `-c` keeps the reference's meaning (host threads, <= hardware concurrency: src/Ratatosk.cpp:318); GPUs are chosen with --gpus.
+// Everything else (`index`, `-2`, `-u`, `-p/-P`) is out of scope.
 #include <getopt.h>
 
 #include <atomic>
@@ -11,7 +21,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -23,20 +35,29 @@
 struct Opt {
     std::vector<std::string> in_long;
     std::string out, graph, udata;
-    int cores = 1, k1 = 31, max_qual = 40;
+    int cores = 1, gpus = 0, workers_per_gpu = 3, k1 = 31, max_qual = 40;
     double min_conf_snp = 0.9;
-    size_t insert_sz = 500, w1 = 1000, batch_bases = 64u << 20;
+    size_t insert_sz = 500, w1 = 1000, batch_bases = 32u << 20;
     bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false;
 };
 
 static void usage() {
     fprintf(stderr, "Ratatosk (MI355X hot-path build)\n\nUsage: Ratatosk correct -1 -g <graph.fasta.gz> -d <unitig_data.rtsk> -l <long_reads> -o <out_prefix> [options]\n"
-                    "  -c, --cores           number of GPUs/worker threads to use (default 1)\n  -i, --insert-sz       insert size of the short reads (default 500)\n"
+                    "  -c, --cores           number of host threads (default 1): index parsing, FASTQ formatting\n"
+                    "      --gpus            number of GPUs to use (default: all visible)\n"
+                    "      --workers-per-gpu tickets in flight per GPU (default 3)\n"
+                    "  -B, --batch-bases     long-read bases per ticket (default 32 Mi)\n"
+                    "  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
                     "  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
                     "      --strip-annotations  drop the short-cycle / SNP annotations of the index before correcting (fixRepeats / fixAmbiguity then have nothing to do)\n"
                     "Writes <out_prefix>.2.fastq (plain FASTQ, input order). Only the `correct -1` step with a pre-built index is in scope.\n");
 }
+
+struct Ticket { // one batch of reads, packed: the reference's >= buffer_sz unit of work (src/Common.hpp:138, src/Ratatosk.cpp:757)
+    size_t id = 0;
+    rtk::PackedReads reads;
+};
 
 int main(int argc, char** argv) {
     Opt opt;
@@ -48,7 +69,7 @@ int main(int argc, char** argv) {
     static struct option lo[] = {{"in-long", required_argument, 0, 'l'}, {"out-long", required_argument, 0, 'o'}, {"cores", required_argument, 0, 'c'},
         {"in-graph", required_argument, 0, 'g'}, {"in-unitig-data", required_argument, 0, 'd'}, {"insert-sz", required_argument, 0, 'i'}, {"k1", required_argument, 0, 'k'},
         {"max-len-weak1", required_argument, 0, 'w'}, {"max-base-qual", required_argument, 0, 'Q'}, {"min-conf-snp-corr", required_argument, 0, 'm'}, {"1st-pass-only", no_argument, 0, '1'}, {"2nd-pass-only", no_argument, 0, '2'},
-        {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
+        {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"gpus", required_argument, 0, 1002}, {"workers-per-gpu", required_argument, 0, 1003}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
     int c, idx = 0;
     while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:12v", lo, &idx)) != -1) {
         switch (c) {
@@ -67,105 +88,170 @@ int main(int argc, char** argv) {
             case '2': opt.pass2 = true; break;
             case 'v': opt.verbose = true; break;
             case 1001: opt.strip = true; break;
+            case 1002: opt.gpus = atoi(optarg); break;
+            case 1003: opt.workers_per_gpu = atoi(optarg); break;
             case 's': fprintf(stderr, "Ratatosk::correct: short reads are only needed by `index` (not in scope); ignored\n"); break;
             default: usage(); return 0; // the reference returns 0 on option errors too (src/Ratatosk.cpp:1018)
         }
     }
     if (opt.pass2 || !opt.pass1) { fprintf(stderr, "Ratatosk::correct: only the first pass (-1) with a pre-built index (-g, -d) is in scope of this build\n"); return 1; }
     if (opt.graph.empty() || opt.udata.empty() || opt.in_long.empty() || opt.out.empty()) { fprintf(stderr, "Ratatosk::correct: -g, -d, -l and -o are required\n"); return 0; }
-    if (opt.cores < 1) opt.cores = 1;
+    { // src/Ratatosk.cpp:312-322
+        const unsigned hc = std::thread::hardware_concurrency();
+        if (opt.cores <= 0) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of threads cannot be less than or equal to 0.\n"); return 0; }
+        if (hc && static_cast<unsigned>(opt.cores) > hc) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of threads cannot be greater than or equal to %u.\n", hc); return 0; }
+    }
     if (opt.min_conf_snp < 0.0 || opt.min_conf_snp > 1.0) { fprintf(stderr, "Ratatosk::Ratatosk(): Minimum confidence threshold to correct a SNP must be in [0.0, 1.0].\n"); return 0; } // src/Ratatosk.cpp:366-376
+    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = 1;
+    if (opt.batch_bases < 1) opt.batch_bases = 1;
+
+    const int n_dev = rtk_n_devices();
+    if (n_dev <= 0) { fprintf(stderr, "Ratatosk::Ratatosk(): no HIP device visible: the correction path has no CPU fallback\n"); return 1; }
+    if (opt.gpus < 0 || opt.gpus > n_dev) { fprintf(stderr, "Ratatosk::Ratatosk(): --gpus %d but %d HIP device(s) are visible\n", opt.gpus, n_dev); return 1; }
+    const int n_gpus = opt.gpus ? opt.gpus : n_dev;
 
     // input files (a text file lists one path per line: src/Common.cpp:428-446)
     std::vector<std::string> files;
     for (size_t i = 0; i < opt.in_long.size(); ++i) { const std::vector<std::string> v = rtk::expand_input_list(opt.in_long[i]); files.insert(files.end(), v.begin(), v.end()); }
 
+    auto now_us = []() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (opt.verbose) printf("Ratatosk::Ratatosk(): Reading graph.\n");
-    // -c N = N GPUs. Two host workers per GPU share its graph: while one batch is in its region stage the next one runs its seed
-    // stage on its own stream (rtk_correct_batch = create + seeds + regions + fetch; the stages of different batches overlap).
-    const int n_gpus = opt.cores, n_workers = 2 * opt.cores;
+    const long long t_load0 = now_us();
     std::vector<rtk_graph*> graphs(n_gpus, nullptr);
     // the per-wave scratch slabs (tens of GB per GPU, seconds of hipMalloc) are reserved while the index files are parsed
     std::vector<std::thread> reservers;
     for (int w = 0; w < n_gpus; ++w) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
-    for (int w = 0; w < n_gpus; ++w) {
-        bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, 1, &graphs[w]) == RTK_OK;
-        if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[w]); if (w == 0 && ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs\n", ns); }
-        if (!ok || rtk_graph_upload(graphs[w], w) != RTK_OK) {
-            fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error());
-            exit(1);
-        }
+    { // ONE parse + flatten, ONE host image; the other GPUs get device-to-device copies of the flat buffers
+        bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, opt.cores, &graphs[0]) == RTK_OK;
+        if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[0]); if (ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs\n", ns); }
+        ok = ok && rtk_graph_upload(graphs[0], 0) == RTK_OK;
+        for (int w = 1; ok && w < n_gpus; ++w) ok = rtk_graph_clone_to_device(graphs[0], w, &graphs[w]) == RTK_OK;
+        if (!ok) { fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join(); exit(1); }
     }
     for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join();
+    const long long t_load1 = now_us();
     rtk_opts ro; rtk_opts_default(graphs[0], &ro);
     ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_qual = opt.max_qual; ro.min_confidence_snp_corr = opt.min_conf_snp;
 
     const std::string fn_out = opt.out + ".2.fastq"; // opt_pass1.filename_long_out += ".2" (src/Ratatosk.cpp:1079) + ".fastq" (:622)
     FILE* fout = fopen(fn_out.c_str(), "w");
     if (!fout) { fprintf(stderr, "Ratatosk::search(): cannot open %s for writing\n", fn_out.c_str()); exit(1); }
+    setvbuf(fout, nullptr, _IOFBF, 8u << 20);
 
     if (opt.verbose) printf("Ratatosk::Ratatosk(): Correcting long reads (1/2).\n");
-    std::mutex m_in, m_out; std::condition_variable cv_out;
-    rtk::FastxReader reader; size_t file_i = 0; bool file_open = false, stop = false;
-    size_t ticket_dispenser = 0, next_to_write = 0, n_reads = 0;
-    std::map<size_t, std::string> done; // ticket -> formatted FASTQ block
-    bool failed = false;
-    std::atomic<long long> us_parse(0), us_correct(0), us_format(0);
-    auto now_us = []() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const int n_workers = opt.workers_per_gpu * n_gpus;
+    const size_t q_cap = static_cast<size_t>(n_workers) + 2, ahead_cap = 2 * static_cast<size_t>(n_workers) + 2;
+    std::mutex m_in, m_out; std::condition_variable cv_in_full, cv_in_empty, cv_out;
+    std::deque<std::unique_ptr<Ticket> > queue; bool reader_done = false;
+    size_t next_to_write = 0;
+    std::map<size_t, std::string> done; // ticket -> formatted FASTQ block, at most ahead_cap entries
+    std::atomic<bool> failed(false);
+    std::string fail_msg; std::mutex m_fail;
+    std::atomic<long long> us_parse(0), us_correct(0), us_format(0), us_write(0), n_reads(0), n_bases(0);
     const long long t_begin = now_us();
+    auto fail = [&](const std::string& msg) {
+        { std::lock_guard<std::mutex> lk(m_fail); if (fail_msg.empty()) fail_msg = msg; }
+        failed = true;
+        { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all(); cv_in_empty.notify_all();
+        { std::lock_guard<std::mutex> lk(m_out); } cv_out.notify_all();
+    };
+
+    std::thread reader_thread([&]() {
+        rtk::FastxReader reader; size_t file_i = 0; bool file_open = false, eof_all = false; size_t ticket = 0;
+        while (!eof_all && !failed) {
+            const long long tp0 = now_us();
+            std::unique_ptr<Ticket> t(new Ticket()); t->id = ticket;
+            t->reads.reserve(opt.batch_bases + (opt.batch_bases >> 3));
+            while (t->reads.n_bases() < opt.batch_bases) {
+                if (!file_open) { if (file_i >= files.size()) { eof_all = true; break; } if (!reader.open(files[file_i++])) { fail("Ratatosk::search(): cannot open input file " + files[file_i - 1]); return; } file_open = true; }
+                if (!reader.next_packed(t->reads)) { file_open = false; continue; }
+                if (opt.verbose && ((n_reads.fetch_add(1) + 1) % 1000 == 0)) printf("Ratatosk::correct(): Processed %lld reads \n", n_reads.load());
+            }
+            us_parse += now_us() - tp0;
+            if (t->reads.size() == 0) break;
+            n_bases += static_cast<long long>(t->reads.n_bases());
+            ++ticket;
+            std::unique_lock<std::mutex> lk(m_in);
+            cv_in_full.wait(lk, [&]() { return queue.size() < q_cap || failed; });
+            if (failed) break;
+            queue.push_back(std::move(t));
+            cv_in_empty.notify_one();
+        }
+        { std::lock_guard<std::mutex> lk(m_in); reader_done = true; }
+        cv_in_empty.notify_all();
+    });
 
     auto worker = [&](int w) {
-        while (true) {
-            std::vector<std::string> names, seqs, quals; size_t ticket, bases = 0;
+        rtk_graph* g = graphs[w % n_gpus];
+        while (!failed) {
+            std::unique_ptr<Ticket> t;
             {
-                std::lock_guard<std::mutex> lk(m_in);
-                if (stop) return;
-                const long long tp0 = now_us();
-                ticket = ticket_dispenser++;
-                std::string n, s, q;
-                while (bases < opt.batch_bases) {
-                    if (!file_open) { if (file_i >= files.size()) { stop = true; break; } if (!reader.open(files[file_i++])) { fprintf(stderr, "Ratatosk::search(): cannot open input file\n"); exit(1); } file_open = true; }
-                    if (!reader.next(n, s, q)) { file_open = false; continue; }
-                    bases += s.size(); names.push_back(n); seqs.push_back(s); quals.push_back(q);
-                    if (opt.verbose && (++n_reads % 1000 == 0)) printf("Ratatosk::correct(): Processed %zu reads \n", n_reads);
-                }
-                us_parse += now_us() - tp0;
+                std::unique_lock<std::mutex> lk(m_in);
+                cv_in_empty.wait(lk, [&]() { return !queue.empty() || reader_done || failed; });
+                if (failed || queue.empty()) return;
+                t = std::move(queue.front()); queue.pop_front();
+                cv_in_full.notify_one();
             }
+            { // do not run further ahead of the writer than the block map may grow
+                std::unique_lock<std::mutex> lk(m_out);
+                cv_out.wait(lk, [&]() { return t->id < next_to_write + ahead_cap || failed; });
+                if (failed) return;
+            }
+            const rtk::PackedReads& R = t->reads;
+            const uint32_t n = static_cast<uint32_t>(R.size());
+            std::vector<const char*> ps(n); std::vector<uint32_t> len(n);
+            for (uint32_t i = 0; i < n; ++i) { ps[i] = R.seq(i); len[i] = R.seq_len(i); }
+            const long long tc0 = now_us();
+            rtk_batch* b = nullptr;
+            int rc = rtk_batch_create(g, n, ps.data(), nullptr, len.data(), &b); // pass 1 replaces every quality (src/Correction.cpp:184-185)
+            if (rc == RTK_OK) rc = rtk_batch_run(b, &ro);
+            const char* pool = nullptr; const uint64_t* off = nullptr; const uint32_t* olen = nullptr;
+            if (rc == RTK_OK) rc = rtk_batch_fetch_view(b, &pool, &off, &olen);
+            us_correct += now_us() - tc0;
+            if (rc != RTK_OK) { fail(std::string("Ratatosk::correct(): ") + rtk_last_error()); if (b) rtk_batch_free(b); return; }
+            const long long tf0 = now_us();
             std::string block;
-            if (!seqs.empty()) {
-                const uint32_t n = static_cast<uint32_t>(seqs.size());
-                std::vector<const char*> ps(n), pq(n); std::vector<uint32_t> len(n), olen(n); std::vector<char*> os(n, nullptr), oq(n, nullptr);
-                for (uint32_t i = 0; i < n; ++i) { ps[i] = seqs[i].c_str(); pq[i] = quals[i].empty() ? nullptr : quals[i].c_str(); len[i] = static_cast<uint32_t>(seqs[i].size()); }
-                const long long tc0 = now_us();
-                const int rc_ = rtk_correct_batch(graphs[w % n_gpus], &ro, n, ps.data(), pq.data(), len.data(), os.data(), oq.data(), olen.data());
-                us_correct += now_us() - tc0;
-                const long long tf0 = now_us();
-                if (rc_ != RTK_OK) {
-                    fprintf(stderr, "Ratatosk::correct(): %s\n", rtk_last_error()); failed = true;
-                } else {
-                    for (uint32_t i = 0; i < n; ++i) { // writeCorrectedOutput, trim == 0 (src/Ratatosk.cpp:516-520)
-                        block += "@"; block += names[i]; block += "\n"; block.append(os[i], olen[i]); block += "\n+\n"; block += oq[i]; block += "\n";
-                        rtk_free(os[i]); rtk_free(oq[i]);
-                    }
+            { size_t tot = 0; for (uint32_t i = 0; i < n; ++i) tot += R.name_len(i) + 2ull * olen[i] + 6; block.resize(tot); }
+            { // writeCorrectedOutput, trim == 0 (src/Ratatosk.cpp:516-520): "@name\nseq\n+\nqual\n"
+                char* p = &block[0];
+                for (uint32_t i = 0; i < n; ++i) {
+                    *p++ = '@'; memcpy(p, R.name(i), R.name_len(i)); p += R.name_len(i); *p++ = '\n';
+                    memcpy(p, pool + off[i], olen[i]); p += olen[i]; *p++ = '\n'; *p++ = '+'; *p++ = '\n';
+                    memcpy(p, pool + off[i] + olen[i], olen[i]); p += olen[i]; *p++ = '\n';
                 }
-                us_format += now_us() - tf0;
             }
+            rtk_batch_free(b);
+            us_format += now_us() - tf0;
             {
                 std::unique_lock<std::mutex> lk(m_out);
-                done[ticket] = block;
-                while (!done.empty() && done.begin()->first == next_to_write) { fwrite(done.begin()->second.data(), 1, done.begin()->second.size(), fout); done.erase(done.begin()); ++next_to_write; }
+                done[t->id].swap(block);
+                const long long tw0 = now_us();
+                while (!done.empty() && done.begin()->first == next_to_write) {
+                    const std::string& blk = done.begin()->second;
+                    if (fwrite(blk.data(), 1, blk.size(), fout) != blk.size()) { lk.unlock(); fail("Ratatosk::search(): write error on " + fn_out); return; }
+                    done.erase(done.begin()); ++next_to_write;
+                }
+                us_write += now_us() - tw0;
             }
-            if (failed) return;
+            cv_out.notify_all();
         }
     };
     std::vector<std::thread> th;
     for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w);
     for (size_t i = 0; i < th.size(); ++i) th[i].join();
-    for (std::map<size_t, std::string>::iterator it = done.begin(); it != done.end(); ++it) fwrite(it->second.data(), 1, it->second.size(), fout);
-    fclose(fout);
-    if (opt.verbose) printf("Ratatosk::correct(): correction phase %.2f s wall; summed over workers: parse %.2f s, correct (pack + GPU + unpack) %.2f s, format %.2f s\n",
-                            1e-6 * (now_us() - t_begin), 1e-6 * us_parse.load(), 1e-6 * us_correct.load(), 1e-6 * us_format.load());
+    { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all();
+    reader_thread.join();
+    const bool write_ok = fclose(fout) == 0;
     for (int w = 0; w < n_gpus; ++w) rtk_graph_free(graphs[w]);
-    if (failed) exit(1);
+    if (failed || !write_ok || !done.empty()) { // a partial OUT.2.fastq must not look like a result
+        remove(fn_out.c_str());
+        fprintf(stderr, "%s\n", fail_msg.empty() ? "Ratatosk::search(): output incomplete" : fail_msg.c_str());
+        exit(1);
+    }
+    const double wall = 1e-6 * (now_us() - t_begin);
+    if (opt.verbose || getenv("RTK_CLI_STATS"))
+        fprintf(opt.verbose ? stdout : stderr, "Ratatosk::correct(): graph load + upload %.2f s; correction phase %.2f s wall, %lld bases, %.3g bases/s on %d GPU(s) x %d workers; "
+                "thread-seconds: parse %.2f, correct (pack + GPU + fetch) %.2f, format %.2f, write %.2f\n", 1e-6 * (t_load1 - t_load0), wall, n_bases.load(),
+                wall > 0 ? static_cast<double>(n_bases.load()) / wall : 0.0, n_gpus, opt.workers_per_gpu, 1e-6 * us_parse.load(), 1e-6 * us_correct.load(), 1e-6 * us_format.load(), 1e-6 * us_write.load());
     return 0;
 }

@@ -19,6 +19,28 @@ def test_cli_usage_and_scope_messages():
     assert r.returncode == 1 and "first pass" in r.stderr
 
 
+def test_cli_cores_keep_the_reference_meaning(ds_small, tmp_path):
+    """-c is the number of host threads and must not exceed the hardware concurrency (src/Ratatosk.cpp:312-322: message, return 0)."""
+    r = subprocess.run([EXE, "correct", "-1", "-c", "100000", "-g", "a", "-d", "b", "-l", "c", "-o", "d"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Number of threads cannot be greater" in r.stderr
+    r = subprocess.run([EXE, "correct", "-1", "-c", "0", "-g", "a", "-d", "b", "-l", "c", "-o", "d"], capture_output=True, text=True)
+    assert r.returncode == 0 and "less than or equal to 0" in r.stderr
+
+
+def test_cli_partial_output_is_removed_on_failure(ds_small, tmp_path):
+    """A ticket that fails (here: an input file that does not exist, second in the list) must not leave an OUT.2.fastq that silently
+    lacks reads (simulator build of the driver)."""
+    import os as _os
+    sim = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "hostsim", "Ratatosk_sim")
+    lst = str(tmp_path / "inputs.txt")
+    with open(lst, "w") as f:
+        f.write(ds_small + ".lr.fq\n" + str(tmp_path / "missing.fq") + "\n")
+    out = str(tmp_path / "out")
+    r = subprocess.run([sim, "correct", "-1", "-c", "1", "-B", "6000", "-g", ds_small + ".index.k31.fasta.gz", "-d", ds_small + ".index.k31.rtsk", "-l", lst, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open input file" in r.stderr
+    assert not _os.path.exists(out + ".2.fastq")
+
+
 def test_cli_fails_loudly_without_gpu(ds_small, tmp_path):
     import torch
     if torch.cuda.is_available():
