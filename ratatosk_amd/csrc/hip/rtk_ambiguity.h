@@ -157,7 +157,7 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
     nma = nms;
     rtk_sync();
     uint32_t nm = 0;
-    rtk_align_path(c, qt, query_len, ref, ref_len, RTK_MODE_SHW, &nm); nm = rtk_u(nm);
+    RTK_SITE(17); rtk_align_path(c, qt, query_len, ref, ref_len, RTK_MODE_SHW, &nm); nm = rtk_u(nm);
     if (rtk_failed(s)) return;
     { // walk of the alignment (:612-706); only moves touching a non-ACGT character on either side do anything
         const uint8_t* mv = rtk_ld(&s.my.moves);

@@ -179,7 +179,7 @@ RTK_DEV void rtk_wp_norm_back(const RCtx& c, WPath& p) { // the former end becom
     if (pn >= 2) { UMap* e = rtk_ld(&p.ums) + (pn - 1); e->dist = 0; e->len = rtk_nkm_u(c, rtk_ld(&e->unitig)); }
 }
 
-RTK_FN void rtk_wp_extend(const RCtx& c, WPath& p_, const UMap& um_) { // Path.hpp:308-330
+RTK_FN_HOT void rtk_wp_extend(const RCtx& c, WPath& p_, const UMap& um_) { // Path.hpp:308-330
     RegionScratch& s = *rtk_u(c.sc); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_);
     if (rtk_um_is_empty(um)) return;
     const uint32_t pn = rtk_ld(&p.n);
@@ -321,22 +321,41 @@ RTK_DEV uint32_t rtk_rec_to_string(const RCtx& c, uint64_t h, char* dst) {
     return rtk_ums_to_string(c, rtk_path_ums(s, rtk_h_lvl(h), rtk_h_off(h)), rtk_rec_n(s, h), dst);
 }
 
-RTK_FN MyersResult rtk_align(const RCtx& c, const char* q_, uint32_t m_, const char* t_, uint32_t n_, int kk_, int mode_, bool iupac_ = true) {
+// Developer statistics (simulator build only): alignments by call site. RTK_SITE(id) names the site of the calls that follow.
+#ifdef RTK_SIM
+#include <atomic>
+extern thread_local int rtk_sim_site;
+extern std::atomic<unsigned long long> rtk_sim_site_stat[32][8]; // calls, 32-bit word-columns, sum m, sum n, stored sweeps, stored word-columns, bounded (k >= 0), m > 2048
+#define RTK_SITE(id) (rtk_sim_site = (id))
+static inline void rtk_site_note(uint32_t m, uint32_t n, int k, bool stored) {
+    std::atomic<unsigned long long>* t = rtk_sim_site_stat[rtk_sim_site & 31];
+    const unsigned long long cells = static_cast<unsigned long long>((m + 31) / 32) * n;
+    if ((rtk_sim_site & 31) == 2) { int b = 0; while (b < 7 && (256u << b) <= n) ++b; rtk_sim_site_stat[26][b] += 1; rtk_sim_site_stat[27][b] += n; }
+    t[0] += 1; t[1] += cells; t[2] += m; t[3] += n; if (stored) { t[4] += 1; t[5] += cells; } if (k >= 0) t[6] += 1; if (m > 2048) t[7] += 1;
+}
+#else
+#define RTK_SITE(id) ((void)0)
+#define rtk_site_note(m, n, k, stored) ((void)0)
+#endif
+
+RTK_FN_HOT MyersResult rtk_align(const RCtx& c, const char* q_, uint32_t m_, const char* t_, uint32_t n_, int kk_, int mode_, bool iupac_ = true) {
     RegionScratch& s = *rtk_u(c.sc); const char* q = rtk_u(q_); const char* t = rtk_u(t_);
     const uint32_t m = rtk_u(m_), n = rtk_u(n_); const int kk = rtk_u(kk_), mode = rtk_u(mode_); const bool iupac = rtk_u(iupac_);
     s.cnt[3] += 1; s.cnt[4] += static_cast<unsigned long long>((m + 63) / 64) * n;
     const unsigned long long t0 = rtk_clock();
+    rtk_site_note(m, n, kk, false);
     const MyersResult r = rtk_myers_distance(s.my, q, static_cast<int>(m), t, static_cast<int>(n), kk, mode, iupac);
     s.cnt[9] += rtk_clock() - t0;
     return r;
 }
 
 // alignment with its moves (left in s.my.moves); counted like the distance call + path call pair it replaces
-RTK_FN MyersResult rtk_align_path(const RCtx& c_, const char* q_, uint32_t m_, const char* t_, uint32_t n_, int mode_, uint32_t* n_moves_) {
+RTK_FN_HOT MyersResult rtk_align_path(const RCtx& c_, const char* q_, uint32_t m_, const char* t_, uint32_t n_, int mode_, uint32_t* n_moves_) {
     const RCtx& c = *rtk_u(&c_); RegionScratch& s = *c.sc; const char* q = rtk_u(q_); const char* t = rtk_u(t_);
     const uint32_t m = rtk_u(m_), n = rtk_u(n_); const int mode = rtk_u(mode_); uint32_t* n_moves = rtk_u(n_moves_);
     s.cnt[3] += (m > 0 && n > 0) ? 2 : 1; s.cnt[4] += static_cast<unsigned long long>((m + 63) / 64) * n;
     const unsigned long long t0 = rtk_clock();
+    rtk_site_note(m, n, -1, true);
     const MyersResult r = rtk_myers_path(s.my, q, static_cast<int>(m), t, static_cast<int>(n), mode, true, n_moves);
     s.cnt[9] += rtk_clock() - t0;
     return r;
@@ -371,17 +390,17 @@ RTK_FN void rtk_select_best(const RCtx& c, const uint64_t* handles_, uint32_t n_
 
 // ------------------------------------------------------------------------------------------------ scoring (src/GraphTraversal.cpp:867-909, 722-772)
 // path string must already be in str[1] (length sl)
-RTK_FN double rtk_score_path(const RCtx& c, uint32_t sl_, const char* ref_, uint32_t ref_len_, bool terminal_) {
+RTK_FN_HOT double rtk_score_path(const RCtx& c, uint32_t sl_, const char* ref_, uint32_t ref_len_, bool terminal_) {
     RegionScratch& s = *rtk_u(c.sc); const uint32_t sl = rtk_u(sl_), ref_len = rtk_u(ref_len_); const char* ref = rtk_u(ref_); const bool terminal = rtk_u(terminal_);
     double score = 0.0;
     if (sl != 0) {
         const char* const str1 = rtk_ld(&s.str[1]);
-        if (terminal) { const MyersResult a = rtk_align(c, str1, sl, ref, ref_len, -1, RTK_MODE_NW); score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(sl)); }
-        else if (sl >= ref_len) { const MyersResult a = rtk_align(c, ref, ref_len, str1, sl, -1, RTK_MODE_HW); score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(ref_len)); }
+        if (terminal) { RTK_SITE(1); const MyersResult a = rtk_align(c, str1, sl, ref, ref_len, -1, RTK_MODE_NW); score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(sl)); }
+        else if (sl >= ref_len) { RTK_SITE(2); const MyersResult a = rtk_align(c, ref, ref_len, str1, sl, -1, RTK_MODE_HW); score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(ref_len)); }
         else {
             const uint64_t cap = static_cast<uint64_t>(static_cast<double>(sl) * (1.0 + rtk_u(c.o.weak_region_len_factor)));
             const uint32_t l_ref_len = ref_len < cap ? ref_len : static_cast<uint32_t>(cap);
-            const MyersResult a = rtk_align(c, str1, sl, ref, l_ref_len, -1, RTK_MODE_HW);
+            RTK_SITE(3); const MyersResult a = rtk_align(c, str1, sl, ref, l_ref_len, -1, RTK_MODE_HW);
             score = 1.0 - (static_cast<double>(rtk_u(a.dist)) / static_cast<double>(sl));
         }
         score = score > 0.0 ? score : 0.0; score = score < 1.0 ? score : 1.0;
@@ -397,7 +416,7 @@ RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl_, const char* ref_, u
     const double score_comp = score_best * ((score_best == 0.0) ? 0.0 : (1.0 - (score_second / score_best)));
     const char* const str1 = rtk_ld(&s.str[1]);
     uint32_t nm = 0;
-    rtk_align_path(c, str1, sl, ref, ref_len, RTK_MODE_SHW, &nm); nm = rtk_u(nm);
+    RTK_SITE(4); rtk_align_path(c, str1, sl, ref, ref_len, RTK_MODE_SHW, &nm); nm = rtk_u(nm);
     const char c_best = rtk_get_qual(score_best, 0, static_cast<uint64_t>(rtk_u(c.o.max_qual)));
     rtk_wfill(qout, rtk_get_qual(score_comp, static_cast<uint64_t>(rtk_u(c.o.out_qual)), static_cast<uint64_t>(rtk_u(c.o.max_qual))), sl);
     // walk the moves: a base gets the best-score quality when it sits on an identical reference base in an M run.
@@ -419,7 +438,7 @@ RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl_, const char* ref_, u
 }
 
 // ------------------------------------------------------------------------------------------------ colour memo (src/GraphTraversal.cpp:485-487)
-RTK_FN bool rtk_colour_ok(const RCtx& c, uint32_t u_, const uint32_t* all_pids_, uint32_t n_all_) {
+RTK_FN_HOT bool rtk_colour_ok(const RCtx& c, uint32_t u_, const uint32_t* all_pids_, uint32_t n_all_) {
     RegionScratch& s = *rtk_u(c.sc); const unsigned long long tk0 = rtk_clock(); const uint32_t u = rtk_u(u_), n_all = rtk_u(n_all_); const uint32_t* all_pids = rtk_u(all_pids_);
     const uint32_t mn = rtk_ld(&s.memo_n); const uint32_t* mu = rtk_ld(&s.memo_u); uint8_t* mvv = rtk_ld(&s.memo_v);
     for (uint32_t i0 = 0; i0 < mn; i0 += RTK_WAVE) { // 64 memo entries per step
@@ -468,6 +487,9 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
     const bool has_end = !rtk_um_is_empty(um_e);
     unsigned long long n_exp = 0;
     const unsigned long long td0 = rtk_clock(); const unsigned long long my0 = s.cnt[9];
+#ifdef RTK_SIM
+    const unsigned long long dfs_al0 = s.cnt[3];
+#endif
     while (sp > 0 && !rtk_failed(s)) {
         --sp;
         const uint64_t hp = rtk_ld(stk + 2 * sp); const uint32_t lvl = static_cast<uint32_t>(rtk_ld(stk + 2 * sp + 1));
@@ -504,6 +526,9 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
                 if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
                 rtk_wp_extend(c, w, sc);
                 if (rtk_failed(s)) break;
+#ifdef RTK_SIM
+                rtk_sim_site_stat[20][0] += 1; rtk_sim_site_stat[20][1] += sc.len + ((hp == ~0ull) ? static_cast<uint32_t>(rtk_u(c.k)) - 1 : 0); // DFS tree nodes and the columns they add
+#endif
                 if (lvl != 0) {
                     if (2 * (sp + 1) > list_cap) { rtk_fail_ovf(s, 8); break; }
                     stk[2 * sp] = rtk_wp_commit(s, w, 2); stk[2 * sp + 1] = lvl - 1; ++sp;
@@ -521,6 +546,9 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
             }
         }
     }
+#ifdef RTK_SIM
+    { const unsigned long long na = s.cnt[3] - dfs_al0; const unsigned b = na > 15 ? 15 : static_cast<unsigned>(na); rtk_sim_site_stat[21][0] += 1; rtk_sim_site_stat[22 + (b >> 3)][b & 7] += 1; rtk_sim_site_stat[24 + (b >> 3)][b & 7] += na; }
+#endif
     s.cnt[0] += n_exp;
     s.cnt[14] += (rtk_clock() - td0) - (s.cnt[9] - my0); // DFS bookkeeping: loop time minus the alignments inside it
     // qualities (:556-584): re-commit every surviving path with its quality string
@@ -553,7 +581,7 @@ RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_al
     if (non_empty_path) {
         const uint32_t sl = rtk_rec_to_string(c, hp, s.str[0]);
         if (sl == 0xFFFFFFFFu) return;
-        const MyersResult a = rtk_align(c, s.str[0], path_len_prefix, ref, ref_len, -1, RTK_MODE_SHW);
+        RTK_SITE(5); const MyersResult a = rtk_align(c, s.str[0], path_len_prefix, ref, ref_len, -1, RTK_MODE_SHW);
         end_pos_ref = static_cast<uint32_t>(a.first + 1);
     }
     if ((ref_len - end_pos_ref) != 0 && path_len < max_len_path) {
@@ -563,7 +591,7 @@ RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_al
         if (o.n_nt && o.nt1 < c.o.min_score) o.n_nt = 0;
         if (o.n_nt > 1) {
             int bid, bend;
-            rtk_select_best(c, s.list[3], o.n_nt, ref + end_pos_ref, ref_len - end_pos_ref, RTK_MODE_HW, -1.0, &bid, &bend);
+            RTK_SITE(6); rtk_select_best(c, s.list[3], o.n_nt, ref + end_pos_ref, ref_len - end_pos_ref, RTK_MODE_HW, -1.0, &bid, &bend);
             s.list[3][0] = s.list[3][bid]; o.n_nt = 1;
         }
         *n_t = o.n_t; *n_nt = o.n_nt;
@@ -590,7 +618,7 @@ RTK_FN void rtk_resize_to_best(const RCtx& c_, uint64_t* v_, uint32_t* n_, const
     const RCtx& c = *rtk_u(&c_); uint64_t* v = rtk_u(v_); uint32_t* n = rtk_u(n_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); // resizeVector
     if (*n <= 1) return;
     int bid, bend;
-    rtk_select_best(c, v, *n, ref, ref_len, RTK_MODE_SHW, -1.0, &bid, &bend);
+    RTK_SITE(7); rtk_select_best(c, v, *n, ref, ref_len, RTK_MODE_SHW, -1.0, &bid, &bend);
     if (rtk_failed(*c.sc)) return;
     v[0] = v[bid]; *n = 1;
 }
@@ -624,7 +652,7 @@ RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, 
     if (rtk_failed(s)) return ~0ull;
     const char q_max = rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual));
     int ed;
-    { const uint32_t sl = rtk_ums_to_string(c, P.ums, P.n, s.str[0]); if (sl == 0xFFFFFFFFu) return ~0ull; ed = rtk_u(rtk_align(c, s.str[0], sl, ref, ref_len, -1, RTK_MODE_NW).dist); }
+    { const uint32_t sl = rtk_ums_to_string(c, P.ums, P.n, s.str[0]); if (sl == 0xFFFFFFFFu) return ~0ull; RTK_SITE(8); ed = rtk_u(rtk_align(c, s.str[0], sl, ref, ref_len, -1, RTK_MODE_NW).dist); }
     for (uint32_t i = 0; i < P.n && !rtk_failed(s); ++i) {
         const UMap um_path = rtk_u(P.ums[i]);
         if (!(g.flags[um_path.unitig] & RTK_F_SHORT_CYCLE)) continue;
@@ -680,7 +708,7 @@ RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, 
                 E.qlen = new_len;
             }
             const uint32_t sl = rtk_ums_to_string(c, E.ums, E.n, s.str[0]); if (sl == 0xFFFFFFFFu) break;
-            const int d = rtk_u(rtk_align(c, s.str[0], sl, ref, ref_len, ed, RTK_MODE_NW).dist);
+            RTK_SITE(9); const int d = rtk_u(rtk_align(c, s.str[0], sl, ref, ref_len, ed, RTK_MODE_NW).dist);
             if (d >= 0 && d < ed) { ed = d; best_h = rtk_wp_commit(s, E, 1); }
         }
         if (rtk_failed(s)) break;
@@ -794,7 +822,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
         }
     }
     if (rtk_failed(s) || nv == 0) return ~0ull;
-    if (nv > 1) { int bid, bend; rtk_select_best(c, v, nv, ref, ref_len, RTK_MODE_NW, -1.0, &bid, &bend); if (rtk_failed(s)) return ~0ull; v[0] = v[bid]; }
+    if (nv > 1) { int bid, bend; RTK_SITE(10); rtk_select_best(c, v, nv, ref, ref_len, RTK_MODE_NW, -1.0, &bid, &bend); if (rtk_failed(s)) return ~0ull; v[0] = v[bid]; }
     return rtk_fix_repeats(c, v[0], ref, ref_len);
 }
 
@@ -1186,7 +1214,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
         uint32_t i_w_s = 0;
         while (complete == ~0ull && n_partial != 0 && nlw != 0 && n_all >= c.o.min_cov_vertices && !rtk_failed(s)) { // :619-651
             int aid, aend;
-            rtk_select_best(c, s.list[5], n_partial, s_read + p1, len_weak_region, RTK_MODE_SHW, c.o.weak_region_len_factor, &aid, &aend);
+            RTK_SITE(11); rtk_select_best(c, s.list[5], n_partial, s_read + p1, len_weak_region, RTK_MODE_SHW, c.o.weak_region_len_factor, &aid, &aend);
             if (rtk_failed(s) || aid == -1) break;
             {
                 const uint32_t next_pos = p1 + static_cast<uint32_t>(aend) + k;
@@ -1216,7 +1244,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
             rtk_bm_add_range(res.bm, p1 - first_pos, p2 - first_pos + k);
         } else if (n_partial != 0) {
             int aid, aend;
-            rtk_select_best(c, s.list[5], n_partial, s_read + p1, len_weak_region, RTK_MODE_SHW, c.o.weak_region_len_factor, &aid, &aend);
+            RTK_SITE(12); rtk_select_best(c, s.list[5], n_partial, s_read + p1, len_weak_region, RTK_MODE_SHW, c.o.weak_region_len_factor, &aid, &aend);
             if (rtk_failed(s)) return;
             if (aid == -1) add_uncorrected(p1, len_weak_region, q_min);
             else {
@@ -1248,7 +1276,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
         if (same) res.is_corrected = true;
     }
     if (!res.is_corrected) { // :727-747 trim the corrected string to the largest SHW end location of the raw region
-        const MyersResult a = rtk_align(c, s_read + first_pos, p2 - first_pos + k, s_corr, sl_, -1, RTK_MODE_SHW);
+        RTK_SITE(13); const MyersResult a = rtk_align(c, s_read + first_pos, p2 - first_pos + k, s_corr, sl_, -1, RTK_MODE_SHW);
         if (a.dist >= 0) {
             const uint32_t keep = (a.first == -1) ? 0u : static_cast<uint32_t>(a.last + 1); // endLocations[0] == -1 wraps to SIZE_MAX in the reference
             if (keep < sl_) sl_ = keep;
@@ -1304,10 +1332,10 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
     if (nbw > nfw) { const ResCorr* t = fw; fw = bw; bw = t; }
     // NW path alignments of both corrections against the raw region; the moves are parked in str[3] (fw) and str[4] (bw)
     uint32_t nm_fw = 0, nm_bw = 0;
-    const MyersResult afw = rtk_align_path(c, fw->seq, fw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_fw);
+    RTK_SITE(14); const MyersResult afw = rtk_align_path(c, fw->seq, fw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_fw);
     if (rtk_failed(s) || nm_fw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
     rtk_wcopy(s.str[3], s.my.moves, nm_fw);
-    const MyersResult abw = rtk_align_path(c, bw->seq, bw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_bw);
+    RTK_SITE(15); const MyersResult abw = rtk_align_path(c, bw->seq, bw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_bw);
     if (rtk_failed(s) || nm_bw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
     rtk_wcopy(s.str[4], s.my.moves, nm_bw);
     const double n_fw = static_cast<double>(afw.dist) / static_cast<double>(fw->seq_len > ref_len ? fw->seq_len : ref_len);
@@ -1341,7 +1369,7 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
         i = rout;
     }
     if (max_norm > 0.0 && !rtk_failed(s)) {
-        const MyersResult a = rtk_align(c, out_s, *out_sl, ref, ref_len, -1, RTK_MODE_NW, /*iupac=*/false); // edlibDefaultAlignConfig (:460)
+        RTK_SITE(16); const MyersResult a = rtk_align(c, out_s, *out_sl, ref, ref_len, -1, RTK_MODE_NW, /*iupac=*/false); // edlibDefaultAlignConfig (:460)
         const double n = static_cast<double>(a.dist) / static_cast<double>(*out_sl > ref_len ? *out_sl : ref_len);
         if (n > max_norm) { *out_sl = 0; *out_ql = 0; return take(fw); }
     }

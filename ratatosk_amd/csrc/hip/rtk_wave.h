@@ -22,6 +22,7 @@
 
 #define RTK_DEV inline
 #define RTK_FN inline
+#define RTK_FN_HOT inline
 #define RTK_WAVE 1
 inline int rtk_lane() { return 0; }
 inline uint64_t rtk_ballot(bool p) { return p ? 1ull : 0ull; }
@@ -40,6 +41,13 @@ inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64;
 
 #define RTK_DEV __device__ __forceinline__
 #define RTK_FN __device__ __noinline__ // large device functions are real calls: keeps hipcc compile time and code size bounded
+// thin wrappers on the hot path (alignment entry, path scoring, record load / commit): a real call costs the callee-saved spills of the
+// AMDGPU calling convention (private-memory stores of 64 lanes each); -DRTK_HOT_CALLS restores calls for A/B measurements
+#ifdef RTK_HOT_CALLS
+#define RTK_FN_HOT RTK_FN
+#else
+#define RTK_FN_HOT RTK_DEV
+#endif
 #define RTK_WAVE 64
 __device__ __forceinline__ int rtk_lane() { return static_cast<int>(threadIdx.x) & 63; }
 __device__ __forceinline__ uint64_t rtk_ballot(bool p) { return __ballot(p ? 1 : 0); }

@@ -1,0 +1,88 @@
+"""Hand-checked toy fixture (derivations in tests/golden/toy/NOTE.md): a 2 kb diploid genome with one SNP bubble and one
+tandem repeat, error-free short reads, eleven hand-made long reads that walk the branches of correctSequence the note lists.
+
+Three independent legs: (1) facts derived BY HAND from the construction (unitig lengths, corrected sequence = the haplotype substring
+the read was made from, the quality patterns of r0 / r1 / r7 / r10) -- no oracle involved; (2) the oracle must reproduce the frozen
+expected.fastq; (3) the device programs (simulator here, HIP on the GPU tier) must reproduce it too."""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT, SIM_LIB
+from oracle import oracle_py as op
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import gen_toy_golden as toy  # noqa: E402
+
+TOY = os.path.join(ROOT, "tests", "golden", "toy")
+
+
+@pytest.fixture(scope="module")
+def toy_index(tmp_path_factory):
+    # the committed inputs must be what the generator writes (they are data; the generator documents them)
+    hap_a, hap_b = toy.haplotypes()
+    assert open(os.path.join(TOY, "hap.fa")).read() == ">hapA\n%s\n>hapB\n%s\n" % (hap_a, hap_b)
+    reads = toy.long_reads(hap_a, hap_b)
+    assert [(r[0], r[1]) for r in op.read_fastq(os.path.join(TOY, "lr.fq"))] == [(n, raw) for n, _, raw in reads]
+    return toy.build_index(str(tmp_path_factory.mktemp("toy"))), reads
+
+
+def _expected():
+    return op.read_fastq(os.path.join(TOY, "expected.fastq"))
+
+
+def test_toy_graph_is_the_hand_derived_one(toy_index):
+    pre, _ = toy_index
+    og = op.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31)
+    assert og.n_unitigs == 7 and og.n_kmers == 670 + 31 + 31 + 599 + 6 + 6 + 601  # NOTE.md section 1
+    assert sorted(len(og.unitig(u)["seq"]) for u in range(7)) == [36, 36, 61, 61, 629, 631, 700]
+    from ratatosk_amd import api
+    info = api.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31, upload=False).info()
+    assert (info.n_unitigs, info.n_kmers) == (7, 1944)
+
+
+def test_toy_expected_records_match_the_hand_derivation(toy_index):
+    """expected.fastq against what NOTE.md derives without running anything."""
+    _, reads = toy_index
+    exp = _expected()
+    assert [e[0] for e in exp] == [r[0] for r in reads]
+    for (name, truth, raw), (_, s, q) in zip(reads, exp):
+        assert s == truth, name            # every read comes out as the haplotype substring it was made from
+        assert len(q) == len(s), name
+    q = {e[0]: e[2] for e in exp}
+    assert q["r0_all_solid"] == "I" * 800                                   # Correction.cpp:168
+    assert q["r1_no_solid"] == "!" * 500                                    # Correction.cpp:170
+    assert q["r2_same_unitig_sub"] == "I" * 600                             # Correction.cpp:814-856
+    assert q["r7_region_too_long"] == "I" * 150 + "!" * 1100 + "I" * 150    # Correction.cpp:924-930
+    # r10: score_best = 1 - 20/107, no second candidate (NOTE.md "r10 by hand"); getQual of src/Common.hpp:410-418
+    best = 1.0 - 20.0 / 107.0
+    c_best, c_comp = chr(int(best * 40 + 33)), chr(int(best * (40 - 1) + 33 + 1))
+    assert c_best == "A" and c_comp == "A"
+    assert q["r10_error_cluster_over_snp"] == "I" * 400 + "A" * 46 + "I" * 354
+    for name in ("r3_bubble_hapA_del2", "r4_bubble_hapB_ins1", "r5_head_errors", "r6_tail_errors", "r8_revcomp_tandem_hapA", "r9_tandem_hapB_two_errors"):
+        assert set(q[name]) == {"I"}, name
+
+
+def test_toy_oracle_reproduces_expected(toy_index):
+    pre, reads = toy_index
+    og = op.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31)
+    want, _ = og.correct_batch([r[2] for r in reads], ["5" * len(r[2]) for r in reads], threads=2)
+    assert want == [(e[1], e[2]) for e in _expected()]
+
+
+def _device(pre, reads, lib_path):
+    from ratatosk_amd import api
+    pg = api.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31, device=0, lib_path=lib_path)
+    return pg.correct_batch([r[2] for r in reads], ["5" * len(r[2]) for r in reads])
+
+
+def test_toy_device_program_on_simulator_reproduces_expected(toy_index):
+    pre, reads = toy_index
+    assert _device(pre, reads, SIM_LIB) == [(e[1], e[2]) for e in _expected()]
+
+
+@pytest.mark.gpu
+def test_gpu_toy_reproduces_expected(toy_index):
+    pre, reads = toy_index
+    assert _device(pre, reads, None) == [(e[1], e[2]) for e in _expected()]
