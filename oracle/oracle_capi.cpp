@@ -1,5 +1,7 @@
 // ORACLE (test infrastructure): flat C entry points so tests/, __graft_entry__.smoke() and bench.py's
 // cpu_baseline leg can drive the CPU restatement through ctypes. Nothing in the product links this.
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -150,5 +152,16 @@ int orc_correct_batch(void* gp, const orc_opts* o, uint64_t n, const char* const
 }
 
 void orc_free(void* p) { free(p); }
+
+// path == NULL: back to the restatement. Returns 0 on success, -1 when the library or the symbol is missing.
+int orc_use_reference_edlib(const char* so_path) {
+    if (!so_path) { g_ref_edlib_moves = nullptr; return 0; }
+    void* h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return -1;
+    void* f = dlsym(h, "ref_edlib_moves");
+    if (!f) return -1;
+    g_ref_edlib_moves = reinterpret_cast<ref_edlib_moves_fn>(f);
+    return 0;
+}
 
 } // extern "C"

@@ -16,6 +16,8 @@
 
 namespace orc {
 
+ref_edlib_moves_fn g_ref_edlib_moves = nullptr; // set by orc_use_reference_edlib (oracle_capi.cpp)
+
 namespace {
 
 // ---------------------------------------------------------------- helpers (src/Common.hpp:410-438)
@@ -35,6 +37,13 @@ struct Ctx {
     Ctx(const Graph& g_, const Opt& o_, Counters* c_) : g(g_), opt(o_), cnt(c_), k(static_cast<size_t>(g_.k)) {}
     AlignResult align(const char* q, size_t ql, const char* t, size_t tl, int kk, AlignMode mode, bool path, bool iupac = true) const {
         if (cnt) { ++cnt->n_align; cnt->n_align_cells += static_cast<uint64_t>((ql + 63) / 64) * tl; }
+        if (g_ref_edlib_moves) { // the REFERENCE's own edlib (oracle/_ref) instead of the restatement: same results (pinned), banded
+            AlignResult r; int nloc = 0, nmv = 0;
+            std::vector<int> locs(tl + 2); std::vector<unsigned char> mv(path ? ql + tl + 2 : 1);
+            r.editDistance = g_ref_edlib_moves(q, static_cast<int>(ql), t, static_cast<int>(tl), kk, static_cast<int>(mode), path ? 1 : 0, iupac ? 1 : 0, &nloc, locs.data(), static_cast<int>(locs.size()), mv.data(), static_cast<int>(mv.size()), &nmv);
+            if (r.editDistance >= 0) { r.endLocations.assign(locs.begin(), locs.begin() + nloc); if (path) r.alignment.assign(mv.begin(), mv.begin() + nmv); }
+            return r;
+        }
         return myers_align(q, static_cast<int>(ql), t, static_cast<int>(tl), kk, mode, path, iupac);
     }
 };

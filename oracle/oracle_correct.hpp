@@ -51,6 +51,12 @@ struct Counters { // event counts feeding the algorithmic-bytes model of SURVEY.
 
 typedef std::pair<size_t, UM> Anchor;
 
+// Optional: alignments through the REFERENCE's own edlib (oracle/_ref/libedlib_ref.so, ref_edlib_moves of ref_edlib_shim.cpp) instead
+// of oracle_myers.cpp. Same results (oracle_myers.cpp is pinned against it); used by bench.py's cpu_baseline so that the CPU leg
+// carries edlib's banded Myers, and as a cross-check in tests.
+typedef int (*ref_edlib_moves_fn)(const char*, int, const char*, int, int, int, int, int, int*, int*, int, unsigned char*, int, int*);
+extern ref_edlib_moves_fn g_ref_edlib_moves;
+
 // src/Graph.cpp:3-482 (long_read_correct=false). Returns (solid, weak).
 std::pair<std::vector<Anchor>, std::vector<Anchor> > getSeeds(const Graph& g, const Opt& opt, const std::string& s, Counters* cnt = nullptr);
 

@@ -49,8 +49,18 @@ def lib():
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                         C.c_int, C.POINTER(C.c_uint64)]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_use_reference_edlib.argtypes = [C.c_char_p]
         _lib = L
     return _lib
+
+
+def use_reference_edlib(on=True):
+    """Route every alignment of the oracle's correction through the REFERENCE's edlib (oracle/_ref); False: back to oracle_myers.cpp."""
+    path = os.path.join(_HERE, "_ref", "libedlib_ref.so")
+    if on and not os.path.exists(path):
+        raise RuntimeError("oracle/_ref/libedlib_ref.so not built")
+    if lib().orc_use_reference_edlib(path.encode() if on else None) != 0:
+        raise RuntimeError("oracle/_ref/libedlib_ref.so lacks ref_edlib_moves: rebuild it (make -C oracle ref)")
 
 
 _ref = None

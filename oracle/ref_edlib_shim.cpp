@@ -30,3 +30,18 @@ extern "C" int ref_edlib(const char* q, int qlen, const char* t, int tlen, int k
     edlibFreeAlignResult(r);
     return d;
 }
+
+// Same call, results as edlib reports them: every end location and the raw alignment operations (EDLIB_EDOP_MATCH 0, INSERT 1,
+// DELETE 2, MISMATCH 3). Lets the oracle's correction run on the REFERENCE's alignment layer (bench.py cpu_baseline, cross-checks).
+extern "C" int ref_edlib_moves(const char* q, int qlen, const char* t, int tlen, int k, int mode, int want_path, int use_iupac,
+                               int* n_loc, int* end_locs, int cap_locs, unsigned char* moves, int cap_moves, int* n_moves) {
+    const EdlibAlignMode m = mode == 0 ? EDLIB_MODE_NW : (mode == 1 ? EDLIB_MODE_SHW : EDLIB_MODE_HW);
+    EdlibAlignConfig cfg = edlibNewAlignConfig(k, m, want_path ? EDLIB_TASK_PATH : EDLIB_TASK_DISTANCE, use_iupac ? kIupac : NULL, use_iupac ? 28 : 0);
+    EdlibAlignResult r = edlibAlign(q, qlen, t, tlen, cfg);
+    const int d = r.editDistance;
+    *n_loc = r.numLocations; *n_moves = 0;
+    for (int i = 0; i < r.numLocations && i < cap_locs; ++i) end_locs[i] = r.endLocations[i];
+    if (want_path && d >= 0 && r.alignment) { *n_moves = r.alignmentLength; for (int i = 0; i < r.alignmentLength && i < cap_moves; ++i) moves[i] = r.alignment[i]; }
+    edlibFreeAlignResult(r);
+    return d;
+}

@@ -71,6 +71,9 @@ def load_library(path=None):
     L.rtk_batch_run_seeds.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
     L.rtk_batch_run_regions.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
     L.rtk_batch_fetch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+    L.rtk_batch_fetch_view.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]
+    L.rtk_n_devices.restype = C.c_int
+    L.rtk_graph_clone_to_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.rtk_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(RtkStats)]
     L.rtk_batch_free.argtypes = [C.c_void_p]
     L.rtk_lookup_exact.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_int64)]

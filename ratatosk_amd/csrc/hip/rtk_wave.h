@@ -41,12 +41,13 @@ inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64;
 
 #define RTK_DEV __device__ __forceinline__
 #define RTK_FN __device__ __noinline__ // large device functions are real calls: keeps hipcc compile time and code size bounded
-// thin wrappers on the hot path (alignment entry, path scoring, record load / commit): a real call costs the callee-saved spills of the
-// AMDGPU calling convention (private-memory stores of 64 lanes each); -DRTK_HOT_CALLS restores calls for A/B measurements
-#ifdef RTK_HOT_CALLS
-#define RTK_FN_HOT RTK_FN
-#else
+// Thin wrappers on the hot path (alignment entry, path scoring, path extension, colour memo). A real call costs the callee-saved
+// spills of the AMDGPU calling convention; inlining them (-DRTK_HOT_INLINE) measured 79.3 -> 77.6 ms on k_regions but made one
+// overflow-redo parity test fail (a call is also a compiler barrier between lane-crossing memory accesses): calls stay the default.
+#ifdef RTK_HOT_INLINE
 #define RTK_FN_HOT RTK_DEV
+#else
+#define RTK_FN_HOT RTK_FN
 #endif
 #define RTK_WAVE 64
 __device__ __forceinline__ int rtk_lane() { return static_cast<int>(threadIdx.x) & 63; }
