@@ -156,13 +156,16 @@ def cli_leg(a, pre, fa, rt):
     env = dict(os.environ, RTK_CLI_STATS="1")
     cores = min(16, os.cpu_count() or 1)
     try:
-        r = subprocess.run([exe, "correct", "-1", "-c", str(cores), "--gpus", "1", "-g", fa, "-d", rt, "-l", pre + ".lr.fq", "-o", out], capture_output=True, text=True, env=env, timeout=600)
+        lst = out + ".inputs.txt" # a list file (src/Common.cpp:428-446): the generated FASTQ six times, ~0.9 Gb, so that the pipeline runs in steady state
+        with open(lst, "w") as f:
+            f.write((pre + ".lr.fq\n") * 6)
+        r = subprocess.run([exe, "correct", "-1", "-c", str(cores), "--gpus", "1", "-g", fa, "-d", rt, "-l", lst, "-o", out], capture_output=True, text=True, env=env, timeout=600)
         m = re.search(r"graph load \+ upload ([0-9.]+) s; correction phase ([0-9.]+) s wall, (\d+) bases, ([0-9.e+]+) bases/s on (\d+) GPU\(s\) x (\d+) workers; thread-seconds: parse ([0-9.]+), correct \(pack \+ GPU \+ fetch\) ([0-9.]+), format ([0-9.]+), write ([0-9.]+)", r.stderr + r.stdout)
         if r.returncode != 0 or not m:
             return {"error": (r.stderr or r.stdout)[-300:]}
         res = {"value": int(m.group(3)) / float(m.group(2)), "unit": "bases/s", "bases": int(m.group(3)), "correction_phase_s": float(m.group(2)), "graph_load_upload_s": float(m.group(1)),
                "workers_per_gpu": int(m.group(6)), "thread_seconds": {"parse": float(m.group(7)), "pack+gpu+fetch": float(m.group(8)), "format": float(m.group(9)), "write": float(m.group(10))},
-               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in, OUT.2.fastq out (input order), wall time of the correction phase" % cores}
+               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in (list file: the generated reads six times), OUT.2.fastq out (input order), wall time of the correction phase" % cores}
         try:
             os.remove(out + ".2.fastq")
         except OSError:
@@ -238,7 +241,10 @@ def main():
     if rank == 0:
         workdir = a.workdir or tempfile.mkdtemp(prefix="rtk_bench_")
         t0 = time.time()
-        pre = make_dataset(workdir, a.ref_len, min(need_bases, 30 * a.ref_len), snps=not a.plain_index)
+        # 30x of long reads (configs[1]) gives two tickets; with N ranks every rank gets two tickets of its OWN (2N distinct tickets:
+        # the long-read coverage of the synthetic set grows with N, the graph and the per-rank work stay those of configs[1])
+        lr_bases = min(need_bases, max(30 * a.ref_len, int(2.05 * a.batch_bases * world))) if world > 1 else min(need_bases, 30 * a.ref_len)
+        pre = make_dataset(workdir, a.ref_len, lr_bases, snps=not a.plain_index)
         t_data = time.time() - t0
     else:
         pre, t_data = None, 0.0
@@ -261,8 +267,9 @@ def main():
     if cur_s and not tickets:
         tickets.append((cur_s, cur_q))
     mine = [t for i, t in enumerate(tickets) if i % world == rank]
+    shared_tickets = False
     if not mine:
-        mine = [tickets[rank % len(tickets)]]
+        mine = [tickets[rank % len(tickets)]]; shared_tickets = True
     opts = graph.opts()
     # resident in HBM before timing; at least two batch objects so that consecutive steps can overlap (stage A of step s+1 with stage B of step s)
     batches = [api.Batch(graph, *mine[i % len(mine)]) for i in range(max(2, min(n_batches, len(mine))))]
@@ -295,8 +302,12 @@ def main():
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_all, bases_all = float(tmax[0]), float(tsum[1])
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "device": device, "bases": int(done_bases), "seconds": round(dt, 4), "distinct_tickets": len(mine), "shared_tickets": shared_tickets})
+        assert dist.get_world_size() == world == a.gpus and (a.sim or dist.get_backend() == "nccl"), "bench.py --gpus N must run as N ranks over RCCL"
     else:
         dt_all, bases_all = dt, float(done_bases)
+        per_rank = [{"rank": 0, "device": device, "bases": int(done_bases), "seconds": round(dt, 4), "distinct_tickets": len(mine), "shared_tickets": shared_tickets}]
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from the HIP-event times of this very run ----
@@ -324,7 +335,7 @@ def main():
             "metric": "corrected long-read bases/sec", "value": bases_all / dt_all if dt_all > 0 else 0.0, "unit": "bases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt_all / max(1, a.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[1]: k=31 first-pass correct, %.1f Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU" % (a.ref_len / 1e6, a.batch_bases),
-                       "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated" % world,
+                       "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated (one RCCL broadcast per flat buffer)" % world, "per_rank": per_rank,
                        "alg_bytes_per_base": round(whole_alg, 1), "setup_s": {"data+index": round(t_data, 1), "graph_load+upload": round(t_graph, 1)}},
             "roofline": roofline,
         }
