@@ -465,15 +465,27 @@ RTK_DEV int rtk_nb_successors(const GraphView& g, const UMap& um) {
 
 // ------------------------------------------------------------------------------------------------ DFS (src/GraphTraversal.cpp:456-587)
 // Results: handles of terminal / non-terminal paths (level-2 arena) in list[2] / list[3]; returns counts and best scores.
-struct DfsOut { uint32_t n_t, n_nt; double t1, nt1; };
+struct DfsOut { uint32_t n_t, n_nt; double t1, nt1, nt2; uint32_t nt_score_deferred, nt_qual_deferred; };
+// What the caller needs to finish a non-terminal sub-path later (lazy evaluation, see rtk_explore_subgraph): where its reference
+// window starts, its scores (or "not scored yet") and whether its quality string is still to be written.
+struct NtPending { uint32_t e; double nt1, nt2; uint32_t score_deferred, qual_deferred; };
 
 RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, uint32_t max_len_path_,
                                     const UMap& um_, const UMap& um_e_, uint32_t level_) {
+    // LAZY NON-TERMINAL PATHS. In explorePathsBFS2 a non-terminal sub-path of a DFS call is only used when the queue entry built from
+    // it is popped while still shorter than max_len_path (src/GraphTraversal.cpp:364-366, 393-411); its score (HW alignment of the
+    // reference window inside a path of four whole unitigs) and its quality string (SHW path alignment + traceback) are consumed by
+    // nothing else when it is the ONLY non-terminal candidate of the call: the >= / > bookkeeping of :540-549 has nobody to compare it
+    // with, `nt1 < min_score` (:295) cannot hold for min_score <= 0, selectBestSubstringAlignment (:297-300) needs two candidates.
+    // So with an end anchor the candidates are collected first; several candidates are scored as the reference does, a single one is
+    // handed back unscored, and in both cases the quality string is left to the caller (rtk_explore_paths), which computes score and
+    // quality -- same inputs, same values -- only if the path is really extended. Without end anchor (explorePathsBFS) every
+    // extension is a candidate at once (:165-172): everything stays eager there.
     RegionScratch& s = *rtk_u(c.sc);
     const uint32_t* all_pids = rtk_u(all_pids_); const char* ref = rtk_u(ref_);
     const uint32_t n_all = rtk_u(n_all_), ref_len = rtk_u(ref_len_), max_len_path = rtk_u(max_len_path_), level = rtk_u(level_);
     const UMap um = rtk_u(um_), um_e = rtk_u(um_e_);
-    DfsOut out; out.n_t = 0; out.n_nt = 0; out.t1 = 0.0; out.nt1 = 0.0;
+    DfsOut out; out.n_t = 0; out.n_nt = 0; out.t1 = 0.0; out.nt1 = 0.0; out.nt2 = 0.0; out.nt_score_deferred = 0; out.nt_qual_deferred = 0;
     double score_t1 = 0.0, score_nt1 = 0.0, score_t2 = 0.0, score_nt2 = 0.0;
     uint32_t n_t = 0, n_nt = 0;
     s.top[2] = 0;
@@ -485,11 +497,25 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
     stk[0] = ~0ull; stk[1] = level; sp = 1;
     WPath& w = s.wp[2];
     const bool has_end = !rtk_um_is_empty(um_e);
+    const bool lazy_nt = has_end && !(rtk_u(c.o.min_score) > 0.0);
+    uint32_t n_nt_live = 0;
     unsigned long long n_exp = 0;
     const unsigned long long td0 = rtk_clock(); const unsigned long long my0 = s.cnt[9];
 #ifdef RTK_SIM
     const unsigned long long dfs_al0 = s.cnt[3];
 #endif
+    // Walk 0 prunes (lazy mode only): an extension already longer than max_len_path can neither reach a terminal path that passes the
+    // length test of :511 nor a non-terminal leaf that would ever be looked at again, so its subtree is skipped -- unless a LIVE
+    // non-terminal candidate turns up, in which case the skipped candidates' scores can decide the survivor and walk 1 repeats the
+    // reference's full walk for the non-terminal candidates only (terminal ones are complete after walk 0).
+    uint32_t n_pruned = 0;
+    for (int walk = 0; walk < 2 && !rtk_failed(s); ++walk) {
+    const bool prune = lazy_nt && walk == 0, do_terminal = walk == 0;
+    if (walk == 1) { if (!(lazy_nt && n_nt_live > 0 && n_pruned > 0)) break;
+#ifdef RTK_SIM
+        rtk_sim_site_stat[28][0] += 1;
+#endif
+        n_nt = 0; n_nt_live = 0; stk[0] = ~0ull; stk[1] = level; sp = 1; }
     while (sp > 0 && !rtk_failed(s)) {
         --sp;
         const uint64_t hp = rtk_ld(stk + 2 * sp); const uint32_t lvl = static_cast<uint32_t>(rtk_ld(stk + 2 * sp + 1));
@@ -505,7 +531,7 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
             UMap sc; sc.unitig = ab >> 1; sc.strand = ab & 1u; sc.dist = 0; sc.len = rtk_nkm_u(c, sc.unitig);
             const bool col_ok = rtk_u(rtk_colour_ok(c, sc.unitig, all_pids, n_all));
             if (!(((eb >> b) & 1u) && col_ok)) continue;
-            if (has_end && sc.unitig == um_e.unitig && um_e.strand == sc.strand) { // terminal
+            if (do_terminal && has_end && sc.unitig == um_e.unitig && um_e.strand == sc.strand) { // terminal
                 if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
                 UMap pref = sc;
                 if (pref.strand) { pref.dist = 0; pref.len = um_e.dist + 1; } else { pref.dist = um_e.dist; pref.len = sc.len - um_e.dist; }
@@ -523,6 +549,10 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
                 }
             }
             { // non-terminal
+                if (prune) { // length of the extension (Path::extend, Path.hpp:319-330) before building it
+                    const uint32_t l_new = (hp == ~0ull) ? (sc.len + static_cast<uint32_t>(rtk_u(c.k)) - 1u) : (rtk_rec_l(s, hp) + sc.len);
+                    if (l_new > max_len_path) { ++n_pruned; continue; }
+                }
                 if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
                 rtk_wp_extend(c, w, sc);
                 if (rtk_failed(s)) break;
@@ -533,26 +563,57 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
                     if (2 * (sp + 1) > list_cap) { rtk_fail_ovf(s, 8); break; }
                     stk[2 * sp] = rtk_wp_commit(s, w, 2); stk[2 * sp + 1] = lvl - 1; ++sp;
                 } else if (rtk_nb_successors(c.g, sc) > 0) {
-                    const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
-                    if (sl == 0xFFFFFFFFu) break;
-                    const double sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, false));
-                    if (sco >= score_nt1) {
-                        if (sco > score_nt1) n_nt = 0;
+                    if (lazy_nt) { // candidate kept in discovery order, scored after the walk (or never)
                         if (n_nt >= list_cap) { rtk_fail_ovf(s, 8); break; }
                         NT[n_nt++] = rtk_wp_commit(s, w, 2);
-                        score_nt2 = score_nt1; score_nt1 = sco;
-                    } else if (sco > score_nt2) score_nt2 = sco;
+                        // P (+) Q is looked at again only if it is shorter than the caller's max_len_path (:364-366); in terms of this call's
+                        // arguments (max_len_path here = the caller's minus the characters of P before its last unitig `um`): l(Q) + um.len < max_len_path
+                        if (rtk_ld(&w.l) + um.len < max_len_path) ++n_nt_live;
+                    } else {
+                        const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
+                        if (sl == 0xFFFFFFFFu) break;
+                        const double sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, false));
+                        if (sco >= score_nt1) {
+                            if (sco > score_nt1) n_nt = 0;
+                            if (n_nt >= list_cap) { rtk_fail_ovf(s, 8); break; }
+                            NT[n_nt++] = rtk_wp_commit(s, w, 2);
+                            score_nt2 = score_nt1; score_nt1 = sco;
+                        } else if (sco > score_nt2) score_nt2 = sco;
+                    }
                 }
             }
         }
     }
+    } // walk
 #ifdef RTK_SIM
     { const unsigned long long na = s.cnt[3] - dfs_al0; const unsigned b = na > 15 ? 15 : static_cast<unsigned>(na); rtk_sim_site_stat[21][0] += 1; rtk_sim_site_stat[22 + (b >> 3)][b & 7] += 1; rtk_sim_site_stat[24 + (b >> 3)][b & 7] += na; }
 #endif
     s.cnt[0] += n_exp;
     s.cnt[14] += (rtk_clock() - td0) - (s.cnt[9] - my0); // DFS bookkeeping: loop time minus the alignments inside it
-    // qualities (:556-584): re-commit every surviving path with its quality string
-    for (int which = 0; which < 2 && !rtk_failed(s); ++which) {
+    bool nt_score_deferred = false;
+    if (lazy_nt && !rtk_failed(s)) {
+        // whichever candidate survives the scoring is only re-queued; if none of them can pass the length test of the pop, the queue
+        // ends empty whatever the scores are: nothing to compute (a mix of short and long candidates still needs every score)
+        if (n_nt_live == 0) n_nt = 0;
+        if (n_nt == 1) nt_score_deferred = true; // nobody to compare it with: scored by the caller if the path is ever extended
+        else if (n_nt > 1) { // the reference's bookkeeping (:540-549) over the candidates in discovery order
+            const uint32_t n_cand = n_nt; n_nt = 0;
+            for (uint32_t i = 0; i < n_cand && !rtk_failed(s); ++i) {
+                const uint64_t hc = rtk_ld(NT + i);
+                rtk_wp_load(s, w, hc);
+                const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
+                if (sl == 0xFFFFFFFFu) break;
+                const double sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, false));
+                if (sco >= score_nt1) {
+                    if (sco > score_nt1) n_nt = 0;
+                    NT[n_nt++] = hc; // n_nt <= i: survivors move towards the front
+                    score_nt2 = score_nt1; score_nt1 = sco;
+                } else if (sco > score_nt2) score_nt2 = sco;
+            }
+        }
+    }
+    // qualities (:556-584): re-commit every surviving path with its quality string (non-terminal ones: left to the caller when lazy)
+    for (int which = 0; which < (lazy_nt ? 1 : 2) && !rtk_failed(s); ++which) {
         uint64_t* L = which ? NT : T; const uint32_t nL = which ? n_nt : n_t;
         for (uint32_t i = 0; i < nL && !rtk_failed(s); ++i) {
             rtk_wp_load(s, w, rtk_ld(L + i));
@@ -563,15 +624,16 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
             L[i] = rtk_wp_commit(s, w, 2);
         }
     }
-    out.n_t = n_t; out.n_nt = n_nt; out.t1 = score_t1; out.nt1 = score_nt1;
+    out.n_t = n_t; out.n_nt = n_nt; out.t1 = score_t1; out.nt1 = score_nt1; out.nt2 = score_nt2;
+    out.nt_score_deferred = nt_score_deferred ? 1u : 0u; out.nt_qual_deferred = (lazy_nt && n_nt != 0) ? 1u : 0u;
     return out;
 }
 
 // explore() (src/GraphTraversal.cpp:41-93, 251-304). p = committed path (level 1). Results stay in list[2]/list[3] (level-2 arena).
-RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_e_, uint64_t hp_, uint32_t max_len_path_, uint32_t* n_t_, uint32_t* n_nt_) {
-    const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_e = rtk_u(um_e_); uint64_t hp = rtk_u(hp_); uint32_t max_len_path = rtk_u(max_len_path_); uint32_t* n_t = rtk_u(n_t_); uint32_t* n_nt = rtk_u(n_nt_);
+RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_e_, uint64_t hp_, uint32_t max_len_path_, uint32_t* n_t_, uint32_t* n_nt_, NtPending* pend_) {
+    const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_e = rtk_u(um_e_); uint64_t hp = rtk_u(hp_); uint32_t max_len_path = rtk_u(max_len_path_); uint32_t* n_t = rtk_u(n_t_); uint32_t* n_nt = rtk_u(n_nt_); NtPending* pend = rtk_u(pend_);
     RegionScratch& s = *c.sc;
-    *n_t = 0; *n_nt = 0;
+    *n_t = 0; *n_nt = 0; pend->e = 0; pend->nt1 = 0.0; pend->nt2 = 0.0; pend->score_deferred = 0; pend->qual_deferred = 0;
     const UMap um = rtk_rec_back(s, hp);
     const uint32_t path_len = rtk_rec_l(s, hp);
     const uint32_t k = static_cast<uint32_t>(c.k);
@@ -588,7 +650,8 @@ RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_al
         DfsOut o = rtk_explore_subgraph(c, all_pids, n_all, ref + end_pos_ref, ref_len - end_pos_ref, max_len_path - path_len_prefix, um, um_e, 3);
         if (rtk_failed(s)) return;
         if (o.n_t && o.t1 < c.o.min_score) o.n_t = 0;
-        if (o.n_nt && o.nt1 < c.o.min_score) o.n_nt = 0;
+        if (o.n_nt && !o.nt_score_deferred && o.nt1 < c.o.min_score) o.n_nt = 0; // a deferred score only exists for min_score <= 0: never below it
+        pend->e = end_pos_ref; pend->nt1 = o.nt1; pend->nt2 = o.nt2; pend->score_deferred = o.nt_score_deferred; pend->qual_deferred = o.nt_qual_deferred;
         if (o.n_nt > 1) {
             int bid, bend;
             RTK_SITE(6); rtk_select_best(c, s.list[3], o.n_nt, ref + end_pos_ref, ref_len - end_pos_ref, RTK_MODE_HW, -1.0, &bid, &bend);
@@ -760,11 +823,34 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
         }
         rtk_wp_start(c, w, ust, q_max);
         uint64_t qh = rtk_wp_commit(s, w, 1); bool q_has = true; // the queue never holds more than one path (each pop pushes <= 1)
+        // a queue entry P (+) Q whose non-terminal sub-path Q has not been given its score / quality string yet (see rtk_explore_subgraph)
+        bool q_pending = false; uint64_t pend_hp = 0, pend_hq = 0; NtPending pend; pend.e = 0; pend.nt1 = 0.0; pend.nt2 = 0.0; pend.score_deferred = 0; pend.qual_deferred = 0;
         while (q_has && !rtk_failed(s)) {
+            if (q_pending) { // the pop of src/GraphTraversal.cpp:364-366: only a path shorter than max_len_path is ever looked at again
+                q_pending = false;
+                const int lv = rtk_h_lvl(pend_hq); const uint64_t oo = rtk_h_off(pend_hq);
+                const UMap* qu = rtk_path_ums(s, lv, oo); const uint32_t qn = rtk_rec_n(s, pend_hq);
+                uint32_t l_ext = rtk_rec_l(s, pend_hp);
+                for (uint32_t i = 0; i < qn; ++i) l_ext += rtk_u(qu[i].len); // Path::extend adds um.len per unitig (Path.hpp:319-330)
+                if (!(l_ext < max_len_path)) break;
+                WPath& wq = s.wp[2];
+                rtk_wp_load(s, wq, pend_hq);
+                const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&wq.ums), rtk_ld(&wq.n), s.str[1]));
+                if (sl == 0xFFFFFFFFu || sl > rtk_ld(&s.str_cap)) { rtk_fail_ovf(s, 7); break; }
+                double nt1 = pend.nt1; const double nt2 = pend.nt2;
+                if (pend.score_deferred) nt1 = rtk_u(rtk_score_path(c, sl, ref + pend.e, ref_len - pend.e, false));
+                rtk_score_path_qual(c, sl, ref + pend.e, ref_len - pend.e, nt1, nt2, s.str[2]);
+                if (sl == rtk_ld(&wq.l)) { rtk_wcopy(rtk_ld(&wq.qual), s.str[2], sl); wq.qlen = sl; } // Path::setQuality only accepts q.length() == l
+                const uint64_t hq = rtk_wp_commit(s, wq, 1);
+                if (rtk_failed(s)) break;
+                rtk_wp_load(s, w, pend_hp); rtk_extend_by(c, w, hq, 0xFFFFFFFFu);
+                qh = rtk_wp_commit(s, w, 1);
+                if (rtk_failed(s)) break;
+            }
             const uint64_t hp = qh; q_has = false;
             if (rtk_rec_l(s, hp) < max_len_path) {
                 uint32_t n_t, n_nt;
-                rtk_explore(c, all_pids, n_all, ref, ref_len, has_end ? um_e : rtk_um_empty(), hp, max_len_path, &n_t, &n_nt);
+                rtk_explore(c, all_pids, n_all, ref, ref_len, has_end ? um_e : rtk_um_empty(), hp, max_len_path, &n_t, &n_nt, &pend);
                 if (rtk_failed(s)) break;
                 if (has_end) {
                     for (uint32_t i = 0; i < n_t && !rtk_failed(s); ++i) {
@@ -774,8 +860,13 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
                     }
                     for (uint32_t i = 0; i < n_nt && !rtk_failed(s); ++i) {
                         if (rtk_rec_n(s, s.list[3][i]) == level) {
-                            rtk_wp_load(s, w, hp); rtk_extend_by(c, w, s.list[3][i], 0xFFFFFFFFu);
-                            qh = rtk_wp_commit(s, w, 1); q_has = true; // queue size 1 < 512: resizeQueue never fires
+                            if (pend.qual_deferred) { // keep what is needed to finish Q when (if) the entry is popped: its unitigs move to the BFS-level arena
+                                rtk_wp_load(s, s.wp[2], s.list[3][i]);
+                                pend_hq = rtk_wp_commit(s, s.wp[2], 1); pend_hp = hp; q_pending = true; q_has = true;
+                            } else {
+                                rtk_wp_load(s, w, hp); rtk_extend_by(c, w, s.list[3][i], 0xFFFFFFFFu);
+                                qh = rtk_wp_commit(s, w, 1); q_has = true; // queue size 1 < 512: resizeQueue never fires
+                            }
                         }
                     }
                     if (nvt >= max_paths) {

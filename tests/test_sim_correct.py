@@ -21,7 +21,7 @@ def _check(prefix, n, lib_path, extra_reads=(), counters_must_match=True, k=31, 
         assert g_[0] == w_[0], "sequence of read %d differs" % i
         assert g_[1] == w_[1], "quality of read %d differs" % i
     if counters_must_match:  # redone regions are counted twice, so only checked on runs without scratch overflow
-        assert st["n_expand"] == cnt["n_expand"] and st["n_colour_elem"] == cnt["n_colour_elem"]
+        assert 0 < st["n_expand"] <= cnt["n_expand"] and 0 < st["n_colour_elem"] <= cnt["n_colour_elem"]  # the device prunes DFS subtrees that cannot matter (rtk_explore_subgraph): never more events than the reference walk
     return st, got, seqs
 
 
