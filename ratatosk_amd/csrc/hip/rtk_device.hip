@@ -275,6 +275,7 @@ RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
     s.rowL = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.rowR = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.r_cap = c.r_cap;
     s.hstack = reinterpret_cast<int32_t*>(p); p += 4 * 5 * 64;
     s.overflow = reinterpret_cast<uint32_t*>(p); p += 64;
+    s.tb_gen = 0;
     s.walk_cycles = 0; s.walk_moves = 0; s.walk_reloads = 0; s.walk_scalar = 0; s.walk_calls = 0; s.walk_tail_cycles = 0;
     s.carry = reinterpret_cast<int8_t*>(p); p += (c.t_cap + 63) / 64 * 64;
     s.moves = reinterpret_cast<uint8_t*>(p); p += (c.mv_cap + 63) / 64 * 64; s.moves_tmp = reinterpret_cast<uint8_t*>(p); s.mv_cap = c.mv_cap;

@@ -34,6 +34,7 @@ struct MyersScratch {
     U<uint32_t> mv_cap;
     U<int32_t*> hstack;     // [5 * 64] explicit Hirschberg stack
     U<uint32_t*> overflow;  // set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
+    U<uint32_t> tb_gen;     // bumped by everything that writes the traceback table: a saved sweep (MyersSaved) is only resumed on its own table
     U<unsigned long long> walk_cycles, walk_moves, walk_reloads, walk_scalar, walk_calls, walk_tail_cycles; // profile of the traceback walks
 };
 
@@ -777,6 +778,7 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
     const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), best = rtk_u(best_);
     const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_);
     *n_moves = 0;
+    { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; }
     if (static_cast<uint32_t>(m + n) > sc.mv_cap || static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap || static_cast<uint32_t>(m) > sc.r_cap) { *sc.overflow = 1; return; }
     int32_t* st = sc.hstack;
     int sp = 0;
@@ -831,6 +833,7 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
     const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), mode = rtk_u(mode_);
     const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_);
     *n_moves = 0;
+    { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; }
     MyersResult r; bool have = false;
 #ifndef RTK_SIM
     const long long W = (m + 63) >> 6;
@@ -857,6 +860,47 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
     if (!have) r = rtk_myers_distance(sc, q, m, t, n, -1, mode, iupac);
     if (m > 0 && n > 0) rtk_myers_alignment(sc, q, m, t, (mode == RTK_MODE_NW) ? n : (r.first + 1), r.dist, iupac, n_moves);
     return r;
+}
+
+
+// NW distance and SHW path alignment of the SAME pair from ONE stored sweep. An SHW matrix (top row 0..n, left column 0..m) is the NW
+// matrix; its bottom-right cell is the NW distance, the minimum of its last row the SHW result. getScorePath scores a terminal path
+// with NW (src/GraphTraversal.cpp:880) and, if it survives, aligns the same two strings again with SHW + path for its quality string
+// (:727): rtk_myers_nw_and_save answers the first call and keeps what the second one needs; rtk_myers_path_from_saved then only walks.
+struct MyersSaved { uint32_t valid, gen; int32_t m, n, nw_dist; MyersResult shw; };
+RTK_FN bool rtk_myers_nw_and_save(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, bool iupac_, MyersSaved* out_) {
+    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_); const bool iupac = rtk_u(iupac_); MyersSaved* out = rtk_u(out_);
+    out->valid = 0;
+#ifndef RTK_SIM
+    const long long W = (m + 63) >> 6;
+    if (!(m > 0 && n > 0 && m <= 4096 && static_cast<uint64_t>(4 * W * n) <= sc.tb_cap_words && static_cast<uint32_t>(m + n) <= sc.mv_cap && static_cast<uint32_t>(n) <= sc.t_cap &&
+          static_cast<uint32_t>(m) <= sc.r_cap && static_cast<uint32_t>(W) <= sc.w_cap)) return false;
+    MyersScratch& msc = const_cast<MyersScratch&>(sc); const uint32_t gen = rtk_ld(&msc.tb_gen) + 1u; msc.tb_gen = gen;
+    const SweepStat st = rtk_myers_fast_any<1, 1>(q, m, t, n, 1, iupac, rtk_ld(&sc.tb));
+    rtk_sync();
+    if (!st.plain) return false;
+    MyersResult r; // same bookkeeping as rtk_myers_distance (SHW)
+    int best = st.best; const bool pseudo = (m & 63) != 0;
+    if (pseudo && m < best) best = m;
+    r.dist = best;
+    if (pseudo && m == best) { r.first = -1; r.last = (st.best == best) ? st.last : -1; r.nloc = 1 + ((st.best == best) ? st.cnt : 0); }
+    else { r.first = st.first; r.last = st.last; r.nloc = st.cnt; }
+    out->m = m; out->n = n; out->nw_dist = st.final_score; out->shw = r; out->gen = gen;
+    const long long tn = r.first + 1;
+    out->valid = (tn > 0 && (2LL * 8 + 4) * W * tn + 8LL * tn < 1024 * 1024) ? 1u : 0u; // the in-memory traceback branch of obtainAlignment (edlib.cpp:1191-1193)
+    return true;
+#else
+    (void)sc; (void)q; (void)t; (void)m; (void)n; (void)iupac;
+    return false;
+#endif
+}
+RTK_FN bool rtk_myers_path_from_saved(const MyersScratch& sc_, const MyersSaved& sv_, uint32_t* n_moves_, MyersResult* r_) {
+    const MyersScratch& sc = *rtk_u(&sc_); const MyersSaved& sv = *rtk_u(&sv_); uint32_t* n_moves = rtk_u(n_moves_); MyersResult* r = rtk_u(r_);
+    *n_moves = 0;
+    if (!sv.valid || sv.gen != rtk_ld(&sc.tb_gen)) return false; // the table has been written again since
+    *r = sv.shw;
+    rtk_myers_walk(sc, sv.m, sv.shw.first + 1, sv.n, sv.shw.dist, n_moves);
+    return true;
 }
 
 #endif

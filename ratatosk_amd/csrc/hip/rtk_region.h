@@ -65,6 +65,7 @@ struct RegionScratch {
     U<uint64_t*> bm[3]; U<uint32_t> bm_words;
     U<uint32_t*> overflow;
     U<unsigned long long> cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
+    U<unsigned long long> fine[16]; // developer cycle counters printed with RTK_TRACE (RTK_FINE names in rtk_pipeline_run.inc)
 };
 
 struct RCtx { // everything a region program needs
@@ -409,14 +410,21 @@ RTK_FN_HOT double rtk_score_path(const RCtx& c, uint32_t sl_, const char* ref_, 
 }
 
 // quality string of a path (SHW path alignment against ref) written to qout[0..sl); path string in str[1]
-RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl_, const char* ref_, uint32_t ref_len_, double score_best_, double score_second_, char* qout_) {
-    RegionScratch& s = *rtk_u(c.sc); const uint32_t sl = rtk_u(sl_), ref_len = rtk_u(ref_len_); const char* ref = rtk_u(ref_); char* qout = rtk_u(qout_);
+RTK_FN void rtk_score_path_qual(const RCtx& c, uint32_t sl_, const char* ref_, uint32_t ref_len_, double score_best_, double score_second_, char* qout_, const MyersSaved* saved_ = nullptr) {
+    RegionScratch& s = *rtk_u(c.sc); const uint32_t sl = rtk_u(sl_), ref_len = rtk_u(ref_len_); const char* ref = rtk_u(ref_); char* qout = rtk_u(qout_); const MyersSaved* saved = rtk_u(saved_);
     const double score_best = rtk_u(score_best_), score_second = rtk_u(score_second_);
     const unsigned long long tq0 = rtk_clock();
     const double score_comp = score_best * ((score_best == 0.0) ? 0.0 : (1.0 - (score_second / score_best)));
     const char* const str1 = rtk_ld(&s.str[1]);
     uint32_t nm = 0;
-    RTK_SITE(4); rtk_align_path(c, str1, sl, ref, ref_len, RTK_MODE_SHW, &nm); nm = rtk_u(nm);
+    bool resumed = false;
+    if (saved && saved->valid && static_cast<uint32_t>(saved->m) == sl && static_cast<uint32_t>(saved->n) == ref_len) { // the sweep that scored this very path is still in the table
+        MyersResult r0; const unsigned long long t0 = rtk_clock();
+        resumed = rtk_myers_path_from_saved(s.my, *saved, &nm, &r0);
+        s.cnt[9] += rtk_clock() - t0;
+    }
+    if (!resumed) { RTK_SITE(4); rtk_align_path(c, str1, sl, ref, ref_len, RTK_MODE_SHW, &nm); }
+    nm = rtk_u(nm);
     const char c_best = rtk_get_qual(score_best, 0, static_cast<uint64_t>(rtk_u(c.o.max_qual)));
     rtk_wfill(qout, rtk_get_qual(score_comp, static_cast<uint64_t>(rtk_u(c.o.out_qual)), static_cast<uint64_t>(rtk_u(c.o.max_qual))), sl);
     // walk the moves: a base gets the best-score quality when it sits on an identical reference base in an M run.
@@ -498,7 +506,8 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
     WPath& w = s.wp[2];
     const bool has_end = !rtk_um_is_empty(um_e);
     const bool lazy_nt = has_end && !(rtk_u(c.o.min_score) > 0.0);
-    uint32_t n_nt_live = 0;
+    uint32_t n_nt_live = 0, n_t_scored = 0;
+    MyersSaved t_saved; t_saved.valid = 0; t_saved.gen = 0; t_saved.m = 0; t_saved.n = 0; t_saved.nw_dist = 0; t_saved.shw.dist = -1; t_saved.shw.first = -1; t_saved.shw.last = -1; t_saved.shw.nloc = 0;
     unsigned long long n_exp = 0;
     const unsigned long long td0 = rtk_clock(); const unsigned long long my0 = s.cnt[9];
 #ifdef RTK_SIM
@@ -539,7 +548,15 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
                 if (rtk_ld(&w.l) <= max_len_path && !rtk_failed(s)) {
                     const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
                     if (sl == 0xFFFFFFFFu) break;
-                    const double sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, true));
+                    // the first terminal candidate of a call -- usually the only one -- is scored by a stored sweep that its quality
+                    // string can be read from afterwards (rtk_myers_nw_and_save); further candidates overwrite nothing
+                    double sco;
+                    ++n_t_scored;
+                    if (n_t_scored == 1 && sl != 0 && rtk_myers_nw_and_save(s.my, str1, static_cast<int>(sl), ref, static_cast<int>(ref_len), true, &t_saved)) {
+                        s.cnt[3] += 1; s.cnt[4] += static_cast<unsigned long long>((sl + 63) / 64) * ref_len;
+                        sco = 1.0 - (static_cast<double>(rtk_u(t_saved.nw_dist)) / static_cast<double>(sl));
+                        sco = sco > 0.0 ? sco : 0.0; sco = sco < 1.0 ? sco : 1.0;
+                    } else sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, true));
                     if (sco >= score_t1) {
                         if (sco > score_t1) n_t = 0;
                         if (n_t >= list_cap) { rtk_fail_ovf(s, 8); break; }
@@ -619,7 +636,7 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
             rtk_wp_load(s, w, rtk_ld(L + i));
             const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
             if (sl == 0xFFFFFFFFu || sl > rtk_ld(&s.str_cap)) { rtk_fail_ovf(s, 7); break; }
-            rtk_score_path_qual(c, sl, ref, ref_len, which ? score_nt1 : score_t1, which ? score_nt2 : score_t2, str2);
+            rtk_score_path_qual(c, sl, ref, ref_len, which ? score_nt1 : score_t1, which ? score_nt2 : score_t2, str2, (which == 0 && n_t_scored == 1) ? &t_saved : nullptr);
             if (sl == rtk_ld(&w.l)) { rtk_wcopy(rtk_ld(&w.qual), str2, sl); w.qlen = sl; } // Path::setQuality only accepts q.length() == l
             L[i] = rtk_wp_commit(s, w, 2);
         }
@@ -987,11 +1004,13 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
     const GraphView& g = c.g;
     // a_pid[shift], shift = side index (0 middle, 1 right, 2 left) + 3 * nonbranching: built one after the other into the arena (level 2 is free here)
     s.top[2] = 0;
+    unsigned long long tf = rtk_clock();
+#define RTK_FINE_LAP(i) { const unsigned long long tn_ = rtk_clock(); s.fine[i] += tn_ - tf; tf = tn_; }
     const SideList* sides[3] = {&side_w, &side_e, &side_s};
-    uint64_t a_off[6]; uint32_t a_n[6];
+    const uint32_t* a_ptr[6]; uint32_t a_n[6];
     for (int sh = 0; sh < 6 && !rtk_failed(s); ++sh) {
         const SideList& sl = *sides[sh % 3]; const uint8_t want_nb = sh >= 3 ? 1 : 0;
-        int cur = 1; uint32_t n = 0;
+        int cur = 1; uint32_t n = 0, n_src = 0; const uint32_t* one = nullptr;
         for (uint32_t i = 0; i < sl.n && !rtk_failed(s); ++i) {
             if (sl.nb[i] != want_nb) continue;
             const uint32_t u = sl.u[i];
@@ -999,13 +1018,24 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
             const uint32_t* src = gi >= 0 ? g.col + g.goff[gi] : g.col + g.loff[u];
             const uint32_t ns = gi >= 0 ? static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]) : static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]);
             s.cnt[1] += ns;
-            n = rtk_rs_union(s, cur, n, src, ns, cur ^ 3); cur ^= 3; // ping-pong between set[1] and set[2]
+            if (ns == 0) continue;
+            // a class fed by ONE anchor set (the usual case: a region is flanked by a unitig or two) is that set: used where it lies in
+            // the graph's colour pool, neither merged nor copied
+            if (n_src == 0) { one = src; n = ns; n_src = 1; continue; }
+            if (n_src == 1) { if (n > s.set_cap) { rtk_fail_ovf(s, 9); break; } rtk_wcopy(s.set[cur], one, 4ull * n); rtk_sync(); }
+            n = rtk_rs_union(s, cur, n, src, ns, cur ^ 3); cur ^= 3; ++n_src; // ping-pong between set[1] and set[2]
         }
-        a_off[sh] = rtk_arena_alloc(s, 2, 4ull * n + 4); a_n[sh] = n;
-        if (!rtk_failed(s)) rtk_wcopy(s.arena[2] + a_off[sh], s.set[cur], 4ull * n);
+        a_n[sh] = n;
+        if (n_src <= 1) a_ptr[sh] = n_src ? one : reinterpret_cast<const uint32_t*>(s.arena[2].get());
+        else {
+            const uint64_t off = rtk_arena_alloc(s, 2, 4ull * n + 4);
+            if (!rtk_failed(s)) rtk_wcopy(s.arena[2] + off, s.set[cur], 4ull * n);
+            a_ptr[sh] = reinterpret_cast<const uint32_t*>(s.arena[2] + off);
+        }
     }
     if (rtk_failed(s)) return 0;
-    auto A = [&](int i) -> const uint32_t* { return reinterpret_cast<const uint32_t*>(s.arena[2] + a_off[i]); };
+    RTK_FINE_LAP(0)
+    auto A = [&](int i) -> const uint32_t* { return a_ptr[i]; };
     // candidate anchors: cardinality >= min_cov_vertices, ordered by (cardinality, unitig id) [D1]
     uint64_t* keys = s.list[4]; uint64_t* vals = s.list[3];
     uint32_t nsp = 0;
@@ -1018,6 +1048,7 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
         keys[nsp] = (static_cast<uint64_t>(g.card[u]) << 32) | u; vals[nsp] = 0; ++nsp; rtk_sync();
     }
     rtk_sort_pairs(keys, vals, nsp);
+    RTK_FINE_LAP(1)
     const uint32_t cov = 30;
     for (uint32_t j = 0; j < nsp; ++j) { const uint32_t cd = static_cast<uint32_t>(keys[j] >> 32); vals[j] = cd < cov ? cd : cov; } // remaining quota (p_spid.second)
     // position unions and their pairwise intersections
@@ -1039,6 +1070,7 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
         park(s.set[7], nnb, &onb); park(s.set[7], nnb, &onbc); nnbc = nnb;
     }
     if (rtk_failed(s)) return 0;
+    RTK_FINE_LAP(2)
     uint32_t n_all = 0; int allb = 0; // all_pids lives in set[0] (while it is being built: in set[allb])
     uint32_t nb_unselected = nsp;
     uint64_t o_prev2 = 0; uint32_t n_prev2 = 0; // a_pid2 of the previous class
@@ -1072,27 +1104,24 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
         }
         if (rtk_failed(s)) break;
         park(s.set[8], n2, &o_prev2); n_prev2 = n2; // a_pid2[i] is needed by the next class
+        RTK_FINE_LAP(3)
         if (n2 != 0) {
             nb_unselected = 0;
             uint32_t ncur = n2; int curb = 8; // curr_pid in set[8] / set[7] (ping-pong)
             for (uint32_t j = 0; j < nsp && !rtk_failed(s); ++j) {
                 const uint32_t u = static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull);
                 int quota = static_cast<int>(vals[j]);
-                if (quota > 0 && (i == 0 || rtk_shared_with_set(g, u, s.set[curb], ncur, 1) >= 1)) {
+                bool touch = false;
+                if (quota > 0) { touch = (i == 0 || rtk_shared_with_set(g, u, s.set[curb], ncur, 1) >= 1); RTK_FINE_LAP(4) }
+                if (touch) {
                     const uint32_t min_cov = g.card[u] < cov ? g.card[u] : cov;
                     const uint32_t sh = rtk_shared_with_set(g, u, s.set[allb], n_all, min_cov);
+                    RTK_FINE_LAP(5)
                     quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
                     if (quota > 0) {
                         const uint32_t all_card = n_all;
                         // pid = (global & curr) | (local & curr), truncated to its `quota` lowest ids
-                        uint32_t npid = 0;
-                        const int32_t gi = g.gid[u];
-                        uint32_t ng = 0;
-                        if (gi >= 0) ng = rtk_set_inter(g.col + g.goff[gi], static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]), s.set[curb], ncur, s.set[6]);
-                        const uint32_t nl = rtk_set_inter(g.col + g.loff[u], static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]), s.set[curb], ncur, s.set[5]);
-                        if (ng + nl > s.set_cap) { rtk_fail_ovf(s, 9); break; }
-                        npid = rtk_set_union(s.set[6], ng, s.set[5], nl, s.set[4], s.set[9]);
-                        if (npid > static_cast<uint32_t>(quota)) npid = static_cast<uint32_t>(quota);
+                        const uint32_t npid = rtk_first_shared(g, u, s.set[curb], ncur, static_cast<uint32_t>(quota), s.set[4]);
                         if (n_all + npid > s.set_cap) { rtk_fail_ovf(s, 9); break; }
                         const uint32_t nn = rtk_set_union(s.set[allb], n_all, s.set[4], npid, s.set[allb ^ 3], s.set[9]);
                         allb ^= 3; n_all = nn; // all_pids alternates between set[0] and set[3]; it is moved to set[0] once, at the end
@@ -1100,6 +1129,7 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
                         ncur = rtk_set_diff(s.set[curb], ncur, s.set[4], npid, s.set[nb2]); curb = nb2;
                         const int gained = static_cast<int>(n_all - all_card);
                         quota -= gained < quota ? gained : quota;
+                        RTK_FINE_LAP(6)
                     }
                 }
                 vals[j] = static_cast<uint64_t>(quota);
@@ -1248,6 +1278,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     }
     uint32_t n_all = 0;
     if (rc == nullptr) {
+        const unsigned long long t_side0 = rtk_clock();
         // side lists live in list[0..2] memory (u32 unitig + flag bytes)
         SideList sl, sr, sm;
         const uint32_t cap = s.list_cap;
@@ -1285,6 +1316,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
             rtk_scan_anchor_runs(v_w, static_cast<int64_t>(lw_lo), +1, [&](uint32_t p) { return p < pos_end_m; }, [&](const UMap& um) { const uint32_t u = um.unitig; if (g.kcov[u] < c.o.max_km_cov) rtk_side_insert(sm, u, !rtk_is_branching(g, u)); });
         }
         if (sl.n >= cap / 2 || sr.n >= cap / 2 || sm.n >= cap / 2) { rtk_fail_ovf(s, 8); return; }
+        s.fine[7] += rtk_clock() - t_side0;
         { const unsigned long long t0 = rtk_clock(); n_all = rtk_choose_colors(c, sl, sr, sm); s.cnt[5] += rtk_clock() - t0; }
         if (rtk_failed(s)) return;
         // keep all_pids for the reverse-complement call (rc = &fw): set[0] is preserved by everything below
@@ -1360,14 +1392,16 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
         rtk_bm_add_range(res.bm, 0, len_weak_region);
     }
     if (rtk_failed(s)) return;
-    if (n_amb != 0) { rtk_fix_ambiguity(c, s_corr, sl_, q_corr, ql_, s_read + first_pos, res.old_len, n_amb); if (rtk_failed(s)) return; } // :716
+    if (n_amb != 0) { const unsigned long long ta0 = rtk_clock(); rtk_fix_ambiguity(c, s_corr, sl_, q_corr, ql_, s_read + first_pos, res.old_len, n_amb); s.fine[9] += rtk_clock() - ta0; if (rtk_failed(s)) return; } // :716
     if (rtk_bm_card(res.bm, res.old_len) == res.old_len) { // :718-725 (G20): last k-mer of the WHOLE read vs last k-mer of the corrected region
         bool same = sl_ >= k && s_len >= k;
         for (uint32_t i = 0; same && i < k; ++i) same = rtk_bifrost_code(s_read[s_len - k + i]) == rtk_bifrost_code(s_corr[sl_ - k + i]);
         if (same) res.is_corrected = true;
     }
     if (!res.is_corrected) { // :727-747 trim the corrected string to the largest SHW end location of the raw region
+        const unsigned long long tt0 = rtk_clock();
         RTK_SITE(13); const MyersResult a = rtk_align(c, s_read + first_pos, p2 - first_pos + k, s_corr, sl_, -1, RTK_MODE_SHW);
+        s.fine[8] += rtk_clock() - tt0;
         if (a.dist >= 0) {
             const uint32_t keep = (a.first == -1) ? 0u : static_cast<uint32_t>(a.last + 1); // endLocations[0] == -1 wraps to SIZE_MAX in the reference
             if (keep < sl_) sl_ = keep;
@@ -1411,6 +1445,16 @@ RTK_FN void rtk_move_into_cigar(uint32_t start_, uint32_t end_, CigCur& cc_, uin
 }
 
 // writes the consensus into out_s/out_q; returns false when the result is "empty" (caller falls back to the raw region)
+// lane-parallel string predicates (wave-uniform results)
+RTK_DEV bool rtk_str_equal(const char* a, const char* b, uint32_t n) {
+    for (uint32_t i0 = 0; i0 < n; i0 += RTK_WAVE) { const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane()); if (rtk_ballot(i < n && a[i] != b[i]) != 0ull) return false; }
+    return true;
+}
+RTK_DEV bool rtk_all_acgt(const char* p, uint32_t n) {
+    for (uint32_t i0 = 0; i0 < n; i0 += RTK_WAVE) { const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane()); const char ch = i < n ? p[i] : 'A'; if (rtk_ballot(!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) != 0ull) return false; }
+    return true;
+}
+
 RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const ResCorr* bw_, const char* ref_, uint32_t ref_len_, double max_norm_, char* out_s_, uint32_t* out_sl_, char* out_q_, uint32_t* out_ql_) {
     const RCtx& c = *rtk_u(&c_); const ResCorr* fw = rtk_u(fw_); const ResCorr* bw = rtk_u(bw_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); double max_norm = rtk_u(max_norm_); char* out_s = rtk_u(out_s_); uint32_t* out_sl = rtk_u(out_sl_); char* out_q = rtk_u(out_q_); uint32_t* out_ql = rtk_u(out_ql_);
     RegionScratch& s = *c.sc;
@@ -1426,9 +1470,15 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
     RTK_SITE(14); const MyersResult afw = rtk_align_path(c, fw->seq, fw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_fw);
     if (rtk_failed(s) || nm_fw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
     rtk_wcopy(s.str[3], s.my.moves, nm_fw);
-    RTK_SITE(15); const MyersResult abw = rtk_align_path(c, bw->seq, bw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_bw);
-    if (rtk_failed(s) || nm_bw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
-    rtk_wcopy(s.str[4], s.my.moves, nm_bw);
+    // Both directions usually arrive at the same corrected string: its alignment against the raw region is then the one just computed
+    const bool same_strings = bw->seq_len == fw->seq_len && rtk_str_equal(bw->seq, fw->seq, fw->seq_len);
+    MyersResult abw = afw;
+    if (same_strings) { nm_bw = nm_fw; rtk_wcopy(s.str[4], s.str[3], nm_fw); }
+    else {
+        RTK_SITE(15); abw = rtk_align_path(c, bw->seq, bw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_bw);
+        if (rtk_failed(s) || nm_bw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
+        rtk_wcopy(s.str[4], s.my.moves, nm_bw);
+    }
     const double n_fw = static_cast<double>(afw.dist) / static_cast<double>(fw->seq_len > ref_len ? fw->seq_len : ref_len);
     const double n_bw = static_cast<double>(abw.dist) / static_cast<double>(bw->seq_len > ref_len ? bw->seq_len : ref_len);
     if (max_norm > 0.0 && (n_fw > max_norm || n_bw > max_norm)) {
@@ -1460,6 +1510,12 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
         i = rout;
     }
     if (max_norm > 0.0 && !rtk_failed(s)) {
+        // The merged string is very often one of the two inputs again. Its distance to the raw region is then the one computed above --
+        // provided the plain configuration of this last call (edlibDefaultAlignConfig, :460: no IUPAC equalities) cannot tell the two
+        // apart, i.e. both strings hold A/C/G/T only -- and that distance already passed the max_norm test above: nothing to compute.
+        const bool is_fw = *out_sl == fw->seq_len && rtk_str_equal(out_s, fw->seq, fw->seq_len);
+        const bool is_bw = !is_fw && *out_sl == bw->seq_len && rtk_str_equal(out_s, bw->seq, bw->seq_len);
+        if ((is_fw || is_bw) && rtk_all_acgt(out_s, *out_sl) && rtk_all_acgt(ref, ref_len)) return true;
         RTK_SITE(16); const MyersResult a = rtk_align(c, out_s, *out_sl, ref, ref_len, -1, RTK_MODE_NW, /*iupac=*/false); // edlibDefaultAlignConfig (:460)
         const double n = static_cast<double>(a.dist) / static_cast<double>(*out_sl > ref_len ? *out_sl : ref_len);
         if (n > max_norm) { *out_sl = 0; *out_ql = 0; return take(fw); }
@@ -1498,7 +1554,7 @@ RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& 
     t.str_cap = c.str_cap;
     t.memo_v = reinterpret_cast<uint8_t*>(p); p += c.memo_cap;
     t.overflow = t.my.overflow;
-    for (int i = 0; i < 16; ++i) t.cnt[i] = 0;
+    for (int i = 0; i < 16; ++i) { t.cnt[i] = 0; t.fine[i] = 0; }
     *s = t; // every lane stores the same header
     return s;
 }

@@ -110,6 +110,42 @@ RTK_FN uint32_t rtk_shared_with_set(const GraphView& g_, uint32_t u_, const uint
     return shared;
 }
 
+// The `want` lowest ids of colours(u) & set, ascending, into out; returns how many (< want when the intersection is smaller). This IS
+// "(global & set) | (local & set), truncated to its `want` lowest ids" (chooseColors, src/Correction.cpp:372-390) without building
+// either intersection: `set` is walked from its smallest id, 64 ids per step, and the walk stops as soon as `want` are found
+// (want <= 30, the sets hold hundreds to thousands of ids).
+RTK_FN uint32_t rtk_first_shared(const GraphView& g_, uint32_t u_, const uint32_t* set_, uint32_t n_, uint32_t want_, uint32_t* out_) {
+    const GraphView& g = *rtk_u(&g_); uint32_t u = rtk_u(u_); const uint32_t* set = rtk_u(set_); uint32_t n = rtk_u(n_); uint32_t want = rtk_u(want_); uint32_t* out = rtk_u(out_);
+    if (n == 0 || want == 0) return 0;
+    const int32_t gi = g.gid[u];
+    const uint32_t* gl = gi >= 0 ? g.col + g.goff[gi] : nullptr; const uint32_t ngl = gi >= 0 ? static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]) : 0u;
+    const uint32_t* lo = g.col + g.loff[u]; const uint32_t nlo = static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]);
+    if (ngl + nlo == 0) return 0;
+#ifndef RTK_SIM
+    uint32_t* const lds = rtk_lds_set_buf();
+    const bool staged = (ngl + nlo) <= RTK_LDS_SET_CAP;
+    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < ngl + nlo; i += RTK_WAVE) lds[i] = i < ngl ? gl[i] : lo[i - ngl]; __syncthreads(); }
+#endif
+    uint32_t found = 0;
+    for (uint32_t i0 = 0; i0 < n && found < want; i0 += RTK_WAVE) {
+        const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+        uint32_t x = 0; bool in = false;
+        if (i < n) {
+            x = set[i];
+#ifndef RTK_SIM
+            if (staged) in = rtk_lds_contains(lds, ngl, x) || rtk_lds_contains(lds + ngl, nlo, x); else
+#endif
+            in = (ngl && rtk_set_contains(gl, ngl, x)) || rtk_set_contains(lo, nlo, x);
+        }
+        const uint64_t bal = rtk_ballot(in);
+        const uint32_t my = found + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)));
+        if (in && my < want) out[my] = x;
+        found += static_cast<uint32_t>(rtk_popc(bal));
+    }
+    rtk_sync();
+    return found < want ? found : want;
+}
+
 // min(|colours(u) & colours(v)|, cap)  (getNumberSharedPairID(SharedPairID, SharedPairID), src/Common.cpp:51-71);
 // global and local parts of one unitig are disjoint, so the four partial intersections add up
 RTK_FN uint32_t rtk_shared_unitigs(const GraphView& g_, uint32_t u_, uint32_t v_, uint32_t cap_) {
