@@ -329,7 +329,7 @@ def main():
         traffic, traffic_src = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
-                    "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()}, "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")), "index_lookups_inexact_per_step": int(S("n_probes_inexact")), "index_slots_inexact_per_step": int(S("n_slots_inexact")), "k_regions_wave_cycle_share": {kk: round(S(kk) / max(1.0, S("cyc_total")), 3) for kk in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "cyc_walk")}, "alignment_moves_per_step": int(S("n_moves")), "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
+                    "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()}, "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")), "index_lookups_inexact_per_step": int(S("n_probes_inexact")), "index_slots_inexact_per_step": int(S("n_slots_inexact")), "k_regions_wave_cycle_share": {kk: round(S(kk) / max(1.0, S("cyc_total")), 3) for kk in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "cyc_walk")}, "alignment_moves_per_step": int(S("n_moves")), "k_regions_wave_ticks_per_step": int(S("cyc_total")), "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
         whole_alg = (8.0 * S("n_probes_exact") + 16.0 * (S("n_slots_exact") + S("n_slots_inexact")) + 40.0 * S("n_expand") + 4.0 * S("n_colour_elem") + 0.25 * S("n_path_base") + 4.0 * S("in_bases")) / max(1.0, S("in_bases"))
         out = {
             "metric": "corrected long-read bases/sec", "value": bases_all / dt_all if dt_all > 0 else 0.0, "unit": "bases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

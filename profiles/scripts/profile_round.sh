@@ -7,14 +7,14 @@ OUT=$PWD/gpurun_out/prof_$R
 SUM=$PWD/gpurun_out/profiles_$R
 mkdir -p $OUT $SUM
 export TMPDIR=/tmp
-BENCH="python bench.py --no-cpu-baseline"          # the default command (steps overlap on two streams)
-SERIAL="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial"   # counter passes: one kernel at a time, so that a dispatch's counters are its own
+BENCH="python bench.py --no-cpu-baseline --no-host-legs"          # the default command (steps overlap on two streams)
+SERIAL="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs --serial"   # counter passes: one kernel at a time, so that a dispatch's counters are its own
 # 1. the bench line itself (with the CPU baseline)
 timeout 900 python bench.py > $SUM/${R}_bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats of the same command
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $SUM/${R}_bench_under_rocprof.json 2> $OUT/stats.err
 # 2b. the same with the steps back to back (per-kernel durations undisturbed by the next step's seed kernels)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o stats -- python bench.py --no-cpu-baseline --serial > /dev/null 2> $OUT/stats_serial.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o stats -- python bench.py --no-cpu-baseline --no-host-legs --serial > /dev/null 2> $OUT/stats_serial.err
 # 3. PMC passes, each on its own (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $SERIAL > /dev/null 2> $OUT/fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $SERIAL > /dev/null 2> $OUT/write.err
