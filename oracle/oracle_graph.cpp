@@ -65,7 +65,20 @@ void read_pairid(Rd& r, IdSet& out) {
             r.p = base + n;
             break;
         }
-        default: throw std::runtime_error("oracle: PairID flag 0 (TinyBitmap) / unknown flag not supported");
+        case 0: { // Bifrost TinyBitmap::write payload, assumed layout [A8] (see oracle_graph.hpp): header, cardinality, offset, data
+            if (w != 0) throw std::runtime_error("oracle: PairID flag 0 with payload bits in the flag word");
+            const uint32_t header = r.u16at(r.p); const uint32_t sz = header >> 3, mode = header & 6u;
+            if (sz == 0) { r.p += 2; break; }
+            if (sz < 3 || sz > 4096 || r.p + 2ull * sz > r.b.size()) throw std::runtime_error("oracle: TinyBitmap block malformed [A8]");
+            const uint32_t card = r.u16at(r.p + 2), hi = r.u16at(r.p + 4) << 16; const size_t d = r.p + 6;
+            if (mode == 0) { for (uint32_t v = 0; v < 16u * (sz - 3); ++v) if ((r.u16at(d + 2 * (v / 16)) >> (v % 16)) & 1u) out.push_back(hi | v); if (out.size() != card) throw std::runtime_error("oracle: TinyBitmap cardinality [A8]"); }
+            else if (mode == 2) { if (3 + card > sz) throw std::runtime_error("oracle: TinyBitmap list [A8]"); for (uint32_t i = 0; i < card; ++i) out.push_back(hi | r.u16at(d + 2 * i)); }
+            else if (mode == 4) { if ((card & 1u) || 3 + card > sz) throw std::runtime_error("oracle: TinyBitmap runs [A8]"); for (uint32_t i = 0; i < card; i += 2) for (uint32_t v = r.u16at(d + 2 * i); v <= r.u16at(d + 2 * i + 2); ++v) out.push_back(hi | v); }
+            else throw std::runtime_error("oracle: TinyBitmap mode [A8]");
+            r.p += 2ull * sz;
+            break;
+        }
+        default: throw std::runtime_error("oracle: unknown PairID flag");
     }
 }
 

@@ -20,6 +20,10 @@
 //   [A7] findUnitig(s, pos, len) = find(k-mer at s+pos) extended along the unitig while s keeps agreeing: forward strand
 //        {dist = d, len = 1 + agreeing characters}; reverse strand the match runs towards the unitig head and
 //        {dist = d - (len - 1)} (the mapping always starts at its lowest forward offset).
+//   [A8] TinyBitmap::write payload behind a PairID flag-0 word (src/PairID.cpp:1158-1167): uint16 words, word 0 = size << 3 | mode,
+//        word 1 = cardinality (words in use for the list modes), word 2 = the high 16 bits shared by all values, data from word 3;
+//        mode 0 bitmap, 2 ascending list, 4 ascending (first, last) runs; empty = the single word 0. From Bifrost's published
+//        TinyBitmap source; not verifiable here (no Bifrost, no reference-written .rtsk).
 // "Parity unpinned" for everything that depends on [A1]-[A3]: the reference has no tests and its binary
 // cannot be built here.
 #ifndef RTK_ORACLE_GRAPH_HPP

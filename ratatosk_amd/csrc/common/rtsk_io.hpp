@@ -13,7 +13,7 @@
 //     u64  n_cycle_bytes  + bytes   NUL separated successor-base strings
 //   PairID stream: one u64 w; (w&7)==1 inline bit-vector, ids = set bits of w>>3 (<61);
 //     (w&7)==2 single id w>>3; (w&7)==3 -> w>>3 bytes of CRoaring *portable* serialisation follow;
-//     (w&7)==0 -> Bifrost TinyBitmap payload (layout not verifiable without Bifrost: rejected loudly).
+//     (w&7)==0 -> Bifrost TinyBitmap::write payload follows (assumed layout [A8], see tinybitmap_read; inconsistent payloads are rejected).
 #ifndef RTK_COMMON_RTSK_IO_HPP
 #define RTK_COMMON_RTSK_IO_HPP
 
@@ -110,6 +110,41 @@ inline void roaring_portable_encode(const std::vector<uint32_t>& ids, std::strin
     (void)base;
 }
 
+// Bifrost TinyBitmap stream (PairID flag 0; reference: src/PairID.cpp:1158-1167 writes the flag word, then TinyBitmap::write).
+// [A8] Layout as published in pmelsted/bifrost src/TinyBitmap.{hpp,cpp} -- NOT verifiable in this build (Bifrost absent, no reference-
+// written .rtsk at hand): an array of uint16 words, word 0 = header (size_in_words << 3 | mode | bits), word 1 = cardinality (words
+// in use for the list modes), word 2 = offset = the high 16 bits shared by every value, data from word 3:
+//   mode 0 bitmap   bit b of word 3 + i  <=>  value (offset << 16) | (16 i + b)
+//   mode 2 list     `cardinality` ascending low halves
+//   mode 4 RLE list `cardinality` / 2 pairs (first, last), inclusive, ascending
+// An empty TinyBitmap is the single word 0. Anything inconsistent with this layout is rejected (never guessed at).
+inline void tinybitmap_read(std::istream& in, std::vector<uint32_t>& ids) {
+    uint16_t header = 0;
+    in.read(reinterpret_cast<char*>(&header), 2);
+    if (!in.good()) throw std::runtime_error("rtsk: truncated TinyBitmap header");
+    const uint32_t sz = header >> 3, mode = header & 0x6u;
+    if (sz == 0) return;
+    if (sz < 3 || sz > 4096 || (mode != 0 && mode != 2 && mode != 4)) throw std::runtime_error("rtsk: TinyBitmap header does not match the assumed Bifrost layout [A8]");
+    std::vector<uint16_t> w(sz); w[0] = header;
+    in.read(reinterpret_cast<char*>(&w[1]), static_cast<std::streamsize>(2 * (sz - 1)));
+    if (!in.good()) throw std::runtime_error("rtsk: truncated TinyBitmap payload");
+    const uint32_t card = w[1], hi = static_cast<uint32_t>(w[2]) << 16;
+    if (mode == 0) {
+        for (uint32_t i = 3; i < sz; ++i) for (uint32_t b = 0; b < 16; ++b) if ((w[i] >> b) & 1u) ids.push_back(hi | (16u * (i - 3) + b));
+        if (ids.size() != card) throw std::runtime_error("rtsk: TinyBitmap bitmap cardinality mismatch [A8]");
+    } else if (mode == 2) {
+        if (3 + card > sz) throw std::runtime_error("rtsk: TinyBitmap list longer than its block [A8]");
+        for (uint32_t i = 0; i < card; ++i) { if (i && w[3 + i] <= w[2 + i]) throw std::runtime_error("rtsk: TinyBitmap list not ascending [A8]"); ids.push_back(hi | w[3 + i]); }
+    } else {
+        if ((card & 1u) || 3 + card > sz) throw std::runtime_error("rtsk: TinyBitmap run list malformed [A8]");
+        for (uint32_t i = 0; i < card; i += 2) {
+            const uint32_t a = w[3 + i], b = w[4 + i];
+            if (b < a || (i && a <= w[2 + i])) throw std::runtime_error("rtsk: TinyBitmap runs not ascending [A8]");
+            for (uint32_t v = a; v <= b; ++v) ids.push_back(hi | v);
+        }
+    }
+}
+
 inline void pairid_read(std::istream& in, std::vector<uint32_t>& ids) {
     ids.clear();
     uint64_t w = 0;
@@ -128,7 +163,8 @@ inline void pairid_read(std::istream& in, std::vector<uint32_t>& ids) {
         if (!in.good() && n) throw std::runtime_error("rtsk: truncated roaring payload");
         roaring_portable_decode(buf.data(), n, ids);
     } else if (flag == 0) {
-        throw std::runtime_error("rtsk: PairID flag 0 (Bifrost TinyBitmap stream) is not supported: layout unverifiable without Bifrost (SURVEY.md §8f-1)");
+        if (w != 0) throw std::runtime_error("rtsk: PairID flag 0 with a non-zero word (src/PairID.cpp:1158-1167 writes the bare flag before the TinyBitmap)");
+        tinybitmap_read(in, ids);
     } else throw std::runtime_error("rtsk: unknown PairID flag");
 }
 

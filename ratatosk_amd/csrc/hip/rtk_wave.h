@@ -41,13 +41,13 @@ inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64;
 
 #define RTK_DEV __device__ __forceinline__
 #define RTK_FN __device__ __noinline__ // large device functions are real calls: keeps hipcc compile time and code size bounded
-// Thin wrappers on the hot path (alignment entry, path scoring, path extension, colour memo). A real call costs the callee-saved
-// spills of the AMDGPU calling convention; inlining them (-DRTK_HOT_INLINE) measured 79.3 -> 77.6 ms on k_regions but made one
-// overflow-redo parity test fail (a call is also a compiler barrier between lane-crossing memory accesses): calls stay the default.
-#ifdef RTK_HOT_INLINE
-#define RTK_FN_HOT RTK_DEV
-#else
+// Thin wrappers and small leaves on the hot path (alignment entry, path scoring, path extension, colour memo, lane copies / fills).
+// A real call costs the callee-saved spills of the AMDGPU calling convention (one private-memory store and load of 64 lanes per
+// saved register, on every call): these are inlined; -DRTK_HOT_CALLS turns them back into calls for A/B measurements.
+#ifdef RTK_HOT_CALLS
 #define RTK_FN_HOT RTK_FN
+#else
+#define RTK_FN_HOT RTK_DEV
 #endif
 #define RTK_WAVE 64
 __device__ __forceinline__ int rtk_lane() { return static_cast<int>(threadIdx.x) & 63; }
@@ -107,18 +107,18 @@ RTK_DEV void rtk_copy_lanes(void* dst, const void* src, uint64_t n) {
     }
     for (uint64_t i = done + static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = s[i];
 }
-RTK_FN void rtk_wcopy(void* dst, const void* src, uint64_t n) {
+RTK_FN_HOT void rtk_wcopy(void* dst, const void* src, uint64_t n) {
     rtk_copy_lanes(rtk_u(dst), rtk_u(src), rtk_u(n));
     rtk_sync();
 }
 // two copies, one publish
-RTK_FN void rtk_wcopy2(void* dst0, const void* src0, uint64_t n0, void* dst1, const void* src1, uint64_t n1) {
+RTK_FN_HOT void rtk_wcopy2(void* dst0, const void* src0, uint64_t n0, void* dst1, const void* src1, uint64_t n1) {
     rtk_copy_lanes(rtk_u(dst0), rtk_u(src0), rtk_u(n0));
     rtk_copy_lanes(rtk_u(dst1), rtk_u(src1), rtk_u(n1));
     rtk_sync();
 }
 
-RTK_FN void rtk_wfill(void* dst, int c, uint64_t n) {
+RTK_FN_HOT void rtk_wfill(void* dst, int c, uint64_t n) {
     char* d = static_cast<char*>(rtk_u(dst)); n = rtk_u(n); c = rtk_u(c);
     for (uint64_t i = static_cast<uint64_t>(rtk_lane()); i < n; i += RTK_WAVE) d[i] = static_cast<char>(c);
     rtk_sync();

@@ -13,10 +13,8 @@
 //   * edge bits      = neighbour shares >= min_cov_vertices colours (reference: src/Graph.cpp:1999-2017)
 //   * global/local   = simplified form of the colour compaction of src/Graph.cpp:2874-2985
 //   * short cycles   = restatement of detectShortCycles (src/Graph.cpp:4660-4735), so that fixRepeats has inputs
-//   * SNP annotations (--snps only) = simplified stand-in for detectSNPs (src/Graph.cpp:484-720): a position is annotated with the
-//     IUPAC union of its base and the substituted base when the k-mer with that substitution lies on ANOTHER unitig and one
-//     neighbour on each side shares >= min_cov colours with both (one-step form of isValidSNPcandidate,
-//     src/GraphTraversal.cpp:1057-1147). Gives fixAmbiguity/getAmbiguityVector inputs; haplotype ids stay empty (no phasing).
+//   * SNP annotations (--snps only) = restatement of detectSNPs (src/Graph.cpp:484-720) with the breadth-first bubble walk of
+//     isValidSNPcandidate (src/GraphTraversal.cpp:1057-1147); haplotype ids stay empty (no phasing input).
 #include <zlib.h>
 
 #include <algorithm>
@@ -265,22 +263,75 @@ int main(int argc, char** argv) {
         fprintf(stderr, "rtk_build_index: %zu unitigs in short cycles\n", n_cyc_unitigs);
     }
 
-    // ---- SNP annotations (simplified stand-in for detectSNPs, see the header) ----
+    // ---- SNP annotations: restatement of detectSNPs (src/Graph.cpp:484-720) with isValidSNPcandidate (src/GraphTraversal.cpp:1057-1147).
+    // For every unitig with an edge bit: every graph k-mer ONE SUBSTITUTION away from one of its windows (searchSequence(seq, false,
+    // false, false, true, false), [A2]) that lies on another unitig is a SNP candidate; the position gets the IUPAC union of its base
+    // and the candidate's base when the other unitig passes isValidSNPcandidate: a breadth-first walk from this unitig, forwards and
+    // backwards, over edges carrying an edge bit and unitigs sharing >= min_cov colours with this one, until a unitig shares >= min_cov
+    // colours with the candidate (or 65536 unitigs were seen). The two walks keep their state from candidate to candidate, and a unitig
+    // that answered one candidate is not expanded further -- reproduced as written. Candidates are visited by (window, substituted
+    // offset, substituted base): Bifrost's own order inside one window is not known ([D3], canonical rule).
     std::vector<std::vector<uint32_t> > ambiguity(n);
     if (detect_snps) {
+        std::vector<uint64_t> headk(n), tailk(n);
+        for (size_t u = 0; u < n; ++u) { kmer_encode(U[u].seq.c_str(), k, headk[u]); kmer_encode(U[u].seq.c_str() + U[u].seq.size() - k, k, tailk[u]); }
+        struct Node { size_t u; bool fw; };
+        // successors of (u, strand) in A,C,G,T order with the base that is appended
+        auto successors = [&](const Node& x, Node out[4], int base[4]) -> int {
+            int m = 0;
+            const uint64_t endk = x.fw ? tailk[x.u] : kmer_revcomp(headk[x.u], k);
+            for (uint64_t b = 0; b < 4; ++b) {
+                const int64_t w = adj[x.u].u[x.fw ? 0 : 1][b];
+                if (w < 0) continue;
+                const uint64_t y = ((endk << 2) | b) & mask;
+                out[m].u = static_cast<size_t>(w); out[m].fw = (y == headk[static_cast<size_t>(w)]); base[m] = static_cast<int>(b); ++m;
+            }
+            return m;
+        };
+        auto edge_bit = [&](const Node& x, int b) -> bool { return (shared[x.u] & (x.fw ? ((1ULL << b) << 4) : (1ULL << b))) != 0; };
+        struct Walk { std::set<std::pair<size_t, bool> > seen; std::vector<size_t> seen_units; std::queue<Node> q; };
+        const size_t limit_sz_stack = 65536;
+        auto explore = [&](Walk& lgt, const Node& a, size_t ub) -> bool {
+            if (U[a.u].colours.size() < min_cov_vertices || U[ub].colours.size() < min_cov_vertices) return false;
+            if (lgt.seen.empty()) { lgt.q.push(a); lgt.seen.insert(std::make_pair(a.u, a.fw)); lgt.seen_units.push_back(a.u); }
+            else if (lgt.seen.size() >= limit_sz_stack) return true;
+            while (!lgt.q.empty()) {
+                const Node x = lgt.q.front(); lgt.q.pop();
+                Node nb[4]; int bs[4];
+                const int m = successors(x, nb, bs);
+                for (int i = 0; i < m; ++i) {
+                    if (!edge_bit(x, bs[i])) continue;
+                    if (!lgt.seen.insert(std::make_pair(nb[i].u, nb[i].fw)).second) continue; // visited (keyed by the mapped head k-mer: unitig + strand)
+                    lgt.seen_units.push_back(nb[i].u);
+                    if (shared_count(U[nb[i].u].colours, U[a.u].colours) >= min_cov_vertices) {
+                        if (shared_count(U[nb[i].u].colours, U[ub].colours) >= min_cov_vertices) return true;
+                        lgt.q.push(nb[i]);
+                    }
+                }
+                if (lgt.seen.size() >= limit_sz_stack) return true;
+            }
+            return false;
+        };
+        auto is_valid = [&](Walk& fw, Walk& bw, size_t ua, size_t ub) -> bool {
+            bool ok_fw = false, ok_bw = false;
+            for (size_t i = 0; i < fw.seen_units.size() && !ok_fw; ++i) ok_fw = shared_count(U[fw.seen_units[i]].colours, U[ub].colours) >= min_cov_vertices;
+            if (!ok_fw) { Node a; a.u = ua; a.fw = true; ok_fw = explore(fw, a, ub); }
+            if (ok_fw) {
+                for (size_t i = 0; i < bw.seen_units.size() && !ok_bw; ++i) ok_bw = shared_count(U[bw.seen_units[i]].colours, U[ub].colours) >= min_cov_vertices;
+                if (!ok_bw) { Node a; a.u = ua; a.fw = false; ok_bw = explore(bw, a, ub); }
+            }
+            return ok_fw && ok_bw;
+        };
+        auto amb_bits = [](char c) -> unsigned { // getAmbiguityRev (src/Common.hpp:351-399): bit0 A, bit1 C, bit2 G, bit3 T
+            switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': return 8; case 'M': return 3; case 'R': return 5; case 'S': return 6; case 'V': return 7;
+                         case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14; case 'N': return 15; default: return 0; } };
+        static const char amb_char[16] = {'.', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'}; // getAmbiguity
         auto annotate = [&](size_t u) {
             if (!(shared[u] & 0xffULL)) return; // hasSharedPids (src/Graph.cpp:500)
             const std::string& s = U[u].seq;
-            std::vector<uint8_t> fin(s.size(), 0);
+            std::string seq_final = s, seq_tried = s;
             std::set<size_t> ok, bad;
-            auto flank = [&](size_t w, int d) {
-                for (int b = 0; b < 4; ++b) {
-                    const int64_t x = adj[u].u[d][b];
-                    if (x < 0 || !(shared[u] & (d == 0 ? ((1ULL << b) << 4) : (1ULL << b)))) continue;
-                    if (shared_count(U[static_cast<size_t>(x)].colours, U[u].colours) >= min_cov_vertices && shared_count(U[static_cast<size_t>(x)].colours, U[w].colours) >= min_cov_vertices) return true;
-                }
-                return false;
-            };
+            Walk lgt_fw, lgt_bw;
             uint64_t fw = 0;
             for (size_t i = 0; i < s.size(); ++i) {
                 fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & mask;
@@ -296,13 +347,19 @@ int main(int argc, char** argv) {
                         if (!v) continue;
                         const size_t w = (*v >> 32) - 1;
                         if (w == u) continue; // a SNP candidate cannot be on the same unitig (src/Graph.cpp:523)
-                        if (bad.count(w)) continue;
-                        if (!ok.count(w)) { if (U[u].colours.size() >= min_cov_vertices && U[w].colours.size() >= min_cov_vertices && flank(w, 0) && flank(w, 1)) ok.insert(w); else { bad.insert(w); continue; } }
-                        fin[p + static_cast<size_t>(j)] |= static_cast<uint8_t>((1u << cur) | (1u << alt)); // bit0 A, bit1 C, bit2 G, bit3 T (src/Common.hpp:260,351)
+                        const size_t at = p + static_cast<size_t>(j); // pos_snp_km = first mismatch = the substituted offset
+                        const unsigned f = amb_bits(seq_final[at]), t = amb_bits(seq_tried[at]), kk = 1u << alt;
+                        const char cf = amb_char[f | kk], ct = amb_char[t | kk];
+                        if (seq_tried[at] == ct) continue; // that base was tried at this position before
+                        seq_tried[at] = ct;
+                        if (ok.count(w)) seq_final[at] = cf;
+                        else if (!bad.count(w)) {
+                            if (is_valid(lgt_fw, lgt_bw, u, w)) { seq_final[at] = cf; ok.insert(w); } else bad.insert(w);
+                        }
                     }
                 }
             }
-            for (size_t i = 0; i < fin.size(); ++i) if (fin[i]) ambiguity[u].push_back(static_cast<uint32_t>((i << 4) + fin[i])); // UnitigData.hpp:448-451
+            for (size_t i = 0; i < seq_final.size(); ++i) if (seq_final[i] != 'A' && seq_final[i] != 'C' && seq_final[i] != 'G' && seq_final[i] != 'T') ambiguity[u].push_back(static_cast<uint32_t>((i << 4) + amb_bits(seq_final[i]))); // UnitigData.hpp:448-451
         };
         { // unitigs are independent and the k-mer table is only read: one strided slice per thread
             unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64;

@@ -73,7 +73,34 @@ def _encode_12347(ids, force_run):
     return out + b"".join(bodies), sum(is_run), n
 
 
-def _rewrite(src, dst, remap):
+def _encode_tiny(ids, mode):
+    """Bifrost TinyBitmap::write payload under the layout assumed in csrc/common/rtsk_io.hpp [A8]; None when the set does not fit."""
+    if len({v >> 16 for v in ids}) != 1:
+        return None
+    hi, lows = ids[0] >> 16, [v & 0xFFFF for v in ids]
+    if mode == 2:
+        body, card = lows, len(lows)
+    elif mode == 4:
+        runs = []
+        for v in lows:
+            if runs and runs[-1][1] + 1 == v:
+                runs[-1][1] = v
+            else:
+                runs.append([v, v])
+        body, card = [x for r in runs for x in r], 2 * len(runs)
+    else:
+        words = [0] * (lows[-1] // 16 + 1)
+        for v in lows:
+            words[v >> 4] |= 1 << (v & 15)
+        body, card = words, len(lows)
+    size = 3 + len(body)
+    alloc = next((a for a in (8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096) if a >= size), None)  # blocks grow in powers of two
+    if alloc is None or card > 0xFFFF:
+        return None
+    return struct.pack("<%dH" % alloc, *([(alloc << 3) | mode, card, hi] + body + [0] * (alloc - size)))
+
+
+def _rewrite(src, dst, remap, tiny=False):
     """Copies an .rtsk file, renaming the colour ids of the global and local sets with `remap` and writing every set that needs a
     Roaring payload in the run-container layout. Returns (payloads, run containers, containers, payloads with >= 4 containers)."""
     data = open(src, "rb").read()
@@ -103,6 +130,11 @@ def _rewrite(src, dst, remap):
             out.extend(struct.pack("<Q", (sum(1 << v for v in ids) << 3) | 1)); return
         if len(ids) == 1:
             out.extend(struct.pack("<Q", (ids[0] << 3) | 2)); return
+        if tiny and colour:
+            t = _encode_tiny(ids, (0, 2, 4)[st[0] % 3])
+            if t is not None:
+                st[0] += 1; st[1 + st[0] % 3] += 1
+                out.extend(struct.pack("<Q", 0)); out.extend(t); return
         payload, n_run, n_cont = _encode_12347(ids, (lambda ci: ci % 3 == 0) if colour else (lambda ci: False))
         st[0] += 1; st[1] += n_run; st[2] += n_cont; st[3] += 1 if n_cont >= 4 else 0
         out.extend(struct.pack("<Q", (len(payload) << 3) | 3)); out.extend(payload)
@@ -161,16 +193,38 @@ def test_run_container_payloads_load_like_the_plain_ones(ds_snps_rich, tmp_path)
     assert pg2.correct_batch(seqs, quals) == want
 
 
-def test_tinybitmap_stream_is_refused_loudly(ds_small, tmp_path):
-    """PairID flag 0 = Bifrost TinyBitmap::write payload (src/PairID.cpp:1158-1167): layout unverifiable without Bifrost. The loader
-    must name the problem instead of mis-parsing the rest of the file."""
+def test_tinybitmap_streams_load_like_roaring_ones(ds_snps_rich, tmp_path):
+    """PairID flag 0 = Bifrost TinyBitmap::write payload (src/PairID.cpp:1158-1167), the form every set of more than one id takes
+    in a reference-written index until it outgrows a TinyBitmap (PairID::add, src/PairID.cpp:599-637). Bifrost is absent, so the
+    layout is the published one as assumed in rtsk_io.hpp [A8] -- unverified against a reference-written file. The same index with
+    its colour sets re-encoded as TinyBitmaps (bitmap, list and run-list modes) must give the same sets and the same corrected reads."""
+    fa, rt = ds_snps_rich + ".index.k31.fasta.gz", ds_snps_rich + ".index.k31.rtsk"
+    rt2 = str(tmp_path / "tiny.rtsk")
+    n_tiny, a, b, c = _rewrite(rt, rt2, lambda v: v, tiny=True)
+    assert n_tiny > 300 and min(a, b, c) > 50  # all three modes
+    og1, og2 = op.Graph(fa, rt, 31), op.Graph(fa, rt2, 31)
+    pg2 = api.Graph(fa, rt2, 31, device=0, lib_path=SIM_LIB)
+    flat = _flat_colours(pg2)
+    for u in range(0, og2.n_unitigs, 3):
+        x, y = og1.unitig(u), og2.unitig(u)
+        assert x["local"] == y["local"] == flat["local"](u)
+        if x["global_id"] >= 0:
+            assert og1.global_set(x["global_id"]) == og2.global_set(y["global_id"]) == flat["global"](u)
+    reads = op.read_fastq(ds_snps_rich + ".lr.fq")[:6]
+    seqs, quals = [r[1] for r in reads], [r[2] for r in reads]
+    assert pg2.correct_batch(seqs, quals) == og1.correct_batch(seqs, quals, threads=4)[0]
+
+
+def test_malformed_tinybitmap_is_refused_loudly(ds_small, tmp_path):
+    """A flag-0 stream that does not fit the assumed layout must name the problem instead of mis-parsing the rest of the file."""
     rt = ds_small + ".index.k31.rtsk"
     data = bytearray(open(rt, "rb").read())
-    data[32:40] = struct.pack("<Q", 0)  # first record's global PairID word -> flag 0
+    data[32:40] = struct.pack("<Q", 0)  # first record's global PairID word -> flag 0; what follows is not a TinyBitmap
+    data[40:42] = struct.pack("<H", (5000 << 3) | 6)  # impossible size and mode
     bad = str(tmp_path / "flag0.rtsk")
     open(bad, "wb").write(bytes(data))
     try:
         api.Graph(ds_small + ".index.k31.fasta.gz", bad, 31, upload=False)
-        assert False, "flag-0 stream accepted"
+        assert False, "malformed flag-0 stream accepted"
     except api.RtkError as e:
-        assert "TinyBitmap" in str(e)
+        assert "TinyBitmap" in str(e) and "A8" in str(e)
