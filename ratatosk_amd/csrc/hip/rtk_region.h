@@ -1051,68 +1051,59 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
     RTK_FINE_LAP(1)
     const uint32_t cov = 30;
     for (uint32_t j = 0; j < nsp; ++j) { const uint32_t cd = static_cast<uint32_t>(keys[j] >> 32); vals[j] = cd < cov ? cd : cov; } // remaining quota (p_spid.second)
-    // position unions and their pairwise intersections
-    // set[3] = pos0 = a0|a3, set[4] = pos1 = a1|a4, set[5] = pos2 = a2|a5
-    uint32_t n_pos[3];
-    for (int p = 0; p < 3; ++p) { if (a_n[p] + a_n[p + 3] > s.set_cap) { rtk_fail_ovf(s, 9); return 0; } n_pos[p] = rtk_set_union(A(p), a_n[p], A(p + 3), a_n[p + 3], s.set[3 + p], s.set[9]); }
-    // park a01, a12, a02, nobranch, nobranch_cpy in the arena
-    uint64_t o01, o12, o02, onb, onbc, oi3, oi2, obr; uint32_t n01, n12, n02, nnb, nnbc, ni3 = 0, ni2 = 0, nbr = 0;
-    auto park = [&](const uint32_t* src, uint32_t n, uint64_t* off) { *off = rtk_arena_alloc(s, 2, 4ull * n + 4); if (!rtk_failed(s)) rtk_wcopy(s.arena[2] + *off, src, 4ull * n); };
-    auto P = [&](uint64_t off) -> uint32_t* { return reinterpret_cast<uint32_t*>(s.arena[2] + off); };
-    n01 = rtk_set_inter(s.set[3], n_pos[0], s.set[4], n_pos[1], s.set[6]); park(s.set[6], n01, &o01);
-    n12 = rtk_set_inter(s.set[4], n_pos[1], s.set[5], n_pos[2], s.set[6]); park(s.set[6], n12, &o12);
-    n02 = rtk_set_inter(s.set[3], n_pos[0], s.set[5], n_pos[2], s.set[6]); park(s.set[6], n02, &o02);
-    if (rtk_failed(s)) return 0;
-    { // nobranch = a3|a4|a5
-        if (a_n[3] + a_n[4] + a_n[5] > s.set_cap) { rtk_fail_ovf(s, 9); return 0; }
-        const uint32_t t = rtk_set_union(A(3), a_n[3], A(4), a_n[4], s.set[6], s.set[9]);
-        nnb = rtk_set_union(s.set[6], t, A(5), a_n[5], s.set[7], s.set[9]);
-        park(s.set[7], nnb, &onb); park(s.set[7], nnb, &onbc); nnbc = nnb;
-    }
+    // Set expressions of src/Correction.cpp:233-275,300-352 on immutable operands: a result is either one of its operands (union with
+    // / difference by the empty set -- the usual case: most regions have no weak anchor, so the whole "middle" side is empty) or a
+    // fresh slice of the DFS-level arena; nothing is copied to be kept, and a class only computes what it reads.
+    struct SetRef { const uint32_t* p; uint32_t n; };
+    const SetRef EMPTY = { reinterpret_cast<const uint32_t*>(s.arena[2].get()), 0u };
+    auto alloc = [&](uint32_t n) -> uint32_t* { const uint64_t off = rtk_arena_alloc(s, 2, 4ull * n + 4); return rtk_failed(s) ? nullptr : reinterpret_cast<uint32_t*>(s.arena[2] + off); };
+    auto Un = [&](SetRef a, SetRef b) -> SetRef {
+        if (!a.n) return b; if (!b.n) return a;
+        if (a.n + b.n > s.set_cap) { rtk_fail_ovf(s, 9); return EMPTY; } // set[9] holds b \ a
+        uint32_t* o = alloc(a.n + b.n); if (!o) return EMPTY;
+        SetRef r; r.p = o; r.n = rtk_set_union(a.p, a.n, b.p, b.n, o, s.set[9]); return r; };
+    auto In = [&](SetRef a, SetRef b) -> SetRef {
+        if (!a.n || !b.n) return EMPTY;
+        if (a.n > b.n) { const SetRef t = a; a = b; b = t; } // walk the smaller set, search the larger one
+        uint32_t* o = alloc(a.n); if (!o) return EMPTY;
+        SetRef r; r.p = o; r.n = rtk_set_inter(a.p, a.n, b.p, b.n, o); return r; };
+    auto Di = [&](SetRef a, SetRef b) -> SetRef {
+        if (!a.n) return EMPTY; if (!b.n) return a;
+        uint32_t* o = alloc(a.n); if (!o) return EMPTY;
+        SetRef r; r.p = o; r.n = rtk_set_diff(a.p, a.n, b.p, b.n, o); return r; };
+    SetRef a[6]; for (int i = 0; i < 6; ++i) { a[i].p = a_ptr[i]; a[i].n = a_n[i]; }
+    const SetRef pos0 = Un(a[0], a[3]), pos1 = Un(a[1], a[4]), pos2 = Un(a[2], a[5]);
+    const SetRef a01 = In(pos0, pos1), a12 = In(pos1, pos2), a02 = In(pos0, pos2);
+    const SetRef nobranch_all = Un(Un(a[3], a[4]), a[5]);
     if (rtk_failed(s)) return 0;
     RTK_FINE_LAP(2)
     uint32_t n_all = 0; int allb = 0; // all_pids lives in set[0] (while it is being built: in set[allb])
     uint32_t nb_unselected = nsp;
-    uint64_t o_prev2 = 0; uint32_t n_prev2 = 0; // a_pid2 of the previous class
+    SetRef nobranch = nobranch_all, branching = EMPTY, i3 = EMPTY, i2 = EMPTY, prev2 = EMPTY; // prev2: a_pid2 of the previous class
+    bool have_i3 = false, have_i2 = false;
     for (int i = 5; i >= 0 && !rtk_failed(s); --i) {
         if (nb_unselected == 0) break;
-        uint32_t n2 = 0; // a_pid2[i] -> set[8]
-        if (i == 5) {
-            ni3 = rtk_set_inter(P(o01), n01, P(o12), n12, s.set[6]); park(s.set[6], ni3, &oi3);
-            n2 = rtk_set_inter(P(onb), nnb, P(oi3), ni3, s.set[8]);
-        } else if (i == 4) {
-            if (n01 + n12 + n02 > s.set_cap) { rtk_fail_ovf(s, 9); break; }
-            const uint32_t t = rtk_set_union(P(o01), n01, P(o12), n12, s.set[6], s.set[9]);
-            ni2 = rtk_set_union(s.set[6], t, P(o02), n02, s.set[7], s.set[9]); park(s.set[7], ni2, &oi2);
-            nnb = rtk_set_diff(P(onb), nnb, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(onb), s.set[6], 4ull * nnb);
-            n2 = rtk_set_inter(P(onb), nnb, P(oi2), ni2, s.set[8]);
-        } else if (i == 3) {
-            nnb = rtk_set_diff(P(onb), nnb, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(onb), s.set[6], 4ull * nnb);
-            n2 = nnb; rtk_wcopy(s.set[8], P(onb), 4ull * nnb);
-        } else if (i == 2) {
-            if (a_n[0] + a_n[1] + a_n[2] > s.set_cap) { rtk_fail_ovf(s, 9); break; }
-            const uint32_t t = rtk_set_union(A(0), a_n[0], A(1), a_n[1], s.set[6], s.set[9]);
-            const uint32_t t2 = rtk_set_union(s.set[6], t, A(2), a_n[2], s.set[7], s.set[9]);
-            nbr = rtk_set_diff(s.set[7], t2, P(onbc), nnbc, s.set[6]); park(s.set[6], nbr, &obr);
-            n2 = rtk_set_inter(P(obr), nbr, P(oi3), ni3, s.set[8]);
-        } else if (i == 1) {
-            nbr = rtk_set_diff(P(obr), nbr, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(obr), s.set[6], 4ull * nbr);
-            n2 = rtk_set_inter(P(obr), nbr, P(oi2), ni2, s.set[8]);
-        } else {
-            nbr = rtk_set_diff(P(obr), nbr, P(o_prev2), n_prev2, s.set[6]); rtk_wcopy(P(obr), s.set[6], 4ull * nbr);
-            n2 = nbr; rtk_wcopy(s.set[8], P(obr), 4ull * nbr);
-        }
+        if ((i == 5 || i == 2) && !have_i3) { i3 = In(a01, a12); have_i3 = true; }
+        if ((i == 4 || i == 1) && !have_i2) { i2 = Un(Un(a01, a12), a02); have_i2 = true; }
+        SetRef a2 = EMPTY; // a_pid2[i]
+        if (i == 5) a2 = In(nobranch, i3);
+        else if (i == 4) { nobranch = Di(nobranch, prev2); a2 = In(nobranch, i2); }
+        else if (i == 3) { nobranch = Di(nobranch, prev2); a2 = nobranch; }
+        else if (i == 2) { branching = Di(Un(Un(a[0], a[1]), a[2]), nobranch_all); a2 = In(branching, i3); }
+        else if (i == 1) { branching = Di(branching, prev2); a2 = In(branching, i2); }
+        else { branching = Di(branching, prev2); a2 = branching; }
+        const uint32_t n2 = a2.n;
         if (rtk_failed(s)) break;
-        park(s.set[8], n2, &o_prev2); n_prev2 = n2; // a_pid2[i] is needed by the next class
+        prev2 = a2; // a_pid2[i] is needed by the next class
         RTK_FINE_LAP(3)
         if (n2 != 0) {
             nb_unselected = 0;
-            uint32_t ncur = n2; int curb = 8; // curr_pid in set[8] / set[7] (ping-pong)
+            const uint32_t* cur_p = a2.p; uint32_t ncur = n2; int curb = 8; // curr_pid: a_pid2[i] itself until the first selection, then set[7] / set[8] (ping-pong)
             for (uint32_t j = 0; j < nsp && !rtk_failed(s); ++j) {
                 const uint32_t u = static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull);
                 int quota = static_cast<int>(vals[j]);
                 bool touch = false;
-                if (quota > 0) { touch = (i == 0 || rtk_shared_with_set(g, u, s.set[curb], ncur, 1) >= 1); RTK_FINE_LAP(4) }
+                if (quota > 0) { touch = (i == 0 || rtk_shared_with_set(g, u, cur_p, ncur, 1) >= 1); RTK_FINE_LAP(4) }
                 if (touch) {
                     const uint32_t min_cov = g.card[u] < cov ? g.card[u] : cov;
                     const uint32_t sh = rtk_shared_with_set(g, u, s.set[allb], n_all, min_cov);
@@ -1121,12 +1112,13 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
                     if (quota > 0) {
                         const uint32_t all_card = n_all;
                         // pid = (global & curr) | (local & curr), truncated to its `quota` lowest ids
-                        const uint32_t npid = rtk_first_shared(g, u, s.set[curb], ncur, static_cast<uint32_t>(quota), s.set[4]);
+                        const uint32_t npid = rtk_first_shared(g, u, cur_p, ncur, static_cast<uint32_t>(quota), s.set[4]);
                         if (n_all + npid > s.set_cap) { rtk_fail_ovf(s, 9); break; }
                         const uint32_t nn = rtk_set_union(s.set[allb], n_all, s.set[4], npid, s.set[allb ^ 3], s.set[9]);
                         allb ^= 3; n_all = nn; // all_pids alternates between set[0] and set[3]; it is moved to set[0] once, at the end
                         const int nb2 = curb == 8 ? 7 : 8;
-                        ncur = rtk_set_diff(s.set[curb], ncur, s.set[4], npid, s.set[nb2]); curb = nb2;
+                        if (ncur > s.set_cap) { rtk_fail_ovf(s, 9); break; }
+                        ncur = rtk_set_diff(cur_p, ncur, s.set[4], npid, s.set[nb2]); curb = nb2; cur_p = s.set[nb2];
                         const int gained = static_cast<int>(n_all - all_card);
                         quota -= gained < quota ? gained : quota;
                         RTK_FINE_LAP(6)
