@@ -1,0 +1,214 @@
+// chooseColors (reference: src/Correction.cpp:215-429) on bit vectors, for the regions that make up nearly all of a batch: the colour
+// sets of the anchors around one weak region hold a few hundred distinct pair ids together (measured on configs[1]: < 512 in 90 % of
+// the calls). Those ids are sorted once into a small universe kept in LDS; every set of the algorithm -- the six anchor classes, their
+// unions / intersections / differences, curr_pid, all_pids -- is then ONE 64-bit word per lane (4096 bits), the whole class loop runs
+// in registers (OR / AND / ANDN, popcount + wave sum, "the quota lowest ids" = a prefix count), and all_pids is expanded back into a
+// sorted id list at the end. Same selections as the general sorted-array version in rtk_region.h, which stays the fallback for
+// larger universes (returns RTK_NONE32 then). Bit order = id order, so "lowest ids first" is "lowest bits first".
+#ifndef RTK_COLOURS_H
+#define RTK_COLOURS_H
+
+#define RTK_CB_MAX_IDS 1920u   // ids gathered from all anchors (with repeats); universe (u32) + 64 scatter words share the 8 KB LDS buffer
+#define RTK_CB_MAX_SLOTS 24u   // side-list entries whose bit vectors are kept
+
+#ifdef RTK_SIM
+struct RtkBM { uint64_t w[64]; };
+inline RtkBM rtk_bm_zero() { RtkBM r; for (int i = 0; i < 64; ++i) r.w[i] = 0; return r; }
+inline RtkBM operator|(const RtkBM& a, const RtkBM& b) { RtkBM r; for (int i = 0; i < 64; ++i) r.w[i] = a.w[i] | b.w[i]; return r; }
+inline RtkBM operator&(const RtkBM& a, const RtkBM& b) { RtkBM r; for (int i = 0; i < 64; ++i) r.w[i] = a.w[i] & b.w[i]; return r; }
+inline RtkBM rtk_bm_andn(const RtkBM& a, const RtkBM& b) { RtkBM r; for (int i = 0; i < 64; ++i) r.w[i] = a.w[i] & ~b.w[i]; return r; }
+inline uint32_t rtk_bm_count(const RtkBM& a) { uint32_t c = 0; for (int i = 0; i < 64; ++i) c += static_cast<uint32_t>(__builtin_popcountll(a.w[i])); return c; }
+inline RtkBM rtk_bm_lowest(const RtkBM& a, uint32_t q) { RtkBM r = rtk_bm_zero(); for (int i = 0; i < 64 && q; ++i) { uint64_t x = a.w[i]; while (x && q) { const uint64_t b = x & (~x + 1ull); r.w[i] |= b; x ^= b; --q; } } return r; }
+inline RtkBM rtk_bm_load(const uint64_t* p) { RtkBM r; for (int i = 0; i < 64; ++i) r.w[i] = p[i]; return r; }
+inline void rtk_bm_store(uint64_t* p, const RtkBM& a) { for (int i = 0; i < 64; ++i) p[i] = a.w[i]; }
+#else
+typedef uint64_t RtkBM; // word `lane` of a 4096-bit vector
+RTK_DEV RtkBM rtk_bm_zero() { return 0ull; }
+RTK_DEV RtkBM rtk_bm_andn(RtkBM a, RtkBM b) { return a & ~b; }
+RTK_DEV uint32_t rtk_bm_count(RtkBM a) { return static_cast<uint32_t>(rtk_u(rtk_wave_sum(rtk_popc(a)))); }
+RTK_DEV RtkBM rtk_bm_lowest(RtkBM a, uint32_t q) { // the q lowest set bits of the 4096-bit vector
+    int total; const int before = rtk_wave_excl_scan(rtk_popc(a), &total);
+    int keep = static_cast<int>(q) - before; const int mine = rtk_popc(a);
+    keep = keep < 0 ? 0 : (keep > mine ? mine : keep);
+    uint64_t rest = a; for (int i = 0; i < keep; ++i) rest &= rest - 1ull; // a without its `keep` lowest bits
+    return a & ~rest;
+}
+RTK_DEV RtkBM rtk_bm_load(const uint64_t* p) { return p[rtk_lane()]; }
+RTK_DEV void rtk_bm_store(uint64_t* p, RtkBM a) { p[rtk_lane()] = a; }
+#endif
+
+// bit vector of the ids of a sorted set inside the universe uni[0..U)
+RTK_DEV RtkBM rtk_bm_from_ids(const uint32_t* uni, uint32_t U, uint64_t* scatter, const uint32_t* ids, uint32_t n) {
+#ifdef RTK_SIM
+    (void)scatter;
+    RtkBM r = rtk_bm_zero();
+    for (uint32_t i = 0; i < n; ++i) { const uint32_t x = rtk_lower_bound(uni, U, ids[i]); r.w[x >> 6] |= 1ull << (x & 63u); }
+    return r;
+#else
+    scatter[rtk_lane()] = 0ull;
+    __syncthreads();
+    for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) {
+        const uint32_t id = ids[i];
+        uint32_t lo = 0, hi = U; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (uni[mid] < id) lo = mid + 1; else hi = mid; }
+        atomicOr(reinterpret_cast<unsigned long long*>(scatter) + (lo >> 6), 1ull << (lo & 63u));
+    }
+    __syncthreads();
+    return scatter[rtk_lane()];
+#endif
+}
+
+// Returns |all_pids| (ids in s.set[0]), or RTK_NONE32 when the anchors' sets do not fit the small universe (caller falls back).
+RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
+    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
+    RegionScratch& s = *c.sc;
+    const GraphView& g = c.g;
+    const SideList* sides[3] = {&side_w, &side_e, &side_s};
+    const uint32_t n_slots = side_w.n + side_e.n + side_s.n;
+    if (n_slots == 0 || n_slots > RTK_CB_MAX_SLOTS || s.set_cap < 2 * RTK_CB_MAX_IDS + 64u * 4u * RTK_CB_MAX_SLOTS || s.list_cap < 2 * RTK_CB_MAX_SLOTS) return RTK_NONE32;
+    // how many ids in all (global + local of every side unitig)
+    uint32_t T = 0;
+    for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i) {
+        const uint32_t u = sides[sd]->u[i]; const int32_t gi = g.gid[u];
+        T += static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]) + (gi >= 0 ? static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]) : 0u);
+        if (T > RTK_CB_MAX_IDS) return RTK_NONE32;
+    }
+    // candidate anchors: cardinality >= min_cov_vertices, ordered by (cardinality, unitig id) [D1]; the value carried through the sort is
+    // the anchor's slot (its position in the concatenated side lists: middle, right, left)
+    uint64_t* keys = s.list[4]; uint64_t* vals = s.list[3]; uint64_t* slot_of = s.list[5];
+    uint32_t nsp = 0;
+    { uint32_t slot = 0;
+      for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i, ++slot) {
+        const uint32_t u = sides[sd]->u[i];
+        if (g.card[u] < c.o.min_cov_vertices) continue;
+        bool dup = false; for (uint32_t j0 = 0; j0 < nsp && !dup; j0 += RTK_WAVE) { const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane()); dup = rtk_ballot(j < nsp && static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull) == u) != 0ull; }
+        if (dup) continue;
+        keys[nsp] = (static_cast<uint64_t>(g.card[u]) << 32) | u; vals[nsp] = slot; ++nsp; rtk_sync();
+      } }
+    rtk_sort_pairs(keys, vals, nsp); // (uses the LDS buffer: before the universe moves in)
+    const uint32_t cov = 30;
+    for (uint32_t j = static_cast<uint32_t>(rtk_lane()); j < nsp; j += RTK_WAVE) { slot_of[j] = vals[j]; const uint32_t cd = static_cast<uint32_t>(keys[j] >> 32); vals[j] = cd < cov ? cd : cov; } // remaining quota (p_spid.second)
+    rtk_sync();
+    // ---- universe: every id of every side unitig, sorted, duplicates dropped ----
+    uint32_t* gathered = s.set[1];
+    { uint32_t at = 0;
+      for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i) {
+        const uint32_t u = sides[sd]->u[i]; const int32_t gi = g.gid[u];
+        const uint32_t nl = static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]); const uint32_t* pl = g.col + g.loff[u];
+        for (uint32_t x = static_cast<uint32_t>(rtk_lane()); x < nl; x += RTK_WAVE) gathered[at + x] = pl[x];
+        at += nl;
+        if (gi >= 0) { const uint32_t ng = static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]); const uint32_t* pg = g.col + g.goff[gi];
+                       for (uint32_t x = static_cast<uint32_t>(rtk_lane()); x < ng; x += RTK_WAVE) gathered[at + x] = pg[x]; at += ng; }
+      } }
+    rtk_sync();
+    s.cnt[1] += T;
+    uint32_t U = 0;
+#ifdef RTK_SIM
+    uint32_t* const uni = s.set[1] + RTK_CB_MAX_IDS; uint64_t* const scatter = nullptr;
+    { for (uint32_t i = 0; i < T; ++i) uni[i] = gathered[i];
+      std::sort(uni, uni + T);
+      for (uint32_t i = 0; i < T; ++i) if (i == 0 || uni[i] != uni[i - 1]) uni[U++] = uni[i]; }
+#else
+    uint32_t* const uni = rtk_lds_set_buf(); uint64_t* const scatter = reinterpret_cast<uint64_t*>(uni + RTK_CB_MAX_IDS);
+    { uint32_t P = 64; while (P < T) P <<= 1; // bitonic sort of the padded ids in LDS
+      for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < P; i += RTK_WAVE) uni[i] = i < T ? gathered[i] : 0xFFFFFFFFu;
+      __syncthreads();
+      for (uint32_t kk = 2; kk <= P; kk <<= 1) for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+          for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < P; i += RTK_WAVE) {
+              const uint32_t l = i ^ j;
+              if (l > i) { const uint32_t a = uni[i], b = uni[l]; if ((a > b) == ((i & kk) == 0)) { uni[i] = b; uni[l] = a; } }
+          }
+          __syncthreads();
+      }
+      for (uint32_t i0 = 0; i0 < T; i0 += RTK_WAVE) { // forward compaction of the first elements of the runs
+          const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+          uint32_t x = 0; bool keep = false;
+          if (i < T) { x = uni[i]; keep = (i == 0) || (uni[i - 1] != x); }
+          __syncthreads();
+          const uint64_t bal = rtk_ballot(keep);
+          if (keep) uni[U + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)))] = x;
+          U += static_cast<uint32_t>(rtk_popc(bal));
+          __syncthreads();
+      } }
+#endif
+    // ---- bit vectors of every side unitig: global part, local part (kept in scratch: 2 x 512 B per slot) ----
+    uint64_t* const store = reinterpret_cast<uint64_t*>(s.set[2].get());
+    { uint32_t slot = 0;
+      for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i, ++slot) {
+        const uint32_t u = sides[sd]->u[i]; const int32_t gi = g.gid[u];
+        const RtkBM bl = rtk_bm_from_ids(uni, U, scatter, g.col + g.loff[u], static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]));
+        rtk_bm_store(store + (2ull * slot) * 64ull, bl);
+        const RtkBM bg = gi >= 0 ? rtk_bm_from_ids(uni, U, scatter, g.col + g.goff[gi], static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi])) : rtk_bm_zero();
+        rtk_bm_store(store + (2ull * slot + 1ull) * 64ull, bg);
+      } }
+    rtk_sync();
+    // ---- the six anchor classes: side (middle, right, left) x branching / non-branching; G2: the global set alone when there is one ----
+    RtkBM a[6];
+    for (int sh = 0; sh < 6; ++sh) {
+        RtkBM acc = rtk_bm_zero();
+        uint32_t slot = (sh % 3 == 0) ? 0u : (sh % 3 == 1 ? side_w.n : side_w.n + side_e.n);
+        const SideList& sl = *sides[sh % 3]; const uint8_t want_nb = sh >= 3 ? 1 : 0;
+        for (uint32_t i = 0; i < sl.n; ++i, ++slot) {
+            if (sl.nb[i] != want_nb) continue;
+            const bool has_global = g.gid[sl.u[i]] >= 0;
+            acc = acc | rtk_bm_load(store + (2ull * slot + (has_global ? 1ull : 0ull)) * 64ull);
+        }
+        a[sh] = acc;
+    }
+    const RtkBM pos0 = a[0] | a[3], pos1 = a[1] | a[4], pos2 = a[2] | a[5];
+    const RtkBM a01 = pos0 & pos1, a12 = pos1 & pos2, a02 = pos0 & pos2;
+    const RtkBM nobranch_all = a[3] | a[4] | a[5];
+    const RtkBM i3 = a01 & a12, i2 = a01 | a12 | a02;
+    RtkBM nobranch = nobranch_all, branching = rtk_bm_zero(), prev2 = rtk_bm_zero(), all = rtk_bm_zero();
+    uint32_t nb_unselected = nsp;
+    for (int i = 5; i >= 0; --i) {
+        if (nb_unselected == 0) break;
+        RtkBM a2;
+        if (i == 5) a2 = nobranch & i3;
+        else if (i == 4) { nobranch = rtk_bm_andn(nobranch, prev2); a2 = nobranch & i2; }
+        else if (i == 3) { nobranch = rtk_bm_andn(nobranch, prev2); a2 = nobranch; }
+        else if (i == 2) { branching = rtk_bm_andn(a[0] | a[1] | a[2], nobranch_all); a2 = branching & i3; }
+        else if (i == 1) { branching = rtk_bm_andn(branching, prev2); a2 = branching & i2; }
+        else { branching = rtk_bm_andn(branching, prev2); a2 = branching; }
+        prev2 = a2;
+        if (rtk_bm_count(a2) == 0) continue;
+        nb_unselected = 0;
+        RtkBM curr = a2;
+        for (uint32_t j = 0; j < nsp; ++j) {
+            const uint32_t u = static_cast<uint32_t>(rtk_ld(keys + j) & 0xFFFFFFFFull);
+            int quota = static_cast<int>(rtk_ld(vals + j));
+            if (quota > 0) {
+                const uint64_t slot = rtk_ld(slot_of + j);
+                const RtkBM cu = rtk_bm_load(store + (2ull * slot) * 64ull) | rtk_bm_load(store + (2ull * slot + 1ull) * 64ull); // all colours of u
+                if (i == 0 || rtk_bm_count(cu & curr) >= 1) {
+                    const uint32_t cd = rtk_ld(rtk_u(g.card) + u); const uint32_t min_cov = cd < cov ? cd : cov;
+                    const uint32_t sh = rtk_bm_count(cu & all);
+                    quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
+                    if (quota > 0) {
+                        const uint32_t all_card = rtk_bm_count(all);
+                        const RtkBM pid = rtk_bm_lowest(cu & curr, static_cast<uint32_t>(quota));
+                        all = all | pid; curr = rtk_bm_andn(curr, pid);
+                        const int gained = static_cast<int>(rtk_bm_count(all) - all_card);
+                        quota -= gained < quota ? gained : quota;
+                    }
+                }
+            }
+            vals[j] = static_cast<uint64_t>(quota);
+            nb_unselected += quota > 0 ? 1u : 0u;
+        }
+        rtk_sync();
+    }
+    // ---- all_pids back to a sorted id list in set[0] ----
+    const uint32_t n_all = rtk_bm_count(all);
+    if (n_all > s.set_cap) { rtk_fail_ovf(s, 9); return 0; }
+    uint32_t* out = s.set[0];
+#ifdef RTK_SIM
+    { uint32_t at = 0; for (uint32_t w = 0; w < 64; ++w) { uint64_t x = all.w[w]; while (x) { const int b = __builtin_ctzll(x); out[at++] = uni[64u * w + static_cast<uint32_t>(b)]; x &= x - 1ull; } } }
+#else
+    { int total; uint32_t at = static_cast<uint32_t>(rtk_wave_excl_scan(rtk_popc(all), &total)); uint64_t x = all;
+      while (x) { const int b = __builtin_ctzll(x); out[at++] = uni[64u * static_cast<uint32_t>(rtk_lane()) + static_cast<uint32_t>(b)]; x &= x - 1ull; } }
+#endif
+    rtk_sync();
+    return n_all;
+}
+
+#endif

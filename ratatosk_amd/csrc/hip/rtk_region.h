@@ -997,14 +997,21 @@ RTK_DEV uint32_t rtk_rs_union(RegionScratch& s, int a, uint32_t na, const uint32
     return rtk_set_union(s.set[a], na, b, nb, s.set[out], s.set[9]);
 }
 
+#include "rtk_colours.h"
+
 // Computes all_pids into set[0]; returns its size. Uses set[1..9] as temporaries.
 RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
     const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
     RegionScratch& s = *c.sc;
     const GraphView& g = c.g;
+    unsigned long long tf = rtk_clock();
+    { // the common case: all the anchors' ids fit a 4096-bit universe -> the whole selection in registers (rtk_colours.h)
+        const uint32_t r = rtk_u(rtk_choose_colors_bits(c, side_s, side_e, side_w));
+        if (r != RTK_NONE32) { s.fine[0] += rtk_clock() - tf; return rtk_failed(s) ? 0 : r; }
+    }
     // a_pid[shift], shift = side index (0 middle, 1 right, 2 left) + 3 * nonbranching: built one after the other into the arena (level 2 is free here)
     s.top[2] = 0;
-    unsigned long long tf = rtk_clock();
+    tf = rtk_clock();
 #define RTK_FINE_LAP(i) { const unsigned long long tn_ = rtk_clock(); s.fine[i] += tn_ - tf; tf = tn_; }
     const SideList* sides[3] = {&side_w, &side_e, &side_s};
     const uint32_t* a_ptr[6]; uint32_t a_n[6];
@@ -1024,6 +1031,9 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
             if (n_src == 0) { one = src; n = ns; n_src = 1; continue; }
             if (n_src == 1) { if (n > s.set_cap) { rtk_fail_ovf(s, 9); break; } rtk_wcopy(s.set[cur], one, 4ull * n); rtk_sync(); }
             n = rtk_rs_union(s, cur, n, src, ns, cur ^ 3); cur ^= 3; ++n_src; // ping-pong between set[1] and set[2]
+#ifdef RTK_SIM
+            rtk_sim_site_stat[29][4] += 1;
+#endif
         }
         a_n[sh] = n;
         if (n_src <= 1) a_ptr[sh] = n_src ? one : reinterpret_cast<const uint32_t*>(s.arena[2].get());
@@ -1034,6 +1044,10 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
         }
     }
     if (rtk_failed(s)) return 0;
+#ifdef RTK_SIM
+    { std::atomic<unsigned long long>* t = rtk_sim_site_stat[29]; t[0] += 1; t[1] += side_s.n; t[2] += side_e.n; t[3] += side_w.n; for (int i = 0; i < 6; ++i) rtk_sim_site_stat[30][i] += a_n[i];
+      unsigned long long tot = 0; for (int i = 0; i < 6; ++i) tot += a_n[i]; int b = 0; while (b < 7 && (256ull << b) <= tot) ++b; rtk_sim_site_stat[31][b] += 1; }
+#endif
     RTK_FINE_LAP(0)
     auto A = [&](int i) -> const uint32_t* { return a_ptr[i]; };
     // candidate anchors: cardinality >= min_cov_vertices, ordered by (cardinality, unitig id) [D1]
@@ -1104,6 +1118,9 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
                 int quota = static_cast<int>(vals[j]);
                 bool touch = false;
                 if (quota > 0) { touch = (i == 0 || rtk_shared_with_set(g, u, cur_p, ncur, 1) >= 1); RTK_FINE_LAP(4) }
+#ifdef RTK_SIM
+                rtk_sim_site_stat[29][5] += 1; if (touch) rtk_sim_site_stat[29][6] += 1;
+#endif
                 if (touch) {
                     const uint32_t min_cov = g.card[u] < cov ? g.card[u] : cov;
                     const uint32_t sh = rtk_shared_with_set(g, u, s.set[allb], n_all, min_cov);
@@ -1119,6 +1136,9 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
                         const int nb2 = curb == 8 ? 7 : 8;
                         if (ncur > s.set_cap) { rtk_fail_ovf(s, 9); break; }
                         ncur = rtk_set_diff(cur_p, ncur, s.set[4], npid, s.set[nb2]); curb = nb2; cur_p = s.set[nb2];
+#ifdef RTK_SIM
+                        rtk_sim_site_stat[29][7] += 1; rtk_sim_site_stat[30][6] += ncur; rtk_sim_site_stat[30][7] += n_all;
+#endif
                         const int gained = static_cast<int>(n_all - all_card);
                         quota -= gained < quota ? gained : quota;
                         RTK_FINE_LAP(6)
