@@ -10,12 +10,25 @@
 #include <map>
 #include <stdexcept>
 #include <cstdlib>
+#include <functional>
+#include <thread>
 
 #include "../common/fastx.hpp"
 #include "../common/kmer.hpp"
 #include "../common/rtsk_io.hpp"
 
 namespace rtk {
+
+// n_threads of rtk_graph_load: independent slices [lo, hi) of a range on std::threads (unitigs are independent for the 2-bit packing,
+// the half-k-mer pairs, the adjacency lookups; the k-mer table is filled with compare-and-swap on the key word of a slot)
+static void parallel_slices(size_t n, int n_threads, const std::function<void(size_t, size_t, int)>& fn) {
+    int nt = n_threads < 1 ? 1 : n_threads; if (static_cast<size_t>(nt) > n) nt = n ? static_cast<int>(n) : 1;
+    if (nt == 1) { fn(0, n, 0); return; }
+    std::vector<std::thread> th; std::vector<std::string> err(nt);
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { try { fn(n * t / nt, n * (t + 1) / nt, t); } catch (const std::exception& e) { err[t] = e.what(); } });
+    for (size_t t = 0; t < th.size(); ++t) th[t].join();
+    for (int t = 0; t < nt; ++t) if (!err[t].empty()) throw std::runtime_error(err[t]);
+}
 
 GraphView FlatGraph::view() const {
     GraphView v;
@@ -33,7 +46,7 @@ uint64_t FlatGraph::bytes() const {
     return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size() + hx.size() + hxl.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
-void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int /*n_threads*/) {
+void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads) {
     k = k_;
     if (k < 3 || k > RTK_MAX_K || !(k & 1)) throw std::runtime_error("k must be odd and <= 31 (pass-1 scope; k=63 is a later row)");
     // ---- unitigs ----
@@ -55,16 +68,18 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     for (size_t u = 0; u < n; ++u) uoff[u + 1] = uoff[u] + seqs[u].size();
     useq.assign((uoff[n] + 31) / 32 + 1, 0);
     n_kmers = 0;
-    for (size_t u = 0; u < n; ++u) {
-        const std::string& s = seqs[u];
-        n_kmers += s.size() - k + 1;
-        for (size_t i = 0; i < s.size(); ++i) {
-            const int b = base2bits(s[i]);
-            if (b < 0) throw std::runtime_error("non-ACGT character in unitig");
-            const uint64_t p = uoff[u] + i;
-            useq[p >> 5] |= static_cast<uint64_t>(b) << (2 * (p & 31));
+    for (size_t u = 0; u < n; ++u) n_kmers += seqs[u].size() - k + 1;
+    parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+        for (size_t u = lo; u < hi; ++u) {
+            const std::string& s = seqs[u];
+            for (size_t i = 0; i < s.size(); ++i) {
+                const int b = base2bits(s[i]);
+                if (b < 0) throw std::runtime_error("non-ACGT character in unitig");
+                const uint64_t p = uoff[u] + i;
+                __atomic_fetch_or(&useq[p >> 5], static_cast<uint64_t>(b) << (2 * (p & 31)), __ATOMIC_RELAXED); // a word can straddle two unitigs
+            }
         }
-    }
+    });
     // ---- half-k-mer index: every h-mer (h = (k-1)/2) of the forward unitig sequences -> the places it starts. A graph k-mer one edit
     // away from a read window shares its first or its last h characters with the read (the edit cannot be in both), so the 1-edit search
     // looks up read h-mers here and verifies the few k-mers they belong to instead of spelling every variant of the window.
@@ -77,18 +92,30 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         const double est_gb = static_cast<double>(uoff[n]) * (8.0 * 4.0 + 8.0 * 1.5) / 1e9; // slots at load 0.25..0.5 + list words
         if ((e_enum && e_enum[0] == '1') || est_gb > max_gb) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); }
         else {
-            std::vector<std::pair<uint64_t, uint64_t> > pairs;
-            pairs.reserve(uoff[n]);
+            std::vector<std::pair<uint64_t, uint64_t> > pairs(uoff[n] - static_cast<uint64_t>(n) * static_cast<uint64_t>(h - 1)); // every h-mer start of every unitig, at its own place
             const uint64_t hm = (1ull << (2 * h)) - 1ull;
-            for (size_t u = 0; u < n; ++u) {
-                const std::string& s = seqs[u];
-                uint64_t fw = 0;
-                for (size_t i = 0; i < s.size(); ++i) {
-                    fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & hm;
-                    if (i + 1 >= static_cast<size_t>(h)) pairs.push_back(std::make_pair(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h)));
+            parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+                for (size_t u = lo; u < hi; ++u) {
+                    const std::string& s = seqs[u];
+                    uint64_t fw = 0, at = uoff[u] - static_cast<uint64_t>(u) * static_cast<uint64_t>(h - 1);
+                    for (size_t i = 0; i < s.size(); ++i) {
+                        fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & hm;
+                        if (i + 1 >= static_cast<size_t>(h)) pairs[at++] = std::make_pair(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h));
+                    }
+                }
+            });
+            { // sorted slices, then pairwise merges (each level on half as many threads)
+                int nt = n_threads < 1 ? 1 : n_threads; while (nt > 1 && pairs.size() / static_cast<size_t>(nt) < (1u << 16)) nt >>= 1;
+                int p2 = 1; while (p2 * 2 <= nt) p2 *= 2; nt = p2;
+                std::vector<size_t> cut(nt + 1); for (int t = 0; t <= nt; ++t) cut[t] = pairs.size() * static_cast<size_t>(t) / static_cast<size_t>(nt);
+                parallel_slices(static_cast<size_t>(nt), nt, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; ++t) std::sort(pairs.begin() + cut[t], pairs.begin() + cut[t + 1]); });
+                for (int w = 1; w < nt; w *= 2) {
+                    const int groups = nt / (2 * w);
+                    parallel_slices(static_cast<size_t>(groups), groups, [&](size_t lo, size_t hi, int) {
+                        for (size_t gI = lo; gI < hi; ++gI) std::inplace_merge(pairs.begin() + cut[2 * w * gI], pairs.begin() + cut[2 * w * gI + w], pairs.begin() + cut[2 * w * gI + 2 * w]);
+                    });
                 }
             }
-            std::sort(pairs.begin(), pairs.end());
             uint64_t uniq = 0;
             for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].first != pairs[i - 1].first) ++uniq;
             if (pairs.size() + uniq >= (1ull << 34)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
@@ -127,24 +154,28 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
       if (e0) { bits = cap_bits; }
       const char* e1 = getenv("RTK_BF1_OFF");
       if (n_kmers > cap_bits || (e1 && e1[0] == '1')) bf1.assign(1, ~0ull); else bf1.assign(bits / 64, 0); } // below one bit per key the array stops paying for itself
-    for (size_t u = 0; u < n; ++u) {
-        const std::string& s = seqs[u];
-        uint64_t fw = 0;
-        for (size_t i = 0; i < s.size(); ++i) {
-            fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & kmask;
-            if (i + 1 < static_cast<size_t>(k)) continue;
-            bool is_fw; const uint64_t can = kmer_canonical(fw, k, &is_fw);
-            uint64_t h = rtk_hash64(can) & hmask;
-            while (ht[2 * h] != RTK_EMPTY_KEY) {
-                if (ht[2 * h] == can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
-                h = (h + 1) & hmask;
+    const bool bf1_off = bf1.size() == 1;
+    parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+        for (size_t u = lo; u < hi; ++u) {
+            const std::string& s = seqs[u];
+            uint64_t fw = 0;
+            for (size_t i = 0; i < s.size(); ++i) {
+                fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & kmask;
+                if (i + 1 < static_cast<size_t>(k)) continue;
+                bool is_fw; const uint64_t can = kmer_canonical(fw, k, &is_fw);
+                uint64_t h = rtk_hash64(can) & hmask;
+                while (true) { // claim an empty slot with compare-and-swap on its key word (another thread may be filling the table too)
+                    uint64_t seen_key = __atomic_load_n(&ht[2 * h], __ATOMIC_RELAXED);
+                    if (seen_key == RTK_EMPTY_KEY) { uint64_t expect = RTK_EMPTY_KEY; if (__atomic_compare_exchange_n(&ht[2 * h], &expect, can, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; seen_key = expect; }
+                    if (seen_key == can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
+                    h = (h + 1) & hmask;
+                }
+                { const uint64_t hh = rtk_hash64(can); __atomic_fetch_or(&bf[(hh >> 32) & (bf_words - 1)], (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)), __ATOMIC_RELAXED);
+                  if (!bf1_off) { const uint64_t b1 = (hh >> 12) & (bf1.size() * 64 - 1); __atomic_fetch_or(&bf1[b1 >> 6], 1ull << (b1 & 63ull), __ATOMIC_RELAXED); } }
+                ht[2 * h + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
             }
-            ht[2 * h] = can;
-            { const uint64_t hh = rtk_hash64(can); bf[(hh >> 32) & (bf_words - 1)] |= (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63));
-              const uint64_t b1 = (hh >> 12) & (bf1.size() * 64 - 1); bf1[b1 >> 6] |= 1ull << (b1 & 63ull); }
-            ht[2 * h + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
         }
-    }
+    });
     const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; return v; }();
     // ---- unitig data (.rtsk) ----
     flags.assign(n, 0); kcov.assign(n, 0); card.assign(n, 0); gid.assign(n, -1); loff.assign(n + 1, 0);
@@ -214,7 +245,8 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     for (size_t u = 0; u < n; ++u) if (!cycles[u].empty()) memcpy(reinterpret_cast<char*>(cyc.data()) + cycoff[u], cycles[u].data(), cycles[u].size());
     // ---- adjacency ([A3]: neighbours of the unitig end in walk direction, A,C,G,T) ----
     adj.assign(n * 8, RTK_NONE32);
-    for (size_t u = 0; u < n; ++u) {
+    parallel_slices(n, n_threads, [&](size_t lo_u, size_t hi_u, int) {
+    for (size_t u = lo_u; u < hi_u; ++u) {
         const std::string& s = seqs[u];
         uint64_t tail, head;
         kmer_encode(s.c_str() + s.size() - k, k, tail);
@@ -231,6 +263,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             adj[u * 8 + d * 4 + b] = (f.unitig << 1) | f.strand;
         }
     }
+    });
     // ---- getMaxKmerCoverage(dbg, 0.001) ----
     {
         std::vector<uint32_t> v(kcov);
