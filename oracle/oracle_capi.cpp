@@ -22,12 +22,13 @@ struct orc_opts { // mirrors the pass-1 fields of Correct_Opt (reference: src/Co
     double weak_region_len_factor, large_k_factor, min_score;
     int32_t max_qual, out_qual;
     double min_confidence_snp_corr;
+    uint64_t max_len_weak_region2; // pass 2 (-W, 5000)
 };
 
 static Opt toOpt(const orc_opts* o) {
     Opt r;
     if (o) { r.insert_sz = o->insert_sz; r.min_cov_vertices = o->min_cov_vertices; r.max_len_weak_region1 = o->max_len_weak_region1; r.max_km_cov = o->max_km_cov;
-             r.weak_region_len_factor = o->weak_region_len_factor; r.large_k_factor = o->large_k_factor; r.min_score = o->min_score; r.max_qual = o->max_qual; r.out_qual = o->out_qual; r.min_confidence_snp_corr = o->min_confidence_snp_corr; }
+             r.weak_region_len_factor = o->weak_region_len_factor; r.large_k_factor = o->large_k_factor; r.min_score = o->min_score; r.max_qual = o->max_qual; r.out_qual = o->out_qual; r.min_confidence_snp_corr = o->min_confidence_snp_corr; if (o->max_len_weak_region2) r.max_len_weak_region2 = o->max_len_weak_region2; }
     return r;
 }
 
@@ -150,6 +151,29 @@ int orc_correct_batch(void* gp, const orc_opts* o, uint64_t n, const char* const
     }
     return 0;
 }
+
+// Pass 2 (`correct -2`): seq / qual = the pass-1 corrected reads, raw = the uncorrected reads in the same order (src/Ratatosk.cpp:774-838).
+int orc_correct_batch2(void* gp, const orc_opts* o, uint64_t n, const char* const* seq, const char* const* qual, const uint32_t* len,
+                       const char* const* raw, const uint32_t* raw_len, char** out_seq, char** out_qual, uint32_t* out_len, int n_threads) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    const Opt opt = toOpt(o);
+    std::atomic<uint64_t> ticket(0);
+    auto work = [&]() {
+        while (true) {
+            const uint64_t i = ticket.fetch_add(1);
+            if (i >= n) break;
+            const std::pair<std::string, std::string> r = correctRead2(*g, opt, std::string(seq[i], len[i]), qual && qual[i] ? std::string(qual[i], len[i]) : std::string(), std::string(raw[i], raw_len[i]), nullptr);
+            out_len[i] = static_cast<uint32_t>(r.first.size());
+            out_seq[i] = static_cast<char*>(malloc(r.first.size() + 1)); memcpy(out_seq[i], r.first.c_str(), r.first.size() + 1);
+            out_qual[i] = static_cast<char*>(malloc(r.second.size() + 1)); memcpy(out_qual[i], r.second.c_str(), r.second.size() + 1);
+        }
+    };
+    if (n_threads <= 1) work();
+    else { std::vector<std::thread> th; for (int t = 0; t < n_threads; ++t) th.emplace_back(work); for (size_t t = 0; t < th.size(); ++t) th[t].join(); }
+    return 0;
+}
+
+uint64_t orc_wyhash8(uint64_t key, uint64_t seed) { return wyhash8(key, seed); }
 
 void orc_free(void* p) { free(p); }
 

@@ -463,7 +463,9 @@ void exploreSubGraph(const Ctx& c, const IdSet& all_pids, const char* ref, const
             { // non-terminal
                 Path path(it.first);
                 pathExtend(c, path, sc);
-                if (it.second != 0) stck.push_back(std::make_pair(path, it.second - 1));
+                // exploreSubGraph descends `level` unitigs (:531-535); exploreSubGraphLong until the sub-path spans k * large_k_factor (:594,:669-671)
+                const bool deeper = c.opt.long_read_correct ? (path.length() < static_cast<size_t>(static_cast<double>(c.k) * c.opt.large_k_factor)) : (it.second != 0);
+                if (deeper) stck.push_back(std::make_pair(path, it.second ? it.second - 1 : 0));
                 else if (c.g.nbSuccessors(sc) > 0) {
                     const double sco = getScorePath(c, path, ref, ref_len, false);
                     if (sco >= score_nt1) { if (sco > score_nt1) out.non_terminal.clear(); out.non_terminal.push_back(path); score_nt2 = score_nt1; score_nt1 = sco; }
@@ -571,7 +573,7 @@ std::vector<Path> explorePathsBFS2(const Ctx& c, const IdSet& all_pids, const ch
                 explore(c, all_pids, ref, ref_len, um_e, p, max_len_path, memo, term, nterm);
                 for (size_t i = 0; i < term.size(); ++i) { Path p_ext(p); extendBy(c, p_ext, term[i]); v_tmp.push_back(p_ext); }
                 for (size_t i = 0; i < nterm.size(); ++i) {
-                    if (nterm[i].size() == level) {
+                    if (c.opt.long_read_correct ? (nterm[i].length() >= static_cast<size_t>(static_cast<double>(c.k) * c.opt.large_k_factor)) : (nterm[i].size() == level)) { // :395
                         Path p_ext(p); extendBy(c, p_ext, nterm[i]);
                         q.push_back(p_ext);
                         if (q.size() >= max_sz_stck) { std::vector<Path> tmp(q.begin(), q.end()); q.clear(); resizeToBest(c, tmp, ref, ref_len); for (size_t j = 0; j < tmp.size(); ++j) q.push_back(tmp[j]); }
@@ -630,7 +632,7 @@ std::vector<Path> explorePathsBFS(const Ctx& c, const IdSet& all_pids, const cha
                         if (p_ext.length() >= min_len_path && p_ext.length() <= max_len_path) v_tmp.push_back(p_ext);
                         j += path.ums[u].len;
                     }
-                    if (path.size() == level) {
+                    if (c.opt.long_read_correct ? (path.length() >= static_cast<size_t>(static_cast<double>(c.k) * c.opt.large_k_factor)) : (path.size() == level)) { // :174
                         q.push_back(p_ext);
                         if (q.size() >= max_sz_stck) { std::vector<Path> tmp(q.begin(), q.end()); q.clear(); resizeToBest(c, tmp, ref, ref_len); for (size_t t = 0; t < tmp.size(); ++t) q.push_back(tmp[t]); }
                     }
@@ -658,7 +660,7 @@ SemiWeak extractSemiWeakPaths(const Ctx& c, const std::string& s, const IdSet& a
     const size_t k = c.k;
     const size_t pos_um_solid2 = no_end ? s.length() - k : um_solid_end.first;
     const size_t len_weak_region = (pos_um_solid2 - um_solid_start.first) + k;
-    const size_t max_len_weak_region = c.opt.max_len_weak_region1;
+    const size_t max_len_weak_region = c.opt.long_read_correct ? c.opt.max_len_weak_region2 : c.opt.max_len_weak_region1; // :23
     const size_t max_paths = 512;
     size_t next_weak_pos = 0;
     bool begin = true, end = false;
@@ -877,12 +879,14 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
     const Ctx c(g, opt, cnt);
     const size_t k = c.k;
     if (s_fw.length() <= k || v_um_solid.empty() || v_um_solid.size() == s_fw.length() - k + 1) {
+        if (opt.long_read_correct) return std::make_pair(s_fw, q_fw); // :167
         if (v_um_solid.size() == s_fw.length() - k + 1) return std::make_pair(s_fw, std::string(s_fw.length(), getQual(1.0, 0, opt.max_qual)));
         return std::make_pair(s_fw, std::string(s_fw.length(), getQual(0.0, 0, opt.max_qual)));
     }
     const size_t seq_len = s_fw.length();
     const std::string s_bw(revcomp(s_fw));
-    const size_t max_len_weak_anchors = opt.max_len_weak_region1;
+    const bool lrc = opt.long_read_correct;
+    const size_t max_len_weak_anchors = lrc ? opt.max_len_weak_region2 : opt.max_len_weak_region1; // :177
     const char q_min = getQual(0.0, 0, opt.max_qual), q_max = getQual(1.0, 0, opt.max_qual);
     std::string q_bw = q_fw;
     size_t prev_pos = v_um_solid[0].first, i_solid = 0, i_weak = 0;
@@ -895,7 +899,12 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
     for (size_t i = 0; i < v_um_weak_rev.size(); ++i) { v_um_weak_rev[i].first = seq_len - v_um_weak_rev[i].first - k; v_um_weak_rev[i].second.strand = !v_um_weak_rev[i].second.strand; }
 
     // the `correct` lambda (src/Correction.cpp:431-753), pass 1
-    auto correct = [&](const std::string& s, const std::vector<Anchor>& v_s, const std::vector<Anchor>& v_w, const size_t i_s, const size_t i_w, const ResultCorrection* rc) -> ResultCorrection {
+    auto hasMinQual = [](const std::string& s, const std::string& q, const size_t start, const size_t end, const char min_q) { // src/Correction.hpp:45-52
+        bool has = true;
+        for (size_t i = start; i < end && has; ++i) has = (q[i] >= min_q) || !isDNA(s[i]);
+        return has;
+    };
+    auto correct = [&](const std::string& s, const std::string& q, const std::vector<Anchor>& v_s, const std::vector<Anchor>& v_w, const size_t i_s, const size_t i_w, const ResultCorrection* rc) -> ResultCorrection {
         if (cnt) ++cnt->n_regions;
         const bool has_end_pt = (i_s + 1) < v_s.size();
         Anchor um_solid1 = v_s[i_s];
@@ -910,8 +919,8 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
         std::vector<Anchor> l_v_w;
         IdSet all_pids;
         const double max_cov_d = static_cast<double>(opt.max_km_cov);
-        auto setUncorrected = [&](const size_t pos, const size_t len, const char qual) { s_corrected = s.substr(pos, len); q_corrected = std::string(len_weak_region, qual); };
-        auto addUncorrected = [&](const size_t pos, const size_t len, const char qual) { s_corrected += s.substr(pos, len); q_corrected += std::string(len_weak_region, qual); };
+        auto setUncorrected = [&](const size_t pos, const size_t len, const char qual) { s_corrected = s.substr(pos, len); q_corrected = lrc ? q.substr(pos, len) : std::string(len_weak_region, qual); }; // :459-463
+        auto addUncorrected = [&](const size_t pos, const size_t len, const char qual) { s_corrected += s.substr(pos, len); q_corrected += lrc ? q.substr(pos, len) : std::string(len_weak_region, qual); }; // :465-469
         auto middle = [&](AnchorSets* s_spid_m) { // :563-585 and :593-604
             if (!v_w.empty()) {
                 const size_t pos_end = has_end_pt ? v_s[i_s + 1].first : s.length();
@@ -974,7 +983,7 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
                 addAmbiguity(best, s_corrected.length());
                 s_corrected += pathToString(c, best) + s.substr(um_solid1.first + align.second + 1, l_v_w[i_w_s].first - um_solid1.first - align.second - 1);
                 q_corrected += best.qual;
-                q_corrected += std::string(l_v_w[i_w_s].first - um_solid1.first - align.second - 1, q_min);
+                q_corrected += lrc ? q.substr(um_solid1.first + align.second + 1, l_v_w[i_w_s].first - um_solid1.first - align.second - 1) : std::string(l_v_w[i_w_s].first - um_solid1.first - align.second - 1, q_min); // :642-643
                 res.addRange(um_solid1.first - v_s[i_s].first, um_solid1.first + align.second + 1 - v_s[i_s].first);
                 um_solid1 = l_v_w[i_w_s];
                 len_weak_region = um_solid2.first - um_solid1.first + k;
@@ -994,7 +1003,7 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
                     addAmbiguity(best, s_corrected.length());
                     s_corrected += pathToString(c, best) + s.substr(um_solid1.first + align.second + 1, len_weak_region - align.second - 1);
                     q_corrected += best.qual;
-                    q_corrected += std::string(len_weak_region - align.second - 1, q_min);
+                    q_corrected += lrc ? q.substr(um_solid1.first + align.second + 1, len_weak_region - align.second - 1) : std::string(len_weak_region - align.second - 1, q_min); // :684-685
                     res.addRange(um_solid1.first - v_s[i_s].first, um_solid1.first + align.second + 1 - v_s[i_s].first);
                 }
             } else if (!s_corrected.empty()) addUncorrected(um_solid1.first, len_weak_region, q_min);
@@ -1026,13 +1035,19 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
     };
 
     if (v_um_solid[0].first != 0) { // head region (:776-797)
-        const size_t i_solid_rev = v_um_solid_rev.size() - 1;
-        size_t i_weak_rev = v_um_weak_rev.size();
-        while (i_weak_rev > 0 && v_um_weak_rev[i_weak_rev - 1].first > v_um_solid_rev[i_solid_rev].first) --i_weak_rev;
-        ResultCorrection bw = correct(s_bw, v_um_solid_rev, v_um_weak_rev, i_solid_rev, i_weak_rev, nullptr);
-        bw.reverseComplement();
-        corrected_s += bw.seq.substr(0, bw.seq.length() - k);
-        corrected_q += bw.qual.substr(0, bw.qual.length() - k);
+        // pass 2 leaves a stretch alone when pass 1 already gave every base of it the maximum quality (:779)
+        if (!lrc || q_fw.empty() || !hasMinQual(s_fw, q_fw, 0, v_um_solid[0].first + k, q_max)) {
+            const size_t i_solid_rev = v_um_solid_rev.size() - 1;
+            size_t i_weak_rev = v_um_weak_rev.size();
+            while (i_weak_rev > 0 && v_um_weak_rev[i_weak_rev - 1].first > v_um_solid_rev[i_solid_rev].first) --i_weak_rev;
+            ResultCorrection bw = correct(s_bw, q_fw, v_um_solid_rev, v_um_weak_rev, i_solid_rev, i_weak_rev, nullptr); // q_fw, not q_bw: as written (:787, G17)
+            bw.reverseComplement();
+            corrected_s += bw.seq.substr(0, bw.seq.length() - k);
+            corrected_q += bw.qual.substr(0, bw.qual.length() - k);
+        } else {
+            corrected_s += s_fw.substr(0, v_um_solid[0].first);
+            corrected_q += lrc ? q_fw.substr(0, v_um_solid[0].first) : std::string(v_um_solid[0].first, q_min);
+        }
     }
     while (i_solid < v_um_solid.size() - 1) { // :799-938
         while (i_weak < v_um_weak.size() && v_um_weak[i_weak].first < v_um_solid[i_solid].first) ++i_weak;
@@ -1040,7 +1055,8 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
             bool isUncorrected = false;
             const UM& start_um = v_um_solid[i_solid].second; const UM& end_um = v_um_solid[i_solid + 1].second;
             bool sameUnitig = (start_um.unitig == end_um.unitig) && (start_um.strand == end_um.strand);
-            if (sameUnitig && !g.isShortCycle(start_um.unitig)) {
+            if (lrc && !q_fw.empty() && hasMinQual(s_fw, q_fw, v_um_solid[i_solid].first, v_um_solid[i_solid + 1].first + k, q_max)) isUncorrected = true; // :808
+            else if (sameUnitig && !g.isShortCycle(start_um.unitig)) {
                 const size_t min_pos = std::min(start_um.dist, end_um.dist), max_pos = std::max(start_um.dist, end_um.dist);
                 const size_t len_query_km = v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first;
                 const size_t len_unitig_km = max_pos - min_pos;
@@ -1053,53 +1069,61 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
                     const std::string s_um_sub = g.mapped(um_sub);
                     if (cnt) cnt->n_path_base += s_um_sub.size();
                     corrected_s += s_fw.substr(prev_pos, v_um_solid[i_solid].first - prev_pos) + s_um_sub.substr(0, s_um_sub.length() - k);
-                    corrected_q += std::string((v_um_solid[i_solid].first - prev_pos) + (s_um_sub.length() - k), q_max);
+                    if (lrc) { // :847-853
+                        const size_t buff = (s_um_sub.length() >= 2 * k) ? k : (s_um_sub.length() - k);
+                        corrected_q += q_fw.substr(prev_pos, v_um_solid[i_solid].first - prev_pos + buff);
+                        if ((s_um_sub.length() - buff - k) > 0) corrected_q += std::string(s_um_sub.length() - buff - k, q_max);
+                    } else corrected_q += std::string((v_um_solid[i_solid].first - prev_pos) + (s_um_sub.length() - k), q_max);
                 } else isUncorrected = true;
             } else if (v_um_solid[i_solid + 1].first >= (v_um_solid[i_solid].first + k)) {
-                const ResultCorrection fw = correct(s_fw, v_um_solid, v_um_weak, i_solid, i_weak, nullptr);
+                const ResultCorrection fw = correct(s_fw, q_fw, v_um_solid, v_um_weak, i_solid, i_weak, nullptr);
                 if (fw.is_corrected) {
                     const size_t l_solid = v_um_solid[i_solid].first - prev_pos;
-                    const std::string sub_s = s_fw.substr(prev_pos, l_solid) + fw.seq, sub_q = std::string(l_solid, q_max) + fw.qual;
+                    const std::string sub_s = s_fw.substr(prev_pos, l_solid) + fw.seq, sub_q = (lrc ? q_fw.substr(prev_pos, l_solid) : std::string(l_solid, q_max)) + fw.qual;
                     corrected_s += sub_s.substr(0, sub_s.length() - k); corrected_q += sub_q.substr(0, sub_q.length() - k);
                 } else {
                     const size_t i_solid_bw = v_um_solid_rev.size() - i_solid - 2;
                     size_t i_weak_bw = v_um_weak_rev.size() - i_weak;
                     while (i_weak_bw > 0 && v_um_weak_rev[i_weak_bw - 1].first > v_um_solid_rev[i_solid_bw].first) --i_weak_bw;
-                    ResultCorrection bw = correct(s_bw, v_um_solid_rev, v_um_weak_rev, i_solid_bw, i_weak_bw, &fw);
+                    ResultCorrection bw = correct(s_bw, q_bw, v_um_solid_rev, v_um_weak_rev, i_solid_bw, i_weak_bw, &fw);
                     bw.reverseComplement();
                     if (bw.is_corrected) {
                         const size_t l_solid = (s_bw.length() - v_um_solid_rev[i_solid_bw + 1].first - k) - prev_pos;
-                        const std::string sub_s = s_fw.substr(prev_pos, l_solid) + bw.seq, sub_q = std::string(l_solid, q_max) + bw.qual;
+                        const std::string sub_s = s_fw.substr(prev_pos, l_solid) + bw.seq, sub_q = (lrc ? q_fw.substr(prev_pos, l_solid) : std::string(l_solid, q_max)) + bw.qual;
                         corrected_s += sub_s.substr(0, sub_s.length() - k); corrected_q += sub_q.substr(0, sub_q.length() - k);
                     } else {
                         std::string l_ref = s_fw.substr(v_um_solid[i_solid].first, v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first + k);
                         std::pair<std::string, std::string> cons = generateConsensus(c, &fw, &bw, l_ref, opt.weak_region_len_factor);
-                        if (cons.first.length() == 0) { cons.first = l_ref; cons.second = std::string(k, q_max) + std::string(v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first, q_min); }
+                        if (cons.first.length() == 0) { cons.first = l_ref; cons.second = lrc ? q_fw.substr(v_um_solid[i_solid].first, v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first + k) : (std::string(k, q_max) + std::string(v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first, q_min)); }
                         const size_t l_solid = v_um_solid[i_solid].first - prev_pos;
-                        const std::string sub_s = s_fw.substr(prev_pos, l_solid) + cons.first, sub_q = std::string(l_solid, q_max) + cons.second;
+                        const std::string sub_s = s_fw.substr(prev_pos, l_solid) + cons.first, sub_q = (lrc ? q_fw.substr(prev_pos, l_solid) : std::string(l_solid, q_max)) + cons.second;
                         corrected_s += sub_s.substr(0, sub_s.length() - k); corrected_q += sub_q.substr(0, sub_q.length() - k);
                     }
                 }
             } else isUncorrected = true;
             if (isUncorrected) {
                 corrected_s += s_fw.substr(prev_pos, v_um_solid[i_solid + 1].first - prev_pos);
-                corrected_q += std::string(v_um_solid[i_solid].first - prev_pos, q_max);
-                if (v_um_solid[i_solid + 1].first < (v_um_solid[i_solid].first + k)) corrected_q += std::string(v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first, q_max);
-                else corrected_q += std::string(k, q_max) + std::string(v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first - k, q_min);
+                if (lrc) corrected_q += q_fw.substr(prev_pos, v_um_solid[i_solid + 1].first - prev_pos); // :924
+                else {
+                    corrected_q += std::string(v_um_solid[i_solid].first - prev_pos, q_max);
+                    if (v_um_solid[i_solid + 1].first < (v_um_solid[i_solid].first + k)) corrected_q += std::string(v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first, q_max);
+                    else corrected_q += std::string(k, q_max) + std::string(v_um_solid[i_solid + 1].first - v_um_solid[i_solid].first - k, q_min);
+                }
             }
             prev_pos = v_um_solid[i_solid + 1].first;
         }
         ++i_solid;
     }
-    if (v_um_solid[v_um_solid.size() - 1].first < s_fw.length() - k) { // tail region (:940-950)
+    if (v_um_solid[v_um_solid.size() - 1].first < s_fw.length() - k && // tail region (:940-950)
+        (!lrc || q_fw.empty() || !hasMinQual(s_fw, q_fw, v_um_solid[v_um_solid.size() - 1].first, s_fw.length(), q_max))) {
         while (i_weak < v_um_weak.size() && v_um_weak[i_weak].first < v_um_solid[i_solid].first) ++i_weak;
-        const ResultCorrection fw = correct(s_fw, v_um_solid, v_um_weak, i_solid, i_weak, nullptr);
+        const ResultCorrection fw = correct(s_fw, q_fw, v_um_solid, v_um_weak, i_solid, i_weak, nullptr);
         const size_t l_solid = v_um_solid[i_solid].first - prev_pos;
         corrected_s += s_fw.substr(prev_pos, l_solid) + fw.seq;
-        corrected_q += std::string(l_solid, q_max) + fw.qual;
+        corrected_q += (lrc ? q_fw.substr(prev_pos, l_solid) : std::string(l_solid, q_max)) + fw.qual;
     } else {
         corrected_s += s_fw.substr(prev_pos);
-        corrected_q += std::string(v_um_solid[i_solid].first - prev_pos + k, q_max) + std::string(s_fw.length() - v_um_solid[i_solid].first - k, q_min);
+        corrected_q += lrc ? q_fw.substr(prev_pos) : (std::string(v_um_solid[i_solid].first - prev_pos + k, q_max) + std::string(s_fw.length() - v_um_solid[i_solid].first - k, q_min));
     }
     return std::make_pair(corrected_s, corrected_q);
 }

@@ -16,7 +16,8 @@
 // fixAmbiguity/getAmbiguityVector on SNP-annotated unitigs (src/Alignment.cpp:527-844, src/GraphTraversal.cpp:966-1036) are
 // restated for an undetermined haplotype (no phasing input); they lean on Bifrost's findUnitig and KmerIterator, assumptions
 // [A6]/[A7] of oracle_graph.hpp. Test inputs come from `build_index --snps` (a simplified stand-in for detectSNPs).
-// Not restated: pass 2 (long_read_correct), phasing (hap ids).
+// Pass 2 (long_read_correct): restated incl. phasing() and exploreSubGraphLong; leans on one more assumption, [A9] = the wyhash
+// version behind TinyBloomFilter (oracle_pass2.cpp). Not restated: haplotype input (-p/-P, hap ids).
 #ifndef RTK_ORACLE_CORRECT_HPP
 #define RTK_ORACLE_CORRECT_HPP
 
@@ -39,8 +40,11 @@ struct Opt { // the Correct_Opt fields the pass-1 hot path reads (src/Common.hpp
     int out_qual;
     double min_confidence_snp_corr; // -m (src/Common.hpp:147)
     size_t max_km_cov; // = max(getMaxKmerCoverage(dbg, 0.001), 128) (src/Ratatosk.cpp:625)
+    // pass 2 (`correct -2`, long_read_correct == true in the reference): graph coloured by the pass-1 reads, qualities carried over
+    bool long_read_correct;
+    size_t max_len_weak_region2; // -W, 5000 (src/Common.hpp:110)
     Opt() : insert_sz(500), min_cov_vertices(2), max_len_weak_region1(1000), weak_region_len_factor(0.25), large_k_factor(1.5),
-            min_score(0.0), max_qual(40), out_qual(1), min_confidence_snp_corr(0.9), max_km_cov(128) {}
+            min_score(0.0), max_qual(40), out_qual(1), min_confidence_snp_corr(0.9), max_km_cov(128), long_read_correct(false), max_len_weak_region2(5000) {}
 };
 
 struct Counters { // event counts feeding the algorithmic-bytes model of SURVEY.md §8(d)
@@ -57,7 +61,7 @@ typedef std::pair<size_t, UM> Anchor;
 typedef int (*ref_edlib_moves_fn)(const char*, int, const char*, int, int, int, int, int, int*, int*, int, unsigned char*, int, int*);
 extern ref_edlib_moves_fn g_ref_edlib_moves;
 
-// src/Graph.cpp:3-482 (long_read_correct=false). Returns (solid, weak).
+// src/Graph.cpp:3-482. Returns (solid, weak); opt.long_read_correct: exact hits only (:100).
 std::pair<std::vector<Anchor>, std::vector<Anchor> > getSeeds(const Graph& g, const Opt& opt, const std::string& s, Counters* cnt = nullptr);
 
 // individual stages of getSeeds, exposed so the device stages can be checked one by one
@@ -72,6 +76,16 @@ std::pair<std::string, std::string> correctSequence(const Graph& g, const Opt& o
 
 // per-read body of the worker loop (src/Ratatosk.cpp:808-864): upper-case, clamp qualities, seeds, correct.
 std::pair<std::string, std::string> correctRead(const Graph& g, const Opt& opt, std::string seq, std::string qual, Counters* cnt = nullptr);
+
+// ---- pass 2 (oracle_pass2.cpp) ----
+// phasing() (src/Graph.cpp:869-1097): reverts the pass-1 corrections that sit on unitigs whose colours (pass-1 read ids) are not
+// shared with any unitig further than insert_sz away on the same read; TinyBloomFilter (src/TinyBloomFilter.hpp) + wyhash [A9].
+std::pair<std::string, std::string> phasing(const Graph& g, const Opt& opt, const std::string& s_raw, const std::string& s_corr, const std::string& q_corr);
+// per-read body for long_read_correct == true (src/Ratatosk.cpp:808-838): upper-case, phasing, getSeeds (exact hits only), correctSequence
+std::pair<std::string, std::string> correctRead2(const Graph& g, const Opt& opt, std::string seq_corr, std::string qual_corr, const std::string& seq_raw, Counters* cnt = nullptr);
+// writeCorrectedOutput with trimming (src/Ratatosk.cpp:510-563): the records one corrected read becomes (name suffixes as the reference writes them)
+std::vector<std::pair<std::string, std::pair<std::string, std::string> > > trimRecords(const std::string& name, const std::string& seq, const std::string& qual, size_t k, int trim_qual);
+uint64_t wyhash8(uint64_t key, uint64_t seed); // wyhash(&key, 8, seed, _wyp) [A9]
 
 } // namespace orc
 

@@ -13,11 +13,12 @@ class OrcOpts(C.Structure):
     # mirrors struct orc_opts in oracle_capi.cpp (pass-1 fields of the reference's Correct_Opt, src/Common.hpp:101-156)
     _fields_ = [("insert_sz", C.c_uint64), ("min_cov_vertices", C.c_uint64), ("max_len_weak_region1", C.c_uint64),
                 ("max_km_cov", C.c_uint64), ("weak_region_len_factor", C.c_double), ("large_k_factor", C.c_double),
-                ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double)]
+                ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double),
+                ("max_len_weak_region2", C.c_uint64)]
 
 
 def default_opts(max_km_cov=128):
-    return OrcOpts(500, 2, 1000, max_km_cov, 0.25, 1.5, 0.0, 40, 1, 0.9)
+    return OrcOpts(500, 2, 1000, max_km_cov, 0.25, 1.5, 0.0, 40, 1, 0.9, 5000)
 
 
 _lib = None
@@ -50,6 +51,10 @@ def lib():
                                         C.c_int, C.POINTER(C.c_uint64)]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_use_reference_edlib.argtypes = [C.c_char_p]
+        L.orc_correct_batch2.argtypes = [C.c_void_p, C.POINTER(OrcOpts), C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_int]
+        L.orc_wyhash8.restype = C.c_uint64
+        L.orc_wyhash8.argtypes = [C.c_uint64, C.c_uint64]
         _lib = L
     return _lib
 
@@ -200,6 +205,26 @@ class Graph:
             lib().orc_free(os_[i]); lib().orc_free(oq[i])
         names = ["n_probe", "n_verify", "n_expand", "n_colour_elem", "n_path_base", "n_align", "n_align_cells", "n_regions"]
         return out, {k_: cnt[i] for i, k_ in enumerate(names)}
+
+
+def _graph_correct_batch2(self, seqs, quals, raws, opts=None, threads=1):
+    """Pass 2 (`correct -2`): seqs / quals = pass-1 corrected reads, raws = the uncorrected reads, same order. Returns [(seq, qual)]."""
+    n = len(seqs)
+    o = opts or self.opts()
+    enc = lambda v: [x.encode() if isinstance(x, str) else x for x in v]
+    bs, bq, br = enc(seqs), enc(quals), enc(raws)
+    sa, qa, ra = (C.c_char_p * n)(*bs), (C.c_char_p * n)(*bq), (C.c_char_p * n)(*br)
+    la, rl = (C.c_uint32 * n)(*[len(b) for b in bs]), (C.c_uint32 * n)(*[len(b) for b in br])
+    os_, oq, ol = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_uint32 * n)()
+    lib().orc_correct_batch2(self.h, C.byref(o), n, sa, qa, la, ra, rl, os_, oq, ol, threads)
+    out = []
+    for i in range(n):
+        out.append((C.string_at(os_[i], ol[i]).decode(), C.string_at(oq[i], ol[i]).decode()))
+        lib().orc_free(os_[i]); lib().orc_free(oq[i])
+    return out
+
+
+Graph.correct_batch2 = _graph_correct_batch2
 
 
 def read_fastq(path):

@@ -189,9 +189,11 @@ std::pair<std::vector<Anchor>, std::vector<Anchor> > getSeeds(const Graph& g, co
     if (s.length() <= k) return std::make_pair(solid, weak); // src/Graph.cpp:49
     v_um = searchExact(g, s, cnt);
     std::sort(v_um.begin(), v_um.end(), CompAnchor(g));                          // :104
-    const std::string l_s = maskForInexact(g, opt, s, v_um);                     // :102-191
-    const std::vector<Anchor> inexact = searchInexact(g, l_s, cnt);              // :193
-    v_um.insert(v_um.end(), inexact.begin(), inexact.end());
+    if (!opt.long_read_correct) {                                                // :100 pass 2 keeps the exact hits only
+        const std::string l_s = maskForInexact(g, opt, s, v_um);                 // :102-191
+        const std::vector<Anchor> inexact = searchInexact(g, l_s, cnt);          // :193
+        v_um.insert(v_um.end(), inexact.begin(), inexact.end());
+    }
     std::sort(v_um.begin(), v_um.end(), CompAnchor(g));                          // :201
     for (size_t i = 0; i < v_um.size(); ++i) {                                   // :209-216
         if (i == 0 || v_um[i] != v_um[i - 1]) {

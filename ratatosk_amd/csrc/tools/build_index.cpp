@@ -66,6 +66,7 @@ int main(int argc, char** argv) {
     size_t min_cov_vertices = 2;
     double global_cov_factor = 3.0, min_color_sharing = 0.5;
     bool detect_cycles = true, detect_snps = false;
+    std::vector<std::string> colour_files; // pass-2 index (`Ratatosk index -2`): colours = ids of these (pass-1 corrected long) reads, one id per read
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char* n) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "rtk_build_index: missing value for %s\n", n); exit(2); } return argv[++i]; };
@@ -76,9 +77,10 @@ int main(int argc, char** argv) {
         else if (a == "--global-cov-factor") global_cov_factor = atof(need("--global-cov-factor"));
         else if (a == "--no-short-cycles") detect_cycles = false;
         else if (a == "--snps") detect_snps = true;
+        else if (a == "--colour-reads") colour_files.push_back(need("--colour-reads"));
         else { fprintf(stderr, "rtk_build_index: unknown option %s\n", a.c_str()); return 2; }
     }
-    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=31)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps]\n"); return 2; }
+    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=31)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
     const uint64_t mask = kmer_mask(k);
 
     // ---- pass 1: count canonical k-mers ----
@@ -158,12 +160,17 @@ int main(int argc, char** argv) {
     {
         std::string name, seq, qual, prev_name;
         uint32_t pair_id = 0; bool first = true;
-        for (size_t f = 0; f < in_files.size(); ++f) {
-            FastxReader fr; fr.open(in_files[f]);
+        // second-pass index: the reads that colour the graph are the (pass-1 corrected) long reads, every read its own id
+        // (addCoverage(dbg, opt_pass2, ..., long_read_correct = true), src/Ratatosk.cpp:1218)
+        const bool by_read = !colour_files.empty();
+        const std::vector<std::string>& col_in = by_read ? colour_files : in_files;
+        for (size_t f = 0; f < col_in.size(); ++f) {
+            FastxReader fr; if (!fr.open(col_in[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); return 1; }
             while (fr.next(name, seq, qual)) {
+                for (size_t x = 0; x < seq.size(); ++x) seq[x] = static_cast<char>(seq[x] & 0xDF);
                 if (name.size() > 2 && name[name.size() - 2] == '/' && (name[name.size() - 1] == '1' || name[name.size() - 1] == '2')) name.erase(name.size() - 2);
                 if (first) { first = false; prev_name = name; }
-                else if (name != prev_name) { ++pair_id; prev_name = name; }
+                else if (by_read || name != prev_name) { ++pair_id; prev_name = name; }
                 uint64_t fw = 0; int valid = 0;
                 for (size_t i = 0; i < seq.size(); ++i) {
                     const int b = base2bits(seq[i]);
