@@ -45,6 +45,12 @@ typedef struct rtk_opts {
     int32_t max_qual;               /* -Q, 40   */
     int32_t out_qual;               /* 1        */
     double min_confidence_snp_corr; /* -m, 0.9 (src/Common.hpp:147): below this confidence a SNP-annotated base is re-decided against the read */
+    /* second correction pass (`correct -2`; `long_read_correct` of search(), src/Ratatosk.cpp:618): the graph is coloured by the pass-1
+     * reads, the reads' qualities are carried over, regions pass 1 already gave the maximum quality are left alone, no 1-edit search.
+     * Needs batches created WITH quality strings. */
+    int32_t long_read_correct;      /* 0 = pass 1 */
+    int32_t reserved;
+    uint64_t max_len_weak_region2;  /* -W, 5000 (src/Common.hpp:110) */
 } rtk_opts;
 
 typedef struct rtk_graph_info {

@@ -43,8 +43,9 @@ struct Opt { // the Correct_Opt fields the pass-1 hot path reads (src/Common.hpp
     // pass 2 (`correct -2`, long_read_correct == true in the reference): graph coloured by the pass-1 reads, qualities carried over
     bool long_read_correct;
     size_t max_len_weak_region2; // -W, 5000 (src/Common.hpp:110)
+    bool skip_phasing;           // test switch (not in the reference): pass 2 without the phasing() pre-filter, to check the rest on its own
     Opt() : insert_sz(500), min_cov_vertices(2), max_len_weak_region1(1000), weak_region_len_factor(0.25), large_k_factor(1.5),
-            min_score(0.0), max_qual(40), out_qual(1), min_confidence_snp_corr(0.9), max_km_cov(128), long_read_correct(false), max_len_weak_region2(5000) {}
+            min_score(0.0), max_qual(40), out_qual(1), min_confidence_snp_corr(0.9), max_km_cov(128), long_read_correct(false), max_len_weak_region2(5000), skip_phasing(false) {}
 };
 
 struct Counters { // event counts feeding the algorithmic-bytes model of SURVEY.md §8(d)

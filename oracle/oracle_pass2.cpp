@@ -168,7 +168,7 @@ std::pair<std::string, std::string> phasing(const Graph& g, const Opt& opt, cons
 std::pair<std::string, std::string> correctRead2(const Graph& g, const Opt& opt_in, std::string seq, std::string qual, const std::string& seq_raw_in, Counters* cnt) {
     Opt opt = opt_in; opt.long_read_correct = true;
     for (size_t i = 0; i < seq.size(); ++i) seq[i] = static_cast<char>(std::toupper(static_cast<unsigned char>(seq[i]))); // :814 (the raw read is used as read: :774-802)
-    const std::pair<std::string, std::string> ph = phasing(g, opt, seq_raw_in, seq, qual); // :832
+    const std::pair<std::string, std::string> ph = opt.skip_phasing ? std::make_pair(seq, qual) : phasing(g, opt, seq_raw_in, seq, qual); // :832
     const std::pair<std::vector<Anchor>, std::vector<Anchor> > seeds = getSeeds(g, opt, ph.first, cnt);
     return correctSequence(g, opt, ph.first, ph.second, seeds.first, seeds.second, cnt);
 }

@@ -14,11 +14,11 @@ class OrcOpts(C.Structure):
     _fields_ = [("insert_sz", C.c_uint64), ("min_cov_vertices", C.c_uint64), ("max_len_weak_region1", C.c_uint64),
                 ("max_km_cov", C.c_uint64), ("weak_region_len_factor", C.c_double), ("large_k_factor", C.c_double),
                 ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double),
-                ("max_len_weak_region2", C.c_uint64)]
+                ("max_len_weak_region2", C.c_uint64), ("skip_phasing", C.c_int32), ("reserved", C.c_int32)]
 
 
 def default_opts(max_km_cov=128):
-    return OrcOpts(500, 2, 1000, max_km_cov, 0.25, 1.5, 0.0, 40, 1, 0.9, 5000)
+    return OrcOpts(500, 2, 1000, max_km_cov, 0.25, 1.5, 0.0, 40, 1, 0.9, 5000, 0, 0)
 
 
 _lib = None

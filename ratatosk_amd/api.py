@@ -19,7 +19,8 @@ class RtkError(RuntimeError):
 class RtkOpts(C.Structure):
     _fields_ = [("insert_sz", C.c_uint64), ("min_cov_vertices", C.c_uint64), ("max_len_weak_region1", C.c_uint64),
                 ("max_km_cov", C.c_uint64), ("weak_region_len_factor", C.c_double), ("large_k_factor", C.c_double),
-                ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double)]
+                ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double),
+                ("long_read_correct", C.c_int32), ("reserved", C.c_int32), ("max_len_weak_region2", C.c_uint64)]
 
 
 class RtkGraphInfo(C.Structure):

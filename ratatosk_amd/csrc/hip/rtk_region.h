@@ -42,6 +42,7 @@ struct RegionBatch {
     U<RegionDesc*> regions; U<uint64_t> regions_cap; U<unsigned long long*> n_regions;
     U<uint64_t*> r_first; U<uint32_t*> r_count;   // per read: its slice of `regions`
     U<char*> seq_rc;                           // reverse complement of every read (same offsets as seq)
+    U<char*> qual_rev;                         // pass 2: every read's quality string reversed (q_bw of src/Correction.cpp:186,198)
     U<char*> seg_pool; U<uint64_t> seg_cap; U<unsigned long long*> seg_top;
     U<unsigned long long*> next_region;        // dequeue head of the persistent region kernel
     U<unsigned long long*> n_overflow;         // regions that ran out of scratch in the last launch
@@ -506,6 +507,8 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
     WPath& w = s.wp[2];
     const bool has_end = !rtk_um_is_empty(um_e);
     const bool lazy_nt = has_end && !(rtk_u(c.o.min_score) > 0.0);
+    const bool lrc = rtk_u(c.o.long_read_correct) != 0;
+    const uint32_t max_len_subpath = static_cast<uint32_t>(static_cast<uint64_t>(static_cast<double>(rtk_u(c.k)) * rtk_u(c.o.large_k_factor)));
     uint32_t n_nt_live = 0, n_t_scored = 0;
     MyersSaved t_saved; t_saved.valid = 0; t_saved.gen = 0; t_saved.m = 0; t_saved.n = 0; t_saved.nw_dist = 0; t_saved.shw.dist = -1; t_saved.shw.first = -1; t_saved.shw.last = -1; t_saved.shw.nloc = 0;
     unsigned long long n_exp = 0;
@@ -576,9 +579,11 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
 #ifdef RTK_SIM
                 rtk_sim_site_stat[20][0] += 1; rtk_sim_site_stat[20][1] += sc.len + ((hp == ~0ull) ? static_cast<uint32_t>(rtk_u(c.k)) - 1 : 0); // DFS tree nodes and the columns they add
 #endif
-                if (lvl != 0) {
+                // exploreSubGraph descends `level` unitigs (:531-535), exploreSubGraphLong (pass 2) until the sub-path spans k * large_k_factor (:594, :669-671)
+                const bool deeper = lrc ? (rtk_ld(&w.l) < max_len_subpath) : (lvl != 0);
+                if (deeper) {
                     if (2 * (sp + 1) > list_cap) { rtk_fail_ovf(s, 8); break; }
-                    stk[2 * sp] = rtk_wp_commit(s, w, 2); stk[2 * sp + 1] = lvl - 1; ++sp;
+                    stk[2 * sp] = rtk_wp_commit(s, w, 2); stk[2 * sp + 1] = lvl ? lvl - 1 : 0; ++sp;
                 } else if (rtk_nb_successors(c.g, sc) > 0) {
                     if (lazy_nt) { // candidate kept in discovery order, scored after the walk (or never)
                         if (n_nt >= list_cap) { rtk_fail_ovf(s, 8); break; }
@@ -816,6 +821,8 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
     const bool ok_end = !has_end || (!rtk_um_is_empty(um_e) && ((c.g.flags[um_e.unitig] & RTK_F_EDGE_MASK) != 0));
     if (ok_start && ok_end) {
         const uint32_t level = 4;
+        const bool lrc = c.o.long_read_correct != 0;
+        const uint32_t max_len_subpath = static_cast<uint32_t>(static_cast<uint64_t>(static_cast<double>(c.k) * c.o.large_k_factor));
         uint64_t mn, mx; rtk_min_max_len(ref_len - k, c.o.weak_region_len_factor, &mn, &mx);
         const uint32_t min_len_path = static_cast<uint32_t>(mn) + k;
         const uint32_t max_len_path = static_cast<uint32_t>(mx > 10 ? mx : 10) + k;
@@ -876,7 +883,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
                         v_tmp[nvt++] = rtk_wp_commit(s, w, 1);
                     }
                     for (uint32_t i = 0; i < n_nt && !rtk_failed(s); ++i) {
-                        if (rtk_rec_n(s, s.list[3][i]) == level) {
+                        if (lrc ? (rtk_rec_l(s, s.list[3][i]) >= max_len_subpath) : (rtk_rec_n(s, s.list[3][i]) == level)) { // :395
                             if (pend.qual_deferred) { // keep what is needed to finish Q when (if) the entry is popped: its unitigs move to the BFS-level arena
                                 rtk_wp_load(s, s.wp[2], s.list[3][i]);
                                 pend_hq = rtk_wp_commit(s, s.wp[2], 1); pend_hp = hp; q_pending = true; q_has = true;
@@ -900,7 +907,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
                         for (uint32_t u = 1; u <= nsub && !rtk_failed(s); ++u) {
                             rtk_wp_load(s, w, hp); rtk_extend_by(c, w, hs, u);
                             if (w.l >= min_len_path && w.l <= max_len_path) { if (nvt >= s.list_cap) { rtk_fail_ovf(s, 8); break; } v_tmp[nvt++] = rtk_wp_commit(s, w, 1); }
-                            if (u == nsub && nsub == level) { qh = rtk_wp_commit(s, w, 1); q_has = true; }
+                            if (u == nsub && (lrc ? (rtk_rec_l(s, hs) >= max_len_subpath) : (nsub == level))) { qh = rtk_wp_commit(s, w, 1); q_has = true; } // :174
                         }
                     }
                     if (nvt >= max_paths) {
@@ -943,7 +950,7 @@ RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint3
     const uint32_t k = static_cast<uint32_t>(c.k);
     const bool no_end = rtk_um_is_empty(end_um);
     const uint32_t pos2 = no_end ? s_len - k : end_pos_in;
-    const uint32_t max_len_weak_region = c.o.max_len_weak_region1;
+    const uint32_t max_len_weak_region = c.o.long_read_correct ? c.o.max_len_weak_region2 : c.o.max_len_weak_region1; // :23
     uint32_t next_weak_pos = 0;
     bool begin = true, end = false;
     WPath& w0 = s.wp[0];
@@ -1258,8 +1265,11 @@ RTK_DEV void rtk_scan_anchor_runs(const Anchors& a, int64_t start, int step, Con
 
 // ------------------------------------------------------------------------------------------------ the `correct` lambda (src/Correction.cpp:431-753)
 // s_read: read in the orientation of this call; v_s / v_w: anchors in that orientation. Result strings go to res.seq / res.qual.
-RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_len_, const Anchors& v_s_, const Anchors& v_w_, uint32_t i_s_, uint32_t i_w_, const ResCorr* rc_, ResCorr& res_) {
-    const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); uint32_t s_len = rtk_u(s_len_); const Anchors& v_s = *rtk_u(&v_s_); const Anchors& v_w = *rtk_u(&v_w_); uint32_t i_s = rtk_u(i_s_); uint32_t i_w = rtk_u(i_w_); const ResCorr* rc = rtk_u(rc_); ResCorr& res = *rtk_u(&res_);
+// q_read: pass 2 only, the quality string that goes with s_read in this call (the reference passes q_fw, q_bw or -- for the head region --
+// q_fw next to the reverse-complemented read, :787 G17); uncorrected stretches keep their qualities instead of getting q_min.
+RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_len_, const Anchors& v_s_, const Anchors& v_w_, uint32_t i_s_, uint32_t i_w_, const ResCorr* rc_, ResCorr& res_, const char* q_read_ = nullptr) {
+    const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); const char* q_read = rtk_u(q_read_);
+    const bool lrc = rtk_u(c.o.long_read_correct) != 0 && q_read != nullptr; uint32_t s_len = rtk_u(s_len_); const Anchors& v_s = *rtk_u(&v_s_); const Anchors& v_w = *rtk_u(&v_w_); uint32_t i_s = rtk_u(i_s_); uint32_t i_w = rtk_u(i_w_); const ResCorr* rc = rtk_u(rc_); ResCorr& res = *rtk_u(&res_);
     RegionScratch& s = *c.sc;
     const uint32_t k = static_cast<uint32_t>(c.k);
     const GraphView& g = c.g;
@@ -1276,7 +1286,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     for (uint32_t w = static_cast<uint32_t>(rtk_lane()); w < (len_weak_region + 63) / 64 + 1; w += RTK_WAVE) res.bm[w] = 0;
     rtk_sync();
     const char q_min = rtk_get_qual(0.0, 0, static_cast<uint64_t>(c.o.max_qual));
-    const uint32_t max_len_weak_anchors = c.o.max_len_weak_region1;
+    const uint32_t max_len_weak_anchors = c.o.long_read_correct ? c.o.max_len_weak_region2 : c.o.max_len_weak_region1; // :177
     // weak anchors inside the region: l_v_w = v_w[lw_lo .. lw_hi)
     uint32_t lw_lo = 0, lw_hi = 0;
     {
@@ -1344,7 +1354,9 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     { const unsigned long long t0 = rtk_clock(); if (n_all >= c.o.min_cov_vertices) complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, 0, &n_partial); s.cnt[6] += rtk_clock() - t0; }
     if (rtk_failed(s)) return;
     const uint32_t nlw = lw_hi - lw_lo;
-    auto add_uncorrected = [&](uint32_t pos, uint32_t len, char q) { rtk_app(s, s_corr, &sl_, s_read + pos, (pos + len <= s_len) ? len : (pos < s_len ? s_len - pos : 0)); rtk_app_fill(s, q_corr, &ql_, q, len_weak_region); };
+    auto clamp_len = [&](uint32_t pos, uint32_t len) -> uint32_t { return (pos + len <= s_len) ? len : (pos < s_len ? s_len - pos : 0); }; // std::string::substr
+    auto add_uncorrected = [&](uint32_t pos, uint32_t len, char q) { rtk_app(s, s_corr, &sl_, s_read + pos, clamp_len(pos, len));
+        if (lrc) rtk_app(s, q_corr, &ql_, q_read + pos, clamp_len(pos, len)); else rtk_app_fill(s, q_corr, &ql_, q, len_weak_region); }; // :459-469
     if (complete == ~0ull) {
         uint32_t i_w_s = 0;
         while (complete == ~0ull && n_partial != 0 && nlw != 0 && n_all >= c.o.min_cov_vertices && !rtk_failed(s)) { // :619-651
@@ -1363,7 +1375,8 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
             rtk_app(s, s_corr, &sl_, s.str[0], pl);
             rtk_app(s, s_corr, &sl_, s_read + p1 + aend + 1, wpos - p1 - static_cast<uint32_t>(aend) - 1);
             rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(hb), rtk_h_off(hb)), rtk_path_hdr(s, rtk_h_lvl(hb), rtk_h_off(hb))->qlen);
-            rtk_app_fill(s, q_corr, &ql_, q_min, wpos - p1 - static_cast<uint32_t>(aend) - 1);
+            if (lrc) rtk_app(s, q_corr, &ql_, q_read + p1 + aend + 1, clamp_len(p1 + static_cast<uint32_t>(aend) + 1, wpos - p1 - static_cast<uint32_t>(aend) - 1)); // :642
+            else rtk_app_fill(s, q_corr, &ql_, q_min, wpos - p1 - static_cast<uint32_t>(aend) - 1);
             rtk_bm_add_range(res.bm, p1 - first_pos, p1 + static_cast<uint32_t>(aend) + 1 - first_pos);
             p1 = wpos; um1 = rtk_an_um(lvw, lw_lo + i_w_s);
             len_weak_region = p2 - p1 + k;
@@ -1390,7 +1403,8 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
                 const uint32_t rest = len_weak_region - static_cast<uint32_t>(aend) - 1;
                 rtk_app(s, s_corr, &sl_, s_read + p1 + aend + 1, rest);
                 rtk_app(s, q_corr, &ql_, rtk_path_qual(s, rtk_h_lvl(hb), rtk_h_off(hb)), rtk_path_hdr(s, rtk_h_lvl(hb), rtk_h_off(hb))->qlen);
-                rtk_app_fill(s, q_corr, &ql_, q_min, rest);
+                if (lrc) rtk_app(s, q_corr, &ql_, q_read + p1 + aend + 1, clamp_len(p1 + static_cast<uint32_t>(aend) + 1, rest)); // :684
+                else rtk_app_fill(s, q_corr, &ql_, q_min, rest);
                 rtk_bm_add_range(res.bm, p1 - first_pos, p1 + static_cast<uint32_t>(aend) + 1 - first_pos);
             }
         } else if (sl_ != 0) add_uncorrected(p1, len_weak_region, q_min);
@@ -1598,18 +1612,34 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     ResCorr fw, bw;
     fw.seq = s.rbuf[0]; fw.qual = s.rbuf[1]; fw.bm = s.bm[0]; bw.seq = s.rbuf[2]; bw.qual = s.rbuf[3]; bw.bm = s.bm[1];
     if (L + 64 > s.str_cap) { rtk_fail_ovf(s, 7); return; }
+    // pass 2 (long_read_correct): the read's own qualities are carried wherever pass 1 writes q_max / q_min, and a stretch whose bases all
+    // have the maximum quality already is left alone (hasMinQual, src/Correction.hpp:45-52; :779, :808, :941)
+    const bool lrc = c.o.long_read_correct != 0 && c.bv.qual.get() != nullptr;
+    const char* q_fw = lrc ? c.bv.qual + base : nullptr; const char* q_bw = lrc ? c.rb.qual_rev + base : nullptr;
+    auto has_min_qual = [&](uint32_t start, uint32_t end) -> bool {
+        for (uint32_t i0 = start; i0 < end; i0 += RTK_WAVE) {
+            const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+            bool bad = false;
+            if (i < end) { const char ch = s_fw[i]; bad = (q_fw[i] < q_max) && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+            if (rtk_ballot(bad) != 0ull) return false;
+        }
+        return true;
+    };
+    auto app_q = [&](uint32_t pos, uint32_t n, char fill) { if (lrc) rtk_app(s, out_q, &oql, q_fw + pos, n); else rtk_app_fill(s, out_q, &oql, fill, n); }; // q_fw.substr(pos, n) | string(n, fill)
     const uint32_t kind = rd->kind;
     if (kind == RTK_RG_WHOLE_MAX || kind == RTK_RG_WHOLE_MIN) { // :165-171
-        rtk_app(s, out_s, &osl, s_fw, L); rtk_app_fill(s, out_q, &oql, kind == RTK_RG_WHOLE_MAX ? q_max : q_min, L);
+        rtk_app(s, out_s, &osl, s_fw, L); app_q(0, L, kind == RTK_RG_WHOLE_MAX ? q_max : q_min);
     } else if (kind == RTK_RG_HEAD) { // :776-797
-        const uint32_t i_solid_rev = so.n - 1;
-        uint32_t i_weak_rev = we.n;
-        while (i_weak_rev > 0 && rtk_an_pos(we_r, i_weak_rev - 1) > rtk_an_pos(so_r, i_solid_rev)) --i_weak_rev;
-        rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_rev, i_weak_rev, nullptr, bw);
-        if (rtk_failed(s)) return;
-        rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
-        rtk_app(s, out_s, &osl, bw.seq, bw.seq_len >= k ? bw.seq_len - k : bw.seq_len); // substr(0, length - k): wraps to "everything" below k
-        rtk_app(s, out_q, &oql, bw.qual, bw.qual_len >= k ? bw.qual_len - k : bw.qual_len);
+        if (!lrc || !has_min_qual(0, so.pos[0] + k)) {
+            const uint32_t i_solid_rev = so.n - 1;
+            uint32_t i_weak_rev = we.n;
+            while (i_weak_rev > 0 && rtk_an_pos(we_r, i_weak_rev - 1) > rtk_an_pos(so_r, i_solid_rev)) --i_weak_rev;
+            rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_rev, i_weak_rev, nullptr, bw, q_fw); // q_fw next to s_bw: as the reference writes it (:787, G17)
+            if (rtk_failed(s)) return;
+            rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
+            rtk_app(s, out_s, &osl, bw.seq, bw.seq_len >= k ? bw.seq_len - k : bw.seq_len); // substr(0, length - k): wraps to "everything" below k
+            rtk_app(s, out_q, &oql, bw.qual, bw.qual_len >= k ? bw.qual_len - k : bw.qual_len);
+        } else { rtk_app(s, out_s, &osl, s_fw, so.pos[0]); app_q(0, so.pos[0], q_min); }
     } else if (kind == RTK_RG_GAP) { // :803-935
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i], pb = so.pos[i + 1];
@@ -1618,7 +1648,8 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
         { uint32_t lo = 0, hi = we.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (we.pos[mid] < pa) lo = mid + 1; else hi = mid; } i_weak = lo; }
         bool isUncorrected = false;
         bool sameUnitig = (ua.unitig == ub.unitig) && (ua.strand == ub.strand);
-        if (sameUnitig && !(c.g.flags[ua.unitig] & RTK_F_SHORT_CYCLE)) { // same-unitig shortcut (:814-858)
+        if (lrc && has_min_qual(pa, pb + k)) isUncorrected = true; // :808
+        else if (sameUnitig && !(c.g.flags[ua.unitig] & RTK_F_SHORT_CYCLE)) { // same-unitig shortcut (:814-858)
             const uint32_t min_pos = ua.dist < ub.dist ? ua.dist : ub.dist, max_pos = ua.dist < ub.dist ? ub.dist : ua.dist;
             const uint32_t len_query_km = pb - pa, len_unitig_km = max_pos - min_pos;
             uint64_t mn, mx; rtk_min_max_len(len_unitig_km, c.o.weak_region_len_factor, &mn, &mx);
@@ -1629,24 +1660,28 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
                 const uint32_t sl = rtk_ums_to_string(c, &sub, 1, s.str[0]); if (sl == 0xFFFFFFFFu) return;
                 rtk_app(s, out_s, &osl, s_fw + prev_pos, pa - prev_pos);
                 rtk_app(s, out_s, &osl, s.str[0], sl >= k ? sl - k : sl);
-                rtk_app_fill(s, out_q, &oql, q_max, (pa - prev_pos) + (sl - k));
+                if (lrc) { // :847-853
+                    const uint32_t buff = (sl >= 2 * k) ? k : (sl - k);
+                    rtk_app(s, out_q, &oql, q_fw + prev_pos, pa - prev_pos + buff);
+                    if (sl - buff - k > 0) rtk_app_fill(s, out_q, &oql, q_max, sl - buff - k);
+                } else rtk_app_fill(s, out_q, &oql, q_max, (pa - prev_pos) + (sl - k));
             } else isUncorrected = true;
         } else if (pb >= pa + k) {
-            rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw);
+            rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw, q_fw);
             if (rtk_failed(s)) return;
             const uint32_t l_solid = pa - prev_pos;
             auto emit_minus_k = [&](const char* seq, uint32_t sl, const char* q, uint32_t ql) { // (prefix + x).substr(0, len - k)
                 const uint32_t ts = l_solid + sl, tq = l_solid + ql;
                 const uint32_t ks = ts >= k ? ts - k : ts, kq = tq >= k ? tq - k : tq;
                 rtk_app(s, out_s, &osl, s_fw + prev_pos, ks < l_solid ? ks : l_solid); if (ks > l_solid) rtk_app(s, out_s, &osl, seq, ks - l_solid);
-                rtk_app_fill(s, out_q, &oql, q_max, kq < l_solid ? kq : l_solid); if (kq > l_solid) rtk_app(s, out_q, &oql, q, kq - l_solid);
+                app_q(prev_pos, kq < l_solid ? kq : l_solid, q_max); if (kq > l_solid) rtk_app(s, out_q, &oql, q, kq - l_solid);
             };
             if (fw.is_corrected) emit_minus_k(fw.seq, fw.seq_len, fw.qual, fw.qual_len);
             else {
                 const uint32_t i_solid_bw = so.n - i - 2;
                 uint32_t i_weak_bw = we.n - i_weak;
                 while (i_weak_bw > 0 && rtk_an_pos(we_r, i_weak_bw - 1) > rtk_an_pos(so_r, i_solid_bw)) --i_weak_bw;
-                rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_bw, i_weak_bw, &fw, bw);
+                rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_bw, i_weak_bw, &fw, bw, q_bw);
                 if (rtk_failed(s)) return;
                 rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
                 if (bw.is_corrected) {
@@ -1662,7 +1697,8 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
                     if (!ok || csl == 0) { // raw region, k solid qualities then minimum quality (:898-904)
                         csl = 0; cql = 0;
                         rtk_app(s, s.rbuf[6], &csl, s_fw + pa, ref_len);
-                        rtk_app_fill(s, s.rbuf[7], &cql, q_max, k); rtk_app_fill(s, s.rbuf[7], &cql, q_min, pb - pa);
+                        if (lrc) rtk_app(s, s.rbuf[7], &cql, q_fw + pa, ref_len); // :902
+                        else { rtk_app_fill(s, s.rbuf[7], &cql, q_max, k); rtk_app_fill(s, s.rbuf[7], &cql, q_min, pb - pa); }
                     }
                     emit_minus_k(s.rbuf[6], csl, s.rbuf[7], cql);
                 }
@@ -1670,25 +1706,33 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
         } else isUncorrected = true;
         if (isUncorrected) { // :920-932
             rtk_app(s, out_s, &osl, s_fw + prev_pos, pb - prev_pos);
-            rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos);
-            if (pb < pa + k) rtk_app_fill(s, out_q, &oql, q_max, pb - pa);
-            else { rtk_app_fill(s, out_q, &oql, q_max, k); rtk_app_fill(s, out_q, &oql, q_min, pb - pa - k); }
+            if (lrc) rtk_app(s, out_q, &oql, q_fw + prev_pos, pb - prev_pos); // :924
+            else {
+                rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos);
+                if (pb < pa + k) rtk_app_fill(s, out_q, &oql, q_max, pb - pa);
+                else { rtk_app_fill(s, out_q, &oql, q_max, k); rtk_app_fill(s, out_q, &oql, q_min, pb - pa - k); }
+            }
         }
     } else if (kind == RTK_RG_TAIL) { // :940-950
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i];
         uint32_t i_weak = 0;
         { uint32_t lo = 0, hi = we.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (we.pos[mid] < pa) lo = mid + 1; else hi = mid; } i_weak = lo; }
-        rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw);
-        if (rtk_failed(s)) return;
-        const uint32_t l_solid = pa - prev_pos;
-        rtk_app(s, out_s, &osl, s_fw + prev_pos, l_solid); rtk_app(s, out_s, &osl, fw.seq, fw.seq_len);
-        rtk_app_fill(s, out_q, &oql, q_max, l_solid); rtk_app(s, out_q, &oql, fw.qual, fw.qual_len);
+        if (lrc && has_min_qual(pa, L)) { // :941: nothing to do, the else branch of :951-955
+            rtk_app(s, out_s, &osl, s_fw + prev_pos, L - prev_pos); rtk_app(s, out_q, &oql, q_fw + prev_pos, L - prev_pos);
+        } else {
+            rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw, q_fw);
+            if (rtk_failed(s)) return;
+            const uint32_t l_solid = pa - prev_pos;
+            rtk_app(s, out_s, &osl, s_fw + prev_pos, l_solid); rtk_app(s, out_s, &osl, fw.seq, fw.seq_len);
+            app_q(prev_pos, l_solid, q_max); rtk_app(s, out_q, &oql, fw.qual, fw.qual_len);
+        }
     } else { // RTK_RG_TAIL_COPY (:951-955)
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i];
         rtk_app(s, out_s, &osl, s_fw + prev_pos, L - prev_pos);
-        rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos + k); rtk_app_fill(s, out_q, &oql, q_min, L - pa - k);
+        if (lrc) rtk_app(s, out_q, &oql, q_fw + prev_pos, L - prev_pos);
+        else { rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos + k); rtk_app_fill(s, out_q, &oql, q_min, L - pa - k); }
     }
     if (rtk_failed(s)) return;
     rtk_emit_segment(c, rd, out_s, osl, out_q, oql);
@@ -1702,6 +1746,7 @@ RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const Regi
     const uint32_t* sp = bv.s_pos + base; const uint32_t ns = bv.n_solid[r];
     // reverse complement of the read (used by the head and backward corrections, src/Correction.cpp:175)
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < L; i += RTK_WAVE) rb.seq_rc[base + i] = rtk_comp(bv.seq[base + (L - 1 - i)]);
+    if (bv.qual.get() != nullptr && rb.qual_rev.get() != nullptr) for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < L; i += RTK_WAVE) rb.qual_rev[base + i] = bv.qual[base + (L - 1 - i)];
     uint32_t n_gaps = 0;
     const bool whole = (L <= k) || ns == 0 || (ns == L - k + 1);
     if (!whole) for (uint32_t c0 = 0; c0 + 1 < ns; c0 += RTK_WAVE) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); n_gaps += static_cast<uint32_t>(rtk_popc(rtk_ballot(i + 1 < ns && sp[i] != sp[i + 1] - 1))); }

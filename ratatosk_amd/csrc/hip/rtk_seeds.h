@@ -16,12 +16,16 @@ struct OptsView {
     U<double> weak_region_len_factor, large_k_factor, min_score;
     U<int32_t> max_qual, out_qual;
     U<double> min_confidence_snp_corr;
+    // second pass (`correct -2`, long_read_correct in the reference): qualities of pass 1 are carried over, no 1-edit search
+    U<int32_t> long_read_correct;
+    U<uint32_t> max_len_weak_region2;
 };
 
 struct BatchView {
     U<uint32_t> n_reads;
     U<uint64_t> n_bases;
     U<const char*> seq;          // upper-cased reads, concatenated
+    U<const char*> qual;         // pass 2: the reads' quality strings (same offsets as seq); null in pass 1, which writes its own
     U<const uint64_t*> roff;     // [n_reads+1]
     U<const uint32_t*> order;    // [n_reads] read indices, longest first (per-read kernels start their longest items first)
     U<uint64_t*> hits;           // [n_bases] exact hit of the window starting at each base (packed, RTK_NO_HIT if none)
