@@ -126,6 +126,11 @@ int rtk_correct_batch(rtk_graph* g, const rtk_opts* opts, uint32_t n, const char
 /* Same work split so that a caller can keep the batch resident in HBM across the timed region:
  * create = pack + H2D copy, run = kernels only (synchronous), fetch = D2H + unpack. */
 int rtk_batch_create(rtk_graph* g, uint32_t n, const char* const* seq, const char* const* qual, const uint32_t* len, rtk_batch** out);
+/* Second pass (`correct -2`): the pass-1 corrected reads WITH their qualities plus the uncorrected reads in the same order (the
+ * reference reads the two files in lock-step and aborts when the names disagree, src/Ratatosk.cpp:774-802). Run with
+ * opts->long_read_correct = 1: phasing() (src/Graph.cpp:869-1097) runs on the device before the seed stage. */
+int rtk_batch_create2(rtk_graph* g, uint32_t n, const char* const* seq, const char* const* qual, const uint32_t* len,
+                      const char* const* raw, const uint32_t* raw_len, rtk_batch** out);
 int rtk_batch_run(rtk_batch* b, const rtk_opts* opts);
 /* rtk_batch_run = rtk_batch_run_seeds (getSeeds of every read: src/Graph.cpp:3-482) followed by rtk_batch_run_regions (correctSequence
  * of every read: src/Correction.cpp:159-958). Every batch owns a HIP stream, and each call only waits for that stream: calling the

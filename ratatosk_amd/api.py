@@ -66,6 +66,8 @@ def load_library(path=None):
     L.rtk_correct_batch.argtypes = [C.c_void_p, C.POINTER(RtkOpts), C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
     L.rtk_batch_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]
+    L.rtk_batch_create2.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]
     L.rtk_batch_run.argtypes = [C.c_void_p, C.POINTER(RtkOpts)]
     L.rtk_graph_strip_annotations.restype = C.c_longlong
     L.rtk_graph_strip_annotations.argtypes = [C.c_void_p]
@@ -147,9 +149,10 @@ class Graph:
         f = lambda a, n: [(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]) for i in range(n)]
         return f(so, ns.value), f(we, nw.value)
 
-    def correct_batch(self, seqs, quals=None, opts=None):
-        """[(corrected seq, corrected qual)] for a batch of long reads (one call == one ticket batch)."""
-        b = Batch(self, seqs, quals)
+    def correct_batch(self, seqs, quals=None, opts=None, raw=None):
+        """[(corrected seq, corrected qual)] for a batch of long reads (one call == one ticket batch).
+        Second pass: opts.long_read_correct = 1, quals = the pass-1 qualities, raw = the uncorrected reads (same order)."""
+        b = Batch(self, seqs, quals, raw)
         try:
             b.run(opts)
             return b.fetch()
@@ -160,7 +163,7 @@ class Graph:
 class Batch:
     """A batch of long reads resident in HBM: create (H2D) / run (kernels) / fetch (D2H)."""
 
-    def __init__(self, graph, seqs, quals=None):
+    def __init__(self, graph, seqs, quals=None, raw=None):
         self.g = graph
         self.L = graph.L
         n = len(seqs)
@@ -174,7 +177,13 @@ class Batch:
         self.n = n
         self.in_bases = sum(len(b) for b in bs)
         self.h = C.c_void_p()
-        graph._check(self.L.rtk_batch_create(graph.h, n, seq_arr, qual_arr, lens, C.byref(self.h)))
+        if raw is not None:
+            br = [_b(s) for s in raw]
+            raw_arr = (C.c_char_p * n)(*br)
+            raw_lens = (C.c_uint32 * n)(*[len(b) for b in br])
+            graph._check(self.L.rtk_batch_create2(graph.h, n, seq_arr, qual_arr, lens, raw_arr, raw_lens, C.byref(self.h)))
+        else:
+            graph._check(self.L.rtk_batch_create(graph.h, n, seq_arr, qual_arr, lens, C.byref(self.h)))
 
     def run(self, opts=None):
         o = opts or self.g.opts()
