@@ -12,8 +12,12 @@
 //                   guaranteed for pass 1: src/Ratatosk.cpp:919); workers that run too far ahead of the writer wait.
 // The index is parsed and flattened ONCE (-c threads), uploaded to the first GPU and replicated device-to-device to the others.
 // `-c` keeps the reference's meaning (host threads, <= hardware concurrency: src/Ratatosk.cpp:318); GPUs are chosen with --gpus.
-// Everything else (`index`, `-2`, `-u`, `-p/-P`) is out of scope.
+// `correct -2 -g G2 -d D2 -l OUT.2.fastq -L raw_reads -o OUT` is the second pass (src/Ratatosk.cpp:1163-1262 with a pre-built second
+// index): the uncorrected reads are read in lock-step with the pass-1 reads (:774-802), qualities are kept, output goes to OUT.fastq
+// (:622), optionally gzipped (-G; one gzip member per ticket block, compressed by the workers) and trimmed / split at low-quality
+// bases (-t, :508-563). Everything else (`index`, `-u`, `-p/-P`, `-a`, `-f`) is out of scope.
 #include <getopt.h>
+#include <zlib.h>
 
 #include <atomic>
 #include <chrono>
@@ -33,12 +37,12 @@
 #include "ratatosk_hip.h"
 
 struct Opt {
-    std::vector<std::string> in_long;
+    std::vector<std::string> in_long, in_long_raw;
     std::string out, graph, udata;
-    int cores = 1, gpus = 0, workers_per_gpu = 3, k1 = 31, max_qual = 40;
+    int cores = 1, gpus = 0, workers_per_gpu = 3, k1 = 31, k2 = 63, max_qual = 40, trim = 0;
     double min_conf_snp = 0.9;
-    size_t insert_sz = 500, w1 = 1000, batch_bases = 32u << 20;
-    bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false;
+    size_t insert_sz = 500, w1 = 1000, w2 = 5000, batch_bases = 32u << 20;
+    bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false, gzip = false;
 };
 
 static void usage() {
@@ -51,13 +55,45 @@ static void usage() {
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
                     "  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
                     "      --strip-annotations  drop the short-cycle / SNP annotations of the index before correcting (fixRepeats / fixAmbiguity then have nothing to do)\n"
-                    "Writes <out_prefix>.2.fastq (plain FASTQ, input order). Only the `correct -1` step with a pre-built index is in scope.\n");
+                    "Writes <out_prefix>.2.fastq (plain FASTQ, input order).\n\n"
+                    "       Ratatosk correct -2 -g <graph2.fasta.gz> -d <unitig_data2.rtsk> -l <out_prefix>.2.fastq -L <long_reads> -o <out_prefix> [options]\n"
+                    "  -L, --in-long-raw     the uncorrected long reads, same order as -l\n  -K, --k2              k-mer length of the 2nd pass graph (default 63)\n"
+                    "  -W, --max-len-weak2   maximum weak region length, 2nd pass (default 5000)\n  -t, --trim-split      trim and split reads at bases with quality below this (default 0: off)\n"
+                    "  -G, --gzip-out        write <out_prefix>.fastq.gz\nWrites <out_prefix>.fastq. Only `correct` with a pre-built index is in scope.\n");
 }
 
 struct Ticket { // one batch of reads, packed: the reference's >= buffer_sz unit of work (src/Common.hpp:138, src/Ratatosk.cpp:757)
     size_t id = 0;
-    rtk::PackedReads reads;
+    rtk::PackedReads reads, raw; // raw: second pass only
+    Ticket(bool keep_qual) : reads(keep_qual), raw(false) {}
 };
+
+// writeCorrectedOutput with trim != 0 (src/Ratatosk.cpp:522-562): maximal runs of bases with quality >= trim, at least k long, as NAME/1, NAME/2, ...
+static void append_trimmed(std::string& out, const char* name, size_t name_len, const char* seq, const char* qual, size_t len, int k, int trim) {
+    const char c_min = static_cast<char>(trim + 33);
+    long long start = -1, run = -1, id = 1;
+    auto emit = [&]() {
+        out += '@'; out.append(name, name_len); out += '/'; out += std::to_string(id++); out += '\n';
+        out.append(seq + start, static_cast<size_t>(run)); out += "\n+\n"; out.append(qual + start, static_cast<size_t>(run)); out += '\n';
+    };
+    for (size_t pos = 0; pos < len; ++pos) {
+        if (qual[pos] >= c_min) { if (start == -1) { start = static_cast<long long>(pos); run = 0; } ++run; }
+        else { if (run >= k) emit(); start = -1; run = -1; }
+    }
+    if (run >= k) emit();
+}
+
+static bool gzip_member(const std::string& in, std::string& out) { // one self-contained gzip member; members concatenate into a valid .gz
+    z_stream zs; memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&zs, in.size()) + 32);
+    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(in.data())); zs.avail_in = static_cast<uInt>(in.size());
+    zs.next_out = reinterpret_cast<Bytef*>(&out[0]); zs.avail_out = static_cast<uInt>(out.size());
+    const int rc = deflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return rc == Z_STREAM_END;
+}
 
 int main(int argc, char** argv) {
     Opt opt;
@@ -69,9 +105,10 @@ int main(int argc, char** argv) {
     static struct option lo[] = {{"in-long", required_argument, 0, 'l'}, {"out-long", required_argument, 0, 'o'}, {"cores", required_argument, 0, 'c'},
         {"in-graph", required_argument, 0, 'g'}, {"in-unitig-data", required_argument, 0, 'd'}, {"insert-sz", required_argument, 0, 'i'}, {"k1", required_argument, 0, 'k'},
         {"max-len-weak1", required_argument, 0, 'w'}, {"max-base-qual", required_argument, 0, 'Q'}, {"min-conf-snp-corr", required_argument, 0, 'm'}, {"1st-pass-only", no_argument, 0, '1'}, {"2nd-pass-only", no_argument, 0, '2'},
+        {"in-long-raw", required_argument, 0, 'L'}, {"k2", required_argument, 0, 'K'}, {"max-len-weak2", required_argument, 0, 'W'}, {"trim-split", required_argument, 0, 't'}, {"gzip-out", no_argument, 0, 'G'},
         {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"gpus", required_argument, 0, 1002}, {"workers-per-gpu", required_argument, 0, 1003}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
     int c, idx = 0;
-    while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:12v", lo, &idx)) != -1) {
+    while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:L:K:W:t:G12v", lo, &idx)) != -1) {
         switch (c) {
             case 'l': opt.in_long.push_back(optarg); break;
             case 'o': opt.out = optarg; break;
@@ -84,6 +121,11 @@ int main(int argc, char** argv) {
             case 'Q': opt.max_qual = atoi(optarg); break;
             case 'm': opt.min_conf_snp = atof(optarg); break;
             case 'B': opt.batch_bases = strtoull(optarg, nullptr, 10); break;
+            case 'L': opt.in_long_raw.push_back(optarg); break;
+            case 'K': opt.k2 = atoi(optarg); break;
+            case 'W': opt.w2 = strtoull(optarg, nullptr, 10); break;
+            case 't': opt.trim = atoi(optarg); break;
+            case 'G': opt.gzip = true; break;
             case '1': opt.pass1 = true; break;
             case '2': opt.pass2 = true; break;
             case 'v': opt.verbose = true; break;
@@ -94,7 +136,10 @@ int main(int argc, char** argv) {
             default: usage(); return 0; // the reference returns 0 on option errors too (src/Ratatosk.cpp:1018)
         }
     }
-    if (opt.pass2 || !opt.pass1) { fprintf(stderr, "Ratatosk::correct: only the first pass (-1) with a pre-built index (-g, -d) is in scope of this build\n"); return 1; }
+    if (opt.pass1 == opt.pass2) { fprintf(stderr, "Ratatosk::correct: one pass per run with a pre-built index (-g, -d): give -1 or -2\n"); return 1; }
+    const bool lrc = opt.pass2;
+    if (lrc && opt.in_long_raw.empty()) { fprintf(stderr, "Ratatosk::correct: -2 needs the uncorrected long reads (-L) next to the pass-1 reads (-l)\n"); return 0; }
+    if (opt.trim < 0 || opt.trim > opt.max_qual) { fprintf(stderr, "Ratatosk::Ratatosk(): Quality score trimming threshold cannot be less than 0 or more than %d (%d given).\n", opt.max_qual, opt.trim); /* src/Ratatosk.cpp:324-326 */ return 0; }
     if (opt.graph.empty() || opt.udata.empty() || opt.in_long.empty() || opt.out.empty()) { fprintf(stderr, "Ratatosk::correct: -g, -d, -l and -o are required\n"); return 0; }
     { // src/Ratatosk.cpp:312-322
         const unsigned hc = std::thread::hardware_concurrency();
@@ -111,8 +156,10 @@ int main(int argc, char** argv) {
     const int n_gpus = opt.gpus ? opt.gpus : n_dev;
 
     // input files (a text file lists one path per line: src/Common.cpp:428-446)
-    std::vector<std::string> files;
+    std::vector<std::string> files, files_raw;
     for (size_t i = 0; i < opt.in_long.size(); ++i) { const std::vector<std::string> v = rtk::expand_input_list(opt.in_long[i]); files.insert(files.end(), v.begin(), v.end()); }
+    for (size_t i = 0; i < opt.in_long_raw.size(); ++i) { const std::vector<std::string> v = rtk::expand_input_list(opt.in_long_raw[i]); files_raw.insert(files_raw.end(), v.begin(), v.end()); }
+    const int k_graph = lrc ? opt.k2 : opt.k1;
 
     auto now_us = []() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (opt.verbose) printf("Ratatosk::Ratatosk(): Reading graph.\n");
@@ -122,7 +169,7 @@ int main(int argc, char** argv) {
     std::vector<std::thread> reservers;
     for (int w = 0; w < n_gpus; ++w) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
     { // ONE parse + flatten, ONE host image; the other GPUs get device-to-device copies of the flat buffers
-        bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), opt.k1, opt.cores, &graphs[0]) == RTK_OK;
+        bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), k_graph, opt.cores, &graphs[0]) == RTK_OK;
         if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[0]); if (ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs\n", ns); }
         ok = ok && rtk_graph_upload(graphs[0], 0) == RTK_OK;
         for (int w = 1; ok && w < n_gpus; ++w) ok = rtk_graph_clone_to_device(graphs[0], w, &graphs[w]) == RTK_OK;
@@ -131,14 +178,18 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join();
     const long long t_load1 = now_us();
     rtk_opts ro; rtk_opts_default(graphs[0], &ro);
-    ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_qual = opt.max_qual; ro.min_confidence_snp_corr = opt.min_conf_snp;
+    ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_len_weak_region2 = opt.w2; ro.max_qual = opt.max_qual; ro.min_confidence_snp_corr = opt.min_conf_snp;
+    ro.long_read_correct = lrc ? 1 : 0;
+    const bool gz_out = opt.gzip && lrc; // compress_out && long_read_correct (src/Ratatosk.cpp:620); output order is kept either way here
+    const int trim = lrc ? opt.trim : 0; // pass 1 qualities are placeholders: the reference trims the final output only (src/Ratatosk.cpp:965-975)
 
-    const std::string fn_out = opt.out + ".2.fastq"; // opt_pass1.filename_long_out += ".2" (src/Ratatosk.cpp:1079) + ".fastq" (:622)
-    FILE* fout = fopen(fn_out.c_str(), "w");
+    // pass 1: opt_pass1.filename_long_out += ".2" (src/Ratatosk.cpp:1079) + ".fastq" (:622); pass 2: OUT.fastq[.gz]
+    const std::string fn_out = opt.out + (lrc ? ".fastq" : ".2.fastq") + (gz_out ? ".gz" : "");
+    FILE* fout = fopen(fn_out.c_str(), "wb");
     if (!fout) { fprintf(stderr, "Ratatosk::search(): cannot open %s for writing\n", fn_out.c_str()); exit(1); }
     setvbuf(fout, nullptr, _IOFBF, 8u << 20);
 
-    if (opt.verbose) printf("Ratatosk::Ratatosk(): Correcting long reads (1/2).\n");
+    if (opt.verbose) printf("Ratatosk::Ratatosk(): Correcting long reads (%d/2).\n", lrc ? 2 : 1);
     const int n_workers = opt.workers_per_gpu * n_gpus;
     const size_t q_cap = static_cast<size_t>(n_workers) + 2, ahead_cap = 2 * static_cast<size_t>(n_workers) + 2;
     std::mutex m_in, m_out; std::condition_variable cv_in_full, cv_in_empty, cv_out;
@@ -157,15 +208,28 @@ int main(int argc, char** argv) {
     };
 
     std::thread reader_thread([&]() {
-        rtk::FastxReader reader; size_t file_i = 0; bool file_open = false, eof_all = false; size_t ticket = 0;
+        rtk::FastxReader reader, reader_raw; size_t file_i = 0, file_raw_i = 0; bool file_open = false, file_raw_open = false, eof_all = false; size_t ticket = 0;
+        const char* out_of_step = "Ratatosk::correct(): Corrected read file is not in the same order as input long read file. Abort."; // src/Ratatosk.cpp:787,796
         while (!eof_all && !failed) {
             const long long tp0 = now_us();
-            std::unique_ptr<Ticket> t(new Ticket()); t->id = ticket;
+            std::unique_ptr<Ticket> t(new Ticket(lrc)); t->id = ticket;
             t->reads.reserve(opt.batch_bases + (opt.batch_bases >> 3));
             while (t->reads.n_bases() < opt.batch_bases) {
                 if (!file_open) { if (file_i >= files.size()) { eof_all = true; break; } if (!reader.open(files[file_i++])) { fail("Ratatosk::search(): cannot open input file " + files[file_i - 1]); return; } file_open = true; }
                 if (!reader.next_packed(t->reads)) { file_open = false; continue; }
                 if (opt.verbose && ((n_reads.fetch_add(1) + 1) % 1000 == 0)) printf("Ratatosk::correct(): Processed %lld reads \n", n_reads.load());
+            }
+            if (lrc) { // the uncorrected reads in lock-step (src/Ratatosk.cpp:774-802)
+                while (t->raw.size() < t->reads.size()) {
+                    if (!file_raw_open) { if (file_raw_i >= files_raw.size()) break; if (!reader_raw.open(files_raw[file_raw_i++])) { fail("Ratatosk::search(): cannot open input file " + files_raw[file_raw_i - 1]); return; } file_raw_open = true; }
+                    if (!reader_raw.next_packed(t->raw)) { file_raw_open = false; continue; }
+                }
+                if (t->raw.size() != t->reads.size()) { fail(out_of_step); return; }
+                for (size_t i = 0; i < t->reads.size(); ++i) { // names are compared from their second character on, like the reference (:794)
+                    const size_t la = t->reads.name_len(i), lb = t->raw.name_len(i);
+                    if (la == 0 || lb == 0 || la != lb || memcmp(t->reads.name(i) + 1, t->raw.name(i) + 1, la - 1) != 0) { fail(out_of_step); return; }
+                    if (t->reads.qual(i) == nullptr && t->reads.seq_len(i)) { fail("Ratatosk::correct(): the second pass needs the base qualities of the first (FASTQ input for -l)"); return; }
+                }
             }
             us_parse += now_us() - tp0;
             if (t->reads.size() == 0) break;
@@ -203,7 +267,13 @@ int main(int argc, char** argv) {
             for (uint32_t i = 0; i < n; ++i) { ps[i] = R.seq(i); len[i] = R.seq_len(i); }
             const long long tc0 = now_us();
             rtk_batch* b = nullptr;
-            int rc = rtk_batch_create(g, n, ps.data(), nullptr, len.data(), &b); // pass 1 replaces every quality (src/Correction.cpp:184-185)
+            int rc;
+            if (lrc) {
+                static const char none[1] = {0};
+                std::vector<const char*> pq(n), pr(n); std::vector<uint32_t> rlen(n);
+                for (uint32_t i = 0; i < n; ++i) { pq[i] = R.qual(i) ? R.qual(i) : none; pr[i] = t->raw.seq(i); rlen[i] = t->raw.seq_len(i); }
+                rc = rtk_batch_create2(g, n, ps.data(), pq.data(), len.data(), pr.data(), rlen.data(), &b);
+            } else rc = rtk_batch_create(g, n, ps.data(), nullptr, len.data(), &b); // pass 1 replaces every quality (src/Correction.cpp:184-185)
             if (rc == RTK_OK) rc = rtk_batch_run(b, &ro);
             const char* pool = nullptr; const uint64_t* off = nullptr; const uint32_t* olen = nullptr;
             if (rc == RTK_OK) rc = rtk_batch_fetch_view(b, &pool, &off, &olen);
@@ -211,8 +281,11 @@ int main(int argc, char** argv) {
             if (rc != RTK_OK) { fail(std::string("Ratatosk::correct(): ") + rtk_last_error()); if (b) rtk_batch_free(b); return; }
             const long long tf0 = now_us();
             std::string block;
-            { size_t tot = 0; for (uint32_t i = 0; i < n; ++i) tot += R.name_len(i) + 2ull * olen[i] + 6; block.resize(tot); }
-            { // writeCorrectedOutput, trim == 0 (src/Ratatosk.cpp:516-520): "@name\nseq\n+\nqual\n"
+            if (trim) {
+                for (uint32_t i = 0; i < n; ++i) append_trimmed(block, R.name(i), R.name_len(i), pool + off[i], pool + off[i] + olen[i], olen[i], k_graph, trim);
+            } else {
+              { size_t tot = 0; for (uint32_t i = 0; i < n; ++i) tot += R.name_len(i) + 2ull * olen[i] + 6; block.resize(tot); }
+              // writeCorrectedOutput, trim == 0 (src/Ratatosk.cpp:516-520): "@name\nseq\n+\nqual\n"
                 char* p = &block[0];
                 for (uint32_t i = 0; i < n; ++i) {
                     *p++ = '@'; memcpy(p, R.name(i), R.name_len(i)); p += R.name_len(i); *p++ = '\n';
@@ -221,6 +294,7 @@ int main(int argc, char** argv) {
                 }
             }
             rtk_batch_free(b);
+            if (gz_out) { std::string z; if (!gzip_member(block, z)) { fail("Ratatosk::search(): gzip compression failed"); return; } block.swap(z); }
             us_format += now_us() - tf0;
             {
                 std::unique_lock<std::mutex> lk(m_out);

@@ -24,7 +24,8 @@ def _second_pass_set(tmpdir, name, sim_args):
     with open(p1, "w") as f:
         for r, (s, q) in zip(raw, out):
             f.write("@%s\n%s\n+\n%s\n" % (r[0], s, q))
-    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", p1, "--colour-reads", p1, "-o", pre + ".p2"], stderr=subprocess.DEVNULL)
+    # the reference's second graph is the short-read graph at k2, coloured by the pass-1 reads (src/Ratatosk.cpp:1193,1227)
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "--colour-reads", p1, "-o", pre + ".p2"], stderr=subprocess.DEVNULL)
     return pre
 
 
@@ -97,3 +98,74 @@ def test_gpu_pass2_matches_oracle(ds_pass2_big):
 @pytest.mark.gpu
 def test_gpu_pass2_small(ds_pass2):
     _check_pass2(ds_pass2, GPU_LIB)
+
+
+def _trim_records(name, seq, qual, k, trim):
+    """writeCorrectedOutput (src/Ratatosk.cpp:508-563), restated for the test."""
+    if trim == 0:
+        return [(name, seq, qual)]
+    out, start, run = [], -1, -1
+    for pos, c in enumerate(qual):
+        if ord(c) >= trim + 33:
+            if start == -1:
+                start, run = pos, 0
+            run += 1
+        else:
+            if run >= k:
+                out.append(("%s/%d" % (name, len(out) + 1), seq[start:start + run], qual[start:start + run]))
+            start, run = -1, -1
+    if run >= k:
+        out.append(("%s/%d" % (name, len(out) + 1), seq[start:start + run], qual[start:start + run]))
+    return out
+
+
+def _cli_pass2(exe, pre, tmp_path, extra, env=None):
+    out = str(tmp_path / "out")
+    r = subprocess.run([exe, "correct", "-2", "-K", "31", "-c", "2", "-B", "20000", "-g", pre + ".p2.index.k31.fasta.gz", "-d", pre + ".p2.index.k31.rtsk",
+                        "-l", pre + ".pass1.fq", "-L", pre + ".lr.fq", "-o", out] + extra, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def _expected_pass2(pre):
+    og, _, seqs, quals, raws = _load(pre, SIM_LIB)
+    names = [r[0] for r in op.read_fastq(pre + ".pass1.fq")]
+    return names, og.correct_batch2(seqs, quals, raws, og.opts(long_read_correct=1), threads=8)
+
+
+def _check_cli_pass2(exe, pre, tmp_path, env=None):
+    names, want = _expected_pass2(pre)
+    out = _cli_pass2(exe, pre, tmp_path, [], env)
+    got = op.read_fastq(out + ".fastq")
+    assert [(g[1], g[2]) for g in got] == want and [g[0] for g in got] == names
+    # -t 20 -G: trimmed / split records, gzip members per ticket block
+    out = _cli_pass2(exe, pre, tmp_path, ["-t", "20", "-G"], env)
+    got = op.read_fastq(out + ".fastq.gz")
+    exp = [rec for n_, (s, q) in zip(names, want) for rec in _trim_records(n_, s, q, 31, 20)]
+    assert got == exp and 0 < len(exp) and any("/2" in e[0] for e in exp)
+
+
+def test_sim_cli_pass2(ds_pass2, tmp_path):
+    sim = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "Ratatosk_sim")
+    env = dict(os.environ, RTK_SIM_DEVICES="2")
+    _check_cli_pass2(sim, ds_pass2, tmp_path, env)
+    # reads out of step with the uncorrected file: the reference aborts (src/Ratatosk.cpp:787-797)
+    raw = op.read_fastq(ds_pass2 + ".lr.fq")
+    swapped = str(tmp_path / "swapped.fq")
+    with open(swapped, "w") as f:
+        for r in [raw[1], raw[0]] + raw[2:]:
+            f.write("@%s\n%s\n+\n%s\n" % r)
+    r = subprocess.run([sim, "correct", "-2", "-K", "31", "-g", ds_pass2 + ".p2.index.k31.fasta.gz", "-d", ds_pass2 + ".p2.index.k31.rtsk", "-l", ds_pass2 + ".pass1.fq",
+                        "-L", swapped, "-o", str(tmp_path / "bad")], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "not in the same order" in r.stderr and not os.path.exists(str(tmp_path / "bad.fastq"))
+
+
+@pytest.mark.gpu
+def test_gpu_cli_pass1_then_pass2(ds_pass2, tmp_path):
+    """`correct -1` then `correct -2` through the executable: both files equal the oracle's."""
+    exe = os.path.join(BIN, "Ratatosk")
+    out = str(tmp_path / "p1")
+    r = subprocess.run([exe, "correct", "-1", "-c", "2", "-g", ds_pass2 + ".index.k31.fasta.gz", "-d", ds_pass2 + ".index.k31.rtsk", "-l", ds_pass2 + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out + ".2.fastq").read() == open(ds_pass2 + ".pass1.fq").read()
+    _check_cli_pass2(exe, ds_pass2, tmp_path)
