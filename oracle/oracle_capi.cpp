@@ -44,7 +44,7 @@ void orc_graph_free(void* g) { delete static_cast<Graph*>(g); }
 
 void orc_graph_stats(void* gp, uint64_t* n_unitigs, uint64_t* n_kmers, uint64_t* max_km_cov_001) {
     const Graph* g = static_cast<const Graph*>(gp);
-    *n_unitigs = g->seq.size(); *n_kmers = g->kmap.size(); *max_km_cov_001 = g->maxKmerCoverage(0.001);
+    *n_unitigs = g->seq.size(); *n_kmers = g->kmap.size() + g->kmap_w.size(); *max_km_cov_001 = g->maxKmerCoverage(0.001);
 }
 
 // unitig record: sequence + the two data words + colour sets, for cross-checking the product's flat graph

@@ -110,8 +110,8 @@ size_t set_inter_card(const IdSet& a, const IdSet& b) {
 
 void Graph::load(const std::string& fasta_gz, const std::string& rtsk, int k_) {
     k = k_;
-    if (k < 3 || k > 31) throw std::runtime_error("oracle: k must be in [3,31]");
-    seq.clear(); info.clear(); globals.clear(); kmap.clear();
+    if (k < 3 || k > 63) throw std::runtime_error("oracle: k must be in [3,63]");
+    seq.clear(); info.clear(); globals.clear(); kmap.clear(); kmap_w.clear();
     gzFile f = gzopen(fasta_gz.c_str(), "rb");
     if (!f) throw std::runtime_error("oracle: cannot open " + fasta_gz);
     {
@@ -131,6 +131,15 @@ void Graph::load(const std::string& fasta_gz, const std::string& rtsk, int k_) {
         std::string& s = seq[u];
         for (size_t i = 0; i < s.size(); ++i) s[i] = static_cast<char>(s[i] & 0xDF);
         if (s.size() < static_cast<size_t>(k)) throw std::runtime_error("oracle: unitig shorter than k");
+        if (k > 31) { // canonical = the smaller of the k-mer and its reverse complement as strings (A < C < G < T, the order of the 2-bit codes)
+            for (size_t i = 0; i < s.size(); ++i) if (code(s[i]) < 0) throw std::runtime_error("oracle: non-ACGT in unitig");
+            for (size_t i = 0; i + static_cast<size_t>(k) <= s.size(); ++i) {
+                const std::string fw = s.substr(i, static_cast<size_t>(k)), rc = revcomp(fw);
+                const uint64_t val = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i) << 1) | (fw < rc ? 1ULL : 0ULL);
+                if (!kmap_w.insert(std::make_pair(fw < rc ? fw : rc, val)).second) throw std::runtime_error("oracle: duplicate k-mer across unitigs (input is not a compacted dBG)");
+            }
+            continue;
+        }
         uint64_t fw = 0; const uint64_t mask = (1ULL << (2 * k)) - 1;
         for (size_t i = 0; i < s.size(); ++i) {
             const int c = code(s[i]);
@@ -228,6 +237,14 @@ std::vector<std::pair<size_t, char> > Graph::ambiguityChars(const UM& um) const 
 }
 
 UM Graph::findKmer(const char* s) const {
+    if (k > 31) {
+        for (int i = 0; i < k; ++i) if (code(s[i]) < 0) return UM();
+        const std::string fws(s, static_cast<size_t>(k)), rcs = revcomp(fws);
+        std::unordered_map<std::string, uint64_t>::const_iterator it = kmap_w.find(fws < rcs ? fws : rcs);
+        if (it == kmap_w.end()) return UM();
+        const bool stored_is_can = it->second & 1ULL, query_is_can = fws < rcs;
+        return UM(static_cast<int32_t>(it->second >> 32), static_cast<uint32_t>((it->second & 0xFFFFFFFFULL) >> 1), 1, stored_is_can == query_is_can);
+    }
     uint64_t fw = 0;
     for (int i = 0; i < k; ++i) { const int c = code(s[i]); if (c < 0) return UM(); fw = (fw << 2) | static_cast<uint64_t>(c); }
     return findKmerCode(fw);

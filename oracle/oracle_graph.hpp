@@ -67,6 +67,7 @@ struct Graph {
     std::vector<UnitigInfo> info;
     std::vector<IdSet> globals;
     std::unordered_map<uint64_t, uint64_t> kmap; // canonical k-mer -> unitig<<32 | offset<<1 | (stored orientation == canonical)
+    std::unordered_map<std::string, uint64_t> kmap_w; // the same for k in 33..63 (second pass, k2 = 63), keyed by the canonical k-mer as TEXT
 
     // loads PREFIX unitig FASTA(.gz) + .rtsk (formats: SURVEY.md Appendix B). Throws std::runtime_error.
     void load(const std::string& fasta_gz, const std::string& rtsk, int k_);

@@ -14,7 +14,7 @@
 
 namespace rtk {
 
-static const int RTK_MAX_K = 31; // pass-1 scope (k=31); k=63 (pass 2) is a "next" row
+static const int RTK_MAX_K = 63; // MAX_KMER_SIZE = 64 build of the reference (CMakeLists.txt:6): k1 = 31 one-word codes, k2 = 63 two-word codes
 
 inline int base2bits(char c) {
     switch (c) {
@@ -64,6 +64,33 @@ inline uint64_t kmer_canonical(uint64_t fw, int k, bool* is_fw = nullptr) {
     const uint64_t rc = kmer_revcomp(fw, k);
     if (is_fw) *is_fw = (fw <= rc);
     return fw <= rc ? fw : rc;
+}
+
+// ---- k in 33..63: the same operations on 128-bit codes (host tools only; the device has its own two-word form, hip/rtk_types.h) ----
+typedef unsigned __int128 u128;
+template <class KM> inline KM km_mask(int k) { return (2 * k >= static_cast<int>(8 * sizeof(KM))) ? ~static_cast<KM>(0) : ((static_cast<KM>(1) << (2 * k)) - static_cast<KM>(1)); }
+inline u128 kmer_revcomp(u128 x, int k) {
+    const u128 full = (static_cast<u128>(kmer_revcomp(static_cast<uint64_t>(x), 32)) << 64) | static_cast<u128>(kmer_revcomp(static_cast<uint64_t>(x >> 64), 32));
+    return full >> (128 - 2 * k);
+}
+inline u128 kmer_canonical(u128 fw, int k, bool* is_fw = nullptr) {
+    const u128 rc = kmer_revcomp(fw, k);
+    if (is_fw) *is_fw = (fw <= rc);
+    return fw <= rc ? fw : rc;
+}
+inline uint64_t hash64(uint64_t x);
+inline uint64_t hash_km(uint64_t x) { return hash64(x); }
+inline uint64_t hash_km(u128 x) { return hash64(static_cast<uint64_t>(x) ^ hash64(static_cast<uint64_t>(x >> 64) ^ 0x9e3779b97f4a7c15ULL)); }
+template <class KM> inline bool km_encode(const char* s, int k, KM& out) {
+    KM x = 0;
+    for (int i = 0; i < k; ++i) { const int b = base2bits(s[i]); if (b < 0) return false; x = (x << 2) | static_cast<KM>(b); }
+    out = x;
+    return true;
+}
+template <class KM> inline std::string km_decode(KM x, int k) {
+    std::string s(k, 'A');
+    for (int i = 0; i < k; ++i) s[i] = bits2base(static_cast<int>(static_cast<uint64_t>(x >> (2 * (k - 1 - i))) & 3));
+    return s;
 }
 
 // Encode s[0..k) ; returns false if a non-ACGT character is met.

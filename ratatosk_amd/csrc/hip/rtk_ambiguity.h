@@ -105,9 +105,9 @@ RTK_FN uint32_t rtk_amb_collect(const RCtx& c_, uint64_t h_, uint32_t offset_, u
 
 // Bifrost findUnitig(s, pos, len) [A7]: the k-mer at s+pos extended along its unitig while s keeps agreeing; on the reverse strand
 // the match runs towards the unitig head and the mapping starts at its lowest forward offset
-RTK_DEV UMap rtk_find_unitig(const RCtx& c, const char* str, uint32_t pos, uint32_t len, uint64_t fw) {
+RTK_DEV UMap rtk_find_unitig(const RCtx& c, const char* str, uint32_t pos, uint32_t len, const RtkKm& fw) {
     const GraphView& g = c.g; const uint32_t k = static_cast<uint32_t>(c.k);
-    const uint64_t hit = rtk_find_kmer(g, fw, nullptr);
+    const uint64_t hit = rtk_find_km(g, fw, nullptr);
     if (hit == RTK_NO_HIT) return rtk_um_empty();
     UMap um = rtk_unpack_hit(hit);
     const uint32_t ul = rtk_ulen(g, um.unitig);
@@ -207,12 +207,11 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
         rtk_wcopy(q_sub, query + pos_buff, len_buff);
         rtk_sync();
         q_sub[pos_snp_buff] = pc;
-        uint64_t fw = 0; uint32_t run = 0, skip_until = 0; bool skip_one = false;
-        const uint64_t kmask = (k < 32) ? ((1ull << (2 * k)) - 1ull) : ~0ull;
+        RtkKm fw = rtk_km_zero(); uint32_t run = 0, skip_until = 0; bool skip_one = false;
         for (uint32_t i = 0; i < len_buff; ++i) {
             const char ch = q_sub[i];
-            if (!rtk_is_dna(ch)) { run = 0; fw = 0; continue; }
-            fw = ((fw << 2) | static_cast<uint64_t>(rtk_cls(static_cast<unsigned char>(ch & 0xDF)))) & kmask; ++run;
+            if (!rtk_is_dna(ch)) { run = 0; fw = rtk_km_zero(); continue; }
+            fw = rtk_km_push(fw, static_cast<uint64_t>(rtk_cls(static_cast<unsigned char>(ch & 0xDF))), static_cast<int>(k)); ++run;
             if (run < k) continue;
             const uint32_t w = i + 1 - k; // [A6] KmerIterator: the all-ACGT windows, in order
             if (w < skip_until) continue;

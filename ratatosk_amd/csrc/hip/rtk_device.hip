@@ -301,8 +301,8 @@ RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* rof
             uint32_t lo = lo0;
             while (lo + 1 < n_reads && roff[lo + 1] <= b) ++lo;
             if (b + static_cast<uint64_t>(g.k) <= roff[lo + 1]) {
-                int n_ok; const uint64_t fw = rtk_pack_acgt(reinterpret_cast<const unsigned char*>(seq) + b, g.k, &n_ok); // the read buffer is padded by 64 bytes
-                if (n_ok == g.k) { uint32_t np; h = rtk_find_kmer(g, fw, &np); probes += 1; slots += np; }
+                RtkKm fw; // the read buffer is padded by 64 bytes
+                if (rtk_km_from_text(reinterpret_cast<const unsigned char*>(seq) + b, g.k, &fw)) { uint32_t np; h = rtk_find_km(g, fw, &np); probes += 1; slots += np; }
             }
             hits[b] = h;
         }

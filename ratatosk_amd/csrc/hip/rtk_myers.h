@@ -104,6 +104,16 @@ RTK_DEV uint64_t rtk_pack_acgt(const unsigned char* p, int want, int* n_ok, uint
     return code;
 }
 
+// the k-mer code (k <= 63) of the k characters at p; false when one of them is not A/C/G/T. Reads at most max(32, k) bytes from p.
+RTK_DEV bool rtk_km_from_text(const unsigned char* p, int k, RtkKm* out) {
+    int n_ok;
+    if (k <= 32) { out->hi = 0; out->lo = rtk_pack_acgt(p, k, &n_ok); return n_ok == k; }
+    out->hi = rtk_pack_acgt(p, k - 32, &n_ok);
+    if (n_ok != k - 32) return false;
+    out->lo = rtk_pack_acgt(p + (k - 32), 32, &n_ok);
+    return n_ok == 32;
+}
+
 // 15-bit set of classes a character of class c is equal to (identity + the 28 (code, base) pairs of Common.hpp:262-274)
 RTK_DEV uint32_t rtk_eq_classes(int c, bool iupac) {
     if (c >= 15) return 0u;

@@ -213,8 +213,8 @@ RTK_FN void rtk_phase_read(const RCtx& c_, const PhaseView& pv_, uint32_t r_) {
             const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane());
             bool hit = false;
             if (j + k <= olen && (rtk_bm_window(cov, ow, static_cast<int64_t>(j)) & kmask_bits) == kmask_bits) {
-                int n_ok = 0; const uint64_t code = rtk_pack_acgt(reinterpret_cast<const unsigned char*>(out_s) + j, static_cast<int>(k), &n_ok);
-                if (n_ok >= static_cast<int>(k)) hit = rtk_find_kmer(g, code, nullptr) != RTK_NO_HIT;
+                RtkKm code;
+                if (rtk_km_from_text(reinterpret_cast<const unsigned char*>(out_s) + j, static_cast<int>(k), &code)) hit = rtk_find_km(g, code, nullptr) != RTK_NO_HIT;
             }
             if (hit) for (uint32_t x = j; x < j + k; ++x) if (out_q[x] == q_min) out_q[x] = q_max;
         }

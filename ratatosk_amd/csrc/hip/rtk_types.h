@@ -165,6 +165,63 @@ RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probe
 }
 
 
+// ---- k in 33..63 (second pass, k2 = 63): two-word k-mers ------------------------------------------------------------------------
+// Code = 2k bits right-aligned in {hi, lo}, first base in the most significant bits (k <= 32: hi = 0 and lo is the one-word code).
+// The table keeps its 16-byte slots: the key word is a 64-bit fingerprint of the canonical k-mer and a fingerprint match is
+// confirmed against the 2-bit unitig sequence the value word points at, so lookups stay exact.
+struct RtkKm { uint64_t hi, lo; };
+RTK_HD RtkKm rtk_km_zero() { RtkKm x; x.hi = 0; x.lo = 0; return x; }
+RTK_HD bool rtk_km_eq(const RtkKm& a, const RtkKm& b) { return a.hi == b.hi && a.lo == b.lo; }
+RTK_HD bool rtk_km_less(const RtkKm& a, const RtkKm& b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; }
+RTK_HD RtkKm rtk_km_mask(int k) { RtkKm m; m.lo = (k >= 32) ? ~0ull : ((1ull << (2 * k)) - 1ull); m.hi = (k <= 32) ? 0ull : ((1ull << (2 * k - 64)) - 1ull); return m; }
+RTK_HD RtkKm rtk_km_push(const RtkKm& x, uint64_t b, int k) { // append base b (0..3) at the end, drop the first
+    const RtkKm m = rtk_km_mask(k); RtkKm r; r.hi = ((x.hi << 2) | (x.lo >> 62)) & m.hi; r.lo = ((x.lo << 2) | b) & m.lo; return r;
+}
+RTK_HD RtkKm rtk_km_revcomp(const RtkKm& x, int k) {
+    if (k <= 32) { RtkKm r; r.hi = 0; r.lo = rtk_revcomp(x.lo, k); return r; }
+    const uint64_t a = rtk_revcomp(x.lo, 32), b = rtk_revcomp(x.hi, 32); // reverse complement of all 128 bits = {a, b}; the k-mer sits in its top 2k bits
+    const int s = 128 - 2 * k; // 2..62
+    RtkKm r; r.lo = (b >> s) | (a << (64 - s)); r.hi = a >> s; return r;
+}
+RTK_HD uint64_t rtk_km_hash(const RtkKm& can) { return rtk_hash64(can.lo ^ rtk_hash64(can.hi ^ 0x9e3779b97f4a7c15ull)); }
+RTK_HD uint64_t rtk_km_fingerprint(const RtkKm& can) { const uint64_t f = rtk_hash64(can.lo + 0x9e3779b97f4a7c15ull) ^ rtk_hash64(can.hi ^ 0xd6e8feb86659fd93ull); return f == RTK_EMPTY_KEY ? 0ull : f; }
+// reverse complement code of the k-mer starting at base `pos` of the 2-bit unitig pool (base p at bits 2(p & 31) of word p >> 5, i.e.
+// last base in the most significant bits: complementing it IS the reverse-complement code). k in 33..63.
+RTK_HD RtkKm rtk_km_rc_of_unitig(const GraphView& g, uint64_t pos, int k) {
+    const uint64_t w = pos >> 5; const int sh = static_cast<int>(2 * (pos & 31));
+    const uint64_t x0 = g.useq[w], x1 = g.useq[w + 1];
+    RtkKm l;
+    if (sh == 0) { l.lo = x0; l.hi = x1; }
+    else { l.lo = (x0 >> sh) | (x1 << (64 - sh)); l.hi = x1 >> sh; if (sh + 2 * k > 128) l.hi |= g.useq[w + 2] << (64 - sh); }
+    const RtkKm m = rtk_km_mask(k);
+    l.lo = ~l.lo & m.lo; l.hi = ~l.hi & m.hi;
+    return l;
+}
+RTK_HD uint64_t rtk_find_kmer_wide(const GraphView& g, const RtkKm& fw, uint32_t* n_probes) {
+    const RtkKm rc = rtk_km_revcomp(fw, g.k);
+    const RtkKm can = rtk_km_less(fw, rc) ? fw : rc;
+    const uint64_t hh = rtk_km_hash(can);
+    { const uint64_t b1 = (hh >> 12) & g.bf1_mask; if (!((g.bf1[b1 >> 6] >> (b1 & 63ull)) & 1ull)) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; } }
+    { const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)); if ((g.bf[(hh >> 32) & g.bf_mask] & bits) != bits) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; } }
+    const uint64_t fp = rtk_km_fingerprint(can);
+    uint64_t i = hh & g.ht_mask;
+    uint32_t np = 0;
+    while (true) {
+        const uint64_t key = g.ht[2 * i];
+        ++np;
+        if (key == fp) {
+            const uint64_t v = g.ht[2 * i + 1];
+            const uint32_t u = static_cast<uint32_t>(v >> 32), off = static_cast<uint32_t>((v & 0xFFFFFFFFull) >> 1);
+            const RtkKm urc = rtk_km_rc_of_unitig(g, g.uoff[u] + off, g.k);
+            if (rtk_km_eq(urc, rc)) { if (n_probes) *n_probes = np; return rtk_pack_hit(u, off, 1u); } // the query reads like the unitig
+            if (rtk_km_eq(urc, fw)) { if (n_probes) *n_probes = np; return rtk_pack_hit(u, off, 0u); } // the query is its reverse complement
+        }
+        if (key == RTK_EMPTY_KEY) { if (n_probes) *n_probes = np; return RTK_NO_HIT; }
+        i = (i + 1) & g.ht_mask;
+    }
+}
+RTK_HD uint64_t rtk_find_km(const GraphView& g, const RtkKm& fw, uint32_t* n_probes) { return g.k <= 31 ? rtk_find_kmer(g, fw.lo, n_probes) : rtk_find_kmer_wide(g, fw, n_probes); }
+
 // Split form of rtk_find_kmer for callers that want several filter reads in flight before any of them is consumed.
 RTK_HD void rtk_kmer_prepare(uint64_t fw, int k, uint64_t* can, uint64_t* hh, uint32_t* query_is_can) {
     const uint64_t rc = rtk_revcomp(fw, k);

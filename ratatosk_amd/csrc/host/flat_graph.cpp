@@ -46,9 +46,16 @@ uint64_t FlatGraph::bytes() const {
     return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size() + hx.size() + hxl.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
+static bool km_from_string(const char* s, int k, RtkKm& out) {
+    out = rtk_km_zero();
+    for (int i = 0; i < k; ++i) { const int b = base2bits(s[i]); if (b < 0) return false; out = rtk_km_push(out, static_cast<uint64_t>(b), k); }
+    return true;
+}
+
 void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads) {
     k = k_;
-    if (k < 3 || k > RTK_MAX_K || !(k & 1)) throw std::runtime_error("k must be odd and <= 31 (pass-1 scope; k=63 is a later row)");
+    if (k < 3 || k > RTK_MAX_K || !(k & 1)) throw std::runtime_error("k must be odd and <= 63 (MAX_KMER_SIZE = 64 build of the reference, CMakeLists.txt:6)");
+    const bool wide = k > 31; // two-word k-mers: fingerprint keys confirmed against the unitig sequence (rtk_find_kmer_wide)
     // ---- unitigs ----
     std::vector<std::string> seqs;
     {
@@ -66,7 +73,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     if (n >= 0x7FFFFFFFull) throw std::runtime_error("too many unitigs for 31-bit ids");
     uoff.assign(n + 1, 0);
     for (size_t u = 0; u < n; ++u) uoff[u + 1] = uoff[u] + seqs[u].size();
-    useq.assign((uoff[n] + 31) / 32 + 1, 0);
+    useq.assign((uoff[n] + 31) / 32 + 2, 0);
     n_kmers = 0;
     for (size_t u = 0; u < n; ++u) n_kmers += seqs[u].size() - k + 1;
     parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
@@ -90,7 +97,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         const char* e_enum = getenv("RTK_INEXACT_ENUM"); const char* e_gb = getenv("RTK_HX_MAX_GB");
         const double max_gb = e_gb ? atof(e_gb) : 96.0;
         const double est_gb = static_cast<double>(uoff[n]) * (8.0 * 4.0 + 8.0 * 1.5) / 1e9; // slots at load 0.25..0.5 + list words
-        if ((e_enum && e_enum[0] == '1') || est_gb > max_gb) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); }
+        if ((e_enum && e_enum[0] == '1') || est_gb > max_gb || wide) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); } // wide k: second pass only, which has no 1-edit search (src/Graph.cpp:100)
         else {
             std::vector<std::pair<uint64_t, uint64_t> > pairs(uoff[n] - static_cast<uint64_t>(n) * static_cast<uint64_t>(h - 1)); // every h-mer start of every unitig, at its own place
             const uint64_t hm = (1ull << (2 * h)) - 1ull;
@@ -141,7 +148,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     while (slots < 2 * n_kmers) slots <<= 1;
     ht.assign(2 * slots, 0);
     for (uint64_t i = 0; i < slots; ++i) ht[2 * i] = RTK_EMPTY_KEY;
-    const uint64_t hmask = slots - 1, kmask = kmer_mask(k);
+    const uint64_t hmask = slots - 1;
     // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer.
     // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
     // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.
@@ -158,25 +165,41 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
         for (size_t u = lo; u < hi; ++u) {
             const std::string& s = seqs[u];
-            uint64_t fw = 0;
+            RtkKm fwk = rtk_km_zero();
             for (size_t i = 0; i < s.size(); ++i) {
-                fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & kmask;
+                fwk = rtk_km_push(fwk, static_cast<uint64_t>(base2bits(s[i])), k);
                 if (i + 1 < static_cast<size_t>(k)) continue;
-                bool is_fw; const uint64_t can = kmer_canonical(fw, k, &is_fw);
-                uint64_t h = rtk_hash64(can) & hmask;
+                bool is_fw; uint64_t can, hh; // can: the key word of the slot
+                if (!wide) { can = kmer_canonical(fwk.lo, k, &is_fw); hh = rtk_hash64(can); }
+                else { const RtkKm rc = rtk_km_revcomp(fwk, k); is_fw = !rtk_km_less(rc, fwk); const RtkKm c2 = is_fw ? fwk : rc; hh = rtk_km_hash(c2); can = rtk_km_fingerprint(c2); }
+                uint64_t h = hh & hmask;
                 while (true) { // claim an empty slot with compare-and-swap on its key word (another thread may be filling the table too)
                     uint64_t seen_key = __atomic_load_n(&ht[2 * h], __ATOMIC_RELAXED);
                     if (seen_key == RTK_EMPTY_KEY) { uint64_t expect = RTK_EMPTY_KEY; if (__atomic_compare_exchange_n(&ht[2 * h], &expect, can, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; seen_key = expect; }
-                    if (seen_key == can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
+                    if (!wide && seen_key == can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
                     h = (h + 1) & hmask;
                 }
-                { const uint64_t hh = rtk_hash64(can); __atomic_fetch_or(&bf[(hh >> 32) & (bf_words - 1)], (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)), __ATOMIC_RELAXED);
+                { __atomic_fetch_or(&bf[(hh >> 32) & (bf_words - 1)], (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)), __ATOMIC_RELAXED);
                   if (!bf1_off) { const uint64_t b1 = (hh >> 12) & (bf1.size() * 64 - 1); __atomic_fetch_or(&bf1[b1 >> 6], 1ull << (b1 & 63ull), __ATOMIC_RELAXED); } }
                 ht[2 * h + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
             }
         }
     });
-    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; return v; }();
+    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; v.useq = useq.data(); v.uoff = uoff.data(); return v; }();
+    if (wide) { // fingerprints cannot tell a repeated k-mer while the table is filled: every k-mer has to find ITSELF afterwards
+        parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+            for (size_t u = lo; u < hi; ++u) {
+                const std::string& s = seqs[u];
+                RtkKm fwk = rtk_km_zero();
+                for (size_t i = 0; i < s.size(); ++i) {
+                    fwk = rtk_km_push(fwk, static_cast<uint64_t>(base2bits(s[i])), k);
+                    if (i + 1 < static_cast<size_t>(k)) continue;
+                    const uint64_t hit = rtk_find_kmer_wide(gv0, fwk, nullptr);
+                    if (hit != rtk_pack_hit(static_cast<uint32_t>(u), static_cast<uint32_t>(i + 1 - k), 1u)) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
+                }
+            }
+        });
+    }
     // ---- unitig data (.rtsk) ----
     flags.assign(n, 0); kcov.assign(n, 0); card.assign(n, 0); gid.assign(n, -1); loff.assign(n + 1, 0);
     std::vector<std::vector<uint32_t> > locals(n);
@@ -191,9 +214,9 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         RtskRecord r;
         while (rtsk_read_record(in, r)) {
             const std::string head = disk_kmer_to_string(r.head, k);
-            uint64_t code;
-            if (!kmer_encode(head.c_str(), k, code)) throw std::runtime_error(".rtsk: bad head k-mer");
-            const uint64_t hit = rtk_find_kmer(gv0, code, nullptr);
+            RtkKm code;
+            if (!km_from_string(head.c_str(), k, code)) throw std::runtime_error(".rtsk: bad head k-mer");
+            const uint64_t hit = rtk_find_km(gv0, code, nullptr);
             if (hit == RTK_NO_HIT) throw std::runtime_error(".rtsk: head k-mer not found in the graph (reference aborts too, src/Graph.cpp:773-780)");
             const UMap um = rtk_unpack_hit(hit);
             const uint32_t nk = static_cast<uint32_t>(seqs[um.unitig].size()) - k + 1;
@@ -248,13 +271,13 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     parallel_slices(n, n_threads, [&](size_t lo_u, size_t hi_u, int) {
     for (size_t u = lo_u; u < hi_u; ++u) {
         const std::string& s = seqs[u];
-        uint64_t tail, head;
-        kmer_encode(s.c_str() + s.size() - k, k, tail);
-        kmer_encode(s.c_str(), k, head);
-        const uint64_t ends[2] = { tail, kmer_revcomp(head, k) };
+        RtkKm tail, head;
+        km_from_string(s.c_str() + s.size() - k, k, tail);
+        km_from_string(s.c_str(), k, head);
+        const RtkKm ends[2] = { tail, rtk_km_revcomp(head, k) };
         for (int d = 0; d < 2; ++d) for (uint64_t b = 0; b < 4; ++b) {
-            const uint64_t y = ((ends[d] << 2) | b) & kmask;
-            const uint64_t hit = rtk_find_kmer(gv0, y, nullptr);
+            const RtkKm y = rtk_km_push(ends[d], b, k);
+            const uint64_t hit = rtk_find_km(gv0, y, nullptr);
             if (hit == RTK_NO_HIT) continue;
             const UMap f = rtk_unpack_hit(hit);
             const uint32_t nk = static_cast<uint32_t>(seqs[f.unitig].size()) - k + 1;

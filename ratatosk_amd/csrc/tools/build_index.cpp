@@ -34,20 +34,19 @@
 
 using namespace rtk;
 
-static const uint64_t EMPTY = ~0ULL;
-
-struct KTable { // open addressing: canonical k-mer -> 64-bit value
-    std::vector<uint64_t> keys, vals;
+template <class KM> struct KTable { // open addressing: canonical k-mer -> 64-bit value
+    const KM EMPTY = ~static_cast<KM>(0);
+    std::vector<KM> keys; std::vector<uint64_t> vals;
     size_t n = 0, mask = 0;
     explicit KTable(size_t cap_pow2 = 1 << 20) { keys.assign(cap_pow2, EMPTY); vals.assign(cap_pow2, 0); mask = cap_pow2 - 1; }
     void grow() {
-        std::vector<uint64_t> ok, ov; ok.swap(keys); ov.swap(vals);
+        std::vector<KM> ok; std::vector<uint64_t> ov; ok.swap(keys); ov.swap(vals);
         keys.assign(ok.size() * 2, EMPTY); vals.assign(ok.size() * 2, 0); mask = keys.size() - 1; n = 0;
         for (size_t i = 0; i < ok.size(); ++i) if (ok[i] != EMPTY) *slot(ok[i], true) = ov[i];
     }
-    uint64_t* slot(uint64_t key, bool insert) {
+    uint64_t* slot(KM key, bool insert) {
         if (insert && (n + 1) * 10 > keys.size() * 6) grow();
-        size_t i = hash64(key) & mask;
+        size_t i = hash_km(key) & mask;
         while (true) {
             if (keys[i] == key) return &vals[i];
             if (keys[i] == EMPTY) { if (!insert) return nullptr; keys[i] = key; ++n; return &vals[i]; }
@@ -58,7 +57,8 @@ struct KTable { // open addressing: canonical k-mer -> 64-bit value
 
 struct Unitig { std::string seq; std::vector<uint32_t> colours; uint64_t cov = 0; };
 
-int main(int argc, char** argv) {
+template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for k <= 31, u128 for k in 33..63
+    const KM EMPTY = ~static_cast<KM>(0);
     std::vector<std::string> in_files;
     std::string prefix = "out";
     int k = 31;
@@ -80,75 +80,75 @@ int main(int argc, char** argv) {
         else if (a == "--colour-reads") colour_files.push_back(need("--colour-reads"));
         else { fprintf(stderr, "rtk_build_index: unknown option %s\n", a.c_str()); return 2; }
     }
-    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=31)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
-    const uint64_t mask = kmer_mask(k);
+    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=63)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
+    const KM mask = km_mask<KM>(k);
 
     // ---- pass 1: count canonical k-mers ----
-    KTable cnt(1 << 22);
+    KTable<KM> cnt(1 << 22);
     {
         std::string name, seq, qual;
         for (size_t f = 0; f < in_files.size(); ++f) {
             FastxReader fr;
             if (!fr.open(in_files[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", in_files[f].c_str()); return 1; }
             while (fr.next(name, seq, qual)) {
-                uint64_t fw = 0; int valid = 0;
+                KM fw = 0; int valid = 0;
                 for (size_t i = 0; i < seq.size(); ++i) {
                     const int b = base2bits(seq[i]);
                     if (b < 0) { valid = 0; fw = 0; continue; }
-                    fw = ((fw << 2) | static_cast<uint64_t>(b)) & mask;
+                    fw = ((fw << 2) | static_cast<KM>(b)) & mask;
                     if (++valid >= k) ++*cnt.slot(kmer_canonical(fw, k), true);
                 }
             }
         }
     }
     // ---- solid k-mers, sorted: unitig construction is independent of table layout ----
-    std::vector<uint64_t> solid;
+    std::vector<KM> solid;
     for (size_t i = 0; i < cnt.keys.size(); ++i) if (cnt.keys[i] != EMPTY && cnt.vals[i] >= min_count) solid.push_back(cnt.keys[i]);
     std::sort(solid.begin(), solid.end());
-    { KTable tmp(16); cnt.keys.swap(tmp.keys); cnt.vals.swap(tmp.vals); } // free
+    { KTable<KM> tmp(16); cnt.keys.swap(tmp.keys); cnt.vals.swap(tmp.vals); } // free
     size_t cap = 16; while (cap * 6 < solid.size() * 10 + 16) cap <<= 1; cap <<= 1;
-    KTable km(cap); // canonical solid k-mer -> 0 (unvisited) or (unitig+1)<<32 | offset<<1 | fw_flag
+    KTable<KM> km(cap); // canonical solid k-mer -> 0 (unvisited) or (unitig+1)<<32 | offset<<1 | fw_flag
     for (size_t i = 0; i < solid.size(); ++i) *km.slot(solid[i], true) = 0;
     fprintf(stderr, "rtk_build_index: %zu solid %d-mers\n", solid.size(), k);
 
-    auto in_graph = [&](uint64_t oriented) -> bool { return km.slot(kmer_canonical(oriented, k), false) != nullptr; };
-    auto succs = [&](uint64_t x, uint64_t out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const uint64_t y = ((x << 2) | b) & mask; if (in_graph(y)) out[n++] = y; } return n; };
-    auto preds = [&](uint64_t x, uint64_t out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const uint64_t y = (x >> 2) | (b << (2 * (k - 1))); if (in_graph(y)) out[n++] = y; } return n; };
+    auto in_graph = [&](KM oriented) -> bool { return km.slot(kmer_canonical(oriented, k), false) != nullptr; };
+    auto succs = [&](KM x, KM out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const KM y = ((x << 2) | static_cast<KM>(b)) & mask; if (in_graph(y)) out[n++] = y; } return n; };
+    auto preds = [&](KM x, KM out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const KM y = (x >> 2) | (static_cast<KM>(b) << (2 * (k - 1))); if (in_graph(y)) out[n++] = y; } return n; };
 
     // ---- unitigs: maximal non-branching paths ----
     std::vector<Unitig> U;
     {
-        std::set<uint64_t> in_this; // canonical k-mers of the unitig being built (cycle / hairpin guard)
+        std::set<KM> in_this; // canonical k-mers of the unitig being built (cycle / hairpin guard)
         for (size_t si = 0; si < solid.size(); ++si) {
             uint64_t* v0 = km.slot(solid[si], false);
             if (*v0 != 0) continue;
             in_this.clear(); in_this.insert(solid[si]);
-            std::vector<uint64_t> fwd(1, solid[si]), bwd; // oriented k-mers
-            uint64_t nb[4], nb2[4];
-            for (uint64_t x = solid[si];;) { // extend forward
+            std::vector<KM> fwd(1, solid[si]), bwd; // oriented k-mers
+            KM nb[4], nb2[4];
+            for (KM x = solid[si];;) { // extend forward
                 if (succs(x, nb) != 1) break;
-                const uint64_t y = nb[0];
+                const KM y = nb[0];
                 if (preds(y, nb2) != 1) break;
-                const uint64_t cy = kmer_canonical(y, k);
+                const KM cy = kmer_canonical(y, k);
                 if (in_this.count(cy) || *km.slot(cy, false) != 0) break;
                 in_this.insert(cy); fwd.push_back(y); x = y;
             }
-            for (uint64_t x = solid[si];;) { // extend backward
+            for (KM x = solid[si];;) { // extend backward
                 if (preds(x, nb) != 1) break;
-                const uint64_t y = nb[0];
+                const KM y = nb[0];
                 if (succs(y, nb2) != 1) break;
-                const uint64_t cy = kmer_canonical(y, k);
+                const KM cy = kmer_canonical(y, k);
                 if (in_this.count(cy) || *km.slot(cy, false) != 0) break;
                 in_this.insert(cy); bwd.push_back(y); x = y;
             }
-            std::vector<uint64_t> path(bwd.rbegin(), bwd.rend());
+            std::vector<KM> path(bwd.rbegin(), bwd.rend());
             path.insert(path.end(), fwd.begin(), fwd.end());
             Unitig u;
-            u.seq = kmer_decode(path[0], k);
-            for (size_t i = 1; i < path.size(); ++i) u.seq.push_back(bits2base(static_cast<int>(path[i] & 3)));
+            u.seq = km_decode<KM>(path[0], k);
+            for (size_t i = 1; i < path.size(); ++i) u.seq.push_back(bits2base(static_cast<int>(static_cast<uint64_t>(path[i]) & 3)));
             const uint64_t uid = U.size();
             for (size_t i = 0; i < path.size(); ++i) {
-                bool is_fw; const uint64_t c = kmer_canonical(path[i], k, &is_fw);
+                bool is_fw; const KM c = kmer_canonical(path[i], k, &is_fw);
                 *km.slot(c, false) = ((uid + 1) << 32) | (static_cast<uint64_t>(i) << 1) | (is_fw ? 1ULL : 0ULL);
             }
             U.push_back(u);
@@ -171,11 +171,11 @@ int main(int argc, char** argv) {
                 if (name.size() > 2 && name[name.size() - 2] == '/' && (name[name.size() - 1] == '1' || name[name.size() - 1] == '2')) name.erase(name.size() - 2);
                 if (first) { first = false; prev_name = name; }
                 else if (by_read || name != prev_name) { ++pair_id; prev_name = name; }
-                uint64_t fw = 0; int valid = 0;
+                KM fw = 0; int valid = 0;
                 for (size_t i = 0; i < seq.size(); ++i) {
                     const int b = base2bits(seq[i]);
                     if (b < 0) { valid = 0; fw = 0; continue; }
-                    fw = ((fw << 2) | static_cast<uint64_t>(b)) & mask;
+                    fw = ((fw << 2) | static_cast<KM>(b)) & mask;
                     if (++valid >= k) {
                         const uint64_t* v = km.slot(kmer_canonical(fw, k), false);
                         if (v) {
@@ -202,14 +202,14 @@ int main(int argc, char** argv) {
     };
     for (size_t u = 0; u < n; ++u) {
         const std::string& s = U[u].seq;
-        uint64_t tail, head;
-        kmer_encode(s.c_str() + s.size() - k, k, tail);
-        kmer_encode(s.c_str(), k, head);
-        const uint64_t ends[2] = { tail, kmer_revcomp(head, k) }; // last k-mer in walk direction fw / rev
+        KM tail = 0, head = 0;
+        km_encode<KM>(s.c_str() + s.size() - k, k, tail);
+        km_encode<KM>(s.c_str(), k, head);
+        const KM ends[2] = { tail, kmer_revcomp(head, k) }; // last k-mer in walk direction fw / rev
         int deg[2] = {0, 0};
         for (int d = 0; d < 2; ++d) for (uint64_t b = 0; b < 4; ++b) {
             adj[u].u[d][b] = -1;
-            const uint64_t y = ((ends[d] << 2) | b) & mask;
+            const KM y = ((ends[d] << 2) | static_cast<KM>(b)) & mask;
             const uint64_t* v = km.slot(kmer_canonical(y, k), false);
             if (!v) continue;
             const size_t w = (*v >> 32) - 1;
@@ -227,8 +227,8 @@ int main(int argc, char** argv) {
     // with theirs keep >= min_cov ids. Stored per unitig as the entering bases of X1..Xm (Path::getMiddleCompactedPath), NUL-terminated.
     std::vector<std::string> cycles(n);
     if (detect_cycles) {
-        std::vector<uint64_t> headk(n);
-        for (size_t u = 0; u < n; ++u) kmer_encode(U[u].seq.c_str(), k, headk[u]);
+        std::vector<KM> headk(n);
+        for (size_t u = 0; u < n; ++u) km_encode<KM>(U[u].seq.c_str(), k, headk[u]);
         auto n_km = [&](size_t u) { return U[u].seq.size() - static_cast<size_t>(k) + 1; };
         struct Step { size_t u; bool fw; char base; };
         size_t n_cyc_unitigs = 0;
@@ -239,16 +239,16 @@ int main(int argc, char** argv) {
                 const std::vector<Step> path = q.front(); q.pop();
                 const Step cur = path.back();
                 const std::string& cs = U[cur.u].seq;
-                uint64_t tail, head;
-                kmer_encode(cs.c_str() + cs.size() - k, k, tail); kmer_encode(cs.c_str(), k, head);
-                const uint64_t endk = cur.fw ? tail : kmer_revcomp(head, k);
+                KM tail = 0, head = 0;
+                km_encode<KM>(cs.c_str() + cs.size() - k, k, tail); km_encode<KM>(cs.c_str(), k, head);
+                const KM endk = cur.fw ? tail : kmer_revcomp(head, k);
                 for (uint64_t b = 0; b < 4; ++b) {
                     const int64_t w = adj[cur.u].u[cur.fw ? 0 : 1][b];
                     if (w < 0) continue;
                     const uint64_t bit = cur.fw ? ((1ULL << b) << 4) : (1ULL << b);
                     if (!(shared[cur.u] & bit)) continue;                                                       // edge seen in enough reads
                     if (shared_count(U[cur.u].colours, U[u0].colours) < min_cov_vertices) continue;            // still read-compatible with the start
-                    const uint64_t y = ((endk << 2) | b) & mask;
+                    const KM y = ((endk << 2) | static_cast<KM>(b)) & mask;
                     const bool w_fw = (y == headk[static_cast<size_t>(w)]);
                     if (static_cast<size_t>(w) == u0 && w_fw) { // came back to the start unitig, same strand
                         bool distinct = true;
@@ -280,17 +280,17 @@ int main(int argc, char** argv) {
     // offset, substituted base): Bifrost's own order inside one window is not known ([D3], canonical rule).
     std::vector<std::vector<uint32_t> > ambiguity(n);
     if (detect_snps) {
-        std::vector<uint64_t> headk(n), tailk(n);
-        for (size_t u = 0; u < n; ++u) { kmer_encode(U[u].seq.c_str(), k, headk[u]); kmer_encode(U[u].seq.c_str() + U[u].seq.size() - k, k, tailk[u]); }
+        std::vector<KM> headk(n), tailk(n);
+        for (size_t u = 0; u < n; ++u) { km_encode<KM>(U[u].seq.c_str(), k, headk[u]); km_encode<KM>(U[u].seq.c_str() + U[u].seq.size() - k, k, tailk[u]); }
         struct Node { size_t u; bool fw; };
         // successors of (u, strand) in A,C,G,T order with the base that is appended
         auto successors = [&](const Node& x, Node out[4], int base[4]) -> int {
             int m = 0;
-            const uint64_t endk = x.fw ? tailk[x.u] : kmer_revcomp(headk[x.u], k);
+            const KM endk = x.fw ? tailk[x.u] : kmer_revcomp(headk[x.u], k);
             for (uint64_t b = 0; b < 4; ++b) {
                 const int64_t w = adj[x.u].u[x.fw ? 0 : 1][b];
                 if (w < 0) continue;
-                const uint64_t y = ((endk << 2) | b) & mask;
+                const KM y = ((endk << 2) | static_cast<KM>(b)) & mask;
                 out[m].u = static_cast<size_t>(w); out[m].fw = (y == headk[static_cast<size_t>(w)]); base[m] = static_cast<int>(b); ++m;
             }
             return m;
@@ -339,17 +339,17 @@ int main(int argc, char** argv) {
             std::string seq_final = s, seq_tried = s;
             std::set<size_t> ok, bad;
             Walk lgt_fw, lgt_bw;
-            uint64_t fw = 0;
+            KM fw = 0;
             for (size_t i = 0; i < s.size(); ++i) {
-                fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & mask;
+                fw = ((fw << 2) | static_cast<KM>(base2bits(s[i]))) & mask;
                 if (i + 1 < static_cast<size_t>(k)) continue;
                 const size_t p = i + 1 - static_cast<size_t>(k);
                 for (int j = 0; j < k; ++j) {
                     const int sh = 2 * (k - 1 - j);
-                    const uint64_t cur = (fw >> sh) & 3ULL;
+                    const uint64_t cur = static_cast<uint64_t>(fw >> sh) & 3ULL;
                     for (uint64_t alt = 0; alt < 4; ++alt) {
                         if (alt == cur) continue;
-                        const uint64_t y = (fw & ~(3ULL << sh)) | (alt << sh);
+                        const KM y = (fw & ~(static_cast<KM>(3) << sh)) | (static_cast<KM>(alt) << sh);
                         const uint64_t* v = km.slot(kmer_canonical(y, k), false);
                         if (!v) continue;
                         const size_t w = (*v >> 32) - 1;
@@ -442,4 +442,10 @@ int main(int argc, char** argv) {
         }
     }
     return 0;
+}
+
+int main(int argc, char** argv) {
+    int k = 31;
+    for (int i = 1; i + 1 < argc; ++i) if (!strcmp(argv[i], "-k")) k = atoi(argv[i + 1]);
+    return k <= 31 ? run<uint64_t>(argc, argv) : run<u128>(argc, argv);
 }

@@ -26,6 +26,8 @@ def _second_pass_set(tmpdir, name, sim_args):
             f.write("@%s\n%s\n+\n%s\n" % (r[0], s, q))
     # the reference's second graph is the short-read graph at k2, coloured by the pass-1 reads (src/Ratatosk.cpp:1193,1227)
     subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "--colour-reads", p1, "-o", pre + ".p2"], stderr=subprocess.DEVNULL)
+    # ... and at the reference's default k2 = 63 (src/Common.hpp:101): two-word k-mers
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "--colour-reads", p1, "-k", "63", "-o", pre + ".p2"], stderr=subprocess.DEVNULL)
     return pre
 
 
@@ -41,14 +43,14 @@ def ds_pass2_big(tmp_path_factory):
                                                                              "--lr-n", 400, "--lr-len", 6000, "--lr-profile", "ont", "--lr-err", 0.08])
 
 
-def _load(pre, lib_path):
-    fa, rt = pre + ".p2.index.k31.fasta.gz", pre + ".p2.index.k31.rtsk"
+def _load(pre, lib_path, k=31):
+    fa, rt = pre + ".p2.index.k%d.fasta.gz" % k, pre + ".p2.index.k%d.rtsk" % k
     p1, raw = op.read_fastq(pre + ".pass1.fq"), op.read_fastq(pre + ".lr.fq")
-    return op.Graph(fa, rt, 31), api.Graph(fa, rt, 31, device=0, lib_path=lib_path), [r[1] for r in p1], [r[2] for r in p1], [r[1] for r in raw]
+    return op.Graph(fa, rt, k), api.Graph(fa, rt, k, device=0, lib_path=lib_path), [r[1] for r in p1], [r[2] for r in p1], [r[1] for r in raw]
 
 
-def _check_pass2(pre, lib_path, n=None, threads=8):
-    og, pg, seqs, quals, raws = _load(pre, lib_path)
+def _check_pass2(pre, lib_path, n=None, threads=8, k=31):
+    og, pg, seqs, quals, raws = _load(pre, lib_path, k)
     if n:
         seqs, quals, raws = seqs[:n], quals[:n], raws[:n]
     oo = og.opts(long_read_correct=1)
@@ -90,9 +92,41 @@ def test_sim_pass2_needs_qualities(ds_pass2):
         pg.correct_batch(seqs[:2], None, pg.opts(long_read_correct=1))
 
 
+def _check_lookup_k63(pre, lib_path):
+    """Exact lookups with two-word k-mers ([A1]): bit-exact (unitig, dist, strand) for reads, both strands of a unitig, N inside."""
+    og, pg, seqs, quals, raws = _load(pre, lib_path, 63)
+    u = og.unitig(0)["seq"]
+    for s in seqs[:6] + raws[:2] + ["ACGT" * 5, "A" * 63, seqs[0][:200] + "N" + seqs[0][200:400], u, op.revcomp(u) if hasattr(op, "revcomp") else u[::-1].translate(str.maketrans("ACGT", "TGCA"))]:
+        assert pg.lookup_exact(s) == og.exact(s)
+    hits = pg.lookup_exact(u)
+    assert len(hits) == len(u) - 62 and all(h >= 0 and (h & 1) for h in hits) and [((h >> 1) & 0xFFFFFFFF) for h in hits] == list(range(len(hits)))
+    assert pg.info().n_kmers == og.n_kmers
+    with pytest.raises(api.RtkError):  # the first pass (1-edit search) is limited to one-word k-mers
+        pg.correct_batch(seqs[:1], None, pg.opts())
+
+
+def test_sim_k63_lookup(ds_pass2):
+    _check_lookup_k63(ds_pass2, SIM_LIB)
+
+
+def test_sim_pass2_k63_matches_oracle(ds_pass2):
+    _check_pass2(ds_pass2, SIM_LIB, k=63)
+
+
+def test_sim_cli_pass2_k63(ds_pass2, tmp_path):
+    sim = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "Ratatosk_sim")
+    _check_cli_pass2(sim, ds_pass2, tmp_path, dict(os.environ, RTK_SIM_DEVICES="1"), k=63)
+
+
 @pytest.mark.gpu
 def test_gpu_pass2_matches_oracle(ds_pass2_big):
     _check_pass2(ds_pass2_big, GPU_LIB, threads=32)
+
+
+@pytest.mark.gpu
+def test_gpu_pass2_k63_matches_oracle(ds_pass2_big):
+    _check_lookup_k63(ds_pass2_big, GPU_LIB)
+    _check_pass2(ds_pass2_big, GPU_LIB, threads=32, k=63)
 
 
 @pytest.mark.gpu
@@ -119,29 +153,29 @@ def _trim_records(name, seq, qual, k, trim):
     return out
 
 
-def _cli_pass2(exe, pre, tmp_path, extra, env=None):
+def _cli_pass2(exe, pre, tmp_path, extra, env=None, k=31):
     out = str(tmp_path / "out")
-    r = subprocess.run([exe, "correct", "-2", "-K", "31", "-c", "2", "-B", "20000", "-g", pre + ".p2.index.k31.fasta.gz", "-d", pre + ".p2.index.k31.rtsk",
+    r = subprocess.run([exe, "correct", "-2"] + (["-K", str(k)] if k != 63 else []) + ["-c", "2", "-B", "20000", "-g", pre + ".p2.index.k%d.fasta.gz" % k, "-d", pre + ".p2.index.k%d.rtsk" % k,
                         "-l", pre + ".pass1.fq", "-L", pre + ".lr.fq", "-o", out] + extra, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     return out
 
 
-def _expected_pass2(pre):
-    og, _, seqs, quals, raws = _load(pre, SIM_LIB)
+def _expected_pass2(pre, k=31):
+    og, _, seqs, quals, raws = _load(pre, SIM_LIB, k)
     names = [r[0] for r in op.read_fastq(pre + ".pass1.fq")]
     return names, og.correct_batch2(seqs, quals, raws, og.opts(long_read_correct=1), threads=8)
 
 
-def _check_cli_pass2(exe, pre, tmp_path, env=None):
-    names, want = _expected_pass2(pre)
-    out = _cli_pass2(exe, pre, tmp_path, [], env)
+def _check_cli_pass2(exe, pre, tmp_path, env=None, k=31):
+    names, want = _expected_pass2(pre, k)
+    out = _cli_pass2(exe, pre, tmp_path, [], env, k)
     got = op.read_fastq(out + ".fastq")
     assert [(g[1], g[2]) for g in got] == want and [g[0] for g in got] == names
     # -t 20 -G: trimmed / split records, gzip members per ticket block
-    out = _cli_pass2(exe, pre, tmp_path, ["-t", "20", "-G"], env)
+    out = _cli_pass2(exe, pre, tmp_path, ["-t", "20", "-G"], env, k)
     got = op.read_fastq(out + ".fastq.gz")
-    exp = [rec for n_, (s, q) in zip(names, want) for rec in _trim_records(n_, s, q, 31, 20)]
+    exp = [rec for n_, (s, q) in zip(names, want) for rec in _trim_records(n_, s, q, k, 20)]
     assert got == exp and 0 < len(exp) and any("/2" in e[0] for e in exp)
 
 
@@ -169,3 +203,4 @@ def test_gpu_cli_pass1_then_pass2(ds_pass2, tmp_path):
     assert r.returncode == 0, r.stderr
     assert open(out + ".2.fastq").read() == open(ds_pass2 + ".pass1.fq").read()
     _check_cli_pass2(exe, ds_pass2, tmp_path)
+    _check_cli_pass2(exe, ds_pass2, tmp_path, k=63)
