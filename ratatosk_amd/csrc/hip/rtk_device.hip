@@ -99,6 +99,7 @@ static void graph_set_view(rtk_graph* g) {
     v.bf = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_BF]); v.bf_mask = g->dbytes[rtk::RTK_BUF_BF] / 8 - 1;
     v.bf1 = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_BF1]); v.bf1_mask = g->dbytes[rtk::RTK_BUF_BF1] * 8 - 1;
     v.cycoff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_CYCOFF]); v.cyc = static_cast<const char*>(g->dbuf[rtk::RTK_BUF_CYC]);
+    v.hap = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HAP]);
     v.amb = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_AMB]); v.n_amb = g->dbytes[rtk::RTK_BUF_AMB] / 8 - (static_cast<uint64_t>(v.n_unitigs) + 1);
     v.hx = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HX]); v.hx_mask = g->dbytes[rtk::RTK_BUF_HX] / 8 - 1; v.hxl = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HXL]);
 }
@@ -156,7 +157,7 @@ extern "C" int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* d
 extern "C" int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n) {
     if (!g || !bytes || n != rtk::RTK_N_BUFS || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer_bytes: needs a loaded graph");
     const rtk::FlatGraph& h = g->host;
-    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size(), 8 * h.hx.size(), 8 * h.hxl.size() };
+    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size(), 8 * h.hx.size(), 8 * h.hxl.size(), 8 * h.hap.size() };
     for (int i = 0; i < n; ++i) bytes[i] = b[i];
     return RTK_OK;
 }
@@ -165,8 +166,8 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
     if (!g || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: graph has no host image");
     int rc = require_device(device); if (rc) return rc;
     const rtk::FlatGraph& h = g->host;
-    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data(), h.bf.data(), h.cycoff.data(), h.cyc.data(), h.bf1.data(), h.amb.data(), h.hx.data(), h.hxl.data() };
-    const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size(), 8 * h.hx.size(), 8 * h.hxl.size() };
+    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data(), h.bf.data(), h.cycoff.data(), h.cyc.data(), h.bf1.data(), h.amb.data(), h.hx.data(), h.hxl.data(), h.hap.data() };
+    const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size(), 8 * h.hx.size(), 8 * h.hxl.size(), 8 * h.hap.size() };
     try {
         rtk_set_device(device);
         for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { if (!g->dbuf[i]) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; } rtk_h2d(g->dbuf[i], src[i], bytes[i]); }

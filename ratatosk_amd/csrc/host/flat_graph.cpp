@@ -37,13 +37,14 @@ GraphView FlatGraph::view() const {
     v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data(); v.bf = bf.data(); v.bf_mask = bf.size() - 1;
     v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1;
     v.cycoff = cycoff.data(); v.cyc = reinterpret_cast<const char*>(cyc.data());
+    v.hap = hap.data();
     v.amb = amb.data(); v.n_amb = amb.size() - (static_cast<uint64_t>(n_unitigs()) + 1);
     v.hx = hx.data(); v.hx_mask = hx.size() - 1; v.hxl = hxl.data();
     return v;
 }
 
 uint64_t FlatGraph::bytes() const {
-    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size() + hx.size() + hxl.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
+    return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size() + hx.size() + hxl.size() + hap.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
 static bool km_from_string(const char* s, int k, RtkKm& out) {
@@ -207,6 +208,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     std::map<std::vector<uint32_t>, int32_t> gdedup; // identical global sets share one id (reference: src/Graph.cpp:748-771)
     std::vector<char> seen(n, 0);
     std::vector<std::vector<uint32_t> > ambs(n); // SNP annotation ids of each unitig (pos<<4 | IUPAC index)
+    std::vector<std::vector<uint32_t> > haps(n); // haplotype ids
     std::vector<std::string> cycles(n); // compact cycles of short-cycle unitigs (UnitigData.hpp:307-327): NUL-terminated strings, concatenated
     {
         std::ifstream in(rtsk.c_str(), std::ios::binary);
@@ -227,6 +229,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             uint32_t f = static_cast<uint32_t>(r.shared & 0xFFull);
             if (r.shared & 0x100ull) f |= RTK_F_SHORT_CYCLE;
             cycles[u] = r.cycles;
+            haps[u].swap(r.hap_ids);
             if (r.kmcov >> 63) f |= RTK_F_BRANCHING;
             if (!r.ambiguity_ids.empty()) { f |= RTK_F_AMBIGUITY; ambs[u].swap(r.ambiguity_ids); }
             flags[u] = f;
@@ -261,6 +264,10 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         }
         for (size_t u = 0; u < n; ++u) for (size_t i = 0; i < ambs[u].size(); ++i) amb.push_back(ambs[u][i]);
     }
+    // ---- haplotype ids ----
+    hap.assign(n + 1, 0);
+    for (size_t u = 0; u < n; ++u) hap[u + 1] = hap[u] + haps[u].size();
+    for (size_t u = 0; u < n; ++u) for (size_t i = 0; i < haps[u].size(); ++i) hap.push_back(haps[u][i]);
     // ---- compact cycles ----
     cycoff.assign(n + 1, 0);
     for (size_t u = 0; u < n; ++u) cycoff[u + 1] = cycoff[u] + cycles[u].size();

@@ -18,6 +18,8 @@ struct FlatGraph {
     std::vector<uint64_t> bf1;                                    // first-level presence bits
     std::vector<uint64_t> hx, hxl;                                // half-k-mer index (GraphView::hx / hxl)
     std::vector<uint64_t> amb;                                    // SNP annotations (GraphView::amb): n+1 offsets, then the entries
+    std::vector<uint64_t> hap;                                    // haplotype ids of each unitig (UnitigData::hap_ids, src/UnitigData.hpp:493-517): n+1 offsets, then the ids. Only the
+                                                                  // phased-input options (-p/-P, out of scope) read them; kept so that a reference-written index loads without loss
     std::vector<uint64_t> cyc;                                    // NUL-terminated successor-base strings, packed 8 characters per word
     std::vector<uint32_t> adj, flags, kcov, card, col;
     std::vector<int32_t> gid;
@@ -31,7 +33,7 @@ struct FlatGraph {
 };
 
 // the flat buffers in a fixed order (upload / RCCL broadcast order)
-enum { RTK_BUF_USEQ = 0, RTK_BUF_UOFF, RTK_BUF_ADJ, RTK_BUF_FLAGS, RTK_BUF_KCOV, RTK_BUF_CARD, RTK_BUF_LOFF, RTK_BUF_GID, RTK_BUF_GOFF, RTK_BUF_COL, RTK_BUF_HT, RTK_BUF_BF, RTK_BUF_CYCOFF, RTK_BUF_CYC, RTK_BUF_BF1, RTK_BUF_AMB, RTK_BUF_HX, RTK_BUF_HXL, RTK_N_BUFS };
+enum { RTK_BUF_USEQ = 0, RTK_BUF_UOFF, RTK_BUF_ADJ, RTK_BUF_FLAGS, RTK_BUF_KCOV, RTK_BUF_CARD, RTK_BUF_LOFF, RTK_BUF_GID, RTK_BUF_GOFF, RTK_BUF_COL, RTK_BUF_HT, RTK_BUF_BF, RTK_BUF_CYCOFF, RTK_BUF_CYC, RTK_BUF_BF1, RTK_BUF_AMB, RTK_BUF_HX, RTK_BUF_HXL, RTK_BUF_HAP, RTK_N_BUFS };
 
 } // namespace rtk
 

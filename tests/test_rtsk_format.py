@@ -100,7 +100,7 @@ def _encode_tiny(ids, mode):
     return struct.pack("<%dH" % alloc, *([(alloc << 3) | mode, card, hi] + body + [0] * (alloc - size)))
 
 
-def _rewrite(src, dst, remap, tiny=False):
+def _rewrite(src, dst, remap, tiny=False, hap_of=None):
     """Copies an .rtsk file, renaming the colour ids of the global and local sets with `remap` and writing every set that needs a
     Roaring payload in the run-container layout. Returns (payloads, run containers, containers, payloads with >= 4 containers)."""
     data = open(src, "rb").read()
@@ -139,10 +139,15 @@ def _rewrite(src, dst, remap, tiny=False):
         st[0] += 1; st[1] += n_run; st[2] += n_cont; st[3] += 1 if n_cont >= 4 else 0
         out.extend(struct.pack("<Q", (len(payload) << 3) | 3)); out.extend(payload)
 
+    rec = 0
     while p < len(data):
         out.extend(data[p:p + 32]); p += 32  # head k-mer, kmCov_cardBranches, shared_pids
-        for colour in (True, True, False, False):  # global, local, ambiguity, hap
-            write_pid(read_pid(), colour)
+        for which, colour in enumerate((True, True, False, False)):  # global, local, ambiguity, hap
+            ids = read_pid()
+            if which == 3 and hap_of is not None:
+                ids = hap_of(rec)
+            write_pid(ids, colour)
+        rec += 1
         (n,) = struct.unpack_from("<Q", data, p)
         out.extend(data[p:p + 8 + n]); p += 8 + n
     open(dst, "wb").write(bytes(out))
@@ -228,3 +233,26 @@ def test_malformed_tinybitmap_is_refused_loudly(ds_small, tmp_path):
         assert False, "malformed flag-0 stream accepted"
     except api.RtkError as e:
         assert "TinyBitmap" in str(e) and "A8" in str(e)
+
+
+def test_haplotype_ids_reach_the_flat_graph(ds_small, tmp_path):
+    """UnitigData::hap_ids (fourth PairID of a record, src/UnitigData.hpp:493-517) are only read by the phased-input options (-p/-P,
+    out of scope), but a reference-written index may carry them: they must load without loss (buffer RTK_BUF_HAP) and must not
+    change `correct -1`."""
+    import ctypes as C
+    fa, rt = ds_small + ".index.k31.fasta.gz", ds_small + ".index.k31.rtsk"
+    rt2 = str(tmp_path / "hap.rtsk")
+    hap_of = lambda rec: [] if rec % 3 == 0 else ([rec % 50] if rec % 3 == 1 else [rec % 7, 100 + rec, 70000 + 2 * rec])  # empty / flag-2 / flag-1 / Roaring forms
+    _rewrite(rt, rt2, lambda v: v, hap_of=hap_of)
+    pg, pg0 = api.Graph(fa, rt2, 31, device=0, lib_path=SIM_LIB), api.Graph(fa, rt, 31, device=0, lib_path=SIM_LIB)
+    n = pg.info().n_unitigs
+    assert pg.L.rtk_graph_n_buffers(pg.h) == 19
+    p, nb = C.c_void_p(), C.c_uint64()
+    assert pg.L.rtk_graph_buffer(pg.h, 18, C.byref(p), C.byref(nb)) == 0
+    hap = C.cast(p, C.POINTER(C.c_uint64))
+    # records are in file order, unitigs in graph order: compare as multisets of id lists
+    got = sorted(tuple(hap[n + 1 + j] for j in range(hap[u], hap[u + 1])) for u in range(n))
+    assert got == sorted(tuple(sorted(hap_of(r))) for r in range(n)) and nb.value == 8 * (n + 1 + hap[n])
+    reads = op.read_fastq(ds_small + ".lr.fq")[:4]
+    seqs, quals = [r[1] for r in reads], [r[2] for r in reads]
+    assert pg.correct_batch(seqs, quals) == pg0.correct_batch(seqs, quals)
