@@ -198,7 +198,10 @@ RTK_FN void rtk_phase_read(const RCtx& c_, const PhaseView& pv_, uint32_t r_) {
         for (uint32_t p0 = 0; p0 < olen; p0 += RTK_WAVE) {
             const uint32_t p = p0 + static_cast<uint32_t>(rtk_lane());
             bool cv = false;
-            if (p < olen) { const uint64_t win = rtk_bm_window(newb, ow, static_cast<int64_t>(p) - static_cast<int64_t>(k) + 1); cv = (win & ((2 * k - 1) >= 64 ? ~0ull : ((1ull << (2 * k - 1)) - 1ull))) != 0ull; }
+            if (p < olen) { // a new base within k - 1 positions on either side: two k-bit windows (2k - 1 bits do not fit one word at k = 63)
+                const uint64_t kb = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+                cv = ((rtk_bm_window(newb, ow, static_cast<int64_t>(p) - static_cast<int64_t>(k) + 1) | rtk_bm_window(newb, ow, static_cast<int64_t>(p))) & kb) != 0ull;
+            }
             const uint64_t b = rtk_ballot(cv);
 #ifdef RTK_SIM
             if (cv) cov[p >> 6] |= 1ull << (p & 63u);

@@ -113,6 +113,12 @@ def test_sim_pass2_k63_matches_oracle(ds_pass2):
     _check_pass2(ds_pass2, SIM_LIB, k=63)
 
 
+def test_sim_pass2_k63_volume(ds_pass2_big):
+    """400 reads: reaches the cases the small set does not (a reverted base more than 32 positions away from the window that
+    restores its quality -- found on the GPU tier first)."""
+    _check_pass2(ds_pass2_big, SIM_LIB, threads=16, k=63)
+
+
 def test_sim_cli_pass2_k63(ds_pass2, tmp_path):
     sim = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "Ratatosk_sim")
     _check_cli_pass2(sim, ds_pass2, tmp_path, dict(os.environ, RTK_SIM_DEVICES="1"), k=63)
