@@ -64,9 +64,10 @@ struct RegionScratch {
     U<uint64_t*> list[11]; U<uint32_t> list_cap;                // 6..10: SNP-annotation sets (rtk_ambiguity.h)
     U<uint32_t*> memo_u; U<uint8_t*> memo_v; U<uint32_t> memo_cap; U<uint32_t> memo_n;
     U<uint64_t*> bm[3]; U<uint32_t> bm_words;
-    U<uint32_t*> overflow;
+    U<uint32_t*> overflow; U<uint32_t> ovf_word; // the flag itself, next to the header (same memory: LDS in the kernels)
     U<unsigned long long> cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
     U<unsigned long long> fine[16]; // developer cycle counters printed with RTK_TRACE (RTK_FINE names in rtk_pipeline_run.inc)
+    U<unsigned long long> hist[32]; // region time by size class: [b] cycles, [8 + b] regions, [16 + b] regions that needed the reverse strand too, [24 + b] DFS calls
 };
 
 struct RCtx { // everything a region program needs
@@ -112,15 +113,39 @@ RTK_DEV UMap rtk_an_um(const Anchors& a, uint32_t i) {
     return u;
 }
 
-// positions are ascending in the anchor index: binary searches replace the reference's linear walks over the lists
-RTK_DEV uint32_t rtk_an_first_ge(const Anchors& a, uint32_t lo, uint32_t hi, uint64_t key) { // first x in [lo, hi) with pos(x) >= key, else hi
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (static_cast<uint64_t>(rtk_u(rtk_an_pos(a, mid))) < key) lo = mid + 1; else hi = mid; }
+// positions are ascending in the anchor index: searches replace the reference's linear walks over the lists. A search is a chain of
+// dependent memory round trips, so it is 64-ary: every lane probes one pivot per step (two steps for 4096 anchors instead of twelve).
+// first x in [lo, hi) with pos(x) >= key (strict: > key), else hi
+RTK_DEV uint32_t rtk_an_search(const Anchors& a, uint32_t lo_, uint32_t hi_, uint64_t key_, bool strict_) {
+    uint32_t lo = rtk_u(lo_), hi = rtk_u(hi_); const uint64_t key = rtk_u(key_); const bool strict = rtk_u(strict_);
+    const uint32_t lane = static_cast<uint32_t>(rtk_lane());
+#ifdef RTK_SIM
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; const uint64_t p = rtk_an_pos(a, mid); if (strict ? (p <= key) : (p < key)) lo = mid + 1; else hi = mid; }
+    (void)lane; return lo;
+#else
+    while (lo < hi) {
+        const uint32_t span = hi - lo;
+        if (span <= RTK_WAVE) { // one probe per candidate
+            const uint32_t x = lo + lane; bool t = false;
+            if (x < hi) { const uint64_t p = rtk_an_pos(a, x); t = strict ? (p > key) : (p >= key); }
+            const uint64_t b = rtk_ballot(t);
+            return b ? lo + static_cast<uint32_t>(rtk_ffs(b) - 1) : hi;
+        }
+        // 64 pivots strictly inside [lo, hi): x_i = lo + (i + 1) * span / 65
+        const uint32_t x = lo + static_cast<uint32_t>((static_cast<uint64_t>(lane + 1) * span) / (RTK_WAVE + 1));
+        const uint64_t p = rtk_an_pos(a, x);
+        const bool t = strict ? (p > key) : (p >= key);
+        const uint64_t b = rtk_ballot(t); // monotone: 0..0 1..1
+        const int j = b ? rtk_ffs(b) - 1 : RTK_WAVE; // first pivot that satisfies the test
+        const uint32_t nlo = (j == 0) ? lo : rtk_u(rtk_shfl(x, j - 1)) + 1u; // the answer is after pivot j-1 ...
+        const uint32_t nhi = (j == RTK_WAVE) ? hi : rtk_u(rtk_shfl(x, j));   // ... and not after pivot j
+        lo = nlo; hi = nhi;
+    }
     return lo;
+#endif
 }
-RTK_DEV uint32_t rtk_an_first_gt(const Anchors& a, uint32_t lo, uint32_t hi, uint64_t key) { // first x in [lo, hi) with pos(x) > key, else hi
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (static_cast<uint64_t>(rtk_u(rtk_an_pos(a, mid))) <= key) lo = mid + 1; else hi = mid; }
-    return lo;
-}
+RTK_DEV uint32_t rtk_an_first_ge(const Anchors& a, uint32_t lo, uint32_t hi, uint64_t key) { return rtk_an_search(a, lo, hi, key, false); }
+RTK_DEV uint32_t rtk_an_first_gt(const Anchors& a, uint32_t lo, uint32_t hi, uint64_t key) { return rtk_an_search(a, lo, hi, key, true); }
 
 // ------------------------------------------------------------------------------------------------ arenas and paths (src/Path.hpp)
 struct PathHdr { U<uint32_t> n, l, qlen, pad; }; // followed by n UMap and qlen quality bytes
@@ -610,7 +635,7 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
 #ifdef RTK_SIM
     { const unsigned long long na = s.cnt[3] - dfs_al0; const unsigned b = na > 15 ? 15 : static_cast<unsigned>(na); rtk_sim_site_stat[21][0] += 1; rtk_sim_site_stat[22 + (b >> 3)][b & 7] += 1; rtk_sim_site_stat[24 + (b >> 3)][b & 7] += na; }
 #endif
-    s.cnt[0] += n_exp;
+    s.cnt[0] += n_exp; s.hist[31] += 1;
     s.cnt[14] += (rtk_clock() - td0) - (s.cnt[9] - my0); // DFS bookkeeping: loop time minus the alignments inside it
     bool nt_score_deferred = false;
     if (lazy_nt && !rtk_failed(s)) {
@@ -957,10 +982,10 @@ RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint3
     rtk_wp_start(c, w0, start_um, rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual)));
     uint64_t cur = rtk_wp_commit(s, w0, 0); uint32_t cur_pos = start_pos; bool have = true;
     const uint32_t nw = lvw_hi - lvw_lo; // weak anchors of the region are lvw[lvw_lo + i], i in [0, nw)
-    while (i_weak < nw && rtk_an_pos(lvw, lvw_lo + i_weak) < start_pos) ++i_weak;
+    if (i_weak < nw) i_weak = rtk_an_first_ge(lvw, lvw_lo + i_weak, lvw_lo + nw, start_pos) - lvw_lo; // the reference's forward walks over the weak anchors, as searches
     if (i_weak < nw) { const uint32_t wp = rtk_an_pos(lvw, lvw_lo + i_weak); next_weak_pos = wp > start_pos + k ? wp : start_pos + k; }
     while (have && !end && !rtk_failed(s)) {
-        if (i_weak < nw) { while (i_weak < nw && static_cast<uint64_t>(rtk_an_pos(lvw, lvw_lo + i_weak)) < static_cast<uint64_t>(pos2 - k) && rtk_an_pos(lvw, lvw_lo + i_weak) < next_weak_pos) ++i_weak; }
+        if (i_weak < nw) { const uint64_t lim_a = static_cast<uint64_t>(pos2 - k), lim_b = next_weak_pos; i_weak = rtk_an_first_ge(lvw, lvw_lo + i_weak, lvw_lo + nw, lim_a < lim_b ? lim_a : lim_b) - lvw_lo; }
         else i_weak = nw;
         end = (i_weak == nw) || (static_cast<uint64_t>(rtk_an_pos(lvw, lvw_lo + i_weak)) >= static_cast<uint64_t>(pos2 - k));
         const uint32_t target_pos = end ? pos2 : rtk_an_pos(lvw, lvw_lo + i_weak);
@@ -1557,9 +1582,11 @@ RTK_HD uint64_t region_scratch_bytes(const RegionScratchCfg& c) {
     return (b + 255) / 256 * 256;
 }
 
-// the RegionScratch header itself lives at the start of the slab so that its mutable fields (arena tops, counters) are per wave
-RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& c) {
-    RegionScratch* s = reinterpret_cast<RegionScratch*>(base);
+// The RegionScratch header (pointers into the slab + the mutable control words: arena tops, working-path lengths, overflow flag,
+// counters) is read on every step of the wave-level programs. The kernels keep it in LDS (`hdr` = a __shared__ object of the
+// one-wave workgroup): a control-word read is an LDS access instead of an L2 / HBM round trip. hdr == nullptr: at the start of the slab.
+RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& c, RegionScratch* hdr = nullptr) {
+    RegionScratch* s = hdr ? hdr : reinterpret_cast<RegionScratch*>(base);
     char* p = base + ((sizeof(RegionScratch) + 255) / 256 * 256);
     RegionScratch t;
     t.my = scratch_carve(p, c.my); p += scratch_bytes(c.my);
@@ -1579,8 +1606,9 @@ RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& 
     for (int i = 0; i < 8; ++i) { t.rbuf[i] = p; p += c.str_cap; }
     t.str_cap = c.str_cap;
     t.memo_v = reinterpret_cast<uint8_t*>(p); p += c.memo_cap;
-    t.overflow = t.my.overflow;
+    t.ovf_word = 0; t.overflow = reinterpret_cast<uint32_t*>(&s->ovf_word); t.my.overflow = t.overflow;
     for (int i = 0; i < 16; ++i) { t.cnt[i] = 0; t.fine[i] = 0; }
+    for (int i = 0; i < 32; ++i) t.hist[i] = 0;
     *s = t; // every lane stores the same header
     return s;
 }
@@ -1633,7 +1661,7 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
         if (!lrc || !has_min_qual(0, so.pos[0] + k)) {
             const uint32_t i_solid_rev = so.n - 1;
             uint32_t i_weak_rev = we.n;
-            while (i_weak_rev > 0 && rtk_an_pos(we_r, i_weak_rev - 1) > rtk_an_pos(so_r, i_solid_rev)) --i_weak_rev;
+            i_weak_rev = rtk_an_first_gt(we_r, 0, i_weak_rev, rtk_an_pos(so_r, i_solid_rev)); // the reference steps back while the previous weak anchor lies after the solid one
             rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_rev, i_weak_rev, nullptr, bw, q_fw); // q_fw next to s_bw: as the reference writes it (:787, G17)
             if (rtk_failed(s)) return;
             rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
@@ -1644,8 +1672,7 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i], pb = so.pos[i + 1];
         const UMap ua = rtk_an_um(so, i), ub = rtk_an_um(so, i + 1);
-        uint32_t i_weak = 0; // first weak anchor at or after the left solid anchor (:801), found by binary search
-        { uint32_t lo = 0, hi = we.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (we.pos[mid] < pa) lo = mid + 1; else hi = mid; } i_weak = lo; }
+        const uint32_t i_weak = rtk_an_first_ge(we, 0, we.n, pa); // first weak anchor at or after the left solid anchor (:801)
         bool isUncorrected = false;
         bool sameUnitig = (ua.unitig == ub.unitig) && (ua.strand == ub.strand);
         if (lrc && has_min_qual(pa, pb + k)) isUncorrected = true; // :808
@@ -1680,7 +1707,8 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
             else {
                 const uint32_t i_solid_bw = so.n - i - 2;
                 uint32_t i_weak_bw = we.n - i_weak;
-                while (i_weak_bw > 0 && rtk_an_pos(we_r, i_weak_bw - 1) > rtk_an_pos(so_r, i_solid_bw)) --i_weak_bw;
+                i_weak_bw = rtk_an_first_gt(we_r, 0, i_weak_bw, rtk_an_pos(so_r, i_solid_bw));
+{ const uint32_t gl_ = pb - pa; s.hist[16 + (gl_ < 40 ? 0 : gl_ < 64 ? 1 : gl_ < 128 ? 2 : gl_ < 256 ? 3 : gl_ < 512 ? 4 : gl_ < 1024 ? 5 : 6)] += 1; }
                 rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_bw, i_weak_bw, &fw, bw, q_bw);
                 if (rtk_failed(s)) return;
                 rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
@@ -1716,8 +1744,7 @@ RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     } else if (kind == RTK_RG_TAIL) { // :940-950
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i];
-        uint32_t i_weak = 0;
-        { uint32_t lo = 0, hi = we.n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (we.pos[mid] < pa) lo = mid + 1; else hi = mid; } i_weak = lo; }
+        const uint32_t i_weak = rtk_an_first_ge(we, 0, we.n, pa);
         if (lrc && has_min_qual(pa, L)) { // :941: nothing to do, the else branch of :951-955
             rtk_app(s, out_s, &osl, s_fw + prev_pos, L - prev_pos); rtk_app(s, out_q, &oql, q_fw + prev_pos, L - prev_pos);
         } else {
