@@ -57,6 +57,161 @@ RTK_DEV RtkBM rtk_bm_from_ids(const uint32_t* uni, uint32_t U, uint64_t* scatter
 #endif
 }
 
+
+#ifndef RTK_SIM
+// The same selection for the common small case -- at most 512 ids (with repeats) on at most 24 side unitigs -- with every chain of
+// dependent memory round trips taken out: slot s lives in lane s (unitig, offsets and sizes of its colour lists, cardinality, flags:
+// three round trips for all slots together instead of five per slot and pass), the candidate anchors are ranked in registers, the
+// ids go from the colour pool straight into LDS (one flat pass over all lists), and the per-slot bit vectors (8 words at this size)
+// stay in LDS. Returns RTK_NONE32 when the case is not small (caller goes on to rtk_choose_colors_bits).
+#define RTK_CS_MAX_IDS 512u
+RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
+    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
+    RegionScratch& s = *c.sc;
+    const GraphView& g = c.g;
+    const uint32_t nw = rtk_u(side_w.n), ne = rtk_u(side_e.n), ns = rtk_u(side_s.n), n_slots = nw + ne + ns; // slot order: middle, right, left
+    if (n_slots == 0 || n_slots > RTK_CB_MAX_SLOTS) return RTK_NONE32;
+    const uint32_t lane = static_cast<uint32_t>(rtk_lane());
+    const uint32_t* const pw = rtk_u(side_w.u); const uint32_t* const pe = rtk_u(side_e.u); const uint32_t* const ps = rtk_u(side_s.u);
+    const uint8_t* const qw = rtk_u(side_w.nb); const uint8_t* const qe = rtk_u(side_e.nb); const uint8_t* const qs = rtk_u(side_s.nb);
+    const uint32_t* const col = g.col; const uint64_t* const loff = g.loff; const uint64_t* const goff = g.goff; const int32_t* const gid = g.gid; const uint32_t* const cardp = g.card;
+    // ---- A. one lane per slot ----
+    uint32_t m_u = 0, m_nl = 0, m_ng = 0, m_card = 0, m_nb = 0; uint64_t m_lo = 0, m_go = 0; int32_t m_gi = -1;
+    if (lane < n_slots) {
+        const uint32_t* pu; const uint8_t* pn; uint32_t i = lane;
+        if (i < nw) { pu = pw; pn = qw; } else if (i - nw < ne) { i -= nw; pu = pe; pn = qe; } else { i -= nw + ne; pu = ps; pn = qs; }
+        m_u = pu[i]; m_nb = pn[i];
+        m_gi = gid[m_u]; m_lo = loff[m_u]; m_nl = static_cast<uint32_t>(loff[m_u + 1] - m_lo); m_card = cardp[m_u];
+        if (m_gi >= 0) { m_go = goff[m_gi]; m_ng = static_cast<uint32_t>(goff[m_gi + 1] - m_go); }
+    }
+    int total = 0; const uint32_t st = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(m_nl + m_ng), &total)); // first id of the slot in the flat order
+    const uint32_t T = static_cast<uint32_t>(rtk_u(total));
+    if (T > RTK_CS_MAX_IDS) return RTK_NONE32;
+    // ---- B. candidate anchors: cardinality >= min_cov_vertices, first occurrence of their unitig, ordered by (cardinality, unitig) [D1] ----
+    const uint32_t min_cov_v = c.o.min_cov_vertices;
+    bool dup = false;
+    for (uint32_t j = 0; j + 1 < n_slots; ++j) { const uint32_t uj = rtk_shfl(m_u, static_cast<int>(j)); dup = dup || ((j < lane) && (uj == m_u)); }
+    const bool cand = lane < n_slots && m_card >= min_cov_v && !dup;
+    const uint64_t cb = rtk_ballot(cand); const uint32_t nsp = static_cast<uint32_t>(rtk_popc(cb));
+    const uint64_t key = (static_cast<uint64_t>(m_card) << 32) | m_u; // distinct among the candidates
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n_slots; ++j) { const uint64_t kj = rtk_shfl(key, static_cast<int>(j)); rank += (((cb >> j) & 1ull) && kj < key) ? 1u : 0u; }
+    uint32_t src = 0;
+    for (uint32_t j = 0; j < n_slots; ++j) { const uint32_t rj = rtk_shfl(rank, static_cast<int>(j)); if (((cb >> j) & 1ull) && rj == lane) src = j; }
+    // lane j < nsp holds the j-th candidate: its slot, cardinality and remaining quota (p_spid.second)
+    const uint32_t cov = 30;
+    const uint32_t k_slot = src; const uint32_t k_card = rtk_shfl(m_card, static_cast<int>(src));
+    uint32_t k_quota = k_card < cov ? k_card : cov;
+    // ---- C. universe: every id of every side unitig, straight into LDS, sorted, duplicates dropped ----
+    uint32_t* const L = rtk_lds_set_buf();
+    uint32_t* const uni = L; uint32_t* const raw = L + RTK_CS_MAX_IDS; uint64_t* const cbm = reinterpret_cast<uint64_t*>(L + 2u * RTK_CS_MAX_IDS);
+    uint64_t* const scatter = reinterpret_cast<uint64_t*>(L + RTK_CB_MAX_IDS); // cbm: 24 x 2 x 8 words = 3 KB, ends at u32 index 1792 <= 1920
+    uint32_t P = 64; while (P < T) P <<= 1;
+    for (uint32_t t0 = 0; t0 < P; t0 += RTK_WAVE) {
+        const uint32_t t = t0 + lane;
+        uint32_t i = 0;
+        for (uint32_t j = 1; j < n_slots; ++j) { const uint32_t sj = rtk_shfl(st, static_cast<int>(j)); if (sj <= t) i = j; } // the last slot that starts at or before t (empty slots share their start with the next one)
+        const uint32_t s_i = rtk_shfl(st, static_cast<int>(i)), nl_i = rtk_shfl(m_nl, static_cast<int>(i));
+        const uint64_t lo_i = rtk_shfl(m_lo, static_cast<int>(i)), go_i = rtk_shfl(m_go, static_cast<int>(i));
+        uint32_t x = 0xFFFFFFFFu;
+        if (t < T) { const uint32_t off = t - s_i; x = col[off < nl_i ? lo_i + off : go_i + (off - nl_i)]; raw[t] = x; }
+        uni[t] = x;
+    }
+    __syncthreads();
+    s.cnt[1] += T;
+    for (uint32_t kk = 2; kk <= P; kk <<= 1) for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = lane; i < P; i += RTK_WAVE) {
+            const uint32_t l = i ^ j;
+            if (l > i) { const uint32_t a = uni[i], b = uni[l]; if ((a > b) == ((i & kk) == 0)) { uni[i] = b; uni[l] = a; } }
+        }
+        __syncthreads();
+    }
+    uint32_t U = 0;
+    for (uint32_t i0 = 0; i0 < T; i0 += RTK_WAVE) {
+        const uint32_t i = i0 + lane;
+        uint32_t x = 0; bool keep = false;
+        if (i < T) { x = uni[i]; keep = (i == 0) || (uni[i - 1] != x); }
+        __syncthreads();
+        const uint64_t bal = rtk_ballot(keep);
+        if (keep) uni[U + static_cast<uint32_t>(rtk_popc(bal & ((1ull << lane) - 1ull)))] = x;
+        U += static_cast<uint32_t>(rtk_popc(bal));
+        __syncthreads();
+    }
+    // ---- D. bit vectors of every slot (local part, global part), 8 words each, in LDS ----
+    for (uint32_t slot = 0; slot < n_slots; ++slot) {
+        const uint32_t s_i = rtk_u(rtk_shfl(st, static_cast<int>(slot))), nl = rtk_u(rtk_shfl(m_nl, static_cast<int>(slot))), ng = rtk_u(rtk_shfl(m_ng, static_cast<int>(slot)));
+        const RtkBM bl = nl ? rtk_bm_from_ids(uni, U, scatter, raw + s_i, nl) : 0ull;
+        const RtkBM bg = ng ? rtk_bm_from_ids(uni, U, scatter, raw + s_i + nl, ng) : 0ull;
+        if (lane < 8) { cbm[(2u * slot) * 8u + lane] = bl; cbm[(2u * slot + 1u) * 8u + lane] = bg; }
+    }
+    __syncthreads();
+    auto ld = [&](uint32_t idx) -> RtkBM { return lane < 8 ? cbm[idx * 8u + lane] : 0ull; };
+    // ---- E. the six anchor classes: side (middle, right, left) x branching / non-branching; G2: the global set alone when there is one ----
+    RtkBM a[6];
+    for (int sh = 0; sh < 6; ++sh) {
+        RtkBM acc = 0ull;
+        const uint32_t first = (sh % 3 == 0) ? 0u : (sh % 3 == 1 ? nw : nw + ne), cnt = (sh % 3 == 0) ? nw : (sh % 3 == 1 ? ne : ns);
+        const uint32_t want_nb = sh >= 3 ? 1u : 0u;
+        for (uint32_t slot = first; slot < first + cnt; ++slot) {
+            if (rtk_u(rtk_shfl(m_nb, static_cast<int>(slot))) != want_nb) continue;
+            const bool has_global = rtk_u(rtk_shfl(m_gi, static_cast<int>(slot))) >= 0;
+            acc |= ld(2u * slot + (has_global ? 1u : 0u));
+        }
+        a[sh] = acc;
+    }
+    const RtkBM pos0 = a[0] | a[3], pos1 = a[1] | a[4], pos2 = a[2] | a[5];
+    const RtkBM a01 = pos0 & pos1, a12 = pos1 & pos2, a02 = pos0 & pos2;
+    const RtkBM nobranch_all = a[3] | a[4] | a[5];
+    const RtkBM i3 = a01 & a12, i2 = a01 | a12 | a02;
+    RtkBM nobranch = nobranch_all, branching = 0ull, prev2 = 0ull, all = 0ull;
+    uint32_t nb_unselected = nsp;
+    // ---- F. class loop (:331-429) ----
+    for (int i = 5; i >= 0; --i) {
+        if (nb_unselected == 0) break;
+        RtkBM a2;
+        if (i == 5) a2 = nobranch & i3;
+        else if (i == 4) { nobranch = rtk_bm_andn(nobranch, prev2); a2 = nobranch & i2; }
+        else if (i == 3) { nobranch = rtk_bm_andn(nobranch, prev2); a2 = nobranch; }
+        else if (i == 2) { branching = rtk_bm_andn(a[0] | a[1] | a[2], nobranch_all); a2 = branching & i3; }
+        else if (i == 1) { branching = rtk_bm_andn(branching, prev2); a2 = branching & i2; }
+        else { branching = rtk_bm_andn(branching, prev2); a2 = branching; }
+        prev2 = a2;
+        if (rtk_bm_count(a2) == 0) continue;
+        nb_unselected = 0;
+        RtkBM curr = a2;
+        for (uint32_t j = 0; j < nsp; ++j) {
+            int quota = static_cast<int>(rtk_u(rtk_shfl(k_quota, static_cast<int>(j))));
+            if (quota > 0) {
+                const uint32_t slot = rtk_u(rtk_shfl(k_slot, static_cast<int>(j)));
+                const RtkBM cu = ld(2u * slot) | ld(2u * slot + 1u); // all colours of the anchor
+                if (i == 0 || rtk_bm_count(cu & curr) >= 1) {
+                    const uint32_t cd = rtk_u(rtk_shfl(k_card, static_cast<int>(j))); const uint32_t min_cov = cd < cov ? cd : cov;
+                    const uint32_t sh = rtk_bm_count(cu & all);
+                    quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
+                    if (quota > 0) {
+                        const uint32_t all_card = rtk_bm_count(all);
+                        const RtkBM pid = rtk_bm_lowest(cu & curr, static_cast<uint32_t>(quota));
+                        all = all | pid; curr = rtk_bm_andn(curr, pid);
+                        const int gained = static_cast<int>(rtk_bm_count(all) - all_card);
+                        quota -= gained < quota ? gained : quota;
+                    }
+                }
+                if (lane == j) k_quota = static_cast<uint32_t>(quota);
+            }
+            nb_unselected += quota > 0 ? 1u : 0u;
+        }
+    }
+    // ---- all_pids back to a sorted id list in set[0] ----
+    const uint32_t n_all = rtk_bm_count(all);
+    if (n_all > s.set_cap) { rtk_fail_ovf(s, 9); return 0; }
+    uint32_t* out = s.set[0];
+    { int tot2; uint32_t at = static_cast<uint32_t>(rtk_wave_excl_scan(rtk_popc(all), &tot2)); uint64_t x = all;
+      while (x) { const int b = __builtin_ctzll(x); out[at++] = uni[64u * lane + static_cast<uint32_t>(b)]; x &= x - 1ull; } }
+    rtk_sync();
+    return n_all;
+}
+#endif
+
 // Returns |all_pids| (ids in s.set[0]), or RTK_NONE32 when the anchors' sets do not fit the small universe (caller falls back).
 RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
     const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);

@@ -364,7 +364,7 @@ RTK_GLOBAL void k_myers_batch(const MyersProb* probs, uint32_t n, const char* po
         const MyersProb p = probs[i];
         *sc.overflow = 0;
         const char* q = pool + p.q_off; const char* t = pool + p.t_off;
-        const MyersResult r = rtk_myers_distance(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.k, p.mode, use_iupac != 0, end_locs + static_cast<uint64_t>(i) * cap_locs, static_cast<int>(cap_locs));
+        const MyersResult r = rtk_myers_distance(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.k, p.mode, use_iupac != 0, cap_locs ? end_locs + static_cast<uint64_t>(i) * cap_locs : nullptr, static_cast<int>(cap_locs)); // cap_locs == 0: no list of end locations (the route the region program takes)
         dist[i] = r.dist; n_loc[i] = r.nloc;
         uint32_t nm = 0;
         if (want_path && r.dist >= 0 && p.qlen > 0 && p.tlen > 0) { // edlib.cpp:271-284 (zero-length inputs return before any path is built)
@@ -383,7 +383,7 @@ RTK_GLOBAL void k_myers_batch(const MyersProb* probs, uint32_t n, const char* po
 extern "C" int rtk_myers_batch(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
                                const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
                                int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar) {
-    if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || !end_locs) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch: null argument");
+    if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || (!end_locs && cap_locs)) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch: null argument");
     if (rtk_device_count() <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_myers_batch: no HIP device visible (no CPU fallback)");
     if (n == 0) return RTK_OK;
     try {
@@ -414,7 +414,7 @@ extern "C" int rtk_myers_batch(uint32_t n, const char* const* query, const uint3
         rtk_launch(k_myers_batch, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst);
         rtk_dsync();
         std::vector<uint32_t> st(n), nm(n);
-        rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs);
+        rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); if (cap_locs) rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs);
         rtk_d2h(st.data(), dst, 4ull * n); rtk_d2h(nm.data(), dnm, 4ull * n);
         int rc = RTK_OK;
         for (uint32_t i = 0; i < n; ++i) if (st[i]) rc = rtk_fail(RTK_ERR_DEVICE, "rtk_myers_batch: scratch capacity exceeded on device");

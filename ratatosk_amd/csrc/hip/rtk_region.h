@@ -1038,6 +1038,10 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
     const GraphView& g = c.g;
     unsigned long long tf = rtk_clock();
     { // the common case: all the anchors' ids fit a 4096-bit universe -> the whole selection in registers (rtk_colours.h)
+#ifndef RTK_SIM
+        { const uint32_t r0 = rtk_u(rtk_choose_colors_small(c, side_s, side_e, side_w));
+          if (r0 != RTK_NONE32) { s.fine[0] += rtk_clock() - tf; return rtk_failed(s) ? 0 : r0; } }
+#endif
         const uint32_t r = rtk_u(rtk_choose_colors_bits(c, side_s, side_e, side_w));
         if (r != RTK_NONE32) { s.fine[0] += rtk_clock() - tf; return rtk_failed(s) ? 0 : r; }
     }
