@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libratatosk_hip.so")
+LIB_PATH = os.environ.get("RTK_LIB_OVERRIDE") or os.path.join(_HERE, "libratatosk_hip.so")  # the override is for A/B runs of two builds (profiles/scripts/ab_lib.sh)
 
 
 class RtkError(RuntimeError):

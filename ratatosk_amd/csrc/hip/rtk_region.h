@@ -166,7 +166,7 @@ RTK_DEV uint64_t rtk_h_off(uint64_t h) { return h & 0x3FFFFFFFFFFFFFFFull; }
 
 RTK_DEV void rtk_wp_clear(WPath& p) { p.n = 0; p.l = 0; p.qlen = 0; }
 
-RTK_FN uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_) { // working path -> immutable record
+RTK_FN_LEAF uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_) { // working path -> immutable record
     RegionScratch& s = *rtk_u(&s_); const WPath& p = *rtk_u(&p_); const int lvl = rtk_u(lvl_);
     const unsigned long long tc0 = rtk_clock();
     const uint32_t pn = rtk_ld(&p.n), pl = rtk_ld(&p.l), pq = rtk_ld(&p.qlen);
@@ -180,7 +180,7 @@ RTK_FN uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_) { //
     return rtk_mk_handle(lvl, off);
 }
 
-RTK_FN void rtk_wp_load(RegionScratch& s_, WPath& p_, uint64_t h_) {
+RTK_FN_LEAF void rtk_wp_load(RegionScratch& s_, WPath& p_, uint64_t h_) {
     RegionScratch& s = *rtk_u(&s_); WPath& p = *rtk_u(&p_); const uint64_t h = rtk_u(h_);
     const int lvl = rtk_h_lvl(h); const uint64_t off = rtk_h_off(h);
     const char* rec = rtk_ld(&s.arena[lvl]) + off;
@@ -237,7 +237,7 @@ RTK_FN void rtk_wp_extend_q(const RCtx& c_, WPath& p_, const UMap& um_, const ch
 }
 
 // fills qual with `ch` for a fresh single-unitig path (string(len + k - 1, getQual(1.0)))
-RTK_FN void rtk_wp_start(const RCtx& c_, WPath& p_, const UMap& um_, char ch_) {
+RTK_FN_LEAF void rtk_wp_start(const RCtx& c_, WPath& p_, const UMap& um_, char ch_) {
     const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_); char ch = rtk_u(ch_);
     RegionScratch& s = *c.sc;
     rtk_wp_clear(p);
@@ -504,7 +504,7 @@ struct DfsOut { uint32_t n_t, n_nt; double t1, nt1, nt2; uint32_t nt_score_defer
 // window starts, its scores (or "not scored yet") and whether its quality string is still to be written.
 struct NtPending { uint32_t e; double nt1, nt2; uint32_t score_deferred, qual_deferred; };
 
-RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, uint32_t max_len_path_,
+RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, uint32_t max_len_path_,
                                     const UMap& um_, const UMap& um_e_, uint32_t level_) {
     // LAZY NON-TERMINAL PATHS. In explorePathsBFS2 a non-terminal sub-path of a DFS call is only used when the queue entry built from
     // it is popped while still shorter than max_len_path (src/GraphTraversal.cpp:364-366, 393-411); its score (HW alignment of the
@@ -677,7 +677,7 @@ RTK_FN DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pids_, uin
 }
 
 // explore() (src/GraphTraversal.cpp:41-93, 251-304). p = committed path (level 1). Results stay in list[2]/list[3] (level-2 arena).
-RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_e_, uint64_t hp_, uint32_t max_len_path_, uint32_t* n_t_, uint32_t* n_nt_, NtPending* pend_) {
+RTK_FN_SEARCH void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_e_, uint64_t hp_, uint32_t max_len_path_, uint32_t* n_t_, uint32_t* n_nt_, NtPending* pend_) {
     const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_e = rtk_u(um_e_); uint64_t hp = rtk_u(hp_); uint32_t max_len_path = rtk_u(max_len_path_); uint32_t* n_t = rtk_u(n_t_); uint32_t* n_nt = rtk_u(n_nt_); NtPending* pend = rtk_u(pend_);
     RegionScratch& s = *c.sc;
     *n_t = 0; *n_nt = 0; pend->e = 0; pend->nt1 = 0.0; pend->nt2 = 0.0; pend->score_deferred = 0; pend->qual_deferred = 0;
@@ -709,7 +709,7 @@ RTK_FN void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_al
 }
 
 // P (+) Q: w = copy of p extended by every mapping of sub with its quality slice (src/GraphTraversal.cpp:379-390)
-RTK_FN void rtk_extend_by(const RCtx& c_, WPath& w_, uint64_t hsub_, uint32_t upto_) {
+RTK_FN_LEAF void rtk_extend_by(const RCtx& c_, WPath& w_, uint64_t hsub_, uint32_t upto_) {
     const RCtx& c = *rtk_u(&c_); WPath& w = *rtk_u(&w_); uint64_t hsub = rtk_u(hsub_); uint32_t upto = rtk_u(upto_);
     RegionScratch& s = *c.sc;
     const int lv = rtk_h_lvl(hsub); const uint64_t oo = rtk_h_off(hsub);
@@ -834,7 +834,7 @@ RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, 
     return rtk_wp_commit(s, P, 1);
 }
 
-RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_s_, const UMap& um_e_, bool has_end_) {
+RTK_FN_SEARCH uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_s_, const UMap& um_e_, bool has_end_) {
     const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_s = rtk_u(um_s_); const UMap um_e = rtk_u(um_e_); bool has_end = rtk_u(has_end_);
     RegionScratch& s = *c.sc;
     const uint32_t k = static_cast<uint32_t>(c.k);
@@ -969,7 +969,7 @@ RTK_FN uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uin
 // ------------------------------------------------------------------------------------------------ extractSemiWeakPaths (src/Correction.cpp:3-157)
 // BFS results never hold more than one path, so `paths1` is a single running path (level 0). Dead ends are appended to
 // `partial` (list[5]). Returns the complete path handle or ~0.
-RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint32_t s_len_, const uint32_t* all_pids_, uint32_t n_all_, uint32_t start_pos_, const UMap& start_um_, uint32_t end_pos_in_, const UMap& end_um_, const Anchors& lvw_, uint32_t lvw_lo_, uint32_t lvw_hi_, uint32_t i_weak_, uint32_t* n_partial_) {
+RTK_FN_SEARCH uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint32_t s_len_, const uint32_t* all_pids_, uint32_t n_all_, uint32_t start_pos_, const UMap& start_um_, uint32_t end_pos_in_, const UMap& end_um_, const Anchors& lvw_, uint32_t lvw_lo_, uint32_t lvw_hi_, uint32_t i_weak_, uint32_t* n_partial_) {
     const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); uint32_t s_len = rtk_u(s_len_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); uint32_t start_pos = rtk_u(start_pos_); const UMap start_um = rtk_u(start_um_); uint32_t end_pos_in = rtk_u(end_pos_in_); const UMap end_um = rtk_u(end_um_); const Anchors& lvw = *rtk_u(&lvw_); uint32_t lvw_lo = rtk_u(lvw_lo_); uint32_t lvw_hi = rtk_u(lvw_hi_); uint32_t i_weak = rtk_u(i_weak_); uint32_t* n_partial = rtk_u(n_partial_);
     RegionScratch& s = *c.sc;
     const uint32_t k = static_cast<uint32_t>(c.k);
@@ -992,10 +992,12 @@ RTK_FN uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint3
         const uint32_t l_len = (target_pos - cur_pos) + k;
         const UMap um_start = begin ? start_um : rtk_rec_back(s, cur);
         uint64_t res = ~0ull; bool called = false;
-        if (end) {
-            if (no_end) { if (l_len <= (max_len_weak_region / 2)) { res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, rtk_um_empty(), false); called = true; } }
-            else if (l_len <= max_len_weak_region) { res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, end_um, true); called = true; }
-        } else if (l_len <= max_len_weak_region) { res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, rtk_an_um(lvw, lvw_lo + i_weak), true); called = true; }
+        { // one call site for the three cases: to the end of the read (:61-72), to the right solid anchor (:74-78), to the next weak anchor (:110-114)
+            UMap um_to = rtk_um_empty(); bool with_end = false;
+            if (end) { if (no_end) called = l_len <= (max_len_weak_region / 2); else { called = l_len <= max_len_weak_region; um_to = end_um; with_end = true; } }
+            else if (l_len <= max_len_weak_region) { called = true; um_to = rtk_an_um(lvw, lvw_lo + i_weak); with_end = true; }
+            if (called) res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, um_to, with_end);
+        }
         if (rtk_failed(s)) break;
         if (called && res != ~0ull) {
             rtk_wp_load(s, w0, cur); rtk_wp_merge(c, w0, res);
@@ -1257,9 +1259,9 @@ RTK_FN void rtk_rc_reverse_complement(RegionScratch& s_, ResCorr& r_, uint64_t* 
 }
 
 // appenders for the growing corrected strings
-RTK_FN void rtk_app(RegionScratch& s_, char* dst_, uint32_t* len_, const char* src_, uint32_t n_) {
+RTK_FN_LEAF void rtk_app(RegionScratch& s_, char* dst_, uint32_t* len_, const char* src_, uint32_t n_) {
     RegionScratch& s = *rtk_u(&s_); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); const char* src = rtk_u(src_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wcopy(dst + *len, src, n); *len += n; }
-RTK_FN void rtk_app_fill(RegionScratch& s_, char* dst_, uint32_t* len_, char ch_, uint32_t n_) {
+RTK_FN_LEAF void rtk_app_fill(RegionScratch& s_, char* dst_, uint32_t* len_, char ch_, uint32_t n_) {
     RegionScratch& s = *rtk_u(&s_); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); char ch = rtk_u(ch_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wfill(dst + *len, ch, n); *len += n; }
 
 // Bifrost Kmer(const char*) 2-bit code of any character (end k-mer test, src/Correction.cpp:720-724)
@@ -1380,15 +1382,21 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     uint64_t complete = ~0ull;
     char* s_corr = res.seq; char* q_corr = res.qual; uint32_t sl_ = 0, ql_ = 0;
     const Anchors& lvw = v_w;
-    { const unsigned long long t0 = rtk_clock(); if (n_all >= c.o.min_cov_vertices) complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, 0, &n_partial); s.cnt[6] += rtk_clock() - t0; }
-    if (rtk_failed(s)) return;
     const uint32_t nlw = lw_hi - lw_lo;
     auto clamp_len = [&](uint32_t pos, uint32_t len) -> uint32_t { return (pos + len <= s_len) ? len : (pos < s_len ? s_len - pos : 0); }; // std::string::substr
     auto add_uncorrected = [&](uint32_t pos, uint32_t len, char q) { rtk_app(s, s_corr, &sl_, s_read + pos, clamp_len(pos, len));
         if (lrc) rtk_app(s, q_corr, &ql_, q_read + pos, clamp_len(pos, len)); else rtk_app_fill(s, q_corr, &ql_, q, len_weak_region); }; // :459-469
-    if (complete == ~0ull) {
-        uint32_t i_w_s = 0;
-        while (complete == ~0ull && n_partial != 0 && nlw != 0 && n_all >= c.o.min_cov_vertices && !rtk_failed(s)) { // :619-651
+    // extractSemiWeakPaths from the left solid anchor (:613), then again from a weak anchor behind the best partial path as long as
+    // there is one (:619-651): ONE call site, so that the whole search can be compiled into this function
+    bool first_call = true, found_first = false, do_call = n_all >= c.o.min_cov_vertices;
+    uint32_t i_w_s = 0;
+    for (;;) {
+        if (do_call) { const unsigned long long t0 = rtk_clock(); complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, first_call ? 0u : i_w_s, &n_partial); s.cnt[6] += rtk_clock() - t0; }
+        if (rtk_failed(s)) return;
+        if (first_call && complete != ~0ull) found_first = true;
+        first_call = false;
+        if (!(complete == ~0ull && n_partial != 0 && nlw != 0 && n_all >= c.o.min_cov_vertices)) break;
+        { // :619-651
             int aid, aend;
             RTK_SITE(11); rtk_select_best(c, s.list[5], n_partial, s_read + p1, len_weak_region, RTK_MODE_SHW, c.o.weak_region_len_factor, &aid, &aend);
             if (rtk_failed(s) || aid == -1) break;
@@ -1410,9 +1418,11 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
             p1 = wpos; um1 = rtk_an_um(lvw, lw_lo + i_w_s);
             len_weak_region = p2 - p1 + k;
             s.top[0] = 0; n_partial = 0; // paths of the previous attempt are dead
-            { const unsigned long long t0 = rtk_clock(); complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, i_w_s, &n_partial); s.cnt[6] += rtk_clock() - t0; }
+            do_call = true;
         }
-        if (rtk_failed(s)) return;
+    }
+    if (rtk_failed(s)) return;
+    if (!found_first) {
         if (complete != ~0ull) {
             const uint32_t pl = rtk_rec_to_string(c, complete, s.str[0]); if (pl == 0xFFFFFFFFu) return;
             n_amb = rtk_amb_collect(c, complete, sl_, n_amb);
@@ -1629,7 +1639,7 @@ RTK_FN void rtk_emit_segment(const RCtx& c_, RegionDesc* rd_, const char* sq_, u
     rd->seg_off = off; rd->seq_len = sl; rd->qual_len = qll;
 }
 
-RTK_FN void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
+RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     const RCtx& c = *rtk_u(&c_); RegionDesc* rd = rtk_u(rd_);
     RegionScratch& s = *c.sc;
     const uint32_t r = rd->read, k = static_cast<uint32_t>(c.k);

@@ -22,6 +22,9 @@
 
 #define RTK_DEV inline
 #define RTK_FN inline
+#define RTK_FN_SEARCH inline
+#define RTK_FN_DRIVER inline
+#define RTK_FN_LEAF inline
 #define RTK_FN_HOT inline
 #define RTK_WAVE 1
 inline int rtk_lane() { return 0; }
@@ -41,6 +44,24 @@ inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64;
 
 #define RTK_DEV __device__ __forceinline__
 #define RTK_FN __device__ __noinline__ // large device functions are real calls: keeps hipcc compile time and code size bounded
+// The path search (extractSemiWeakPaths -> explorePathsBFS -> exploreSubGraph) is compiled into its caller: each of these programs
+// has ONE call site, and a call between two of them costs tens of 64-lane stack stores and reloads (register saves, by-reference
+// arguments) per region / hop / BFS step: k_regions 40.8 -> 38.5 ms per 64 Mb. -DRTK_SEARCH_CALLS restores the calls (A/B).
+#ifdef RTK_SEARCH_CALLS
+#define RTK_FN_SEARCH RTK_FN
+#else
+#define RTK_FN_SEARCH __device__ __forceinline__
+#endif
+#ifdef RTK_INLINE_LEAVES
+#define RTK_FN_LEAF __device__ __forceinline__
+#else
+#define RTK_FN_LEAF RTK_FN
+#endif
+#ifdef RTK_INLINE_DRIVER
+#define RTK_FN_DRIVER __device__ __forceinline__
+#else
+#define RTK_FN_DRIVER RTK_FN
+#endif
 // Thin wrappers and small leaves on the hot path (alignment entry, path scoring, path extension, colour memo, lane copies / fills).
 // A real call costs the callee-saved spills of the AMDGPU calling convention (one private-memory store and load of 64 lanes per
 // saved register, on every call): these are inlined; -DRTK_HOT_CALLS turns them back into calls for A/B measurements.
