@@ -745,18 +745,20 @@ RTK_DEV UMap rtk_start_suffix(const RCtx& c, const UMap& um_s) { // src/GraphTra
 // For every unitig of the path that lies on a short cycle (micro / mini-satellite motif) the stored compact cycles are tried as one
 // more turn through it: prefix + [unitig to its end, cycle unitigs, unitig from its start] + suffix; a turn is kept when it lowers the
 // NW distance to the read window (bounded by the distance so far). Identity when no unitig of the path is flagged.
+// is any unitig of the path on a short cycle? (the fast way out of fixRepeats, tested by the caller so that the common case costs no call)
+RTK_DEV bool rtk_path_has_short_cycle(const RCtx& c, uint64_t hp) {
+    RegionScratch& s = *c.sc; const GraphView& g = c.g;
+    const int lv = rtk_h_lvl(hp); const uint64_t oo = rtk_h_off(hp);
+    const UMap* pu = rtk_path_ums(s, lv, oo); const uint32_t pn = rtk_rec_n(s, hp);
+    bool any = false;
+    for (uint32_t i0 = 0; i0 < pn && !any; i0 += RTK_WAVE) { const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane()); any = rtk_ballot(i < pn && (g.flags[pu[i].unitig] & RTK_F_SHORT_CYCLE)) != 0ull; }
+    return any;
+}
 RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, uint32_t ref_len_) {
     const RCtx& c = *rtk_u(&c_); const uint64_t hp = rtk_u(hp_); const char* ref = rtk_u(ref_); const uint32_t ref_len = rtk_u(ref_len_);
     RegionScratch& s = *c.sc;
     const GraphView& g = c.g;
     const uint32_t k = static_cast<uint32_t>(c.k);
-    { // fast way out: no flagged unitig on the path
-        const int lv = rtk_h_lvl(hp); const uint64_t oo = rtk_h_off(hp);
-        const UMap* pu = rtk_path_ums(s, lv, oo); const uint32_t pn = rtk_rec_n(s, hp);
-        bool any = false;
-        for (uint32_t i0 = 0; i0 < pn && !any; i0 += RTK_WAVE) { const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane()); any = rtk_ballot(i < pn && (g.flags[pu[i].unitig] & RTK_F_SHORT_CYCLE)) != 0ull; }
-        if (!any) return hp;
-    }
     WPath& P = s.wp[1]; WPath& E = s.wp[2]; UMap* R = s.wp[3].ums;
     rtk_wp_load(s, P, hp);
     if (rtk_failed(s)) return ~0ull;
@@ -963,7 +965,7 @@ RTK_FN_SEARCH uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pid
     }
     if (rtk_failed(s) || nv == 0) return ~0ull;
     if (nv > 1) { int bid, bend; RTK_SITE(10); rtk_select_best(c, v, nv, ref, ref_len, RTK_MODE_NW, -1.0, &bid, &bend); if (rtk_failed(s)) return ~0ull; v[0] = v[bid]; }
-    return rtk_fix_repeats(c, v[0], ref, ref_len);
+    return rtk_path_has_short_cycle(c, v[0]) ? rtk_fix_repeats(c, v[0], ref, ref_len) : v[0];
 }
 
 // ------------------------------------------------------------------------------------------------ extractSemiWeakPaths (src/Correction.cpp:3-157)
