@@ -336,6 +336,7 @@ def main():
             "ms_per_step": 1e3 * dt_all / max(1, a.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[1]: k=31 first-pass correct, %.1f Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU" % (a.ref_len / 1e6, a.batch_bases),
                        "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated (one RCCL broadcast per flat buffer)" % world, "per_rank": per_rank,
+                       "value_is": "kernel-resident throughput: batches packed and in HBM before the clock starts (the contract's definition); the host-buffer-to-host-buffer rate is host_inclusive, the file-to-file rate cli_file_to_file",
                        "alg_bytes_per_base": round(whole_alg, 1), "setup_s": {"data+index": round(t_data, 1), "graph_load+upload": round(t_graph, 1)}},
             "roofline": roofline,
         }
