@@ -68,7 +68,17 @@ struct rtk_graph {
         if (pool_bytes + bytes > (24ull << 30)) { rtk_dfree(p); return; } // keep at most 24 GB parked
         pool.insert(std::make_pair(bytes, p)); pool_bytes += bytes;
     }
+    // work areas of the phasing step (second pass): one per ticket in flight, so that the hour-glass launches of several tickets (each as
+    // long as its longest read) overlap instead of queueing behind one lock; kept until the graph goes (tens of GB each: never hipFree'd mid-run)
+    std::vector<std::pair<void*, uint64_t> > phase_free;
+    void* phase_take(uint64_t bytes, uint64_t* got) {
+        { std::lock_guard<std::mutex> h(pool_lock);
+          for (size_t i = 0; i < phase_free.size(); ++i) if (phase_free[i].second >= bytes) { void* p = phase_free[i].first; *got = phase_free[i].second; phase_free.erase(phase_free.begin() + i); return p; } }
+        *got = bytes; return rtk_dmalloc(bytes);
+    }
+    void phase_give(void* p, uint64_t bytes) { std::lock_guard<std::mutex> h(pool_lock); phase_free.push_back(std::make_pair(p, bytes)); }
     void pool_clear() { std::lock_guard<std::mutex> h(pool_lock); for (std::multimap<uint64_t, void*>::iterator it = pool.begin(); it != pool.end(); ++it) rtk_dfree(it->second); pool.clear(); pool_bytes = 0;
+                        for (size_t i = 0; i < phase_free.size(); ++i) rtk_dfree(phase_free[i].first); phase_free.clear();
                         for (std::multimap<uint64_t, void*>::iterator it = hpool.begin(); it != hpool.end(); ++it) rtk_hfree_pinned(it->second); hpool.clear(); hpool_bytes = 0; }
     // pinned host staging buffers of finished batches (packed reads in, packed records out): hipHostMalloc costs milliseconds per call
     std::multimap<uint64_t, void*> hpool; uint64_t hpool_bytes = 0;
