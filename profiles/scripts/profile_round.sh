@@ -9,8 +9,6 @@ mkdir -p $OUT $SUM
 export TMPDIR=/tmp
 BENCH="python bench.py --no-cpu-baseline --no-host-legs"          # the default command (steps overlap on two streams)
 SERIAL="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs --serial"   # counter passes: one kernel at a time, so that a dispatch's counters are its own
-# 1. the bench line itself (with the CPU baseline)
-timeout 900 python bench.py > $SUM/${R}_bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats of the same command
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $SUM/${R}_bench_under_rocprof.json 2> $OUT/stats.err
 # 2b. the same with the steps back to back (per-kernel durations undisturbed by the next step's seed kernels)
@@ -23,4 +21,7 @@ timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -o calib -- python profiles/scripts/calib_gather.py > /dev/null 2> $OUT/calib_fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/calib_write -o calib -- python profiles/scripts/calib_gather.py > /dev/null 2> $OUT/calib_write.err
 python profiles/scripts/summarise.py $OUT $SUM $R
+# 5. the bench line itself (with the host legs and the CPU baseline), after the counter summary it quotes: roofline.traffic is read from profiles/<round>_pmc_summary.json
+cp $SUM/${R}_pmc_summary.json profiles/${R}_pmc_summary.json
+timeout 900 python bench.py > $SUM/${R}_bench.json 2> $OUT/bench.err
 ls -la $SUM
