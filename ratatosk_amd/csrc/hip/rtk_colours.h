@@ -46,13 +46,13 @@ RTK_DEV RtkBM rtk_bm_from_ids(const uint32_t* uni, uint32_t U, uint64_t* scatter
     return r;
 #else
     scatter[rtk_lane()] = 0ull;
-    __syncthreads();
+    RTK_WG_SYNC();
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) {
         const uint32_t id = ids[i];
         uint32_t lo = 0, hi = U; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (uni[mid] < id) lo = mid + 1; else hi = mid; }
         atomicOr(reinterpret_cast<unsigned long long*>(scatter) + (lo >> 6), 1ull << (lo & 63u));
     }
-    __syncthreads();
+    RTK_WG_SYNC();
     return scatter[rtk_lane()];
 #endif
 }
@@ -117,25 +117,25 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         if (t < T) { const uint32_t off = t - s_i; x = col[off < nl_i ? lo_i + off : go_i + (off - nl_i)]; raw[t] = x; }
         uni[t] = x;
     }
-    __syncthreads();
+    RTK_WG_SYNC();
     s.cnt[1] += T;
     for (uint32_t kk = 2; kk <= P; kk <<= 1) for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
         for (uint32_t i = lane; i < P; i += RTK_WAVE) {
             const uint32_t l = i ^ j;
             if (l > i) { const uint32_t a = uni[i], b = uni[l]; if ((a > b) == ((i & kk) == 0)) { uni[i] = b; uni[l] = a; } }
         }
-        __syncthreads();
+        RTK_WG_SYNC();
     }
     uint32_t U = 0;
     for (uint32_t i0 = 0; i0 < T; i0 += RTK_WAVE) {
         const uint32_t i = i0 + lane;
         uint32_t x = 0; bool keep = false;
         if (i < T) { x = uni[i]; keep = (i == 0) || (uni[i - 1] != x); }
-        __syncthreads();
+        RTK_WG_SYNC();
         const uint64_t bal = rtk_ballot(keep);
         if (keep) uni[U + static_cast<uint32_t>(rtk_popc(bal & ((1ull << lane) - 1ull)))] = x;
         U += static_cast<uint32_t>(rtk_popc(bal));
-        __syncthreads();
+        RTK_WG_SYNC();
     }
     // ---- D. bit vectors of every slot (local part, global part), 8 words each, in LDS ----
     for (uint32_t slot = 0; slot < n_slots; ++slot) {
@@ -144,7 +144,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         const RtkBM bg = ng ? rtk_bm_from_ids(uni, U, scatter, raw + s_i + nl, ng) : 0ull;
         if (lane < 8) { cbm[(2u * slot) * 8u + lane] = bl; cbm[(2u * slot + 1u) * 8u + lane] = bg; }
     }
-    __syncthreads();
+    RTK_WG_SYNC();
     auto ld = [&](uint32_t idx) -> RtkBM { return lane < 8 ? cbm[idx * 8u + lane] : 0ull; };
     // ---- E. the six anchor classes: side (middle, right, left) x branching / non-branching; G2: the global set alone when there is one ----
     RtkBM a[6];
@@ -266,23 +266,23 @@ RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, 
     uint32_t* const uni = rtk_lds_set_buf(); uint64_t* const scatter = reinterpret_cast<uint64_t*>(uni + RTK_CB_MAX_IDS);
     { uint32_t P = 64; while (P < T) P <<= 1; // bitonic sort of the padded ids in LDS
       for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < P; i += RTK_WAVE) uni[i] = i < T ? gathered[i] : 0xFFFFFFFFu;
-      __syncthreads();
+      RTK_WG_SYNC();
       for (uint32_t kk = 2; kk <= P; kk <<= 1) for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
           for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < P; i += RTK_WAVE) {
               const uint32_t l = i ^ j;
               if (l > i) { const uint32_t a = uni[i], b = uni[l]; if ((a > b) == ((i & kk) == 0)) { uni[i] = b; uni[l] = a; } }
           }
-          __syncthreads();
+          RTK_WG_SYNC();
       }
       for (uint32_t i0 = 0; i0 < T; i0 += RTK_WAVE) { // forward compaction of the first elements of the runs
           const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
           uint32_t x = 0; bool keep = false;
           if (i < T) { x = uni[i]; keep = (i == 0) || (uni[i - 1] != x); }
-          __syncthreads();
+          RTK_WG_SYNC();
           const uint64_t bal = rtk_ballot(keep);
           if (keep) uni[U + static_cast<uint32_t>(rtk_popc(bal & ((1ull << rtk_lane()) - 1ull)))] = x;
           U += static_cast<uint32_t>(rtk_popc(bal));
-          __syncthreads();
+          RTK_WG_SYNC();
       } }
 #endif
     // ---- bit vectors of every side unitig: global part, local part (kept in scratch: 2 x 512 B per slot) ----

@@ -271,30 +271,6 @@ static char* graph_scratch(rtk_graph* g, int slot, uint64_t bytes) { // grows mo
     return static_cast<char*>(g->scratch[slot]);
 }
 
-struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };
-
-RTK_HD uint64_t scratch_bytes(const ScratchCfg& c) {
-    uint64_t b = 0;
-    b += 8ull * 15 * c.w_cap; b += (c.t_cap + 63) / 64 * 64; b += 4ull * c.t_cap; b += 8ull * c.tb_cap_words; b += 8ull * c.r_cap;
-    b += 2ull * ((c.mv_cap + 63) / 64 * 64); b += 4 * 5 * 64; b += 64;
-    return (b + 255) / 256 * 256;
-}
-
-RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
-    MyersScratch s; char* p = base;
-    s.peq = reinterpret_cast<uint64_t*>(p); p += 8ull * 15 * c.w_cap; s.w_cap = c.w_cap;
-    s.tb = reinterpret_cast<uint64_t*>(p); p += 8ull * c.tb_cap_words; s.tb_cap_words = c.tb_cap_words;
-    s.colscore = reinterpret_cast<int32_t*>(p); p += 4ull * c.t_cap; s.t_cap = c.t_cap;
-    s.rowL = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.rowR = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.r_cap = c.r_cap;
-    s.hstack = reinterpret_cast<int32_t*>(p); p += 4 * 5 * 64;
-    s.overflow = reinterpret_cast<uint32_t*>(p); p += 64;
-    s.tb_gen = 0;
-    s.walk_cycles = 0; s.walk_moves = 0; s.walk_reloads = 0; s.walk_scalar = 0; s.walk_calls = 0; s.walk_tail_cycles = 0;
-    s.carry = reinterpret_cast<int8_t*>(p); p += (c.t_cap + 63) / 64 * 64;
-    s.moves = reinterpret_cast<uint8_t*>(p); p += (c.mv_cap + 63) / 64 * 64; s.moves_tmp = reinterpret_cast<uint8_t*>(p); s.mv_cap = c.mv_cap;
-    return s;
-}
-
 // ------------------------------------------------------------------------------------------------ K1: exact k-mer lookup
 // dbg.searchSequence(s, exact) (reference: src/Graph.cpp:97 [A1]). One lane per k-mer window; windows are addressed
 // by their base position in the concatenated read buffer. hits[b] = packed (unitig, dist, strand) or RTK_NO_HIT.

@@ -428,6 +428,208 @@ __device__ __forceinline__ SweepStat rtk_myers_fast_any(const char* __restrict__
 #endif
 
 
+#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
+// ------------------------------------------------------------------------------------------------ one pass on several waves
+// The row blocks (64 words = 4096 query rows each) of ONE pass run on the waves of the workgroup at the same time: block b consumes
+// the horizontal deltas block b-1 leaves at its bottom row (`carry`, one byte per column, in memory) one 64-column chunk behind it, so
+// a pass over B blocks takes about n + 128 B steps instead of B n. The waves of a workgroup sit on one CU and share its L1, so
+// workgroup-scope fences (no cache maintenance) order the carries in memory against the progress counters in LDS. The program wave (wave 0) publishes the pass in an LDS mailbox, the
+// helper waves of the workgroup pick it up, everybody takes the blocks b = wave, wave + NW, ... in ascending order (a block only ever
+// waits for a lower-numbered one, and those are started first: no cycle), wave 0 continues when all helpers have reported.
+#define RTK_COOP_MAXB 512
+struct RtkCoopJob { const char* qp; const char* tp; int m, n, qrev, trev, top_h, iupac; uint64_t* fin_pv; uint64_t* fin_mv; int8_t* carry; int32_t* colscore; };
+struct RtkCoop { RtkCoopJob job[2]; int n_jobs, seq, n_done, exit_flag, n_waves; int progress[RTK_COOP_MAXB]; }; // two passes at a time: the two halves of a Hirschberg split are independent
+__device__ __forceinline__ RtkCoop* rtk_coop() { __shared__ RtkCoop st; return &st; }
+__device__ __forceinline__ int rtk_coop_ld(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void rtk_coop_st(int* p, int v) { if (rtk_lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// one row block of the published pass (same arithmetic as the general loop of rtk_myers_pass)
+__device__ __noinline__ void rtk_myers_coop_block(RtkCoop* st, int ji, int b, int* progress) { // progress: the counters of this pass (one per row block)
+    const RtkCoopJob& J = st->job[ji];
+    const char* __restrict__ const qp = rtk_u(J.qp); const char* __restrict__ const tp = rtk_u(J.tp);
+    const int m = rtk_u(J.m), n = rtk_u(J.n), qrev = rtk_u(J.qrev), trev = rtk_u(J.trev), top_h = rtk_u(J.top_h); const bool iupac = rtk_u(J.iupac) != 0;
+    int8_t* __restrict__ const carry = rtk_u(J.carry); int32_t* __restrict__ const colscore = rtk_u(J.colscore);
+    uint64_t* const fin_pv = rtk_u(J.fin_pv); uint64_t* const fin_mv = rtk_u(J.fin_mv);
+    const int W = (m + 63) >> 6, last_bit = (m - 1) & 63;
+    const int lane = rtk_lane();
+    const int w0 = 64 * b;
+    const int nw = (W - w0) < 64 ? (W - w0) : 64;
+    const int w = w0 + lane;
+    const bool has_word = lane < nw;
+    const bool is_last_word = has_word && (w == W - 1);
+    const bool is_block_tail = (lane == nw - 1);
+    const int bit = is_last_word ? last_bit : 63;
+    const bool last_block = (w0 + nw >= W);
+    uint64_t eqA = 0, eqC = 0, eqG = 0, eqT = 0;
+    if (has_word) {
+        const int lim = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+        for (int i = 0; i < lim; ++i) {
+            const unsigned char qc = static_cast<unsigned char>(qrev ? qp[m - 1 - (64 * w + i)] : qp[64 * w + i]);
+            const uint32_t bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu;
+            eqA |= static_cast<uint64_t>(bm & 1u) << i; eqC |= static_cast<uint64_t>((bm >> 1) & 1u) << i;
+            eqG |= static_cast<uint64_t>((bm >> 2) & 1u) << i; eqT |= static_cast<uint64_t>((bm >> 3) & 1u) << i;
+        }
+    }
+    uint64_t Pv = ~0ull, Mv = 0ull;
+    int hout_prev = 0; unsigned tc_prev = 0;
+    int score = m;
+    const int steps = n + nw - 1;
+    int sbuf = 0;
+    bool plain = true; // target made of A/C/G/T only: the profile word is a select, no branches in the step
+    for (int c0 = 0; c0 < n && plain; c0 += 64) {
+        const int cj = c0 + lane; bool okc = true;
+        if (cj < n) { const unsigned char ch = static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj]); okc = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+        plain = (rtk_ballot(!okc) == 0ull);
+    }
+    for (int c0 = 0; c0 < steps; c0 += 64) {
+        const int cj = c0 + lane;
+        if (b > 0) { // the deltas of columns [c0, c0 + 64) must have left the block above
+            const int need = (c0 + 64) < n ? (c0 + 64) : n;
+            if (c0 < n) { while (rtk_coop_ld(&progress[b - 1]) < need) __builtin_amdgcn_s_sleep(8); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        int my_t = (cj < n) ? static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj])) : 0;
+        int my_c = (b != 0 && cj < n) ? static_cast<int>(carry[cj]) : top_h;
+        asm volatile("" : "+v"(my_t), "+v"(my_c));
+        const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
+        if (plain && last_block) { // the same for the block that holds the last query row: its bottom-row scores are parked 64 columns at a time
+            for (int j = 0; j < lim; ++j) {
+                const int s = c0 + j;
+                const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
+                const int in_c = __builtin_amdgcn_readlane(my_c, j);
+                const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+                const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(in_c + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
+                const int hin = static_cast<int>(got & 0xFFu) - 1;
+                const unsigned tc = got >> 8;
+                const unsigned sel = (tc >> 1) & 3u;
+                const uint64_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
+                uint64_t nPv = Pv, nMv = Mv, Ph, Mh;
+                const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
+                const int col = s - lane;
+                const bool active = has_word && col >= 0 && col < n;
+                Pv = active ? nPv : Pv; Mv = active ? nMv : Mv; hout_prev = active ? hout : hout_prev;
+                score += (active && is_block_tail) ? hout : 0;
+                tc_prev = tc;
+                const int tcol = s - (nw - 1);
+                if (tcol >= 0 && tcol < n) { // uniform
+                    const int sv = __builtin_amdgcn_readlane(score, nw - 1);
+                    sbuf = (lane == (tcol & 63)) ? sv : sbuf;
+                    if ((tcol & 63) == 63 || tcol == n - 1) { const int cc = (tcol & ~63) + lane; if (cc <= tcol) colscore[cc] = sbuf; }
+                }
+            }
+        } else
+        if (plain && !last_block) { // the common case, predicated instead of branched (scalar branches cost an instruction-fetch restart)
+            for (int j = 0; j < lim; ++j) {
+                const int s = c0 + j;
+                const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
+                const int in_c = __builtin_amdgcn_readlane(my_c, j);
+                const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+                const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(in_c + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
+                const int hin = static_cast<int>(got & 0xFFu) - 1;
+                const unsigned tc = got >> 8;
+                const unsigned sel = (tc >> 1) & 3u; // 'A' -> 0, 'C' -> 1, 'T' -> 2, 'G' -> 3
+                const uint64_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
+                uint64_t nPv = Pv, nMv = Mv, Ph, Mh;
+                const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
+                const int col = s - lane;
+                const bool active = has_word && col >= 0 && col < n;
+                Pv = active ? nPv : Pv; Mv = active ? nMv : Mv; hout_prev = active ? hout : hout_prev;
+                if (active && is_block_tail) carry[col] = static_cast<int8_t>(hout);
+                tc_prev = tc;
+            }
+        } else
+        for (int j = 0; j < lim; ++j) {
+            const int s = c0 + j;
+            const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
+            const int in_c = __builtin_amdgcn_readlane(my_c, j);
+            const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+            const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(in_c + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
+            const int hin = static_cast<int>(got & 0xFFu) - 1;
+            const unsigned tc = got >> 8;
+            const int col = s - lane;
+            const bool active = has_word && col >= 0 && col < n;
+            if (active) {
+                uint64_t Eq;
+                if (tc == 'A') Eq = eqA; else if (tc == 'C') Eq = eqC; else if (tc == 'G') Eq = eqG; else if (tc == 'T') Eq = eqT;
+                else {
+                    Eq = 0; const int lim2 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                    for (int i = 0; i < lim2; ++i) Eq |= static_cast<uint64_t>(rtk_chars_equal(static_cast<unsigned char>(qrev ? qp[m - 1 - (64 * w + i)] : qp[64 * w + i]), static_cast<unsigned char>(tc), iupac)) << i;
+                }
+                uint64_t Ph, Mh;
+                const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
+                if (is_block_tail) { if (!last_block) carry[col] = static_cast<int8_t>(hout); else score += hout; }
+                hout_prev = hout;
+            }
+            tc_prev = tc;
+            if (last_block) {
+                const int tcol = s - (nw - 1);
+                if (tcol >= 0 && tcol < n) {
+                    const int sv = __builtin_amdgcn_readlane(score, nw - 1);
+                    if (lane == (tcol & 63)) sbuf = sv;
+                    if ((tcol & 63) == 63 || tcol == n - 1) { const int cc = (tcol & ~63) + lane; if (cc <= tcol) colscore[cc] = sbuf; }
+                }
+            }
+        }
+        if (!last_block) { // columns whose delta has left this block: the tail lane is nw - 1 columns behind lane 0
+            int done = c0 + lim - (nw - 1); done = done < 0 ? 0 : (done > n ? n : done);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            rtk_coop_st(&progress[b], done);
+        }
+    }
+    if (fin_pv && has_word) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (!last_block) rtk_coop_st(&progress[b], n);
+}
+
+__device__ __forceinline__ void rtk_myers_coop_run(RtkCoop* st, int wave) {
+    // the passes of a job have the same query length, hence the same number B of row blocks; block index i < B: pass 0, else pass 1.
+    // Every wave takes its indices in ascending order and a block only waits for index i - 1 of its own pass: the lowest unfinished
+    // index can always run, so nobody waits for ever.
+    const int W = (rtk_u(st->job[0].m) + 63) >> 6, B = (W + 63) >> 6, nj = rtk_coop_ld(&st->n_jobs), nwv = rtk_coop_ld(&st->n_waves);
+    for (int i = wave; i < nj * B; i += nwv) { const int ji = i >= B ? 1 : 0; rtk_myers_coop_block(st, ji, i - ji * B, st->progress + ji * B); }
+}
+
+// helper waves of the workgroup: wait for passes until the program wave says it is done
+__device__ __forceinline__ void rtk_myers_coop_helper(int wave) {
+    RtkCoop* st = rtk_coop();
+    int seen = 0;
+    while (true) {
+        int sq;
+        while ((sq = rtk_coop_ld(&st->seq)) == seen) { if (rtk_coop_ld(&st->exit_flag)) return; __builtin_amdgcn_s_sleep(32); }
+        seen = sq;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        rtk_myers_coop_run(st, wave);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (rtk_lane() == 0) __hip_atomic_fetch_add(&st->n_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// program wave: publish one pass -- or two passes of the same query length (q2 != nullptr: the second one works on the columns behind
+// the first one's in the carry / score arrays) --, take part, wait for the helpers. Returns false when not worth sharing (caller runs them alone).
+__device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, uint64_t* fin_pv, uint64_t* fin_mv,
+                                                    const MySeq* q2 = nullptr, const MySeq* t2 = nullptr, uint64_t* fin_pv2 = nullptr, uint64_t* fin_mv2 = nullptr) {
+    RtkCoop* st = rtk_coop();
+    const int nwv = rtk_coop_ld(&st->n_waves);
+    const int W = (q.n + 63) >> 6, B = (W + 63) >> 6, nj = q2 ? 2 : 1;
+    if (nwv < 2 || B * nj < 2 || B * nj > RTK_COOP_MAXB || (q2 && q2->n != q.n)) return false;
+    if (rtk_lane() == 0) {
+        RtkCoopJob j; j.qp = q.p; j.tp = t.p; j.m = q.n; j.n = t.n; j.qrev = q.rev; j.trev = t.rev; j.top_h = top_h; j.iupac = iupac ? 1 : 0;
+        j.fin_pv = fin_pv; j.fin_mv = fin_mv; j.carry = rtk_u(sc.carry); j.colscore = rtk_u(sc.colscore);
+        st->job[0] = j;
+        if (q2) { j.qp = q2->p; j.tp = t2->p; j.m = q2->n; j.n = t2->n; j.qrev = q2->rev; j.trev = t2->rev; j.fin_pv = fin_pv2; j.fin_mv = fin_mv2; j.carry += t.n; j.colscore += t.n; st->job[1] = j; }
+        st->n_jobs = nj;
+    }
+    for (int i = rtk_lane(); i < nj * B; i += RTK_WAVE) st->progress[i] = 0;
+    if (rtk_lane() == 0) st->n_done = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the strings of the pass (global memory) and the mailbox
+    rtk_coop_st(&st->seq, rtk_coop_ld(&st->seq) + 1);
+    rtk_myers_coop_run(st, 0);
+    while (rtk_coop_ld(&st->n_done) < nwv - 1) __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+#endif
+
 // Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
 // top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
@@ -460,6 +662,9 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq
     delete[] heapPv; delete[] heapMv;
 #else
     const int lane = rtk_lane();
+#ifdef RTK_MULTIWAVE
+    if (!store && rtk_myers_pass_coop(sc, q, t, top_h, iupac, fin_pv, fin_mv)) { rtk_sync(); return; } // several row blocks: shared with the helper waves of the workgroup
+#endif
     // local copies: the scratch descriptor lives in private memory and its fields could alias the stores below,
     // which would force a (slow) reload of every pointer on every step
     int8_t* __restrict__ const carry = rtk_u(sc.carry); int32_t* __restrict__ const colscore = rtk_u(sc.colscore); uint64_t* __restrict__ const tb = rtk_u(sc.tb);
@@ -810,9 +1015,15 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
         }
         const int lh = tn / 2, rh = tn - lh;
         if (lh == 0 || static_cast<uint64_t>(4 * W) > sc.tb_cap_words || sp + 2 > 60) { *sc.overflow = 1; return; }
-        rtk_myers_pass(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, lh), 1, iupac, 0, fin, fin + W);
+        bool both = false;
+#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
+        { const MySeq qa = rtk_seq(q + q0, qm), ta = rtk_seq(t + t0, lh), qb = rtk_seq(q + q0, qm, 1), tb_ = rtk_seq(t + t0 + lh, rh, 1); // the two half passes side by side on the waves of the workgroup
+          both = static_cast<uint32_t>(lh + rh) <= sc.t_cap && rtk_myers_pass_coop(sc, qa, ta, 1, iupac, fin, fin + W, &qb, &tb_, fin + 2 * W, fin + 3 * W);
+          if (both) rtk_sync(); }
+#endif
+        if (!both) rtk_myers_pass(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, lh), 1, iupac, 0, fin, fin + W);
         rtk_myers_column(fin, fin + W, qm, lh, sc.rowL);
-        rtk_myers_pass(sc, rtk_seq(q + q0, qm, 1), rtk_seq(t + t0 + lh, rh, 1), 1, iupac, 0, fin + 2 * W, fin + 3 * W);
+        if (!both) rtk_myers_pass(sc, rtk_seq(q + q0, qm, 1), rtk_seq(t + t0 + lh, rh, 1), 1, iupac, 0, fin + 2 * W, fin + 3 * W);
         rtk_myers_column(fin + 2 * W, fin + 3 * W, qm, rh, sc.rowR);
         // R(i) = cost of aligning q[i..qm) with the right half = rowR[qm-1-i]
         int split = -2;
@@ -912,5 +1123,31 @@ RTK_FN bool rtk_myers_path_from_saved(const MyersScratch& sc_, const MyersSaved&
     rtk_myers_walk(sc, sv.m, sv.shw.first + 1, sv.n, sv.shw.dist, n_moves);
     return true;
 }
+
+// ------------------------------------------------------------------------------------------------ work area of one wave
+struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };
+
+RTK_HD uint64_t scratch_bytes(const ScratchCfg& c) {
+    uint64_t b = 0;
+    b += 8ull * 15 * c.w_cap; b += (c.t_cap + 63) / 64 * 64; b += 4ull * c.t_cap; b += 8ull * c.tb_cap_words; b += 8ull * c.r_cap;
+    b += 2ull * ((c.mv_cap + 63) / 64 * 64); b += 4 * 5 * 64; b += 64;
+    return (b + 255) / 256 * 256;
+}
+
+RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
+    MyersScratch s; char* p = base;
+    s.peq = reinterpret_cast<uint64_t*>(p); p += 8ull * 15 * c.w_cap; s.w_cap = c.w_cap;
+    s.tb = reinterpret_cast<uint64_t*>(p); p += 8ull * c.tb_cap_words; s.tb_cap_words = c.tb_cap_words;
+    s.colscore = reinterpret_cast<int32_t*>(p); p += 4ull * c.t_cap; s.t_cap = c.t_cap;
+    s.rowL = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.rowR = reinterpret_cast<int32_t*>(p); p += 4ull * c.r_cap; s.r_cap = c.r_cap;
+    s.hstack = reinterpret_cast<int32_t*>(p); p += 4 * 5 * 64;
+    s.overflow = reinterpret_cast<uint32_t*>(p); p += 64;
+    s.tb_gen = 0;
+    s.walk_cycles = 0; s.walk_moves = 0; s.walk_reloads = 0; s.walk_scalar = 0; s.walk_calls = 0; s.walk_tail_cycles = 0;
+    s.carry = reinterpret_cast<int8_t*>(p); p += (c.t_cap + 63) / 64 * 64;
+    s.moves = reinterpret_cast<uint8_t*>(p); p += (c.mv_cap + 63) / 64 * 64; s.moves_tmp = reinterpret_cast<uint8_t*>(p); s.mv_cap = c.mv_cap;
+    return s;
+}
+
 
 #endif

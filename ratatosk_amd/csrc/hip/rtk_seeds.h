@@ -128,7 +128,7 @@ RTK_FN uint32_t rtk_first_shared(const GraphView& g_, uint32_t u_, const uint32_
 #ifndef RTK_SIM
     uint32_t* const lds = rtk_lds_set_buf();
     const bool staged = (ngl + nlo) <= RTK_LDS_SET_CAP;
-    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < ngl + nlo; i += RTK_WAVE) lds[i] = i < ngl ? gl[i] : lo[i - ngl]; __syncthreads(); }
+    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < ngl + nlo; i += RTK_WAVE) lds[i] = i < ngl ? gl[i] : lo[i - ngl]; RTK_WG_SYNC(); }
 #endif
     uint32_t found = 0;
     for (uint32_t i0 = 0; i0 < n && found < want; i0 += RTK_WAVE) {
@@ -342,7 +342,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
         const uint64_t a0 = tile * 64 + static_cast<uint64_t>(rtk_lane()), a1 = a0 + 64;
         tile_chars[rtk_lane()] = (a0 < bv.n_bases) ? static_cast<unsigned char>(bv.masked[a0]) : 'N';
         tile_chars[64 + rtk_lane()] = (a1 < bv.n_bases) ? static_cast<unsigned char>(bv.masked[a1]) : 'N';
-        __syncthreads();
+        RTK_WG_SYNC();
     }
 #endif
 #ifdef RTK_SIM

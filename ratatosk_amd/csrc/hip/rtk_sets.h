@@ -41,7 +41,7 @@ RTK_FN uint32_t rtk_set_filter(const uint32_t* a_, uint32_t na_, const uint32_t*
 #ifndef RTK_SIM
     uint32_t* const lds_b = rtk_lds_set_buf();
     const bool staged = nb <= RTK_LDS_SET_CAP && na >= 16;
-    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nb; i += RTK_WAVE) lds_b[i] = b[i]; __syncthreads(); }
+    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nb; i += RTK_WAVE) lds_b[i] = b[i]; RTK_WG_SYNC(); }
 #endif
     for (uint32_t i0 = 0; i0 < na; i0 += RTK_WAVE) {
         const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
@@ -70,7 +70,7 @@ RTK_FN uint32_t rtk_set_inter_count(const uint32_t* a_, uint32_t na_, const uint
 #ifndef RTK_SIM
     uint32_t* const lds_b = rtk_lds_set_buf();
     const bool staged = nb <= RTK_LDS_SET_CAP && na >= 16;
-    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nb; i += RTK_WAVE) lds_b[i] = b[i]; __syncthreads(); }
+    if (staged) { for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nb; i += RTK_WAVE) lds_b[i] = b[i]; RTK_WG_SYNC(); }
 #endif
     for (uint32_t i0 = 0; i0 < na && cnt < cap; i0 += RTK_WAVE) {
         const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
@@ -117,7 +117,7 @@ RTK_FN void rtk_sort_pairs(uint64_t* key_, uint64_t* val_, uint32_t n_) {
     if (p <= RTK_LDS_SORT_CAP) {
         uint64_t* const lk = rtk_lds_sort_buf(); uint64_t* const lv = lk + RTK_LDS_SORT_CAP;
         for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) { lk[i] = i < n ? key[i] : ~0ull; lv[i] = i < n ? val[i] : ~0ull; }
-        __syncthreads();
+        RTK_WG_SYNC();
         for (uint32_t kk = 2; kk <= p; kk <<= 1) {
             for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
                 for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) {
@@ -129,7 +129,7 @@ RTK_FN void rtk_sort_pairs(uint64_t* key_, uint64_t* val_, uint32_t n_) {
                         if (gt == up) { lk[i] = kl; lk[l] = ki; lv[i] = vl; lv[l] = vi; }
                     }
                 }
-                __syncthreads();
+                RTK_WG_SYNC();
             }
         }
         for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) { key[i] = lk[i]; val[i] = lv[i]; }

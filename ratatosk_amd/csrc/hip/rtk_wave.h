@@ -76,8 +76,15 @@ __device__ __forceinline__ uint64_t rtk_ballot(bool p) { return __ballot(p ? 1 :
 template <class T> __device__ __forceinline__ T rtk_shfl(T v, int src) { return __shfl(v, src, 64); }
 // value of lane-1 (lane 0 receives lane0_value)
 template <class T> __device__ __forceinline__ T rtk_shfl_up1(T v, T lane0_value) { const T r = __shfl_up(v, 1, 64); return rtk_lane() == 0 ? lane0_value : r; }
-// publishes lane-parallel stores to the other lanes of the (single-wave) workgroup
-__device__ __forceinline__ void rtk_sync() { __syncthreads(); }
+// publishes lane-parallel stores to the other lanes of the (single-wave) workgroup. In the translation unit of the multi-wave kernels
+// (RTK_MULTIWAVE: one program wave + helper waves per workgroup, rtk_phase_long.hip) a program runs on ONE wave of a bigger
+// workgroup, so the workgroup barrier becomes a fence + wave barrier: a real s_barrier would wait for waves that never come.
+#ifdef RTK_MULTIWAVE
+#define RTK_WG_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define RTK_WG_SYNC() __syncthreads()
+#endif
+__device__ __forceinline__ void rtk_sync() { RTK_WG_SYNC(); }
 __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
 template <class T> __device__ __forceinline__ T rtk_atomic_add_raw(T* p, T v) { return atomicAdd(p, v); }

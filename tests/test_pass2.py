@@ -135,6 +135,30 @@ def test_gpu_pass2_k63_matches_oracle(ds_pass2_big):
     _check_pass2(ds_pass2_big, GPU_LIB, threads=32, k=63)
 
 
+@pytest.fixture(scope="module")
+def ds_pass2_long(tmp_path_factory):
+    """A few very long reads (up to ~90 kb: more than 16 row blocks of 4096 query rows in the whole-read alignment of phasing())."""
+    return _second_pass_set(tmp_path_factory.mktemp("ds_pass2_long"), "p2l", ["--seed", 35, "--ref-len", 400000, "--het", 0.002, "--sr-cov", 30, "--sr-err", 0.005,
+                                                                              "--lr-n", 12, "--lr-len", 45000, "--lr-profile", "ont", "--lr-err", 0.07])
+
+
+@pytest.mark.gpu
+def test_gpu_pass2_multiwave_kernel(ds_pass2_big, ds_pass2_long, monkeypatch):
+    """The multi-wave phasing kernel (rtk_phase_long.hip: the row blocks of one alignment pass on the waves of a workgroup) against
+    the oracle: forced onto every read longer than 2 kb of the 6 kb set (two row blocks per pass), then on reads of tens of kb with its
+    default threshold (several blocks per wave)."""
+    monkeypatch.setenv("RTK_PHASE_LONG", "2000")
+    _check_pass2(ds_pass2_big, GPU_LIB, threads=32, k=63)
+    monkeypatch.delenv("RTK_PHASE_LONG")
+    og, pg, seqs, quals, raws = _load(ds_pass2_long, GPU_LIB, 31)
+    assert max(len(r) for r in raws) > 70000
+    want = og.correct_batch2(seqs, quals, raws, og.opts(long_read_correct=1), threads=12)
+    got = pg.correct_batch(seqs, quals, pg.opts(long_read_correct=1), raw=raws)
+    assert got == want
+    monkeypatch.setenv("RTK_PHASE_LONG", "0")  # the same reads on one wave each
+    assert pg.correct_batch(seqs, quals, pg.opts(long_read_correct=1), raw=raws) == want
+
+
 @pytest.mark.gpu
 def test_gpu_pass2_small(ds_pass2):
     _check_pass2(ds_pass2, GPU_LIB)
