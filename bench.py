@@ -175,6 +175,33 @@ def cli_leg(a, pre, fa, rt):
         return {"error": str(e)[-300:]}
 
 
+def second_pass_leg(a, pre):
+    """The next row of the scope table, measured the same way (not part of `value`): `Ratatosk correct -1`, the second index at k2 = 63
+    (short-read graph coloured by the pass-1 reads, like src/Ratatosk.cpp:1193,1227), then `Ratatosk correct -2`, file to file."""
+    import re
+    exe = os.path.join(ROOT, "ratatosk_amd", "bin", "Ratatosk")
+    out = os.path.join(os.path.dirname(pre), "p2_out")
+    env = dict(os.environ, RTK_CLI_STATS="1")
+    cores = min(16, os.cpu_count() or 1)
+    pat = r"correction phase ([0-9.]+) s wall, (\d+) bases"
+    try:
+        r1 = subprocess.run([exe, "correct", "-1", "-c", str(cores), "--gpus", "1", "-g", pre + ".index.k31.fasta.gz", "-d", pre + ".index.k31.rtsk", "-l", pre + ".lr.fq", "-o", out], capture_output=True, text=True, env=env, timeout=300)
+        if r1.returncode != 0:
+            return {"error": (r1.stderr or r1.stdout)[-300:]}
+        t0 = time.time()
+        subprocess.run([os.path.join(ROOT, "ratatosk_amd", "bin", "rtk_build_index"), "-s", pre + ".sr.fq", "--colour-reads", out + ".2.fastq", "-k", "63", "-o", out + ".p2"], stderr=subprocess.DEVNULL, check=True, timeout=600)
+        t_idx = time.time() - t0
+        r2 = subprocess.run([exe, "correct", "-2", "-c", str(cores), "--gpus", "1", "-g", out + ".p2.index.k63.fasta.gz", "-d", out + ".p2.index.k63.rtsk", "-l", out + ".2.fastq", "-L", pre + ".lr.fq", "-o", out],
+                            capture_output=True, text=True, env=env, timeout=300)
+        m = re.search(pat, r2.stderr + r2.stdout)
+        if r2.returncode != 0 or not m:
+            return {"error": (r2.stderr or r2.stdout)[-300:]}
+        return {"value": int(m.group(2)) / float(m.group(1)), "unit": "bases/s", "bases": int(m.group(2)), "correction_phase_s": float(m.group(1)), "k2": 63, "second_index_build_s": round(t_idx, 1),
+                "what": "Ratatosk correct -2 -c %d --gpus 1 on the OUT.2.fastq of a `correct -1` run + the uncorrected reads, OUT.fastq out; phasing() pre-filter, exact anchors, k2 = 63 (two-word k-mers)" % cores}
+    except Exception as e:
+        return {"error": str(e)[-300:]}
+
+
 def cpu_baseline_leg(a, api, graph, opts, fa, rt, tickets, whole_alg, out):
     """CPU baseline: the oracle (C++ restatement of the reference path; the reference binary cannot be built: Bifrost absent) with the
     reference's threading model (N threads pulling reads, src/Ratatosk.cpp:727-904) and the REFERENCE's own edlib underneath
@@ -343,6 +370,7 @@ def main():
         if world == 1 and not a.no_host_legs:
             out["host_inclusive"] = host_inclusive_leg(a, api, graph, opts, mine)
             out["cli_file_to_file"] = cli_leg(a, pre, fa, rt)
+            out["second_pass"] = second_pass_leg(a, pre)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(a, api, graph, opts, fa, rt, mine, whole_alg, out)
         print(json.dumps(out))
