@@ -1,0 +1,41 @@
+"""The bench.py contract on CPU: one JSON line with the fields the driver reads, at N = 1 and as two ranks under torch.distributed.run
+(developer simulator + gloo: the plumbing of `--gpus N` -- graph replication, ticket sharding, max-over-ranks timing -- not a measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--sim", "--ref-len", "60000", "--batch-bases", "120000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-host-legs"]
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_common(d, n):
+    assert d["metric"] == "corrected long-read bases/sec" and d["unit"] == "bases/s" and d["n_gpus"] == n and d["steps"] == 1 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["value"] > 0
+    assert "workload" in d["config"] and len(d["config"]["per_rank"]) == n
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and "traffic" in r
+
+
+def test_bench_line_single(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--workdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_common(_line(r.stdout), 1)
+
+
+def test_bench_line_two_ranks(tmp_path):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL + ["--workdir", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    _check_common(d, 2)
+    pr = d["config"]["per_rank"]
+    assert sorted(p["rank"] for p in pr) == [0, 1] and all(p["bases"] > 0 for p in pr)
+    assert abs(d["value"] - sum(p["bases"] for p in pr) / max(p["seconds"] for p in pr)) / d["value"] < 0.05  # whole-job rate: all ranks' bases over the slowest rank's time
