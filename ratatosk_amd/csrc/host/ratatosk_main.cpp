@@ -39,7 +39,7 @@
 struct Opt {
     std::vector<std::string> in_long, in_long_raw;
     std::string out, graph, udata;
-    int cores = 1, gpus = 0, workers_per_gpu = 3, k1 = 31, k2 = 63, max_qual = 40, trim = 0;
+    int cores = 1, gpus = 0, workers_per_gpu = 3, k1 = 31, k2 = 63, max_qual = 40, trim = 0, rounds = 1;
     double min_conf_snp = 0.9;
     size_t insert_sz = 500, w1 = 1000, w2 = 5000, batch_bases = 32u << 20;
     bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false, gzip = false;
@@ -53,7 +53,7 @@ static void usage() {
                     "  -B, --batch-bases     long-read bases per ticket (default 32 Mi)\n"
                     "  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
-                    "  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
+                    "  -r, --correction-rounds  correction rounds of the 1st pass (default 1)\n  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
                     "      --strip-annotations  drop the short-cycle / SNP annotations of the index before correcting (fixRepeats / fixAmbiguity then have nothing to do)\n"
                     "Writes <out_prefix>.2.fastq (plain FASTQ, input order).\n\n"
                     "       Ratatosk correct -2 -g <graph2.fasta.gz> -d <unitig_data2.rtsk> -l <out_prefix>.2.fastq -L <long_reads> -o <out_prefix> [options]\n"
@@ -106,9 +106,12 @@ int main(int argc, char** argv) {
         {"in-graph", required_argument, 0, 'g'}, {"in-unitig-data", required_argument, 0, 'd'}, {"insert-sz", required_argument, 0, 'i'}, {"k1", required_argument, 0, 'k'},
         {"max-len-weak1", required_argument, 0, 'w'}, {"max-base-qual", required_argument, 0, 'Q'}, {"min-conf-snp-corr", required_argument, 0, 'm'}, {"1st-pass-only", no_argument, 0, '1'}, {"2nd-pass-only", no_argument, 0, '2'},
         {"in-long-raw", required_argument, 0, 'L'}, {"k2", required_argument, 0, 'K'}, {"max-len-weak2", required_argument, 0, 'W'}, {"trim-split", required_argument, 0, 't'}, {"gzip-out", no_argument, 0, 'G'},
+        {"correction-rounds", required_argument, 0, 'r'}, {"no-snp-correction", no_argument, 0, 'F'}, {"force-io-order", no_argument, 0, 'O'}, {"no-graph-index", no_argument, 0, 'I'},
+        {"in-unmapped-short", required_argument, 0, 'u'}, {"in-accurate-long", required_argument, 0, 'a'}, {"in-short-phase", required_argument, 0, 'p'}, {"in-long-phase", required_argument, 0, 'P'}, {"force-correct-snp", no_argument, 0, 'f'},
+        {"sampling", required_argument, 0, 'S'}, {"min-conf-color2", required_argument, 0, 'M'}, {"min-len-color2", required_argument, 0, 'C'},
         {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"gpus", required_argument, 0, 1002}, {"workers-per-gpu", required_argument, 0, 1003}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
     int c, idx = 0;
-    while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:L:K:W:t:G12v", lo, &idx)) != -1) {
+    while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:L:K:W:t:r:u:a:p:P:S:M:C:GFOIf12v", lo, &idx)) != -1) {
         switch (c) {
             case 'l': opt.in_long.push_back(optarg); break;
             case 'o': opt.out = optarg; break;
@@ -121,6 +124,10 @@ int main(int argc, char** argv) {
             case 'Q': opt.max_qual = atoi(optarg); break;
             case 'm': opt.min_conf_snp = atof(optarg); break;
             case 'B': opt.batch_bases = strtoull(optarg, nullptr, 10); break;
+            case 'r': opt.rounds = atoi(optarg); break;
+            case 'F': case 'I': case 'S': case 'M': case 'C': break; // only read by `index` (detectSNPs, .bfi, addCoverage: src/Ratatosk.cpp:1067,1124; src/Graph.cpp:1573,1796,2117)
+            case 'O': break; // output is in input order in both passes here (src/Ratatosk.cpp:919 re-orders only when asked in pass 2)
+            case 'u': case 'a': case 'p': case 'P': case 'f': fprintf(stderr, "Ratatosk::correct: -%c (unmapped-read rescue / helper long reads / phased input / forced SNP correction) is not in scope of this build\n", c); return 1;
             case 'L': opt.in_long_raw.push_back(optarg); break;
             case 'K': opt.k2 = atoi(optarg); break;
             case 'W': opt.w2 = strtoull(optarg, nullptr, 10); break;
@@ -139,6 +146,7 @@ int main(int argc, char** argv) {
     if (opt.pass1 == opt.pass2) { fprintf(stderr, "Ratatosk::correct: one pass per run with a pre-built index (-g, -d): give -1 or -2\n"); return 1; }
     const bool lrc = opt.pass2;
     if (lrc && opt.in_long_raw.empty()) { fprintf(stderr, "Ratatosk::correct: -2 needs the uncorrected long reads (-L) next to the pass-1 reads (-l)\n"); return 0; }
+    if (opt.rounds < 1) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of correction rounds cannot be less than 1.\n"); return 0; } // src/Ratatosk.cpp:348-352
     if (opt.trim < 0 || opt.trim > opt.max_qual) { fprintf(stderr, "Ratatosk::Ratatosk(): Quality score trimming threshold cannot be less than 0 or more than %d (%d given).\n", opt.max_qual, opt.trim); /* src/Ratatosk.cpp:324-326 */ return 0; }
     if (opt.graph.empty() || opt.udata.empty() || opt.in_long.empty() || opt.out.empty()) { fprintf(stderr, "Ratatosk::correct: -g, -d, -l and -o are required\n"); return 0; }
     { // src/Ratatosk.cpp:312-322
@@ -267,6 +275,7 @@ int main(int argc, char** argv) {
             for (uint32_t i = 0; i < n; ++i) { ps[i] = R.seq(i); len[i] = R.seq_len(i); }
             const long long tc0 = now_us();
             rtk_batch* b = nullptr;
+            rtk_batch* b_prev = nullptr; // -r N: the previous round's batch (its fetch view is the next round's input)
             int rc;
             if (lrc) {
                 static const char none[1] = {0};
@@ -274,9 +283,28 @@ int main(int argc, char** argv) {
                 for (uint32_t i = 0; i < n; ++i) { pq[i] = R.qual(i) ? R.qual(i) : none; pr[i] = t->raw.seq(i); rlen[i] = t->raw.seq_len(i); }
                 rc = rtk_batch_create2(g, n, ps.data(), pq.data(), len.data(), pr.data(), rlen.data(), &b);
             } else rc = rtk_batch_create(g, n, ps.data(), nullptr, len.data(), &b); // pass 1 replaces every quality (src/Correction.cpp:184-185)
-            if (rc == RTK_OK) rc = rtk_batch_run(b, &ro);
             const char* pool = nullptr; const uint64_t* off = nullptr; const uint32_t* olen = nullptr;
-            if (rc == RTK_OK) rc = rtk_batch_fetch_view(b, &pool, &off, &olen);
+            const int n_rounds = lrc ? 1 : opt.rounds;
+            for (int j = 0; j < n_rounds && rc == RTK_OK; ++j) { // src/Ratatosk.cpp:847-866: every round corrects the output of the one before with its own thresholds
+                rtk_opts rj = ro;
+                if (n_rounds > 1) {
+                    const double step_min_score = 1.0 / static_cast<double>(n_rounds);
+                    const double step_f = (ro.weak_region_len_factor - 0.10) / static_cast<double>(n_rounds - 1);
+                    const uint64_t step_w = ro.max_len_weak_region1 / static_cast<uint64_t>(n_rounds);
+                    rj.min_score = 1.0 - static_cast<double>(j + 1) * step_min_score;
+                    rj.weak_region_len_factor = ro.weak_region_len_factor - static_cast<double>(n_rounds - j - 1) * step_f;
+                    rj.max_len_weak_region1 = static_cast<uint64_t>(j + 1) * step_w;
+                }
+                if (j > 0) { // the reads of this round = the records of the last one
+                    for (uint32_t i = 0; i < n; ++i) { ps[i] = pool + off[i]; len[i] = olen[i]; }
+                    b_prev = b; b = nullptr;
+                    rc = rtk_batch_create(g, n, ps.data(), nullptr, len.data(), &b);
+                    rtk_batch_free(b_prev); b_prev = nullptr;
+                    if (rc != RTK_OK) break;
+                }
+                rc = rtk_batch_run(b, &rj);
+                if (rc == RTK_OK) rc = rtk_batch_fetch_view(b, &pool, &off, &olen);
+            }
             us_correct += now_us() - tc0;
             if (rc != RTK_OK) { fail(std::string("Ratatosk::correct(): ") + rtk_last_error()); if (b) rtk_batch_free(b); return; }
             const long long tf0 = now_us();

@@ -125,3 +125,50 @@ def test_cli_snp_annotated_index_and_min_conf_option(ds_snps, tmp_path):
     plain, _ = op.Graph(ds_snps + "_plain.index.k31.fasta.gz", ds_snps + "_plain.index.k31.rtsk", 31).correct_batch(seqs, quals, threads=4)
     assert [(g[1], g[2]) for g in op.read_fastq(out + ".2.fastq")] == plain
     assert want != plain
+
+
+def _oracle_rounds(og, seqs, quals, n_rounds):
+    """The round loop of src/Ratatosk.cpp:847-866 around the oracle's per-read correction."""
+    base = og.opts()
+    f0, w0 = base.weak_region_len_factor, base.max_len_weak_region1
+    for j in range(n_rounds):
+        o = og.opts()
+        o.min_score = 1.0 - (j + 1) * (1.0 / n_rounds)
+        o.weak_region_len_factor = f0 - (n_rounds - j - 1) * ((f0 - 0.10) / (n_rounds - 1))
+        o.max_len_weak_region1 = (j + 1) * (w0 // n_rounds)
+        out, _ = og.correct_batch(seqs, quals, opts=o, threads=4)
+        seqs, quals = [s for s, _ in out], [q for _, q in out]
+    return list(zip(seqs, quals))
+
+
+def test_cli_correction_rounds_and_reference_flags(ds_small, tmp_path):
+    """-r N (src/Ratatosk.cpp:847-866: N passes over a read with min_score / length window / maximum region length stepping towards
+    the one-round values) through the simulator build of the driver against the oracle; the flags a reference command line may carry
+    that only `index` reads (-F -O -I -S -M -C) are accepted, the out-of-scope inputs (-u -a -p -P -f) are named and refused."""
+    sim = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "Ratatosk_sim")
+    fa, rt = ds_small + ".index.k31.fasta.gz", ds_small + ".index.k31.rtsk"
+    og = op.Graph(fa, rt, 31)
+    reads = op.read_fastq(ds_small + ".lr.fq")
+    want = _oracle_rounds(og, [r[1] for r in reads], [r[2] for r in reads], 3)
+    assert want != og.correct_batch([r[1] for r in reads], [r[2] for r in reads], threads=4)[0]  # the rounds make a difference on this set
+    out = str(tmp_path / "r3")
+    r = subprocess.run([sim, "correct", "-1", "-r", "3", "-F", "-O", "-I", "-S", "0.5", "-c", "2", "-B", "9000", "-g", fa, "-d", rt, "-l", ds_small + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = op.read_fastq(out + ".2.fastq")
+    assert [(g[1], g[2]) for g in got] == want and [g[0] for g in got] == [x[0] for x in reads]
+    r = subprocess.run([sim, "correct", "-1", "-u", "x.fq", "-g", fa, "-d", rt, "-l", ds_small + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 1 and "not in scope" in r.stderr
+    r = subprocess.run([sim, "correct", "-1", "-r", "0", "-g", fa, "-d", rt, "-l", ds_small + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0 and "correction rounds" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpu_cli_correction_rounds(ds_small, tmp_path):
+    fa, rt = ds_small + ".index.k31.fasta.gz", ds_small + ".index.k31.rtsk"
+    og = op.Graph(fa, rt, 31)
+    reads = op.read_fastq(ds_small + ".lr.fq")
+    want = _oracle_rounds(og, [r[1] for r in reads], [r[2] for r in reads], 2)
+    out = str(tmp_path / "r2")
+    r = subprocess.run([EXE, "correct", "-1", "-r", "2", "-c", "2", "-B", "9000", "-g", fa, "-d", rt, "-l", ds_small + ".lr.fq", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert [(g[1], g[2]) for g in op.read_fastq(out + ".2.fastq")] == want
