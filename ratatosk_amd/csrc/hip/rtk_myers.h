@@ -36,6 +36,7 @@ struct MyersScratch {
     U<uint32_t*> overflow;  // set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
     U<uint32_t> tb_gen;     // bumped by everything that writes the traceback table: a saved sweep (MyersSaved) is only resumed on its own table
     U<unsigned long long> walk_cycles, walk_moves, walk_reloads, walk_scalar, walk_calls, walk_tail_cycles; // profile of the traceback walks
+    U<unsigned long long> hb_pass, hb_split, hb_leaf, hb_total; // profile of the Hirschberg driver: half passes, column extraction + split search, leaf tracebacks, all
 };
 
 // traceback table entry of (column, 64-bit query word): word-major, so that the walk's window of 64 consecutive columns of one word is
@@ -989,19 +990,24 @@ RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, i
 // obtainAlignment (edlib.cpp:1164-1216) with the Hirschberg split of edlib.cpp:1234-1399 restated canonically:
 // target halved at n/2; the FIRST query row (ascending) whose left + right scores add up to the optimum, then the
 // row -1 boundary, then the last row. Iterative (explicit stack), emits moves in order into sc.moves.
-RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int best_, bool iupac_, uint32_t* n_moves_) {
+// best < 0: the distance is not known yet. A problem that is split learns it from the split itself (the optimum is the smallest sum of a
+// left and a right score), one that fits the in-memory traceback does not need it; *best_out (optional) receives it either way
+// (-1 when the traceback branch was taken without it). Saves the separate distance pass of a Hirschberg-sized problem.
+RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int best_, bool iupac_, uint32_t* n_moves_, int* best_out_ = nullptr) {
     const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), best = rtk_u(best_);
-    const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_);
+    const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_); int* best_out = rtk_u(best_out_);
+    if (best_out) *best_out = best;
     *n_moves = 0;
     { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; }
     if (static_cast<uint32_t>(m + n) > sc.mv_cap || static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap || static_cast<uint32_t>(m) > sc.r_cap) { *sc.overflow = 1; return; }
     int32_t* st = sc.hstack;
     int sp = 0;
+    MyersScratch& prof = const_cast<MyersScratch&>(sc); const unsigned long long t_all0 = rtk_clock();
     st[0] = 0; st[1] = m; st[2] = 0; st[3] = n; st[4] = best; sp = 1;
     uint64_t* fin = sc.tb; // Hirschberg passes do not store the table, so its memory holds the final delta vectors (2 x 2 x W words)
     while (sp > 0) {
         --sp;
-        const int q0 = st[5 * sp], qm = st[5 * sp + 1], t0 = st[5 * sp + 2], tn = st[5 * sp + 3], bs = st[5 * sp + 4];
+        const int q0 = st[5 * sp], qm = st[5 * sp + 1], t0 = st[5 * sp + 2], tn = st[5 * sp + 3], bs_in = st[5 * sp + 4];
         if (qm == 0 || tn == 0) { // edlib.cpp:1171-1178
             rtk_wfill(sc.moves + *n_moves, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn));
             *n_moves += static_cast<uint32_t>(qm + tn);
@@ -1010,22 +1016,38 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
         const long long W = (qm + 63) >> 6;
         if ((2LL * 8 + 4) * W * tn + 8LL * tn < 1024 * 1024) { // edlib.cpp:1191-1193
             if (static_cast<uint64_t>(4 * W * tn) > sc.tb_cap_words) { *sc.overflow = 1; return; }
-            rtk_myers_traceback(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, n_moves);
+            { const unsigned long long t0_ = rtk_clock(); rtk_myers_traceback(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, n_moves); prof.hb_leaf += rtk_clock() - t0_; }
             continue;
         }
         const int lh = tn / 2, rh = tn - lh;
         if (lh == 0 || static_cast<uint64_t>(4 * W) > sc.tb_cap_words || sp + 2 > 60) { *sc.overflow = 1; return; }
         bool both = false;
+        const unsigned long long t_p0 = rtk_clock();
 #if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
         { const MySeq qa = rtk_seq(q + q0, qm), ta = rtk_seq(t + t0, lh), qb = rtk_seq(q + q0, qm, 1), tb_ = rtk_seq(t + t0 + lh, rh, 1); // the two half passes side by side on the waves of the workgroup
           both = static_cast<uint32_t>(lh + rh) <= sc.t_cap && rtk_myers_pass_coop(sc, qa, ta, 1, iupac, fin, fin + W, &qb, &tb_, fin + 2 * W, fin + 3 * W);
           if (both) rtk_sync(); }
 #endif
         if (!both) rtk_myers_pass(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, lh), 1, iupac, 0, fin, fin + W);
-        rtk_myers_column(fin, fin + W, qm, lh, sc.rowL);
         if (!both) rtk_myers_pass(sc, rtk_seq(q + q0, qm, 1), rtk_seq(t + t0 + lh, rh, 1), 1, iupac, 0, fin + 2 * W, fin + 3 * W);
+        const unsigned long long t_p1 = rtk_clock(); prof.hb_pass += t_p1 - t_p0;
+        rtk_myers_column(fin, fin + W, qm, lh, sc.rowL);
         rtk_myers_column(fin + 2 * W, fin + 3 * W, qm, rh, sc.rowR);
         // R(i) = cost of aligning q[i..qm) with the right half = rowR[qm-1-i]
+        int bs_known = bs_in;
+        if (bs_known < 0) { // the optimum = the smallest left + right sum over every split point (rows 0 .. qm-2, the row -1 boundary, the last row)
+            int mn = 0x7fffffff;
+            for (int b0 = 0; b0 + 1 < qm; b0 += RTK_WAVE) { const int qi = b0 + rtk_lane(); if (qi + 1 < qm) { const int v = sc.rowL[qi] + sc.rowR[qm - 2 - qi]; mn = v < mn ? v : mn; } }
+#ifndef RTK_SIM
+            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o, 64); mn = v < mn ? v : mn; }
+#endif
+            mn = rtk_u(mn);
+            const int e0 = lh + sc.rowR[qm - 1], e1 = sc.rowL[qm - 1] + rh;
+            mn = e0 < mn ? e0 : mn; mn = e1 < mn ? e1 : mn;
+            bs_known = mn;
+            if (best_out) *best_out = mn;
+        }
+        const int bs = bs_known;
         int split = -2;
         for (int b0 = 0; b0 + 1 < qm && split == -2; b0 += RTK_WAVE) {
             const int qi = b0 + rtk_lane();
@@ -1042,7 +1064,9 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
         // push right then left so that the left half is emitted first
         st[5 * sp] = q0 + ul; st[5 * sp + 1] = qm - ul; st[5 * sp + 2] = t0 + lh; st[5 * sp + 3] = rh; st[5 * sp + 4] = rs; ++sp;
         st[5 * sp] = q0; st[5 * sp + 1] = ul; st[5 * sp + 2] = t0; st[5 * sp + 3] = lh; st[5 * sp + 4] = ls; ++sp;
+        prof.hb_split += rtk_clock() - t_p1;
     }
+    prof.hb_total += rtk_clock() - t_all0;
 }
 
 // edlibAlign(..., k = -1, NW or SHW, TASK_PATH): result and moves. When the whole table fits the in-memory traceback branch of
@@ -1078,6 +1102,13 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
         }
     }
 #endif
+    if (!have && mode == RTK_MODE_NW && m > 0 && n > 0 && (2LL * 8 + 4) * ((m + 63) >> 6) * n + 8LL * n >= 1024 * 1024) {
+        // Hirschberg-sized NW problem: the first split yields the distance, no separate distance pass
+        int d = -1;
+        rtk_myers_alignment(sc, q, m, t, n, -1, iupac, n_moves, &d);
+        r.dist = d; r.first = r.last = n - 1; r.nloc = 1;
+        return r;
+    }
     if (!have) r = rtk_myers_distance(sc, q, m, t, n, -1, mode, iupac);
     if (m > 0 && n > 0) rtk_myers_alignment(sc, q, m, t, (mode == RTK_MODE_NW) ? n : (r.first + 1), r.dist, iupac, n_moves);
     return r;
@@ -1144,6 +1175,7 @@ RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
     s.overflow = reinterpret_cast<uint32_t*>(p); p += 64;
     s.tb_gen = 0;
     s.walk_cycles = 0; s.walk_moves = 0; s.walk_reloads = 0; s.walk_scalar = 0; s.walk_calls = 0; s.walk_tail_cycles = 0;
+    s.hb_pass = 0; s.hb_split = 0; s.hb_leaf = 0; s.hb_total = 0;
     s.carry = reinterpret_cast<int8_t*>(p); p += (c.t_cap + 63) / 64 * 64;
     s.moves = reinterpret_cast<uint8_t*>(p); p += (c.mv_cap + 63) / 64 * 64; s.moves_tmp = reinterpret_cast<uint8_t*>(p); s.mv_cap = c.mv_cap;
     return s;

@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(1024) k_phase_long(GraphView g, OptsView o, Ba
         rtk_phase_read(c, pv, r);
         if (rtk_lane() == 0) bv.status[r] = *sc->overflow;
     }
+    if (rtk_lane() == 0) { rtk_atomic_add(bv.counters + 60, sc->my.hb_pass); rtk_atomic_add(bv.counters + 61, sc->my.hb_split); rtk_atomic_add(bv.counters + 62, sc->my.hb_leaf); rtk_atomic_add(bv.counters + 63, sc->my.hb_total); rtk_atomic_add(bv.counters + 59, sc->cnt[9]); }
     rtk_coop_st(&st->exit_flag, 1); // the helpers leave
 }
 
