@@ -25,6 +25,6 @@ r2 = subprocess.run([exe, "correct", "-2", "-K", str(k2), "-c", "16", "-g", pre 
 t_p2 = time.time() - t0
 assert r2.returncode == 0, r2.stderr
 stats = lambda txt: [l for l in txt.splitlines() if "correction phase" in l]
-tr = [l for l in r2.stderr.splitlines() if "rtk trace" in l and ("attempt" in l or "phase" in l or "seeds" in l)]
+tr = [l for l in r2.stderr.splitlines() if "rtk trace" in l and ("attempt" in l or "phase" in l or "seeds" in l or "shares" in l or "size class" in l or "DFS book" in l)]
 print(json.dumps({"ref_len": ref_len, "lr_bases": lr_bases, "k2": k2, "data_s": round(t_data, 1), "pass1_wall_s": round(t_p1, 2), "pass1": stats(r1.stderr), "index2_s": round(t_idx2, 1),
-                  "pass2_wall_s": round(t_p2, 2), "pass2_options": extra2, "pass2": stats(r2.stderr), "pass2_trace_head": tr[:24]}, indent=1))
+                  "pass2_wall_s": round(t_p2, 2), "pass2_options": extra2, "pass2": stats(r2.stderr), "pass2_trace_head": tr[:40]}, indent=1))
