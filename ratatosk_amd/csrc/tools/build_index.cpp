@@ -21,7 +21,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <fstream>
+#include <mutex>
 #include <queue>
 #include <set>
 #include <string>
@@ -83,29 +86,40 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=63)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
     const KM mask = km_mask<KM>(k);
 
-    // ---- pass 1: count canonical k-mers ----
-    KTable<KM> cnt(1 << 22);
+    // ---- pass 1: count canonical k-mers. The k-mer space is cut into one shard per thread by a hash; every thread reads the input
+    // itself (parsing is cheap next to a table insert) and counts the k-mers of its shard in a table of its own ----
+    unsigned n_thr = std::thread::hardware_concurrency(); if (n_thr == 0) n_thr = 1; if (n_thr > 32) n_thr = 32;
+    { const char* e = getenv("RTK_INDEX_THREADS"); if (e && atoi(e) > 0) n_thr = static_cast<unsigned>(atoi(e)); }
+    std::vector<KM> solid;
     {
-        std::string name, seq, qual;
-        for (size_t f = 0; f < in_files.size(); ++f) {
-            FastxReader fr;
-            if (!fr.open(in_files[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", in_files[f].c_str()); return 1; }
-            while (fr.next(name, seq, qual)) {
-                KM fw = 0; int valid = 0;
-                for (size_t i = 0; i < seq.size(); ++i) {
-                    const int b = base2bits(seq[i]);
-                    if (b < 0) { valid = 0; fw = 0; continue; }
-                    fw = ((fw << 2) | static_cast<KM>(b)) & mask;
-                    if (++valid >= k) ++*cnt.slot(kmer_canonical(fw, k), true);
+        std::vector<std::vector<KM> > part(n_thr);
+        std::vector<int> bad(n_thr, 0);
+        auto count_shard = [&](unsigned t) {
+            KTable<KM> cnt(1 << 20);
+            std::string name, seq, qual;
+            for (size_t f = 0; f < in_files.size(); ++f) {
+                FastxReader fr;
+                if (!fr.open(in_files[f])) { bad[t] = 1; return; }
+                while (fr.next(name, seq, qual)) {
+                    KM fw = 0; int valid = 0;
+                    for (size_t i = 0; i < seq.size(); ++i) {
+                        const int b = base2bits(seq[i]);
+                        if (b < 0) { valid = 0; fw = 0; continue; }
+                        fw = ((fw << 2) | static_cast<KM>(b)) & mask;
+                        if (++valid >= k) { const KM c = kmer_canonical(fw, k); if ((hash_km(c) >> 40) % n_thr == t) ++*cnt.slot(c, true); }
+                    }
                 }
             }
-        }
+            for (size_t i = 0; i < cnt.keys.size(); ++i) if (cnt.keys[i] != EMPTY && cnt.vals[i] >= min_count) part[t].push_back(cnt.keys[i]);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(count_shard, t);
+        for (size_t t = 0; t < th.size(); ++t) th[t].join();
+        for (unsigned t = 0; t < n_thr; ++t) if (bad[t]) { fprintf(stderr, "rtk_build_index: cannot open an input file\n"); return 1; }
+        // ---- solid k-mers, sorted: unitig construction is independent of table layout ----
+        for (unsigned t = 0; t < n_thr; ++t) { solid.insert(solid.end(), part[t].begin(), part[t].end()); std::vector<KM>().swap(part[t]); }
+        std::sort(solid.begin(), solid.end());
     }
-    // ---- solid k-mers, sorted: unitig construction is independent of table layout ----
-    std::vector<KM> solid;
-    for (size_t i = 0; i < cnt.keys.size(); ++i) if (cnt.keys[i] != EMPTY && cnt.vals[i] >= min_count) solid.push_back(cnt.keys[i]);
-    std::sort(solid.begin(), solid.end());
-    { KTable<KM> tmp(16); cnt.keys.swap(tmp.keys); cnt.vals.swap(tmp.vals); } // free
     size_t cap = 16; while (cap * 6 < solid.size() * 10 + 16) cap <<= 1; cap <<= 1;
     KTable<KM> km(cap); // canonical solid k-mer -> 0 (unvisited) or (unitig+1)<<32 | offset<<1 | fw_flag
     for (size_t i = 0; i < solid.size(); ++i) *km.slot(solid[i], true) = 0;
@@ -156,36 +170,68 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     }
     fprintf(stderr, "rtk_build_index: %zu unitigs\n", U.size());
 
-    // ---- pass 2: colours (pair ids) and coverage ----
+    // ---- pass 2: colours (pair ids) and coverage. One reader parses the records and numbers them (a pair keeps one id), worker threads
+    // look their k-mers up (the table is only read) and collect (unitig, id) events and per-unitig counts of their own ----
     {
-        std::string name, seq, qual, prev_name;
-        uint32_t pair_id = 0; bool first = true;
         // second-pass index: the reads that colour the graph are the (pass-1 corrected) long reads, every read its own id
         // (addCoverage(dbg, opt_pass2, ..., long_read_correct = true), src/Ratatosk.cpp:1218)
         const bool by_read = !colour_files.empty();
         const std::vector<std::string>& col_in = by_read ? colour_files : in_files;
-        for (size_t f = 0; f < col_in.size(); ++f) {
-            FastxReader fr; if (!fr.open(col_in[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); return 1; }
-            while (fr.next(name, seq, qual)) {
-                for (size_t x = 0; x < seq.size(); ++x) seq[x] = static_cast<char>(seq[x] & 0xDF);
-                if (name.size() > 2 && name[name.size() - 2] == '/' && (name[name.size() - 1] == '1' || name[name.size() - 1] == '2')) name.erase(name.size() - 2);
-                if (first) { first = false; prev_name = name; }
-                else if (by_read || name != prev_name) { ++pair_id; prev_name = name; }
-                KM fw = 0; int valid = 0;
-                for (size_t i = 0; i < seq.size(); ++i) {
-                    const int b = base2bits(seq[i]);
-                    if (b < 0) { valid = 0; fw = 0; continue; }
-                    fw = ((fw << 2) | static_cast<KM>(b)) & mask;
-                    if (++valid >= k) {
-                        const uint64_t* v = km.slot(kmer_canonical(fw, k), false);
-                        if (v) {
-                            Unitig& u = U[(*v >> 32) - 1];
-                            ++u.cov;
-                            if (u.colours.empty() || u.colours.back() != pair_id) u.colours.push_back(pair_id);
+        struct Chunk { std::vector<std::string> seq; std::vector<uint32_t> id; size_t bytes = 0; };
+        std::mutex mq; std::condition_variable cv_put, cv_get; std::deque<Chunk*> q; bool done = false; int open_failed = 0;
+        const size_t n_u = U.size();
+        std::vector<std::vector<uint64_t> > t_cov(n_thr); std::vector<std::vector<std::pair<uint32_t, uint32_t> > > t_ev(n_thr);
+        auto work = [&](unsigned t) {
+            std::vector<uint64_t>& cov = t_cov[t]; cov.assign(n_u, 0);
+            std::vector<std::pair<uint32_t, uint32_t> >& ev = t_ev[t];
+            while (true) {
+                Chunk* c = nullptr;
+                { std::unique_lock<std::mutex> lk(mq); cv_get.wait(lk, [&]() { return !q.empty() || done; }); if (q.empty()) return; c = q.front(); q.pop_front(); }
+                cv_put.notify_one();
+                for (size_t r = 0; r < c->seq.size(); ++r) {
+                    const std::string& seq = c->seq[r]; const uint32_t pair_id = c->id[r];
+                    KM fw = 0; int valid = 0;
+                    for (size_t x = 0; x < seq.size(); ++x) {
+                        const int b = base2bits(seq[x]);
+                        if (b < 0) { valid = 0; fw = 0; continue; }
+                        fw = ((fw << 2) | static_cast<KM>(b)) & mask;
+                        if (++valid >= k) {
+                            const uint64_t* v = km.slot(kmer_canonical(fw, k), false);
+                            if (v) { const uint32_t u = static_cast<uint32_t>((*v >> 32) - 1); ++cov[u]; if (ev.empty() || ev.back().first != u || ev.back().second != pair_id) ev.push_back(std::make_pair(u, pair_id)); }
                         }
                     }
                 }
+                delete c;
             }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(work, t);
+        {
+            std::string name, seq, qual, prev_name;
+            uint32_t pair_id = 0; bool first = true;
+            Chunk* cur = new Chunk();
+            auto flush = [&]() { if (cur->seq.empty()) return; { std::unique_lock<std::mutex> lk(mq); cv_put.wait(lk, [&]() { return q.size() < 4u * n_thr; }); q.push_back(cur); } cv_get.notify_one(); cur = new Chunk(); };
+            for (size_t f = 0; f < col_in.size() && !open_failed; ++f) {
+                FastxReader fr; if (!fr.open(col_in[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); open_failed = 1; break; }
+                while (fr.next(name, seq, qual)) {
+                    for (size_t x = 0; x < seq.size(); ++x) seq[x] = static_cast<char>(seq[x] & 0xDF);
+                    if (name.size() > 2 && name[name.size() - 2] == '/' && (name[name.size() - 1] == '1' || name[name.size() - 1] == '2')) name.erase(name.size() - 2);
+                    if (first) { first = false; prev_name = name; }
+                    else if (by_read || name != prev_name) { ++pair_id; prev_name = name; }
+                    cur->bytes += seq.size(); cur->seq.push_back(std::string()); cur->seq.back().swap(seq); cur->id.push_back(pair_id);
+                    if (cur->bytes >= (1u << 20)) flush();
+                }
+            }
+            flush(); delete cur;
+            { std::lock_guard<std::mutex> lk(mq); done = true; }
+            cv_get.notify_all();
+        }
+        for (size_t t = 0; t < th.size(); ++t) th[t].join();
+        if (open_failed) return 1;
+        for (unsigned t = 0; t < n_thr; ++t) {
+            for (size_t u = 0; u < n_u; ++u) U[u].cov += t_cov[t][u];
+            for (size_t e = 0; e < t_ev[t].size(); ++e) U[t_ev[t][e].first].colours.push_back(t_ev[t][e].second);
+            std::vector<uint64_t>().swap(t_cov[t]); std::vector<std::pair<uint32_t, uint32_t> >().swap(t_ev[t]);
         }
         for (size_t i = 0; i < U.size(); ++i) { std::sort(U[i].colours.begin(), U[i].colours.end()); U[i].colours.erase(std::unique(U[i].colours.begin(), U[i].colours.end()), U[i].colours.end()); }
     }
