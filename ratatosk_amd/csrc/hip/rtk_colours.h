@@ -105,7 +105,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     // ---- C. universe: every id of every side unitig, straight into LDS, sorted, duplicates dropped ----
     uint32_t* const L = rtk_lds_set_buf();
     uint32_t* const uni = L; uint32_t* const raw = L + RTK_CS_MAX_IDS; uint64_t* const cbm = reinterpret_cast<uint64_t*>(L + 2u * RTK_CS_MAX_IDS);
-    uint64_t* const scatter = reinterpret_cast<uint64_t*>(L + RTK_CB_MAX_IDS); // cbm: 24 x 2 x 8 words = 3 KB, ends at u32 index 1792 <= 1920
+    // cbm: 24 x 2 x 8 words = 3 KB, ends at u32 index 1792
     uint32_t P = 64; while (P < T) P <<= 1;
     for (uint32_t t0 = 0; t0 < P; t0 += RTK_WAVE) {
         const uint32_t t = t0 + lane;
@@ -137,12 +137,21 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         U += static_cast<uint32_t>(rtk_popc(bal));
         RTK_WG_SYNC();
     }
-    // ---- D. bit vectors of every slot (local part, global part), 8 words each, in LDS ----
-    for (uint32_t slot = 0; slot < n_slots; ++slot) {
-        const uint32_t s_i = rtk_u(rtk_shfl(st, static_cast<int>(slot))), nl = rtk_u(rtk_shfl(m_nl, static_cast<int>(slot))), ng = rtk_u(rtk_shfl(m_ng, static_cast<int>(slot)));
-        const RtkBM bl = nl ? rtk_bm_from_ids(uni, U, scatter, raw + s_i, nl) : 0ull;
-        const RtkBM bg = ng ? rtk_bm_from_ids(uni, U, scatter, raw + s_i + nl, ng) : 0ull;
-        if (lane < 8) { cbm[(2u * slot) * 8u + lane] = bl; cbm[(2u * slot + 1u) * 8u + lane] = bg; }
+    // ---- D. bit vectors of every slot (local part, global part), 8 words each, in LDS: one flat pass over the gathered ids, every id
+    // ranked in the universe by a binary search in LDS and its bit set in the vector of the list it came from ----
+    for (uint32_t i = lane; i < n_slots * 16u; i += RTK_WAVE) cbm[i] = 0ull;
+    RTK_WG_SYNC();
+    for (uint32_t t0 = 0; t0 < T; t0 += RTK_WAVE) {
+        const uint32_t t = t0 + lane;
+        uint32_t i = 0;
+        for (uint32_t j = 1; j < n_slots; ++j) { const uint32_t sj = rtk_shfl(st, static_cast<int>(j)); if (sj <= t) i = j; }
+        const uint32_t s_i = rtk_shfl(st, static_cast<int>(i)), nl_i = rtk_shfl(m_nl, static_cast<int>(i));
+        if (t < T) {
+            const uint32_t id = raw[t];
+            uint32_t lo = 0, hi = U; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (uni[mid] < id) lo = mid + 1; else hi = mid; }
+            const uint32_t seg = 2u * i + ((t - s_i) >= nl_i ? 1u : 0u);
+            atomicOr(reinterpret_cast<unsigned long long*>(cbm) + seg * 8u + (lo >> 6), 1ull << (lo & 63u));
+        }
     }
     RTK_WG_SYNC();
     auto ld = [&](uint32_t idx) -> RtkBM { return lane < 8 ? cbm[idx * 8u + lane] : 0ull; };
