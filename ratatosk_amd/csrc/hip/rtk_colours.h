@@ -8,8 +8,60 @@
 #ifndef RTK_COLOURS_H
 #define RTK_COLOURS_H
 
-#define RTK_CB_MAX_IDS 1920u   // ids gathered from all anchors (with repeats); universe (u32) + 64 scatter words share the 8 KB LDS buffer
+#define RTK_CB_MAX_IDS 1664u   // ids gathered from all anchors (with repeats); universe (u32), 256 radix counters and 64 scatter words share the 8 KB LDS buffer
 #define RTK_CB_MAX_SLOTS 24u   // side-list entries whose bit vectors are kept
+
+#ifndef RTK_SIM
+// Least-significant-digit radix sort of n 32-bit keys by one wave, 8 bits per pass: the bitonic network it replaces costs 45-66 stages of
+// LDS compare-exchanges (1 400 LDS operations per lane for 512 keys), this costs two passes over the keys per digit. `a` holds the keys
+// (LDS) and the result; `b` is the other buffer (LDS or global memory, n entries); `bins` = 256 counters in LDS. A pass is stable: the 64
+// keys of a chunk find their equals by eight ballots (one per digit bit), rank themselves among them, and chunks are taken in order.
+RTK_DEV void rtk_radix_sort_u32(uint32_t* a, uint32_t* b, uint32_t n, uint32_t* bins, uint32_t max_key) {
+    const uint32_t lane = static_cast<uint32_t>(rtk_lane());
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int passes = 0; { uint32_t m = max_key; while (m) { ++passes; m >>= 8; } if (passes == 0) passes = 1; }
+    if (passes & 1) ++passes; // an even number of passes: the result ends in `a`
+    uint32_t* src = a; uint32_t* dst = b;
+    for (int ps = 0; ps < passes; ++ps) {
+        const int sh = 8 * ps;
+        for (uint32_t i = lane; i < 256u; i += RTK_WAVE) bins[i] = 0u;
+        RTK_WG_SYNC();
+        // histogram of the digit
+        for (uint32_t c0 = 0; c0 < n; c0 += RTK_WAVE) {
+            const uint32_t i = c0 + lane; const bool ok = i < n;
+            const uint32_t d = ok ? ((src[i] >> sh) & 0xFFu) : 0x100u;
+            uint64_t eq = rtk_ballot(ok);
+            for (int bt = 0; bt < 8; ++bt) { const uint64_t bb = rtk_ballot((d >> bt) & 1u); eq &= ((d >> bt) & 1u) ? bb : ~bb; }
+            if (ok && (eq & lt) == 0ull) atomicAdd(&bins[d], static_cast<uint32_t>(rtk_popc(eq))); // the first lane of every group of equal digits
+        }
+        RTK_WG_SYNC();
+        { // exclusive prefix over the 256 bins: four bins per lane
+            uint32_t v[4]; uint32_t sum = 0;
+            for (int x = 0; x < 4; ++x) { v[x] = bins[4u * lane + static_cast<uint32_t>(x)]; sum += v[x]; }
+            int tot; uint32_t base = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(sum), &tot));
+            RTK_WG_SYNC();
+            for (int x = 0; x < 4; ++x) { bins[4u * lane + static_cast<uint32_t>(x)] = base; base += v[x]; }
+        }
+        RTK_WG_SYNC();
+        // stable scatter, chunk by chunk
+        for (uint32_t c0 = 0; c0 < n; c0 += RTK_WAVE) {
+            const uint32_t i = c0 + lane; const bool ok = i < n;
+            const uint32_t key = ok ? src[i] : 0u;
+            const uint32_t d = ok ? ((key >> sh) & 0xFFu) : 0x100u;
+            uint64_t eq = rtk_ballot(ok);
+            for (int bt = 0; bt < 8; ++bt) { const uint64_t bb = rtk_ballot((d >> bt) & 1u); eq &= ((d >> bt) & 1u) ? bb : ~bb; }
+            const uint32_t before = static_cast<uint32_t>(rtk_popc(eq & lt));
+            uint32_t base = 0;
+            if (ok) base = bins[d];
+            RTK_WG_SYNC();
+            if (ok && before == 0u) bins[d] = base + static_cast<uint32_t>(rtk_popc(eq));
+            if (ok) dst[base + before] = key;
+            RTK_WG_SYNC();
+        }
+        uint32_t* t_ = src; src = dst; dst = t_;
+    }
+}
+#endif
 
 #ifdef RTK_SIM
 struct RtkBM { uint64_t w[64]; };
@@ -65,6 +117,26 @@ RTK_DEV RtkBM rtk_bm_from_ids(const uint32_t* uni, uint32_t U, uint64_t* scatter
 // ids go from the colour pool straight into LDS (one flat pass over all lists), and the per-slot bit vectors (8 words at this size)
 // stay in LDS. Returns RTK_NONE32 when the case is not small (caller goes on to rtk_choose_colors_bits).
 #define RTK_CS_MAX_IDS 512u
+// the 512-bit vectors of the small case live in lanes 0..7 (the other lanes hold zero): sums and prefix sums over eight lanes by DPP
+// moves inside one row (quad permutes, half-row mirror, row shifts) instead of six cross-lane permutes through LDS
+RTK_DEV int rtk_sum8(int v) { // every lane of 0..7 gets the sum over lanes 0..7 (callers read lane 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); // row_half_mirror: lane i <-> 7 - i
+    return v;
+}
+RTK_DEV uint32_t rtk_bm8_count(RtkBM a) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rtk_sum8(rtk_popc(a)))); }
+RTK_DEV RtkBM rtk_bm8_lowest(RtkBM a, uint32_t q) { // the q lowest set bits
+    const int mine = rtk_popc(a);
+    int inc = mine; // inclusive prefix sum over the row (zeros shifted in)
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true); // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true); // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true); // row_shr:4
+    int keep = static_cast<int>(q) - (inc - mine);
+    keep = keep < 0 ? 0 : (keep > mine ? mine : keep);
+    uint64_t rest = a; for (int i = 0; i < keep; ++i) rest &= rest - 1ull;
+    return a & ~rest;
+}
 RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
     const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
     RegionScratch& s = *c.sc;
@@ -75,6 +147,8 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     const uint32_t* const pw = rtk_u(side_w.u); const uint32_t* const pe = rtk_u(side_e.u); const uint32_t* const ps = rtk_u(side_s.u);
     const uint8_t* const qw = rtk_u(side_w.nb); const uint8_t* const qe = rtk_u(side_e.nb); const uint8_t* const qs = rtk_u(side_s.nb);
     const uint32_t* const col = g.col; const uint64_t* const loff = g.loff; const uint64_t* const goff = g.goff; const int32_t* const gid = g.gid; const uint32_t* const cardp = g.card;
+    unsigned long long tl_ = rtk_clock();
+#define RTK_CS_LAP(i) { const unsigned long long tn_ = rtk_clock(); s.fine[i] += tn_ - tl_; tl_ = tn_; }
     // ---- A. one lane per slot ----
     uint32_t m_u = 0, m_nl = 0, m_ng = 0, m_card = 0, m_nb = 0; uint64_t m_lo = 0, m_go = 0; int32_t m_gi = -1;
     if (lane < n_slots) {
@@ -87,6 +161,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     int total = 0; const uint32_t st = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(m_nl + m_ng), &total)); // first id of the slot in the flat order
     const uint32_t T = static_cast<uint32_t>(rtk_u(total));
     if (T > RTK_CS_MAX_IDS) return RTK_NONE32;
+    RTK_CS_LAP(1)
     // ---- B. candidate anchors: cardinality >= min_cov_vertices, first occurrence of their unitig, ordered by (cardinality, unitig) [D1] ----
     const uint32_t min_cov_v = c.o.min_cov_vertices;
     bool dup = false;
@@ -102,6 +177,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     const uint32_t cov = 30;
     const uint32_t k_slot = src; const uint32_t k_card = rtk_shfl(m_card, static_cast<int>(src));
     uint32_t k_quota = k_card < cov ? k_card : cov;
+    RTK_CS_LAP(2)
     // ---- C. universe: every id of every side unitig, straight into LDS, sorted, duplicates dropped ----
     uint32_t* const L = rtk_lds_set_buf();
     uint32_t* const uni = L; uint32_t* const raw = L + RTK_CS_MAX_IDS; uint64_t* const cbm = reinterpret_cast<uint64_t*>(L + 2u * RTK_CS_MAX_IDS);
@@ -119,12 +195,11 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     }
     RTK_WG_SYNC();
     s.cnt[1] += T;
-    for (uint32_t kk = 2; kk <= P; kk <<= 1) for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-        for (uint32_t i = lane; i < P; i += RTK_WAVE) {
-            const uint32_t l = i ^ j;
-            if (l > i) { const uint32_t a = uni[i], b = uni[l]; if ((a > b) == ((i & kk) == 0)) { uni[i] = b; uni[l] = a; } }
-        }
-        RTK_WG_SYNC();
+    RTK_CS_LAP(3)
+    { // sorted by id (radix, 8 bits per pass; the second buffer and the counters sit in the part of the LDS buffer the slot bit vectors take later)
+        uint32_t mx = 0; for (uint32_t i2 = lane; i2 < T; i2 += RTK_WAVE) mx = uni[i2] > mx ? uni[i2] : mx;
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t v2 = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mx), o, 64)); mx = v2 > mx ? v2 : mx; }
+        rtk_radix_sort_u32(uni, L + 2u * RTK_CS_MAX_IDS, T, L + 2u * RTK_CS_MAX_IDS + RTK_CS_MAX_IDS, rtk_u(mx));
     }
     uint32_t U = 0;
     for (uint32_t i0 = 0; i0 < T; i0 += RTK_WAVE) {
@@ -137,6 +212,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         U += static_cast<uint32_t>(rtk_popc(bal));
         RTK_WG_SYNC();
     }
+    RTK_CS_LAP(4)
     // ---- D. bit vectors of every slot (local part, global part), 8 words each, in LDS: one flat pass over the gathered ids, every id
     // ranked in the universe by a binary search in LDS and its bit set in the vector of the list it came from ----
     for (uint32_t i = lane; i < n_slots * 16u; i += RTK_WAVE) cbm[i] = 0ull;
@@ -154,6 +230,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         }
     }
     RTK_WG_SYNC();
+    RTK_CS_LAP(5)
     auto ld = [&](uint32_t idx) -> RtkBM { return lane < 8 ? cbm[idx * 8u + lane] : 0ull; };
     // ---- E. the six anchor classes: side (middle, right, left) x branching / non-branching; G2: the global set alone when there is one ----
     RtkBM a[6];
@@ -185,7 +262,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         else if (i == 1) { branching = rtk_bm_andn(branching, prev2); a2 = branching & i2; }
         else { branching = rtk_bm_andn(branching, prev2); a2 = branching; }
         prev2 = a2;
-        if (rtk_bm_count(a2) == 0) continue;
+        if (rtk_bm8_count(a2) == 0) continue;
         nb_unselected = 0;
         RtkBM curr = a2;
         for (uint32_t j = 0; j < nsp; ++j) {
@@ -193,15 +270,15 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
             if (quota > 0) {
                 const uint32_t slot = rtk_u(rtk_shfl(k_slot, static_cast<int>(j)));
                 const RtkBM cu = ld(2u * slot) | ld(2u * slot + 1u); // all colours of the anchor
-                if (i == 0 || rtk_bm_count(cu & curr) >= 1) {
+                if (i == 0 || rtk_bm8_count(cu & curr) >= 1) {
                     const uint32_t cd = rtk_u(rtk_shfl(k_card, static_cast<int>(j))); const uint32_t min_cov = cd < cov ? cd : cov;
-                    const uint32_t sh = rtk_bm_count(cu & all);
+                    const uint32_t sh = rtk_bm8_count(cu & all);
                     quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
                     if (quota > 0) {
-                        const uint32_t all_card = rtk_bm_count(all);
-                        const RtkBM pid = rtk_bm_lowest(cu & curr, static_cast<uint32_t>(quota));
+                        const uint32_t all_card = rtk_bm8_count(all);
+                        const RtkBM pid = rtk_bm8_lowest(cu & curr, static_cast<uint32_t>(quota));
                         all = all | pid; curr = rtk_bm_andn(curr, pid);
-                        const int gained = static_cast<int>(rtk_bm_count(all) - all_card);
+                        const int gained = static_cast<int>(rtk_bm8_count(all) - all_card);
                         quota -= gained < quota ? gained : quota;
                     }
                 }
@@ -210,6 +287,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
             nb_unselected += quota > 0 ? 1u : 0u;
         }
     }
+    RTK_CS_LAP(6)
     // ---- all_pids back to a sorted id list in set[0] ----
     const uint32_t n_all = rtk_bm_count(all);
     if (n_all > s.set_cap) { rtk_fail_ovf(s, 9); return 0; }
@@ -272,17 +350,13 @@ RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, 
       std::sort(uni, uni + T);
       for (uint32_t i = 0; i < T; ++i) if (i == 0 || uni[i] != uni[i - 1]) uni[U++] = uni[i]; }
 #else
-    uint32_t* const uni = rtk_lds_set_buf(); uint64_t* const scatter = reinterpret_cast<uint64_t*>(uni + RTK_CB_MAX_IDS);
-    { uint32_t P = 64; while (P < T) P <<= 1; // bitonic sort of the padded ids in LDS
-      for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < P; i += RTK_WAVE) uni[i] = i < T ? gathered[i] : 0xFFFFFFFFu;
+    uint32_t* const uni = rtk_lds_set_buf(); uint64_t* const scatter = reinterpret_cast<uint64_t*>(uni + 1920); // [0, 1664) ids, [1664, 1920) radix counters, [1920, 2048) scatter words
+    { // radix sort of the ids in LDS (second buffer: the gathered copy in scratch memory)
+      uint32_t mx = 0;
+      for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < T; i += RTK_WAVE) { const uint32_t x = gathered[i]; uni[i] = x; mx = x > mx ? x : mx; }
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t v2 = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mx), o, 64)); mx = v2 > mx ? v2 : mx; }
       RTK_WG_SYNC();
-      for (uint32_t kk = 2; kk <= P; kk <<= 1) for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-          for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < P; i += RTK_WAVE) {
-              const uint32_t l = i ^ j;
-              if (l > i) { const uint32_t a = uni[i], b = uni[l]; if ((a > b) == ((i & kk) == 0)) { uni[i] = b; uni[l] = a; } }
-          }
-          RTK_WG_SYNC();
-      }
+      rtk_radix_sort_u32(uni, gathered, T, uni + RTK_CB_MAX_IDS, rtk_u(mx));
       for (uint32_t i0 = 0; i0 < T; i0 += RTK_WAVE) { // forward compaction of the first elements of the runs
           const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
           uint32_t x = 0; bool keep = false;

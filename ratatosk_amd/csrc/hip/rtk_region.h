@@ -1044,10 +1044,10 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
     { // the common case: all the anchors' ids fit a 4096-bit universe -> the whole selection in registers (rtk_colours.h)
 #ifndef RTK_SIM
         { const uint32_t r0 = rtk_u(rtk_choose_colors_small(c, side_s, side_e, side_w));
-          if (r0 != RTK_NONE32) { s.fine[0] += rtk_clock() - tf; return rtk_failed(s) ? 0 : r0; } }
+          if (r0 != RTK_NONE32) { const unsigned long long d_ = rtk_clock() - tf; s.fine[0] += d_; s.fine[12] += d_; s.fine[14] += 1; return rtk_failed(s) ? 0 : r0; } }
 #endif
         const uint32_t r = rtk_u(rtk_choose_colors_bits(c, side_s, side_e, side_w));
-        if (r != RTK_NONE32) { s.fine[0] += rtk_clock() - tf; return rtk_failed(s) ? 0 : r; }
+        if (r != RTK_NONE32) { const unsigned long long d_ = rtk_clock() - tf; s.fine[0] += d_; s.fine[13] += d_; s.fine[15] += 1; return rtk_failed(s) ? 0 : r; }
     }
     // a_pid[shift], shift = side index (0 middle, 1 right, 2 left) + 3 * nonbranching: built one after the other into the arena (level 2 is free here)
     s.top[2] = 0;
