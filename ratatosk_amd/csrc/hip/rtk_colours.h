@@ -160,7 +160,9 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     }
     int total = 0; const uint32_t st = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(m_nl + m_ng), &total)); // first id of the slot in the flat order
     const uint32_t T = static_cast<uint32_t>(rtk_u(total));
-    if (T > RTK_CS_MAX_IDS) return RTK_NONE32;
+    // two sizes: <= 512 ids -> 8-word bit vectors, the unsorted ids and the vectors in LDS; <= 1664 ids -> 64-word vectors in scratch memory
+    const bool big = T > RTK_CS_MAX_IDS;
+    if (T > RTK_CB_MAX_IDS || (big && (s.set_cap < RTK_CB_MAX_IDS || s.set_cap < 2u * 2u * 64u * RTK_CB_MAX_SLOTS))) return RTK_NONE32;
     RTK_CS_LAP(1)
     // ---- B. candidate anchors: cardinality >= min_cov_vertices, first occurrence of their unitig, ordered by (cardinality, unitig) [D1] ----
     const uint32_t min_cov_v = c.o.min_cov_vertices;
@@ -180,8 +182,11 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     RTK_CS_LAP(2)
     // ---- C. universe: every id of every side unitig, straight into LDS, sorted, duplicates dropped ----
     uint32_t* const L = rtk_lds_set_buf();
-    uint32_t* const uni = L; uint32_t* const raw = L + RTK_CS_MAX_IDS; uint64_t* const cbm = reinterpret_cast<uint64_t*>(L + 2u * RTK_CS_MAX_IDS);
-    // cbm: 24 x 2 x 8 words = 3 KB, ends at u32 index 1792
+    uint32_t* const uni = L; uint32_t* const raw = L + RTK_CS_MAX_IDS;
+    // small: [0, 512) universe, [512, 1024) unsorted ids, [1024, 1792) 24 x 2 x 8 vector words (before that: second sort buffer + counters)
+    // big:   [0, 1664) universe, [1664, 1920) sort counters; second sort buffer = set[1], 64-word vectors = set[2] (scratch memory)
+    uint64_t* const cbm = big ? reinterpret_cast<uint64_t*>(s.set[2].get()) : reinterpret_cast<uint64_t*>(L + 2u * RTK_CS_MAX_IDS);
+    const uint32_t VW = big ? 64u : 8u; // words per bit vector
     uint32_t P = 64; while (P < T) P <<= 1;
     for (uint32_t t0 = 0; t0 < P; t0 += RTK_WAVE) {
         const uint32_t t = t0 + lane;
@@ -190,8 +195,8 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         const uint32_t s_i = rtk_shfl(st, static_cast<int>(i)), nl_i = rtk_shfl(m_nl, static_cast<int>(i));
         const uint64_t lo_i = rtk_shfl(m_lo, static_cast<int>(i)), go_i = rtk_shfl(m_go, static_cast<int>(i));
         uint32_t x = 0xFFFFFFFFu;
-        if (t < T) { const uint32_t off = t - s_i; x = col[off < nl_i ? lo_i + off : go_i + (off - nl_i)]; raw[t] = x; }
-        uni[t] = x;
+        if (t < T) { const uint32_t off = t - s_i; x = col[off < nl_i ? lo_i + off : go_i + (off - nl_i)]; if (!big) raw[t] = x; }
+        if (t < T || !big) uni[t] = x;
     }
     RTK_WG_SYNC();
     s.cnt[1] += T;
@@ -199,7 +204,8 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     { // sorted by id (radix, 8 bits per pass; the second buffer and the counters sit in the part of the LDS buffer the slot bit vectors take later)
         uint32_t mx = 0; for (uint32_t i2 = lane; i2 < T; i2 += RTK_WAVE) mx = uni[i2] > mx ? uni[i2] : mx;
         for (int o = 32; o > 0; o >>= 1) { const uint32_t v2 = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mx), o, 64)); mx = v2 > mx ? v2 : mx; }
-        rtk_radix_sort_u32(uni, L + 2u * RTK_CS_MAX_IDS, T, L + 2u * RTK_CS_MAX_IDS + RTK_CS_MAX_IDS, rtk_u(mx));
+        if (big) rtk_radix_sort_u32(uni, s.set[1], T, L + RTK_CB_MAX_IDS, rtk_u(mx));
+        else rtk_radix_sort_u32(uni, L + 2u * RTK_CS_MAX_IDS, T, L + 2u * RTK_CS_MAX_IDS + RTK_CS_MAX_IDS, rtk_u(mx));
     }
     uint32_t U = 0;
     for (uint32_t i0 = 0; i0 < T; i0 += RTK_WAVE) {
@@ -215,23 +221,28 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     RTK_CS_LAP(4)
     // ---- D. bit vectors of every slot (local part, global part), 8 words each, in LDS: one flat pass over the gathered ids, every id
     // ranked in the universe by a binary search in LDS and its bit set in the vector of the list it came from ----
-    for (uint32_t i = lane; i < n_slots * 16u; i += RTK_WAVE) cbm[i] = 0ull;
+    for (uint32_t i = lane; i < n_slots * 2u * VW; i += RTK_WAVE) cbm[i] = 0ull;
     RTK_WG_SYNC();
     for (uint32_t t0 = 0; t0 < T; t0 += RTK_WAVE) {
         const uint32_t t = t0 + lane;
         uint32_t i = 0;
         for (uint32_t j = 1; j < n_slots; ++j) { const uint32_t sj = rtk_shfl(st, static_cast<int>(j)); if (sj <= t) i = j; }
         const uint32_t s_i = rtk_shfl(st, static_cast<int>(i)), nl_i = rtk_shfl(m_nl, static_cast<int>(i));
+        const uint64_t lo_i2 = rtk_shfl(m_lo, static_cast<int>(i)), go_i2 = rtk_shfl(m_go, static_cast<int>(i));
         if (t < T) {
-            const uint32_t id = raw[t];
+            const uint32_t off2 = t - s_i;
+            const uint32_t id = big ? col[off2 < nl_i ? lo_i2 + off2 : go_i2 + (off2 - nl_i)] : raw[t];
             uint32_t lo = 0, hi = U; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (uni[mid] < id) lo = mid + 1; else hi = mid; }
             const uint32_t seg = 2u * i + ((t - s_i) >= nl_i ? 1u : 0u);
-            atomicOr(reinterpret_cast<unsigned long long*>(cbm) + seg * 8u + (lo >> 6), 1ull << (lo & 63u));
+            atomicOr(reinterpret_cast<unsigned long long*>(cbm) + seg * VW + (lo >> 6), 1ull << (lo & 63u));
         }
     }
     RTK_WG_SYNC();
     RTK_CS_LAP(5)
-    auto ld = [&](uint32_t idx) -> RtkBM { return lane < 8 ? cbm[idx * 8u + lane] : 0ull; };
+    // (big: the vectors were written by L2 atomics, so they are read past the L1, whose copy of these lines may be older)
+    auto ld = [&](uint32_t idx) -> RtkBM { if (lane >= VW) return 0ull; return big ? static_cast<RtkBM>(__hip_atomic_load(reinterpret_cast<const unsigned long long*>(cbm) + idx * VW + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : cbm[idx * VW + lane]; };
+    auto cnt_ = [&](RtkBM a) -> uint32_t { return big ? rtk_bm_count(a) : rtk_bm8_count(a); };
+    auto low_ = [&](RtkBM a, uint32_t q) -> RtkBM { return big ? rtk_bm_lowest(a, q) : rtk_bm8_lowest(a, q); };
     // ---- E. the six anchor classes: side (middle, right, left) x branching / non-branching; G2: the global set alone when there is one ----
     RtkBM a[6];
     for (int sh = 0; sh < 6; ++sh) {
@@ -262,7 +273,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
         else if (i == 1) { branching = rtk_bm_andn(branching, prev2); a2 = branching & i2; }
         else { branching = rtk_bm_andn(branching, prev2); a2 = branching; }
         prev2 = a2;
-        if (rtk_bm8_count(a2) == 0) continue;
+        if (cnt_(a2) == 0) continue;
         nb_unselected = 0;
         RtkBM curr = a2;
         for (uint32_t j = 0; j < nsp; ++j) {
@@ -270,15 +281,15 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
             if (quota > 0) {
                 const uint32_t slot = rtk_u(rtk_shfl(k_slot, static_cast<int>(j)));
                 const RtkBM cu = ld(2u * slot) | ld(2u * slot + 1u); // all colours of the anchor
-                if (i == 0 || rtk_bm8_count(cu & curr) >= 1) {
+                if (i == 0 || cnt_(cu & curr) >= 1) {
                     const uint32_t cd = rtk_u(rtk_shfl(k_card, static_cast<int>(j))); const uint32_t min_cov = cd < cov ? cd : cov;
-                    const uint32_t sh = rtk_bm8_count(cu & all);
+                    const uint32_t sh = cnt_(cu & all);
                     quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
                     if (quota > 0) {
-                        const uint32_t all_card = rtk_bm8_count(all);
-                        const RtkBM pid = rtk_bm8_lowest(cu & curr, static_cast<uint32_t>(quota));
+                        const uint32_t all_card = cnt_(all);
+                        const RtkBM pid = low_(cu & curr, static_cast<uint32_t>(quota));
                         all = all | pid; curr = rtk_bm_andn(curr, pid);
-                        const int gained = static_cast<int>(rtk_bm8_count(all) - all_card);
+                        const int gained = static_cast<int>(cnt_(all) - all_card);
                         quota -= gained < quota ? gained : quota;
                     }
                 }
