@@ -118,6 +118,33 @@ RTK_DEV UMap rtk_find_unitig(const RCtx& c, const char* str, uint32_t pos, uint3
     return um;
 }
 
+// The same from a k-mer hit that is already known (the windows of a string are looked up in one lane-parallel batch by the caller);
+// the characters behind the k-mer are compared 64 at a time instead of one dependent load per character.
+RTK_DEV UMap rtk_extend_hit(const RCtx& c, uint64_t hit, const char* str, uint32_t pos, uint32_t len) {
+    const GraphView& g = c.g; const uint32_t k = static_cast<uint32_t>(c.k);
+    UMap um = rtk_unpack_hit(hit);
+    const uint32_t ul = rtk_ulen(g, um.unitig);
+    const uint32_t j0 = pos + k;
+    // characters available on both sides
+    const uint32_t room_s = len > j0 ? len - j0 : 0u;
+    const uint32_t room_u = um.strand ? (ul > um.dist + k ? ul - (um.dist + k) : 0u) : um.dist;
+    const uint32_t room = room_s < room_u ? room_s : room_u;
+    uint32_t n = 0; bool stop = false;
+    for (uint32_t b0 = 0; b0 < room && !stop; b0 += RTK_WAVE) {
+        const uint32_t i = b0 + static_cast<uint32_t>(rtk_lane());
+        bool bad = false;
+        if (i < room) {
+            const char uc = um.strand ? rtk_unitig_char(g, um.unitig, um.dist + k + i) : rtk_iupac_comp(rtk_unitig_char(g, um.unitig, um.dist - 1 - i));
+            bad = str[j0 + i] != uc;
+        }
+        const uint64_t bb = rtk_ballot(bad);
+        if (bb) { n += static_cast<uint32_t>(rtk_ffs(bb) - 1); stop = true; } else n += (room - b0) < RTK_WAVE ? (room - b0) : RTK_WAVE;
+    }
+    if (!um.strand) um.dist -= n;
+    um.len = n + 1;
+    return um;
+}
+
 // fixAmbiguity (src/Alignment.cpp:527-844). query/quality = s_corrected/q_corrected of the region (same length), ref = the raw region.
 RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_, char* quality_, uint32_t quality_len_, const char* ref_, uint32_t ref_len_, uint32_t n_amb_) {
     const RCtx& c = *rtk_u(&c_); char* query = rtk_u(query_); char* quality = rtk_u(quality_); const char* ref = rtk_u(ref_);
@@ -138,13 +165,14 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
         const uint32_t p = rtk_amb_pos(v[i]);
         if (quality[p] < q_min_conf_corr && rtk_amb_find(ms, nms, p) < 0) ms[nms++] = v[i]; // n_amb <= cap
     }
+    s.fine[10] += 1;
     if (nms == 0) {
         // every annotated base is confident: nothing enters the sets unless the alignment meets a non-ACGT character of the
         // corrected or the raw region (:630-678), and with both clean the whole call leaves query and quality as they are
         bool odd = false;
         for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < query_len; i += RTK_WAVE) odd |= !rtk_is_dna(query[i]);
         for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < ref_len; i += RTK_WAVE) odd |= !rtk_is_dna(ref[i]);
-        if (rtk_ballot(odd) == 0) return;
+        if (rtk_ballot(odd) == 0) { s.fine[11] += 1; return; }
     }
     char* qt = s.str[0]; // query_tmp
     rtk_wcopy(qt, query, query_len);
@@ -157,8 +185,11 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
     nma = nms;
     rtk_sync();
     uint32_t nm = 0;
+    unsigned long long tfa_ = rtk_clock();
+#define RTK_FA_LAP(i) { const unsigned long long tn_ = rtk_clock(); s.fine[i] += tn_ - tfa_; tfa_ = tn_; }
     RTK_SITE(17); rtk_align_path(c, qt, query_len, ref, ref_len, RTK_MODE_SHW, &nm); nm = rtk_u(nm);
     if (rtk_failed(s)) return;
+    RTK_FA_LAP(1)
     { // walk of the alignment (:612-706); only moves touching a non-ACGT character on either side do anything
         const uint8_t* mv = rtk_ld(&s.my.moves);
         uint32_t qp = 0, rp = 0;
@@ -195,6 +226,7 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
             qp += static_cast<uint32_t>(rtk_popc(bq)); rp += static_cast<uint32_t>(rtk_popc(br));
         }
     }
+    RTK_FA_LAP(2)
     // alleles of the other annotated positions of the unitig a decided SNP lies on (:713-768)
     for (uint32_t e = 0; e < nms; ++e) {
         const char pc = rtk_amb_chr(ms[e]);
@@ -207,17 +239,40 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
         rtk_wcopy(q_sub, query + pos_buff, len_buff);
         rtk_sync();
         q_sub[pos_snp_buff] = pc;
-        RtkKm fw = rtk_km_zero(); uint32_t run = 0, skip_until = 0; bool skip_one = false;
-        for (uint32_t i = 0; i < len_buff; ++i) {
-            const char ch = q_sub[i];
-            if (!rtk_is_dna(ch)) { run = 0; fw = rtk_km_zero(); continue; }
-            fw = rtk_km_push(fw, static_cast<uint64_t>(rtk_cls(static_cast<unsigned char>(ch & 0xDF))), static_cast<int>(k)); ++run;
-            if (run < k) continue;
-            const uint32_t w = i + 1 - k; // [A6] KmerIterator: the all-ACGT windows, in order
+        rtk_sync();
+        // every window of the 2k - 1 characters looked up at once, one lane per window (the walk below only follows a few of them, but
+        // a lookup is a chain of dependent memory round trips and the chains of one batch overlap)
+        const uint32_t nwin = len_buff >= k ? len_buff - k + 1 : 0u; // <= k <= 63
+        auto window = [&](uint32_t w, bool* valid) -> uint64_t { // is window w all A/C/G/T, and where is its k-mer in the graph
+            const char* wp = q_sub + w;
+            bool ok = true; for (uint32_t x = 0; x < k; ++x) ok = ok && rtk_is_dna(wp[x]);
+            *valid = ok;
+            if (!ok) return RTK_NO_HIT;
+            RtkKm km = rtk_km_zero(); for (uint32_t x = 0; x < k; ++x) km = rtk_km_push(km, static_cast<uint64_t>(rtk_cls(static_cast<unsigned char>(wp[x] & 0xDF))), static_cast<int>(k));
+            return rtk_find_km(g, km, nullptr);
+        };
+#ifndef RTK_SIM
+        uint64_t my_hit = RTK_NO_HIT; bool my_valid = false;
+        if (static_cast<uint32_t>(rtk_lane()) < nwin) my_hit = window(static_cast<uint32_t>(rtk_lane()), &my_valid);
+        const uint64_t vmask = rtk_ballot(my_valid);
+#endif
+        uint32_t skip_until = 0; bool skip_one = false;
+        for (uint32_t w = 0; w < nwin; ++w) { // [A6] KmerIterator: the all-ACGT windows, in order
+#ifdef RTK_SIM
+            bool valid_w = false; const uint64_t hit_w = window(w, &valid_w); // the 1-lane simulator looks the windows up as it meets them
+            if (!valid_w) continue;
+#else
+            if (!((vmask >> w) & 1ull)) continue;
+#endif
             if (w < skip_until) continue;
             if (skip_one) { skip_one = false; continue; }
-            const UMap um = rtk_find_unitig(c, q_sub, w, len_buff, fw);
-            if (rtk_um_is_empty(um)) continue;
+#ifdef RTK_SIM
+            const uint64_t hit = hit_w;
+#else
+            const uint64_t hit = rtk_u(rtk_shfl(my_hit, static_cast<int>(w)));
+#endif
+            if (hit == RTK_NO_HIT) continue;
+            const UMap um = rtk_extend_hit(c, hit, q_sub, w, len_buff);
             const uint32_t usz = rtk_ulen(g, um.unitig);
             UMap full = um; full.dist = 0; full.len = usz - k + 1;
             const uint32_t nvu = rtk_amb_of_um(c, full, vu, cap);
@@ -240,6 +295,7 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
         }
         rtk_sync();
     }
+    RTK_FA_LAP(3)
     for (uint32_t i = 0; i < nsa; ++i) { // a linked position with exactly one candidate allele takes it, when compatible (:771-790)
         const uint32_t pos = rtk_amb_pos(sa[i]);
         uint32_t same = 0;
@@ -260,6 +316,7 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
     rtk_sync();
     rtk_wcopy(query, qt, query_len);
     rtk_sync();
+    RTK_FA_LAP(4)
 }
 
 #endif

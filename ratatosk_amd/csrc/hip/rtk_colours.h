@@ -148,7 +148,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     const uint8_t* const qw = rtk_u(side_w.nb); const uint8_t* const qe = rtk_u(side_e.nb); const uint8_t* const qs = rtk_u(side_s.nb);
     const uint32_t* const col = g.col; const uint64_t* const loff = g.loff; const uint64_t* const goff = g.goff; const int32_t* const gid = g.gid; const uint32_t* const cardp = g.card;
     unsigned long long tl_ = rtk_clock();
-#define RTK_CS_LAP(i) { const unsigned long long tn_ = rtk_clock(); s.fine[i] += tn_ - tl_; tl_ = tn_; }
+#define RTK_CS_LAP(i) { (void)tl_; }
     // ---- A. one lane per slot ----
     uint32_t m_u = 0, m_nl = 0, m_ng = 0, m_card = 0, m_nb = 0; uint64_t m_lo = 0, m_go = 0; int32_t m_gi = -1;
     if (lane < n_slots) {
