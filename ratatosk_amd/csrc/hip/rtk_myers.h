@@ -429,24 +429,14 @@ __device__ __forceinline__ SweepStat rtk_myers_fast_any(const char* __restrict__
 #endif
 
 
-#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
-// ------------------------------------------------------------------------------------------------ one pass on several waves
-// The row blocks (64 words = 4096 query rows each) of ONE pass run on the waves of the workgroup at the same time: block b consumes
-// the horizontal deltas block b-1 leaves at its bottom row (`carry`, one byte per column, in memory) one 64-column chunk behind it, so
-// a pass over B blocks takes about n + 128 B steps instead of B n. The waves of a workgroup sit on one CU and share its L1, so
-// workgroup-scope fences (no cache maintenance) order the carries in memory against the progress counters in LDS. The program wave (wave 0) publishes the pass in an LDS mailbox, the
-// helper waves of the workgroup pick it up, everybody takes the blocks b = wave, wave + NW, ... in ascending order (a block only ever
-// waits for a lower-numbered one, and those are started first: no cycle), wave 0 continues when all helpers have reported.
-#define RTK_COOP_MAXB 512
+#ifndef RTK_SIM
 struct RtkCoopJob { const char* qp; const char* tp; int m, n, qrev, trev, top_h, iupac; uint64_t* fin_pv; uint64_t* fin_mv; int8_t* carry; int32_t* colscore; };
-struct RtkCoop { RtkCoopJob job[2]; int n_jobs, seq, n_done, exit_flag, n_waves; int progress[RTK_COOP_MAXB]; }; // two passes at a time: the two halves of a Hirschberg split are independent
-__device__ __forceinline__ RtkCoop* rtk_coop() { __shared__ RtkCoop st; return &st; }
 __device__ __forceinline__ int rtk_coop_ld(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void rtk_coop_st(int* p, int v) { if (rtk_lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// one row block of the published pass (same arithmetic as the general loop of rtk_myers_pass)
-__device__ __noinline__ void rtk_myers_coop_block(RtkCoop* st, int ji, int b, int* progress) { // progress: the counters of this pass (one per row block)
-    const RtkCoopJob& J = st->job[ji];
+// One row block (64 words = 4096 query rows) of a pass over several blocks: same arithmetic as the general loop of rtk_myers_pass, without
+// branches in the step when the target holds A/C/G/T only. progress == nullptr: the blocks are swept one after the other by this wave;
+// otherwise the counters of the pass (completed columns per block), through which the waves of a workgroup follow each other.
+__device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* progress) {
     const char* __restrict__ const qp = rtk_u(J.qp); const char* __restrict__ const tp = rtk_u(J.tp);
     const int m = rtk_u(J.m), n = rtk_u(J.n), qrev = rtk_u(J.qrev), trev = rtk_u(J.trev), top_h = rtk_u(J.top_h); const bool iupac = rtk_u(J.iupac) != 0;
     int8_t* __restrict__ const carry = rtk_u(J.carry); int32_t* __restrict__ const colscore = rtk_u(J.colscore);
@@ -484,7 +474,7 @@ __device__ __noinline__ void rtk_myers_coop_block(RtkCoop* st, int ji, int b, in
     }
     for (int c0 = 0; c0 < steps; c0 += 64) {
         const int cj = c0 + lane;
-        if (b > 0) { // the deltas of columns [c0, c0 + 64) must have left the block above
+        if (b > 0 && progress) { // the deltas of columns [c0, c0 + 64) must have left the block above
             const int need = (c0 + 64) < n ? (c0 + 64) : n;
             if (c0 < n) { while (rtk_coop_ld(&progress[b - 1]) < need) __builtin_amdgcn_s_sleep(8); }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -571,23 +561,37 @@ __device__ __noinline__ void rtk_myers_coop_block(RtkCoop* st, int ji, int b, in
                 }
             }
         }
-        if (!last_block) { // columns whose delta has left this block: the tail lane is nw - 1 columns behind lane 0
+        if (!last_block && progress) { // columns whose delta has left this block: the tail lane is nw - 1 columns behind lane 0
             int done = c0 + lim - (nw - 1); done = done < 0 ? 0 : (done > n ? n : done);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             rtk_coop_st(&progress[b], done);
         }
     }
     if (fin_pv && has_word) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (!last_block) rtk_coop_st(&progress[b], n);
+    if (progress) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (!last_block) rtk_coop_st(&progress[b], n); }
+    else rtk_sync();
 }
+
+#endif
+
+#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
+// ------------------------------------------------------------------------------------------------ one pass on several waves
+// The row blocks (64 words = 4096 query rows each) of ONE pass run on the waves of the workgroup at the same time: block b consumes
+// the horizontal deltas block b-1 leaves at its bottom row (`carry`, one byte per column, in memory) one 64-column chunk behind it, so
+// a pass over B blocks takes about n + 128 B steps instead of B n. The waves of a workgroup sit on one CU and share its L1, so
+// workgroup-scope fences (no cache maintenance) order the carries in memory against the progress counters in LDS. The program wave (wave 0) publishes the pass in an LDS mailbox, the
+// helper waves of the workgroup pick it up, everybody takes the blocks b = wave, wave + NW, ... in ascending order (a block only ever
+// waits for a lower-numbered one, and those are started first: no cycle), wave 0 continues when all helpers have reported.
+#define RTK_COOP_MAXB 512
+struct RtkCoop { RtkCoopJob job[2]; int n_jobs, seq, n_done, exit_flag, n_waves; int progress[RTK_COOP_MAXB]; }; // two passes at a time: the two halves of a Hirschberg split are independent
+__device__ __forceinline__ RtkCoop* rtk_coop() { __shared__ RtkCoop st; return &st; }
 
 __device__ __forceinline__ void rtk_myers_coop_run(RtkCoop* st, int wave) {
     // the passes of a job have the same query length, hence the same number B of row blocks; block index i < B: pass 0, else pass 1.
     // Every wave takes its indices in ascending order and a block only waits for index i - 1 of its own pass: the lowest unfinished
     // index can always run, so nobody waits for ever.
     const int W = (rtk_u(st->job[0].m) + 63) >> 6, B = (W + 63) >> 6, nj = rtk_coop_ld(&st->n_jobs), nwv = rtk_coop_ld(&st->n_waves);
-    for (int i = wave; i < nj * B; i += nwv) { const int ji = i >= B ? 1 : 0; rtk_myers_coop_block(st, ji, i - ji * B, st->progress + ji * B); }
+    for (int i = wave; i < nj * B; i += nwv) { const int ji = i >= B ? 1 : 0; rtk_myers_block(st->job[ji], i - ji * B, st->progress + ji * B); }
 }
 
 // helper waves of the workgroup: wait for passes until the program wave says it is done
@@ -666,6 +670,13 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq
 #ifdef RTK_MULTIWAVE
     if (!store && rtk_myers_pass_coop(sc, q, t, top_h, iupac, fin_pv, fin_mv)) { rtk_sync(); return; } // several row blocks: shared with the helper waves of the workgroup
 #endif
+    if (!store && W > 64) { // several row blocks on this wave: the block sweep without branches in the step
+        RtkCoopJob j; j.qp = q.p; j.tp = t.p; j.m = m; j.n = n; j.qrev = q.rev; j.trev = t.rev; j.top_h = top_h; j.iupac = iupac ? 1 : 0;
+        j.fin_pv = fin_pv; j.fin_mv = fin_mv; j.carry = rtk_u(sc.carry); j.colscore = rtk_u(sc.colscore);
+        for (int b = 0; b < ((W + 63) >> 6); ++b) rtk_myers_block(j, b, nullptr);
+        rtk_sync();
+        return;
+    }
     // local copies: the scratch descriptor lives in private memory and its fields could alias the stores below,
     // which would force a (slow) reload of every pointer on every step
     int8_t* __restrict__ const carry = rtk_u(sc.carry); int32_t* __restrict__ const colscore = rtk_u(sc.colscore); uint64_t* __restrict__ const tb = rtk_u(sc.tb);
