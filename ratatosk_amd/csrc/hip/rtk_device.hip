@@ -71,11 +71,7 @@ struct rtk_graph {
     // work areas of the phasing step (second pass): one per ticket in flight, so that the hour-glass launches of several tickets (each as
     // long as its longest read) overlap instead of queueing behind one lock; kept until the graph goes (tens of GB each: never hipFree'd mid-run)
     std::vector<std::pair<void*, uint64_t> > phase_free;
-    void* phase_take(uint64_t bytes, uint64_t* got) {
-        { std::lock_guard<std::mutex> h(pool_lock);
-          for (size_t i = 0; i < phase_free.size(); ++i) if (phase_free[i].second >= bytes) { void* p = phase_free[i].first; *got = phase_free[i].second; phase_free.erase(phase_free.begin() + i); return p; } }
-        *got = bytes; return rtk_dmalloc(bytes);
-    }
+    void* phase_take(uint64_t bytes, uint64_t* got); // (defined below the reserved-slab list)
     void phase_give(void* p, uint64_t bytes) { std::lock_guard<std::mutex> h(pool_lock); phase_free.push_back(std::make_pair(p, bytes)); }
     void pool_clear() { std::lock_guard<std::mutex> h(pool_lock); for (std::multimap<uint64_t, void*>::iterator it = pool.begin(); it != pool.end(); ++it) rtk_dfree(it->second); pool.clear(); pool_bytes = 0;
                         for (size_t i = 0; i < phase_free.size(); ++i) rtk_dfree(phase_free[i].first); phase_free.clear();
@@ -256,6 +252,16 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
 struct ReservedSlab { int device; void* p; uint64_t bytes; };
 static std::mutex g_reserved_lock;
 static std::vector<ReservedSlab> g_reserved;
+
+void* rtk_graph::phase_take(uint64_t bytes, uint64_t* got) {
+    { std::lock_guard<std::mutex> h(pool_lock);
+      for (size_t i = 0; i < phase_free.size(); ++i) if (phase_free[i].second >= bytes) { void* p = phase_free[i].first; *got = phase_free[i].second; phase_free.erase(phase_free.begin() + i); return p; } }
+    { std::lock_guard<std::mutex> lk(g_reserved_lock); // reserved ahead (rtk_reserve_second_pass): the smallest one that fits, but not one several times too big (those are the first pass's)
+      int best = -1;
+      for (size_t i = 0; i < g_reserved.size(); ++i) if (g_reserved[i].device == device && g_reserved[i].bytes >= bytes && g_reserved[i].bytes <= 4 * bytes + (1ull << 30) && (best < 0 || g_reserved[i].bytes < g_reserved[static_cast<size_t>(best)].bytes)) best = static_cast<int>(i);
+      if (best >= 0) { void* p = g_reserved[static_cast<size_t>(best)].p; *got = g_reserved[static_cast<size_t>(best)].bytes; g_reserved.erase(g_reserved.begin() + best); return p; } }
+    *got = bytes; return rtk_dmalloc(bytes);
+}
 
 static char* graph_scratch(rtk_graph* g, int slot, uint64_t bytes) { // grows monotonically; hipMalloc/hipFree of tens of GB per batch would dominate a step
     if (bytes > g->scratch_bytes_[slot]) {

@@ -175,7 +175,10 @@ int main(int argc, char** argv) {
     std::vector<rtk_graph*> graphs(n_gpus, nullptr);
     // the per-wave scratch slabs (tens of GB per GPU, seconds of hipMalloc) are reserved while the index files are parsed
     std::vector<std::thread> reservers;
-    for (int w = 0; w < n_gpus; ++w) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
+    for (int w = 0; w < n_gpus; ++w) {
+        if (!lrc) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
+        else for (int t = 0; t < opt.workers_per_gpu; ++t) reservers.emplace_back([w]() { rtk_reserve_second_pass(w, 1u, 16ull << 30, 18ull << 30); }); // a 32 Mi ticket of long reads: ~9-12 GB for the phasing step, 17 GB for its regions
+    }
     { // ONE parse + flatten, ONE host image; the other GPUs get device-to-device copies of the flat buffers
         bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), k_graph, opt.cores, &graphs[0]) == RTK_OK;
         if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[0]); if (ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs\n", ns); }
