@@ -49,7 +49,7 @@ typedef struct rtk_opts {
      * reads, the reads' qualities are carried over, regions pass 1 already gave the maximum quality are left alone, no 1-edit search.
      * Needs batches created WITH quality strings. */
     int32_t long_read_correct;      /* 0 = pass 1 */
-    int32_t reserved;
+    int32_t force_unres_snp_corr;   /* -f (src/Ratatosk.cpp:279): second pass only, fixSNPs() (src/Alignment.cpp:846-965) on every read before phasing() (src/Ratatosk.cpp:828) */
     uint64_t max_len_weak_region2;  /* -W, 5000 (src/Common.hpp:110) */
 } rtk_opts;
 
@@ -153,6 +153,10 @@ void rtk_batch_free(rtk_batch* b);
 /* dbg.searchSequence(s, true, false, false, false, false) (reference: src/Graph.cpp:97): for every k-mer window p of
  * seq, hits[p] = unitig<<33 | dist<<1 | strand, or -1 when the window is not in the graph / holds a non-ACGT. */
 int rtk_lookup_exact(rtk_graph* g, const char* seq, uint32_t len, int64_t* hits);
+
+/* fixSNPs (reference: src/Alignment.cpp:846-965; `-f`, src/Ratatosk.cpp:828) of one read, upper-cased first (src/Ratatosk.cpp:814):
+ * out[0..len) = the read with every ambiguous character that has exactly one graph-supported base replaced by it. */
+int rtk_fix_snps(rtk_graph* g, const char* seq, uint32_t len, char* out);
 
 /* getSeeds (reference: src/Graph.cpp:3-482): anchors as (pos, unitig, dist, strand) quadruples. */
 int rtk_seeds(rtk_graph* g, const rtk_opts* opts, const char* seq, uint32_t len,

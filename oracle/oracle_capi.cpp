@@ -23,13 +23,13 @@ struct orc_opts { // mirrors the pass-1 fields of Correct_Opt (reference: src/Co
     int32_t max_qual, out_qual;
     double min_confidence_snp_corr;
     uint64_t max_len_weak_region2; // pass 2 (-W, 5000)
-    int32_t skip_phasing, reserved; // test switch, see Opt::skip_phasing
+    int32_t skip_phasing, force_unres_snp_corr; // test switch, see Opt::skip_phasing; -f
 };
 
 static Opt toOpt(const orc_opts* o) {
     Opt r;
     if (o) { r.insert_sz = o->insert_sz; r.min_cov_vertices = o->min_cov_vertices; r.max_len_weak_region1 = o->max_len_weak_region1; r.max_km_cov = o->max_km_cov;
-             r.weak_region_len_factor = o->weak_region_len_factor; r.large_k_factor = o->large_k_factor; r.min_score = o->min_score; r.max_qual = o->max_qual; r.out_qual = o->out_qual; r.min_confidence_snp_corr = o->min_confidence_snp_corr; if (o->max_len_weak_region2) r.max_len_weak_region2 = o->max_len_weak_region2; r.skip_phasing = o->skip_phasing != 0; }
+             r.weak_region_len_factor = o->weak_region_len_factor; r.large_k_factor = o->large_k_factor; r.min_score = o->min_score; r.max_qual = o->max_qual; r.out_qual = o->out_qual; r.min_confidence_snp_corr = o->min_confidence_snp_corr; if (o->max_len_weak_region2) r.max_len_weak_region2 = o->max_len_weak_region2; r.skip_phasing = o->skip_phasing != 0; r.force_unres_snp_corr = o->force_unres_snp_corr != 0; }
     return r;
 }
 
@@ -173,6 +173,9 @@ int orc_correct_batch2(void* gp, const orc_opts* o, uint64_t n, const char* cons
     else { std::vector<std::thread> th; for (int t = 0; t < n_threads; ++t) th.emplace_back(work); for (size_t t = 0; t < th.size(); ++t) th[t].join(); }
     return 0;
 }
+
+// fixSNPs() of one read; out has room for len characters (the length does not change)
+void orc_fix_snps(void* gp, const char* seq, uint64_t len, char* out) { const std::string r = fixSNPs(*static_cast<Graph*>(gp), std::string(seq, len)); memcpy(out, r.data(), r.size()); }
 
 uint64_t orc_wyhash8(uint64_t key, uint64_t seed) { return wyhash8(key, seed); }
 

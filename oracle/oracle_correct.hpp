@@ -44,8 +44,9 @@ struct Opt { // the Correct_Opt fields the pass-1 hot path reads (src/Common.hpp
     bool long_read_correct;
     size_t max_len_weak_region2; // -W, 5000 (src/Common.hpp:110)
     bool skip_phasing;           // test switch (not in the reference): pass 2 without the phasing() pre-filter, to check the rest on its own
+    bool force_unres_snp_corr;   // -f (src/Ratatosk.cpp:279): fixSNPs() on the corrected read before phasing()
     Opt() : insert_sz(500), min_cov_vertices(2), max_len_weak_region1(1000), weak_region_len_factor(0.25), large_k_factor(1.5),
-            min_score(0.0), max_qual(40), out_qual(1), min_confidence_snp_corr(0.9), max_km_cov(128), long_read_correct(false), max_len_weak_region2(5000), skip_phasing(false) {}
+            min_score(0.0), max_qual(40), out_qual(1), min_confidence_snp_corr(0.9), max_km_cov(128), long_read_correct(false), max_len_weak_region2(5000), skip_phasing(false), force_unres_snp_corr(false) {}
 };
 
 struct Counters { // event counts feeding the algorithmic-bytes model of SURVEY.md §8(d)
@@ -82,6 +83,8 @@ std::pair<std::string, std::string> correctRead(const Graph& g, const Opt& opt, 
 // phasing() (src/Graph.cpp:869-1097): reverts the pass-1 corrections that sit on unitigs whose colours (pass-1 read ids) are not
 // shared with any unitig further than insert_sz away on the same read; TinyBloomFilter (src/TinyBloomFilter.hpp) + wyhash [A9].
 std::pair<std::string, std::string> phasing(const Graph& g, const Opt& opt, const std::string& s_raw, const std::string& s_corr, const std::string& q_corr);
+// fixSNPs() (src/Alignment.cpp:846-965), `-f`: ambiguous characters of a read with exactly one base that has graph support
+std::string fixSNPs(const Graph& g, const std::string& s);
 // per-read body for long_read_correct == true (src/Ratatosk.cpp:808-838): upper-case, phasing, getSeeds (exact hits only), correctSequence
 std::pair<std::string, std::string> correctRead2(const Graph& g, const Opt& opt, std::string seq_corr, std::string qual_corr, const std::string& seq_raw, Counters* cnt = nullptr);
 // writeCorrectedOutput with trimming (src/Ratatosk.cpp:510-563): the records one corrected read becomes (name suffixes as the reference writes them)

@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <set>
 
 #include "oracle_correct.hpp"
 #include "oracle_myers.hpp"
@@ -165,9 +167,65 @@ std::pair<std::string, std::string> phasing(const Graph& g, const Opt& opt, cons
     return std::make_pair(s_out, q_out);
 }
 
+// fixSNPs (src/Alignment.cpp:846-965; `-f`, applied to the corrected read before phasing(), src/Ratatosk.cpp:672,828): every character
+// of the read that is not A/C/G/T is replaced by a base when exactly ONE of its bases gives the 2k-1 window around it a k-mer of the
+// graph. Restated as written, including
+//   * the candidate enumeration j < 4 * |v_amb| with digit p of j = (j >> 2p) & 3 (so only the first ambiguity of a window sees all
+//     four bases; the p-th one sees the values of j >> 2p below 4 * |v_amb| >> 2p), stopped once two bases are candidates (:922);
+//   * `upper_bound(min_pos_amb + len_buff_amb)` (:893): an ambiguous character at the position right BEHIND the window counts in the
+//     number of k-mers to query and takes a digit; its substitution writes one past the window copy. [A10] that write does not reach
+//     the k-mers of the window (KmerHashIterator is given len_buff_amb and stays inside it);
+//   * resolved characters leave m_amb, later windows see the resolved read (out_s), unresolved ones stay ambiguous.
+// KmerHashIterator visits the windows of k A/C/G/T characters [A5]; after a valid substitution every character of the window is one.
+std::string fixSNPs(const Graph& g, const std::string& s) {
+    const size_t k = static_cast<size_t>(g.k), limit_nb_km_cand = 64;
+    std::string out_s = s;
+    if (s.length() < k) return out_s;
+    std::map<size_t, uint8_t> m_amb; // position -> set of bases (bit 0 A, 1 C, 2 G, 3 T; getAmbiguityRev, src/Common.hpp:389-399)
+    for (size_t i = 0; i < s.length(); ++i) if (!isDNA(s[i])) m_amb.insert(std::make_pair(i, iupacIndex(s[i])));
+    static const char alpha[4] = {'A', 'C', 'G', 'T'};
+    for (size_t i = 0; i < s.length(); ++i) {
+        if (isDNA(out_s[i])) continue;
+        const size_t min_pos_amb = (i < (k - 1)) ? 0 : (i - k + 1);
+        const size_t len_buff_amb = std::min(i + k, s.length()) - min_pos_amb;
+        const size_t pos_amb_buff = i - min_pos_amb;
+        const std::string s_sub = out_s.substr(min_pos_amb, len_buff_amb);
+        std::vector<std::pair<size_t, uint8_t> > v_amb(m_amb.lower_bound(min_pos_amb), m_amb.upper_bound(min_pos_amb + len_buff_amb));
+        if (v_amb.empty()) continue;
+        size_t nb_km_cand = 1;
+        for (size_t a = 0; a < v_amb.size(); ++a) {
+            const uint8_t m = v_amb[a].second;
+            nb_km_cand *= static_cast<size_t>(m & 1) + static_cast<size_t>((m >> 1) & 1) + static_cast<size_t>((m >> 2) & 1) + static_cast<size_t>((m >> 3) & 1);
+            if (nb_km_cand >= limit_nb_km_cand) break;
+        }
+        if (nb_km_cand >= limit_nb_km_cand) continue;
+        std::set<char> s_amb_cand;
+        for (size_t a = 0; a < v_amb.size(); ++a) v_amb[a].first -= min_pos_amb;
+        for (size_t j = 0; (j < v_amb.size() * 4) && (s_amb_cand.size() <= 1); ++j) {
+            std::string l_s_sub = s_sub + '\0'; // one spare character: the write of an ambiguity right behind the window lands here [A10]
+            bool valid = true;
+            for (size_t pos_v_amb = 0; (pos_v_amb < v_amb.size()) && valid; ++pos_v_amb) {
+                const size_t subpos_v_amb = (j >> ((pos_v_amb << 1) & 63)) & 0x3ULL; // x86-64 shift semantics; shifts >= 64 are not reached (fewer than 6 ambiguities with bases precede an invalid one)
+                if ((v_amb[pos_v_amb].second >> subpos_v_amb) & 1) l_s_sub[v_amb[pos_v_amb].first] = alpha[subpos_v_amb];
+                else valid = false;
+            }
+            if (valid && (s_amb_cand.find(l_s_sub[pos_amb_buff]) == s_amb_cand.end())) {
+                for (size_t p = 0; p + k <= len_buff_amb; ++p) {
+                    bool ok = true; for (size_t x = 0; x < k && ok; ++x) ok = isDNA(l_s_sub[p + x]);
+                    if (!ok) continue;
+                    if (!g.findUnitig(l_s_sub.c_str(), p, len_buff_amb).isEmpty()) { s_amb_cand.insert(l_s_sub[pos_amb_buff]); break; }
+                }
+            }
+        }
+        if (s_amb_cand.size() == 1) { out_s[i] = *s_amb_cand.begin(); m_amb.erase(i); }
+    }
+    return out_s;
+}
+
 std::pair<std::string, std::string> correctRead2(const Graph& g, const Opt& opt_in, std::string seq, std::string qual, const std::string& seq_raw_in, Counters* cnt) {
     Opt opt = opt_in; opt.long_read_correct = true;
     for (size_t i = 0; i < seq.size(); ++i) seq[i] = static_cast<char>(std::toupper(static_cast<unsigned char>(seq[i]))); // :814 (the raw read is used as read: :774-802)
+    if (opt.force_unres_snp_corr) seq = fixSNPs(g, seq); // :828
     const std::pair<std::string, std::string> ph = opt.skip_phasing ? std::make_pair(seq, qual) : phasing(g, opt, seq_raw_in, seq, qual); // :832
     const std::pair<std::vector<Anchor>, std::vector<Anchor> > seeds = getSeeds(g, opt, ph.first, cnt);
     return correctSequence(g, opt, ph.first, ph.second, seeds.first, seeds.second, cnt);

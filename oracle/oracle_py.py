@@ -14,7 +14,7 @@ class OrcOpts(C.Structure):
     _fields_ = [("insert_sz", C.c_uint64), ("min_cov_vertices", C.c_uint64), ("max_len_weak_region1", C.c_uint64),
                 ("max_km_cov", C.c_uint64), ("weak_region_len_factor", C.c_double), ("large_k_factor", C.c_double),
                 ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double),
-                ("max_len_weak_region2", C.c_uint64), ("skip_phasing", C.c_int32), ("reserved", C.c_int32)]
+                ("max_len_weak_region2", C.c_uint64), ("skip_phasing", C.c_int32), ("force_unres_snp_corr", C.c_int32)]
 
 
 def default_opts(max_km_cov=128):
@@ -53,6 +53,7 @@ def lib():
         L.orc_use_reference_edlib.argtypes = [C.c_char_p]
         L.orc_correct_batch2.argtypes = [C.c_void_p, C.POINTER(OrcOpts), C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_int]
+        L.orc_fix_snps.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p]
         L.orc_wyhash8.restype = C.c_uint64
         L.orc_wyhash8.argtypes = [C.c_uint64, C.c_uint64]
         _lib = L
@@ -153,6 +154,13 @@ class Graph:
         out = (C.c_int64 * 4)()
         lib().orc_neighbours(self.h, u, direction, out)
         return [out[i] for i in range(4)]
+
+    def fix_snps(self, seq):
+        """fixSNPs() of one read (src/Alignment.cpp:846-965)."""
+        s = seq.encode() if isinstance(seq, str) else seq
+        out = C.create_string_buffer(len(s) + 1)
+        lib().orc_fix_snps(self.h, s, len(s), out)
+        return out.raw[:len(s)]
 
     def exact(self, seq):
         s = seq.encode() if isinstance(seq, str) else seq

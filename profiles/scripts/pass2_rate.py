@@ -26,5 +26,11 @@ t_p2 = time.time() - t0
 assert r2.returncode == 0, r2.stderr
 stats = lambda txt: [l for l in txt.splitlines() if "correction phase" in l]
 tr = [l for l in r2.stderr.splitlines() if "rtk trace" in l and ("attempt" in l or "phase" in l or "seeds" in l or "shares" in l or "size class" in l or "DFS book" in l)]
-print(json.dumps({"ref_len": ref_len, "lr_bases": lr_bases, "k2": k2, "data_s": round(t_data, 1), "pass1_wall_s": round(t_p1, 2), "pass1": stats(r1.stderr), "index2_s": round(t_idx2, 1),
+# A/B on the same files: RTK_P2_AB="A=1,B=2;C=3" re-runs the second pass once per ';'-separated set of environment overrides
+ab = []
+for spec in [x for x in os.environ.get("RTK_P2_AB", "").split(";") if x]:
+    e2 = dict(env, RTK_TRACE="1", **dict(kv.split("=", 1) for kv in spec.split(",")))
+    t0 = time.time(); rr = subprocess.run(r2.args, capture_output=True, text=True, env=e2); ab.append({"env": spec, "rc": rr.returncode, "wall_s": round(time.time() - t0, 2), "pass2": stats(rr.stderr),
+               "phase": [l for l in rr.stderr.splitlines() if "rtk trace" in l and "phase" in l][:12]})
+print(json.dumps({"ab": ab, "ref_len": ref_len, "lr_bases": lr_bases, "k2": k2, "data_s": round(t_data, 1), "pass1_wall_s": round(t_p1, 2), "pass1": stats(r1.stderr), "index2_s": round(t_idx2, 1),
                   "pass2_wall_s": round(t_p2, 2), "pass2_options": extra2, "pass2": stats(r2.stderr), "pass2_trace_head": tr[:40]}, indent=1))

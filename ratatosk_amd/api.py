@@ -20,7 +20,7 @@ class RtkOpts(C.Structure):
     _fields_ = [("insert_sz", C.c_uint64), ("min_cov_vertices", C.c_uint64), ("max_len_weak_region1", C.c_uint64),
                 ("max_km_cov", C.c_uint64), ("weak_region_len_factor", C.c_double), ("large_k_factor", C.c_double),
                 ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double),
-                ("long_read_correct", C.c_int32), ("reserved", C.c_int32), ("max_len_weak_region2", C.c_uint64)]
+                ("long_read_correct", C.c_int32), ("force_unres_snp_corr", C.c_int32), ("max_len_weak_region2", C.c_uint64)]
 
 
 class RtkGraphInfo(C.Structure):
@@ -80,6 +80,7 @@ def load_library(path=None):
     L.rtk_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(RtkStats)]
     L.rtk_batch_free.argtypes = [C.c_void_p]
     L.rtk_lookup_exact.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_int64)]
+    L.rtk_fix_snps.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p]
     L.rtk_seeds.argtypes = [C.c_void_p, C.POINTER(RtkOpts), C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_int64),
                             C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_uint64]
     L.rtk_myers_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
@@ -138,6 +139,13 @@ class Graph:
         out = (C.c_int64 * max(1, nw))()
         self._check(self.L.rtk_lookup_exact(self.h, s, len(s), out))
         return [out[i] for i in range(nw)]
+
+    def fix_snps(self, seq):
+        """fixSNPs() of one read (`-f` of the second pass, src/Alignment.cpp:846-965)."""
+        s = _b(seq)
+        out = C.create_string_buffer(len(s) + 1)
+        self._check(self.L.rtk_fix_snps(self.h, s, len(s), out))
+        return out.raw[:len(s)]
 
     def seeds(self, seq, opts=None):
         s = _b(seq)

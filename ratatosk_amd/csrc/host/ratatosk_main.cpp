@@ -15,7 +15,7 @@
 // `correct -2 -g G2 -d D2 -l OUT.2.fastq -L raw_reads -o OUT` is the second pass (src/Ratatosk.cpp:1163-1262 with a pre-built second
 // index): the uncorrected reads are read in lock-step with the pass-1 reads (:774-802), qualities are kept, output goes to OUT.fastq
 // (:622), optionally gzipped (-G; one gzip member per ticket block, compressed by the workers) and trimmed / split at low-quality
-// bases (-t, :508-563). Everything else (`index`, `-u`, `-p/-P`, `-a`, `-f`) is out of scope.
+// bases (-t, :508-563). `-f` = fixSNPs() on the reads of the second pass (:828). Everything else (`index`, `-u`, `-p/-P`, `-a`) is out of scope.
 #include <getopt.h>
 #include <zlib.h>
 
@@ -40,6 +40,7 @@ struct Opt {
     std::vector<std::string> in_long, in_long_raw;
     std::string out, graph, udata;
     int cores = 1, gpus = 0, workers_per_gpu = 3, k1 = 31, k2 = 63, max_qual = 40, trim = 0, rounds = 1;
+    bool force_snp = false;
     double min_conf_snp = 0.9;
     size_t insert_sz = 500, w1 = 1000, w2 = 5000, batch_bases = 32u << 20;
     bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false, gzip = false;
@@ -59,7 +60,7 @@ static void usage() {
                     "       Ratatosk correct -2 -g <graph2.fasta.gz> -d <unitig_data2.rtsk> -l <out_prefix>.2.fastq -L <long_reads> -o <out_prefix> [options]\n"
                     "  -L, --in-long-raw     the uncorrected long reads, same order as -l\n  -K, --k2              k-mer length of the 2nd pass graph (default 63)\n"
                     "  -W, --max-len-weak2   maximum weak region length, 2nd pass (default 5000)\n  -t, --trim-split      trim and split reads at bases with quality below this (default 0: off)\n"
-                    "  -G, --gzip-out        write <out_prefix>.fastq.gz\nWrites <out_prefix>.fastq. Only `correct` with a pre-built index is in scope.\n");
+                    "  -G, --gzip-out        write <out_prefix>.fastq.gz\n  -f, --force-correct-snp  resolve ambiguous characters of the reads that have one graph-supported base before correcting (default off)\nWrites <out_prefix>.fastq. Only `correct` with a pre-built index is in scope.\n");
 }
 
 struct Ticket { // one batch of reads, packed: the reference's >= buffer_sz unit of work (src/Common.hpp:138, src/Ratatosk.cpp:757)
@@ -127,7 +128,8 @@ int main(int argc, char** argv) {
             case 'r': opt.rounds = atoi(optarg); break;
             case 'F': case 'I': case 'S': case 'M': case 'C': break; // only read by `index` (detectSNPs, .bfi, addCoverage: src/Ratatosk.cpp:1067,1124; src/Graph.cpp:1573,1796,2117)
             case 'O': break; // output is in input order in both passes here (src/Ratatosk.cpp:919 re-orders only when asked in pass 2)
-            case 'u': case 'a': case 'p': case 'P': case 'f': fprintf(stderr, "Ratatosk::correct: -%c (unmapped-read rescue / helper long reads / phased input / forced SNP correction) is not in scope of this build\n", c); return 1;
+            case 'f': opt.force_snp = true; break; // fixSNPs() before phasing() in the second pass (src/Ratatosk.cpp:279,828); the first pass does not look at it
+            case 'u': case 'a': case 'p': case 'P': fprintf(stderr, "Ratatosk::correct: -%c (unmapped-read rescue / helper long reads / phased input) is not in scope of this build\n", c); return 1;
             case 'L': opt.in_long_raw.push_back(optarg); break;
             case 'K': opt.k2 = atoi(optarg); break;
             case 'W': opt.w2 = strtoull(optarg, nullptr, 10); break;
@@ -191,6 +193,7 @@ int main(int argc, char** argv) {
     rtk_opts ro; rtk_opts_default(graphs[0], &ro);
     ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_len_weak_region2 = opt.w2; ro.max_qual = opt.max_qual; ro.min_confidence_snp_corr = opt.min_conf_snp;
     ro.long_read_correct = lrc ? 1 : 0;
+    ro.force_unres_snp_corr = (lrc && opt.force_snp) ? 1 : 0;
     const bool gz_out = opt.gzip && lrc; // compress_out && long_read_correct (src/Ratatosk.cpp:620); output order is kept either way here
     const int trim = lrc ? opt.trim : 0; // pass 1 qualities are placeholders: the reference trims the final output only (src/Ratatosk.cpp:965-975)
 
