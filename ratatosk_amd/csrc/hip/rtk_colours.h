@@ -8,7 +8,7 @@
 #ifndef RTK_COLOURS_H
 #define RTK_COLOURS_H
 
-#define RTK_CB_MAX_IDS 1664u   // ids gathered from all anchors (with repeats); universe (u32), 256 radix counters and 64 scatter words share the 8 KB LDS buffer
+#define RTK_CB_MAX_IDS (RTK_LDS_SET_CAP - 384u)   // ids gathered from all anchors (with repeats); universe (u32), 256 radix counters and 64 scatter words share the 8 KB LDS buffer
 #define RTK_CB_MAX_SLOTS 24u   // side-list entries whose bit vectors are kept
 
 #ifndef RTK_SIM
@@ -361,7 +361,7 @@ RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, 
       std::sort(uni, uni + T);
       for (uint32_t i = 0; i < T; ++i) if (i == 0 || uni[i] != uni[i - 1]) uni[U++] = uni[i]; }
 #else
-    uint32_t* const uni = rtk_lds_set_buf(); uint64_t* const scatter = reinterpret_cast<uint64_t*>(uni + 1920); // [0, 1664) ids, [1664, 1920) radix counters, [1920, 2048) scatter words
+    uint32_t* const uni = rtk_lds_set_buf(); uint64_t* const scatter = reinterpret_cast<uint64_t*>(uni + RTK_CB_MAX_IDS + 256u); // [0, 1664) ids, [1664, 1920) radix counters, [1920, 2048) scatter words
     { // radix sort of the ids in LDS (second buffer: the gathered copy in scratch memory)
       uint32_t mx = 0;
       for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < T; i += RTK_WAVE) { const uint32_t x = gathered[i]; uni[i] = x; mx = x > mx ? x : mx; }

@@ -4,6 +4,6 @@
 #include "rtk_phasing.h"
 // reads list[0..n_list) (long reads: their whole-read alignment spans several 4096-row blocks), one workgroup of `waves` waves per read at a
 // time, `grid` workgroups, each with its own work area scratch + i * stride. Status as k_phase: bv.status[r] = overflow code.
-void rtk_launch_phase_long(int grid, int waves, rtk_stream_t st, const GraphView& g, const OptsView& o, const BatchView& bv, const PhaseView& pv, char* scratch, uint64_t stride,
+void rtk_launch_phase_long(int grid, int waves, rtk_stream_t st, const LaunchCtx* L, const GraphView& g, const OptsView& o, const BatchView& bv, const PhaseView& pv, char* scratch, uint64_t stride,
                            const RegionScratchCfg& cfg, const uint32_t* list, uint32_t n_list, int only_flagged);
 #endif

@@ -24,7 +24,7 @@
 #include "rtk_region.h"
 #include "rtk_phase_long.h"
 
-__global__ void __launch_bounds__(1024) k_phase_long(GraphView g, OptsView o, BatchView bv, PhaseView pv, char* scratch, uint64_t stride, RegionScratchCfg cfg, const uint32_t* list, uint32_t n_list, int only_flagged) {
+__global__ void __launch_bounds__(1024) k_phase_long(const LaunchCtx* L, GraphView g, OptsView o, BatchView bv, PhaseView pv, char* scratch, uint64_t stride, RegionScratchCfg cfg, const uint32_t* list, uint32_t n_list, int only_flagged) {
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     RtkCoop* st = rtk_coop();
     if (threadIdx.x == 0) { st->seq = 0; st->n_done = 0; st->exit_flag = 0; st->n_waves = static_cast<int>(blockDim.x) >> 6; }
@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(1024) k_phase_long(GraphView g, OptsView o, Ba
     __shared__ RegionScratch hdr;
     RegionScratch* sc = region_scratch_carve(scratch + static_cast<uint64_t>(blockIdx.x) * stride, cfg, &hdr);
     rtk_sync();
-    RCtx c; c.g = g; c.o = o; c.bv = bv; memset(&c.rb, 0, sizeof(c.rb)); c.sc = sc; c.k = g.k;
+    (void)o;
+    RCtx c = {L->g, L->o, L->bv, L->rb, {rtk_opaque(sc)}, {g.k}};
     for (uint32_t ri = blockIdx.x; ri < n_list; ri += gridDim.x) {
         const uint32_t r = list[ri];
         if (only_flagged && bv.status[r] == 0) continue;
@@ -45,8 +46,8 @@ __global__ void __launch_bounds__(1024) k_phase_long(GraphView g, OptsView o, Ba
     rtk_coop_st(&st->exit_flag, 1); // the helpers leave
 }
 
-void rtk_launch_phase_long(int grid, int waves, rtk_stream_t s, const GraphView& g, const OptsView& o, const BatchView& bv, const PhaseView& pv, char* scratch, uint64_t stride,
+void rtk_launch_phase_long(int grid, int waves, rtk_stream_t s, const LaunchCtx* L, const GraphView& g, const OptsView& o, const BatchView& bv, const PhaseView& pv, char* scratch, uint64_t stride,
                            const RegionScratchCfg& cfg, const uint32_t* list, uint32_t n_list, int only_flagged) {
-    hipLaunchKernelGGL(k_phase_long, dim3(static_cast<unsigned>(grid)), dim3(static_cast<unsigned>(64 * waves)), 0, s, g, o, bv, pv, scratch, stride, cfg, list, n_list, only_flagged);
+    hipLaunchKernelGGL(k_phase_long, dim3(static_cast<unsigned>(grid)), dim3(static_cast<unsigned>(64 * waves)), 0, s, L, g, o, bv, pv, scratch, stride, cfg, list, n_list, only_flagged);
     rtk_check(hipGetLastError(), "kernel launch (k_phase_long)");
 }

@@ -67,11 +67,25 @@ struct RegionScratch {
     U<uint32_t*> overflow; U<uint32_t> ovf_word; // the flag itself, next to the header (same memory: LDS in the kernels)
     U<unsigned long long> cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
     U<unsigned long long> fine[16]; // developer cycle counters printed with RTK_TRACE (RTK_FINE names in rtk_pipeline_run.inc)
+#ifndef RTK_SLIM_HDR
     U<unsigned long long> hist[32]; // region time by size class: [b] cycles, [8 + b] regions, [16 + b] regions that needed the reverse strand too, [24 + b] DFS calls
+#endif
 };
+#ifdef RTK_SLIM_HDR // A/B build: header of 1 KB (20 waves per CU fit next to a 7 KB set buffer); the size-class table is not kept
+#define RTK_HIST_ADD(sc, i, v) ((void)0)
+#define RTK_HIST_GET(sc, i) 0ull
+#else
+#define RTK_HIST_ADD(sc, i, v) ((sc).hist[i] += (v))
+#define RTK_HIST_GET(sc, i) ((sc).hist[i])
+#endif
+
+// The views of a launch, ONE copy in device memory per batch (written by k_set_ctx in front of the kernels that read it). The wave
+// programs read them through RCtx: a per-wave copy on the wave's stack costs 64 lanes x the struct in scratch memory (the stack is
+// interleaved per lane), 45 KB per wave that every `c.g.x` then fetches a 256-byte row of.
+struct LaunchCtx { GraphView g; OptsView o; BatchView bv; RegionBatch rb; };
 
 struct RCtx { // everything a region program needs
-    GraphView g; OptsView o; BatchView bv; RegionBatch rb;
+    const GraphView& g; const OptsView& o; const BatchView& bv; const RegionBatch& rb; // -> the LaunchCtx of the launch
     U<RegionScratch*> sc;
     U<int> k;
 };
@@ -635,7 +649,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
 #ifdef RTK_SIM
     { const unsigned long long na = s.cnt[3] - dfs_al0; const unsigned b = na > 15 ? 15 : static_cast<unsigned>(na); rtk_sim_site_stat[21][0] += 1; rtk_sim_site_stat[22 + (b >> 3)][b & 7] += 1; rtk_sim_site_stat[24 + (b >> 3)][b & 7] += na; }
 #endif
-    s.cnt[0] += n_exp; s.hist[31] += 1;
+    s.cnt[0] += n_exp; RTK_HIST_ADD(s, 31, 1);
     s.cnt[14] += (rtk_clock() - td0) - (s.cnt[9] - my0); // DFS bookkeeping: loop time minus the alignments inside it
     bool nt_score_deferred = false;
     if (lazy_nt && !rtk_failed(s)) {
@@ -1624,7 +1638,9 @@ RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& 
     t.memo_v = reinterpret_cast<uint8_t*>(p); p += c.memo_cap;
     t.ovf_word = 0; t.overflow = reinterpret_cast<uint32_t*>(&s->ovf_word); t.my.overflow = t.overflow;
     for (int i = 0; i < 16; ++i) { t.cnt[i] = 0; t.fine[i] = 0; }
+#ifndef RTK_SLIM_HDR
     for (int i = 0; i < 32; ++i) t.hist[i] = 0;
+#endif
     *s = t; // every lane stores the same header
     return s;
 }
@@ -1724,7 +1740,7 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
                 const uint32_t i_solid_bw = so.n - i - 2;
                 uint32_t i_weak_bw = we.n - i_weak;
                 i_weak_bw = rtk_an_first_gt(we_r, 0, i_weak_bw, rtk_an_pos(so_r, i_solid_bw));
-{ const uint32_t gl_ = pb - pa; s.hist[16 + (gl_ < 40 ? 0 : gl_ < 64 ? 1 : gl_ < 128 ? 2 : gl_ < 256 ? 3 : gl_ < 512 ? 4 : gl_ < 1024 ? 5 : 6)] += 1; }
+{ const uint32_t gl_ = pb - pa; RTK_HIST_ADD(s, 16 + (gl_ < 40 ? 0 : gl_ < 64 ? 1 : gl_ < 128 ? 2 : gl_ < 256 ? 3 : gl_ < 512 ? 4 : gl_ < 1024 ? 5 : 6), 1); }
                 rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_bw, i_weak_bw, &fw, bw, q_bw);
                 if (rtk_failed(s)) return;
                 rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);

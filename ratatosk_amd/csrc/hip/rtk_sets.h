@@ -15,10 +15,12 @@ RTK_DEV uint32_t rtk_lower_bound(const uint32_t* a, uint32_t n, uint32_t x) { //
 
 RTK_DEV bool rtk_set_contains(const uint32_t* a, uint32_t n, uint32_t x) { const uint32_t i = rtk_lower_bound(a, n, x); return i < n && a[i] == x; }
 
+#ifndef RTK_LDS_SET_CAP
+#define RTK_LDS_SET_CAP 2048u // words of the per-wave LDS buffer; the colour selection needs >= 1792 (rtk_colours.h)
+#endif
 #ifndef RTK_SIM
 // The set that is searched is staged in LDS when it fits: a binary search is a chain of dependent reads, and an LDS read returns
 // several times sooner than one from L2. One wave per workgroup, so the buffer is private to the wave.
-#define RTK_LDS_SET_CAP 2048
 __device__ __forceinline__ uint32_t* rtk_lds_set_buf() { __shared__ uint32_t buf[RTK_LDS_SET_CAP]; return buf; } // ONE 8 KB buffer per wave for every user
 RTK_DEV bool rtk_lds_contains(const uint32_t* lds, uint32_t n, uint32_t x) {
     uint32_t lo = 0, hi = n;

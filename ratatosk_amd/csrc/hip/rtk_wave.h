@@ -32,6 +32,7 @@ inline uint64_t rtk_ballot(bool p) { return p ? 1ull : 0ull; }
 template <class T> inline T rtk_shfl(T v, int) { return v; }
 template <class T> inline T rtk_shfl_up1(T v, T lane0_value) { (void)v; return lane0_value; }
 inline void rtk_sync() {}
+template <class T> inline T* rtk_opaque(T* p) { return p; }
 inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
 template <class T> inline T rtk_atomic_add_raw(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
@@ -85,6 +86,9 @@ template <class T> __device__ __forceinline__ T rtk_shfl_up1(T v, T lane0_value)
 #define RTK_WG_SYNC() __syncthreads()
 #endif
 __device__ __forceinline__ void rtk_sync() { RTK_WG_SYNC(); }
+// a wave-uniform pointer the optimiser knows nothing about (address space, constant value): for pointers into LDS that travel through
+// generic-pointer code -- the backend folds the null test of the cast back to LDS into an instruction it cannot encode
+template <class T> __device__ __forceinline__ T* rtk_opaque(T* p) { unsigned long long v = reinterpret_cast<unsigned long long>(p); asm volatile("" : "+s"(v)); return reinterpret_cast<T*>(v); }
 __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
 template <class T> __device__ __forceinline__ T rtk_atomic_add_raw(T* p, T v) { return atomicAdd(p, v); }
