@@ -54,6 +54,14 @@ struct RegionScratchCfg { ScratchCfg my; uint32_t set_cap, um_cap, str_cap, list
 
 struct WPath { U<UMap*> ums; U<char*> qual; U<uint32_t> n, l, qlen; }; // mutable working path
 
+// anchors of a read in one orientation, side lists of chooseColors, result of one `correct` call (functions further down)
+struct Anchors { U<const uint32_t*> pos; U<const uint64_t*> hit; U<const uint64_t*> hits_by_pos; U<uint32_t> n, L; U<int> rev; U<int> k; };
+struct SideList { uint32_t* u; uint8_t* nb; uint32_t n, cap; };
+struct ResCorr { char* seq; char* qual; uint32_t seq_len, qual_len; uint64_t* bm; uint32_t old_len; bool is_corrected; uint32_t n_all; int all_set; };
+// Locals of the region drivers that travel by reference (rtk_correct_region, rtk_generate_consensus, rtk_choose_colors): kept in the
+// header (LDS in the kernels) instead of the wave's stack, where every wave-uniform word is a 256-byte row per store and per load
+struct DriverLocals { Anchors an[4]; ResCorr rc[2]; SideList side[3]; };
+
 struct RegionScratch {
     MyersScratch my;
     U<uint32_t*> set[10]; U<uint32_t> set_cap;
@@ -65,6 +73,7 @@ struct RegionScratch {
     U<uint32_t*> memo_u; U<uint8_t*> memo_v; U<uint32_t> memo_cap; U<uint32_t> memo_n;
     U<uint64_t*> bm[3]; U<uint32_t> bm_words;
     U<uint32_t*> overflow; U<uint32_t> ovf_word; // the flag itself, next to the header (same memory: LDS in the kernels)
+    DriverLocals loc;
     U<unsigned long long> cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
     U<unsigned long long> fine[16]; // developer cycle counters printed with RTK_TRACE (RTK_FINE names in rtk_pipeline_run.inc)
 #ifndef RTK_SLIM_HDR
@@ -118,7 +127,6 @@ RTK_DEV void rtk_fail_ovf(RegionScratch& s, uint32_t code) { *s.overflow = code;
 RTK_DEV bool rtk_failed(const RegionScratch& s) { return rtk_ld(rtk_ld(&s.overflow)) != 0; }
 
 // anchors of a read in forward or reverse-complement orientation (src/Correction.cpp:196-213)
-struct Anchors { U<const uint32_t*> pos; U<const uint64_t*> hit; U<const uint64_t*> hits_by_pos; U<uint32_t> n, L; U<int> rev; U<int> k; };
 RTK_DEV uint32_t rtk_an_pos(const Anchors& a, uint32_t i) { return a.rev ? (a.L - a.pos[a.n - 1 - i] - static_cast<uint32_t>(a.k)) : a.pos[i]; }
 RTK_DEV UMap rtk_an_um(const Anchors& a, uint32_t i) {
     const uint32_t j = a.rev ? (a.n - 1 - i) : i;
@@ -1030,7 +1038,6 @@ RTK_FN_SEARCH uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_
 
 // ------------------------------------------------------------------------------------------------ chooseColors (src/Correction.cpp:215-429)
 // anchors of the three sides are given as small (unitig, non-branching) lists, first insertion wins (unordered_map::insert).
-struct SideList { uint32_t* u; uint8_t* nb; uint32_t n, cap; };
 RTK_DEV bool rtk_side_insert(SideList& l, uint32_t u, bool nonbranching) { // returns true when unseen
     const uint32_t n = rtk_u(l.n); const uint32_t* lu = rtk_u(l.u);
     for (uint32_t i0 = 0; i0 < n; i0 += RTK_WAVE) { // 64 entries per step
@@ -1208,7 +1215,6 @@ RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const
 }
 
 // ------------------------------------------------------------------------------------------------ ResultCorrection (src/ResultCorrection.hpp)
-struct ResCorr { char* seq; char* qual; uint32_t seq_len, qual_len; uint64_t* bm; uint32_t old_len; bool is_corrected; uint32_t n_all; int all_set; };
 
 // position bitmaps (ResultCorrection's Roaring set of corrected old positions): word-wise, one word per lane
 RTK_DEV void rtk_bm_add_range(uint64_t* bm, uint32_t a, uint32_t b) { // [a, b)
@@ -1349,7 +1355,7 @@ RTK_FN void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_l
     if (rc == nullptr) {
         const unsigned long long t_side0 = rtk_clock();
         // side lists live in list[0..2] memory (u32 unitig + flag bytes)
-        SideList sl, sr, sm;
+        SideList& sl = s.loc.side[0]; SideList& sr = s.loc.side[1]; SideList& sm = s.loc.side[2];
         const uint32_t cap = s.list_cap;
         sl.u = reinterpret_cast<uint32_t*>(s.list[0].get()); sl.nb = reinterpret_cast<uint8_t*>(s.list[0].get() + cap / 2); sl.n = 0; sl.cap = cap;
         sr.u = reinterpret_cast<uint32_t*>(s.list[1].get()); sr.nb = reinterpret_cast<uint8_t*>(s.list[1].get() + cap / 2); sr.n = 0; sr.cap = cap;
@@ -1666,10 +1672,12 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     const char* s_fw = c.bv.seq + base; const char* s_bw = c.rb.seq_rc + base;
     const char q_min = rtk_get_qual(0.0, 0, static_cast<uint64_t>(c.o.max_qual)), q_max = rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual));
     char* out_s = s.rbuf[4]; char* out_q = s.rbuf[5]; uint32_t osl = 0, oql = 0;
-    Anchors so; so.pos = c.bv.s_pos + base; so.hit = nullptr; so.hits_by_pos = c.bv.hits + base; so.n = c.bv.n_solid[r]; so.L = L; so.rev = 0; so.k = c.k;
-    Anchors we; we.pos = c.bv.wk_pos + c.bv.w_off[r]; we.hit = c.bv.wk_hit + c.bv.w_off[r]; we.hits_by_pos = nullptr; we.n = c.bv.w_cnt[r]; we.L = L; we.rev = 0; we.k = c.k;
-    Anchors so_r = so; so_r.rev = 1; Anchors we_r = we; we_r.rev = 1;
-    ResCorr fw, bw;
+    Anchors& so = s.loc.an[0]; Anchors& we = s.loc.an[1]; Anchors& so_r = s.loc.an[2]; Anchors& we_r = s.loc.an[3];
+    so.pos = c.bv.s_pos + base; so.hit = nullptr; so.hits_by_pos = c.bv.hits + base; so.n = c.bv.n_solid[r]; so.L = L; so.rev = 0; so.k = c.k;
+    we.pos = c.bv.wk_pos + c.bv.w_off[r]; we.hit = c.bv.wk_hit + c.bv.w_off[r]; we.hits_by_pos = nullptr; we.n = c.bv.w_cnt[r]; we.L = L; we.rev = 0; we.k = c.k;
+    so_r = so; so_r.rev = 1; we_r = we; we_r.rev = 1;
+    rtk_sync();
+    ResCorr& fw = s.loc.rc[0]; ResCorr& bw = s.loc.rc[1];
     fw.seq = s.rbuf[0]; fw.qual = s.rbuf[1]; fw.bm = s.bm[0]; bw.seq = s.rbuf[2]; bw.qual = s.rbuf[3]; bw.bm = s.bm[1];
     if (L + 64 > s.str_cap) { rtk_fail_ovf(s, 7); return; }
     // pass 2 (long_read_correct): the read's own qualities are carried wherever pass 1 writes q_max / q_min, and a stretch whose bases all
