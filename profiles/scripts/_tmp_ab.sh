@@ -1,6 +1,6 @@
 cd /root/repo
-run() { RTK_REGION_WAVES=$1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs --serial 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['roofline']['kernel_ms_per_step'])"; }
-run 4096
-run 4096
-timeout 600 python -m pytest tests/test_gpu_correct.py tests/test_pass2.py -m gpu -x -q 2>&1 | tail -3
+run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-legs --serial 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms_per_step'])"; }
+run
+run
+timeout 600 python -m pytest tests/test_gpu_correct.py tests/test_gpu_myers.py tests/test_pass2.py -m gpu -x -q 2>&1 | tail -2

@@ -152,7 +152,7 @@ RTK_DEV int rtk_myers_step(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hin, int
 }
 
 // Query profile: peq[cls * W + w], bit i of word w set iff query[64w+i] equals a character of class cls.
-RTK_FN void rtk_myers_build_peq(const MyersScratch& sc, const MySeq& q, int W, bool iupac) {
+RTK_FN void rtk_myers_build_peq(const MyersScratch& sc, MySeq q, int W, bool iupac) {
     for (int w = rtk_lane(); w < W; w += RTK_WAVE) {
         uint64_t acc[15];
         for (int c = 0; c < 15; ++c) acc[c] = 0;
@@ -638,7 +638,7 @@ __device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, cons
 // Full pass of query q over target t. Writes colscore[j] = D[m][j+1] for every column; optionally the traceback
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
 // top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
-RTK_FN void rtk_myers_pass(const MyersScratch& sc_, const MySeq& q_, const MySeq& t_, int top_h_, bool iupac_, int store_, uint64_t* fin_pv_, uint64_t* fin_mv_) {
+RTK_FN void rtk_myers_pass(const MyersScratch& sc_, MySeq q_, MySeq t_, int top_h_, bool iupac_, int store_, uint64_t* fin_pv_, uint64_t* fin_mv_) {
     const MyersScratch& sc = *rtk_u(&sc_);
     MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
     const int top_h = rtk_u(top_h_), store = rtk_u(store_); const bool iupac = rtk_u(iupac_); uint64_t* fin_pv = rtk_u(fin_pv_); uint64_t* fin_mv = rtk_u(fin_mv_);
@@ -957,7 +957,7 @@ RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int ncols_, 
     { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.walk_cycles += rtk_clock() - tw0; msc.walk_moves += nt; msc.walk_reloads += n_rel; msc.walk_scalar += n_sc; msc.walk_calls += 1; msc.walk_tail_cycles += rtk_clock() - tw1; }
 }
 
-RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, const MySeq& q_, const MySeq& t_, bool iupac_, uint32_t* n_moves_) {
+RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, MySeq q_, MySeq t_, bool iupac_, uint32_t* n_moves_) {
     const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_); const bool iupac = rtk_u(iupac_);
     MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
     const int m = q.n, n = t.n;

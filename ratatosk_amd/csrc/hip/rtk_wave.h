@@ -24,6 +24,7 @@
 #define RTK_FN inline
 #define RTK_FN_SEARCH inline
 #define RTK_FN_DRIVER inline
+#define RTK_FN_REGION inline
 #define RTK_FN_LEAF inline
 #define RTK_FN_HOT inline
 #define RTK_WAVE 1
@@ -57,6 +58,11 @@ inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64;
 #define RTK_FN_LEAF __device__ __forceinline__
 #else
 #define RTK_FN_LEAF RTK_FN
+#endif
+#ifdef RTK_INLINE_REGION
+#define RTK_FN_REGION __device__ __forceinline__
+#else
+#define RTK_FN_REGION RTK_FN
 #endif
 #ifdef RTK_INLINE_DRIVER
 #define RTK_FN_DRIVER __device__ __forceinline__
