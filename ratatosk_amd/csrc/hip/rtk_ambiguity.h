@@ -62,7 +62,7 @@ RTK_DEV uint32_t rtk_amb_of_um(const RCtx& c, const UMap& um, uint64_t* out, uin
 RTK_FN uint32_t rtk_amb_collect(const RCtx& c_, uint64_t h_, uint32_t offset_, uint32_t n_amb_) { // returns the new size of v_ambiguity
     const RCtx& c = *rtk_u(&c_); const uint64_t h = rtk_u(h_); const uint32_t offset = rtk_u(offset_), n_amb = rtk_u(n_amb_);
     if (c.g.n_amb == 0) return n_amb;
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const UMap* ums = rtk_path_ums(s, rtk_h_lvl(h), rtk_h_off(h));
     const uint32_t n = rtk_rec_n(s, h), k1 = static_cast<uint32_t>(c.k) - 1, cap = s.list_cap;
     { // nothing to do unless some unitig of the path is annotated (one lane per unitig)
@@ -150,7 +150,7 @@ RTK_FN void rtk_fix_ambiguity(const RCtx& c_, char* query_, uint32_t query_len_,
     const RCtx& c = *rtk_u(&c_); char* query = rtk_u(query_); char* quality = rtk_u(quality_); const char* ref = rtk_u(ref_);
     const uint32_t query_len = rtk_u(query_len_), quality_len = rtk_u(quality_len_), ref_len = rtk_u(ref_len_), n_amb = rtk_u(n_amb_);
     if (n_amb == 0) return;
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     const uint32_t k = static_cast<uint32_t>(c.k), cap = s.list_cap;
     if (quality_len < query_len || query_len > s.str_cap) { rtk_fail_ovf(s, 11); return; }

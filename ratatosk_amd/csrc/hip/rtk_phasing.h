@@ -40,7 +40,7 @@ RTK_DEV void rtk_or64(uint64_t* p, uint64_t v) {
 
 RTK_FN void rtk_phase_read(const RCtx& c_, const PhaseView& pv_, uint32_t r_) {
     const RCtx& c = *rtk_u(&c_); const PhaseView& pv = *rtk_u(&pv_); const uint32_t r = rtk_u(r_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     const uint32_t k = static_cast<uint32_t>(c.k);
     const uint64_t base = c.bv.roff[r];

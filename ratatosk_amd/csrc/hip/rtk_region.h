@@ -60,7 +60,7 @@ struct SideList { uint32_t* u; uint8_t* nb; uint32_t n, cap; };
 struct ResCorr { char* seq; char* qual; uint32_t seq_len, qual_len; uint64_t* bm; uint32_t old_len; bool is_corrected; uint32_t n_all; int all_set; };
 // Locals of the region drivers that travel by reference (rtk_correct_region, rtk_generate_consensus, rtk_choose_colors): kept in the
 // header (LDS in the kernels) instead of the wave's stack, where every wave-uniform word is a 256-byte row per store and per load
-struct DriverLocals { Anchors an[4]; ResCorr rc[2]; SideList side[3]; uint32_t len[6]; int best[2]; };
+struct DriverLocals { Anchors an[4]; ResCorr rc[2]; SideList side[3]; uint32_t len[6]; int best[2]; MyersSaved saved; };
 
 struct RegionScratch {
     MyersScratch my;
@@ -99,6 +99,9 @@ struct RCtx { // everything a region program needs
     U<int> k;
 };
 
+// the header of the wave's work area: in LDS in every kernel that runs the region / read programs (k_regions, k_phase, k_phase_long)
+RTK_DEV RegionScratch& rtk_hdr(const RCtx& c) { RegionScratch* p = c.sc; RTK_ASSUME_LDS(p); return *p; }
+
 #ifndef RTK_SIM
 RTK_DEV UMap rtk_u(const UMap& m) { UMap r; r.unitig = rtk_u(m.unitig); r.dist = rtk_u(m.dist); r.len = rtk_u(m.len); r.strand = rtk_u(m.strand); return r; }
 #endif
@@ -123,8 +126,9 @@ RTK_DEV char rtk_comp(char c) {
                  case 'V': return 'B'; case 'B': return 'V'; case 'H': return 'D'; case 'D': return 'H'; default: return c; }
 }
 
-RTK_DEV void rtk_fail_ovf(RegionScratch& s, uint32_t code) { *s.overflow = code; }
-RTK_DEV bool rtk_failed(const RegionScratch& s) { return rtk_ld(rtk_ld(&s.overflow)) != 0; }
+// the flag is the header's own ovf_word (s.overflow points at it for the alignment code, which only knows its MyersScratch)
+RTK_DEV void rtk_fail_ovf(RegionScratch& s, uint32_t code) { s.ovf_word = code; }
+RTK_DEV bool rtk_failed(const RegionScratch& s) { return s.ovf_word != 0; }
 
 // anchors of a read in forward or reverse-complement orientation (src/Correction.cpp:196-213)
 RTK_DEV uint32_t rtk_an_pos(const Anchors& a, uint32_t i) { return a.rev ? (a.L - a.pos[a.n - 1 - i] - static_cast<uint32_t>(a.k)) : a.pos[i]; }
@@ -189,7 +193,7 @@ RTK_DEV uint64_t rtk_h_off(uint64_t h) { return h & 0x3FFFFFFFFFFFFFFFull; }
 RTK_DEV void rtk_wp_clear(WPath& p) { p.n = 0; p.l = 0; p.qlen = 0; }
 
 RTK_FN_LEAF uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_) { // working path -> immutable record
-    RegionScratch& s = *rtk_u(&s_); const WPath& p = *rtk_u(&p_); const int lvl = rtk_u(lvl_);
+    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); const WPath& p = *rtk_u(&p_); const int lvl = rtk_u(lvl_);
     const unsigned long long tc0 = rtk_clock();
     const uint32_t pn = rtk_ld(&p.n), pl = rtk_ld(&p.l), pq = rtk_ld(&p.qlen);
     const uint64_t off = rtk_arena_alloc(s, lvl, sizeof(PathHdr) + sizeof(UMap) * pn + pq);
@@ -203,7 +207,7 @@ RTK_FN_LEAF uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_)
 }
 
 RTK_FN_LEAF void rtk_wp_load(RegionScratch& s_, WPath& p_, uint64_t h_) {
-    RegionScratch& s = *rtk_u(&s_); WPath& p = *rtk_u(&p_); const uint64_t h = rtk_u(h_);
+    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); WPath& p = *rtk_u(&p_); const uint64_t h = rtk_u(h_);
     const int lvl = rtk_h_lvl(h); const uint64_t off = rtk_h_off(h);
     const char* rec = rtk_ld(&s.arena[lvl]) + off;
     const PathHdr* hd = reinterpret_cast<const PathHdr*>(rec);
@@ -241,7 +245,7 @@ RTK_FN_HOT void rtk_wp_extend(const RCtx& c, WPath& p_, const UMap& um_) { // Pa
 // extend with a quality slice q[0..qn) (Path.hpp:332-363): appended only when its length equals um.len + k - 1
 RTK_FN void rtk_wp_extend_q(const RCtx& c_, WPath& p_, UMap um_, const char* q_, uint32_t qn_) {
     const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_); const char* q = rtk_u(q_); uint32_t qn = rtk_u(qn_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     if (rtk_um_is_empty(um)) return;
     if (p.n >= s.um_cap) { rtk_fail_ovf(s, 5); return; }
     const uint32_t want = um.len + static_cast<uint32_t>(c.k) - 1;
@@ -261,7 +265,7 @@ RTK_FN void rtk_wp_extend_q(const RCtx& c_, WPath& p_, UMap um_, const char* q_,
 // fills qual with `ch` for a fresh single-unitig path (string(len + k - 1, getQual(1.0)))
 RTK_FN_LEAF void rtk_wp_start(const RCtx& c_, WPath& p_, UMap um_, char ch_) {
     const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_); char ch = rtk_u(ch_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     rtk_wp_clear(p);
     const uint32_t want = um.len + static_cast<uint32_t>(c.k) - 1;
     if (want > s.str_cap) { rtk_fail_ovf(s, 6); return; }
@@ -272,7 +276,7 @@ RTK_FN_LEAF void rtk_wp_start(const RCtx& c_, WPath& p_, UMap um_, char ch_) {
 // p.merge(o) where o is a committed record (Path.hpp:366-414)
 RTK_FN void rtk_wp_merge(const RCtx& c_, WPath& p_, uint64_t ho_) {
     const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); uint64_t ho = rtk_u(ho_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const int lv = rtk_h_lvl(ho); const uint64_t oo = rtk_h_off(ho);
     const PathHdr* o = rtk_path_hdr(s, lv, oo);
     const UMap* oums = rtk_path_ums(s, lv, oo);
@@ -400,7 +404,7 @@ RTK_FN_HOT MyersResult rtk_align(const RCtx& c, const char* q_, uint32_t m_, con
 
 // alignment with its moves (left in s.my.moves); counted like the distance call + path call pair it replaces
 RTK_FN_HOT MyersResult rtk_align_path(const RCtx& c_, const char* q_, uint32_t m_, const char* t_, uint32_t n_, int mode_, uint32_t* n_moves_) {
-    const RCtx& c = *rtk_u(&c_); RegionScratch& s = *c.sc; const char* q = rtk_u(q_); const char* t = rtk_u(t_);
+    const RCtx& c = *rtk_u(&c_); RegionScratch& s = rtk_hdr(c); const char* q = rtk_u(q_); const char* t = rtk_u(t_);
     const uint32_t m = rtk_u(m_), n = rtk_u(n_); const int mode = rtk_u(mode_); uint32_t* n_moves = rtk_u(n_moves_);
     s.cnt[3] += (m > 0 && n > 0) ? 2 : 1; s.cnt[4] += static_cast<unsigned long long>((m + 63) / 64) * n;
     const unsigned long long t0 = rtk_clock();
@@ -557,7 +561,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
     const bool lrc = rtk_u(c.o.long_read_correct) != 0;
     const uint32_t max_len_subpath = static_cast<uint32_t>(static_cast<uint64_t>(static_cast<double>(rtk_u(c.k)) * rtk_u(c.o.large_k_factor)));
     uint32_t n_nt_live = 0, n_t_scored = 0;
-    MyersSaved t_saved; t_saved.valid = 0; t_saved.gen = 0; t_saved.m = 0; t_saved.n = 0; t_saved.nw_dist = 0; t_saved.shw.dist = -1; t_saved.shw.first = -1; t_saved.shw.last = -1; t_saved.shw.nloc = 0;
+    MyersSaved& t_saved = s.loc.saved; t_saved.valid = 0; t_saved.gen = 0; t_saved.m = 0; t_saved.n = 0; t_saved.nw_dist = 0; t_saved.shw.dist = -1; t_saved.shw.first = -1; t_saved.shw.last = -1; t_saved.shw.nloc = 0;
     unsigned long long n_exp = 0;
     const unsigned long long td0 = rtk_clock(); const unsigned long long my0 = s.cnt[9];
 #ifdef RTK_SIM
@@ -701,7 +705,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
 // explore() (src/GraphTraversal.cpp:41-93, 251-304). p = committed path (level 1). Results stay in list[2]/list[3] (level-2 arena).
 RTK_FN_SEARCH void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_e_, uint64_t hp_, uint32_t max_len_path_, uint32_t* n_t_, uint32_t* n_nt_, NtPending* pend_) {
     const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_e = rtk_u(um_e_); uint64_t hp = rtk_u(hp_); uint32_t max_len_path = rtk_u(max_len_path_); uint32_t* n_t = rtk_u(n_t_); uint32_t* n_nt = rtk_u(n_nt_); NtPending* pend = rtk_u(pend_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     *n_t = 0; *n_nt = 0; pend->e = 0; pend->nt1 = 0.0; pend->nt2 = 0.0; pend->score_deferred = 0; pend->qual_deferred = 0;
     const UMap um = rtk_rec_back(s, hp);
     const uint32_t path_len = rtk_rec_l(s, hp);
@@ -733,7 +737,7 @@ RTK_FN_SEARCH void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32
 // P (+) Q: w = copy of p extended by every mapping of sub with its quality slice (src/GraphTraversal.cpp:379-390)
 RTK_FN_LEAF void rtk_extend_by(const RCtx& c_, WPath& w_, uint64_t hsub_, uint32_t upto_) {
     const RCtx& c = *rtk_u(&c_); WPath& w = *rtk_u(&w_); uint64_t hsub = rtk_u(hsub_); uint32_t upto = rtk_u(upto_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const int lv = rtk_h_lvl(hsub); const uint64_t oo = rtk_h_off(hsub);
     const PathHdr* h = rtk_path_hdr(s, lv, oo); const UMap* ums = rtk_path_ums(s, lv, oo); const char* q = rtk_path_qual(s, lv, oo);
     uint32_t j = 0;
@@ -769,7 +773,7 @@ RTK_DEV UMap rtk_start_suffix(const RCtx& c, const UMap& um_s) { // src/GraphTra
 // NW distance to the read window (bounded by the distance so far). Identity when no unitig of the path is flagged.
 // is any unitig of the path on a short cycle? (the fast way out of fixRepeats, tested by the caller so that the common case costs no call)
 RTK_DEV bool rtk_path_has_short_cycle(const RCtx& c, uint64_t hp) {
-    RegionScratch& s = *c.sc; const GraphView& g = c.g;
+    RegionScratch& s = rtk_hdr(c); const GraphView& g = c.g;
     const int lv = rtk_h_lvl(hp); const uint64_t oo = rtk_h_off(hp);
     const UMap* pu = rtk_path_ums(s, lv, oo); const uint32_t pn = rtk_rec_n(s, hp);
     bool any = false;
@@ -778,7 +782,7 @@ RTK_DEV bool rtk_path_has_short_cycle(const RCtx& c, uint64_t hp) {
 }
 RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, uint32_t ref_len_) {
     const RCtx& c = *rtk_u(&c_); const uint64_t hp = rtk_u(hp_); const char* ref = rtk_u(ref_); const uint32_t ref_len = rtk_u(ref_len_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     const uint32_t k = static_cast<uint32_t>(c.k);
     WPath& P = s.wp[1]; WPath& E = s.wp[2]; UMap* R = s.wp[3].ums;
@@ -860,7 +864,7 @@ RTK_FN uint64_t rtk_fix_repeats(const RCtx& c_, uint64_t hp_, const char* ref_, 
 
 RTK_FN_SEARCH uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pids_, uint32_t n_all_, const char* ref_, uint32_t ref_len_, const UMap& um_s_, const UMap& um_e_, bool has_end_) {
     const RCtx& c = *rtk_u(&c_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); const UMap um_s = rtk_u(um_s_); const UMap um_e = rtk_u(um_e_); bool has_end = rtk_u(has_end_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const uint32_t k = static_cast<uint32_t>(c.k);
     s.top[1] = 0; s.memo_n = 0;
     uint64_t* v = s.list[0]; uint64_t* v_tmp = s.list[1];
@@ -995,7 +999,7 @@ RTK_FN_SEARCH uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pid
 // `partial` (list[5]). Returns the complete path handle or ~0.
 RTK_FN_SEARCH uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_, uint32_t s_len_, const uint32_t* all_pids_, uint32_t n_all_, uint32_t start_pos_, const UMap& start_um_, uint32_t end_pos_in_, const UMap& end_um_, const Anchors& lvw_, uint32_t lvw_lo_, uint32_t lvw_hi_, uint32_t i_weak_, uint32_t* n_partial_) {
     const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); uint32_t s_len = rtk_u(s_len_); const uint32_t* all_pids = rtk_u(all_pids_); uint32_t n_all = rtk_u(n_all_); uint32_t start_pos = rtk_u(start_pos_); const UMap start_um = rtk_u(start_um_); uint32_t end_pos_in = rtk_u(end_pos_in_); const UMap end_um = rtk_u(end_um_); const Anchors& lvw = *rtk_u(&lvw_); uint32_t lvw_lo = rtk_u(lvw_lo_); uint32_t lvw_hi = rtk_u(lvw_hi_); uint32_t i_weak = rtk_u(i_weak_); uint32_t* n_partial = rtk_u(n_partial_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const uint32_t k = static_cast<uint32_t>(c.k);
     const bool no_end = rtk_um_is_empty(end_um);
     const uint32_t pos2 = no_end ? s_len - k : end_pos_in;
@@ -1059,7 +1063,7 @@ RTK_DEV uint32_t rtk_rs_union(RegionScratch& s, int a, uint32_t na, const uint32
 // Computes all_pids into set[0]; returns its size. Uses set[1..9] as temporaries.
 RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
     const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     unsigned long long tf = rtk_clock();
     { // the common case: all the anchors' ids fit a 4096-bit universe -> the whole selection in registers (rtk_colours.h)
@@ -1264,7 +1268,7 @@ RTK_DEV uint64_t rtk_bm_window(const uint64_t* bm, uint32_t words, int64_t lo) {
 }
 
 RTK_FN void rtk_rc_reverse_complement(RegionScratch& s_, ResCorr& r_, uint64_t* tmp_bm_, char* tmp_) {
-    RegionScratch& s = *rtk_u(&s_); ResCorr& r = *rtk_u(&r_); uint64_t* tmp_bm = rtk_u(tmp_bm_); char* tmp = rtk_u(tmp_); // :72-88
+    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); ResCorr& r = *rtk_u(&r_); uint64_t* tmp_bm = rtk_u(tmp_bm_); char* tmp = rtk_u(tmp_); // :72-88
     if (r.seq_len == 0) return;
     const uint32_t words = (r.old_len + 63) / 64;
     // new bit j = old bit old_len-1-j: output word ow is the bit reversal of the 64 old bits ending at old_len-1-64*ow
@@ -1282,9 +1286,9 @@ RTK_FN void rtk_rc_reverse_complement(RegionScratch& s_, ResCorr& r_, uint64_t* 
 
 // appenders for the growing corrected strings
 RTK_FN_LEAF void rtk_app(RegionScratch& s_, char* dst_, uint32_t* len_, const char* src_, uint32_t n_) {
-    RegionScratch& s = *rtk_u(&s_); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); const char* src = rtk_u(src_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wcopy(dst + *len, src, n); *len += n; }
+    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); const char* src = rtk_u(src_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wcopy(dst + *len, src, n); *len += n; }
 RTK_FN_LEAF void rtk_app_fill(RegionScratch& s_, char* dst_, uint32_t* len_, char ch_, uint32_t n_) {
-    RegionScratch& s = *rtk_u(&s_); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); char ch = rtk_u(ch_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wfill(dst + *len, ch, n); *len += n; }
+    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); char* dst = rtk_u(dst_); uint32_t* len = rtk_u(len_); char ch = rtk_u(ch_); uint32_t n = rtk_u(n_); if (*len + n > s.str_cap) { rtk_fail_ovf(s, 7); return; } rtk_wfill(dst + *len, ch, n); *len += n; }
 
 // Bifrost Kmer(const char*) 2-bit code of any character (end k-mer test, src/Correction.cpp:720-724)
 RTK_DEV int rtk_bifrost_code(char ch) { const int x = (ch & 4) >> 1; return x + ((x ^ (ch & 2)) >> 1); }
@@ -1323,7 +1327,7 @@ RTK_DEV void rtk_scan_anchor_runs(const Anchors& a, int64_t start, int step, Con
 RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_len_, const Anchors& v_s_, const Anchors& v_w_, uint32_t i_s_, uint32_t i_w_, const ResCorr* rc_, ResCorr& res_, const char* q_read_ = nullptr) {
     const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); const char* q_read = rtk_u(q_read_);
     const bool lrc = rtk_u(c.o.long_read_correct) != 0 && q_read != nullptr; uint32_t s_len = rtk_u(s_len_); const Anchors& v_s = *rtk_u(&v_s_); const Anchors& v_w = *rtk_u(&v_w_); uint32_t i_s = rtk_u(i_s_); uint32_t i_w = rtk_u(i_w_); const ResCorr* rc = rtk_u(rc_); ResCorr& res = *rtk_u(&res_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const uint32_t k = static_cast<uint32_t>(c.k);
     const GraphView& g = c.g;
     const bool has_end_pt = (i_s + 1) < v_s.n;
@@ -1544,7 +1548,7 @@ RTK_DEV bool rtk_all_acgt(const char* p, uint32_t n) {
 
 RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const ResCorr* bw_, const char* ref_, uint32_t ref_len_, double max_norm_, char* out_s_, uint32_t* out_sl_, char* out_q_, uint32_t* out_ql_) {
     const RCtx& c = *rtk_u(&c_); const ResCorr* fw = rtk_u(fw_); const ResCorr* bw = rtk_u(bw_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); double max_norm = rtk_u(max_norm_); char* out_s = rtk_u(out_s_); uint32_t* out_sl = rtk_u(out_sl_); char* out_q = rtk_u(out_q_); uint32_t* out_ql = rtk_u(out_ql_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     *out_sl = 0; *out_ql = 0;
     const uint32_t nfw = rtk_bm_card(fw->bm, fw->old_len), nbw = rtk_bm_card(bw->bm, bw->old_len);
     auto take = [&](const ResCorr* r) { rtk_app(s, out_s, out_sl, r->seq, r->seq_len); rtk_app(s, out_q, out_ql, r->qual, r->qual_len); return true; };
@@ -1665,7 +1669,7 @@ RTK_FN void rtk_emit_segment(const RCtx& c_, RegionDesc* rd_, const char* sq_, u
 
 RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     const RCtx& c = *rtk_u(&c_); RegionDesc* rd = rtk_u(rd_);
-    RegionScratch& s = *c.sc;
+    RegionScratch& s = rtk_hdr(c);
     const uint32_t r = rd->read, k = static_cast<uint32_t>(c.k);
     const uint64_t base = c.bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(c.bv.roff[r + 1] - base);

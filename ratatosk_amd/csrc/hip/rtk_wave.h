@@ -34,6 +34,7 @@ template <class T> inline T rtk_shfl(T v, int) { return v; }
 template <class T> inline T rtk_shfl_up1(T v, T lane0_value) { (void)v; return lane0_value; }
 inline void rtk_sync() {}
 template <class T> inline T* rtk_opaque(T* p) { return p; }
+#define RTK_ASSUME_LDS(p) ((void)0)
 inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
 template <class T> inline T rtk_atomic_add_raw(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
@@ -94,6 +95,8 @@ template <class T> __device__ __forceinline__ T rtk_shfl_up1(T v, T lane0_value)
 __device__ __forceinline__ void rtk_sync() { RTK_WG_SYNC(); }
 // a wave-uniform pointer the optimiser knows nothing about (address space, constant value): for pointers into LDS that travel through
 // generic-pointer code -- the backend folds the null test of the cast back to LDS into an instruction it cannot encode
+// the object behind a generic pointer is in LDS: lets the compiler turn the flat accesses through it into ds_ instructions
+#define RTK_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)(p)))
 template <class T> __device__ __forceinline__ T* rtk_opaque(T* p) { unsigned long long v = reinterpret_cast<unsigned long long>(p); asm volatile("" : "+s"(v)); return reinterpret_cast<T*>(v); }
 __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
