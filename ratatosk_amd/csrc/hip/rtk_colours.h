@@ -138,7 +138,7 @@ RTK_DEV RtkBM rtk_bm8_lowest(RtkBM a, uint32_t q) { // the q lowest set bits
     return a & ~rest;
 }
 RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
-    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
+    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_); RTK_ASSUME_LDS(&side_s); RTK_ASSUME_LDS(&side_e); RTK_ASSUME_LDS(&side_w);
     RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     const uint32_t nw = rtk_u(side_w.n), ne = rtk_u(side_e.n), ns = rtk_u(side_s.n), n_slots = nw + ne + ns; // slot order: middle, right, left
@@ -312,7 +312,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
 
 // Returns |all_pids| (ids in s.set[0]), or RTK_NONE32 when the anchors' sets do not fit the small universe (caller falls back).
 RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
-    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
+    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_); RTK_ASSUME_LDS(&side_s); RTK_ASSUME_LDS(&side_e); RTK_ASSUME_LDS(&side_w);
     RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     const SideList* sides[3] = {&side_w, &side_e, &side_s};

@@ -351,7 +351,13 @@ struct MyersProb { uint64_t q_off, t_off; uint32_t qlen, tlen; int32_t k, mode; 
 
 RTK_GLOBAL void k_myers_batch(const MyersProb* probs, uint32_t n, const char* pool, int want_path, int use_iupac, char* scratch, uint64_t scratch_stride, ScratchCfg cfg,
                               int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status) {
+#ifdef RTK_SIM
     const MyersScratch sc = scratch_carve(scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * scratch_stride, cfg);
+#else
+    __shared__ MyersScratch sc; // in LDS like the header it is part of in the region kernels (the alignment code assumes so: RTK_ASSUME_LDS)
+    sc = scratch_carve(scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * scratch_stride, cfg); // every lane stores the same words
+    __syncthreads();
+#endif
     for (uint32_t i = static_cast<uint32_t>(RTK_BLOCK_ID); i < n; i += static_cast<uint32_t>(grid)) {
         const MyersProb p = probs[i];
         *sc.overflow = 0;

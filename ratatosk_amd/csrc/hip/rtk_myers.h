@@ -639,7 +639,7 @@ __device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, cons
 // table (store != 0) and the final vertical delta vectors (fin_pv/fin_mv, W words each) for column extraction.
 // top_h: +1 NW/SHW, 0 HW (edlib.cpp:584).
 RTK_FN void rtk_myers_pass(const MyersScratch& sc_, MySeq q_, MySeq t_, int top_h_, bool iupac_, int store_, uint64_t* fin_pv_, uint64_t* fin_mv_) {
-    const MyersScratch& sc = *rtk_u(&sc_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc);
     MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
     const int top_h = rtk_u(top_h_), store = rtk_u(store_); const bool iupac = rtk_u(iupac_); uint64_t* fin_pv = rtk_u(fin_pv_); uint64_t* fin_mv = rtk_u(fin_mv_);
     const int m = q.n, n = t.n, W = (m + 63) >> 6, last_bit = (m - 1) & 63;
@@ -779,7 +779,7 @@ struct MyersResult { int32_t dist, first, last, nloc; };
 // (edlib.cpp:658-692). Optionally lists every end location (locs_out, up to cap).
 RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int k_, int mode_, bool iupac_,
                                         int32_t* locs_out_ = nullptr, int cap_ = 0) {
-    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), k = rtk_u(k_), mode = rtk_u(mode_), cap = rtk_u(cap_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), k = rtk_u(k_), mode = rtk_u(mode_), cap = rtk_u(cap_);
     const bool iupac = rtk_u(iupac_); int32_t* locs_out = rtk_u(locs_out_);
     MyersResult r; r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
     if (m == 0 || n == 0) { // edlib.cpp:161-179
@@ -851,7 +851,7 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, i
 // (edlib.cpp:1021-1137). Appends the moves (already in forward order) to sc.moves at *n_moves.
 // Walks the stored table from cell (m, n) back to the origin; `cur` = D[m][n]. Appends the moves to sc.moves (after *n_moves).
 RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int ncols_, int cur_, uint32_t* n_moves_) { // ncols: columns of the sweep that stored the table (>= n)
-    const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); uint32_t* n_moves = rtk_u(n_moves_);
     const int m = rtk_u(m_), n = rtk_u(n_), ncols = rtk_u(ncols_);
     int cur = rtk_u(cur_);
     const unsigned long long tw0 = rtk_clock(); unsigned n_rel = 0, n_sc = 0;
@@ -958,7 +958,7 @@ RTK_FN void rtk_myers_walk(const MyersScratch& sc_, int m_, int n_, int ncols_, 
 }
 
 RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, MySeq q_, MySeq t_, bool iupac_, uint32_t* n_moves_) {
-    const MyersScratch& sc = *rtk_u(&sc_); uint32_t* n_moves = rtk_u(n_moves_); const bool iupac = rtk_u(iupac_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); uint32_t* n_moves = rtk_u(n_moves_); const bool iupac = rtk_u(iupac_);
     MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
     const int m = q.n, n = t.n;
     int cur;
@@ -1005,7 +1005,7 @@ RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, i
 // left and a right score), one that fits the in-memory traceback does not need it; *best_out (optional) receives it either way
 // (-1 when the traceback branch was taken without it). Saves the separate distance pass of a Hirschberg-sized problem.
 RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int best_, bool iupac_, uint32_t* n_moves_, int* best_out_ = nullptr) {
-    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), best = rtk_u(best_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), best = rtk_u(best_);
     const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_); int* best_out = rtk_u(best_out_);
     if (best_out) *best_out = best;
     *n_moves = 0;
@@ -1086,7 +1086,7 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
 // entries, the walk and the moves are the same. Anything else (IUPAC/N in the target, long queries, Hirschberg-sized tables)
 // takes the two-pass route.
 RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, int mode_, bool iupac_, uint32_t* n_moves_) {
-    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), mode = rtk_u(mode_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_), mode = rtk_u(mode_);
     const bool iupac = rtk_u(iupac_); uint32_t* n_moves = rtk_u(n_moves_);
     *n_moves = 0;
     { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; }
@@ -1132,7 +1132,7 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
 // (:727): rtk_myers_nw_and_save answers the first call and keeps what the second one needs; rtk_myers_path_from_saved then only walks.
 struct MyersSaved { uint32_t valid, gen; int32_t m, n, nw_dist; MyersResult shw; };
 RTK_FN bool rtk_myers_nw_and_save(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, bool iupac_, MyersSaved* out_) {
-    const MyersScratch& sc = *rtk_u(&sc_); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_); const bool iupac = rtk_u(iupac_); MyersSaved* out = rtk_u(out_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_); const bool iupac = rtk_u(iupac_); MyersSaved* out = rtk_u(out_);
     out->valid = 0;
 #ifndef RTK_SIM
     const long long W = (m + 63) >> 6;
@@ -1158,7 +1158,7 @@ RTK_FN bool rtk_myers_nw_and_save(const MyersScratch& sc_, const char* q_, int m
 #endif
 }
 RTK_FN bool rtk_myers_path_from_saved(const MyersScratch& sc_, const MyersSaved& sv_, uint32_t* n_moves_, MyersResult* r_) {
-    const MyersScratch& sc = *rtk_u(&sc_); const MyersSaved& sv = *rtk_u(&sv_); uint32_t* n_moves = rtk_u(n_moves_); MyersResult* r = rtk_u(r_);
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); const MyersSaved& sv = *rtk_u(&sv_); uint32_t* n_moves = rtk_u(n_moves_); MyersResult* r = rtk_u(r_);
     *n_moves = 0;
     if (!sv.valid || sv.gen != rtk_ld(&sc.tb_gen)) return false; // the table has been written again since
     *r = sv.shw;

@@ -193,7 +193,7 @@ RTK_DEV uint64_t rtk_h_off(uint64_t h) { return h & 0x3FFFFFFFFFFFFFFFull; }
 RTK_DEV void rtk_wp_clear(WPath& p) { p.n = 0; p.l = 0; p.qlen = 0; }
 
 RTK_FN_LEAF uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_) { // working path -> immutable record
-    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); const WPath& p = *rtk_u(&p_); const int lvl = rtk_u(lvl_);
+    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); const WPath& p = *rtk_u(&p_); RTK_ASSUME_LDS(&p); const int lvl = rtk_u(lvl_);
     const unsigned long long tc0 = rtk_clock();
     const uint32_t pn = rtk_ld(&p.n), pl = rtk_ld(&p.l), pq = rtk_ld(&p.qlen);
     const uint64_t off = rtk_arena_alloc(s, lvl, sizeof(PathHdr) + sizeof(UMap) * pn + pq);
@@ -207,7 +207,7 @@ RTK_FN_LEAF uint64_t rtk_wp_commit(RegionScratch& s_, const WPath& p_, int lvl_)
 }
 
 RTK_FN_LEAF void rtk_wp_load(RegionScratch& s_, WPath& p_, uint64_t h_) {
-    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); WPath& p = *rtk_u(&p_); const uint64_t h = rtk_u(h_);
+    RegionScratch& s = *rtk_u(&s_); RTK_ASSUME_LDS(&s); WPath& p = *rtk_u(&p_); RTK_ASSUME_LDS(&p); const uint64_t h = rtk_u(h_);
     const int lvl = rtk_h_lvl(h); const uint64_t off = rtk_h_off(h);
     const char* rec = rtk_ld(&s.arena[lvl]) + off;
     const PathHdr* hd = reinterpret_cast<const PathHdr*>(rec);
@@ -233,7 +233,7 @@ RTK_DEV void rtk_wp_norm_back(const RCtx& c, WPath& p) { // the former end becom
 }
 
 RTK_FN_HOT void rtk_wp_extend(const RCtx& c, WPath& p_, const UMap& um_) { // Path.hpp:308-330
-    RegionScratch& s = *rtk_u(c.sc); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_);
+    RegionScratch& s = *rtk_u(c.sc); WPath& p = *rtk_u(&p_); RTK_ASSUME_LDS(&p); const UMap um = rtk_u(um_);
     if (rtk_um_is_empty(um)) return;
     const uint32_t pn = rtk_ld(&p.n);
     if (pn >= rtk_ld(&s.um_cap)) { rtk_fail_ovf(s, 5); return; }
@@ -244,7 +244,7 @@ RTK_FN_HOT void rtk_wp_extend(const RCtx& c, WPath& p_, const UMap& um_) { // Pa
 
 // extend with a quality slice q[0..qn) (Path.hpp:332-363): appended only when its length equals um.len + k - 1
 RTK_FN void rtk_wp_extend_q(const RCtx& c_, WPath& p_, UMap um_, const char* q_, uint32_t qn_) {
-    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_); const char* q = rtk_u(q_); uint32_t qn = rtk_u(qn_);
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); RTK_ASSUME_LDS(&p); const UMap um = rtk_u(um_); const char* q = rtk_u(q_); uint32_t qn = rtk_u(qn_);
     RegionScratch& s = rtk_hdr(c);
     if (rtk_um_is_empty(um)) return;
     if (p.n >= s.um_cap) { rtk_fail_ovf(s, 5); return; }
@@ -264,7 +264,7 @@ RTK_FN void rtk_wp_extend_q(const RCtx& c_, WPath& p_, UMap um_, const char* q_,
 
 // fills qual with `ch` for a fresh single-unitig path (string(len + k - 1, getQual(1.0)))
 RTK_FN_LEAF void rtk_wp_start(const RCtx& c_, WPath& p_, UMap um_, char ch_) {
-    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); const UMap um = rtk_u(um_); char ch = rtk_u(ch_);
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); RTK_ASSUME_LDS(&p); const UMap um = rtk_u(um_); char ch = rtk_u(ch_);
     RegionScratch& s = rtk_hdr(c);
     rtk_wp_clear(p);
     const uint32_t want = um.len + static_cast<uint32_t>(c.k) - 1;
@@ -275,7 +275,7 @@ RTK_FN_LEAF void rtk_wp_start(const RCtx& c_, WPath& p_, UMap um_, char ch_) {
 
 // p.merge(o) where o is a committed record (Path.hpp:366-414)
 RTK_FN void rtk_wp_merge(const RCtx& c_, WPath& p_, uint64_t ho_) {
-    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); uint64_t ho = rtk_u(ho_);
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); RTK_ASSUME_LDS(&p); uint64_t ho = rtk_u(ho_);
     RegionScratch& s = rtk_hdr(c);
     const int lv = rtk_h_lvl(ho); const uint64_t oo = rtk_h_off(ho);
     const PathHdr* o = rtk_path_hdr(s, lv, oo);
@@ -308,7 +308,7 @@ RTK_FN void rtk_wp_merge(const RCtx& c_, WPath& p_, uint64_t ho_) {
 }
 
 RTK_FN void rtk_wp_prune_prefix(const RCtx& c_, WPath& p_, uint32_t len_) {
-    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); uint32_t len = rtk_u(len_); // Path.hpp:487-571
+    const RCtx& c = *rtk_u(&c_); WPath& p = *rtk_u(&p_); RTK_ASSUME_LDS(&p); uint32_t len = rtk_u(len_); // Path.hpp:487-571
     if (p.n == 0 || p.l == 0 || len >= p.l) return;
     const uint32_t k = static_cast<uint32_t>(c.k);
     UMap& st = p.ums[0];
@@ -736,7 +736,7 @@ RTK_FN_SEARCH void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32
 
 // P (+) Q: w = copy of p extended by every mapping of sub with its quality slice (src/GraphTraversal.cpp:379-390)
 RTK_FN_LEAF void rtk_extend_by(const RCtx& c_, WPath& w_, uint64_t hsub_, uint32_t upto_) {
-    const RCtx& c = *rtk_u(&c_); WPath& w = *rtk_u(&w_); uint64_t hsub = rtk_u(hsub_); uint32_t upto = rtk_u(upto_);
+    const RCtx& c = *rtk_u(&c_); WPath& w = *rtk_u(&w_); RTK_ASSUME_LDS(&w); uint64_t hsub = rtk_u(hsub_); uint32_t upto = rtk_u(upto_);
     RegionScratch& s = rtk_hdr(c);
     const int lv = rtk_h_lvl(hsub); const uint64_t oo = rtk_h_off(hsub);
     const PathHdr* h = rtk_path_hdr(s, lv, oo); const UMap* ums = rtk_path_ums(s, lv, oo); const char* q = rtk_path_qual(s, lv, oo);
@@ -1062,7 +1062,7 @@ RTK_DEV uint32_t rtk_rs_union(RegionScratch& s, int a, uint32_t na, const uint32
 
 // Computes all_pids into set[0]; returns its size. Uses set[1..9] as temporaries.
 RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
-    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_);
+    const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_); RTK_ASSUME_LDS(&side_s); RTK_ASSUME_LDS(&side_e); RTK_ASSUME_LDS(&side_w);
     RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     unsigned long long tf = rtk_clock();
@@ -1326,7 +1326,7 @@ RTK_DEV void rtk_scan_anchor_runs(const Anchors& a, int64_t start, int step, Con
 // q_fw next to the reverse-complemented read, :787 G17); uncorrected stretches keep their qualities instead of getting q_min.
 RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint32_t s_len_, const Anchors& v_s_, const Anchors& v_w_, uint32_t i_s_, uint32_t i_w_, const ResCorr* rc_, ResCorr& res_, const char* q_read_ = nullptr) {
     const RCtx& c = *rtk_u(&c_); const char* s_read = rtk_u(s_read_); const char* q_read = rtk_u(q_read_);
-    const bool lrc = rtk_u(c.o.long_read_correct) != 0 && q_read != nullptr; uint32_t s_len = rtk_u(s_len_); const Anchors& v_s = *rtk_u(&v_s_); const Anchors& v_w = *rtk_u(&v_w_); uint32_t i_s = rtk_u(i_s_); uint32_t i_w = rtk_u(i_w_); const ResCorr* rc = rtk_u(rc_); ResCorr& res = *rtk_u(&res_);
+    const bool lrc = rtk_u(c.o.long_read_correct) != 0 && q_read != nullptr; uint32_t s_len = rtk_u(s_len_); const Anchors& v_s = *rtk_u(&v_s_); const Anchors& v_w = *rtk_u(&v_w_); RTK_ASSUME_LDS(&v_s); RTK_ASSUME_LDS(&v_w); uint32_t i_s = rtk_u(i_s_); uint32_t i_w = rtk_u(i_w_); const ResCorr* rc = rtk_u(rc_); ResCorr& res = *rtk_u(&res_); RTK_ASSUME_LDS(&res);
     RegionScratch& s = rtk_hdr(c);
     const uint32_t k = static_cast<uint32_t>(c.k);
     const GraphView& g = c.g;
@@ -1547,7 +1547,7 @@ RTK_DEV bool rtk_all_acgt(const char* p, uint32_t n) {
 }
 
 RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const ResCorr* bw_, const char* ref_, uint32_t ref_len_, double max_norm_, char* out_s_, uint32_t* out_sl_, char* out_q_, uint32_t* out_ql_) {
-    const RCtx& c = *rtk_u(&c_); const ResCorr* fw = rtk_u(fw_); const ResCorr* bw = rtk_u(bw_); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); double max_norm = rtk_u(max_norm_); char* out_s = rtk_u(out_s_); uint32_t* out_sl = rtk_u(out_sl_); char* out_q = rtk_u(out_q_); uint32_t* out_ql = rtk_u(out_ql_);
+    const RCtx& c = *rtk_u(&c_); const ResCorr* fw = rtk_u(fw_); const ResCorr* bw = rtk_u(bw_); RTK_ASSUME_LDS(fw); RTK_ASSUME_LDS(bw); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); double max_norm = rtk_u(max_norm_); char* out_s = rtk_u(out_s_); uint32_t* out_sl = rtk_u(out_sl_); char* out_q = rtk_u(out_q_); uint32_t* out_ql = rtk_u(out_ql_);
     RegionScratch& s = rtk_hdr(c);
     *out_sl = 0; *out_ql = 0;
     const uint32_t nfw = rtk_bm_card(fw->bm, fw->old_len), nbw = rtk_bm_card(bw->bm, bw->old_len);
