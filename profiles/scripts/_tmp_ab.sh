@@ -3,4 +3,4 @@ run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-
 import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms_per_step'])"; }
 run
 run
-timeout 600 python -m pytest tests/test_gpu_correct.py tests/test_gpu_myers.py tests/test_pass2.py -m gpu -x -q 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_correct.py tests/test_gpu_seeds.py tests/test_gpu_lookup.py tests/test_pass2.py -m gpu -x -q 2>&1 | tail -2

@@ -169,7 +169,7 @@ RTK_FN uint32_t rtk_shared_unitigs(const GraphView& g_, uint32_t u_, uint32_t v_
 
 // colours(u) = global | local, merged into the running union held in sc.set[cur]; returns new size (0xFFFFFFFF on overflow)
 RTK_FN uint32_t rtk_union_unitig(const GraphView& g_, const SeedScratch& sc_, int& cur_, uint32_t n_cur_, uint32_t u_) {
-    const GraphView& g = *rtk_u(&g_); const SeedScratch& sc = *rtk_u(&sc_); int& cur = *rtk_u(&cur_); uint32_t n_cur = rtk_u(n_cur_); uint32_t u = rtk_u(u_);
+    const GraphView& g = *rtk_u(&g_); const SeedScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); int& cur = *rtk_u(&cur_); uint32_t n_cur = rtk_u(n_cur_); uint32_t u = rtk_u(u_);
     const int32_t gi = g.gid[u];
     if (gi >= 0) {
         const uint32_t ng = static_cast<uint32_t>(g.goff[gi + 1] - g.goff[gi]);
@@ -225,6 +225,7 @@ RTK_DEV void rtk_scan_hit_runs(const uint64_t* hits, const uint64_t* hmap, uint6
 }
 
 RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
+    RTK_ASSUME_LDS(&sc);
     const uint64_t base = bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
     const uint32_t k = static_cast<uint32_t>(g.k);
@@ -667,6 +668,7 @@ RTK_FN uint64_t rtk_weak_key(const char* ref, uint32_t pos, uint64_t code, int k
 }
 
 RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
+    RTK_ASSUME_LDS(&sc);
     const uint64_t base = bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
     const uint32_t k = static_cast<uint32_t>(g.k);
