@@ -1699,14 +1699,6 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     };
     auto app_q = [&](uint32_t pos, uint32_t n, char fill) { if (lrc) rtk_app(s, out_q, &oql, q_fw + pos, n); else rtk_app_fill(s, out_q, &oql, fill, n); }; // q_fw.substr(pos, n) | string(n, fill)
     const uint32_t kind = rd->kind;
-    // ONE call site of rtk_correct_region (so that it can be compiled into this function: a call to it saves and restores every
-    // callee-saved vector register, 48 rows of 256 bytes each way): the kinds below set up a call (`st`), the loop makes it and runs the
-    // part of the kind that follows it, which may ask for a second one (gap: the reverse strand)
-    enum { ST_NONE = 0, ST_HEAD, ST_GAP_FW, ST_GAP_BW, ST_TAIL };
-    int st = ST_NONE;
-    const char* a_read = nullptr; const Anchors* a_vs = nullptr; const Anchors* a_vw = nullptr; uint32_t a_is = 0, a_iw = 0; const ResCorr* a_rc = nullptr; ResCorr* a_res = nullptr; const char* a_q = nullptr;
-    uint32_t g_i = 0, g_prev = 0, g_pa = 0, g_pb = 0, g_iw = 0; // gap / tail: solid anchor index, previous position, anchor positions, first weak anchor
-    bool isUncorrected = false;
     if (kind == RTK_RG_WHOLE_MAX || kind == RTK_RG_WHOLE_MIN) { // :165-171
         rtk_app(s, out_s, &osl, s_fw, L); app_q(0, L, kind == RTK_RG_WHOLE_MAX ? q_max : q_min);
     } else if (kind == RTK_RG_HEAD) { // :776-797
@@ -1714,14 +1706,18 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
             const uint32_t i_solid_rev = so.n - 1;
             uint32_t i_weak_rev = we.n;
             i_weak_rev = rtk_an_first_gt(we_r, 0, i_weak_rev, rtk_an_pos(so_r, i_solid_rev)); // the reference steps back while the previous weak anchor lies after the solid one
-            st = ST_HEAD; a_read = s_bw; a_vs = &so_r; a_vw = &we_r; a_is = i_solid_rev; a_iw = i_weak_rev; a_rc = nullptr; a_res = &bw; a_q = q_fw; // q_fw next to s_bw: as the reference writes it (:787, G17)
+            rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_rev, i_weak_rev, nullptr, bw, q_fw); // q_fw next to s_bw: as the reference writes it (:787, G17)
+            if (rtk_failed(s)) return;
+            rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
+            rtk_app(s, out_s, &osl, bw.seq, bw.seq_len >= k ? bw.seq_len - k : bw.seq_len); // substr(0, length - k): wraps to "everything" below k
+            rtk_app(s, out_q, &oql, bw.qual, bw.qual_len >= k ? bw.qual_len - k : bw.qual_len);
         } else { rtk_app(s, out_s, &osl, s_fw, so.pos[0]); app_q(0, so.pos[0], q_min); }
     } else if (kind == RTK_RG_GAP) { // :803-935
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i], pb = so.pos[i + 1];
         const UMap ua = rtk_an_um(so, i), ub = rtk_an_um(so, i + 1);
         const uint32_t i_weak = rtk_an_first_ge(we, 0, we.n, pa); // first weak anchor at or after the left solid anchor (:801)
-        g_i = i; g_prev = prev_pos; g_pa = pa; g_pb = pb; g_iw = i_weak;
+        bool isUncorrected = false;
         bool sameUnitig = (ua.unitig == ub.unitig) && (ua.strand == ub.strand);
         if (lrc && has_min_qual(pa, pb + k)) isUncorrected = true; // :808
         else if (sameUnitig && !(c.g.flags[ua.unitig] & RTK_F_SHORT_CYCLE)) { // same-unitig shortcut (:814-858)
@@ -1742,82 +1738,72 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
                 } else rtk_app_fill(s, out_q, &oql, q_max, (pa - prev_pos) + (sl - k));
             } else isUncorrected = true;
         } else if (pb >= pa + k) {
-            st = ST_GAP_FW; a_read = s_fw; a_vs = &so; a_vw = &we; a_is = i; a_iw = i_weak; a_rc = nullptr; a_res = &fw; a_q = q_fw;
+            rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw, q_fw);
+            if (rtk_failed(s)) return;
+            const uint32_t l_solid = pa - prev_pos;
+            auto emit_minus_k = [&](const char* seq, uint32_t sl, const char* q, uint32_t ql) { // (prefix + x).substr(0, len - k)
+                const uint32_t ts = l_solid + sl, tq = l_solid + ql;
+                const uint32_t ks = ts >= k ? ts - k : ts, kq = tq >= k ? tq - k : tq;
+                rtk_app(s, out_s, &osl, s_fw + prev_pos, ks < l_solid ? ks : l_solid); if (ks > l_solid) rtk_app(s, out_s, &osl, seq, ks - l_solid);
+                app_q(prev_pos, kq < l_solid ? kq : l_solid, q_max); if (kq > l_solid) rtk_app(s, out_q, &oql, q, kq - l_solid);
+            };
+            if (fw.is_corrected) emit_minus_k(fw.seq, fw.seq_len, fw.qual, fw.qual_len);
+            else {
+                const uint32_t i_solid_bw = so.n - i - 2;
+                uint32_t i_weak_bw = we.n - i_weak;
+                i_weak_bw = rtk_an_first_gt(we_r, 0, i_weak_bw, rtk_an_pos(so_r, i_solid_bw));
+{ const uint32_t gl_ = pb - pa; RTK_HIST_ADD(s, 16 + (gl_ < 40 ? 0 : gl_ < 64 ? 1 : gl_ < 128 ? 2 : gl_ < 256 ? 3 : gl_ < 512 ? 4 : gl_ < 1024 ? 5 : 6), 1); }
+                rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_bw, i_weak_bw, &fw, bw, q_bw);
+                if (rtk_failed(s)) return;
+                rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
+                if (bw.is_corrected) {
+                    // l_solid = (|s_bw| - rev_pos(i_solid_bw + 1) - k) - prev_pos == pa - prev_pos
+                    emit_minus_k(bw.seq, bw.seq_len, bw.qual, bw.qual_len);
+                } else {
+                    const uint32_t ref_len = pb - pa + k;
+                    uint32_t& csl = s.loc.len[2]; uint32_t& cql = s.loc.len[3]; csl = 0; cql = 0;
+                    const unsigned long long tc0 = rtk_clock();
+                    const bool ok = rtk_generate_consensus(c, &fw, &bw, s_fw + pa, ref_len, c.o.weak_region_len_factor, s.rbuf[6], &csl, s.rbuf[7], &cql);
+                    s.cnt[7] += rtk_clock() - tc0;
+                    if (rtk_failed(s)) return;
+                    if (!ok || csl == 0) { // raw region, k solid qualities then minimum quality (:898-904)
+                        csl = 0; cql = 0;
+                        rtk_app(s, s.rbuf[6], &csl, s_fw + pa, ref_len);
+                        if (lrc) rtk_app(s, s.rbuf[7], &cql, q_fw + pa, ref_len); // :902
+                        else { rtk_app_fill(s, s.rbuf[7], &cql, q_max, k); rtk_app_fill(s, s.rbuf[7], &cql, q_min, pb - pa); }
+                    }
+                    emit_minus_k(s.rbuf[6], csl, s.rbuf[7], cql);
+                }
+            }
         } else isUncorrected = true;
+        if (isUncorrected) { // :920-932
+            rtk_app(s, out_s, &osl, s_fw + prev_pos, pb - prev_pos);
+            if (lrc) rtk_app(s, out_q, &oql, q_fw + prev_pos, pb - prev_pos); // :924
+            else {
+                rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos);
+                if (pb < pa + k) rtk_app_fill(s, out_q, &oql, q_max, pb - pa);
+                else { rtk_app_fill(s, out_q, &oql, q_max, k); rtk_app_fill(s, out_q, &oql, q_min, pb - pa - k); }
+            }
+        }
     } else if (kind == RTK_RG_TAIL) { // :940-950
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i];
         const uint32_t i_weak = rtk_an_first_ge(we, 0, we.n, pa);
-        g_i = i; g_prev = prev_pos; g_pa = pa;
         if (lrc && has_min_qual(pa, L)) { // :941: nothing to do, the else branch of :951-955
             rtk_app(s, out_s, &osl, s_fw + prev_pos, L - prev_pos); rtk_app(s, out_q, &oql, q_fw + prev_pos, L - prev_pos);
-        } else { st = ST_TAIL; a_read = s_fw; a_vs = &so; a_vw = &we; a_is = i; a_iw = i_weak; a_rc = nullptr; a_res = &fw; a_q = q_fw; }
+        } else {
+            rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw, q_fw);
+            if (rtk_failed(s)) return;
+            const uint32_t l_solid = pa - prev_pos;
+            rtk_app(s, out_s, &osl, s_fw + prev_pos, l_solid); rtk_app(s, out_s, &osl, fw.seq, fw.seq_len);
+            app_q(prev_pos, l_solid, q_max); rtk_app(s, out_q, &oql, fw.qual, fw.qual_len);
+        }
     } else { // RTK_RG_TAIL_COPY (:951-955)
         const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
         const uint32_t pa = so.pos[i];
         rtk_app(s, out_s, &osl, s_fw + prev_pos, L - prev_pos);
         if (lrc) rtk_app(s, out_q, &oql, q_fw + prev_pos, L - prev_pos);
         else { rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos + k); rtk_app_fill(s, out_q, &oql, q_min, L - pa - k); }
-    }
-    while (st != ST_NONE) {
-        rtk_correct_region(c, a_read, L, *a_vs, *a_vw, a_is, a_iw, a_rc, *a_res, a_q);
-        if (rtk_failed(s)) return;
-        const int was = st; st = ST_NONE;
-        const uint32_t prev_pos = g_prev, pa = g_pa, pb = g_pb;
-        const uint32_t l_solid = pa - prev_pos;
-        auto emit_minus_k = [&](const char* seq, uint32_t sl, const char* q, uint32_t ql) { // (prefix + x).substr(0, len - k)
-            const uint32_t ts = l_solid + sl, tq = l_solid + ql;
-            const uint32_t ks = ts >= k ? ts - k : ts, kq = tq >= k ? tq - k : tq;
-            rtk_app(s, out_s, &osl, s_fw + prev_pos, ks < l_solid ? ks : l_solid); if (ks > l_solid) rtk_app(s, out_s, &osl, seq, ks - l_solid);
-            app_q(prev_pos, kq < l_solid ? kq : l_solid, q_max); if (kq > l_solid) rtk_app(s, out_q, &oql, q, kq - l_solid);
-        };
-        if (was == ST_HEAD) {
-            rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
-            rtk_app(s, out_s, &osl, bw.seq, bw.seq_len >= k ? bw.seq_len - k : bw.seq_len); // substr(0, length - k): wraps to "everything" below k
-            rtk_app(s, out_q, &oql, bw.qual, bw.qual_len >= k ? bw.qual_len - k : bw.qual_len);
-        } else if (was == ST_GAP_FW) {
-            if (fw.is_corrected) emit_minus_k(fw.seq, fw.seq_len, fw.qual, fw.qual_len);
-            else {
-                const uint32_t i_solid_bw = so.n - g_i - 2;
-                uint32_t i_weak_bw = we.n - g_iw;
-                i_weak_bw = rtk_an_first_gt(we_r, 0, i_weak_bw, rtk_an_pos(so_r, i_solid_bw));
-                { const uint32_t gl_ = pb - pa; RTK_HIST_ADD(s, 16 + (gl_ < 40 ? 0 : gl_ < 64 ? 1 : gl_ < 128 ? 2 : gl_ < 256 ? 3 : gl_ < 512 ? 4 : gl_ < 1024 ? 5 : 6), 1); }
-                st = ST_GAP_BW; a_read = s_bw; a_vs = &so_r; a_vw = &we_r; a_is = i_solid_bw; a_iw = i_weak_bw; a_rc = &fw; a_res = &bw; a_q = q_bw;
-            }
-        } else if (was == ST_GAP_BW) {
-            rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
-            if (bw.is_corrected) {
-                // l_solid = (|s_bw| - rev_pos(i_solid_bw + 1) - k) - prev_pos == pa - prev_pos
-                emit_minus_k(bw.seq, bw.seq_len, bw.qual, bw.qual_len);
-            } else {
-                const uint32_t ref_len = pb - pa + k;
-                uint32_t& csl = s.loc.len[2]; uint32_t& cql = s.loc.len[3]; csl = 0; cql = 0;
-                const unsigned long long tc0 = rtk_clock();
-                const bool ok = rtk_generate_consensus(c, &fw, &bw, s_fw + pa, ref_len, c.o.weak_region_len_factor, s.rbuf[6], &csl, s.rbuf[7], &cql);
-                s.cnt[7] += rtk_clock() - tc0;
-                if (rtk_failed(s)) return;
-                if (!ok || csl == 0) { // raw region, k solid qualities then minimum quality (:898-904)
-                    csl = 0; cql = 0;
-                    rtk_app(s, s.rbuf[6], &csl, s_fw + pa, ref_len);
-                    if (lrc) rtk_app(s, s.rbuf[7], &cql, q_fw + pa, ref_len); // :902
-                    else { rtk_app_fill(s, s.rbuf[7], &cql, q_max, k); rtk_app_fill(s, s.rbuf[7], &cql, q_min, pb - pa); }
-                }
-                emit_minus_k(s.rbuf[6], csl, s.rbuf[7], cql);
-            }
-        } else { // ST_TAIL
-            rtk_app(s, out_s, &osl, s_fw + prev_pos, l_solid); rtk_app(s, out_s, &osl, fw.seq, fw.seq_len);
-            app_q(prev_pos, l_solid, q_max); rtk_app(s, out_q, &oql, fw.qual, fw.qual_len);
-        }
-    }
-    if (isUncorrected) { // gap, :920-932
-        const uint32_t prev_pos = g_prev, pa = g_pa, pb = g_pb;
-        rtk_app(s, out_s, &osl, s_fw + prev_pos, pb - prev_pos);
-        if (lrc) rtk_app(s, out_q, &oql, q_fw + prev_pos, pb - prev_pos); // :924
-        else {
-            rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos);
-            if (pb < pa + k) rtk_app_fill(s, out_q, &oql, q_max, pb - pa);
-            else { rtk_app_fill(s, out_q, &oql, q_max, k); rtk_app_fill(s, out_q, &oql, q_min, pb - pa - k); }
-        }
     }
     if (rtk_failed(s)) return;
     rtk_emit_segment(c, rd, out_s, osl, out_q, oql);
