@@ -582,16 +582,22 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
 // workgroup-scope fences (no cache maintenance) order the carries in memory against the progress counters in LDS. The program wave (wave 0) publishes the pass in an LDS mailbox, the
 // helper waves of the workgroup pick it up, everybody takes the blocks b = wave, wave + NW, ... in ascending order (a block only ever
 // waits for a lower-numbered one, and those are started first: no cycle), wave 0 continues when all helpers have reported.
-#define RTK_COOP_MAXB 512
-struct RtkCoop { RtkCoopJob job[2]; int n_jobs, seq, n_done, exit_flag, n_waves; int progress[RTK_COOP_MAXB]; }; // two passes at a time: the two halves of a Hirschberg split are independent
+#define RTK_COOP_MAXB 512 // row blocks of all the passes of a round
+#define RTK_COOP_MAXJ 64  // passes of a round (two per Hirschberg sub-problem)
+struct RtkCoop { RtkCoopJob job[RTK_COOP_MAXJ]; int first[RTK_COOP_MAXJ + 1]; int node[RTK_COOP_MAXJ / 2][8]; int n_jobs, n_items, seq, n_done, exit_flag, n_waves; int progress[RTK_COOP_MAXB]; };
 __device__ __forceinline__ RtkCoop* rtk_coop() { __shared__ RtkCoop st; return &st; }
 
 __device__ __forceinline__ void rtk_myers_coop_run(RtkCoop* st, int wave) {
-    // the passes of a job have the same query length, hence the same number B of row blocks; block index i < B: pass 0, else pass 1.
-    // Every wave takes its indices in ascending order and a block only waits for index i - 1 of its own pass: the lowest unfinished
+    // A round is a list of passes; pass j owns the row blocks first[j] .. first[j + 1) of the round's block list. Every wave takes its
+    // indices in ascending order and a block only waits for index i - 1 (the block above it in its own pass): the lowest unfinished
     // index can always run, so nobody waits for ever.
-    const int W = (rtk_u(st->job[0].m) + 63) >> 6, B = (W + 63) >> 6, nj = rtk_coop_ld(&st->n_jobs), nwv = rtk_coop_ld(&st->n_waves);
-    for (int i = wave; i < nj * B; i += nwv) { const int ji = i >= B ? 1 : 0; rtk_myers_block(st->job[ji], i - ji * B, st->progress + ji * B); }
+    const int nit = rtk_coop_ld(&st->n_items), nwv = rtk_coop_ld(&st->n_waves);
+    int j = 0;
+    for (int i = wave; i < nit; i += nwv) {
+        while (i >= rtk_coop_ld(&st->first[j + 1])) ++j;
+        const int f = rtk_coop_ld(&st->first[j]);
+        rtk_myers_block(st->job[j], i - f, st->progress + f);
+    }
 }
 
 // helper waves of the workgroup: wait for passes until the program wave says it is done
@@ -622,7 +628,7 @@ __device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, cons
         j.fin_pv = fin_pv; j.fin_mv = fin_mv; j.carry = rtk_u(sc.carry); j.colscore = rtk_u(sc.colscore);
         st->job[0] = j;
         if (q2) { j.qp = q2->p; j.tp = t2->p; j.m = q2->n; j.n = t2->n; j.qrev = q2->rev; j.trev = t2->rev; j.fin_pv = fin_pv2; j.fin_mv = fin_mv2; j.carry += t.n; j.colscore += t.n; st->job[1] = j; }
-        st->n_jobs = nj;
+        st->n_jobs = nj; st->n_items = nj * B; st->first[0] = 0; st->first[1] = B; st->first[2] = 2 * B;
     }
     for (int i = rtk_lane(); i < nj * B; i += RTK_WAVE) st->progress[i] = 0;
     if (rtk_lane() == 0) st->n_done = 0;
@@ -632,6 +638,18 @@ __device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, cons
     while (rtk_coop_ld(&st->n_done) < nwv - 1) __builtin_amdgcn_s_sleep(8);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return true;
+}
+
+// program wave: the passes in st->job[0 .. n_jobs) with their block ranges st->first[] are ready: run them with the helpers
+__device__ __forceinline__ void rtk_myers_round_coop(RtkCoop* st, int n_items) {
+    const int nwv = rtk_coop_ld(&st->n_waves);
+    for (int i = rtk_lane(); i < n_items; i += RTK_WAVE) st->progress[i] = 0;
+    if (rtk_lane() == 0) st->n_done = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    rtk_coop_st(&st->seq, rtk_coop_ld(&st->seq) + 1);
+    rtk_myers_coop_run(st, 0);
+    while (rtk_coop_ld(&st->n_done) < nwv - 1) __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 #endif
 
@@ -998,6 +1016,149 @@ RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, i
     rtk_sync();
 }
 
+#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
+// The same alignment with the sub-problems of a Hirschberg level side by side (multi-wave workgroups only). The depth-first driver
+// below runs the two half passes of ONE sub-problem at a time: a level of the recursion costs n/2 column steps whatever its number of
+// sub-problems, and below the first levels most waves of the workgroup have nothing to do. Here the tree is built level by level:
+// every sub-problem of a level that still needs a split contributes its two passes to a round (rtk_myers_round_coop: up to 64 passes /
+// 512 row blocks on the waves of the workgroup), then the program wave extracts the split columns and finds the split rows exactly as
+// the depth-first driver does. The list of a level keeps the sub-problems in read order (a finished one stays where it is, a split
+// one is replaced by its two halves), so the last list is the sequence of leaf problems whose tracebacks, in order, are the alignment.
+// Lists: behind the final delta vectors in the traceback table's memory while the tree is built, in rowL for the leaf tracebacks
+// (which need the table). Returns false when the problem does not fit (nothing emitted: the caller walks depth first).
+__device__ __forceinline__ bool rtk_hb_is_leaf(int qm, int tn) { return qm == 0 || tn == 0 || (2LL * 8 + 4) * ((qm + 63) >> 6) * tn + 8LL * tn < 1024 * 1024; }
+__device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, const char* q, int m, const char* t, int n, int best, bool iupac, uint32_t* n_moves, int* best_out) {
+    RtkCoop* st = rtk_coop();
+    if (rtk_coop_ld(&st->n_waves) < 2 || rtk_hb_is_leaf(m, n)) return false;
+    const int lane = rtk_lane();
+    const long long W0 = (m + 63) >> 6;
+    uint64_t* const tb = rtk_ld(&sc.tb);
+    const uint64_t tbw = rtk_ld(&sc.tb_cap_words), fin_words = 4ull * (static_cast<uint64_t>(W0) + RTK_COOP_MAXJ);
+    if (tbw < fin_words + 64) return false;
+    uint64_t cap = (tbw - fin_words) / 6; // two lists of `cap` nodes, 6 ints each, in the words behind the final vectors
+    if (cap > rtk_ld(&sc.r_cap) / 6u) cap = rtk_ld(&sc.r_cap) / 6u;
+    if (cap < 8) return false;
+    int32_t* cur = reinterpret_cast<int32_t*>(tb + fin_words); int32_t* nxt = cur + 6 * cap;
+    int8_t* const carry = rtk_ld(&sc.carry); int32_t* const colscore = rtk_ld(&sc.colscore); int32_t* const rowL = rtk_ld(&sc.rowL); int32_t* const rowR = rtk_ld(&sc.rowR);
+    MyersScratch& prof = const_cast<MyersScratch&>(sc); const unsigned long long t_all0 = rtk_clock();
+    if (lane == 0) { cur[0] = 0; cur[1] = m; cur[2] = 0; cur[3] = n; cur[4] = best; cur[5] = 0; }
+    RTK_WG_SYNC();
+    int n_cur = 1;
+    for (;;) {
+        // ---- slots of the next list: a leaf keeps one, a sub-problem that is split gets two (its halves, in order) ----
+        int n_next = 0, n_split = 0;
+        for (int c0 = 0; c0 < n_cur; c0 += RTK_WAVE) {
+            const int i = c0 + lane; const bool valid = i < n_cur;
+            int e[5] = {0, 0, 0, 0, 0};
+            if (valid) for (int k = 0; k < 5; ++k) e[k] = cur[6 * i + k];
+            const bool leaf = valid && rtk_hb_is_leaf(e[1], e[3]);
+            int total; const int excl = rtk_wave_excl_scan(valid ? (leaf ? 1 : 2) : 0, &total);
+            const int pos = n_next + excl;
+            if (valid && static_cast<uint64_t>(pos) + 2 <= cap) { if (leaf) { for (int k = 0; k < 5; ++k) nxt[6 * pos + k] = e[k]; nxt[6 * pos + 5] = 0; } else cur[6 * i + 5] = pos; }
+            n_next += rtk_u(total); n_split += rtk_popc(rtk_ballot(valid && !leaf));
+        }
+        if (static_cast<uint64_t>(n_next) > cap) return false; // (nothing emitted yet)
+        RTK_WG_SYNC();
+        if (n_split == 0) break;
+        // ---- the passes of the sub-problems that are split, a round at a time ----
+        int rn = 0, items = 0; uint64_t fin_off = 0; bool bad = false;
+        auto run_round = [&]() {
+            if (lane == 0) { st->n_jobs = 2 * rn; st->n_items = items; st->first[2 * rn] = items; }
+            const unsigned long long t_p0 = rtk_clock();
+            rtk_myers_round_coop(st, items);
+            const unsigned long long t_p1 = rtk_clock(); prof.hb_pass += t_p1 - t_p0;
+            for (int x = 0; x < rn && !bad; ++x) {
+                const int q0 = rtk_coop_ld(&st->node[x][0]), qm = rtk_coop_ld(&st->node[x][1]), t0 = rtk_coop_ld(&st->node[x][2]), tn = rtk_coop_ld(&st->node[x][3]);
+                const int bs_in = rtk_coop_ld(&st->node[x][4]), slot = rtk_coop_ld(&st->node[x][5]), foff = rtk_coop_ld(&st->node[x][6]);
+                const int Wn = (qm + 63) >> 6, lh = tn / 2, rh = tn - lh;
+                uint64_t* const fin = tb + foff;
+                int32_t* const rl = rowL + q0; int32_t* const rr = rowR + q0;
+                rtk_myers_column(fin, fin + Wn, qm, lh, rl);
+                rtk_myers_column(fin + 2 * Wn, fin + 3 * Wn, qm, rh, rr);
+                RTK_WG_SYNC();
+                int bs = bs_in;
+                if (bs < 0) { // only the whole problem: the optimum = the smallest left + right sum over every split point
+                    int mn = 0x7fffffff;
+                    for (int b0 = 0; b0 + 1 < qm; b0 += RTK_WAVE) { const int qi = b0 + lane; if (qi + 1 < qm) { const int v = rl[qi] + rr[qm - 2 - qi]; mn = v < mn ? v : mn; } }
+                    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o, 64); mn = v < mn ? v : mn; }
+                    mn = rtk_u(mn);
+                    const int e0 = lh + rtk_ld(rr + (qm - 1)), e1 = rtk_ld(rl + (qm - 1)) + rh;
+                    mn = e0 < mn ? e0 : mn; mn = e1 < mn ? e1 : mn;
+                    bs = mn;
+                    if (best_out) *best_out = mn;
+                }
+                int split = -2;
+                for (int b0 = 0; b0 + 1 < qm && split == -2; b0 += RTK_WAVE) {
+                    const int qi = b0 + lane;
+                    const bool ok = (qi + 1 < qm) && (rl[qi] + rr[qm - 2 - qi] == bs);
+                    const uint64_t bal = rtk_ballot(ok);
+                    if (bal) split = b0 + rtk_ffs(bal) - 1;
+                }
+                int ls, rs;
+                if (split >= 0) { ls = rtk_ld(rl + split); rs = rtk_ld(rr + (qm - 2 - split)); }
+                else if (lh + rtk_ld(rr + (qm - 1)) == bs) { split = -1; ls = lh; rs = rtk_ld(rr + (qm - 1)); }
+                else if (rtk_ld(rl + (qm - 1)) + rh == bs) { split = qm - 1; ls = rtk_ld(rl + (qm - 1)); rs = rh; }
+                else { *sc.overflow = 2; bad = true; break; } // inconsistent optimum: cannot happen for a correct distance
+                const int ul = split + 1;
+                if (lane == 0) {
+                    int32_t* a = nxt + 6 * slot;
+                    a[0] = q0; a[1] = ul; a[2] = t0; a[3] = lh; a[4] = ls; a[5] = 0;
+                    a[6] = q0 + ul; a[7] = qm - ul; a[8] = t0 + lh; a[9] = rh; a[10] = rs; a[11] = 0;
+                }
+            }
+            prof.hb_split += rtk_clock() - t_p1;
+            RTK_WG_SYNC();
+            rn = 0; items = 0; fin_off = 0;
+        };
+        for (int c0 = 0; c0 < n_cur && !bad; c0 += RTK_WAVE) {
+            const int i = c0 + lane; const bool valid = i < n_cur;
+            int e[6] = {0, 0, 0, 0, 0, 0};
+            if (valid) for (int k = 0; k < 6; ++k) e[k] = cur[6 * i + k];
+            uint64_t todo = rtk_ballot(valid && !rtk_hb_is_leaf(e[1], e[3]));
+            while (todo && !bad) {
+                const int l = rtk_ffs(todo) - 1; todo &= todo - 1ull;
+                const int q0 = rtk_shfl(e[0], l), qm = rtk_shfl(e[1], l), t0 = rtk_shfl(e[2], l), tn = rtk_shfl(e[3], l), bs = rtk_shfl(e[4], l), slot = rtk_shfl(e[5], l);
+                const int Wn = (qm + 63) >> 6, Bn = (Wn + 63) >> 6, lh = tn / 2, rh = tn - lh;
+                if (lh == 0 || 2 * Bn > RTK_COOP_MAXB) { *sc.overflow = 1; bad = true; break; }
+                if (rn == RTK_COOP_MAXJ / 2 || items + 2 * Bn > RTK_COOP_MAXB) run_round();
+                if (bad) break;
+                if (lane == 0) {
+                    uint64_t* const fin = tb + fin_off;
+                    RtkCoopJob j; j.qp = q + q0; j.tp = t + t0; j.m = qm; j.n = lh; j.qrev = 0; j.trev = 0; j.top_h = 1; j.iupac = iupac ? 1 : 0;
+                    j.fin_pv = fin; j.fin_mv = fin + Wn; j.carry = carry + t0; j.colscore = colscore + t0;
+                    st->job[2 * rn] = j;
+                    j.tp = t + t0 + lh; j.n = rh; j.qrev = 1; j.trev = 1; j.fin_pv = fin + 2 * Wn; j.fin_mv = fin + 3 * Wn; j.carry = carry + t0 + lh; j.colscore = colscore + t0 + lh;
+                    st->job[2 * rn + 1] = j;
+                    st->first[2 * rn] = items; st->first[2 * rn + 1] = items + Bn;
+                    int* nd = st->node[rn]; nd[0] = q0; nd[1] = qm; nd[2] = t0; nd[3] = tn; nd[4] = bs; nd[5] = slot; nd[6] = static_cast<int>(fin_off);
+                }
+                fin_off += 4ull * static_cast<uint64_t>(Wn); items += 2 * Bn; ++rn;
+            }
+        }
+        if (rn && !bad) run_round();
+        if (bad) { prof.hb_total += rtk_clock() - t_all0; return true; } // the overflow flag is set: the caller's caller retries or gives up, as with the depth-first driver
+        { int32_t* x = cur; cur = nxt; nxt = x; } n_cur = n_next;
+    }
+    // ---- leaf problems, in read order ----
+    for (int i = lane; i < 6 * n_cur; i += RTK_WAVE) rowL[i] = cur[i];
+    RTK_WG_SYNC();
+    for (int x = 0; x < n_cur; ++x) {
+        const int q0 = rtk_ld(rowL + 6 * x), qm = rtk_ld(rowL + 6 * x + 1), t0 = rtk_ld(rowL + 6 * x + 2), tn = rtk_ld(rowL + 6 * x + 3);
+        if (qm == 0 || tn == 0) { // edlib.cpp:1171-1178
+            rtk_wfill(sc.moves + *n_moves, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn));
+            *n_moves += static_cast<uint32_t>(qm + tn);
+            continue;
+        }
+        const long long W = (qm + 63) >> 6;
+        if (static_cast<uint64_t>(4 * W * tn) > tbw) { *sc.overflow = 1; break; }
+        { const unsigned long long t0_ = rtk_clock(); rtk_myers_traceback(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, n_moves); prof.hb_leaf += rtk_clock() - t0_; }
+        if (rtk_ld(rtk_ld(&sc.overflow)) != 0) break;
+    }
+    prof.hb_total += rtk_clock() - t_all0;
+    return true;
+}
+#endif
+
 // obtainAlignment (edlib.cpp:1164-1216) with the Hirschberg split of edlib.cpp:1234-1399 restated canonically:
 // target halved at n/2; the FIRST query row (ascending) whose left + right scores add up to the optimum, then the
 // row -1 boundary, then the last row. Iterative (explicit stack), emits moves in order into sc.moves.
@@ -1011,6 +1172,9 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
     *n_moves = 0;
     { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; }
     if (static_cast<uint32_t>(m + n) > sc.mv_cap || static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap || static_cast<uint32_t>(m) > sc.r_cap) { *sc.overflow = 1; return; }
+#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
+    if (rtk_myers_alignment_bfs(sc, q, m, t, n, best, iupac, n_moves, best_out)) return; // level by level on the waves of the workgroup
+#endif
     int32_t* st = sc.hstack;
     int sp = 0;
     MyersScratch& prof = const_cast<MyersScratch&>(sc); const unsigned long long t_all0 = rtk_clock();
