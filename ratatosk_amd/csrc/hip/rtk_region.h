@@ -1836,14 +1836,22 @@ RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const Regi
     if (whole) { put((L > k && ns != 0 && ns == L - k + 1) ? RTK_RG_WHOLE_MAX : RTK_RG_WHOLE_MIN, 0, 0); rtk_sync(); return; }
     if (sp[0] != 0) put(RTK_RG_HEAD, 0, 0);
     uint32_t prev_pos = sp[0];
-    for (uint32_t c0 = 0; c0 + 1 < ns; c0 += 64) {
-        uint64_t bal;
-#ifdef RTK_SIM
-        bal = 0; for (uint32_t j = 0; j < 64 && c0 + j + 1 < ns; ++j) if (sp[c0 + j] != sp[c0 + j + 1] - 1) bal |= 1ull << j;
-#else
-        { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); bal = rtk_ballot(i + 1 < ns && sp[i] != sp[i + 1] - 1); }
-#endif
-        while (bal) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u; bal &= bal - 1ull; put(RTK_RG_GAP, i, prev_pos); prev_pos = sp[i + 1]; }
+    // the gaps between runs of consecutive solid anchors, 64 anchors at a time: every lane that sees a gap writes its descriptor. The
+    // segment before it stopped at the anchor behind the PREVIOUS gap (prev_pos = sp[previous gap + 1], sp[0] for the first one)
+    for (uint32_t c0 = 0; c0 + 1 < ns; c0 += RTK_WAVE) {
+        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
+        const bool gap = i + 1 < ns && sp[i] != sp[i + 1] - 1;
+        const uint64_t bal = rtk_ballot(gap);
+        if (bal == 0ull) continue;
+        const uint64_t below = bal & ((1ull << rtk_lane()) - 1ull); // gaps of this chunk in front of this lane's
+        if (gap) {
+            uint32_t pp = prev_pos;
+            if (below) pp = sp[c0 + static_cast<uint32_t>(63 - __builtin_clzll(below)) + 1];
+            RegionDesc d; d.read = r; d.kind = RTK_RG_GAP; d.i_solid = i; d.prev_pos = pp; d.seg_off = 0; d.seq_len = 0; d.qual_len = 0; d.status = 0; d.pad = 0;
+            out[w + static_cast<uint32_t>(rtk_popc(below))] = d;
+        }
+        w += static_cast<uint32_t>(rtk_popc(bal));
+        prev_pos = rtk_u(sp[c0 + static_cast<uint32_t>(63 - __builtin_clzll(bal)) + 1]);
     }
     put(sp[ns - 1] < L - k ? RTK_RG_TAIL : RTK_RG_TAIL_COPY, ns - 1, prev_pos);
     rtk_sync();
@@ -1852,17 +1860,29 @@ RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const Regi
 // ------------------------------------------------------------------------------------------------ stitch (one wave per read)
 RTK_FN void rtk_stitch_read(const BatchView& bv, const RegionBatch& rb, uint32_t r) {
     const RegionDesc* rg = rb.regions + rb.r_first[r]; const uint32_t n = rb.r_count[r];
+    // lengths of the read's segments, 64 at a time (the loads of a chunk are independent: one round trip per chunk, not per segment)
     uint64_t ts = 0, tq = 0;
-    for (uint32_t i = 0; i < n; ++i) { ts += rg[i].seq_len; tq += rg[i].qual_len; }
+    for (uint32_t c0 = 0; c0 < n; c0 += RTK_WAVE) {
+        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
+        int a = 0, b = 0; if (i < n) { a = static_cast<int>(rg[i].seq_len); b = static_cast<int>(rg[i].qual_len); }
+        int ta, tb; (void)rtk_wave_excl_scan(a, &ta); (void)rtk_wave_excl_scan(b, &tb);
+        ts += static_cast<uint64_t>(rtk_u(ta)); tq += static_cast<uint64_t>(rtk_u(tb));
+    }
     unsigned long long off = 0;
     if (rtk_lane() == 0) off = rtk_atomic_add(rb.out_top, static_cast<unsigned long long>(ts + tq));
     off = rtk_shfl(off, 0);
     rb.out_off[r] = off; rb.out_seq_len[r] = static_cast<uint32_t>(ts); rb.out_qual_len[r] = static_cast<uint32_t>(tq);
     if (off + ts + tq > rb.out_cap) return;
     uint64_t ws = off, wq = off + ts;
-    for (uint32_t i = 0; i < n; ++i) {
-        rtk_wcopy(rb.out_pool + ws, rb.seg_pool + rg[i].seg_off, rg[i].seq_len); ws += rg[i].seq_len;
-        rtk_wcopy(rb.out_pool + wq, rb.seg_pool + rg[i].seg_off + rg[i].seq_len, rg[i].qual_len); wq += rg[i].qual_len;
+    for (uint32_t c0 = 0; c0 < n; c0 += RTK_WAVE) { // descriptors of a chunk in registers, then its copies back to back
+        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
+        uint32_t sl = 0, ql = 0; uint64_t so = 0; if (i < n) { sl = rg[i].seq_len; ql = rg[i].qual_len; so = rg[i].seg_off; }
+        const uint32_t m = (n - c0) < static_cast<uint32_t>(RTK_WAVE) ? (n - c0) : static_cast<uint32_t>(RTK_WAVE);
+        for (uint32_t j = 0; j < m; ++j) {
+            const uint32_t jsl = rtk_shfl(sl, static_cast<int>(j)), jql = rtk_shfl(ql, static_cast<int>(j)); const uint64_t jso = rtk_shfl(so, static_cast<int>(j));
+            rtk_wcopy(rb.out_pool + ws, rb.seg_pool + jso, jsl); ws += jsl;
+            rtk_wcopy(rb.out_pool + wq, rb.seg_pool + jso + jsl, jql); wq += jql;
+        }
     }
     (void)bv;
 }
