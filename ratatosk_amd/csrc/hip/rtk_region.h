@@ -1331,9 +1331,11 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
     const uint32_t k = static_cast<uint32_t>(c.k);
     const GraphView& g = c.g;
     const bool has_end_pt = (i_s + 1) < v_s.n;
-    uint32_t p1 = rtk_an_pos(v_s, i_s); UMap um1 = rtk_an_um(v_s, i_s);
-    const uint32_t p2 = has_end_pt ? rtk_an_pos(v_s, i_s + 1) : (s_len - k);
-    const UMap um2 = has_end_pt ? rtk_an_um(v_s, i_s + 1) : rtk_um_empty();
+    // (values that live across the calls below are made scalar on purpose: a wave-uniform value in a vector register costs a 256-byte row
+    // every time it is saved around a call, in a scalar register it is one lane of a spill register)
+    uint32_t p1 = rtk_u(rtk_an_pos(v_s, i_s)); UMap um1 = rtk_u(rtk_an_um(v_s, i_s));
+    const uint32_t p2 = rtk_u(has_end_pt ? rtk_an_pos(v_s, i_s + 1) : (s_len - k));
+    const UMap um2 = rtk_u(has_end_pt ? rtk_an_um(v_s, i_s + 1) : rtk_um_empty());
     const uint32_t first_pos = p1;
     uint32_t len_weak_region = p2 - p1 + k;
     const uint64_t u_min_start = static_cast<uint64_t>(p1) - static_cast<uint64_t>(c.o.insert_sz); // wraps below insert_sz (G1)
@@ -1351,8 +1353,8 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
         if (v_w_sz) {
             const uint32_t pos_end = has_end_pt ? p2 : s_len;
             const uint32_t x = i_w - (((i_w != 0) && (i_w >= v_w_sz)) ? 1u : 0u);
-            lw_lo = rtk_an_first_ge(v_w, x, v_w_sz, first_pos);
-            lw_hi = rtk_an_first_ge(v_w, lw_lo, v_w_sz, pos_end);
+            lw_lo = rtk_u(rtk_an_first_ge(v_w, x, v_w_sz, first_pos));
+            lw_hi = rtk_u(rtk_an_first_ge(v_w, lw_lo, v_w_sz, pos_end));
         }
     }
     uint32_t n_all = 0;
@@ -1396,10 +1398,10 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
         }
         if (sl.n >= cap / 2 || sr.n >= cap / 2 || sm.n >= cap / 2) { rtk_fail_ovf(s, 8); return; }
         s.fine[7] += rtk_clock() - t_side0;
-        { const unsigned long long t0 = rtk_clock(); n_all = rtk_choose_colors(c, sl, sr, sm); s.cnt[5] += rtk_clock() - t0; }
+        { const unsigned long long t0 = rtk_clock(); n_all = rtk_u(rtk_choose_colors(c, sl, sr, sm)); s.cnt[5] += rtk_clock() - t0; }
         if (rtk_failed(s)) return;
         // keep all_pids for the reverse-complement call (rc = &fw): set[0] is preserved by everything below
-    } else n_all = rc->n_all;
+    } else n_all = rtk_u(rc->n_all);
     res.n_all = n_all;
     const uint32_t* all_pids = s.set[0];
     // ---- paths ----
@@ -1417,7 +1419,7 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
     bool first_call = true, found_first = false, do_call = n_all >= c.o.min_cov_vertices;
     uint32_t i_w_s = 0;
     for (;;) {
-        if (do_call) { const unsigned long long t0 = rtk_clock(); complete = rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, first_call ? 0u : i_w_s, &n_partial); s.cnt[6] += rtk_clock() - t0; }
+        if (do_call) { const unsigned long long t0 = rtk_clock(); complete = rtk_u(rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, first_call ? 0u : i_w_s, &n_partial)); n_partial = rtk_u(n_partial); s.cnt[6] += rtk_clock() - t0; }
         if (rtk_failed(s)) return;
         if (first_call && complete != ~0ull) found_first = true;
         first_call = false;
@@ -1431,8 +1433,8 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
                 while (i_w_s < nlw && rtk_an_pos(lvw, lw_lo + i_w_s) < next_pos) ++i_w_s;
                 if (i_w_s >= nlw || static_cast<uint64_t>(rtk_an_pos(lvw, lw_lo + i_w_s)) >= static_cast<uint64_t>(p2) - k || (rtk_an_pos(lvw, lw_lo + i_w_s) - p1) >= max_len_weak_anchors) break;
             }
-            const uint64_t hb = s.list[5][aid];
-            const uint32_t wpos = rtk_an_pos(lvw, lw_lo + i_w_s);
+            const uint64_t hb = rtk_u(s.list[5][aid]);
+            const uint32_t wpos = rtk_u(rtk_an_pos(lvw, lw_lo + i_w_s));
             const uint32_t pl = rtk_rec_to_string(c, hb, s.str[0]); if (pl == 0xFFFFFFFFu) break;
             n_amb = rtk_amb_collect(c, hb, sl_, n_amb);
             rtk_app(s, s_corr, &sl_, s.str[0], pl);
@@ -1441,7 +1443,7 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
             if (lrc) rtk_app(s, q_corr, &ql_, q_read + p1 + aend + 1, clamp_len(p1 + static_cast<uint32_t>(aend) + 1, wpos - p1 - static_cast<uint32_t>(aend) - 1)); // :642
             else rtk_app_fill(s, q_corr, &ql_, q_min, wpos - p1 - static_cast<uint32_t>(aend) - 1);
             rtk_bm_add_range(res.bm, p1 - first_pos, p1 + static_cast<uint32_t>(aend) + 1 - first_pos);
-            p1 = wpos; um1 = rtk_an_um(lvw, lw_lo + i_w_s);
+            p1 = wpos; um1 = rtk_u(rtk_an_um(lvw, lw_lo + i_w_s));
             len_weak_region = p2 - p1 + k;
             s.top[0] = 0; n_partial = 0; // paths of the previous attempt are dead
             do_call = true;
@@ -1670,9 +1672,9 @@ RTK_FN void rtk_emit_segment(const RCtx& c_, RegionDesc* rd_, const char* sq_, u
 RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     const RCtx& c = *rtk_u(&c_); RegionDesc* rd = rtk_u(rd_);
     RegionScratch& s = rtk_hdr(c);
-    const uint32_t r = rd->read, k = static_cast<uint32_t>(c.k);
-    const uint64_t base = c.bv.roff[r];
-    const uint32_t L = static_cast<uint32_t>(c.bv.roff[r + 1] - base);
+    const uint32_t r = rtk_u(rd->read), k = static_cast<uint32_t>(c.k);
+    const uint64_t base = rtk_u(c.bv.roff[r]);
+    const uint32_t L = rtk_u(static_cast<uint32_t>(c.bv.roff[r + 1] - base));
     const char* s_fw = c.bv.seq + base; const char* s_bw = c.rb.seq_rc + base;
     const char q_min = rtk_get_qual(0.0, 0, static_cast<uint64_t>(c.o.max_qual)), q_max = rtk_get_qual(1.0, 0, static_cast<uint64_t>(c.o.max_qual));
     char* out_s = s.rbuf[4]; char* out_q = s.rbuf[5]; uint32_t& osl = s.loc.len[0]; uint32_t& oql = s.loc.len[1]; osl = 0; oql = 0;
@@ -1698,7 +1700,7 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
         return true;
     };
     auto app_q = [&](uint32_t pos, uint32_t n, char fill) { if (lrc) rtk_app(s, out_q, &oql, q_fw + pos, n); else rtk_app_fill(s, out_q, &oql, fill, n); }; // q_fw.substr(pos, n) | string(n, fill)
-    const uint32_t kind = rd->kind;
+    const uint32_t kind = rtk_u(rd->kind);
     if (kind == RTK_RG_WHOLE_MAX || kind == RTK_RG_WHOLE_MIN) { // :165-171
         rtk_app(s, out_s, &osl, s_fw, L); app_q(0, L, kind == RTK_RG_WHOLE_MAX ? q_max : q_min);
     } else if (kind == RTK_RG_HEAD) { // :776-797
@@ -1713,10 +1715,10 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
             rtk_app(s, out_q, &oql, bw.qual, bw.qual_len >= k ? bw.qual_len - k : bw.qual_len);
         } else { rtk_app(s, out_s, &osl, s_fw, so.pos[0]); app_q(0, so.pos[0], q_min); }
     } else if (kind == RTK_RG_GAP) { // :803-935
-        const uint32_t i = rd->i_solid, prev_pos = rd->prev_pos;
-        const uint32_t pa = so.pos[i], pb = so.pos[i + 1];
-        const UMap ua = rtk_an_um(so, i), ub = rtk_an_um(so, i + 1);
-        const uint32_t i_weak = rtk_an_first_ge(we, 0, we.n, pa); // first weak anchor at or after the left solid anchor (:801)
+        const uint32_t i = rtk_u(rd->i_solid), prev_pos = rtk_u(rd->prev_pos);
+        const uint32_t pa = rtk_u(so.pos[i]), pb = rtk_u(so.pos[i + 1]);
+        const UMap ua = rtk_u(rtk_an_um(so, i)), ub = rtk_u(rtk_an_um(so, i + 1));
+        const uint32_t i_weak = rtk_u(rtk_an_first_ge(we, 0, we.n, pa)); // first weak anchor at or after the left solid anchor (:801)
         bool isUncorrected = false;
         bool sameUnitig = (ua.unitig == ub.unitig) && (ua.strand == ub.strand);
         if (lrc && has_min_qual(pa, pb + k)) isUncorrected = true; // :808
