@@ -1011,19 +1011,19 @@ RTK_FN_SEARCH uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_
     uint64_t cur = rtk_wp_commit(s, w0, 0); uint32_t cur_pos = start_pos; bool have = true;
     const uint32_t nw = lvw_hi - lvw_lo; // weak anchors of the region are lvw[lvw_lo + i], i in [0, nw)
     if (i_weak < nw) i_weak = rtk_an_first_ge(lvw, lvw_lo + i_weak, lvw_lo + nw, start_pos) - lvw_lo; // the reference's forward walks over the weak anchors, as searches
-    if (i_weak < nw) { const uint32_t wp = rtk_an_pos(lvw, lvw_lo + i_weak); next_weak_pos = wp > start_pos + k ? wp : start_pos + k; }
+    if (i_weak < nw) { const uint32_t wp = rtk_u(rtk_an_pos(lvw, lvw_lo + i_weak)); next_weak_pos = wp > start_pos + k ? wp : start_pos + k; }
     while (have && !end && !rtk_failed(s)) {
         if (i_weak < nw) { const uint64_t lim_a = static_cast<uint64_t>(pos2 - k), lim_b = next_weak_pos; i_weak = rtk_an_first_ge(lvw, lvw_lo + i_weak, lvw_lo + nw, lim_a < lim_b ? lim_a : lim_b) - lvw_lo; }
         else i_weak = nw;
-        end = (i_weak == nw) || (static_cast<uint64_t>(rtk_an_pos(lvw, lvw_lo + i_weak)) >= static_cast<uint64_t>(pos2 - k));
-        const uint32_t target_pos = end ? pos2 : rtk_an_pos(lvw, lvw_lo + i_weak);
+        end = (i_weak == nw) || (static_cast<uint64_t>(rtk_u(rtk_an_pos(lvw, lvw_lo + i_weak))) >= static_cast<uint64_t>(pos2 - k));
+        const uint32_t target_pos = end ? pos2 : rtk_u(rtk_an_pos(lvw, lvw_lo + i_weak));
         const uint32_t l_len = (target_pos - cur_pos) + k;
         const UMap um_start = begin ? start_um : rtk_rec_back(s, cur);
         uint64_t res = ~0ull; bool called = false;
         { // one call site for the three cases: to the end of the read (:61-72), to the right solid anchor (:74-78), to the next weak anchor (:110-114)
             UMap um_to = rtk_um_empty(); bool with_end = false;
             if (end) { if (no_end) called = l_len <= (max_len_weak_region / 2); else { called = l_len <= max_len_weak_region; um_to = end_um; with_end = true; } }
-            else if (l_len <= max_len_weak_region) { called = true; um_to = rtk_an_um(lvw, lvw_lo + i_weak); with_end = true; }
+            else if (l_len <= max_len_weak_region) { called = true; um_to = rtk_u(rtk_an_um(lvw, lvw_lo + i_weak)); with_end = true; }
             if (called) res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, um_to, with_end);
         }
         if (rtk_failed(s)) break;
@@ -1034,7 +1034,7 @@ RTK_FN_SEARCH uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_
             if (*n_partial >= s.list_cap) { rtk_fail_ovf(s, 8); break; }
             s.list[5][(*n_partial)++] = cur; have = false;
         }
-        if (!end) next_weak_pos = rtk_an_pos(lvw, lvw_lo + i_weak) + k;
+        if (!end) next_weak_pos = rtk_u(rtk_an_pos(lvw, lvw_lo + i_weak)) + k;
         begin = false;
     }
     return (have && !rtk_failed(s)) ? cur : ~0ull;
