@@ -1818,8 +1818,15 @@ RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const Regi
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
     const uint32_t* sp = bv.s_pos + base; const uint32_t ns = bv.n_solid[r];
     // reverse complement of the read (used by the head and backward corrections, src/Correction.cpp:175)
-    for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < L; i += RTK_WAVE) rb.seq_rc[base + i] = rtk_comp(bv.seq[base + (L - 1 - i)]);
-    if (bv.qual.get() != nullptr && rb.qual_rev.get() != nullptr) for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < L; i += RTK_WAVE) rb.qual_rev[base + i] = bv.qual[base + (L - 1 - i)];
+    { // eight characters per lane in flight: one wave reverses the whole read, and a load-then-store step at a time is a memory round trip each
+        const char* __restrict__ const src = bv.seq.get() + base; char* __restrict__ const dst = rb.seq_rc.get() + base;
+        const char* __restrict__ const qsrc = (bv.qual.get() != nullptr && rb.qual_rev.get() != nullptr) ? bv.qual.get() + base : nullptr; char* __restrict__ const qdst = qsrc ? rb.qual_rev.get() + base : nullptr;
+        for (uint32_t i0 = 0; i0 < L; i0 += 8u * RTK_WAVE) {
+            char t[8], tq[8];
+            for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); t[u] = i < L ? src[L - 1 - i] : 'N'; tq[u] = (qsrc && i < L) ? qsrc[L - 1 - i] : '!'; }
+            for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); if (i < L) { dst[i] = rtk_comp(t[u]); if (qdst) qdst[i] = tq[u]; } }
+        }
+    }
     uint32_t n_gaps = 0;
     const bool whole = (L <= k) || ns == 0 || (ns == L - k + 1);
     if (!whole) for (uint32_t c0 = 0; c0 + 1 < ns; c0 += RTK_WAVE) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); n_gaps += static_cast<uint32_t>(rtk_popc(rtk_ballot(i + 1 < ns && sp[i] != sp[i + 1] - 1))); }
@@ -1882,8 +1889,7 @@ RTK_FN void rtk_stitch_read(const BatchView& bv, const RegionBatch& rb, uint32_t
         const uint32_t m = (n - c0) < static_cast<uint32_t>(RTK_WAVE) ? (n - c0) : static_cast<uint32_t>(RTK_WAVE);
         for (uint32_t j = 0; j < m; ++j) {
             const uint32_t jsl = rtk_shfl(sl, static_cast<int>(j)), jql = rtk_shfl(ql, static_cast<int>(j)); const uint64_t jso = rtk_shfl(so, static_cast<int>(j));
-            rtk_wcopy(rb.out_pool + ws, rb.seg_pool + jso, jsl); ws += jsl;
-            rtk_wcopy(rb.out_pool + wq, rb.seg_pool + jso + jsl, jql); wq += jql;
+            rtk_wcopy2(rb.out_pool + ws, rb.seg_pool + jso, jsl, rb.out_pool + wq, rb.seg_pool + jso + jsl, jql); ws += jsl; wq += jql;
         }
     }
     (void)bv;
