@@ -1061,19 +1061,25 @@ RTK_DEV uint32_t rtk_rs_union(RegionScratch& s, int a, uint32_t na, const uint32
 #include "rtk_colours.h"
 
 // Computes all_pids into set[0]; returns its size. Uses set[1..9] as temporaries.
-RTK_FN uint32_t rtk_choose_colors(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
+RTK_FN uint32_t rtk_choose_colors_general(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_);
+// chooseColors: the two register / bit-vector programs of rtk_colours.h first (nearly every region), the general program below otherwise.
+// Compiled into its caller: the dispatcher itself as a function would save 17 register rows on every region for a path it almost never takes.
+RTK_DEV uint32_t rtk_choose_colors(const RCtx& c, const SideList& side_s, const SideList& side_e, const SideList& side_w) {
+    RegionScratch& s = rtk_hdr(c);
+    const unsigned long long tf = rtk_clock();
+#ifndef RTK_SIM
+    { const uint32_t r0 = rtk_u(rtk_choose_colors_small(c, side_s, side_e, side_w));
+      if (r0 != RTK_NONE32) { const unsigned long long d_ = rtk_clock() - tf; s.fine[0] += d_; s.fine[12] += d_; s.fine[14] += 1; return rtk_failed(s) ? 0 : r0; } }
+#endif
+    const uint32_t r = rtk_u(rtk_choose_colors_bits(c, side_s, side_e, side_w));
+    if (r != RTK_NONE32) { const unsigned long long d_ = rtk_clock() - tf; s.fine[0] += d_; s.fine[13] += d_; s.fine[15] += 1; return rtk_failed(s) ? 0 : r; }
+    return rtk_u(rtk_choose_colors_general(c, side_s, side_e, side_w));
+}
+RTK_FN uint32_t rtk_choose_colors_general(const RCtx& c_, const SideList& side_s_, const SideList& side_e_, const SideList& side_w_) {
     const RCtx& c = *rtk_u(&c_); const SideList& side_s = *rtk_u(&side_s_); const SideList& side_e = *rtk_u(&side_e_); const SideList& side_w = *rtk_u(&side_w_); RTK_ASSUME_LDS(&side_s); RTK_ASSUME_LDS(&side_e); RTK_ASSUME_LDS(&side_w);
     RegionScratch& s = rtk_hdr(c);
     const GraphView& g = c.g;
     unsigned long long tf = rtk_clock();
-    { // the common case: all the anchors' ids fit a 4096-bit universe -> the whole selection in registers (rtk_colours.h)
-#ifndef RTK_SIM
-        { const uint32_t r0 = rtk_u(rtk_choose_colors_small(c, side_s, side_e, side_w));
-          if (r0 != RTK_NONE32) { const unsigned long long d_ = rtk_clock() - tf; s.fine[0] += d_; s.fine[12] += d_; s.fine[14] += 1; return rtk_failed(s) ? 0 : r0; } }
-#endif
-        const uint32_t r = rtk_u(rtk_choose_colors_bits(c, side_s, side_e, side_w));
-        if (r != RTK_NONE32) { const unsigned long long d_ = rtk_clock() - tf; s.fine[0] += d_; s.fine[13] += d_; s.fine[15] += 1; return rtk_failed(s) ? 0 : r; }
-    }
     // a_pid[shift], shift = side index (0 middle, 1 right, 2 left) + 3 * nonbranching: built one after the other into the arena (level 2 is free here)
     s.top[2] = 0;
     tf = rtk_clock();
