@@ -113,7 +113,8 @@ long long rtk_graph_strip_annotations(rtk_graph* g);
  * max_read_len on `device` ahead of time, e.g. from a helper thread while rtk_graph_load parses the index. The first graph uploaded
  * to that device adopts them. Not part of the reference's seam; there is nothing to release. */
 int rtk_reserve_scratch(int device, uint32_t max_read_len);
-/* Second pass: n_tickets x (work area of the phasing step, work area of the region stage) reserved ahead; every ticket in flight owns a pair. */
+/* Second pass: n_tickets x (work area of the phasing step, work area of the region stage) reserved ahead; every ticket in flight owns a pair.
+ * The first call for a device also reserves the work areas of the per-read seed kernels (one slab per graph). */
 int rtk_reserve_second_pass(int device, uint32_t n_tickets, uint64_t phase_bytes, uint64_t region_bytes);
 
 /* Correct_Opt defaults + max_km_cov derived from the graph (reference: src/Common.hpp:101-156, src/Ratatosk.cpp:625). */
