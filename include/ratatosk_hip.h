@@ -171,6 +171,13 @@ int rtk_myers_batch(uint32_t n, const char* const* query, const uint32_t* qlen, 
                     const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
                     int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar);
 
+/* The same problems on workgroups of `waves` wavefronts (2..16): the schedule the second pass uses for the whole-read alignment of its long
+ * reads (reference: phasing(), src/Graph.cpp:975) -- wave 0 runs the alignment program, the others take the row blocks / banded passes it
+ * publishes. waves <= 1 is rtk_myers_batch. Stage entry for parity tests and timing of that schedule; same results. */
+int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
+                          const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
+                          int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar, int waves);
+
 void rtk_free(void* p);
 const char* rtk_last_error(void);
 const char* rtk_version(void);

@@ -86,6 +86,7 @@ def load_library(path=None):
     L.rtk_myers_batch.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int,
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32, C.c_char_p, C.c_uint32]
+    L.rtk_myers_batch_waves.argtypes = L.rtk_myers_batch.argtypes + [C.c_int]
     L.rtk_free.argtypes = [C.c_void_p]
     _libs[path] = L
     return L
@@ -235,7 +236,7 @@ class Batch:
             pass
 
 
-def myers_batch(queries, targets, ks=None, modes=None, want_path=False, use_iupac=True, lib_path=None):
+def myers_batch(queries, targets, ks=None, modes=None, want_path=False, use_iupac=True, lib_path=None, waves=0):
     """edlibAlign over a batch on the device: returns [(editDistance, endLocations, cigar)]."""
     L = load_library(lib_path)
     n = len(queries)
@@ -249,7 +250,10 @@ def myers_batch(queries, targets, ks=None, modes=None, want_path=False, use_iupa
     cap_cig = 4 * (max((len(x) for x in bq), default=0) + max((len(x) for x in bt), default=0)) + 16
     dist = (C.c_int32 * n)(); nloc = (C.c_int32 * n)(); locs = (C.c_int32 * (n * cap_locs))()
     cig = C.create_string_buffer(n * cap_cig) if want_path else None
-    rc = L.rtk_myers_batch(n, qa, ql, ta, tl, ka, ma, 1 if want_path else 0, 1 if use_iupac else 0, dist, nloc, locs, cap_locs, cig, cap_cig)
+    if waves > 1:  # the multi-wave schedule of the second pass's whole-read alignment (stage entry)
+        rc = L.rtk_myers_batch_waves(n, qa, ql, ta, tl, ka, ma, 1 if want_path else 0, 1 if use_iupac else 0, dist, nloc, locs, cap_locs, cig, cap_cig, waves)
+    else:
+        rc = L.rtk_myers_batch(n, qa, ql, ta, tl, ka, ma, 1 if want_path else 0, 1 if use_iupac else 0, dist, nloc, locs, cap_locs, cig, cap_cig)
     if rc != 0:
         raise RtkError("rtk error %d: %s" % (rc, L.rtk_last_error().decode()))
     out = []

@@ -347,10 +347,28 @@ extern "C" int rtk_lookup_exact(rtk_graph* g, const char* seq, uint32_t len, int
 }
 
 // ------------------------------------------------------------------------------------------------ K6/K7: Myers batch
-struct MyersProb { uint64_t q_off, t_off; uint32_t qlen, tlen; int32_t k, mode; };
+// one problem of the batch on this wave (shared with the multi-wave variant of the kernel, rtk_phase_long.hip)
+RTK_FN void rtk_myers_batch_item(const MyersScratch& sc, const MyersProb& p, uint32_t i, const char* pool, int want_path, int use_iupac, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs,
+                                 uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status) {
+    *sc.overflow = 0;
+    const char* q = pool + p.q_off; const char* t = pool + p.t_off;
+    const MyersResult r = rtk_myers_distance(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.k, p.mode, use_iupac != 0, cap_locs ? end_locs + static_cast<uint64_t>(i) * cap_locs : nullptr, static_cast<int>(cap_locs)); // cap_locs == 0: no list of end locations (the route the region program takes)
+    dist[i] = r.dist; n_loc[i] = r.nloc;
+    uint32_t nm = 0;
+    if (want_path && r.dist >= 0 && p.qlen > 0 && p.tlen > 0) { // edlib.cpp:271-284 (zero-length inputs return before any path is built)
+        if (p.k < 0 && p.mode != RTK_MODE_HW) { // the single-sweep route the region program takes for NW / SHW paths
+            const MyersResult r2 = rtk_myers_path(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.mode, use_iupac != 0, &nm);
+            if (r2.dist != r.dist || r2.first != r.first) *sc.overflow = 3; // must agree with the distance pass
+        } else
+        rtk_myers_alignment(sc, q, static_cast<int>(p.qlen), t, r.first + 1, r.dist, use_iupac != 0, &nm);
+        if (nm <= cap_moves) rtk_wcopy(moves_out + static_cast<uint64_t>(i) * cap_moves, sc.moves, nm);
+    }
+    n_moves_out[i] = nm;
+    status[i] = *sc.overflow;
+}
 
 RTK_GLOBAL void k_myers_batch(const MyersProb* probs, uint32_t n, const char* pool, int want_path, int use_iupac, char* scratch, uint64_t scratch_stride, ScratchCfg cfg,
-                              int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status) {
+                              int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status, unsigned long long* prof) {
 #ifdef RTK_SIM
     const MyersScratch sc = scratch_carve(scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * scratch_stride, cfg);
 #else
@@ -358,29 +376,25 @@ RTK_GLOBAL void k_myers_batch(const MyersProb* probs, uint32_t n, const char* po
     sc = scratch_carve(scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * scratch_stride, cfg); // every lane stores the same words
     __syncthreads();
 #endif
-    for (uint32_t i = static_cast<uint32_t>(RTK_BLOCK_ID); i < n; i += static_cast<uint32_t>(grid)) {
-        const MyersProb p = probs[i];
-        *sc.overflow = 0;
-        const char* q = pool + p.q_off; const char* t = pool + p.t_off;
-        const MyersResult r = rtk_myers_distance(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.k, p.mode, use_iupac != 0, cap_locs ? end_locs + static_cast<uint64_t>(i) * cap_locs : nullptr, static_cast<int>(cap_locs)); // cap_locs == 0: no list of end locations (the route the region program takes)
-        dist[i] = r.dist; n_loc[i] = r.nloc;
-        uint32_t nm = 0;
-        if (want_path && r.dist >= 0 && p.qlen > 0 && p.tlen > 0) { // edlib.cpp:271-284 (zero-length inputs return before any path is built)
-            if (p.k < 0 && p.mode != RTK_MODE_HW) { // the single-sweep route the region program takes for NW / SHW paths
-                const MyersResult r2 = rtk_myers_path(sc, q, static_cast<int>(p.qlen), t, static_cast<int>(p.tlen), p.mode, use_iupac != 0, &nm);
-                if (r2.dist != r.dist || r2.first != r.first) *sc.overflow = 3; // must agree with the distance pass
-            } else
-            rtk_myers_alignment(sc, q, static_cast<int>(p.qlen), t, r.first + 1, r.dist, use_iupac != 0, &nm);
-            if (nm <= cap_moves) rtk_wcopy(moves_out + static_cast<uint64_t>(i) * cap_moves, sc.moves, nm);
-        }
-        n_moves_out[i] = nm;
-        status[i] = *sc.overflow;
-    }
+    for (uint32_t i = static_cast<uint32_t>(RTK_BLOCK_ID); i < n; i += static_cast<uint32_t>(grid))
+        rtk_myers_batch_item(sc, probs[i], i, pool, want_path, use_iupac, dist, n_loc, end_locs, cap_locs, moves_out, n_moves_out, cap_moves, status);
+    if (prof && rtk_lane() == 0) { rtk_atomic_add(prof + 0, sc.hb_total.get()); rtk_atomic_add(prof + 1, sc.hb_pass.get()); rtk_atomic_add(prof + 2, sc.hb_split.get()); rtk_atomic_add(prof + 3, sc.hb_leaf.get()); rtk_atomic_add(prof + 4, sc.walk_cycles.get()); }
 }
 
+#ifndef RTK_SIM
+// multi-wave variant of k_myers_batch (rtk_phase_long.hip)
+void rtk_launch_myers_batch_waves(int grid, int waves, const MyersProb* probs, uint32_t n, const char* pool, int want_path, int use_iupac, char* scratch, uint64_t scratch_stride, const ScratchCfg& cfg,
+                                  int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status, unsigned long long* prof);
+#endif
 extern "C" int rtk_myers_batch(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
                                const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
                                int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar) {
+    return rtk_myers_batch_waves(n, query, qlen, target, tlen, k, mode, want_path, use_iupac, dist, n_loc, end_locs, cap_locs, cigar, cap_cigar, 1);
+}
+extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
+                                     const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
+                                     int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar, int waves) {
+    if (waves > 16) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch_waves: at most 16 waves per workgroup");
     if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || (!end_locs && cap_locs)) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch: null argument");
     if (rtk_device_count() <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_myers_batch: no HIP device visible (no CPU fallback)");
     if (n == 0) return RTK_OK;
@@ -399,7 +413,7 @@ extern "C" int rtk_myers_batch(uint32_t n, const char* const* query, const uint3
         cfg.w_cap = (max_q + 63) / 64 + 1; cfg.t_cap = max_t + 64; cfg.r_cap = max_q + 64; cfg.mv_cap = max_q + max_t + 64;
         cfg.tb_cap_words = std::max<uint64_t>(4ull * 52429 + 64, 4ull * cfg.w_cap + 64);
         const int grid = static_cast<int>(std::min<uint32_t>(n, static_cast<uint32_t>(default_grid() / 4 > 0 ? default_grid() / 4 : 1)));
-        const uint64_t stride = scratch_bytes(cfg);
+        const uint64_t stride = scratch_bytes(cfg) + (waves > 1 ? static_cast<uint64_t>(waves - 1) * scratch_bytes(rtk_leaf_cfg()) : 0ull); // + the leaf-traceback areas of the helper waves
         const uint32_t cap_moves = want_path ? (max_q + max_t + 8) : 1;
         char* dpool = static_cast<char*>(rtk_dmalloc(pool.size() + 64));
         MyersProb* dprobs = static_cast<MyersProb*>(rtk_dmalloc(sizeof(MyersProb) * n));
@@ -409,7 +423,15 @@ extern "C" int rtk_myers_batch(uint32_t n, const char* const* query, const uint3
         uint8_t* dmoves = static_cast<uint8_t*>(rtk_dmalloc(static_cast<uint64_t>(n) * cap_moves + 8));
         uint32_t* dnm = static_cast<uint32_t*>(rtk_dmalloc(4ull * n)); uint32_t* dst = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
         rtk_h2d(dpool, pool.data(), pool.size()); rtk_h2d(dprobs, probs.data(), sizeof(MyersProb) * n);
-        rtk_launch(k_myers_batch, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst);
+        unsigned long long* dprof = nullptr; // RTK_MYERS_PROF=1: cycle counters of the Hirschberg drivers (developer)
+        if (getenv("RTK_MYERS_PROF")) { dprof = static_cast<unsigned long long*>(rtk_dmalloc(64)); const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; rtk_h2d(dprof, z, 64); }
+#ifndef RTK_SIM
+        if (waves > 1) rtk_launch_myers_batch_waves(grid, waves, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst, dprof);
+        else
+#endif
+        rtk_launch(k_myers_batch, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst, dprof);
+        if (dprof) { rtk_dsync(); unsigned long long pc[8]; rtk_d2h(pc, dprof, 64); rtk_dfree(dprof);
+            fprintf(stderr, "[rtk myers prof] waves %d: Hirschberg driver %.3g cycles (half passes %.3g, columns + split %.3g, leaf tracebacks %.3g of which walks %.3g)\n", waves, double(pc[0]), double(pc[1]), double(pc[2]), double(pc[3]), double(pc[4])); }
         rtk_dsync();
         std::vector<uint32_t> st(n), nm(n);
         rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); if (cap_locs) rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs);

@@ -5,9 +5,21 @@
 // Layout: one 64-bit word of the query per lane; the carry between vertically adjacent words travels lane->lane+1
 // with one __shfl_up per step, so the wave sweeps the DP matrix along anti-diagonals ("step s: lane l works on
 // column s-l"). Queries longer than 64 words are processed in row blocks of 64 words; the horizontal deltas leaving
-// a block are parked in a per-column int8 array and picked up by lane 0 of the next block. Whole columns are
-// computed (no Ukkonen band): the band of edlib only prunes cells that cannot lie on an optimal path, so distances,
-// end locations and the traceback are unaffected (see oracle/oracle_myers.hpp; pinned against the reference build).
+// a block are parked in a per-column int8 array and picked up by lane 0 of the next block.
+//
+// Band (edlib.cpp:194-212 k doubling, :778-915 firstBlock/lastBlock): the big NW problems -- bounded distances and the half passes of
+// the Hirschberg recursion, i.e. the whole-read alignment of phasing() -- only compute the Ukkonen band of their k: the cells (i, j)
+// with |j - i| + |(n - m) - (j - i)| <= k, a stripe of k + 1 diagonals, at word granularity. Everything outside is an upper bound
+// ("+1 per step away from the band"), so the computed value D' is >= the true D everywhere and equal to it on every cell an optimal
+// path of cost <= k visits: the distance, the Hirschberg split rows (left + right == optimum only holds on optimal-path cells, which
+// are exact) and the tracebacks are those of the unbanded matrix. edlib's band prunes the same way (only cells that cannot lie on an
+// optimal path), which is why its results equal the unbanded oracle's (oracle/oracle_myers.hpp; pinned against the reference build).
+// Where edlib doubles k until the score fits, the first split of an unknown-distance problem runs with a guess and is repeated once
+// with the (real, reachable) score it found if that score exceeds the guess. Two schedules:
+//   * ring (band <= 4000 diagonals, one wave): lane = word & 63; a word enters the band at the bottom, leaves it at the top 64 + band
+//     columns later and its lane takes word + 64; a pass is n + W steps whatever the number of row blocks (rtk_myers_ring);
+//   * blocks (wider bands): the 4096-row blocks of rtk_myers_block each sweep the columns [4096 b + dlo, 4096 b + 4095 + dhi] only.
+// Small problems (one row block) and the stored sweeps of the tracebacks compute whole columns: the wave sweeps them in n + W steps anyway.
 // The query profile is indexed by character class (15 IUPAC letters); any other byte is compared on the fly.
 #ifndef RTK_MYERS_H
 #define RTK_MYERS_H
@@ -429,16 +441,61 @@ __device__ __forceinline__ SweepStat rtk_myers_fast_any(const char* __restrict__
 #endif
 
 
+// ---- band of a pass: diagonals dlo <= j - i <= dhi (i = query row, j = target column, 0-based) -----------------------------------------------
+#define RTK_BAND_FULL (1 << 29)
+#define RTK_BAND_INF 0x3fffffff      // score of a row outside the band
+#define RTK_RING_MAX_BAND 4000       // widest band (diagonals) of the ring schedule: a lane must be done with word w before word w + 64 starts
+struct RtkBand { int dlo, dhi; };
+RTK_HD RtkBand rtk_band_full() { RtkBand b; b.dlo = -RTK_BAND_FULL; b.dhi = RTK_BAND_FULL; return b; }
+// Ukkonen band of an NW problem of m rows and n columns whose distance is <= k (k is raised to |n - m| if smaller)
+RTK_HD RtkBand rtk_band_nw(int m, int n, int k) {
+    const int d = n - m, ad = d < 0 ? -d : d;
+    const int h = k > ad ? (k - ad) / 2 : 0;
+    RtkBand b; b.dlo = (d < 0 ? d : 0) - h; b.dhi = (d > 0 ? d : 0) + h; return b;
+}
+RTK_HD bool rtk_band_is_full(const RtkBand& b, int m, int n) { return b.dlo <= -m && b.dhi >= n; }
+// words computed together share their column range: gran = 1 (ring: every word its own) or 64 (row blocks)
+RTK_HD int rtk_band_clo(int w, int dlo, int gran) { const long long c = 64LL * ((w / gran) * gran) + dlo; return c < 0 ? 0 : static_cast<int>(c); }
+RTK_HD int rtk_band_chi(int w, int W, int n, int dhi, int gran) { int wl = (w / gran) * gran + gran - 1; if (wl > W - 1) wl = W - 1; const long long c = 64LL * wl + 63 + dhi; return c > n - 1 ? n - 1 : static_cast<int>(c); }
+// words that have a column at all: the band reaches row n - 1 - dlo at most
+RTK_HD int rtk_band_words(int m, int n, int dlo) { const int W = (m + 63) >> 6; const long long r = static_cast<long long>(n) - 1 - dlo; if (r < 0) return 0; const long long w = (r >> 6) + 1; return w < W ? static_cast<int>(w) : W; }
+// schedule of a banded pass: the ring (every word its own column range) when it pays and fits, row blocks otherwise
+RTK_HD int rtk_band_gran(int m, int dlo, int dhi) { return (((m + 63) >> 6) > 64 && (dhi - dlo) <= RTK_RING_MAX_BAND) ? 1 : 64; }
+// first guess of the distance of an NW problem (the top of a Hirschberg recursion): generous where the ring makes the width free
+RTK_HD int rtk_band_guess(int m, int n) {
+    const int d = n - m, ad = d < 0 ? -d : d, mn = m < n ? m : n;
+    int g = ad + (mn / 8 > 64 ? mn / 8 : 64);
+    if (g < RTK_RING_MAX_BAND - 100) g = RTK_RING_MAX_BAND - 100;
+    return g < m + n ? g : m + n;
+}
+
+struct RtkCoopJob { const char* qp; const char* tp; int m, n, qrev, trev, top_h, iupac; uint64_t* fin_pv; uint64_t* fin_mv; int8_t* carry; int32_t* colscore; int dlo, dhi, ring; uint64_t* peq4; };
 #ifndef RTK_SIM
-struct RtkCoopJob { const char* qp; const char* tp; int m, n, qrev, trev, top_h, iupac; uint64_t* fin_pv; uint64_t* fin_mv; int8_t* carry; int32_t* colscore; };
 __device__ __forceinline__ int rtk_coop_ld(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void rtk_coop_st(int* p, int v) { if (rtk_lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // One row block (64 words = 4096 query rows) of a pass over several blocks: same arithmetic as the general loop of rtk_myers_pass, without
 // branches in the step when the target holds A/C/G/T only. progress == nullptr: the blocks are swept one after the other by this wave;
 // otherwise the counters of the pass (completed columns per block), through which the waves of a workgroup follow each other.
+// Band (J.dlo, J.dhi): the block only sweeps the columns [cb_lo, cb_hi] in which one of its words has a row inside the band; it starts from
+// the "+1 per row" vertical deltas, takes "+1 per column" from above once the block above is past its own last column, and leaves the
+// vertical deltas of column cb_hi in fin_pv / fin_mv (rtk_myers_column knows which rows of them are inside the band at the last column).
+__device__ __forceinline__ unsigned char rtk_job_qc(const char* __restrict__ qp, int m, int qrev, int i) { return static_cast<unsigned char>(qrev ? qp[m - 1 - i] : qp[i]); }
+__device__ __forceinline__ void rtk_myers_eq4(const char* __restrict__ qp, int m, int qrev, int w, bool iupac, uint64_t& eqA, uint64_t& eqC, uint64_t& eqG, uint64_t& eqT) {
+    eqA = 0; eqC = 0; eqG = 0; eqT = 0;
+    const int lim = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+    for (int i = 0; i < lim; ++i) {
+        const unsigned char qc = rtk_job_qc(qp, m, qrev, 64 * w + i);
+        uint32_t bm;
+        if (qc == 'A') bm = 1u; else if (qc == 'C') bm = 2u; else if (qc == 'G') bm = 4u; else if (qc == 'T') bm = 8u;
+        else bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu; // bases this query character equals
+        eqA |= static_cast<uint64_t>(bm & 1u) << i; eqC |= static_cast<uint64_t>((bm >> 1) & 1u) << i;
+        eqG |= static_cast<uint64_t>((bm >> 2) & 1u) << i; eqT |= static_cast<uint64_t>((bm >> 3) & 1u) << i;
+    }
+}
 __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* progress) {
     const char* __restrict__ const qp = rtk_u(J.qp); const char* __restrict__ const tp = rtk_u(J.tp);
     const int m = rtk_u(J.m), n = rtk_u(J.n), qrev = rtk_u(J.qrev), trev = rtk_u(J.trev), top_h = rtk_u(J.top_h); const bool iupac = rtk_u(J.iupac) != 0;
+    const int dlo = rtk_u(J.dlo), dhi = rtk_u(J.dhi);
     int8_t* __restrict__ const carry = rtk_u(J.carry); int32_t* __restrict__ const colscore = rtk_u(J.colscore);
     uint64_t* const fin_pv = rtk_u(J.fin_pv); uint64_t* const fin_mv = rtk_u(J.fin_mv);
     const int W = (m + 63) >> 6, last_bit = (m - 1) & 63;
@@ -451,39 +508,41 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
     const bool is_block_tail = (lane == nw - 1);
     const int bit = is_last_word ? last_bit : 63;
     const bool last_block = (w0 + nw >= W);
-    uint64_t eqA = 0, eqC = 0, eqG = 0, eqT = 0;
-    if (has_word) {
-        const int lim = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
-        for (int i = 0; i < lim; ++i) {
-            const unsigned char qc = static_cast<unsigned char>(qrev ? qp[m - 1 - (64 * w + i)] : qp[64 * w + i]);
-            const uint32_t bm = rtk_eq_classes(rtk_cls(qc), iupac) & 0xFu;
-            eqA |= static_cast<uint64_t>(bm & 1u) << i; eqC |= static_cast<uint64_t>((bm >> 1) & 1u) << i;
-            eqG |= static_cast<uint64_t>((bm >> 2) & 1u) << i; eqT |= static_cast<uint64_t>((bm >> 3) & 1u) << i;
-        }
+    const bool banded = !(dlo <= -m && dhi >= n);
+    const int cb_lo = rtk_band_clo(w0, dlo, 64), cb_hi = rtk_band_chi(w0, W, n, dhi, 64); // columns of this block
+    const int prev_hi = b > 0 ? rtk_band_chi(w0 - 1, W, n, dhi, 64) : -1;               // last column of the block above
+    const int above_h = b == 0 ? top_h : 1;                                              // delta entering the block where nothing is above it
+    if (cb_lo > cb_hi) { // no column (below the band): nothing to do, nobody waits
+        if (progress) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (!last_block) rtk_coop_st(&progress[b], n); } else rtk_sync();
+        return;
     }
+    const int nc = cb_hi - cb_lo + 1;
+    uint64_t eqA = 0, eqC = 0, eqG = 0, eqT = 0;
+    if (has_word) rtk_myers_eq4(qp, m, qrev, w, iupac, eqA, eqC, eqG, eqT);
     uint64_t Pv = ~0ull, Mv = 0ull;
     int hout_prev = 0; unsigned tc_prev = 0;
     int score = m;
-    const int steps = n + nw - 1;
+    const int steps = nc + nw - 1;
     int sbuf = 0;
+    const bool track = last_block && !banded; // bottom-row scores of every column: only meaningful when the sweep starts at column 0
     bool plain = true; // target made of A/C/G/T only: the profile word is a select, no branches in the step
-    for (int c0 = 0; c0 < n && plain; c0 += 64) {
+    for (int c0 = cb_lo; c0 <= cb_hi && plain; c0 += 64) {
         const int cj = c0 + lane; bool okc = true;
-        if (cj < n) { const unsigned char ch = static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj]); okc = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+        if (cj <= cb_hi) { const unsigned char ch = static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj]); okc = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
         plain = (rtk_ballot(!okc) == 0ull);
     }
     for (int c0 = 0; c0 < steps; c0 += 64) {
-        const int cj = c0 + lane;
-        if (b > 0 && progress) { // the deltas of columns [c0, c0 + 64) must have left the block above
-            const int need = (c0 + 64) < n ? (c0 + 64) : n;
-            if (c0 < n) { while (rtk_coop_ld(&progress[b - 1]) < need) __builtin_amdgcn_s_sleep(8); }
+        const int cj = cb_lo + c0 + lane; // absolute column this lane fetches for the chunk
+        if (b > 0 && progress && cb_lo + c0 <= prev_hi) { // the deltas of the chunk's columns must have left the block above (as far as it goes)
+            const int need = (cb_lo + c0 + 64) <= prev_hi ? (cb_lo + c0 + 64) : (prev_hi + 1);
+            while (rtk_coop_ld(&progress[b - 1]) < need) __builtin_amdgcn_s_sleep(8);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        int my_t = (cj < n) ? static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj])) : 0;
-        int my_c = (b != 0 && cj < n) ? static_cast<int>(carry[cj]) : top_h;
+        int my_t = (cj <= cb_hi) ? static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj])) : 0;
+        int my_c = (b != 0 && cj <= prev_hi) ? static_cast<int>(carry[cj]) : above_h;
         asm volatile("" : "+v"(my_t), "+v"(my_c));
         const int lim = (steps - c0) < 64 ? (steps - c0) : 64;
-        if (plain && last_block) { // the same for the block that holds the last query row: its bottom-row scores are parked 64 columns at a time
+        if (plain && track) { // the block that holds the last query row of an unbanded pass: its bottom-row scores are parked 64 columns at a time
             for (int j = 0; j < lim; ++j) {
                 const int s = c0 + j;
                 const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
@@ -496,8 +555,8 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
                 const uint64_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
                 uint64_t nPv = Pv, nMv = Mv, Ph, Mh;
                 const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
-                const int col = s - lane;
-                const bool active = has_word && col >= 0 && col < n;
+                const int lc = s - lane; // column index inside the block's range
+                const bool active = has_word && lc >= 0 && lc < nc;
                 Pv = active ? nPv : Pv; Mv = active ? nMv : Mv; hout_prev = active ? hout : hout_prev;
                 score += (active && is_block_tail) ? hout : 0;
                 tc_prev = tc;
@@ -509,7 +568,7 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
                 }
             }
         } else
-        if (plain && !last_block) { // the common case, predicated instead of branched (scalar branches cost an instruction-fetch restart)
+        if (plain) { // the common case, predicated instead of branched (scalar branches cost an instruction-fetch restart)
             for (int j = 0; j < lim; ++j) {
                 const int s = c0 + j;
                 const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, j));
@@ -522,10 +581,10 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
                 const uint64_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
                 uint64_t nPv = Pv, nMv = Mv, Ph, Mh;
                 const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
-                const int col = s - lane;
-                const bool active = has_word && col >= 0 && col < n;
+                const int lc = s - lane;
+                const bool active = has_word && lc >= 0 && lc < nc;
                 Pv = active ? nPv : Pv; Mv = active ? nMv : Mv; hout_prev = active ? hout : hout_prev;
-                if (active && is_block_tail) carry[col] = static_cast<int8_t>(hout);
+                if (active && is_block_tail && !last_block) carry[cb_lo + lc] = static_cast<int8_t>(hout);
                 tc_prev = tc;
             }
         } else
@@ -537,22 +596,22 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
             const unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(static_cast<unsigned>(in_c + 1) | (in_t << 8)), static_cast<int>(mine), 0x138, 0xF, 0xF, false));
             const int hin = static_cast<int>(got & 0xFFu) - 1;
             const unsigned tc = got >> 8;
-            const int col = s - lane;
-            const bool active = has_word && col >= 0 && col < n;
+            const int lc = s - lane;
+            const bool active = has_word && lc >= 0 && lc < nc;
             if (active) {
                 uint64_t Eq;
                 if (tc == 'A') Eq = eqA; else if (tc == 'C') Eq = eqC; else if (tc == 'G') Eq = eqG; else if (tc == 'T') Eq = eqT;
                 else {
                     Eq = 0; const int lim2 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
-                    for (int i = 0; i < lim2; ++i) Eq |= static_cast<uint64_t>(rtk_chars_equal(static_cast<unsigned char>(qrev ? qp[m - 1 - (64 * w + i)] : qp[64 * w + i]), static_cast<unsigned char>(tc), iupac)) << i;
+                    for (int i = 0; i < lim2; ++i) Eq |= static_cast<uint64_t>(rtk_chars_equal(rtk_job_qc(qp, m, qrev, 64 * w + i), static_cast<unsigned char>(tc), iupac)) << i;
                 }
                 uint64_t Ph, Mh;
                 const int hout = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
-                if (is_block_tail) { if (!last_block) carry[col] = static_cast<int8_t>(hout); else score += hout; }
+                if (is_block_tail) { if (!last_block) carry[cb_lo + lc] = static_cast<int8_t>(hout); else score += hout; }
                 hout_prev = hout;
             }
             tc_prev = tc;
-            if (last_block) {
+            if (track) {
                 const int tcol = s - (nw - 1);
                 if (tcol >= 0 && tcol < n) {
                     const int sv = __builtin_amdgcn_readlane(score, nw - 1);
@@ -562,9 +621,9 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
             }
         }
         if (!last_block && progress) { // columns whose delta has left this block: the tail lane is nw - 1 columns behind lane 0
-            int done = c0 + lim - (nw - 1); done = done < 0 ? 0 : (done > n ? n : done);
+            int done = c0 + lim - (nw - 1); done = done < 0 ? 0 : (done > nc ? nc : done);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            rtk_coop_st(&progress[b], done);
+            rtk_coop_st(&progress[b], cb_lo + done);
         }
     }
     if (fin_pv && has_word) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
@@ -572,6 +631,130 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
     else rtk_sync();
 }
 
+// ------------------------------------------------------------------------------------------------ banded pass on one wave: the ring
+// NW pass (top row +1 per column) over a band of at most RTK_RING_MAX_BAND diagonals, any number of query words. Word w owns lane w & 63
+// and is swept over its own columns [64 w + dlo, 64 w + 63 + dhi] (clipped to the matrix) at step column + w, as in the anti-diagonal
+// pipeline of the row blocks; the words above and below it at that moment sit in the neighbouring lanes (the ring closes from lane 63 to
+// lane 0: DPP wave_ror:1). The word at the top of the band (the "head": nothing above it any more) takes +1 per column from above and the
+// target character of its column from the chunk register; every other word takes both from the lane above. A word that is past its last
+// column parks its vertical deltas in fin_pv / fin_mv and its lane moves on to word + 64, whose first column lies at least 65 steps later
+// because the band is narrower than 4096 - 65 - 31 diagonals: the switch is done lazily, once per chunk of 64 steps. J.peq4: 4 words
+// (A, C, G, T profile) per query word, filled here.
+template <int PLAIN>
+__device__ __forceinline__ void rtk_myers_ring_sweep(const RtkCoopJob& J) {
+    const char* __restrict__ const qp = rtk_u(J.qp); const char* __restrict__ const tp = rtk_u(J.tp);
+    const int m = rtk_u(J.m), n = rtk_u(J.n), qrev = rtk_u(J.qrev), trev = rtk_u(J.trev); const bool iupac = rtk_u(J.iupac) != 0;
+    const int dlo = rtk_u(J.dlo), dhi = rtk_u(J.dhi);
+    uint64_t* const fin_pv = rtk_u(J.fin_pv); uint64_t* const fin_mv = rtk_u(J.fin_mv);
+    const uint64_t* __restrict__ const peq4 = rtk_u(J.peq4);
+    const int W = (m + 63) >> 6, last_bit = (m - 1) & 63;
+    const int Wa = rtk_u(rtk_band_words(m, n, dlo));
+    const int lane = rtk_lane();
+    // this lane's current word
+    int w = lane; bool live = w < Wa;
+    uint64_t eqA = 0, eqC = 0, eqG = 0, eqT = 0, Pv = ~0ull, Mv = 0ull;
+    int clo_w = 0x7fffffff, chi_w = -1, head_from = 0x7fffffff, bit = 63;
+#define RTK_RING_LOAD_WORD()                                                                                                                  \
+    {                                                                                                                                        \
+        eqA = peq4[4ull * w]; eqC = peq4[4ull * w + 1]; eqG = peq4[4ull * w + 2]; eqT = peq4[4ull * w + 3];                                   \
+        Pv = ~0ull; Mv = 0ull;                                                                                                               \
+        clo_w = rtk_band_clo(w, dlo, 1); chi_w = rtk_band_chi(w, W, n, dhi, 1);                                                               \
+        head_from = (w == 0) ? -0x7fffffff : 64 * w + dhi; /* columns at which no word is above this one (dhi < 2^29: no overflow) */       \
+        bit = (w == W - 1) ? last_bit : 63;                                                                                                  \
+    }
+    if (live) RTK_RING_LOAD_WORD()
+    int hout_prev = 0; unsigned tc_prev = 0;
+    const int steps = rtk_u(n + Wa - 1);
+    int s = 0, w_head = 0, head_chi = rtk_u(rtk_band_chi(0, W, n, dhi, 1)), cb = 0;
+    int nxt_t = 0;
+    { const int cn = lane; if (cn < n) nxt_t = static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cn] : tp[cn])); }
+    int my_t = nxt_t;
+    { const int cn = 64 + lane; nxt_t = 0; if (cn < n) nxt_t = static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cn] : tp[cn])); }
+    // The sweep is cut into runs in which nothing wave-level changes: the head of the band stays the same word and its columns stay in
+    // the chunk register, so the run is a counted loop with scalar control (column of the head = c0 + j).
+    while (s < steps) {
+        s = rtk_u(s); w_head = rtk_u(w_head); head_chi = rtk_u(head_chi); cb = rtk_u(cb);
+        { // words that are past their last column: park the deltas, take the next word of this lane
+            const bool done = live && (s - w > chi_w);
+            if (rtk_ballot(done) != 0ull) {
+                if (done) {
+                    if (fin_pv) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
+                    w += 64; live = w < Wa;
+                    if (live) RTK_RING_LOAD_WORD() else { clo_w = 0x7fffffff; chi_w = -1; }
+                }
+            }
+        }
+        asm volatile("" : "+v"(my_t));
+        const int c0 = s - w_head; // column of the head at step s
+        int run = steps - s;
+        { const int r1 = head_chi - c0 + 1, r2 = cb + 64 - c0; run = run < r1 ? run : r1; run = run < r2 ? run : r2; run = run < 64 ? run : 64; run = rtk_u(run); }
+        const int ci = c0 - cb;
+        for (int j = 0; j < run; ++j) {
+            const unsigned in_t = static_cast<unsigned>(__builtin_amdgcn_readlane(my_t, ci + j));
+            const unsigned mine = static_cast<unsigned>(hout_prev + 1) | (tc_prev << 8);
+            unsigned got = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine), 0x13C, 0xF, 0xF, false)); // wave_ror:1
+            const int c = s + j - w;
+            got = (c >= head_from) ? (2u | (in_t << 8)) : got;
+            const int hin = static_cast<int>(got & 0xFFu) - 1;
+            const unsigned tc = got >> 8;
+            const bool active = c >= clo_w && c <= chi_w;
+            if (PLAIN) {
+                const unsigned sel = (tc >> 1) & 3u; // 'A' -> 0, 'C' -> 1, 'T' -> 2, 'G' -> 3
+                const uint64_t Eq = (sel & 2u) ? ((sel & 1u) ? eqG : eqT) : ((sel & 1u) ? eqC : eqA);
+                uint64_t nPv = Pv, nMv = Mv, Ph, Mh;
+                const int hout = rtk_myers_step(nPv, nMv, Eq, hin, bit, Ph, Mh);
+                Pv = active ? nPv : Pv; Mv = active ? nMv : Mv; hout_prev = active ? hout : hout_prev;
+            } else if (active) {
+                uint64_t Eq;
+                if (tc == 'A') Eq = eqA; else if (tc == 'C') Eq = eqC; else if (tc == 'G') Eq = eqG; else if (tc == 'T') Eq = eqT;
+                else { // rare: IUPAC code, N or foreign byte in the target -> compare the 64 query characters of this word directly
+                    Eq = 0; const int lim2 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                    for (int i = 0; i < lim2; ++i) Eq |= static_cast<uint64_t>(rtk_chars_equal(rtk_job_qc(qp, m, qrev, 64 * w + i), static_cast<unsigned char>(tc), iupac)) << i;
+                }
+                uint64_t Ph, Mh;
+                hout_prev = rtk_myers_step(Pv, Mv, Eq, hin, bit, Ph, Mh);
+            }
+            tc_prev = tc;
+        }
+        s += run;
+        if (s - w_head > head_chi && w_head + 1 < Wa) { ++w_head; head_chi = rtk_band_chi(w_head, W, n, dhi, 1); } // the head of the band moves down (one step without a new column)
+        if (s - w_head >= cb + 64) {
+            cb += 64; my_t = nxt_t;
+            const int cn = cb + 64 + lane; nxt_t = 0; if (cn < n) nxt_t = static_cast<int>(static_cast<unsigned char>(trev ? tp[n - 1 - cn] : tp[cn]));
+        }
+    }
+#undef RTK_RING_LOAD_WORD
+    if (live && fin_pv) { fin_pv[w] = Pv; fin_mv[w] = Mv; }
+}
+__device__ __noinline__ void rtk_myers_ring(const RtkCoopJob& J) {
+    const char* __restrict__ const qp = rtk_u(J.qp); const char* __restrict__ const tp = rtk_u(J.tp);
+    const int m = rtk_u(J.m), n = rtk_u(J.n), qrev = rtk_u(J.qrev), trev = rtk_u(J.trev); const bool iupac = rtk_u(J.iupac) != 0;
+    uint64_t* const peq4 = rtk_u(J.peq4);
+    const int Wa = rtk_band_words(m, n, rtk_u(J.dlo));
+    const int lane = rtk_lane();
+    for (int w = lane; w < Wa; w += RTK_WAVE) { // the profile of every word that gets a column
+        uint64_t a, c, g, t; rtk_myers_eq4(qp, m, qrev, w, iupac, a, c, g, t);
+        peq4[4ull * w] = a; peq4[4ull * w + 1] = c; peq4[4ull * w + 2] = g; peq4[4ull * w + 3] = t;
+    }
+    bool plain = true;
+    for (int c0 = 0; c0 < n && plain; c0 += 64) {
+        const int cj = c0 + lane; bool okc = true;
+        if (cj < n) { const unsigned char ch = static_cast<unsigned char>(trev ? tp[n - 1 - cj] : tp[cj]); okc = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+        plain = (rtk_ballot(!okc) == 0ull);
+    }
+    rtk_sync(); // the profile words are read by other lanes than wrote them
+    if (plain) rtk_myers_ring_sweep<1>(J); else rtk_myers_ring_sweep<0>(J);
+    rtk_sync();
+}
+// work items of a pass: one for the ring, else its row blocks that have a column
+__device__ __forceinline__ bool rtk_pass_is_ring(int m, const RtkBand& band) { return rtk_band_gran(m, band.dlo, band.dhi) == 1; }
+__device__ __forceinline__ int rtk_pass_items(int m, int n, const RtkBand& band) { return rtk_pass_is_ring(m, band) ? 1 : ((rtk_band_words(m, n, band.dlo) + 63) >> 6); }
+__device__ __forceinline__ RtkCoopJob rtk_make_job(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, const RtkBand& band, uint64_t* fin_pv, uint64_t* fin_mv) {
+    RtkCoopJob j; j.qp = q.p; j.tp = t.p; j.m = q.n; j.n = t.n; j.qrev = q.rev; j.trev = t.rev; j.top_h = top_h; j.iupac = iupac ? 1 : 0;
+    j.fin_pv = fin_pv; j.fin_mv = fin_mv; j.carry = rtk_u(sc.carry); j.colscore = rtk_u(sc.colscore);
+    j.dlo = band.dlo; j.dhi = band.dhi; j.ring = rtk_pass_is_ring(q.n, band) ? 1 : 0; j.peq4 = rtk_u(sc.peq);
+    return j;
+}
 #endif
 
 #if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
@@ -584,19 +767,31 @@ __device__ __noinline__ void rtk_myers_block(const RtkCoopJob& J, int b, int* pr
 // waits for a lower-numbered one, and those are started first: no cycle), wave 0 continues when all helpers have reported.
 #define RTK_COOP_MAXB 512 // row blocks of all the passes of a round
 #define RTK_COOP_MAXJ 64  // passes of a round (two per Hirschberg sub-problem)
-struct RtkCoop { RtkCoopJob job[RTK_COOP_MAXJ]; int first[RTK_COOP_MAXJ + 1]; int node[RTK_COOP_MAXJ / 2][8]; int n_jobs, n_items, seq, n_done, exit_flag, n_waves; int progress[RTK_COOP_MAXB]; };
+struct RtkCoop { RtkCoopJob job[RTK_COOP_MAXJ]; int first[RTK_COOP_MAXJ + 1]; int node[RTK_COOP_MAXJ / 2][8]; int n_jobs, n_items, seq, n_done, exit_flag, n_waves, next_item; int progress[RTK_COOP_MAXB];
+                 // a round of leaf tracebacks (rtk_myers_alignment_bfs): every wave of the workgroup takes leaves, each with its own traceback table
+                 int leaf_mode, liupac; const char* lq; const char* lt; int32_t* llist; uint8_t* lmoves; MyersScratch* lsc; uint32_t lnm[16]; };
+__device__ __noinline__ void rtk_myers_leaf_item(RtkCoop* st, int wave, int x);
 __device__ __forceinline__ RtkCoop* rtk_coop() { __shared__ RtkCoop st; return &st; }
 
 __device__ __forceinline__ void rtk_myers_coop_run(RtkCoop* st, int wave) {
     // A round is a list of passes; pass j owns the row blocks first[j] .. first[j + 1) of the round's block list. Every wave takes its
     // indices in ascending order and a block only waits for index i - 1 (the block above it in its own pass): the lowest unfinished
     // index can always run, so nobody waits for ever.
-    const int nit = rtk_coop_ld(&st->n_items), nwv = rtk_coop_ld(&st->n_waves);
+    // Items are claimed in ascending order from a shared counter (their durations differ: a ring pass is a whole pass, a row block a slice of
+    // one): whoever holds item i - 1 is running, so the wait of a block for the one above it always ends.
+    const int nit = rtk_coop_ld(&st->n_items);
+    const bool leaves = rtk_coop_ld(&st->leaf_mode) != 0;
     int j = 0;
-    for (int i = wave; i < nit; i += nwv) {
+    for (;;) {
+        int i = 0;
+        if (rtk_lane() == 0) i = __hip_atomic_fetch_add(&st->next_item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= nit) break;
+        if (leaves) { rtk_myers_leaf_item(st, wave, i); continue; }
         while (i >= rtk_coop_ld(&st->first[j + 1])) ++j;
         const int f = rtk_coop_ld(&st->first[j]);
-        rtk_myers_block(st->job[j], i - f, st->progress + f);
+        if (rtk_coop_ld(&st->job[j].ring)) rtk_myers_ring(st->job[j]); // a banded pass on one wave
+        else rtk_myers_block(st->job[j], i - f, st->progress + f);
     }
 }
 
@@ -617,21 +812,21 @@ __device__ __forceinline__ void rtk_myers_coop_helper(int wave) {
 
 // program wave: publish one pass -- or two passes of the same query length (q2 != nullptr: the second one works on the columns behind
 // the first one's in the carry / score arrays) --, take part, wait for the helpers. Returns false when not worth sharing (caller runs them alone).
-__device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, uint64_t* fin_pv, uint64_t* fin_mv,
+__device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, const MySeq& q, const MySeq& t, int top_h, bool iupac, const RtkBand& band, uint64_t* fin_pv, uint64_t* fin_mv,
                                                     const MySeq* q2 = nullptr, const MySeq* t2 = nullptr, uint64_t* fin_pv2 = nullptr, uint64_t* fin_mv2 = nullptr) {
     RtkCoop* st = rtk_coop();
     const int nwv = rtk_coop_ld(&st->n_waves);
-    const int W = (q.n + 63) >> 6, B = (W + 63) >> 6, nj = q2 ? 2 : 1;
-    if (nwv < 2 || B * nj < 2 || B * nj > RTK_COOP_MAXB || (q2 && q2->n != q.n)) return false;
+    const int W = (q.n + 63) >> 6, nj = q2 ? 2 : 1;
+    const int it1 = rtk_pass_items(q.n, t.n, band), it2 = q2 ? rtk_pass_items(q2->n, t2->n, band) : 0;
+    if (nwv < 2 || it1 + it2 < 2 || it1 + it2 > RTK_COOP_MAXB || (q2 && q2->n != q.n)) return false;
+    if (static_cast<uint64_t>(8 * W + 8) > 15ull * sc.w_cap) return false; // two profile tables
     if (rtk_lane() == 0) {
-        RtkCoopJob j; j.qp = q.p; j.tp = t.p; j.m = q.n; j.n = t.n; j.qrev = q.rev; j.trev = t.rev; j.top_h = top_h; j.iupac = iupac ? 1 : 0;
-        j.fin_pv = fin_pv; j.fin_mv = fin_mv; j.carry = rtk_u(sc.carry); j.colscore = rtk_u(sc.colscore);
-        st->job[0] = j;
-        if (q2) { j.qp = q2->p; j.tp = t2->p; j.m = q2->n; j.n = t2->n; j.qrev = q2->rev; j.trev = t2->rev; j.fin_pv = fin_pv2; j.fin_mv = fin_mv2; j.carry += t.n; j.colscore += t.n; st->job[1] = j; }
-        st->n_jobs = nj; st->n_items = nj * B; st->first[0] = 0; st->first[1] = B; st->first[2] = 2 * B;
+        st->job[0] = rtk_make_job(sc, q, t, top_h, iupac, band, fin_pv, fin_mv);
+        if (q2) { RtkCoopJob j = rtk_make_job(sc, *q2, *t2, top_h, iupac, band, fin_pv2, fin_mv2); j.carry += t.n; j.colscore += t.n; j.peq4 += 4ull * W + 4; st->job[1] = j; }
+        st->n_jobs = nj; st->n_items = it1 + it2; st->first[0] = 0; st->first[1] = it1; st->first[2] = it1 + it2;
     }
-    for (int i = rtk_lane(); i < nj * B; i += RTK_WAVE) st->progress[i] = 0;
-    if (rtk_lane() == 0) st->n_done = 0;
+    for (int i = rtk_lane(); i < it1 + it2; i += RTK_WAVE) st->progress[i] = 0;
+    if (rtk_lane() == 0) { st->n_done = 0; st->next_item = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the strings of the pass (global memory) and the mailbox
     rtk_coop_st(&st->seq, rtk_coop_ld(&st->seq) + 1);
     rtk_myers_coop_run(st, 0);
@@ -644,7 +839,7 @@ __device__ __forceinline__ bool rtk_myers_pass_coop(const MyersScratch& sc, cons
 __device__ __forceinline__ void rtk_myers_round_coop(RtkCoop* st, int n_items) {
     const int nwv = rtk_coop_ld(&st->n_waves);
     for (int i = rtk_lane(); i < n_items; i += RTK_WAVE) st->progress[i] = 0;
-    if (rtk_lane() == 0) st->n_done = 0;
+    if (rtk_lane() == 0) { st->n_done = 0; st->next_item = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     rtk_coop_st(&st->seq, rtk_coop_ld(&st->seq) + 1);
     rtk_myers_coop_run(st, 0);
@@ -686,11 +881,10 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, MySeq q_, MySeq t_, int top_
 #else
     const int lane = rtk_lane();
 #ifdef RTK_MULTIWAVE
-    if (!store && rtk_myers_pass_coop(sc, q, t, top_h, iupac, fin_pv, fin_mv)) { rtk_sync(); return; } // several row blocks: shared with the helper waves of the workgroup
+    if (!store && rtk_myers_pass_coop(sc, q, t, top_h, iupac, rtk_band_full(), fin_pv, fin_mv)) { rtk_sync(); return; } // several row blocks: shared with the helper waves of the workgroup
 #endif
     if (!store && W > 64) { // several row blocks on this wave: the block sweep without branches in the step
-        RtkCoopJob j; j.qp = q.p; j.tp = t.p; j.m = m; j.n = n; j.qrev = q.rev; j.trev = t.rev; j.top_h = top_h; j.iupac = iupac ? 1 : 0;
-        j.fin_pv = fin_pv; j.fin_mv = fin_mv; j.carry = rtk_u(sc.carry); j.colscore = rtk_u(sc.colscore);
+        const RtkCoopJob j = rtk_make_job(sc, q, t, top_h, iupac, rtk_band_full(), fin_pv, fin_mv);
         for (int b = 0; b < ((W + 63) >> 6); ++b) rtk_myers_block(j, b, nullptr);
         rtk_sync();
         return;
@@ -790,6 +984,45 @@ RTK_FN void rtk_myers_pass(const MyersScratch& sc_, MySeq q_, MySeq t_, int top_
     rtk_sync();
 }
 
+RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, int m_, int n_, int32_t* out_, int dlo_ = -RTK_BAND_FULL, int dhi_ = RTK_BAND_FULL, int gran_ = 64);
+// NW pass (top row +1 per column) over the band [dlo, dhi] of diagonals only. Leaves the vertical deltas of every word at the word's last
+// column in fin_pv / fin_mv (both required) and returns the granularity of the schedule it took (1: ring, 64: row blocks), which
+// rtk_myers_column needs to tell the rows that are inside the band at the last column from the others.
+RTK_FN int rtk_myers_pass_banded(const MyersScratch& sc_, MySeq q_, MySeq t_, bool iupac_, int dlo_, int dhi_, uint64_t* fin_pv_, uint64_t* fin_mv_) {
+    const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc);
+    MySeq q, t; q.p = rtk_u(q_.p); q.n = rtk_u(q_.n); q.rev = rtk_u(q_.rev); t.p = rtk_u(t_.p); t.n = rtk_u(t_.n); t.rev = rtk_u(t_.rev);
+    const bool iupac = rtk_u(iupac_); uint64_t* fin_pv = rtk_u(fin_pv_); uint64_t* fin_mv = rtk_u(fin_mv_);
+    RtkBand band; band.dlo = rtk_u(dlo_); band.dhi = rtk_u(dhi_);
+    const int m = q.n, n = t.n, W = (m + 63) >> 6;
+    const int gran = rtk_band_gran(m, band.dlo, band.dhi);
+#ifdef RTK_SIM
+    // the simulator walks the band column by column with the same column ranges per word as the device schedules
+    const int last_bit = (m - 1) & 63, Wa = rtk_band_words(m, n, band.dlo);
+    rtk_myers_build_peq(sc, q, W, iupac);
+    for (int w = 0; w < Wa; ++w) { fin_pv[w] = ~0ull; fin_mv[w] = 0; }
+    for (int j = 0; j < n; ++j) {
+        const unsigned char tc = rtk_seq_at(t, j);
+        int hin = 1;
+        for (int w = 0; w < Wa; ++w) {
+            if (j < rtk_band_clo(w, band.dlo, gran) || j > rtk_band_chi(w, W, n, band.dhi, gran)) continue;
+            if (w > 0 && j > rtk_band_chi(w - 1, W, n, band.dhi, gran)) hin = 1; // nothing above any more: the row above the band grows by one per column
+            uint64_t Ph, Mh;
+            const uint64_t Eq = rtk_myers_eq_word(sc, q, W, w, tc);
+            hin = rtk_myers_step(fin_pv[w], fin_mv[w], Eq, hin, (w == W - 1) ? last_bit : 63, Ph, Mh);
+        }
+    }
+#else
+#ifdef RTK_MULTIWAVE
+    if (rtk_myers_pass_coop(sc, q, t, 1, iupac, band, fin_pv, fin_mv)) { rtk_sync(); return gran; }
+#endif
+    const RtkCoopJob j = rtk_make_job(sc, q, t, 1, iupac, band, fin_pv, fin_mv);
+    if (gran == 1) rtk_myers_ring(j);
+    else { const int nb = (rtk_band_words(m, n, band.dlo) + 63) >> 6; for (int b = 0; b < nb; ++b) rtk_myers_block(j, b, nullptr); }
+    rtk_sync();
+#endif
+    return gran;
+}
+
 struct MyersResult { int32_t dist, first, last, nloc; };
 
 // edlibAlign(..., TASK_DISTANCE): edit distance (or -1 if above a non-negative k), first and largest end location and
@@ -824,6 +1057,23 @@ RTK_FN MyersResult rtk_myers_distance(const MyersScratch& sc_, const char* q_, i
         }
     }
 #endif
+    if (mode == RTK_MODE_NW && m > 4096 && static_cast<uint32_t>(m) <= sc.r_cap && static_cast<uint64_t>(2 * ((m + 63) >> 6)) <= sc.tb_cap_words) {
+        // several row blocks: only the Ukkonen band of k (edlib.cpp:744-775). Unknown distance: a guess instead of edlib's doubling (:199-212) -- a score
+        // found inside a band is a real one, so when it exceeds the guess the band of that score holds the optimum and one more pass settles it.
+        const int W = (m + 63) >> 6;
+        uint64_t* fin = sc.tb; int32_t* col = sc.rowL;
+        { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; } // the table's memory holds the delta vectors
+        int kk = k >= 0 ? k : rtk_band_guess(m, n);
+        for (;;) {
+            const RtkBand band = rtk_band_nw(m, n, kk);
+            const int gran = rtk_myers_pass_banded(sc, rtk_seq(q, m), rtk_seq(t, n), iupac, band.dlo, band.dhi, fin, fin + W);
+            rtk_myers_column(fin, fin + W, m, n, col, band.dlo, band.dhi, gran);
+            const int d = rtk_ld(col + (m - 1));
+            if (d <= kk) { r.dist = d; r.first = r.last = n - 1; r.nloc = 1; if (locs_out && cap > 0) locs_out[0] = n - 1; return r; }
+            if (k >= 0) return r; // above k
+            kk = d;
+        }
+    }
     rtk_myers_pass(sc, rtk_seq(q, m), rtk_seq(t, n), mode == RTK_MODE_HW ? 0 : 1, iupac, 0, nullptr, nullptr);
     if (mode == RTK_MODE_NW) {
         const int d = sc.colscore[n - 1];
@@ -989,15 +1239,21 @@ RTK_FN void rtk_myers_traceback(const MyersScratch& sc_, MySeq q_, MySeq t_, boo
     { rtk_myers_pass(sc, q, t, 1, iupac, 1, nullptr, nullptr); cur = rtk_ld(rtk_ld(&sc.colscore) + (n - 1)); }
     rtk_myers_walk(sc, m, n, n, cur, n_moves);
 }
-RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, int m_, int n_, int32_t* out_) {
+// Scores of the last column of a pass from the vertical deltas it left behind: out[i] = D[i + 1][n] for the rows of the words that are
+// inside the band at the last column, RTK_BAND_INF for the others. A word parks its deltas at ITS last column; the row above the band
+// then grows by one per column, so the score at the top of word w in the last column is n + the sum of the column totals of the words
+// above it, whatever their last columns were (for a pass without a band: the usual prefix sum).
+RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, int m_, int n_, int32_t* out_, int dlo_, int dhi_, int gran_) {
     const uint64_t* fin_pv = rtk_u(fin_pv_); const uint64_t* fin_mv = rtk_u(fin_mv_); const int m = rtk_u(m_), n = rtk_u(n_); int32_t* out = rtk_u(out_);
-    const int W = (m + 63) >> 6;
+    const int dlo = rtk_u(dlo_), dhi = rtk_u(dhi_), gran = rtk_u(gran_);
+    const int W = (m + 63) >> 6, Wa = rtk_band_words(m, n, dlo);
     // word prefix: value at the top of word w = n + sum over previous words of (popc(P) - popc(M)) restricted to valid rows
     for (int w0 = 0, base = n; w0 < W; w0 += RTK_WAVE) {
         const int w = w0 + rtk_lane();
         int delta = 0;
         uint64_t pv = 0, mv = 0;
-        if (w < W) {
+        const bool have = w < Wa; // the word had a column
+        if (have) {
             pv = fin_pv[w]; mv = fin_mv[w];
             const int rows = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
             const uint64_t mask = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
@@ -1007,9 +1263,11 @@ RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, i
         int total;
         const int excl = rtk_wave_excl_scan(delta, &total);
         if (w < W) {
-            int v = base + excl;
             const int rows = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
-            for (int b = 0; b < rows; ++b) { v += static_cast<int>((pv >> b) & 1ull) - static_cast<int>((mv >> b) & 1ull); out[64 * w + b] = v; }
+            if (have && rtk_band_chi(w, W, n, dhi, gran) == n - 1) {
+                int v = base + excl;
+                for (int b = 0; b < rows; ++b) { v += static_cast<int>((pv >> b) & 1ull) - static_cast<int>((mv >> b) & 1ull); out[64 * w + b] = v; }
+            } else for (int b = 0; b < rows; ++b) out[64 * w + b] = RTK_BAND_INF;
         }
         base += total;
     }
@@ -1026,6 +1284,35 @@ RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, i
 // one is replaced by its two halves), so the last list is the sequence of leaf problems whose tracebacks, in order, are the alignment.
 // Lists: behind the final delta vectors in the traceback table's memory while the tree is built, in rowL for the leaf tracebacks
 // (which need the table). Returns false when the problem does not fit (nothing emitted: the caller walks depth first).
+// one leaf traceback of a leaf round, on whichever wave claimed it (its work area: st->lsc[wave]); leaves that do not fit a helper's
+// work area are left to the program wave (length stays -1)
+__device__ __noinline__ void rtk_myers_leaf_item(RtkCoop* st, int wave, int x) {
+    int32_t* const L = reinterpret_cast<int32_t*>(rtk_u(reinterpret_cast<unsigned long long>(st->llist)));
+    const char* const q = reinterpret_cast<const char*>(rtk_u(reinterpret_cast<unsigned long long>(st->lq)));
+    const char* const t = reinterpret_cast<const char*>(rtk_u(reinterpret_cast<unsigned long long>(st->lt)));
+    uint8_t* const mvs = reinterpret_cast<uint8_t*>(rtk_u(reinterpret_cast<unsigned long long>(st->lmoves)));
+    MyersScratch* const hs = reinterpret_cast<MyersScratch*>(rtk_u(reinterpret_cast<unsigned long long>(st->lsc))) + wave;
+    MyersScratch& h = *hs; RTK_ASSUME_LDS(&h);
+    const bool iupac = rtk_coop_ld(&st->liupac) != 0;
+    const int q0 = rtk_ld(L + 6 * x), qm = rtk_ld(L + 6 * x + 1), t0 = rtk_ld(L + 6 * x + 2), tn = rtk_ld(L + 6 * x + 3), off = rtk_ld(L + 6 * x + 5);
+    int len = -1;
+    if (qm == 0 || tn == 0) { rtk_wfill(mvs + off, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn)); len = qm + tn; } // edlib.cpp:1171-1178
+    else {
+        const long long W = (qm + 63) >> 6;
+        const bool fits = static_cast<uint64_t>(4 * W * tn) <= h.tb_cap_words && static_cast<uint32_t>(qm + tn) + 64u <= h.mv_cap && static_cast<uint32_t>(tn) <= h.t_cap && static_cast<uint32_t>(W) <= h.w_cap;
+        if (fits) {
+            h.moves = mvs + off;
+            uint32_t* const nm = &st->lnm[wave];
+            if (rtk_lane() == 0) *nm = 0;
+            rtk_sync();
+            rtk_myers_traceback(h, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, nm);
+            len = static_cast<int>(rtk_u(*nm));
+            if (rtk_ld(rtk_ld(&h.overflow)) != 0) len = -1; // (cannot happen after the fit test; the program wave does it again)
+        }
+    }
+    if (rtk_lane() == 0) L[6 * x + 4] = len;
+    rtk_sync();
+}
 __device__ __forceinline__ bool rtk_hb_is_leaf(int qm, int tn) { return qm == 0 || tn == 0 || (2LL * 8 + 4) * ((qm + 63) >> 6) * tn + 8LL * tn < 1024 * 1024; }
 __device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, const char* q, int m, const char* t, int n, int best, bool iupac, uint32_t* n_moves, int* best_out) {
     RtkCoop* st = rtk_coop();
@@ -1044,7 +1331,10 @@ __device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, con
     if (lane == 0) { cur[0] = 0; cur[1] = m; cur[2] = 0; cur[3] = n; cur[4] = best; cur[5] = 0; }
     RTK_WG_SYNC();
     int n_cur = 1;
+    int k_top = rtk_band_guess(m, n); // band of the one problem whose distance is not known (the whole one, when best < 0): see rtk_myers_alignment
+    uint64_t* const peq = rtk_ld(&sc.peq); const uint64_t peq_words = 15ull * rtk_ld(&sc.w_cap);
     for (;;) {
+        bool redo = false;
         // ---- slots of the next list: a leaf keeps one, a sub-problem that is split gets two (its halves, in order) ----
         int n_next = 0, n_split = 0;
         for (int c0 = 0; c0 < n_cur; c0 += RTK_WAVE) {
@@ -1061,7 +1351,7 @@ __device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, con
         RTK_WG_SYNC();
         if (n_split == 0) break;
         // ---- the passes of the sub-problems that are split, a round at a time ----
-        int rn = 0, items = 0; uint64_t fin_off = 0; bool bad = false;
+        int rn = 0, items = 0; uint64_t fin_off = 0, peq_off = 0; bool bad = false;
         auto run_round = [&]() {
             if (lane == 0) { st->n_jobs = 2 * rn; st->n_items = items; st->first[2 * rn] = items; }
             const unsigned long long t_p0 = rtk_clock();
@@ -1071,10 +1361,12 @@ __device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, con
                 const int q0 = rtk_coop_ld(&st->node[x][0]), qm = rtk_coop_ld(&st->node[x][1]), t0 = rtk_coop_ld(&st->node[x][2]), tn = rtk_coop_ld(&st->node[x][3]);
                 const int bs_in = rtk_coop_ld(&st->node[x][4]), slot = rtk_coop_ld(&st->node[x][5]), foff = rtk_coop_ld(&st->node[x][6]);
                 const int Wn = (qm + 63) >> 6, lh = tn / 2, rh = tn - lh;
+                const int kk = rtk_coop_ld(&st->node[x][7]);
+                const RtkBand band = rtk_band_nw(qm, tn, kk); const int gran = rtk_band_gran(qm, band.dlo, band.dhi);
                 uint64_t* const fin = tb + foff;
                 int32_t* const rl = rowL + q0; int32_t* const rr = rowR + q0;
-                rtk_myers_column(fin, fin + Wn, qm, lh, rl);
-                rtk_myers_column(fin + 2 * Wn, fin + 3 * Wn, qm, rh, rr);
+                rtk_myers_column(fin, fin + Wn, qm, lh, rl, band.dlo, band.dhi, gran);
+                rtk_myers_column(fin + 2 * Wn, fin + 3 * Wn, qm, rh, rr, band.dlo, band.dhi, gran);
                 RTK_WG_SYNC();
                 int bs = bs_in;
                 if (bs < 0) { // only the whole problem: the optimum = the smallest left + right sum over every split point
@@ -1084,6 +1376,7 @@ __device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, con
                     mn = rtk_u(mn);
                     const int e0 = lh + rtk_ld(rr + (qm - 1)), e1 = rtk_ld(rl + (qm - 1)) + rh;
                     mn = e0 < mn ? e0 : mn; mn = e1 < mn ? e1 : mn;
+                    if (mn > kk) { k_top = mn; redo = true; continue; } // a real score above the guess: the level again, with the band of that score
                     bs = mn;
                     if (best_out) *best_out = mn;
                 }
@@ -1108,7 +1401,7 @@ __device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, con
             }
             prof.hb_split += rtk_clock() - t_p1;
             RTK_WG_SYNC();
-            rn = 0; items = 0; fin_off = 0;
+            rn = 0; items = 0; fin_off = 0; peq_off = 0;
         };
         for (int c0 = 0; c0 < n_cur && !bad; c0 += RTK_WAVE) {
             const int i = c0 + lane; const bool valid = i < n_cur;
@@ -1118,42 +1411,77 @@ __device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, con
             while (todo && !bad) {
                 const int l = rtk_ffs(todo) - 1; todo &= todo - 1ull;
                 const int q0 = rtk_shfl(e[0], l), qm = rtk_shfl(e[1], l), t0 = rtk_shfl(e[2], l), tn = rtk_shfl(e[3], l), bs = rtk_shfl(e[4], l), slot = rtk_shfl(e[5], l);
-                const int Wn = (qm + 63) >> 6, Bn = (Wn + 63) >> 6, lh = tn / 2, rh = tn - lh;
-                if (lh == 0 || 2 * Bn > RTK_COOP_MAXB) { *sc.overflow = 1; bad = true; break; }
-                if (rn == RTK_COOP_MAXJ / 2 || items + 2 * Bn > RTK_COOP_MAXB) run_round();
+                const int Wn = (qm + 63) >> 6, lh = tn / 2, rh = tn - lh;
+                const int kk = bs >= 0 ? bs : k_top;
+                const RtkBand band = rtk_band_nw(qm, tn, kk);
+                const int itl = rtk_pass_items(qm, lh, band), itr = rtk_pass_items(qm, rh, band); // one item for a ring pass, the row blocks with a column otherwise
+                if (lh == 0 || itl + itr > RTK_COOP_MAXB || 8ull * static_cast<uint64_t>(Wn) > peq_words) { *sc.overflow = 1; bad = true; break; }
+                if (rn == RTK_COOP_MAXJ / 2 || items + itl + itr > RTK_COOP_MAXB || peq_off + 8ull * static_cast<uint64_t>(Wn) > peq_words) run_round();
                 if (bad) break;
                 if (lane == 0) {
                     uint64_t* const fin = tb + fin_off;
                     RtkCoopJob j; j.qp = q + q0; j.tp = t + t0; j.m = qm; j.n = lh; j.qrev = 0; j.trev = 0; j.top_h = 1; j.iupac = iupac ? 1 : 0;
                     j.fin_pv = fin; j.fin_mv = fin + Wn; j.carry = carry + t0; j.colscore = colscore + t0;
+                    j.dlo = band.dlo; j.dhi = band.dhi; j.ring = rtk_pass_is_ring(qm, band) ? 1 : 0; j.peq4 = peq + peq_off;
                     st->job[2 * rn] = j;
                     j.tp = t + t0 + lh; j.n = rh; j.qrev = 1; j.trev = 1; j.fin_pv = fin + 2 * Wn; j.fin_mv = fin + 3 * Wn; j.carry = carry + t0 + lh; j.colscore = colscore + t0 + lh;
+                    j.peq4 = peq + peq_off + 4ull * static_cast<uint64_t>(Wn);
                     st->job[2 * rn + 1] = j;
-                    st->first[2 * rn] = items; st->first[2 * rn + 1] = items + Bn;
-                    int* nd = st->node[rn]; nd[0] = q0; nd[1] = qm; nd[2] = t0; nd[3] = tn; nd[4] = bs; nd[5] = slot; nd[6] = static_cast<int>(fin_off);
+                    st->first[2 * rn] = items; st->first[2 * rn + 1] = items + itl;
+                    int* nd = st->node[rn]; nd[0] = q0; nd[1] = qm; nd[2] = t0; nd[3] = tn; nd[4] = bs; nd[5] = slot; nd[6] = static_cast<int>(fin_off); nd[7] = kk;
                 }
-                fin_off += 4ull * static_cast<uint64_t>(Wn); items += 2 * Bn; ++rn;
+                fin_off += 4ull * static_cast<uint64_t>(Wn); peq_off += 8ull * static_cast<uint64_t>(Wn); items += itl + itr; ++rn;
             }
         }
         if (rn && !bad) run_round();
         if (bad) { prof.hb_total += rtk_clock() - t_all0; return true; } // the overflow flag is set: the caller's caller retries or gives up, as with the depth-first driver
+        if (redo) continue; // (only ever the first level: the one problem without a known distance)
         { int32_t* x = cur; cur = nxt; nxt = x; } n_cur = n_next;
     }
-    // ---- leaf problems, in read order ----
+    // ---- leaf problems, in read order: every wave of the workgroup takes leaves (own traceback table each), the moves of leaf x go to
+    //      moves + (sum of the query and target lengths of the leaves before it) and are moved together afterwards ----
     for (int i = lane; i < 6 * n_cur; i += RTK_WAVE) rowL[i] = cur[i];
     RTK_WG_SYNC();
+    { int run = 0;
+      for (int c0 = 0; c0 < n_cur; c0 += RTK_WAVE) {
+          const int x = c0 + lane; const int len = x < n_cur ? rowL[6 * x + 1] + rowL[6 * x + 3] : 0;
+          int total; const int excl = rtk_wave_excl_scan(len, &total);
+          if (x < n_cur) { rowL[6 * x + 5] = run + excl; rowL[6 * x + 4] = -1; }
+          run += rtk_u(total);
+      } }
+    RTK_WG_SYNC();
+    const unsigned long long t_l0 = rtk_clock();
+    uint8_t* const mvs = rtk_ld(&sc.moves);
+    MyersScratch* const lsc = reinterpret_cast<MyersScratch*>(rtk_u(reinterpret_cast<unsigned long long>(st->lsc))); // work areas of the waves for leaf tracebacks (nullptr: none)
+    if (lsc) {
+        if (lane == 0) { st->lq = q; st->lt = t; st->liupac = iupac ? 1 : 0; st->llist = rowL; st->lmoves = mvs; st->n_items = n_cur; st->leaf_mode = 1; }
+        rtk_myers_round_coop(st, 0);
+        if (lane == 0) st->leaf_mode = 0;
+        RTK_WG_SYNC();
+    }
+    uint32_t total = 0;
     for (int x = 0; x < n_cur; ++x) {
-        const int q0 = rtk_ld(rowL + 6 * x), qm = rtk_ld(rowL + 6 * x + 1), t0 = rtk_ld(rowL + 6 * x + 2), tn = rtk_ld(rowL + 6 * x + 3);
-        if (qm == 0 || tn == 0) { // edlib.cpp:1171-1178
-            rtk_wfill(sc.moves + *n_moves, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn));
-            *n_moves += static_cast<uint32_t>(qm + tn);
+        const int q0 = rtk_ld(rowL + 6 * x), qm = rtk_ld(rowL + 6 * x + 1), t0 = rtk_ld(rowL + 6 * x + 2), tn = rtk_ld(rowL + 6 * x + 3), off = rtk_ld(rowL + 6 * x + 5);
+        int len = rtk_ld(rowL + 6 * x + 4);
+        if (len < 0) { // not done by the round (no helper scratch, or too big for a helper's): here, with this wave's own work area, straight to its final place
+            uint32_t nm = total;
+            if (qm == 0 || tn == 0) { rtk_wfill(mvs + nm, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn)); nm += static_cast<uint32_t>(qm + tn); } // edlib.cpp:1171-1178
+            else {
+                const long long W = (qm + 63) >> 6;
+                if (static_cast<uint64_t>(4 * W * tn) > tbw) { *sc.overflow = 1; break; }
+                // the leaves behind this one may already sit at their staging offsets: this leaf's moves must not run into them
+                // (total <= off always, and a traceback writes at most qm + tn moves)
+                rtk_myers_traceback(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, &nm);
+            }
+            if (rtk_ld(rtk_ld(&sc.overflow)) != 0) break;
+            total = nm;
             continue;
         }
-        const long long W = (qm + 63) >> 6;
-        if (static_cast<uint64_t>(4 * W * tn) > tbw) { *sc.overflow = 1; break; }
-        { const unsigned long long t0_ = rtk_clock(); rtk_myers_traceback(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, n_moves); prof.hb_leaf += rtk_clock() - t0_; }
-        if (rtk_ld(rtk_ld(&sc.overflow)) != 0) break;
+        if (static_cast<uint32_t>(off) != total && len > 0) { rtk_copy_lanes(mvs + total, mvs + off, static_cast<uint64_t>(len)); RTK_WG_SYNC(); }
+        total += static_cast<uint32_t>(len);
     }
+    *n_moves += total;
+    prof.hb_leaf += rtk_clock() - t_l0;
     prof.hb_total += rtk_clock() - t_all0;
     return true;
 }
@@ -1196,21 +1524,30 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
         }
         const int lh = tn / 2, rh = tn - lh;
         if (lh == 0 || static_cast<uint64_t>(4 * W) > sc.tb_cap_words || sp + 2 > 60) { *sc.overflow = 1; return; }
-        bool both = false;
-        const unsigned long long t_p0 = rtk_clock();
-#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
-        { const MySeq qa = rtk_seq(q + q0, qm), ta = rtk_seq(t + t0, lh), qb = rtk_seq(q + q0, qm, 1), tb_ = rtk_seq(t + t0 + lh, rh, 1); // the two half passes side by side on the waves of the workgroup
-          both = static_cast<uint32_t>(lh + rh) <= sc.t_cap && rtk_myers_pass_coop(sc, qa, ta, 1, iupac, fin, fin + W, &qb, &tb_, fin + 2 * W, fin + 3 * W);
-          if (both) rtk_sync(); }
-#endif
-        if (!both) rtk_myers_pass(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, lh), 1, iupac, 0, fin, fin + W);
-        if (!both) rtk_myers_pass(sc, rtk_seq(q + q0, qm, 1), rtk_seq(t + t0 + lh, rh, 1), 1, iupac, 0, fin + 2 * W, fin + 3 * W);
-        const unsigned long long t_p1 = rtk_clock(); prof.hb_pass += t_p1 - t_p0;
-        rtk_myers_column(fin, fin + W, qm, lh, sc.rowL);
-        rtk_myers_column(fin + 2 * W, fin + 3 * W, qm, rh, sc.rowR);
-        // R(i) = cost of aligning q[i..qm) with the right half = rowR[qm-1-i]
+        // The two half passes only sweep the Ukkonen band of the sub-problem's distance (the right one is the same band seen from the other
+        // corner: the band is symmetric under d -> (tn - qm) - d). The distance of the whole problem may be unknown (bs_in < 0): a guess,
+        // and a second round with the score the first one found when that score is above the guess.
+        int kk = bs_in >= 0 ? bs_in : rtk_band_guess(qm, tn);
         int bs_known = bs_in;
-        if (bs_known < 0) { // the optimum = the smallest left + right sum over every split point (rows 0 .. qm-2, the row -1 boundary, the last row)
+        for (;;) {
+            const RtkBand band = rtk_band_nw(qm, tn, kk);
+            const int gran = rtk_band_gran(qm, band.dlo, band.dhi);
+            bool both = false;
+            const unsigned long long t_p0 = rtk_clock();
+#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
+            { const MySeq qa = rtk_seq(q + q0, qm), ta = rtk_seq(t + t0, lh), qb = rtk_seq(q + q0, qm, 1), tb_ = rtk_seq(t + t0 + lh, rh, 1); // the two half passes side by side on the waves of the workgroup
+              both = static_cast<uint32_t>(lh + rh) <= sc.t_cap && rtk_myers_pass_coop(sc, qa, ta, 1, iupac, band, fin, fin + W, &qb, &tb_, fin + 2 * W, fin + 3 * W);
+              if (both) rtk_sync(); }
+#endif
+            if (!both) rtk_myers_pass_banded(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, lh), iupac, band.dlo, band.dhi, fin, fin + W);
+            if (!both) rtk_myers_pass_banded(sc, rtk_seq(q + q0, qm, 1), rtk_seq(t + t0 + lh, rh, 1), iupac, band.dlo, band.dhi, fin + 2 * W, fin + 3 * W);
+            const unsigned long long t_p1 = rtk_clock(); prof.hb_pass += t_p1 - t_p0;
+            rtk_myers_column(fin, fin + W, qm, lh, sc.rowL, band.dlo, band.dhi, gran);
+            rtk_myers_column(fin + 2 * W, fin + 3 * W, qm, rh, sc.rowR, band.dlo, band.dhi, gran);
+            prof.hb_split += rtk_clock() - t_p1;
+            if (bs_in >= 0) break;
+            // R(i) = cost of aligning q[i..qm) with the right half = rowR[qm-1-i]
+            // the optimum = the smallest left + right sum over every split point (rows 0 .. qm-2, the row -1 boundary, the last row)
             int mn = 0x7fffffff;
             for (int b0 = 0; b0 + 1 < qm; b0 += RTK_WAVE) { const int qi = b0 + rtk_lane(); if (qi + 1 < qm) { const int v = sc.rowL[qi] + sc.rowR[qm - 2 - qi]; mn = v < mn ? v : mn; } }
 #ifndef RTK_SIM
@@ -1219,9 +1556,10 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
             mn = rtk_u(mn);
             const int e0 = lh + sc.rowR[qm - 1], e1 = sc.rowL[qm - 1] + rh;
             mn = e0 < mn ? e0 : mn; mn = e1 < mn ? e1 : mn;
-            bs_known = mn;
-            if (best_out) *best_out = mn;
+            if (mn <= kk) { bs_known = mn; if (best_out) *best_out = mn; break; }
+            kk = mn; // a real score, above the guess: its band holds the optimum
         }
+        const unsigned long long t_p1 = rtk_clock();
         const int bs = bs_known;
         int split = -2;
         for (int b0 = 0; b0 + 1 < qm && split == -2; b0 += RTK_WAVE) {
@@ -1330,9 +1668,16 @@ RTK_FN bool rtk_myers_path_from_saved(const MyersScratch& sc_, const MyersSaved&
     return true;
 }
 
+// work area of a helper wave for the leaf tracebacks of a multi-wave alignment: a table of the in-memory traceback branch (< 1 MB by edlib's
+// count, edlib.cpp:1191-1193), one row block, the longest target / move list such a leaf can have with that
+struct ScratchCfg;
+// one problem of the stage entry rtk_myers_batch (offsets into one character pool)
+struct MyersProb { uint64_t q_off, t_off; uint32_t qlen, tlen; int32_t k, mode; };
+
 // ------------------------------------------------------------------------------------------------ work area of one wave
 struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };
 
+RTK_HD ScratchCfg rtk_leaf_cfg() { ScratchCfg c; c.w_cap = 64; c.t_cap = 37504; c.r_cap = 64; c.mv_cap = 53248; c.tb_cap_words = 4ull * 52429 + 64; return c; }
 RTK_HD uint64_t scratch_bytes(const ScratchCfg& c) {
     uint64_t b = 0;
     b += 8ull * 15 * c.w_cap; b += (c.t_cap + 63) / 64 * 64; b += 4ull * c.t_cap; b += 8ull * c.tb_cap_words; b += 8ull * c.r_cap;
