@@ -259,6 +259,8 @@ void* rtk_graph::phase_take(uint64_t bytes, uint64_t* got) {
     { std::lock_guard<std::mutex> lk(g_reserved_lock); // reserved ahead (rtk_reserve_second_pass): the smallest one that fits, but not one several times too big (those are the first pass's)
       int best = -1;
       for (size_t i = 0; i < g_reserved.size(); ++i) if (g_reserved[i].device == device && g_reserved[i].bytes >= bytes && g_reserved[i].bytes <= 4 * bytes + (1ull << 30) && (best < 0 || g_reserved[i].bytes < g_reserved[static_cast<size_t>(best)].bytes)) best = static_cast<int>(i);
+      if (best < 0) // nothing of a fitting size: any reserved slab that is large enough, before more memory is asked for next to the reservation
+          for (size_t i = 0; i < g_reserved.size(); ++i) if (g_reserved[i].device == device && g_reserved[i].bytes >= bytes && (best < 0 || g_reserved[i].bytes < g_reserved[static_cast<size_t>(best)].bytes)) best = static_cast<int>(i);
       if (best >= 0) { void* p = g_reserved[static_cast<size_t>(best)].p; *got = g_reserved[static_cast<size_t>(best)].bytes; g_reserved.erase(g_reserved.begin() + best); return p; } }
     *got = bytes; return rtk_dmalloc(bytes);
 }
@@ -413,7 +415,7 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
         cfg.w_cap = (max_q + 63) / 64 + 1; cfg.t_cap = max_t + 64; cfg.r_cap = max_q + 64; cfg.mv_cap = max_q + max_t + 64;
         cfg.tb_cap_words = std::max<uint64_t>(4ull * 52429 + 64, 4ull * cfg.w_cap + 64);
         const int grid = static_cast<int>(std::min<uint32_t>(n, static_cast<uint32_t>(default_grid() / 4 > 0 ? default_grid() / 4 : 1)));
-        const uint64_t stride = scratch_bytes(cfg) + (waves > 1 ? static_cast<uint64_t>(waves - 1) * scratch_bytes(rtk_leaf_cfg()) : 0ull); // + the leaf-traceback areas of the helper waves
+        const uint64_t stride = scratch_bytes(cfg) + (waves > 1 ? static_cast<uint64_t>((waves < RTK_LEAF_WAVES ? waves : RTK_LEAF_WAVES) - 1) * scratch_bytes(rtk_leaf_cfg()) : 0ull); // + the leaf-traceback areas of the helper waves
         const uint32_t cap_moves = want_path ? (max_q + max_t + 8) : 1;
         char* dpool = static_cast<char*>(rtk_dmalloc(pool.size() + 64));
         MyersProb* dprobs = static_cast<MyersProb*>(rtk_dmalloc(sizeof(MyersProb) * n));

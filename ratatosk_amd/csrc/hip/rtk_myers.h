@@ -469,6 +469,7 @@ RTK_HD int rtk_band_guess(int m, int n) {
     return g < m + n ? g : m + n;
 }
 
+struct RtkGangCtx { const char* q; const char* t; char* stage; uint64_t* peq; uint64_t* fin; int32_t* nodes; int n_nodes, iupac; }; // one round of gang sweeps (rtk_myers_lvl.h)
 struct RtkCoopJob { const char* qp; const char* tp; int m, n, qrev, trev, top_h, iupac; uint64_t* fin_pv; uint64_t* fin_mv; int8_t* carry; int32_t* colscore; int dlo, dhi, ring; uint64_t* peq4; };
 #ifndef RTK_SIM
 __device__ __forceinline__ int rtk_coop_ld(const int* p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
@@ -769,8 +770,11 @@ __device__ __forceinline__ RtkCoopJob rtk_make_job(const MyersScratch& sc, const
 #define RTK_COOP_MAXJ 64  // passes of a round (two per Hirschberg sub-problem)
 struct RtkCoop { RtkCoopJob job[RTK_COOP_MAXJ]; int first[RTK_COOP_MAXJ + 1]; int node[RTK_COOP_MAXJ / 2][8]; int n_jobs, n_items, seq, n_done, exit_flag, n_waves, next_item; int progress[RTK_COOP_MAXB];
                  // a round of leaf tracebacks (rtk_myers_alignment_bfs): every wave of the workgroup takes leaves, each with its own traceback table
+                 int n_gangs; RtkGangCtx gctx; // gang sweeps of a round (items 0 .. n_gangs - 1; the row blocks of the jobs follow)
+                 int n_leaf_waves; // waves that own a work area for leaf tracebacks (the others sit a leaf round out)
                  int leaf_mode, liupac; const char* lq; const char* lt; int32_t* llist; uint8_t* lmoves; MyersScratch* lsc; uint32_t lnm[16]; };
 __device__ __noinline__ void rtk_myers_leaf_item(RtkCoop* st, int wave, int x);
+__device__ __noinline__ void rtk_myers_gang(const RtkGangCtx& C_, int gang_);
 __device__ __forceinline__ RtkCoop* rtk_coop() { __shared__ RtkCoop st; return &st; }
 
 __device__ __forceinline__ void rtk_myers_coop_run(RtkCoop* st, int wave) {
@@ -781,6 +785,8 @@ __device__ __forceinline__ void rtk_myers_coop_run(RtkCoop* st, int wave) {
     // one): whoever holds item i - 1 is running, so the wait of a block for the one above it always ends.
     const int nit = rtk_coop_ld(&st->n_items);
     const bool leaves = rtk_coop_ld(&st->leaf_mode) != 0;
+    if (leaves && wave >= rtk_coop_ld(&st->n_leaf_waves)) return; // no work area for a traceback table
+    const int ng = leaves ? 0 : rtk_coop_ld(&st->n_gangs);
     int j = 0;
     for (;;) {
         int i = 0;
@@ -788,6 +794,8 @@ __device__ __forceinline__ void rtk_myers_coop_run(RtkCoop* st, int wave) {
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= nit) break;
         if (leaves) { rtk_myers_leaf_item(st, wave, i); continue; }
+        if (i < ng) { rtk_myers_gang(st->gctx, i); continue; }
+        i -= ng;
         while (i >= rtk_coop_ld(&st->first[j + 1])) ++j;
         const int f = rtk_coop_ld(&st->first[j]);
         if (rtk_coop_ld(&st->job[j].ring)) rtk_myers_ring(st->job[j]); // a banded pass on one wave
@@ -1274,16 +1282,10 @@ RTK_FN void rtk_myers_column(const uint64_t* fin_pv_, const uint64_t* fin_mv_, i
     rtk_sync();
 }
 
+#ifndef RTK_SIM
+#include "rtk_myers_lvl.h"
+#endif
 #if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
-// The same alignment with the sub-problems of a Hirschberg level side by side (multi-wave workgroups only). The depth-first driver
-// below runs the two half passes of ONE sub-problem at a time: a level of the recursion costs n/2 column steps whatever its number of
-// sub-problems, and below the first levels most waves of the workgroup have nothing to do. Here the tree is built level by level:
-// every sub-problem of a level that still needs a split contributes its two passes to a round (rtk_myers_round_coop: up to 64 passes /
-// 512 row blocks on the waves of the workgroup), then the program wave extracts the split columns and finds the split rows exactly as
-// the depth-first driver does. The list of a level keeps the sub-problems in read order (a finished one stays where it is, a split
-// one is replaced by its two halves), so the last list is the sequence of leaf problems whose tracebacks, in order, are the alignment.
-// Lists: behind the final delta vectors in the traceback table's memory while the tree is built, in rowL for the leaf tracebacks
-// (which need the table). Returns false when the problem does not fit (nothing emitted: the caller walks depth first).
 // one leaf traceback of a leaf round, on whichever wave claimed it (its work area: st->lsc[wave]); leaves that do not fit a helper's
 // work area are left to the program wave (length stays -1)
 __device__ __noinline__ void rtk_myers_leaf_item(RtkCoop* st, int wave, int x) {
@@ -1313,178 +1315,6 @@ __device__ __noinline__ void rtk_myers_leaf_item(RtkCoop* st, int wave, int x) {
     if (rtk_lane() == 0) L[6 * x + 4] = len;
     rtk_sync();
 }
-__device__ __forceinline__ bool rtk_hb_is_leaf(int qm, int tn) { return qm == 0 || tn == 0 || (2LL * 8 + 4) * ((qm + 63) >> 6) * tn + 8LL * tn < 1024 * 1024; }
-__device__ __noinline__ bool rtk_myers_alignment_bfs(const MyersScratch& sc, const char* q, int m, const char* t, int n, int best, bool iupac, uint32_t* n_moves, int* best_out) {
-    RtkCoop* st = rtk_coop();
-    if (rtk_coop_ld(&st->n_waves) < 2 || rtk_hb_is_leaf(m, n)) return false;
-    const int lane = rtk_lane();
-    const long long W0 = (m + 63) >> 6;
-    uint64_t* const tb = rtk_ld(&sc.tb);
-    const uint64_t tbw = rtk_ld(&sc.tb_cap_words), fin_words = 4ull * (static_cast<uint64_t>(W0) + RTK_COOP_MAXJ);
-    if (tbw < fin_words + 64) return false;
-    uint64_t cap = (tbw - fin_words) / 6; // two lists of `cap` nodes, 6 ints each, in the words behind the final vectors
-    if (cap > rtk_ld(&sc.r_cap) / 6u) cap = rtk_ld(&sc.r_cap) / 6u;
-    if (cap < 8) return false;
-    int32_t* cur = reinterpret_cast<int32_t*>(tb + fin_words); int32_t* nxt = cur + 6 * cap;
-    int8_t* const carry = rtk_ld(&sc.carry); int32_t* const colscore = rtk_ld(&sc.colscore); int32_t* const rowL = rtk_ld(&sc.rowL); int32_t* const rowR = rtk_ld(&sc.rowR);
-    MyersScratch& prof = const_cast<MyersScratch&>(sc); const unsigned long long t_all0 = rtk_clock();
-    if (lane == 0) { cur[0] = 0; cur[1] = m; cur[2] = 0; cur[3] = n; cur[4] = best; cur[5] = 0; }
-    RTK_WG_SYNC();
-    int n_cur = 1;
-    int k_top = rtk_band_guess(m, n); // band of the one problem whose distance is not known (the whole one, when best < 0): see rtk_myers_alignment
-    uint64_t* const peq = rtk_ld(&sc.peq); const uint64_t peq_words = 15ull * rtk_ld(&sc.w_cap);
-    for (;;) {
-        bool redo = false;
-        // ---- slots of the next list: a leaf keeps one, a sub-problem that is split gets two (its halves, in order) ----
-        int n_next = 0, n_split = 0;
-        for (int c0 = 0; c0 < n_cur; c0 += RTK_WAVE) {
-            const int i = c0 + lane; const bool valid = i < n_cur;
-            int e[5] = {0, 0, 0, 0, 0};
-            if (valid) for (int k = 0; k < 5; ++k) e[k] = cur[6 * i + k];
-            const bool leaf = valid && rtk_hb_is_leaf(e[1], e[3]);
-            int total; const int excl = rtk_wave_excl_scan(valid ? (leaf ? 1 : 2) : 0, &total);
-            const int pos = n_next + excl;
-            if (valid && static_cast<uint64_t>(pos) + 2 <= cap) { if (leaf) { for (int k = 0; k < 5; ++k) nxt[6 * pos + k] = e[k]; nxt[6 * pos + 5] = 0; } else cur[6 * i + 5] = pos; }
-            n_next += rtk_u(total); n_split += rtk_popc(rtk_ballot(valid && !leaf));
-        }
-        if (static_cast<uint64_t>(n_next) > cap) return false; // (nothing emitted yet)
-        RTK_WG_SYNC();
-        if (n_split == 0) break;
-        // ---- the passes of the sub-problems that are split, a round at a time ----
-        int rn = 0, items = 0; uint64_t fin_off = 0, peq_off = 0; bool bad = false;
-        auto run_round = [&]() {
-            if (lane == 0) { st->n_jobs = 2 * rn; st->n_items = items; st->first[2 * rn] = items; }
-            const unsigned long long t_p0 = rtk_clock();
-            rtk_myers_round_coop(st, items);
-            const unsigned long long t_p1 = rtk_clock(); prof.hb_pass += t_p1 - t_p0;
-            for (int x = 0; x < rn && !bad; ++x) {
-                const int q0 = rtk_coop_ld(&st->node[x][0]), qm = rtk_coop_ld(&st->node[x][1]), t0 = rtk_coop_ld(&st->node[x][2]), tn = rtk_coop_ld(&st->node[x][3]);
-                const int bs_in = rtk_coop_ld(&st->node[x][4]), slot = rtk_coop_ld(&st->node[x][5]), foff = rtk_coop_ld(&st->node[x][6]);
-                const int Wn = (qm + 63) >> 6, lh = tn / 2, rh = tn - lh;
-                const int kk = rtk_coop_ld(&st->node[x][7]);
-                const RtkBand band = rtk_band_nw(qm, tn, kk); const int gran = rtk_band_gran(qm, band.dlo, band.dhi);
-                uint64_t* const fin = tb + foff;
-                int32_t* const rl = rowL + q0; int32_t* const rr = rowR + q0;
-                rtk_myers_column(fin, fin + Wn, qm, lh, rl, band.dlo, band.dhi, gran);
-                rtk_myers_column(fin + 2 * Wn, fin + 3 * Wn, qm, rh, rr, band.dlo, band.dhi, gran);
-                RTK_WG_SYNC();
-                int bs = bs_in;
-                if (bs < 0) { // only the whole problem: the optimum = the smallest left + right sum over every split point
-                    int mn = 0x7fffffff;
-                    for (int b0 = 0; b0 + 1 < qm; b0 += RTK_WAVE) { const int qi = b0 + lane; if (qi + 1 < qm) { const int v = rl[qi] + rr[qm - 2 - qi]; mn = v < mn ? v : mn; } }
-                    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o, 64); mn = v < mn ? v : mn; }
-                    mn = rtk_u(mn);
-                    const int e0 = lh + rtk_ld(rr + (qm - 1)), e1 = rtk_ld(rl + (qm - 1)) + rh;
-                    mn = e0 < mn ? e0 : mn; mn = e1 < mn ? e1 : mn;
-                    if (mn > kk) { k_top = mn; redo = true; continue; } // a real score above the guess: the level again, with the band of that score
-                    bs = mn;
-                    if (best_out) *best_out = mn;
-                }
-                int split = -2;
-                for (int b0 = 0; b0 + 1 < qm && split == -2; b0 += RTK_WAVE) {
-                    const int qi = b0 + lane;
-                    const bool ok = (qi + 1 < qm) && (rl[qi] + rr[qm - 2 - qi] == bs);
-                    const uint64_t bal = rtk_ballot(ok);
-                    if (bal) split = b0 + rtk_ffs(bal) - 1;
-                }
-                int ls, rs;
-                if (split >= 0) { ls = rtk_ld(rl + split); rs = rtk_ld(rr + (qm - 2 - split)); }
-                else if (lh + rtk_ld(rr + (qm - 1)) == bs) { split = -1; ls = lh; rs = rtk_ld(rr + (qm - 1)); }
-                else if (rtk_ld(rl + (qm - 1)) + rh == bs) { split = qm - 1; ls = rtk_ld(rl + (qm - 1)); rs = rh; }
-                else { *sc.overflow = 2; bad = true; break; } // inconsistent optimum: cannot happen for a correct distance
-                const int ul = split + 1;
-                if (lane == 0) {
-                    int32_t* a = nxt + 6 * slot;
-                    a[0] = q0; a[1] = ul; a[2] = t0; a[3] = lh; a[4] = ls; a[5] = 0;
-                    a[6] = q0 + ul; a[7] = qm - ul; a[8] = t0 + lh; a[9] = rh; a[10] = rs; a[11] = 0;
-                }
-            }
-            prof.hb_split += rtk_clock() - t_p1;
-            RTK_WG_SYNC();
-            rn = 0; items = 0; fin_off = 0; peq_off = 0;
-        };
-        for (int c0 = 0; c0 < n_cur && !bad; c0 += RTK_WAVE) {
-            const int i = c0 + lane; const bool valid = i < n_cur;
-            int e[6] = {0, 0, 0, 0, 0, 0};
-            if (valid) for (int k = 0; k < 6; ++k) e[k] = cur[6 * i + k];
-            uint64_t todo = rtk_ballot(valid && !rtk_hb_is_leaf(e[1], e[3]));
-            while (todo && !bad) {
-                const int l = rtk_ffs(todo) - 1; todo &= todo - 1ull;
-                const int q0 = rtk_shfl(e[0], l), qm = rtk_shfl(e[1], l), t0 = rtk_shfl(e[2], l), tn = rtk_shfl(e[3], l), bs = rtk_shfl(e[4], l), slot = rtk_shfl(e[5], l);
-                const int Wn = (qm + 63) >> 6, lh = tn / 2, rh = tn - lh;
-                const int kk = bs >= 0 ? bs : k_top;
-                const RtkBand band = rtk_band_nw(qm, tn, kk);
-                const int itl = rtk_pass_items(qm, lh, band), itr = rtk_pass_items(qm, rh, band); // one item for a ring pass, the row blocks with a column otherwise
-                if (lh == 0 || itl + itr > RTK_COOP_MAXB || 8ull * static_cast<uint64_t>(Wn) > peq_words) { *sc.overflow = 1; bad = true; break; }
-                if (rn == RTK_COOP_MAXJ / 2 || items + itl + itr > RTK_COOP_MAXB || peq_off + 8ull * static_cast<uint64_t>(Wn) > peq_words) run_round();
-                if (bad) break;
-                if (lane == 0) {
-                    uint64_t* const fin = tb + fin_off;
-                    RtkCoopJob j; j.qp = q + q0; j.tp = t + t0; j.m = qm; j.n = lh; j.qrev = 0; j.trev = 0; j.top_h = 1; j.iupac = iupac ? 1 : 0;
-                    j.fin_pv = fin; j.fin_mv = fin + Wn; j.carry = carry + t0; j.colscore = colscore + t0;
-                    j.dlo = band.dlo; j.dhi = band.dhi; j.ring = rtk_pass_is_ring(qm, band) ? 1 : 0; j.peq4 = peq + peq_off;
-                    st->job[2 * rn] = j;
-                    j.tp = t + t0 + lh; j.n = rh; j.qrev = 1; j.trev = 1; j.fin_pv = fin + 2 * Wn; j.fin_mv = fin + 3 * Wn; j.carry = carry + t0 + lh; j.colscore = colscore + t0 + lh;
-                    j.peq4 = peq + peq_off + 4ull * static_cast<uint64_t>(Wn);
-                    st->job[2 * rn + 1] = j;
-                    st->first[2 * rn] = items; st->first[2 * rn + 1] = items + itl;
-                    int* nd = st->node[rn]; nd[0] = q0; nd[1] = qm; nd[2] = t0; nd[3] = tn; nd[4] = bs; nd[5] = slot; nd[6] = static_cast<int>(fin_off); nd[7] = kk;
-                }
-                fin_off += 4ull * static_cast<uint64_t>(Wn); peq_off += 8ull * static_cast<uint64_t>(Wn); items += itl + itr; ++rn;
-            }
-        }
-        if (rn && !bad) run_round();
-        if (bad) { prof.hb_total += rtk_clock() - t_all0; return true; } // the overflow flag is set: the caller's caller retries or gives up, as with the depth-first driver
-        if (redo) continue; // (only ever the first level: the one problem without a known distance)
-        { int32_t* x = cur; cur = nxt; nxt = x; } n_cur = n_next;
-    }
-    // ---- leaf problems, in read order: every wave of the workgroup takes leaves (own traceback table each), the moves of leaf x go to
-    //      moves + (sum of the query and target lengths of the leaves before it) and are moved together afterwards ----
-    for (int i = lane; i < 6 * n_cur; i += RTK_WAVE) rowL[i] = cur[i];
-    RTK_WG_SYNC();
-    { int run = 0;
-      for (int c0 = 0; c0 < n_cur; c0 += RTK_WAVE) {
-          const int x = c0 + lane; const int len = x < n_cur ? rowL[6 * x + 1] + rowL[6 * x + 3] : 0;
-          int total; const int excl = rtk_wave_excl_scan(len, &total);
-          if (x < n_cur) { rowL[6 * x + 5] = run + excl; rowL[6 * x + 4] = -1; }
-          run += rtk_u(total);
-      } }
-    RTK_WG_SYNC();
-    const unsigned long long t_l0 = rtk_clock();
-    uint8_t* const mvs = rtk_ld(&sc.moves);
-    MyersScratch* const lsc = reinterpret_cast<MyersScratch*>(rtk_u(reinterpret_cast<unsigned long long>(st->lsc))); // work areas of the waves for leaf tracebacks (nullptr: none)
-    if (lsc) {
-        if (lane == 0) { st->lq = q; st->lt = t; st->liupac = iupac ? 1 : 0; st->llist = rowL; st->lmoves = mvs; st->n_items = n_cur; st->leaf_mode = 1; }
-        rtk_myers_round_coop(st, 0);
-        if (lane == 0) st->leaf_mode = 0;
-        RTK_WG_SYNC();
-    }
-    uint32_t total = 0;
-    for (int x = 0; x < n_cur; ++x) {
-        const int q0 = rtk_ld(rowL + 6 * x), qm = rtk_ld(rowL + 6 * x + 1), t0 = rtk_ld(rowL + 6 * x + 2), tn = rtk_ld(rowL + 6 * x + 3), off = rtk_ld(rowL + 6 * x + 5);
-        int len = rtk_ld(rowL + 6 * x + 4);
-        if (len < 0) { // not done by the round (no helper scratch, or too big for a helper's): here, with this wave's own work area, straight to its final place
-            uint32_t nm = total;
-            if (qm == 0 || tn == 0) { rtk_wfill(mvs + nm, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn)); nm += static_cast<uint32_t>(qm + tn); } // edlib.cpp:1171-1178
-            else {
-                const long long W = (qm + 63) >> 6;
-                if (static_cast<uint64_t>(4 * W * tn) > tbw) { *sc.overflow = 1; break; }
-                // the leaves behind this one may already sit at their staging offsets: this leaf's moves must not run into them
-                // (total <= off always, and a traceback writes at most qm + tn moves)
-                rtk_myers_traceback(sc, rtk_seq(q + q0, qm), rtk_seq(t + t0, tn), iupac, &nm);
-            }
-            if (rtk_ld(rtk_ld(&sc.overflow)) != 0) break;
-            total = nm;
-            continue;
-        }
-        if (static_cast<uint32_t>(off) != total && len > 0) { rtk_copy_lanes(mvs + total, mvs + off, static_cast<uint64_t>(len)); RTK_WG_SYNC(); }
-        total += static_cast<uint32_t>(len);
-    }
-    *n_moves += total;
-    prof.hb_leaf += rtk_clock() - t_l0;
-    prof.hb_total += rtk_clock() - t_all0;
-    return true;
-}
 #endif
 
 // obtainAlignment (edlib.cpp:1164-1216) with the Hirschberg split of edlib.cpp:1234-1399 restated canonically:
@@ -1500,8 +1330,8 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
     *n_moves = 0;
     { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; }
     if (static_cast<uint32_t>(m + n) > sc.mv_cap || static_cast<uint32_t>((m + 63) >> 6) > sc.w_cap || static_cast<uint32_t>(n) > sc.t_cap || static_cast<uint32_t>(m) > sc.r_cap) { *sc.overflow = 1; return; }
-#if defined(RTK_MULTIWAVE) && !defined(RTK_SIM)
-    if (rtk_myers_alignment_bfs(sc, q, m, t, n, best, iupac, n_moves, best_out)) return; // level by level on the waves of the workgroup
+#ifndef RTK_SIM
+    if (rtk_myers_alignment_lvl(sc, q, m, t, n, best, iupac, n_moves, best_out)) return; // level by level, the half passes of a level side by side in the lanes (rtk_myers_lvl.h)
 #endif
     int32_t* st = sc.hstack;
     int sp = 0;
@@ -1677,6 +1507,7 @@ struct MyersProb { uint64_t q_off, t_off; uint32_t qlen, tlen; int32_t k, mode; 
 // ------------------------------------------------------------------------------------------------ work area of one wave
 struct ScratchCfg { uint32_t w_cap, t_cap, r_cap, mv_cap; uint64_t tb_cap_words; };
 
+#define RTK_LEAF_WAVES 8 // waves of a workgroup that take part in leaf rounds (the program wave + 7 helpers with a work area each)
 RTK_HD ScratchCfg rtk_leaf_cfg() { ScratchCfg c; c.w_cap = 64; c.t_cap = 37504; c.r_cap = 64; c.mv_cap = 53248; c.tb_cap_words = 4ull * 52429 + 64; return c; }
 RTK_HD uint64_t scratch_bytes(const ScratchCfg& c) {
     uint64_t b = 0;

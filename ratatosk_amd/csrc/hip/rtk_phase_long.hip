@@ -29,9 +29,9 @@ __global__ void __launch_bounds__(1024) k_phase_long(const LaunchCtx* L, GraphVi
     RtkCoop* st = rtk_coop();
     __shared__ RegionScratch hdr;
     __shared__ MyersScratch lsc[16]; // work areas of the waves for the leaf tracebacks of an alignment: [0] = the program wave's own, the helpers' behind the read program's area
-    if (threadIdx.x == 0) { st->seq = 0; st->n_done = 0; st->exit_flag = 0; st->next_item = 0; st->leaf_mode = 0; st->lsc = lsc; st->n_waves = static_cast<int>(blockDim.x) >> 6; }
+    if (threadIdx.x == 0) { st->seq = 0; st->n_done = 0; st->exit_flag = 0; st->next_item = 0; st->leaf_mode = 0; st->n_gangs = 0; st->lsc = lsc; st->n_leaf_waves = (static_cast<int>(blockDim.x) >> 6) < RTK_LEAF_WAVES ? (static_cast<int>(blockDim.x) >> 6) : RTK_LEAF_WAVES; st->n_waves = static_cast<int>(blockDim.x) >> 6; }
     char* const wg_base = scratch + static_cast<uint64_t>(blockIdx.x) * stride;
-    if (wave != 0) lsc[wave] = scratch_carve(wg_base + region_scratch_bytes(cfg) + static_cast<uint64_t>(wave - 1) * scratch_bytes(rtk_leaf_cfg()), rtk_leaf_cfg());
+    if (wave != 0 && wave < RTK_LEAF_WAVES) lsc[wave] = scratch_carve(wg_base + region_scratch_bytes(cfg) + static_cast<uint64_t>(wave - 1) * scratch_bytes(rtk_leaf_cfg()), rtk_leaf_cfg());
     __syncthreads(); // the only workgroup barrier of the kernel: every wave is here
     if (wave != 0) { rtk_myers_coop_helper(wave); return; }
     RegionScratch* sc = region_scratch_carve(wg_base, cfg, &hdr);
@@ -83,9 +83,9 @@ __global__ void __launch_bounds__(1024) k_myers_batch_waves(const MyersProb* pro
     RtkCoop* st = rtk_coop();
     __shared__ MyersScratch sc;
     __shared__ MyersScratch lsc[16];
-    if (threadIdx.x == 0) { st->seq = 0; st->n_done = 0; st->exit_flag = 0; st->next_item = 0; st->leaf_mode = 0; st->lsc = lsc; st->n_waves = static_cast<int>(blockDim.x) >> 6; }
+    if (threadIdx.x == 0) { st->seq = 0; st->n_done = 0; st->exit_flag = 0; st->next_item = 0; st->leaf_mode = 0; st->n_gangs = 0; st->lsc = lsc; st->n_leaf_waves = (static_cast<int>(blockDim.x) >> 6) < RTK_LEAF_WAVES ? (static_cast<int>(blockDim.x) >> 6) : RTK_LEAF_WAVES; st->n_waves = static_cast<int>(blockDim.x) >> 6; }
     char* const wg_base = scratch + static_cast<uint64_t>(blockIdx.x) * scratch_stride;
-    if (wave != 0) lsc[wave] = scratch_carve(wg_base + scratch_bytes(cfg) + static_cast<uint64_t>(wave - 1) * scratch_bytes(rtk_leaf_cfg()), rtk_leaf_cfg());
+    if (wave != 0 && wave < RTK_LEAF_WAVES) lsc[wave] = scratch_carve(wg_base + scratch_bytes(cfg) + static_cast<uint64_t>(wave - 1) * scratch_bytes(rtk_leaf_cfg()), rtk_leaf_cfg());
     __syncthreads(); // the only workgroup barrier of the kernel
     if (wave != 0) { rtk_myers_coop_helper(wave); return; }
     sc = scratch_carve(wg_base, cfg); lsc[0] = sc;

@@ -39,7 +39,7 @@
 struct Opt {
     std::vector<std::string> in_long, in_long_raw;
     std::string out, graph, udata;
-    int cores = 1, gpus = 0, workers_per_gpu = 3, k1 = 31, k2 = 63, max_qual = 40, trim = 0, rounds = 1;
+    int cores = 1, gpus = 0, workers_per_gpu = 0, k1 = 31, k2 = 63, max_qual = 40, trim = 0, rounds = 1;
     bool force_snp = false;
     double min_conf_snp = 0.9;
     size_t insert_sz = 500, w1 = 1000, w2 = 5000, batch_bases = 32u << 20;
@@ -50,7 +50,7 @@ static void usage() {
     fprintf(stderr, "Ratatosk (MI355X hot-path build)\n\nUsage: Ratatosk correct -1 -g <graph.fasta.gz> -d <unitig_data.rtsk> -l <long_reads> -o <out_prefix> [options]\n"
                     "  -c, --cores           number of host threads (default 1): index parsing, FASTQ formatting\n"
                     "      --gpus            number of GPUs to use (default: all visible)\n"
-                    "      --workers-per-gpu tickets in flight per GPU (default 3)\n"
+                    "      --workers-per-gpu tickets in flight per GPU (default 3; 6 with -2)\n"
                     "  -B, --batch-bases     long-read bases per ticket (default 32 Mi)\n"
                     "  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
@@ -88,12 +88,20 @@ static bool gzip_member(const std::string& in, std::string& out) { // one self-c
     z_stream zs; memset(&zs, 0, sizeof(zs));
     if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
     out.resize(deflateBound(&zs, in.size()) + 32);
-    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(in.data())); zs.avail_in = static_cast<uInt>(in.size());
-    zs.next_out = reinterpret_cast<Bytef*>(&out[0]); zs.avail_out = static_cast<uInt>(out.size());
-    const int rc = deflate(&zs, Z_FINISH);
-    out.resize(zs.total_out);
+    // zlib counts in 32 bits: a block of a big ticket (name + 2 x bases, -B has no upper bound) is fed and drained in pieces of at most 1 GiB
+    const size_t piece = static_cast<size_t>(1) << 30;
+    size_t ip = 0, op = 0; int rc = Z_OK;
+    do {
+        const size_t ni = std::min(piece, in.size() - ip), no = std::min(piece, out.size() - op);
+        zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(in.data())) + ip; zs.avail_in = static_cast<uInt>(ni);
+        zs.next_out = reinterpret_cast<Bytef*>(&out[0]) + op; zs.avail_out = static_cast<uInt>(no);
+        rc = deflate(&zs, ip + ni == in.size() ? Z_FINISH : Z_NO_FLUSH);
+        ip += ni - zs.avail_in; op += no - zs.avail_out;
+        if (rc == Z_BUF_ERROR && op == out.size()) break; // cannot happen with deflateBound
+    } while (rc == Z_OK || (rc == Z_BUF_ERROR && op < out.size()));
+    out.resize(op);
     deflateEnd(&zs);
-    return rc == Z_STREAM_END;
+    return rc == Z_STREAM_END && ip == in.size();
 }
 
 int main(int argc, char** argv) {
@@ -157,7 +165,7 @@ int main(int argc, char** argv) {
         if (hc && static_cast<unsigned>(opt.cores) > hc) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of threads cannot be greater than or equal to %u.\n", hc); return 0; }
     }
     if (opt.min_conf_snp < 0.0 || opt.min_conf_snp > 1.0) { fprintf(stderr, "Ratatosk::Ratatosk(): Minimum confidence threshold to correct a SNP must be in [0.0, 1.0].\n"); return 0; } // src/Ratatosk.cpp:366-376
-    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = 1;
+    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = opt.pass2 ? 6 : 3; // second pass: a ticket's launches are long and mostly narrow (its longest read, its biggest region): more of them in flight
     if (opt.batch_bases < 1) opt.batch_bases = 1;
 
     const int n_dev = rtk_n_devices();
@@ -179,7 +187,8 @@ int main(int argc, char** argv) {
     std::vector<std::thread> reservers;
     for (int w = 0; w < n_gpus; ++w) {
         if (!lrc) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
-        else for (int t = 0; t < opt.workers_per_gpu; ++t) reservers.emplace_back([w]() { rtk_reserve_second_pass(w, 1u, 16ull << 30, 18ull << 30); }); // a 32 Mi ticket of long reads: ~9-12 GB for the phasing step, 17 GB for its regions
+        else for (int t = 0; t < opt.workers_per_gpu; ++t) reservers.emplace_back([w, &opt]() { // a 32 Mi ticket of long reads: ~12 GB for the phasing step, ~9 GB for its regions
+            if (rtk_reserve_second_pass(w, 1u, 13ull << 30, 9ull << 30) != RTK_OK && opt.verbose) fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); });
     }
     { // ONE parse + flatten, ONE host image; the other GPUs get device-to-device copies of the flat buffers
         bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), k_graph, opt.cores, &graphs[0]) == RTK_OK;
