@@ -22,6 +22,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before torch / HIP initialise: streams of several tickets need hardware queues of their own (ROCm default: 4)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -99,6 +99,8 @@ int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n);
  * replicated to the others device-to-device (xGMI peer copies, one per flat buffer) -- the reference's worker threads likewise
  * share one graph (src/Ratatosk.cpp:618,727). The clone has no host image; release it with rtk_graph_free. */
 int rtk_n_devices(void); /* HIP devices visible to the process (0: every compute call fails with RTK_ERR_NO_DEVICE) */
+/* free and total bytes of a device's memory (hipMemGetInfo): a host driver sizes its number of tickets in flight with it */
+int rtk_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 int rtk_graph_clone_to_device(const rtk_graph* src, int device, rtk_graph** out);
 
 int rtk_graph_get_info(const rtk_graph* g, rtk_graph_info* info);

@@ -42,6 +42,11 @@ class RtkStats(C.Structure):
 _libs = {}
 
 
+# kernels of several tickets / streams only run side by side if the HIP runtime may open enough hardware queues (default 4 per process);
+# read when the runtime initialises, so it is set before the library is loaded (and only if the caller has not chosen a value)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+
 def load_library(path=None):
     """dlopen the extension; fails loudly when it has not been built (no silent fallback)."""
     path = path or LIB_PATH
@@ -76,6 +81,7 @@ def load_library(path=None):
     L.rtk_batch_fetch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
     L.rtk_batch_fetch_view.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]
     L.rtk_n_devices.restype = C.c_int
+    L.rtk_device_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rtk_graph_clone_to_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.rtk_batch_get_stats.argtypes = [C.c_void_p, C.POINTER(RtkStats)]
     L.rtk_batch_free.argtypes = [C.c_void_p]

@@ -184,6 +184,17 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
 }
 
 extern "C" int rtk_n_devices(void) { return rtk_device_count(); }
+extern "C" int rtk_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return rtk_fail(RTK_ERR_ARG, "rtk_device_memory: null argument");
+    if (rtk_device_count() <= device || device < 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_device_memory: no such HIP device");
+#ifdef RTK_SIM
+    *free_bytes = 64ull << 30; *total_bytes = 64ull << 30;
+#else
+    try { rtk_set_device(device); size_t fr = 0, tot = 0; rtk_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo"); *free_bytes = fr; *total_bytes = tot; }
+    catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
+#endif
+    return RTK_OK;
+}
 
 // One more replica of a resident graph on another GPU of the same process: the flat buffers go device to device (xGMI peers), the host
 // image is neither parsed again nor copied (reference counterpart: ONE graph shared by all worker threads, src/Ratatosk.cpp:618,727).

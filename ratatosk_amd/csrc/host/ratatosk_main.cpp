@@ -39,6 +39,7 @@
 struct Opt {
     std::vector<std::string> in_long, in_long_raw;
     std::string out, graph, udata;
+    bool workers_given = false;
     int cores = 1, gpus = 0, workers_per_gpu = 0, k1 = 31, k2 = 63, max_qual = 40, trim = 0, rounds = 1;
     bool force_snp = false;
     double min_conf_snp = 0.9;
@@ -50,7 +51,7 @@ static void usage() {
     fprintf(stderr, "Ratatosk (MI355X hot-path build)\n\nUsage: Ratatosk correct -1 -g <graph.fasta.gz> -d <unitig_data.rtsk> -l <long_reads> -o <out_prefix> [options]\n"
                     "  -c, --cores           number of host threads (default 1): index parsing, FASTQ formatting\n"
                     "      --gpus            number of GPUs to use (default: all visible)\n"
-                    "      --workers-per-gpu tickets in flight per GPU (default 3; 6 with -2)\n"
+                    "      --workers-per-gpu tickets in flight per GPU (default 3; with -2 up to 8, as many as the device memory holds)\n"
                     "  -B, --batch-bases     long-read bases per ticket (default 32 Mi)\n"
                     "  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
@@ -105,6 +106,9 @@ static bool gzip_member(const std::string& in, std::string& out) { // one self-c
 }
 
 int main(int argc, char** argv) {
+    // Every ticket in flight owns a HIP stream (the phasing step of the second pass three), and their kernels are mostly narrow (one long read,
+    // one big region): they only overlap if the runtime gives the streams hardware queues of their own. ROCm's default is 4 per process.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     Opt opt;
     if (argc <= 1 || !strcmp(argv[1], "--help")) { usage(); return 0; }
     if (!strcmp(argv[1], "--version")) { printf("%s\n", rtk_version()); return 0; }
@@ -148,7 +152,7 @@ int main(int argc, char** argv) {
             case 'v': opt.verbose = true; break;
             case 1001: opt.strip = true; break;
             case 1002: opt.gpus = atoi(optarg); break;
-            case 1003: opt.workers_per_gpu = atoi(optarg); break;
+            case 1003: opt.workers_per_gpu = atoi(optarg); opt.workers_given = true; break;
             case 's': fprintf(stderr, "Ratatosk::correct: short reads are only needed by `index` (not in scope); ignored\n"); break;
             default: usage(); return 0; // the reference returns 0 on option errors too (src/Ratatosk.cpp:1018)
         }
@@ -165,7 +169,7 @@ int main(int argc, char** argv) {
         if (hc && static_cast<unsigned>(opt.cores) > hc) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of threads cannot be greater than or equal to %u.\n", hc); return 0; }
     }
     if (opt.min_conf_snp < 0.0 || opt.min_conf_snp > 1.0) { fprintf(stderr, "Ratatosk::Ratatosk(): Minimum confidence threshold to correct a SNP must be in [0.0, 1.0].\n"); return 0; } // src/Ratatosk.cpp:366-376
-    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = opt.pass2 ? 6 : 3; // second pass: a ticket's launches are long and mostly narrow (its longest read, its biggest region): more of them in flight
+    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = opt.pass2 ? 8 : 3; // second pass: a ticket's launches are long and mostly narrow (its longest read, its biggest region): more of them in flight
     if (opt.batch_bases < 1) opt.batch_bases = 1;
 
     const int n_dev = rtk_n_devices();
@@ -187,7 +191,7 @@ int main(int argc, char** argv) {
     std::vector<std::thread> reservers;
     for (int w = 0; w < n_gpus; ++w) {
         if (!lrc) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
-        else for (int t = 0; t < opt.workers_per_gpu; ++t) reservers.emplace_back([w, &opt]() { // a 32 Mi ticket of long reads: ~12 GB for the phasing step, ~9 GB for its regions
+        else for (int t = 0; t < std::min(opt.workers_per_gpu, 4); ++t) reservers.emplace_back([w, &opt]() { // a 32 Mi ticket of long reads: ~12 GB for the phasing step, ~9 GB for its regions
             if (rtk_reserve_second_pass(w, 1u, 13ull << 30, 9ull << 30) != RTK_OK && opt.verbose) fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); });
     }
     { // ONE parse + flatten, ONE host image; the other GPUs get device-to-device copies of the flat buffers
@@ -198,6 +202,15 @@ int main(int argc, char** argv) {
         if (!ok) { fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join(); exit(1); }
     }
     for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join();
+    if (lrc && !opt.workers_given) { // second pass, tickets in flight not given: as many as the memory next to the graph image holds (~24 GB of work areas + ~4 GB of buffers each)
+        uint64_t fr = 0, tot = 0; int fit = opt.workers_per_gpu;
+        for (int w = 0; w < n_gpus; ++w) if (rtk_device_memory(w, &fr, &tot) == RTK_OK) {
+            const uint64_t reserved = static_cast<uint64_t>(std::min(opt.workers_per_gpu, 4)) * (22ull << 30);
+            const uint64_t avail = fr + reserved > tot / 8 ? fr + reserved - tot / 8 : 0;
+            fit = std::min<int>(fit, static_cast<int>(avail / (28ull << 30)));
+        }
+        opt.workers_per_gpu = std::max(2, fit);
+    }
     const long long t_load1 = now_us();
     rtk_opts ro; rtk_opts_default(graphs[0], &ro);
     ro.insert_sz = opt.insert_sz; ro.max_len_weak_region1 = opt.w1; ro.max_len_weak_region2 = opt.w2; ro.max_qual = opt.max_qual; ro.min_confidence_snp_corr = opt.min_conf_snp;
