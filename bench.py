@@ -36,7 +36,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--serial", action="store_true", help="run the two stages of every step back to back (no overlap between steps)")
-    ap.add_argument("--ref-len", type=int, default=5_000_000)
+    ap.add_argument("--ref-len", type=int, default=None, help="reference length; default: 5 Mb at N = 1 (configs[1]), 60 Mb at N > 1 (configs[2], the graph the multi-GPU run of BASELINE.json is quoted on)")
+    ap.add_argument("--het", type=float, default=None, help="heterozygous SNP rate of the diploid reference; default: 0 at N = 1 (configs[1]), 0.001 at N > 1 (configs[2])")
+    ap.add_argument("--config2", action="store_true", help="N = 1 on the configs[2] graph (60 Mb diploid): the first point of the scaling series measured on the same graph as N > 1")
     ap.add_argument("--batch-bases", type=int, default=64_000_000, help="long-read bases per step (per GPU)")
     ap.add_argument("--cpu-sample-bases", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -46,16 +48,22 @@ def parse():
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--plain-index", action="store_true", help="index without SNP annotations (like the reference's `index -F`); for A/B measurements only")
     ap.add_argument("--sim", action="store_true", help="CPU-only developer simulator + gloo (tests of the N>1 plumbing); never a benchmark")
-    return ap.parse_args()
+    a = ap.parse_args()
+    big = a.gpus > 1 or a.config2
+    if a.ref_len is None:
+        a.ref_len = 60_000_000 if big else 5_000_000
+    if a.het is None:
+        a.het = 0.001 if big else 0.0
+    return a
 
 
-def make_dataset(workdir, ref_len, lr_bases, snps=True):
+def make_dataset(workdir, ref_len, lr_bases, snps=True, het=0.0):
     """Seeded synthetic inputs + index in the reference's file formats."""
     bin_dir = os.path.join(ROOT, "ratatosk_amd", "bin")
     pre = os.path.join(workdir, "c2")
     lr_cov = max(1.0, float(lr_bases) / ref_len)
     subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "2", "--ref-len", str(ref_len), "--sr-cov", "30",
-                           "--sr-err", "0.005", "--lr-cov", "%.3f" % lr_cov, "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07"], stderr=subprocess.DEVNULL)
+                           "--sr-err", "0.005", "--lr-cov", "%.3f" % lr_cov, "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07"] + (["--het", "%g" % het] if het > 0 else []), stderr=subprocess.DEVNULL)
     # --snps: SNP annotations like the reference's default `index` step (detectSNPs runs unless -F, src/Ratatosk.cpp:1120-1127)
     r = subprocess.run([os.path.join(bin_dir, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + (["--snps"] if snps else []), stderr=subprocess.PIPE, text=True, check=True)
     for line in r.stderr.splitlines():
@@ -288,8 +296,8 @@ def main():
         t0 = time.time()
         # 30x of long reads (configs[1]) gives two tickets; with N ranks every rank gets two tickets of its OWN (2N distinct tickets:
         # the long-read coverage of the synthetic set grows with N, the graph and the per-rank work stay those of configs[1])
-        lr_bases = min(need_bases, max(30 * a.ref_len, int(2.05 * a.batch_bases * world))) if world > 1 else min(need_bases, 30 * a.ref_len)
-        pre = make_dataset(workdir, a.ref_len, lr_bases, snps=not a.plain_index)
+        lr_bases = int(2.3 * a.batch_bases * world) + 200_000 if world > 1 else min(need_bases, 30 * a.ref_len) # N > 1: at least 2 distinct tickets per rank (a ticket ends with the read that fills it)
+        pre = make_dataset(workdir, a.ref_len, lr_bases, snps=not a.plain_index, het=a.het)
         t_data = time.time() - t0
     else:
         pre, t_data = None, 0.0
@@ -299,10 +307,11 @@ def main():
         pre = box[0]
     fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
     t0 = time.time()
-    graph = rdist.load_graph_replicated(fa, rt, 31, rank, world, device, lib_path=lib_path)
+    repl = {}
+    graph = rdist.load_graph_replicated(fa, rt, 31, rank, world, device, lib_path=lib_path, report=repl)
     t_graph = time.time() - t0
     info = graph.info()
-    seqs, quals = read_long_reads(pre + ".lr.fq", need_bases)
+    seqs, quals = read_long_reads(pre + ".lr.fq", max(need_bases, int(2.3 * a.batch_bases * world) + 200_000) if world > 1 else need_bases)
     # batches by ticket: consecutive reads until >= batch_bases; rank r owns tickets r, r+N, ...
     tickets, cur_s, cur_q, cur = [], [], [], 0
     for s, q in zip(seqs, quals):
@@ -342,6 +351,13 @@ def main():
     for b in seq_b:
         done_bases += b.in_bases
         stats.append(b.stats())
+    # per-kernel times of a step on an otherwise idle GPU (after the clock has stopped): in the timed region two batches overlap, and the
+    # HIP-event span of the seed kernels of one then includes their wait for wave slots behind the other's persistent region kernel
+    stats_serial = []
+    if not a.serial:
+        for b in seq_b[:2]:
+            b.run(opts); stats_serial.append(b.stats())
+        sync()
     if world > 1:
         t = torch.tensor([dt, float(done_bases)], dtype=torch.float64, device="cpu" if a.sim else "cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -374,12 +390,16 @@ def main():
         traffic, traffic_src = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
-                    "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()}, "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")), "index_lookups_inexact_per_step": int(S("n_probes_inexact")), "index_slots_inexact_per_step": int(S("n_slots_inexact")), "k_regions_wave_cycle_share": {kk: round(S(kk) / max(1.0, S("cyc_total")), 3) for kk in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "cyc_walk")}, "alignment_moves_per_step": int(S("n_moves")), "k_regions_wave_ticks_per_step": int(S("cyc_total")), "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
+                    "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()},
+                    "kernel_ms_per_step_is": "HIP-event spans inside the timed region, where consecutive steps overlap on two streams: the spans of k_mask / k_inexact / k_finalize include waiting for wave slots behind the other step's persistent k_regions; kernel_ms_per_step_serial has the same kernels with one step at a time",
+                    "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in stats_serial) / len(stats_serial), 3) for k_, v in kern.items()} if stats_serial else None), "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")), "index_lookups_inexact_per_step": int(S("n_probes_inexact")), "index_slots_inexact_per_step": int(S("n_slots_inexact")), "k_regions_wave_cycle_share": {kk: round(S(kk) / max(1.0, S("cyc_total")), 3) for kk in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "cyc_walk")}, "alignment_moves_per_step": int(S("n_moves")), "k_regions_wave_ticks_per_step": int(S("cyc_total")), "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
         whole_alg = (8.0 * S("n_probes_exact") + 16.0 * (S("n_slots_exact") + S("n_slots_inexact")) + 40.0 * S("n_expand") + 4.0 * S("n_colour_elem") + 0.25 * S("n_path_base") + 4.0 * S("in_bases")) / max(1.0, S("in_bases"))
         out = {
             "metric": "corrected long-read bases/sec", "value": bases_all / dt_all if dt_all > 0 else 0.0, "unit": "bases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt_all / max(1, a.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[1]: k=31 first-pass correct, %.1f Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU" % (a.ref_len / 1e6, a.batch_bases),
+            "config": {"workload": ("configs[2]: k=31 first pass sharded across %d MI355X, %.1f Mb diploid random ref (%.2f %% het SNPs), 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU, >= 2 distinct tickets per GPU" % (world, a.ref_len / 1e6, 100 * a.het, a.batch_bases))
+                                   if (world > 1 or a.config2) else ("configs[1]: k=31 first-pass correct, %.1f Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU" % (a.ref_len / 1e6, a.batch_bases)),
+                       "graph_replication": repl or None,
                        "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated (one RCCL broadcast per flat buffer)" % world, "per_rank": per_rank,
                        "value_is": "kernel-resident throughput: batches packed and in HBM before the clock starts (the contract's definition); the host-buffer-to-host-buffer rate is host_inclusive, the file-to-file rate cli_file_to_file",
                        "alg_bytes_per_base": round(whole_alg, 1), "setup_s": {"data+index": round(t_data, 1), "graph_load+upload": round(t_graph, 1)}},

@@ -77,7 +77,8 @@ typedef struct rtk_stats {
 
 /* dbg.read(G.fasta.gz) + readGraphData(G.rtsk) (reference: src/Ratatosk.cpp:1087-1089; src/Graph.cpp:722-784).
  * Parses the unitig FASTA(.gz) and the .rtsk records, rebuilds the k-mer index (the .bfi file is ignored),
- * flattens everything to SoA/CSR arrays. k must be odd and <= 31 (pass-1 scope). */
+ * flattens everything to SoA/CSR arrays. k must be odd and <= 63: one-word k-mers (k <= 31) serve both passes, two-word k-mers
+ * (33 .. 63) the second pass only (long_read_correct = 1; the 1-edit anchor search of the first pass is built on one-word k-mers). */
 int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out);
 
 /* Copies the flat graph into HBM of `device` (HIP device ordinal). Must precede any compute call. */

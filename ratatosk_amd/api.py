@@ -105,10 +105,12 @@ def _b(s):
 class Graph:
     """The compacted coloured de Bruijn graph, loaded from the reference's index files and resident in HBM."""
 
-    def __init__(self, fasta_gz, rtsk, k=31, device=0, lib_path=None, upload=True):
+    def __init__(self, fasta_gz, rtsk, k=31, device=0, lib_path=None, upload=True, n_threads=None):
         self.L = load_library(lib_path)
         self.h = C.c_void_p()
-        self._check(self.L.rtk_graph_load(_b(fasta_gz), _b(rtsk), k, 1, C.byref(self.h)))
+        if n_threads is None:  # parse + flatten on the host's threads (same image whatever their number)
+            n_threads = max(1, min(32, os.cpu_count() or 1))
+        self._check(self.L.rtk_graph_load(_b(fasta_gz), _b(rtsk), k, n_threads, C.byref(self.h)))
         self.k = k
         if upload:
             self._check(self.L.rtk_graph_upload(self.h, device))

@@ -8,10 +8,15 @@ import ctypes as C
 from . import api
 
 
-def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None):
-    """Returns an api.Graph whose HBM image is valid on `device` of every rank."""
+def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None, report=None, n_threads=None):
+    """Returns an api.Graph whose HBM image is valid on `device` of every rank. report (a dict, optional) receives on rank 0 what the
+    replication cost: parse + flatten seconds and threads, bytes and seconds of every broadcast."""
+    import os
+    import time
+    if n_threads is None:  # rank 0 parses and flattens alone while the others wait: it may use the host's threads
+        n_threads = max(1, min(64, os.cpu_count() or 1))
     if world <= 1:
-        return api.Graph(fasta_gz, rtsk, k, device=device, lib_path=lib_path)
+        return api.Graph(fasta_gz, rtsk, k, device=device, lib_path=lib_path, n_threads=n_threads)
     import torch
     import torch.distributed as dist
     L = api.load_library(lib_path)
@@ -22,7 +27,9 @@ def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None)
     g = api.Graph.__new__(api.Graph)
     g.L, g.k, g.h = L, k, C.c_void_p()
     if rank == 0:
-        g._check(L.rtk_graph_load(api._b(fasta_gz), api._b(rtsk), k, 1, C.byref(g.h)))
+        t0 = time.time()
+        g._check(L.rtk_graph_load(api._b(fasta_gz), api._b(rtsk), k, n_threads, C.byref(g.h)))
+        t_load = time.time() - t0
         g._check(L.rtk_graph_buffer_bytes(g.h, sizes, n_buf))
         g._check(L.rtk_graph_get_info(g.h, C.byref(info)))
         meta = [[int(sizes[i]) for i in range(n_buf)], bytes(info)]
@@ -40,10 +47,17 @@ def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None)
     g._check(L.rtk_graph_attach_buffers(g.h, device, ptrs, sizes, n_buf, C.byref(info)))
     if rank == 0:
         g._check(L.rtk_graph_upload(g.h, device))  # host image -> the attached buffers
+    secs = []
     for t in tensors:  # one large contiguous broadcast per buffer; ring/tree over xGMI is per-link bound
+        t0 = time.time()
         dist.broadcast(t, src=0)
-    if not sim:
-        torch.cuda.synchronize()
+        if not sim:
+            torch.cuda.synchronize()
+        secs.append(time.time() - t0)
+    if report is not None and rank == 0:
+        tot_b, tot_s = sum(int(sizes[i]) for i in range(n_buf)), sum(secs)
+        report.update({"ranks": world, "load_flatten_s": round(t_load, 3), "load_threads": n_threads, "bytes_per_buffer": [int(sizes[i]) for i in range(n_buf)],
+                       "broadcast_s_per_buffer": [round(x, 5) for x in secs], "broadcast_total_s": round(tot_s, 4), "broadcast_GBps": round(tot_b / tot_s / 1e9, 2) if tot_s > 0 else None})
     if rank != 0:
         g._check(L.rtk_graph_adopt_device(g.h))
     g._tensors = tensors  # keep the HBM buffers alive as long as the graph

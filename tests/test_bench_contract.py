@@ -39,3 +39,34 @@ def test_bench_line_two_ranks(tmp_path):
     pr = d["config"]["per_rank"]
     assert sorted(p["rank"] for p in pr) == [0, 1] and all(p["bases"] > 0 for p in pr)
     assert abs(d["value"] - sum(p["bases"] for p in pr) / max(p["seconds"] for p in pr)) / d["value"] < 0.05  # whole-job rate: all ranks' bases over the slowest rank's time
+
+
+def test_bench_line_eight_ranks_is_the_configs2_run(tmp_path):
+    """`--gpus 8` as the driver launches it (8 ranks; here gloo + the simulator, a reduced reference): the line a SCALE record would be made of.
+    N > 1 is the configs[2] run (diploid graph, >= 2 distinct tickets per rank, per-rank bases, the broadcast of every flat buffer timed)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29537",
+           os.path.join(ROOT, "bench.py"), "--gpus", "8"] + SMALL + ["--workdir", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    _check_common(d, 8)
+    assert d["config"]["workload"].startswith("configs[2]") and "diploid" in d["config"]["workload"]
+    pr = d["config"]["per_rank"]
+    assert sorted(p["rank"] for p in pr) == list(range(8)) and all(p["bases"] > 0 and p["distinct_tickets"] >= 2 and not p["shared_tickets"] for p in pr)
+    rep = d["config"]["graph_replication"]
+    assert rep["ranks"] == 8 and len(rep["bytes_per_buffer"]) == len(rep["broadcast_s_per_buffer"]) >= 19 and rep["load_threads"] >= 1
+    assert abs(d["value"] - sum(p["bases"] for p in pr) / max(p["seconds"] for p in pr)) / d["value"] < 0.05
+
+
+def test_default_graph_of_the_multi_gpu_run():
+    """Without --ref-len, N > 1 (and --config2) take the configs[2] reference: 60 Mb, 0.1 % heterozygous SNPs; N = 1 stays configs[1]."""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]; a = bench.parse(); assert (a.ref_len, a.het) == (5_000_000, 0.0)
+        sys.argv = ["bench.py", "--gpus", "8"]; a = bench.parse(); assert (a.ref_len, a.het) == (60_000_000, 0.001)
+        sys.argv = ["bench.py", "--config2"]; a = bench.parse(); assert (a.ref_len, a.het) == (60_000_000, 0.001)
+        sys.argv = ["bench.py", "--gpus", "4", "--ref-len", "1000"]; a = bench.parse(); assert a.ref_len == 1000
+    finally:
+        sys.argv = old

@@ -57,15 +57,16 @@ def test_config0_device_program_on_simulator(config0):
         assert zlib.crc32((w[0] + "\n" + w[1]).encode()) == GOLD0["read_crc32"][i], "read %d" % i
 
 
-def test_config0_cli_on_simulator_with_three_replicas(config0, tmp_path):
+@pytest.mark.parametrize("n_dev", [3, 8])
+def test_config0_cli_on_simulator_with_three_replicas(config0, tmp_path, n_dev):
     """The C++ host driver (reader thread, tickets, 3 workers per GPU, ordered writer, ONE index parse + device-to-device replicas)
-    linked against the simulator with three pretend GPUs: OUT.2.fastq is the frozen configs[0] file byte for byte."""
+    linked against the simulator with three / eight pretend GPUs (a node's worth): OUT.2.fastq is the frozen configs[0] file byte for byte."""
     out = str(tmp_path / "out")
-    env = dict(os.environ, RTK_SIM_DEVICES="3")
-    r = subprocess.run([os.path.join(ROOT, "tests", "hostsim", "Ratatosk_sim"), "correct", "-1", "-v", "-c", "2", "--gpus", "3", "-B", "70000", "-g", config0 + ".index.k31.fasta.gz",
+    env = dict(os.environ, RTK_SIM_DEVICES=str(n_dev))
+    r = subprocess.run([os.path.join(ROOT, "tests", "hostsim", "Ratatosk_sim"), "correct", "-1", "-v", "-c", "2", "--gpus", str(n_dev), "-B", "40000", "-g", config0 + ".index.k31.fasta.gz",
                         "-d", config0 + ".index.k31.rtsk", "-l", config0 + ".lr.fq", "-o", out], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
-    assert "on 3 GPU(s)" in r.stdout
+    assert "on %d GPU(s)" % n_dev in r.stdout
     assert hashlib.sha256(open(out + ".2.fastq", "rb").read()).hexdigest() == GOLD0["fastq_sha256"]
 
 
