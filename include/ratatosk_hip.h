@@ -51,6 +51,12 @@ typedef struct rtk_opts {
     int32_t long_read_correct;      /* 0 = pass 1 */
     int32_t force_unres_snp_corr;   /* -f (src/Ratatosk.cpp:279): second pass only, fixSNPs() (src/Alignment.cpp:846-965) on every read before phasing() (src/Ratatosk.cpp:828) */
     uint64_t max_len_weak_region2;  /* -W, 5000 (src/Common.hpp:110) */
+    /* Bifrost assumption [A2] as a switch (the reference calls searchSequence(l_s, false, true, true, true, or_exclusive_match = true),
+     * src/Graph.cpp:193, and Bifrost is not in the tree): 0 = every graph k-mer one substitution / insertion / deletion away from a window is
+     * reported (union of the three searches); 1 = the searches run substitution -> insertion -> deletion and a window that one of them
+     * matched is not searched by the next. rtk_opts_default takes it from the environment: RTK_A2_XOR=union (default) | exclusive. */
+    int32_t a2_exclusive;
+    int32_t reserved0;
 } rtk_opts;
 
 typedef struct rtk_graph_info {

@@ -19,6 +19,7 @@ struct OptsView {
     // second pass (`correct -2`, long_read_correct in the reference): qualities of pass 1 are carried over, no 1-edit search
     U<int32_t> long_read_correct;
     U<uint32_t> max_len_weak_region2;
+    U<uint32_t> a2_exclusive; // [A2] switch (rtk_opts::a2_exclusive): 1 = a window matched by one kind of edit is not searched with the next kind
 };
 
 struct BatchView {
@@ -293,6 +294,10 @@ RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView
 // One tile = 64 consecutive base positions; every candidate window of the tile is expanded by the whole wave into its
 // 93 substitution + 124 "insertion" + 29 "deletion" variants (one variant per lane per round), each probed in the k-mer table.
 #define RTK_N_VARIANTS 246
+// kinds of 1-edit relation between a window and a graph k-mer ([A2] switch: rtk_opts::a2_exclusive)
+#define RTK_EDIT_SUB 1u
+#define RTK_EDIT_INS 2u
+#define RTK_EDIT_DEL 4u
 
 // variant v (0..245) of the window whose first k-1 / k / k+1 characters are (w_k1, w_ck, w_ck1): 2-bit code of the graph k-mer to look for
 RTK_DEV bool rtk_variant_code(int v, int k, uint64_t w_k1, uint32_t w_ck, uint32_t w_ck1, uint64_t* code_out) {
@@ -333,7 +338,8 @@ RTK_DEV bool rtk_variant_code(int v, int k, uint64_t w_k1, uint32_t w_ck, uint32
 struct PoolChunk { unsigned long long base; uint32_t left; }; // wave-private slice of the raw-hit pool (one device atomic per 4096 entries)
 #define RTK_POOL_CHUNK 4096u
 
-RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk) {
+RTK_DEV uint32_t rtk_variant_kind(int v) { return v < 93 ? RTK_EDIT_SUB : (v < 217 ? RTK_EDIT_INS : RTK_EDIT_DEL); }
+RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, bool exclusive) {
     const int k = g.k;
 #ifndef RTK_SIM
     const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
@@ -405,12 +411,13 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
 #ifdef RTK_SIM
         while (bal) { // simulator: one lane walks all variants of its window
             bal &= bal - 1ull;
-            uint64_t sim_code[RTK_N_VARIANTS], sim_hit[RTK_N_VARIANTS]; int total = 0; uint32_t probes = 0, slots = 0;
+            uint64_t sim_code[RTK_N_VARIANTS], sim_hit[RTK_N_VARIANTS]; uint32_t sim_kind[RTK_N_VARIANTS]; int total = 0; uint32_t probes = 0, slots = 0, any = 0;
             for (int v = 0; v < RTK_N_VARIANTS; ++v) {
                 uint64_t code; uint64_t hit = RTK_NO_HIT;
                 if (rtk_variant_code(v, k, c_k1, ck, ck1, &code)) { uint32_t np; hit = rtk_find_kmer(g, code, &np); probes += 1; slots += np; }
-                if (hit != RTK_NO_HIT) { sim_code[total] = code; sim_hit[total] = hit; ++total; }
+                if (hit != RTK_NO_HIT) { sim_code[total] = code; sim_hit[total] = hit; sim_kind[total] = rtk_variant_kind(v); any |= sim_kind[total]; ++total; }
             }
+            if (exclusive && total) { const uint32_t keep = any & (0u - any); int w2 = 0; for (int i = 0; i < total; ++i) if (sim_kind[i] & keep) { sim_code[w2] = sim_code[i]; sim_hit[w2] = sim_hit[i]; ++w2; } total = w2; }
             emit(bb, total, sim_code, sim_hit, total, probes, slots);
         }
 #else
@@ -448,7 +455,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
             }
         };
         auto stage_resolve = [&](const Win& wn, uint32_t pass, const uint64_t* skey, const uint64_t* sval) {
-            uint64_t my_code[4]; uint64_t my_hit[4]; int my_n = 0; uint32_t slots = 0; int total = 0;
+            uint64_t my_code[4]; uint64_t my_hit[4]; uint32_t my_kind[4]; int my_n = 0; uint32_t slots = 0; int total = 0; uint32_t any = 0;
             for (int rr = 0; rr < 4; ++rr) {
                 uint64_t hit = RTK_NO_HIT; uint64_t code = 0;
                 if ((pass >> rr) & 1u) {
@@ -460,8 +467,14 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
                     else if (skey[rr] != RTK_EMPTY_KEY) { uint32_t np; hit = rtk_table_lookup(g, can, hh + 1, q, &np); slots += np; } // collision: keep probing from the next slot
                 }
                 const uint64_t hb = rtk_ballot(hit != RTK_NO_HIT);
-                if (hit != RTK_NO_HIT) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; }
+                if (hit != RTK_NO_HIT) { my_code[my_n] = code; my_hit[my_n] = hit; my_kind[my_n] = rtk_variant_kind(rtk_lane() + 64 * rr); any |= my_kind[my_n]; ++my_n; }
                 total += rtk_popc(hb);
+            }
+            if (exclusive && total) { // [A2] exclusive: only the hits of the first kind of edit (substitution -> insertion -> deletion) that has one in this window
+                for (int o = 32; o > 0; o >>= 1) any |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(any), o, 64));
+                const uint32_t keep = any & (0u - any);
+                int w2 = 0; for (int i = 0; i < my_n; ++i) if (my_kind[i] & keep) { my_code[w2] = my_code[i]; my_hit[w2] = my_hit[i]; ++w2; }
+                my_n = w2; total = rtk_wave_sum(my_n);
             }
             emit(wn.w_b, total, my_code, my_hit, my_n, 0u, slots);
         };
@@ -503,32 +516,35 @@ RTK_DEV uint64_t rtk_pool_kmer(const GraphView& g, uint64_t gp, int k) { // 2-bi
 RTK_DEV int rtk_clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
 RTK_DEV int rtk_ctz64(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
 
-// is G one of the 1-edit variants of the window whose first k-1 characters are w_k1 (and ck, ck1 the next two, 4 = unusable)? (oracle: searchInexact)
-RTK_DEV bool rtk_one_edit(uint64_t G, int k, uint64_t w_k1, uint32_t ck, uint32_t ck1) {
+// which 1-edit variants of the window whose first k-1 characters are w_k1 (and ck, ck1 the next two, 4 = unusable) is G? (oracle: searchInexact)
+// bit 0 substitution, bit 1 graph k-mer has an extra base ("insertion"), bit 2 graph k-mer lacks a read base ("deletion"); 0 = none.
+// want = the kinds that matter to the caller: the tests stop at the first of them that holds when only "any" is asked for.
+RTK_DEV uint32_t rtk_one_edit(uint64_t G, int k, uint64_t w_k1, uint32_t ck, uint32_t ck1, bool all_kinds) {
     const uint64_t mk = (k < 32) ? ((1ull << (2 * k)) - 1ull) : ~0ull, mk1 = (1ull << (2 * (k - 1))) - 1ull;
+    uint32_t kinds = 0;
     if (ck <= 3) { // substitution: exactly one differing character
         const uint64_t x = (G ^ ((w_k1 << 2) | static_cast<uint64_t>(ck))) & mk;
-        if (rtk_popc((x | (x >> 1)) & 0x5555555555555555ull) == 1) return true;
+        if (rtk_popc((x | (x >> 1)) & 0x5555555555555555ull) == 1) { kinds |= RTK_EDIT_SUB; if (!all_kinds) return kinds; }
     }
     { // G = the k-1 read characters with one base inserted anywhere: common prefix + common suffix cover the k-1 characters
         const uint64_t xp = ((G >> 2) ^ w_k1) & mk1, xs = (G ^ w_k1) & mk1;
         const int lcp = xp ? (rtk_clz64(xp) - (64 - 2 * (k - 1))) / 2 : k - 1, lcs = xs ? rtk_ctz64(xs) / 2 : k - 1;
-        if (lcp + lcs >= k - 1) return true;
+        if (lcp + lcs >= k - 1) { kinds |= RTK_EDIT_INS; if (!all_kinds) return kinds; }
     }
     if (ck <= 3 && ck1 <= 3) { // G = the k+1 read characters without one interior character (offset 1..k-2)
         const uint64_t S = (w_k1 << 4) | (static_cast<uint64_t>(ck) << 2) | static_cast<uint64_t>(ck1);
         const uint64_t xp = (G ^ (S >> 2)) & mk, xs = (G ^ S) & mk;
         const int lcp = xp ? (rtk_clz64(xp) - (64 - 2 * k)) / 2 : k, lcs = xs ? rtk_ctz64(xs) / 2 : k;
         const int lo = (k - lcs) > 1 ? (k - lcs) : 1, hi = lcp < (k - 2) ? lcp : (k - 2);
-        if (lo <= hi) return true;
+        if (lo <= hi) kinds |= RTK_EDIT_DEL;
     }
-    return false;
+    return kinds;
 }
 
 // visits (code, hit) of every graph k-mer that is a 1-edit variant of the window and contains one of its seed h-mers; a k-mer reached
 // through two seeds is visited twice (the hits of a window are reduced to distinct k-mers downstream, src/Graph.cpp:201-216)
 template <class V>
-RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_t ck, uint32_t ck1, uint32_t* n_lookups, uint32_t* n_slots, V visit) {
+RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_t ck, uint32_t ck1, uint32_t* n_lookups, uint32_t* n_slots, bool all_kinds, V visit) { // visit(code, hit, kinds)
     const int h = (k - 1) / 2;
     const uint64_t hm = (1ull << (2 * h)) - 1ull;
     const uint64_t* const hx = g.hx; const uint64_t hx_mask = g.hx_mask; const uint64_t* const hxl = g.hxl; const uint64_t* const uoff = g.uoff;
@@ -558,7 +574,8 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
                 if (t < 0 || static_cast<uint64_t>(t) + static_cast<uint64_t>(k) > ulen) continue;
                 const uint64_t F = rtk_pool_kmer(g, u0 + static_cast<uint64_t>(t), k);
                 const uint64_t G = ori ? rtk_revcomp(F, k) : F;
-                if (rtk_one_edit(G, k, w_k1, ck, ck1)) visit(G, rtk_pack_hit(u, static_cast<uint32_t>(t), ori ? 0u : 1u));
+                const uint32_t kinds = rtk_one_edit(G, k, w_k1, ck, ck1, all_kinds);
+                if (kinds) visit(G, rtk_pack_hit(u, static_cast<uint32_t>(t), ori ? 0u : 1u), kinds);
             }
         }
     }
@@ -567,7 +584,7 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
 #ifndef RTK_SEED_REGS
 #define RTK_SEED_REGS 4 // distinct hits of a window kept in registers; windows with more take the counted slow path
 #endif
-RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk) {
+RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, bool exclusive) {
     const int k = g.k;
     const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
     uint32_t lo_tile = 0; // one scalar search per tile: largest r with roff[r] <= first base of the tile
@@ -599,18 +616,22 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
         }
         // pass 1: up to four distinct hits of the lane's window stay in registers
         uint64_t my_code[RTK_SEED_REGS], my_hit[RTK_SEED_REGS]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
-        if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, [&](uint64_t code, uint64_t hit) {
+        // [A2] exclusive: the kinds of edit are searched substitution -> insertion -> deletion and the first kind with a hit is the window's only one
+        uint32_t keep = 7u;
+        if (exclusive && cand) { uint32_t any = 0, l0 = 0, s0 = 0; rtk_seeded_window(g, k, c_k1, ck, ck1, &l0, &s0, true, [&](uint64_t, uint64_t, uint32_t kinds) { any |= kinds; }); keep = any & (0u - any); }
+        if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, exclusive, [&](uint64_t code, uint64_t hit, uint32_t kinds) {
+            if (!(kinds & keep)) return;
             for (int i = 0; i < my_n; ++i) if (my_hit[i] == hit) return;
             if (my_n < RTK_SEED_REGS) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; } else more = true;
         });
         *acc_probes += lookups; *acc_slots += slots;
         if (more) { // a window inside a repeat: count every visit, take a private slice of the pool, write them all
             uint32_t n_all = 0, l2 = 0, s2 = 0;
-            rtk_seeded_window(g, k, c_k1, ck, ck1, &l2, &s2, [&](uint64_t, uint64_t) { ++n_all; });
+            rtk_seeded_window(g, k, c_k1, ck, ck1, &l2, &s2, exclusive, [&](uint64_t, uint64_t, uint32_t kinds) { if (kinds & keep) ++n_all; });
             const unsigned long long pb = rtk_atomic_add(bv.ipool_top, static_cast<unsigned long long>(n_all));
             if (pb + n_all <= bv.ipool_cap && n_all < (1u << 24)) {
                 uint32_t w = 0;
-                rtk_seeded_window(g, k, c_k1, ck, ck1, &l2, &s2, [&](uint64_t code, uint64_t hit) { bv.ipool[2 * (pb + w)] = code; bv.ipool[2 * (pb + w) + 1] = hit; ++w; });
+                rtk_seeded_window(g, k, c_k1, ck, ck1, &l2, &s2, exclusive, [&](uint64_t code, uint64_t hit, uint32_t kinds) { if (!(kinds & keep)) return; bv.ipool[2 * (pb + w)] = code; bv.ipool[2 * (pb + w) + 1] = hit; ++w; });
                 bv.wdesc[bb] = (static_cast<uint64_t>(pb) << 24) | static_cast<uint64_t>(n_all);
                 rtk_atomic_add(bv.counters + RTK_CNT_HITS_INEXACT, static_cast<unsigned long long>(n_all));
             } else rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);

@@ -3,7 +3,7 @@
 Genome (k = 31): two 2 kb haplotypes that differ by ONE SNP (position 700: hapA 'A' / hapB 'C' after forcing) and by ONE copy of a
 12 bp tandem unit (hapA 8 copies at 1300, hapB 7). Short reads: error-free 2x100 bp pairs, insert 400, one pair every 5 bp on both
 haplotypes and both strands alternating -> the graph is exactly the de Bruijn graph of the two haplotypes (every k-mer seen >= 2x).
-Long reads: eleven hand-made reads, each built from a haplotype substring by the explicit edits listed in READS below; what each one
+Long reads: thirteen hand-made reads, each built from a haplotype substring by the explicit edits listed in READS below; what each one
 must come out as, and why, is worked out in tests/golden/toy/NOTE.md. expected.fastq is the oracle's output, frozen after the hand
 check; tests/test_toy_golden.py holds oracle AND HIP path to it and re-derives the hand-checkable parts independently.
 
@@ -87,6 +87,17 @@ def long_reads(hap_a, hap_b):
     t = rc(hap_a[900:1700]); R.append(("r8_revcomp_tandem_hapA", t, edit(t, [(100, "sub", other(t[100])), (650, "del", 1)])))
     t = hap_b[1000:1800]; R.append(("r9_tandem_hapB_two_errors", t, edit(t, [(250, "sub", other(t[250])), (500, "ins", "A")])))
     t = hap_a[300:1100]; R.append(("r10_error_cluster_over_snp", t, edit(t, [(385, "sub", other(t[385])), (405, "sub", other(t[405])), (425, "del", 1), (445, "sub", other(t[445]))])))
+    # r11 / r12: an interior region with NO exact k-mer for 557 windows (errors 25 bp apart from read 70 = hapA 450 to read 595 = hapA 975): wider than
+    # insert_sz = 500, so the stretch is searched for 1-edit k-mers (Graph.cpp:112-118,193) and the region, which runs from `left flank` over the
+    # bubble into `middle`, is corrected hop by hop over its weak anchors (Correction.cpp:609-651, extractSemiWeakPaths :3-157).
+    # r11: the 11th error sits ON the SNP (read 320 = hapA 700) with a base that is neither allele: one substitution away from the k-mers of BOTH
+    #      bubble branches -> two overlapping variants on different unitigs, keep_non_overlap drops both (Alignment.cpp:1103-1194).
+    # r12: the same construction 5 bp further right (no error on the SNP): every weak anchor survives.
+    t = hap_a[380:1080]
+    def third(c):  # a base that is neither c nor the other allele of the SNP
+        return [b for b in "ACGT" if b not in (c, "A", "C")][0]
+    R.append(("r11_weak_anchors_snp_conflict", t, edit(t, [(70 + 25 * j, "sub", third(t[70 + 25 * j]) if 70 + 25 * j == 320 else other(t[70 + 25 * j])) for j in range(22)])))
+    R.append(("r12_weak_anchors_hops", t, edit(t, [(75 + 25 * j, "sub", other(t[75 + 25 * j])) for j in range(22)])))
     return R
 
 

@@ -82,12 +82,13 @@ def test_gpu_config0_frozen_fastq_through_the_cli(config0, tmp_path):
     _check_config0([(g[1], g[2]) for g in got], [g[0] for g in got])
 
 
-def _sized(tmp, name, sim_args, index_args, sample_bases, skip_bases=0):
+def _sized(tmp, name, sim_args, index_args, sample_bases, skip_bases=0, keep_short_reads=False):
     t0 = time.time()
     pre = os.path.join(str(tmp), name)
     subprocess.check_call([os.path.join(BIN, "rtk_simulate"), "--prefix", pre] + [str(a) for a in sim_args], stderr=subprocess.DEVNULL)
     subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + list(index_args), stderr=subprocess.DEVNULL)
-    os.remove(pre + ".sr.fq")
+    if not keep_short_reads:
+        os.remove(pre + ".sr.fq")
     t_data = time.time() - t0
     reads = op.read_fastq(pre + ".lr.fq")
     seqs, quals, tot, skipped = [], [], 0, 0
@@ -125,12 +126,51 @@ def test_gpu_config1_size(tmp_path_factory):
     print("configs[1]: %d reads / %d bases, data %.0f s, HIP (host-inclusive) %.1f s, oracle %.1f s" % (len(seqs), tot, t_data, t_gpu, t_cpu))
 
 
+@pytest.fixture(scope="module")
+def config2_set(tmp_path_factory):
+    """configs[2] / configs[3]: 60 Mb diploid reference (0.1 % heterozygous SNPs), 30x short reads, 8 Mb of its long reads (the short reads are
+    kept: the second-pass index of configs[3] is built from them)."""
+    return _sized(tmp_path_factory.mktemp("config2"), "c2",
+                  ["--seed", 3, "--ref-len", 60_000_000, "--het", 0.001, "--sr-cov", 30, "--sr-err", 0.005, "--lr-cov", 0.15, "--lr-len", 8000, "--lr-profile", "ont", "--lr-err", 0.07],
+                  [], 8_000_000, keep_short_reads=True)
+
+
 @pytest.mark.gpu
-def test_gpu_config2_graph_size(tmp_path_factory):
+def test_gpu_config2_graph_size(config2_set):
     """configs[2]'s graph: 60 Mb diploid reference (0.1 % heterozygous SNPs), 30x short reads; 8 Mb of its long reads."""
-    pre, seqs, quals, tot, t_data = _sized(tmp_path_factory.mktemp("config2"), "c2",
-                                           ["--seed", 3, "--ref-len", 60_000_000, "--het", 0.001, "--sr-cov", 30, "--sr-err", 0.005, "--lr-cov", 0.15, "--lr-len", 8000, "--lr-profile", "ont", "--lr-err", 0.07],
-                                           [], 8_000_000)
+    pre, seqs, quals, tot, t_data = config2_set
     info, t_gpu, t_cpu = _parity(pre, seqs, quals)
     assert info.n_kmers > 60_000_000
     print("configs[2] graph: %d reads / %d bases, data %.0f s, HIP (host-inclusive) %.1f s, oracle %.1f s" % (len(seqs), tot, t_data, t_gpu, t_cpu))
+
+
+@pytest.mark.gpu
+def test_gpu_config3_two_passes_on_the_config2_graph(config2_set):
+    """configs[3] at its graph size: `-1` on the 60 Mb diploid graph (HIP), the second index at k2 = 63 from the same 30x short reads coloured
+    by the pass-1 reads (src/Ratatosk.cpp:1193,1227), then `-2` on >= 4 Mb of them: HIP against the oracle, sequence and quality of every read."""
+    from ratatosk_amd import api
+    pre, seqs, quals, tot, _ = config2_set
+    n, acc = 0, 0
+    while n < len(seqs) and acc < 4_200_000:
+        acc += len(seqs[n]); n += 1
+    seqs, quals = seqs[:n], quals[:n]
+    assert acc >= 4_000_000
+    pg1 = api.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31, device=0)
+    out1 = pg1.correct_batch(seqs, quals)
+    pg1.close()
+    p1 = pre + ".pass1.fq"
+    with open(p1, "w") as f:
+        for i, (s, q) in enumerate(out1):
+            f.write("@r%d\n%s\n+\n%s\n" % (i, s, q))
+    t0 = time.time()
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "--colour-reads", p1, "-k", "63", "-o", pre + ".p2"], stderr=subprocess.DEVNULL)
+    t_idx = time.time() - t0
+    fa, rt = pre + ".p2.index.k63.fasta.gz", pre + ".p2.index.k63.rtsk"
+    pg, og = api.Graph(fa, rt, 63, device=0), op.Graph(fa, rt, 63)
+    s1, q1 = [o[0] for o in out1], [o[1] for o in out1]
+    t0 = time.time(); got = pg.correct_batch(s1, q1, pg.opts(long_read_correct=1), raw=seqs); t_gpu = time.time() - t0
+    t0 = time.time(); want = og.correct_batch2(s1, q1, seqs, og.opts(long_read_correct=1), threads=os.cpu_count() or 4); t_cpu = time.time() - t0
+    bad = [i for i, (a, b) in enumerate(zip(got, want)) if tuple(a) != tuple(b)]
+    assert not bad, "%d of %d reads differ from the oracle (first: %s)" % (len(bad), len(seqs), bad[:5])
+    assert sum(1 for a, b in zip(want, s1) if a[0] != b) > 0  # the second pass did something
+    print("configs[3] on the configs[2] graph: %d reads / %d bases, second index %.0f s, HIP -2 (host-inclusive) %.1f s, oracle %.1f s" % (n, acc, t_idx, t_gpu, t_cpu))

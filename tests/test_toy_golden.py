@@ -1,5 +1,5 @@
 """Hand-checked toy fixture (derivations in tests/golden/toy/NOTE.md): a 2 kb diploid genome with one SNP bubble and one
-tandem repeat, error-free short reads, eleven hand-made long reads that walk the branches of correctSequence the note lists.
+tandem repeat, error-free short reads, thirteen hand-made long reads that walk the branches of correctSequence the note lists.
 
 Three independent legs: (1) facts derived BY HAND from the construction (unitig lengths, corrected sequence = the haplotype substring
 the read was made from, the quality patterns of r0 / r1 / r7 / r10) -- no oracle involved; (2) the oracle must reproduce the frozen
@@ -62,6 +62,58 @@ def test_toy_expected_records_match_the_hand_derivation(toy_index):
     assert q["r10_error_cluster_over_snp"] == "I" * 400 + "A" * 46 + "I" * 354
     for name in ("r3_bubble_hapA_del2", "r4_bubble_hapB_ins1", "r5_head_errors", "r6_tail_errors", "r8_revcomp_tandem_hapA", "r9_tandem_hapB_two_errors"):
         assert set(q[name]) == {"I"}, name
+
+
+def _hand_anchors(first_err, conflict_at=None):
+    """r11 / r12 (NOTE.md "r11 and r12 by hand"): 22 substitutions 25 bp apart from read position first_err. Windows without an error are
+    solid: [0, first_err - 31] and [first_err + 526, 669]. The 557 windows between them have no exact k-mer (>= insert_sz 500): read
+    [first_err, first_err + 526) is searched for 1-edit k-mers. A window holds exactly one error e_j = first_err + 25 j iff it starts in
+    [e_j - 24, e_j - 6], and must lie inside the searched stretch: j = 1 .. 20, 19 windows each. conflict_at: the error whose windows are
+    one substitution away from k-mers of two unitigs (the SNP bubble) and are dropped by keep_non_overlap."""
+    solid = list(range(0, first_err - 31 + 1)) + list(range(first_err + 526, 670))
+    weak = []
+    for j in range(1, 21):
+        e = first_err + 25 * j
+        if e == conflict_at:
+            continue
+        weak += list(range(e - 24, e - 6 + 1))
+    return solid, weak
+
+
+def _check_hand_anchors(seeds_of, og, reads):
+    rc = lambda x: x[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    by = {r[0]: r for r in reads}
+    for name, first_err, conflict in (("r11_weak_anchors_snp_conflict", 70, 320), ("r12_weak_anchors_hops", 75, None)):
+        _, truth, raw = by[name]
+        solid, weak = seeds_of(raw)
+        h_solid, h_weak = _hand_anchors(first_err, conflict)
+        assert [a[0] for a in solid] == h_solid, name
+        assert [a[0] for a in weak] == h_weak, name
+        assert len(h_weak) == (361 if conflict else 380)
+        for pos, u, dist, strand in weak:  # every weak anchor is the k-mer of the haplotype the read was made from: the read window with its one error undone
+            useq = og.unitig(u)["seq"]
+            km = useq[dist:dist + 31]
+            assert (km if strand else rc(km)) == truth[pos:pos + 31], (name, pos)
+
+
+def test_toy_weak_anchor_lists_are_the_hand_derived_ones(toy_index):
+    """getSeeds of r11 / r12 against lists written down from the construction alone: which windows are solid, which stretch is searched for
+    1-edit k-mers, which windows have a hit, and which hits keep_non_overlap drops (the error on the SNP: hits on both bubble branches)."""
+    pre, reads = toy_index
+    og = op.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31)
+    _check_hand_anchors(og.seeds, og, reads)
+    from ratatosk_amd import api
+    pg = api.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31, device=0, lib_path=SIM_LIB)
+    _check_hand_anchors(pg.seeds, og, reads)
+
+
+@pytest.mark.gpu
+def test_gpu_toy_weak_anchor_lists_are_the_hand_derived_ones(toy_index):
+    pre, reads = toy_index
+    og = op.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31)
+    from ratatosk_amd import api
+    pg = api.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31, device=0)
+    _check_hand_anchors(pg.seeds, og, reads)
 
 
 def test_toy_oracle_reproduces_expected(toy_index):
