@@ -7,6 +7,9 @@
 #ifndef RTK_COMMON_FASTX_HPP
 #define RTK_COMMON_FASTX_HPP
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cctype>
@@ -34,6 +37,7 @@ public:
     const char* qual(size_t i) const { return rec_[i].has_qual ? buf_.data() + rec_[i].seq_off + rec_[i].seq_len : nullptr; } // seq_len characters
 private:
     friend class FastxReader;
+    friend class PlainChunks;
     struct Rec { size_t name_off, seq_off; uint32_t name_len, seq_len; bool has_qual; };
     std::vector<char> buf_;
     std::vector<Rec> rec_;
@@ -175,6 +179,120 @@ private:
     bool eof_;
     std::string peek_;
     bool has_peek_;
+};
+
+// Plain (uncompressed) FASTA / FASTQ file read as independent byte ranges, so that any number of threads can parse one file: range i is
+// [i * chunk_bytes, (i + 1) * chunk_bytes) and owns the records that START inside it. A record start is the start of a line that begins
+// with '>' (FASTA) or with '@' and is followed two lines further down by a line that begins with '+' (4-line FASTQ: a quality line may begin
+// with '@' too, but then the line two below it is a sequence line). Same record conventions as FastxReader::next_packed.
+class PlainChunks {
+public:
+    PlainChunks() : fd_(-1), size_(0), chunk_(0), fastq_(false) {}
+    ~PlainChunks() { close(); }
+    static bool is_plain(const std::string& fn) { // not gzip (magic 1f 8b) and starts like a FASTA / FASTQ file
+        FILE* f = fopen(fn.c_str(), "rb"); if (!f) return false;
+        unsigned char m[2] = {0, 0}; const size_t n = fread(m, 1, 2, f); fclose(f);
+        return n >= 1 && (m[0] == '@' || m[0] == '>');
+    }
+    bool open(const std::string& fn, size_t chunk_bytes) {
+        close();
+        fd_ = ::open(fn.c_str(), O_RDONLY); if (fd_ < 0) return false;
+        struct stat st; if (fstat(fd_, &st) != 0) { close(); return false; }
+        size_ = static_cast<size_t>(st.st_size); chunk_ = chunk_bytes < 256 ? 256 : chunk_bytes;
+        char c = 0; fastq_ = (size_ > 0 && pread(fd_, &c, 1, 0) == 1 && c == '@');
+        return true;
+    }
+    void close() { if (fd_ >= 0) { ::close(fd_); fd_ = -1; } }
+    size_t n_chunks() const { return size_ == 0 ? 0 : (size_ + chunk_ - 1) / chunk_; }
+    size_t file_bytes() const { return size_; }
+    // the records of range i appended to `out`; false on a read error. Thread-safe (pread).
+    bool parse_chunk(size_t i, PackedReads& out) const {
+        const size_t lo = i * chunk_, hi = (i + 1) * chunk_ < size_ ? (i + 1) * chunk_ : size_;
+        std::vector<char> buf;
+        size_t base = lo ? lo - 1 : 0; // one byte back: is `lo` the start of a line?
+        if (!fill(buf, base, hi + (1u << 16))) return false;
+        auto locate = [&](size_t off, size_t* res) -> bool { // record_start with the buffer grown until the answer is known (a long record may reach far beyond `hi`)
+            for (;;) {
+                const size_t e = record_start(buf, base, off);
+                if (e != static_cast<size_t>(-1)) { *res = e; return true; }
+                if (base + buf.size() >= size_) { *res = size_; return true; }
+                if (!fill(buf, base, base + buf.size() + (4u << 20))) return false;
+            }
+        };
+        size_t start = 0, end = hi;
+        if (!locate(lo, &start)) return false;
+        if (start >= hi) return true; // no record starts in this range
+        if (hi < size_ && !locate(hi, &end)) return false;
+        parse(buf.data() + (start - base), end - start, out);
+        return true;
+    }
+private:
+    bool fill(std::vector<char>& buf, size_t base, size_t upto) const { // buf = file[base, min(upto, size))
+        if (upto > size_) upto = size_;
+        size_t have = buf.size();
+        if (base + have >= upto) return true;
+        buf.resize(upto - base);
+        while (base + have < upto) { const ssize_t n = pread(fd_, buf.data() + have, upto - base - have, static_cast<off_t>(base + have)); if (n <= 0) return false; have += static_cast<size_t>(n); }
+        return true;
+    }
+    // first record start at or after file offset `off`, judged from what `buf` holds; size_ when the file ends first; -1 when `buf` ends first
+    size_t record_start(const std::vector<char>& buf, size_t base, size_t off) const {
+        const char* b = buf.data(); const size_t n = buf.size();
+        size_t p = off - base;
+        if (off != 0 && p >= 1) { // move to the start of a line
+            if (b[p - 1] != '\n') { const char* q = static_cast<const char*>(memchr(b + p, '\n', n - p)); if (!q) return base + n >= size_ ? size_ : static_cast<size_t>(-1); p = static_cast<size_t>(q - b) + 1; }
+        }
+        while (true) {
+            if (p >= n) return base + n >= size_ ? size_ : static_cast<size_t>(-1);
+            if (!fastq_) { if (b[p] == '>') return base + p; }
+            else if (b[p] == '@') {
+                const char* l1 = static_cast<const char*>(memchr(b + p, '\n', n - p));
+                if (!l1) return base + n >= size_ ? base + p : static_cast<size_t>(-1);
+                const char* l2 = static_cast<const char*>(memchr(l1 + 1, '\n', n - static_cast<size_t>(l1 + 1 - b)));
+                if (!l2) return base + n >= size_ ? base + p : static_cast<size_t>(-1);
+                if (static_cast<size_t>(l2 + 1 - b) >= n) { if (base + n >= size_) return base + p; return static_cast<size_t>(-1); }
+                if (l2[1] == '+') return base + p;
+            }
+            const char* q = static_cast<const char*>(memchr(b + p, '\n', n - p));
+            if (!q) return base + n >= size_ ? size_ : static_cast<size_t>(-1);
+            p = static_cast<size_t>(q - b) + 1;
+        }
+    }
+    void parse(const char* s, size_t n, PackedReads& out) const {
+        std::vector<char>& b = out.buf_;
+        b.reserve(b.size() + n);
+        size_t p = 0;
+        auto line = [&](size_t& ls, size_t& le) -> bool { // next line [ls, le) without its end-of-line characters
+            if (p >= n) return false;
+            ls = p; const char* q = static_cast<const char*>(memchr(s + p, '\n', n - p));
+            le = q ? static_cast<size_t>(q - s) : n; p = q ? le + 1 : n;
+            if (le > ls && s[le - 1] == '\r') --le;
+            return true;
+        };
+        size_t ls, le;
+        bool have = line(ls, le);
+        while (have) {
+            if (le == ls || (s[ls] != '>' && s[ls] != '@')) { have = line(ls, le); continue; } // not a header: skipped like FastxReader does
+            const bool fq = s[ls] == '@';
+            size_t e = ls + 1; while (e < le && !isspace(static_cast<unsigned char>(s[e]))) ++e;
+            PackedReads::Rec r; r.name_off = b.size(); r.name_len = static_cast<uint32_t>(e - (ls + 1)); r.has_qual = false;
+            b.insert(b.end(), s + ls + 1, s + e);
+            r.seq_off = b.size();
+            if (fq) {
+                size_t s0, s1, q0, q1;
+                if (!line(s0, s1)) { b.resize(r.name_off); return; }
+                b.insert(b.end(), s + s0, s + s1); r.seq_len = static_cast<uint32_t>(s1 - s0);
+                if (!line(q0, q1) || !line(q0, q1)) { b.resize(r.name_off); return; } // '+' line, quality line
+                if (out.keep_qual_ && q1 - q0 == r.seq_len) { b.insert(b.end(), s + q0, s + q1); r.has_qual = true; }
+                have = line(ls, le);
+            } else {
+                while ((have = line(ls, le)) && !(le > ls && (s[ls] == '>' || s[ls] == '@'))) b.insert(b.end(), s + ls, s + le);
+                r.seq_len = static_cast<uint32_t>(b.size() - r.seq_off);
+            }
+            out.rec_.push_back(r); out.n_bases_ += r.seq_len;
+        }
+    }
+    int fd_; size_t size_, chunk_; bool fastq_;
 };
 
 // Reads a text file listing one path per line if `fn` is not itself FASTA/FASTQ

@@ -33,6 +33,9 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "../common/fastx.hpp"
 #include "ratatosk_hip.h"
 
@@ -44,18 +47,19 @@ struct Opt {
     bool force_snp = false;
     double min_conf_snp = 0.9;
     size_t insert_sz = 500, w1 = 1000, w2 = 5000, batch_bases = 32u << 20;
-    bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false, gzip = false;
+    bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false, gzip = false, parse_only = false;
 };
 
 static void usage() {
     fprintf(stderr, "Ratatosk (MI355X hot-path build)\n\nUsage: Ratatosk correct -1 -g <graph.fasta.gz> -d <unitig_data.rtsk> -l <long_reads> -o <out_prefix> [options]\n"
                     "  -c, --cores           number of host threads (default 1): index parsing, FASTQ formatting\n"
                     "      --gpus            number of GPUs to use (default: all visible)\n"
-                    "      --workers-per-gpu tickets in flight per GPU (default 3; with -2 up to 8, as many as the device memory holds)\n"
+                    "      --workers-per-gpu tickets in flight per GPU (default 4; with -2 up to 8, as many as the device memory holds)\n"
                     "  -B, --batch-bases     long-read bases per ticket (default 32 Mi)\n"
                     "  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
                     "  -r, --correction-rounds  correction rounds of the 1st pass (default 1)\n  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
+                    "      --parse-only      developer: read and parse the long reads with -c threads, report the rate, correct nothing\n"
                     "      --strip-annotations  drop the short-cycle / SNP annotations of the index before correcting (fixRepeats / fixAmbiguity then have nothing to do)\n"
                     "Writes <out_prefix>.2.fastq (plain FASTQ, input order).\n\n"
                     "       Ratatosk correct -2 -g <graph2.fasta.gz> -d <unitig_data2.rtsk> -l <out_prefix>.2.fastq -L <long_reads> -o <out_prefix> [options]\n"
@@ -122,7 +126,7 @@ int main(int argc, char** argv) {
         {"correction-rounds", required_argument, 0, 'r'}, {"no-snp-correction", no_argument, 0, 'F'}, {"force-io-order", no_argument, 0, 'O'}, {"no-graph-index", no_argument, 0, 'I'},
         {"in-unmapped-short", required_argument, 0, 'u'}, {"in-accurate-long", required_argument, 0, 'a'}, {"in-short-phase", required_argument, 0, 'p'}, {"in-long-phase", required_argument, 0, 'P'}, {"force-correct-snp", no_argument, 0, 'f'},
         {"sampling", required_argument, 0, 'S'}, {"min-conf-color2", required_argument, 0, 'M'}, {"min-len-color2", required_argument, 0, 'C'},
-        {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"gpus", required_argument, 0, 1002}, {"workers-per-gpu", required_argument, 0, 1003}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
+        {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"gpus", required_argument, 0, 1002}, {"workers-per-gpu", required_argument, 0, 1003}, {"parse-only", no_argument, 0, 1004}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
     int c, idx = 0;
     while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:L:K:W:t:r:u:a:p:P:S:M:C:GFOIf12v", lo, &idx)) != -1) {
         switch (c) {
@@ -153,6 +157,7 @@ int main(int argc, char** argv) {
             case 1001: opt.strip = true; break;
             case 1002: opt.gpus = atoi(optarg); break;
             case 1003: opt.workers_per_gpu = atoi(optarg); opt.workers_given = true; break;
+            case 1004: opt.parse_only = true; break;
             case 's': fprintf(stderr, "Ratatosk::correct: short reads are only needed by `index` (not in scope); ignored\n"); break;
             default: usage(); return 0; // the reference returns 0 on option errors too (src/Ratatosk.cpp:1018)
         }
@@ -162,16 +167,35 @@ int main(int argc, char** argv) {
     if (lrc && opt.in_long_raw.empty()) { fprintf(stderr, "Ratatosk::correct: -2 needs the uncorrected long reads (-L) next to the pass-1 reads (-l)\n"); return 0; }
     if (opt.rounds < 1) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of correction rounds cannot be less than 1.\n"); return 0; } // src/Ratatosk.cpp:348-352
     if (opt.trim < 0 || opt.trim > opt.max_qual) { fprintf(stderr, "Ratatosk::Ratatosk(): Quality score trimming threshold cannot be less than 0 or more than %d (%d given).\n", opt.max_qual, opt.trim); /* src/Ratatosk.cpp:324-326 */ return 0; }
-    if (opt.graph.empty() || opt.udata.empty() || opt.in_long.empty() || opt.out.empty()) { fprintf(stderr, "Ratatosk::correct: -g, -d, -l and -o are required\n"); return 0; }
+    if (!opt.parse_only && (opt.graph.empty() || opt.udata.empty() || opt.in_long.empty() || opt.out.empty())) { fprintf(stderr, "Ratatosk::correct: -g, -d, -l and -o are required\n"); return 0; }
     { // src/Ratatosk.cpp:312-322
         const unsigned hc = std::thread::hardware_concurrency();
         if (opt.cores <= 0) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of threads cannot be less than or equal to 0.\n"); return 0; }
         if (hc && static_cast<unsigned>(opt.cores) > hc) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of threads cannot be greater than or equal to %u.\n", hc); return 0; }
     }
     if (opt.min_conf_snp < 0.0 || opt.min_conf_snp > 1.0) { fprintf(stderr, "Ratatosk::Ratatosk(): Minimum confidence threshold to correct a SNP must be in [0.0, 1.0].\n"); return 0; } // src/Ratatosk.cpp:366-376
-    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = opt.pass2 ? 8 : 3; // second pass: a ticket's launches are long and mostly narrow (its longest read, its biggest region): more of them in flight
+    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = opt.pass2 ? 8 : 4; // second pass: a ticket's launches are long and mostly narrow (its longest read, its biggest region): more of them in flight
     if (opt.batch_bases < 1) opt.batch_bases = 1;
 
+    if (opt.parse_only) { // reader alone: how fast do -c threads turn the input files into tickets?
+        std::vector<std::string> fl; for (size_t i = 0; i < opt.in_long.size(); ++i) { const std::vector<std::string> v = rtk::expand_input_list(opt.in_long[i]); fl.insert(fl.end(), v.begin(), v.end()); }
+        const auto t0 = std::chrono::steady_clock::now();
+        std::atomic<unsigned long long> bases(0), bytes(0), reads(0); int n_plain = 0;
+        for (size_t f = 0; f < fl.size(); ++f) {
+            if (rtk::PlainChunks::is_plain(fl[f])) {
+                ++n_plain;
+                rtk::PlainChunks pc; if (!pc.open(fl[f], 2 * opt.batch_bases + (opt.batch_bases >> 4))) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; }
+                std::atomic<size_t> next(0); std::vector<std::thread> th;
+                for (int t = 0; t < opt.cores; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= pc.n_chunks()) break; rtk::PackedReads r(false); if (!pc.parse_chunk(i, r)) break; bases += r.n_bases(); reads += r.size(); } });
+                for (size_t t = 0; t < th.size(); ++t) th[t].join();
+                bytes += pc.file_bytes();
+            } else { rtk::FastxReader rd; if (!rd.open(fl[f])) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; } rtk::PackedReads r(false); while (rd.next_packed(r)) { if (r.n_bases() > opt.batch_bases) { bases += r.n_bases(); reads += r.size(); r = rtk::PackedReads(false); } } bases += r.n_bases(); reads += r.size(); }
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("Ratatosk::parse-only: %zu file(s) (%d plain, read as byte ranges by %d threads), %llu reads, %llu bases, %.3f s: %.3g bases/s, %.2f GB/s of plain file\n", fl.size(), n_plain, opt.cores,
+               reads.load(), bases.load(), dt, dt > 0 ? bases.load() / dt : 0.0, dt > 0 ? bytes.load() / dt / 1e9 : 0.0);
+        return 0;
+    }
     const int n_dev = rtk_n_devices();
     if (n_dev <= 0) { fprintf(stderr, "Ratatosk::Ratatosk(): no HIP device visible: the correction path has no CPU fallback\n"); return 1; }
     if (opt.gpus < 0 || opt.gpus > n_dev) { fprintf(stderr, "Ratatosk::Ratatosk(): --gpus %d but %d HIP device(s) are visible\n", opt.gpus, n_dev); return 1; }
@@ -221,17 +245,19 @@ int main(int argc, char** argv) {
 
     // pass 1: opt_pass1.filename_long_out += ".2" (src/Ratatosk.cpp:1079) + ".fastq" (:622); pass 2: OUT.fastq[.gz]
     const std::string fn_out = opt.out + (lrc ? ".fastq" : ".2.fastq") + (gz_out ? ".gz" : "");
-    FILE* fout = fopen(fn_out.c_str(), "wb");
-    if (!fout) { fprintf(stderr, "Ratatosk::search(): cannot open %s for writing\n", fn_out.c_str()); exit(1); }
-    setvbuf(fout, nullptr, _IOFBF, 8u << 20);
+    // Blocks of formatted records are written with pwrite at offsets handed out in ticket order (a block's offset is the sum of the sizes of the
+    // blocks before it, known as soon as those are formatted): the writes themselves run side by side on the threads that formatted them.
+    const int fd_out = ::open(fn_out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd_out < 0) { fprintf(stderr, "Ratatosk::search(): cannot open %s for writing\n", fn_out.c_str()); exit(1); }
 
     if (opt.verbose) printf("Ratatosk::Ratatosk(): Correcting long reads (%d/2).\n", lrc ? 2 : 1);
     const int n_workers = opt.workers_per_gpu * n_gpus;
     const size_t q_cap = static_cast<size_t>(n_workers) + 2, ahead_cap = 2 * static_cast<size_t>(n_workers) + 2;
     std::mutex m_in, m_out; std::condition_variable cv_in_full, cv_in_empty, cv_out;
     std::deque<std::unique_ptr<Ticket> > queue; bool reader_done = false;
-    size_t next_to_write = 0;
-    std::map<size_t, std::string> done; // ticket -> formatted FASTQ block, at most ahead_cap entries
+    size_t next_to_write = 0; // first ticket whose block has no offset yet (every ticket before it is formatted)
+    unsigned long long out_off = 0; // offset of that block in the output file
+    std::map<size_t, std::string> done; // ticket -> formatted FASTQ block waiting for the blocks before it, at most ahead_cap entries
     std::atomic<bool> failed(false);
     std::string fail_msg; std::mutex m_fail;
     std::atomic<long long> us_parse(0), us_correct(0), us_format(0), us_write(0), n_reads(0), n_bases(0);
@@ -243,7 +269,45 @@ int main(int argc, char** argv) {
         { std::lock_guard<std::mutex> lk(m_out); } cv_out.notify_all();
     };
 
+    // Reader. First pass on plain (uncompressed) files: the files are cut into byte ranges of about one ticket each and -c threads parse them
+    // independently (rtk::PlainChunks; ticket id = range number, so the output keeps the input order). Everything else -- gzip input (one
+    // inflate stream per file is sequential), the lock-step pair of files of the second pass -- goes through the one reader thread below.
+    bool par_read = !lrc && !getenv("RTK_SERIAL_READER"); // (the environment switch: A/B against the one-thread reader)
+    for (size_t i = 0; par_read && i < files.size(); ++i) par_read = rtk::PlainChunks::is_plain(files[i]);
+    std::vector<std::unique_ptr<rtk::PlainChunks> > pcs; std::vector<size_t> pc_first; size_t n_chunks_all = 0;
+    if (par_read) {
+        for (size_t i = 0; i < files.size(); ++i) {
+            pcs.emplace_back(new rtk::PlainChunks());
+            if (!pcs.back()->open(files[i], 2 * opt.batch_bases + (opt.batch_bases >> 4))) { fprintf(stderr, "Ratatosk::search(): cannot open input file %s\n", files[i].c_str()); exit(1); }
+            pc_first.push_back(n_chunks_all); n_chunks_all += pcs.back()->n_chunks();
+        }
+    }
+    std::atomic<size_t> next_chunk(0); std::atomic<int> parsers_left(0);
+    auto parser = [&]() {
+        for (;;) {
+            const size_t id = next_chunk.fetch_add(1);
+            if (id >= n_chunks_all || failed) break;
+            { std::unique_lock<std::mutex> lk(m_out); cv_out.wait(lk, [&]() { return id < next_to_write + ahead_cap || failed; }); if (failed) break; } // bounded run-ahead of the writer
+            const long long tp0 = now_us();
+            size_t f = pcs.size() - 1; while (pc_first[f] > id) --f;
+            std::unique_ptr<Ticket> t(new Ticket(lrc)); t->id = id;
+            if (!pcs[f]->parse_chunk(id - pc_first[f], t->reads)) { fail("Ratatosk::search(): read error on " + files[f]); break; }
+            us_parse += now_us() - tp0;
+            n_bases += static_cast<long long>(t->reads.n_bases());
+            if (opt.verbose) { const long long a = n_reads.fetch_add(static_cast<long long>(t->reads.size())), b2 = a + static_cast<long long>(t->reads.size()); if (a / 1000 != b2 / 1000) printf("Ratatosk::correct(): Processed %lld reads \n", b2 / 1000 * 1000); }
+            std::unique_lock<std::mutex> lk(m_in);
+            cv_in_full.wait(lk, [&]() { return queue.size() < q_cap + static_cast<size_t>(opt.cores) || failed; });
+            if (failed) break;
+            queue.push_back(std::move(t));
+            cv_in_empty.notify_one();
+        }
+        if (parsers_left.fetch_sub(1) == 1) { { std::lock_guard<std::mutex> lk(m_in); reader_done = true; } cv_in_empty.notify_all(); }
+    };
+    std::vector<std::thread> parser_threads;
+    if (par_read) { const int np = std::max(1, std::min(opt.cores, 16)); parsers_left = np; for (int i = 0; i < np; ++i) parser_threads.emplace_back(parser); }
+
     std::thread reader_thread([&]() {
+        if (par_read) return;
         rtk::FastxReader reader, reader_raw; size_t file_i = 0, file_raw_i = 0; bool file_open = false, file_raw_open = false, eof_all = false; size_t ticket = 0;
         const char* out_of_step = "Ratatosk::correct(): Corrected read file is not in the same order as input long read file. Abort."; // src/Ratatosk.cpp:787,796
         while (!eof_all && !failed) {
@@ -299,6 +363,8 @@ int main(int argc, char** argv) {
             }
             const rtk::PackedReads& R = t->reads;
             const uint32_t n = static_cast<uint32_t>(R.size());
+            std::string block;
+            if (n != 0) { // (a byte range of the parallel reader may hold no record start at all)
             std::vector<const char*> ps(n); std::vector<uint32_t> len(n);
             for (uint32_t i = 0; i < n; ++i) { ps[i] = R.seq(i); len[i] = R.seq_len(i); }
             const long long tc0 = now_us();
@@ -336,7 +402,6 @@ int main(int argc, char** argv) {
             us_correct += now_us() - tc0;
             if (rc != RTK_OK) { fail(std::string("Ratatosk::correct(): ") + rtk_last_error()); if (b) rtk_batch_free(b); return; }
             const long long tf0 = now_us();
-            std::string block;
             if (trim) {
                 for (uint32_t i = 0; i < n; ++i) append_trimmed(block, R.name(i), R.name_len(i), pool + off[i], pool + off[i] + olen[i], olen[i], k_graph, trim);
             } else {
@@ -352,18 +417,28 @@ int main(int argc, char** argv) {
             rtk_batch_free(b);
             if (gz_out) { std::string z; if (!gzip_member(block, z)) { fail("Ratatosk::search(): gzip compression failed"); return; } block.swap(z); }
             us_format += now_us() - tf0;
+            }
+            std::vector<std::pair<unsigned long long, std::string> > to_write; // blocks that got their offset by this ticket's arrival (its own, and later ones that were waiting for it)
             {
                 std::unique_lock<std::mutex> lk(m_out);
                 done[t->id].swap(block);
-                const long long tw0 = now_us();
                 while (!done.empty() && done.begin()->first == next_to_write) {
-                    const std::string& blk = done.begin()->second;
-                    if (fwrite(blk.data(), 1, blk.size(), fout) != blk.size()) { lk.unlock(); fail("Ratatosk::search(): write error on " + fn_out); return; }
+                    to_write.emplace_back(out_off, std::string()); to_write.back().second.swap(done.begin()->second);
+                    out_off += to_write.back().second.size();
                     done.erase(done.begin()); ++next_to_write;
                 }
-                us_write += now_us() - tw0;
             }
             cv_out.notify_all();
+            const long long tw0 = now_us();
+            for (size_t i = 0; i < to_write.size(); ++i) {
+                const std::string& blk = to_write[i].second; size_t w_done = 0;
+                while (w_done < blk.size()) {
+                    const ssize_t nw = pwrite(fd_out, blk.data() + w_done, blk.size() - w_done, static_cast<off_t>(to_write[i].first + w_done));
+                    if (nw <= 0) { fail("Ratatosk::search(): write error on " + fn_out); return; }
+                    w_done += static_cast<size_t>(nw);
+                }
+            }
+            us_write += now_us() - tw0;
         }
     };
     std::vector<std::thread> th;
@@ -371,7 +446,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < th.size(); ++i) th[i].join();
     { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all();
     reader_thread.join();
-    const bool write_ok = fclose(fout) == 0;
+    for (size_t i = 0; i < parser_threads.size(); ++i) parser_threads[i].join();
+    const bool write_ok = ::close(fd_out) == 0;
     for (int w = 0; w < n_gpus; ++w) rtk_graph_free(graphs[w]);
     if (failed || !write_ok || !done.empty()) { // a partial OUT.2.fastq must not look like a result
         remove(fn_out.c_str());

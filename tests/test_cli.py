@@ -5,7 +5,7 @@ import subprocess
 
 import pytest
 
-from conftest import BIN
+from conftest import BIN, ROOT
 from oracle import oracle_py as op
 
 EXE = os.path.join(BIN, "Ratatosk")
@@ -172,3 +172,34 @@ def test_gpu_cli_correction_rounds(ds_small, tmp_path):
     r = subprocess.run([EXE, "correct", "-1", "-r", "2", "-c", "2", "-B", "9000", "-g", fa, "-d", rt, "-l", ds_small + ".lr.fq", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert [(g[1], g[2]) for g in op.read_fastq(out + ".2.fastq")] == want
+
+
+def test_parallel_reader_cuts_files_like_the_serial_one(ds_small, tmp_path):
+    """First pass on plain files: -c threads parse byte ranges of the input independently (rtk::PlainChunks). With ranges of a few hundred
+    bytes every kind of boundary occurs: records longer than a range, quality lines that start with '@' or '+', CRLF line ends, a FASTA file
+    with multi-line records next to the FASTQ one. The output must be the serial reader's, byte for byte (simulator build of the driver)."""
+    import random
+    rnd = random.Random(4)
+    reads = op.read_fastq(ds_small + ".lr.fq")[:6]
+    fq, fa = str(tmp_path / "in.fq"), str(tmp_path / "in.fa")
+    with open(fq, "w", newline="") as f:
+        for i, (name, s, q) in enumerate(reads):
+            lead = "@+I5"[i % 4]
+            qq = lead + "".join(rnd.choice("@+5I!") for _ in range(len(s) - 1))
+            eol = "\r\n" if i % 2 else "\n"
+            f.write("@%s some comment%s%s%s+%s%s%s" % (name, eol, s, eol, eol, qq, eol))
+    with open(fa, "w") as f:
+        for name, s, q in reads[:3]:
+            f.write(">%s_fa\n" % name + "\n".join(s[i:i + 70] for i in range(0, len(s), 70)) + "\n")
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write(fq + "\n" + fa + "\n")
+    exe = os.path.join(ROOT, "tests", "hostsim", "Ratatosk_sim")
+    outs = []
+    for tag, env, batch in (("serial", dict(os.environ, RTK_SERIAL_READER="1"), "100000"), ("ranges_of_256_bytes", dict(os.environ), "100"), ("ranges_of_one_ticket", dict(os.environ), "3000")):
+        out = str(tmp_path / tag)
+        r = subprocess.run([exe, "correct", "-1", "-c", "4", "-B", batch, "-g", ds_small + ".index.k31.fasta.gz", "-d", ds_small + ".index.k31.rtsk", "-l", lst, "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out + ".2.fastq", "rb").read())
+    assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") == 4 * 9
+    r = subprocess.run([exe, "correct", "-1", "--parse-only", "-c", "3", "-B", "100", "-l", lst], capture_output=True, text=True)
+    assert r.returncode == 0 and "9 reads" in r.stdout, r.stdout + r.stderr
