@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,9 +24,28 @@ namespace rtk {
 
 // A batch of reads in ONE buffer (names, sequences and, on request, qualities back to back) + offsets: what a ticket of the host
 // driver carries from the reader thread to a GPU worker without per-record strings.
+// big character buffers travel from the reader to the workers and back: a fresh 100 MB vector costs its page faults every time
+inline std::vector<std::vector<char> >& packed_pool_() { static std::vector<std::vector<char> > p; return p; }
+inline std::mutex& packed_pool_lock_() { static std::mutex m; return m; }
+inline std::vector<char> packed_buffer_take() {
+    std::lock_guard<std::mutex> lk(packed_pool_lock_());
+    std::vector<std::vector<char> >& p = packed_pool_();
+    if (p.empty()) return std::vector<char>();
+    std::vector<char> v; v.swap(p.back()); p.pop_back(); v.clear(); return v;
+}
+inline void packed_buffer_give(std::vector<char>& v) {
+    if (v.capacity() < (1u << 20)) return;
+    std::lock_guard<std::mutex> lk(packed_pool_lock_());
+    if (packed_pool_().size() < 64) { packed_pool_().emplace_back(); packed_pool_().back().swap(v); }
+}
+
 class PackedReads {
 public:
     explicit PackedReads(bool keep_qual = false) : keep_qual_(keep_qual), n_bases_(0) {}
+    ~PackedReads() { packed_buffer_give(buf_); }
+    PackedReads(const PackedReads&) = delete; PackedReads& operator=(const PackedReads&) = delete;
+    PackedReads(PackedReads&& o) : buf_(std::move(o.buf_)), rec_(std::move(o.rec_)), keep_qual_(o.keep_qual_), n_bases_(o.n_bases_) {}
+    PackedReads& operator=(PackedReads&& o) { packed_buffer_give(buf_); buf_ = std::move(o.buf_); rec_ = std::move(o.rec_); keep_qual_ = o.keep_qual_; n_bases_ = o.n_bases_; return *this; }
     void reserve(size_t bytes) { buf_.reserve(bytes); }
     size_t size() const { return rec_.size(); }
     size_t n_bases() const { return n_bases_; }
@@ -34,11 +54,11 @@ public:
     uint32_t name_len(size_t i) const { return rec_[i].name_len; }
     const char* seq(size_t i) const { return buf_.data() + rec_[i].seq_off; }
     uint32_t seq_len(size_t i) const { return rec_[i].seq_len; }
-    const char* qual(size_t i) const { return rec_[i].has_qual ? buf_.data() + rec_[i].seq_off + rec_[i].seq_len : nullptr; } // seq_len characters
+    const char* qual(size_t i) const { return rec_[i].has_qual ? buf_.data() + rec_[i].qual_off : nullptr; } // seq_len characters
 private:
     friend class FastxReader;
     friend class PlainChunks;
-    struct Rec { size_t name_off, seq_off; uint32_t name_len, seq_len; bool has_qual; };
+    struct Rec { size_t name_off, seq_off, qual_off; uint32_t name_len, seq_len; bool has_qual; };
     std::vector<char> buf_;
     std::vector<Rec> rec_;
     bool keep_qual_;
@@ -103,7 +123,7 @@ public:
         size_t e = h0 + 1;
         while (e < b.size() && !isspace(static_cast<unsigned char>(b[e]))) ++e;
         memmove(&b[h0], &b[h0 + 1], e - (h0 + 1)); // drop the marker, keep the name
-        PackedReads::Rec r; r.name_off = h0; r.name_len = static_cast<uint32_t>(e - (h0 + 1)); r.has_qual = false;
+        PackedReads::Rec r; r.name_off = h0; r.name_len = static_cast<uint32_t>(e - (h0 + 1)); r.has_qual = false; r.qual_off = 0;
         b.resize(h0 + r.name_len);
         r.seq_off = b.size();
         if (fastq) {
@@ -113,6 +133,7 @@ public:
             if (!getline_append(b)) { b.resize(h0); return false; } // '+'
             b.resize(p0);
             if (!getline_append(b)) { b.resize(h0); return false; }
+            r.qual_off = p0;
             if (out.keep_qual_ && b.size() - p0 == r.seq_len) r.has_qual = true; else b.resize(p0);
         } else {
             while (true) {
@@ -208,7 +229,7 @@ public:
     // the records of range i appended to `out`; false on a read error. Thread-safe (pread).
     bool parse_chunk(size_t i, PackedReads& out) const {
         const size_t lo = i * chunk_, hi = (i + 1) * chunk_ < size_ ? (i + 1) * chunk_ : size_;
-        std::vector<char> buf;
+        std::vector<char> buf = packed_buffer_take(); // (recycled: becomes the ticket's character buffer, the records point into it)
         size_t base = lo ? lo - 1 : 0; // one byte back: is `lo` the start of a line?
         if (!fill(buf, base, hi + (1u << 16))) return false;
         auto locate = [&](size_t off, size_t* res) -> bool { // record_start with the buffer grown until the answer is known (a long record may reach far beyond `hi`)
@@ -221,9 +242,10 @@ public:
         };
         size_t start = 0, end = hi;
         if (!locate(lo, &start)) return false;
-        if (start >= hi) return true; // no record starts in this range
+        if (start >= hi) { packed_buffer_give(buf); return true; } // no record starts in this range
         if (hi < size_ && !locate(hi, &end)) return false;
-        parse(buf.data() + (start - base), end - start, out);
+        if (out.rec_.empty() && out.buf_.empty()) { out.buf_.swap(buf); parse_in_place(out, start - base, end - base); }
+        else { parse_in_place_from(buf, start - base, end - base, out); packed_buffer_give(buf); }
         return true;
     }
 private:
@@ -258,10 +280,11 @@ private:
             p = static_cast<size_t>(q - b) + 1;
         }
     }
-    void parse(const char* s, size_t n, PackedReads& out) const {
-        std::vector<char>& b = out.buf_;
-        b.reserve(b.size() + n);
-        size_t p = 0;
+    // the records of buf[from, to): the ticket keeps `buf` itself and its records point into it (nothing is copied; the lines of a multi-line
+    // FASTA record are moved together in place)
+    void parse_in_place(PackedReads& out, size_t from, size_t to) const {
+        char* s = out.buf_.data(); const size_t n = to;
+        size_t p = from;
         auto line = [&](size_t& ls, size_t& le) -> bool { // next line [ls, le) without its end-of-line characters
             if (p >= n) return false;
             ls = p; const char* q = static_cast<const char*>(memchr(s + p, '\n', n - p));
@@ -275,22 +298,29 @@ private:
             if (le == ls || (s[ls] != '>' && s[ls] != '@')) { have = line(ls, le); continue; } // not a header: skipped like FastxReader does
             const bool fq = s[ls] == '@';
             size_t e = ls + 1; while (e < le && !isspace(static_cast<unsigned char>(s[e]))) ++e;
-            PackedReads::Rec r; r.name_off = b.size(); r.name_len = static_cast<uint32_t>(e - (ls + 1)); r.has_qual = false;
-            b.insert(b.end(), s + ls + 1, s + e);
-            r.seq_off = b.size();
+            PackedReads::Rec r; r.name_off = ls + 1; r.name_len = static_cast<uint32_t>(e - (ls + 1)); r.has_qual = false; r.qual_off = 0;
             if (fq) {
                 size_t s0, s1, q0, q1;
-                if (!line(s0, s1)) { b.resize(r.name_off); return; }
-                b.insert(b.end(), s + s0, s + s1); r.seq_len = static_cast<uint32_t>(s1 - s0);
-                if (!line(q0, q1) || !line(q0, q1)) { b.resize(r.name_off); return; } // '+' line, quality line
-                if (out.keep_qual_ && q1 - q0 == r.seq_len) { b.insert(b.end(), s + q0, s + q1); r.has_qual = true; }
+                if (!line(s0, s1)) return;
+                r.seq_off = s0; r.seq_len = static_cast<uint32_t>(s1 - s0);
+                if (!line(q0, q1) || !line(q0, q1)) return; // '+' line, quality line
+                if (out.keep_qual_ && q1 - q0 == r.seq_len) { r.qual_off = q0; r.has_qual = true; }
                 have = line(ls, le);
             } else {
-                while ((have = line(ls, le)) && !(le > ls && (s[ls] == '>' || s[ls] == '@'))) b.insert(b.end(), s + ls, s + le);
-                r.seq_len = static_cast<uint32_t>(b.size() - r.seq_off);
+                r.seq_off = p; size_t w = p; // sequence lines are moved together, starting where the first one starts
+                while ((have = line(ls, le)) && !(le > ls && (s[ls] == '>' || s[ls] == '@'))) { if (w != ls) memmove(s + w, s + ls, le - ls); w += le - ls; }
+                r.seq_len = static_cast<uint32_t>(w - r.seq_off);
             }
             out.rec_.push_back(r); out.n_bases_ += r.seq_len;
         }
+    }
+    // (a ticket that already holds records: the new ones are appended to its buffer)
+    void parse_in_place_from(std::vector<char>& buf, size_t from, size_t to, PackedReads& out) const {
+        PackedReads tmp(out.keep_qual_); tmp.buf_.swap(buf); parse_in_place(tmp, from, to);
+        const size_t shift = out.buf_.size();
+        out.buf_.insert(out.buf_.end(), tmp.buf_.begin(), tmp.buf_.begin() + to);
+        for (size_t i = 0; i < tmp.rec_.size(); ++i) { PackedReads::Rec r = tmp.rec_[i]; r.name_off += shift; r.seq_off += shift; r.qual_off += shift; out.rec_.push_back(r); out.n_bases_ += r.seq_len; }
+        buf.swap(tmp.buf_);
     }
     int fd_; size_t size_, chunk_; bool fastq_;
 };

@@ -54,7 +54,7 @@ static void usage() {
     fprintf(stderr, "Ratatosk (MI355X hot-path build)\n\nUsage: Ratatosk correct -1 -g <graph.fasta.gz> -d <unitig_data.rtsk> -l <long_reads> -o <out_prefix> [options]\n"
                     "  -c, --cores           number of host threads (default 1): index parsing, FASTQ formatting\n"
                     "      --gpus            number of GPUs to use (default: all visible)\n"
-                    "      --workers-per-gpu tickets in flight per GPU (default 4; with -2 up to 8, as many as the device memory holds)\n"
+                    "      --workers-per-gpu tickets in flight per GPU (default 3; with -2 up to 8, as many as the device memory holds)\n"
                     "  -B, --batch-bases     long-read bases per ticket (default 32 Mi)\n"
                     "  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
@@ -174,7 +174,7 @@ int main(int argc, char** argv) {
         if (hc && static_cast<unsigned>(opt.cores) > hc) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of threads cannot be greater than or equal to %u.\n", hc); return 0; }
     }
     if (opt.min_conf_snp < 0.0 || opt.min_conf_snp > 1.0) { fprintf(stderr, "Ratatosk::Ratatosk(): Minimum confidence threshold to correct a SNP must be in [0.0, 1.0].\n"); return 0; } // src/Ratatosk.cpp:366-376
-    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = opt.pass2 ? 8 : 4; // second pass: a ticket's launches are long and mostly narrow (its longest read, its biggest region): more of them in flight
+    if (opt.workers_per_gpu < 1) opt.workers_per_gpu = opt.pass2 ? 8 : 3; // second pass: a ticket's launches are long and mostly narrow (its longest read, its biggest region): more of them in flight
     if (opt.batch_bases < 1) opt.batch_bases = 1;
 
     if (opt.parse_only) { // reader alone: how fast do -c threads turn the input files into tickets?
@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
                 for (int t = 0; t < opt.cores; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= pc.n_chunks()) break; rtk::PackedReads r(false); if (!pc.parse_chunk(i, r)) break; bases += r.n_bases(); reads += r.size(); } });
                 for (size_t t = 0; t < th.size(); ++t) th[t].join();
                 bytes += pc.file_bytes();
-            } else { rtk::FastxReader rd; if (!rd.open(fl[f])) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; } rtk::PackedReads r(false); while (rd.next_packed(r)) { if (r.n_bases() > opt.batch_bases) { bases += r.n_bases(); reads += r.size(); r = rtk::PackedReads(false); } } bases += r.n_bases(); reads += r.size(); }
+            } else { rtk::FastxReader rd; if (!rd.open(fl[f])) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; } rtk::PackedReads r(false); while (rd.next_packed(r)) { if (r.n_bases() > opt.batch_bases) { bases += r.n_bases(); reads += r.size(); rtk::PackedReads fresh(false); r = std::move(fresh); } } bases += r.n_bases(); reads += r.size(); }
         }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("Ratatosk::parse-only: %zu file(s) (%d plain, read as byte ranges by %d threads), %llu reads, %llu bases, %.3f s: %.3g bases/s, %.2f GB/s of plain file\n", fl.size(), n_plain, opt.cores,
@@ -262,6 +262,7 @@ int main(int argc, char** argv) {
     std::string fail_msg; std::mutex m_fail;
     std::atomic<long long> us_parse(0), us_correct(0), us_format(0), us_write(0), n_reads(0), n_bases(0);
     const long long t_begin = now_us();
+    const bool cli_trace = getenv("RTK_CLI_TRACE") != nullptr; // developer: per-ticket times of the workers
     auto fail = [&](const std::string& msg) {
         { std::lock_guard<std::mutex> lk(m_fail); if (fail_msg.empty()) fail_msg = msg; }
         failed = true;
@@ -377,6 +378,7 @@ int main(int argc, char** argv) {
                 for (uint32_t i = 0; i < n; ++i) { pq[i] = R.qual(i) ? R.qual(i) : none; pr[i] = t->raw.seq(i); rlen[i] = t->raw.seq_len(i); }
                 rc = rtk_batch_create2(g, n, ps.data(), pq.data(), len.data(), pr.data(), rlen.data(), &b);
             } else rc = rtk_batch_create(g, n, ps.data(), nullptr, len.data(), &b); // pass 1 replaces every quality (src/Correction.cpp:184-185)
+            const long long tc1 = now_us();
             const char* pool = nullptr; const uint64_t* off = nullptr; const uint32_t* olen = nullptr;
             const int n_rounds = lrc ? 1 : opt.rounds;
             for (int j = 0; j < n_rounds && rc == RTK_OK; ++j) { // src/Ratatosk.cpp:847-866: every round corrects the output of the one before with its own thresholds
@@ -397,7 +399,9 @@ int main(int argc, char** argv) {
                     if (rc != RTK_OK) break;
                 }
                 rc = rtk_batch_run(b, &rj);
+                const long long tc2 = now_us();
                 if (rc == RTK_OK) rc = rtk_batch_fetch_view(b, &pool, &off, &olen);
+                if (cli_trace) fprintf(stderr, "[cli trace] ticket %zu worker %d: start %+.1f ms, create %.1f, run %.1f, fetch %.1f ms\n", t->id, w, 1e-3 * (tc0 - t_begin), 1e-3 * (tc1 - tc0), 1e-3 * (tc2 - tc1), 1e-3 * (now_us() - tc2));
             }
             us_correct += now_us() - tc0;
             if (rc != RTK_OK) { fail(std::string("Ratatosk::correct(): ") + rtk_last_error()); if (b) rtk_batch_free(b); return; }
