@@ -187,6 +187,12 @@ int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* 
                           const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
                           int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar, int waves);
 
+/* Index build, device side (the reference builds its index on the CPU: `Ratatosk index`, src/Ratatosk.cpp:1066-1067, Bifrost
+ * build + addCoverage src/Graph.cpp:1561). rtk_index_count_kmers: the canonical k-mers (odd k <= 31, A=0 C=1 G=2 T=3, first base in the
+ * high bits) that the reads of `files` (plain or gzipped FASTA/FASTQ) hold at least min_count times, sorted ascending; *solid is freed
+ * with rtk_free. The tool csrc/tools/build_index.cpp (--gpu) builds the same files with it as its CPU path does. */
+int rtk_index_count_kmers(int device, int k, const char* const* files, int n_files, uint32_t min_count, int n_threads, uint64_t** solid, uint64_t* n_solid);
+
 void rtk_free(void* p);
 const char* rtk_last_error(void);
 const char* rtk_version(void);

@@ -28,7 +28,7 @@ extern "C" void rtk_sim_site_stats(unsigned long long* out, int reset) { for (in
 
 // ------------------------------------------------------------------------------------------------ error handling
 static thread_local std::string g_last_error;
-static int rtk_fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+int rtk_fail(int code, const std::string& msg) { g_last_error = msg; return code; } // (also used by the other translation units of the library)
 
 extern "C" const char* rtk_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* rtk_version(void) {
