@@ -15,9 +15,13 @@
 //   * short cycles   = restatement of detectShortCycles (src/Graph.cpp:4660-4735), so that fixRepeats has inputs
 //   * SNP annotations (--snps only) = restatement of detectSNPs (src/Graph.cpp:484-720) with the breadth-first bubble walk of
 //     isValidSNPcandidate (src/GraphTraversal.cpp:1057-1147); haplotype ids stay empty (no phasing input).
+#include <dlfcn.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +64,121 @@ template <class KM> struct KTable { // open addressing: canonical k-mer -> 64-bi
 
 struct Unitig { std::string seq; std::vector<uint32_t> colours; uint64_t cov = 0; };
 
+// ---------------------------------------------------------------------------------------------- --fast / --gpu: thread-parallel steps (one-word k-mers)
+// They must produce what the plain path produces, byte for byte: the plain path stays the definition (and the fallback).
+template <class F> static void parallel_for(size_t n, unsigned n_thr, F f) { // f(begin, end, thread)
+    if (n_thr < 1) n_thr = 1;
+    std::vector<std::thread> th; const size_t per = (n + n_thr - 1) / n_thr;
+    for (unsigned t = 0; t < n_thr; ++t) { const size_t b = std::min(n, per * t), e = std::min(n, per * (t + 1)); if (b < e) th.emplace_back([=]() { f(b, e, t); }); }
+    for (size_t t = 0; t < th.size(); ++t) th[t].join();
+}
+
+// (two-word k-mers take the plain path: these overloads are never reached)
+static void fast_table_fill(KTable<u128>&, const std::vector<u128>&, unsigned) {}
+static bool fast_unitigs(KTable<u128>&, const std::vector<u128>&, int, unsigned, std::vector<Unitig>&) { return false; }
+
+// every solid k-mer into the table with value 0 (slots claimed with a compare-and-swap on the key word; the table does not grow here)
+static void fast_table_fill(KTable<uint64_t>& km, const std::vector<uint64_t>& solid, unsigned n_thr) {
+    const uint64_t EMPTY = ~0ULL;
+    uint64_t* keys = km.keys.data(); const size_t mask = km.mask;
+    parallel_for(solid.size(), n_thr, [&](size_t b, size_t e, unsigned) {
+        for (size_t i = b; i < e; ++i) {
+            const uint64_t key = solid[i]; size_t s = hash_km(key) & mask;
+            while (true) {
+                uint64_t cur = __atomic_load_n(&keys[s], __ATOMIC_RELAXED);
+                if (cur == key) break;
+                if (cur == EMPTY) { uint64_t exp = EMPTY; if (__atomic_compare_exchange_n(&keys[s], &exp, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED) || exp == key) break; continue; }
+                s = (s + 1) & mask;
+            }
+        }
+    });
+    km.n = solid.size();
+}
+
+// Unitigs by walking every maximal chain of mutually unique links from its ends, on all threads. The plain construction starts a unitig at the
+// first unvisited k-mer in sorted order, in its canonical orientation, and follows the links both ways: for a chain that never meets one of its
+// own k-mers again that is the chain oriented so that its smallest canonical k-mer reads forwards, and the unitigs are numbered by those
+// smallest k-mers. Chains that do meet themselves (closed loops, hairpins through a reverse complement) are left to the plain code, which
+// then only sees their k-mers; all unitigs are put in the order of their first k-mers at the end. Returns false (nothing kept) if a k-mer
+// ended up on two unitigs -- the caller then runs the plain construction.
+static bool fast_unitigs(KTable<uint64_t>& km, const std::vector<uint64_t>& solid, int k, unsigned n_thr, std::vector<Unitig>& U) {
+    const uint64_t mask = kmer_mask(k);
+    auto in_graph = [&](uint64_t oriented) -> bool { return km.slot(kmer_canonical(oriented, k), false) != nullptr; };
+    auto succs = [&](uint64_t x, uint64_t out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const uint64_t y = ((x << 2) | b) & mask; if (in_graph(y)) out[n++] = y; } return n; };
+    auto preds = [&](uint64_t x, uint64_t out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const uint64_t y = (x >> 2) | (b << (2 * (k - 1))); if (in_graph(y)) out[n++] = y; } return n; };
+    auto next = [&](uint64_t x, uint64_t* y) -> bool { uint64_t nb[4], nb2[4]; if (succs(x, nb) != 1) return false; if (preds(nb[0], nb2) != 1) return false; *y = nb[0]; return true; }; // the link the plain code follows forwards
+    auto prev = [&](uint64_t x, uint64_t* y) -> bool { uint64_t nb[4], nb2[4]; if (preds(x, nb) != 1) return false; if (succs(nb[0], nb2) != 1) return false; *y = nb[0]; return true; };
+    struct Rec { uint64_t seed; std::string seq; };
+    std::vector<std::vector<Rec> > out(n_thr);
+    std::atomic<bool> clash(false);
+    auto claim = [&](uint64_t canonical) { uint64_t* v = km.slot(canonical, false); if (__atomic_exchange_n(v, 1ULL, __ATOMIC_RELAXED) != 0) clash = true; };
+    parallel_for(solid.size(), n_thr, [&](size_t b, size_t e, unsigned t) {
+        std::vector<uint64_t> path;
+        for (size_t i = b; i < e && !clash; ++i) {
+            const uint64_t s = solid[i]; uint64_t y;
+            const bool has_fw = next(s, &y), has_bw = prev(s, &y);
+            if (has_fw && has_bw) continue; // inside a chain (or on a closed loop)
+            // walk inwards from this end: forwards from s if nothing links into it from behind, else forwards from its reverse complement
+            uint64_t x = has_bw ? kmer_revcomp(s, k) : s;
+            path.clear(); path.push_back(x);
+            while (next(x, &y)) { path.push_back(y); x = y; if (path.size() > solid.size()) break; }
+            const uint64_t end_c = kmer_canonical(path.back(), k);
+            if (path.size() > 1 && end_c == s) continue;         // the chain comes back to its own first k-mer (hairpin): plain code
+            if (end_c < s) continue;                              // the other end owns the chain
+            if (path.size() > solid.size()) continue;
+            // orient: the smallest canonical k-mer of the chain reads forwards
+            size_t m = 0; uint64_t mc = kmer_canonical(path[0], k);
+            for (size_t j = 1; j < path.size(); ++j) { const uint64_t c = kmer_canonical(path[j], k); if (c < mc) { mc = c; m = j; } }
+            bool dup = false; // a chain that holds a k-mer and its reverse complement without coming back to its first k-mer cannot exist (the links are symmetric); checked by the claims below
+            if (path[m] != mc) { std::reverse(path.begin(), path.end()); for (size_t j = 0; j < path.size(); ++j) path[j] = kmer_revcomp(path[j], k); }
+            Rec r; r.seed = mc; r.seq = kmer_decode(path[0], k);
+            for (size_t j = 1; j < path.size(); ++j) r.seq.push_back(bits2base(static_cast<int>(path[j] & 3)));
+            for (size_t j = 0; j < path.size(); ++j) claim(kmer_canonical(path[j], k));
+            (void)dup;
+            out[t].push_back(r);
+        }
+    });
+    if (clash) return false;
+    // what is left belongs to chains that meet themselves: the plain construction, which finds every other k-mer taken
+    std::vector<Rec> rest;
+    {
+        std::set<uint64_t> in_this;
+        for (size_t si = 0; si < solid.size(); ++si) {
+            uint64_t* v0 = km.slot(solid[si], false);
+            if (*v0 != 0) continue;
+            in_this.clear(); in_this.insert(solid[si]);
+            std::vector<uint64_t> fwd(1, solid[si]), bwd; uint64_t nb[4], nb2[4];
+            for (uint64_t x = solid[si];;) { if (succs(x, nb) != 1) break; const uint64_t y = nb[0]; if (preds(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); fwd.push_back(y); x = y; }
+            for (uint64_t x = solid[si];;) { if (preds(x, nb) != 1) break; const uint64_t y = nb[0]; if (succs(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); bwd.push_back(y); x = y; }
+            std::vector<uint64_t> path(bwd.rbegin(), bwd.rend()); path.insert(path.end(), fwd.begin(), fwd.end());
+            Rec r; r.seed = solid[si]; r.seq = kmer_decode(path[0], k);
+            for (size_t j = 1; j < path.size(); ++j) r.seq.push_back(bits2base(static_cast<int>(path[j] & 3)));
+            for (size_t j = 0; j < path.size(); ++j) *km.slot(kmer_canonical(path[j], k), false) = 1;
+            rest.push_back(r);
+        }
+    }
+    if (getenv("RTK_INDEX_TRACE")) fprintf(stderr, "rtk_build_index: %zu unitigs of chains that meet themselves built by the plain code\n", rest.size());
+    // all unitigs in the order of their first k-mers; the table values from the final numbers
+    std::vector<Rec*> all;
+    for (unsigned t = 0; t < n_thr; ++t) for (size_t i = 0; i < out[t].size(); ++i) all.push_back(&out[t][i]);
+    for (size_t i = 0; i < rest.size(); ++i) all.push_back(&rest[i]);
+    std::sort(all.begin(), all.end(), [](const Rec* a, const Rec* b) { return a->seed < b->seed; });
+    U.resize(all.size());
+    parallel_for(all.size(), n_thr, [&](size_t b, size_t e, unsigned) {
+        for (size_t uid = b; uid < e; ++uid) {
+            U[uid].seq.swap(all[uid]->seq);
+            const std::string& q = U[uid].seq; uint64_t fw = 0;
+            for (size_t i = 0; i < q.size(); ++i) {
+                fw = ((fw << 2) | static_cast<uint64_t>(base2bits(q[i]))) & mask;
+                if (i + 1 < static_cast<size_t>(k)) continue;
+                bool is_fw; const uint64_t c = kmer_canonical(fw, k, &is_fw);
+                *km.slot(c, false) = ((static_cast<uint64_t>(uid) + 1) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ULL : 0ULL);
+            }
+        }
+    });
+    return true;
+}
+
 template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for k <= 31, u128 for k in 33..63
     const KM EMPTY = ~static_cast<KM>(0);
     std::vector<std::string> in_files;
@@ -69,6 +188,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     size_t min_cov_vertices = 2;
     double global_cov_factor = 3.0, min_color_sharing = 0.5;
     bool detect_cycles = true, detect_snps = false;
+    bool fast = false, gpu = false; // --fast: the same files from thread-parallel counting-table build / compaction / adjacency / cycle search; --gpu: --fast with the k-mers counted on the device
     std::vector<std::string> colour_files; // pass-2 index (`Ratatosk index -2`): colours = ids of these (pass-1 corrected long) reads, one id per read
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -80,17 +200,38 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         else if (a == "--global-cov-factor") global_cov_factor = atof(need("--global-cov-factor"));
         else if (a == "--no-short-cycles") detect_cycles = false;
         else if (a == "--snps") detect_snps = true;
+        else if (a == "--fast") fast = true;
+        else if (a == "--gpu") { fast = true; gpu = true; }
         else if (a == "--colour-reads") colour_files.push_back(need("--colour-reads"));
         else { fprintf(stderr, "rtk_build_index: unknown option %s\n", a.c_str()); return 2; }
     }
-    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=63)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
+    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=63)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--fast | --gpu (k <= 31: same files, threads / the device for the heavy steps)] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
     const KM mask = km_mask<KM>(k);
+    if (fast && sizeof(KM) != 8) { fprintf(stderr, "rtk_build_index: --fast / --gpu serve one-word k-mers (k <= 31); k = %d takes the plain path\n", k); fast = false; gpu = false; }
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (getenv("RTK_INDEX_TRACE")) fprintf(stderr, "rtk_build_index: [%8.2f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what); };
 
     // ---- pass 1: count canonical k-mers. The k-mer space is cut into one shard per thread by a hash; every thread reads the input
     // itself (parsing is cheap next to a table insert) and counts the k-mers of its shard in a table of its own ----
     unsigned n_thr = std::thread::hardware_concurrency(); if (n_thr == 0) n_thr = 1; if (n_thr > 32) n_thr = 32;
     { const char* e = getenv("RTK_INDEX_THREADS"); if (e && atoi(e) > 0) n_thr = static_cast<unsigned>(atoi(e)); }
     std::vector<KM> solid;
+    if (gpu) { // the k-mers counted on the device (csrc/hip/rtk_index.hip, through the C ABI of libratatosk_hip.so next to this executable)
+        typedef int (*count_fn)(int, int, const char* const*, int, uint32_t, int, uint64_t**, uint64_t*);
+        typedef const char* (*err_fn)(void); typedef void (*free_fn)(void*);
+        std::string lib = "libratatosk_hip.so";
+        { char exe[4096]; const ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1); if (n > 0) { exe[n] = 0; std::string d(exe); d = d.substr(0, d.rfind('/')); lib = d + "/../libratatosk_hip.so"; } }
+        void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { fprintf(stderr, "rtk_build_index: --gpu: cannot load %s (%s)\n", lib.c_str(), dlerror()); return 1; }
+        count_fn cf = reinterpret_cast<count_fn>(dlsym(h, "rtk_index_count_kmers")); err_fn ef = reinterpret_cast<err_fn>(dlsym(h, "rtk_last_error")); free_fn ff = reinterpret_cast<free_fn>(dlsym(h, "rtk_free"));
+        if (!cf || !ef || !ff) { fprintf(stderr, "rtk_build_index: --gpu: %s lacks the index entry points\n", lib.c_str()); return 1; }
+        std::vector<const char*> fp; for (size_t f = 0; f < in_files.size(); ++f) fp.push_back(in_files[f].c_str());
+        uint64_t* sk = nullptr; uint64_t ns = 0;
+        if (cf(0, k, fp.data(), static_cast<int>(fp.size()), min_count, static_cast<int>(n_thr), &sk, &ns) != 0) { fprintf(stderr, "rtk_build_index: --gpu: %s\n", ef()); return 1; }
+        solid.resize(ns);
+        for (uint64_t i = 0; i < ns; ++i) solid[i] = static_cast<KM>(sk[i]);
+        ff(sk);
+    } else
     {
         std::vector<std::vector<KM> > part(n_thr);
         std::vector<int> bad(n_thr, 0);
@@ -120,10 +261,13 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         for (unsigned t = 0; t < n_thr; ++t) { solid.insert(solid.end(), part[t].begin(), part[t].end()); std::vector<KM>().swap(part[t]); }
         std::sort(solid.begin(), solid.end());
     }
+    lap("k-mers counted");
     size_t cap = 16; while (cap * 6 < solid.size() * 10 + 16) cap <<= 1; cap <<= 1;
     KTable<KM> km(cap); // canonical solid k-mer -> 0 (unvisited) or (unitig+1)<<32 | offset<<1 | fw_flag
-    for (size_t i = 0; i < solid.size(); ++i) *km.slot(solid[i], true) = 0;
+    if (fast) fast_table_fill(km, solid, n_thr);
+    else for (size_t i = 0; i < solid.size(); ++i) *km.slot(solid[i], true) = 0;
     fprintf(stderr, "rtk_build_index: %zu solid %d-mers\n", solid.size(), k);
+    lap("k-mer table filled");
 
     auto in_graph = [&](KM oriented) -> bool { return km.slot(kmer_canonical(oriented, k), false) != nullptr; };
     auto succs = [&](KM x, KM out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const KM y = ((x << 2) | static_cast<KM>(b)) & mask; if (in_graph(y)) out[n++] = y; } return n; };
@@ -131,7 +275,12 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
 
     // ---- unitigs: maximal non-branching paths ----
     std::vector<Unitig> U;
+    bool fast_done = false;
+    if (fast) fast_done = fast_unitigs(km, solid, k, n_thr, U);
+    if (!fast_done)
     {
+        if (fast) for (size_t i = 0; i < km.vals.size(); ++i) km.vals[i] = 0; // (the thread-parallel construction backed out: every k-mer unvisited again)
+        U.clear();
         std::set<KM> in_this; // canonical k-mers of the unitig being built (cycle / hairpin guard)
         for (size_t si = 0; si < solid.size(); ++si) {
             uint64_t* v0 = km.slot(solid[si], false);
@@ -169,6 +318,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         }
     }
     fprintf(stderr, "rtk_build_index: %zu unitigs\n", U.size());
+    lap("unitigs built");
 
     // ---- pass 2: colours (pair ids) and coverage. One reader parses the records and numbers them (a pair keeps one id), worker threads
     // look their k-mers up (the table is only read) and collect (unitig, id) events and per-unitig counts of their own ----
@@ -246,7 +396,8 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         while (i < a.size() && j < b.size()) { if (a[i] < b[j]) ++i; else if (b[j] < a[i]) ++j; else { ++c; ++i; ++j; } }
         return c;
     };
-    for (size_t u = 0; u < n; ++u) {
+    lap("colours and coverage done");
+    auto adjacency_of = [&](size_t u) {
         const std::string& s = U[u].seq;
         KM tail = 0, head = 0;
         km_encode<KM>(s.c_str() + s.size() - k, k, tail);
@@ -265,7 +416,10 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         }
         const uint64_t cov = std::min<uint64_t>(U[u].cov, 0x7fffffffULL);
         kmcov[u] = (cov << 31) | ((deg[0] > 1 || deg[1] > 1) ? (1ULL << 63) : 0ULL);
-    }
+    };
+    if (fast) parallel_for(n, n_thr, [&](size_t b, size_t e, unsigned) { for (size_t u = b; u < e; ++u) adjacency_of(u); }); // (unitigs are independent: the table is only read)
+    else for (size_t u = 0; u < n; ++u) adjacency_of(u);
+    lap("adjacency and edge bits done");
 
     // ---- short cycles (restatement of detectShortCycles, src/Graph.cpp:4660-4735): for every unitig U in forward direction, breadth
     // first over paths U -> X1 .. Xm -> U whose interior spans fewer than k + 1 k-mers, following only edges carrying an edge bit and
@@ -278,7 +432,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         auto n_km = [&](size_t u) { return U[u].seq.size() - static_cast<size_t>(k) + 1; };
         struct Step { size_t u; bool fw; char base; };
         size_t n_cyc_unitigs = 0;
-        for (size_t u0 = 0; u0 < n; ++u0) {
+        auto cycles_of = [&](size_t u0) {
             std::queue<std::vector<Step> > q;
             { std::vector<Step> p0; Step s0; s0.u = u0; s0.fw = true; s0.base = 0; p0.push_back(s0); q.push(p0); }
             while (!q.empty()) {
@@ -311,9 +465,13 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                     }
                 }
             }
-            if (!cycles[u0].empty()) { shared[u0] |= 0x100ULL; ++n_cyc_unitigs; }
-        }
+        };
+        // (the search of one unitig reads the edge bits of others: the short-cycle flags are set afterwards, not during the searches)
+        if (fast) parallel_for(n, n_thr, [&](size_t b, size_t e, unsigned) { for (size_t u = b; u < e; ++u) cycles_of(u); });
+        else for (size_t u0 = 0; u0 < n; ++u0) cycles_of(u0);
+        for (size_t u0 = 0; u0 < n; ++u0) if (!cycles[u0].empty()) { shared[u0] |= 0x100ULL; ++n_cyc_unitigs; }
         fprintf(stderr, "rtk_build_index: %zu unitigs in short cycles\n", n_cyc_unitigs);
+        lap("short cycles done");
     }
 
     // ---- SNP annotations: restatement of detectSNPs (src/Graph.cpp:484-720) with isValidSNPcandidate (src/GraphTraversal.cpp:1057-1147).
@@ -423,6 +581,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         size_t n_amb = 0, n_amb_unitigs = 0;
         for (size_t u = 0; u < n; ++u) { n_amb += ambiguity[u].size(); n_amb_unitigs += ambiguity[u].empty() ? 0 : 1; }
         fprintf(stderr, "rtk_build_index: %zu SNP annotations on %zu unitigs\n", n_amb, n_amb_unitigs);
+        lap("SNP annotations done");
     }
 
     // ---- global / local colour split (simplified restatement of src/Graph.cpp:2874-2985) ----
@@ -470,6 +629,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         size_t ng = 0;
         for (size_t u = 0; u < n; ++u) { if (global_ids[u].empty()) local_ids[u] = U[u].colours; else ++ng; }
         fprintf(stderr, "rtk_build_index: est. k-mer coverage %.2f, %zu unitigs carry a global colour set\n", est_cov, ng);
+        lap("global / local colour sets done");
     }
 
     // ---- write ----
@@ -487,6 +647,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             rtsk_write_record(out, r);
         }
     }
+    lap("files written");
     return 0;
 }
 

@@ -1,0 +1,91 @@
+"""Index build, fast paths: `rtk_build_index --fast` (thread-parallel table fill, unitig construction, adjacency, cycle search)
+and `--gpu` (--fast with the k-mers counted on the device: csrc/hip/rtk_index.hip, rtk_index_count_kmers) must write the SAME two files as the
+plain single-path tool, byte for byte -- the plain tool is their oracle. Seeded sets with heterozygous SNPs, two-copy repeats and tandem
+repeats, k = 31 and k = 21, and two hand-made genomes whose chains of k-mers meet themselves (a closed loop, a hairpin): those take the
+plain construction inside the fast path."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import BIN
+
+SETS = [
+    ("het_repeats", ["--seed", "11", "--ref-len", "30000", "--het", "0.004", "--repeat-frac", "0.1", "--sr-cov", "40", "--sr-err", "0.01"]),
+    ("tandem", ["--seed", "21", "--ref-len", "60000", "--het", "0.003", "--tandem", "30", "--sr-cov", "40", "--sr-err", "0.005"]),
+    ("diploid_400k", ["--seed", "7", "--ref-len", "400000", "--het", "0.002", "--repeat-frac", "0.05", "--sr-cov", "30", "--sr-err", "0.005"]),
+]
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def _build(sr, out, k, extra):
+    r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", sr, "-o", out, "-k", str(k), "--snps"] + extra, capture_output=True, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1"))
+    assert r.returncode == 0, r.stderr
+    return open(out + ".index.k%d.fasta.gz" % k, "rb").read(), open(out + ".index.k%d.rtsk" % k, "rb").read(), r.stderr
+
+
+def _same(tmp, name, sr, mode, ks=(31, 21)):
+    for k in ks:
+        a = _build(sr, os.path.join(tmp, name + "_plain"), k, [])
+        b = _build(sr, os.path.join(tmp, name + "_" + mode.strip("-")), k, [mode])
+        assert a[0] == b[0], (name, k, "unitig FASTA differs")
+        assert a[1] == b[1], (name, k, ".rtsk differs")
+    return b[2]
+
+
+def _simulated(tmp, name, args):
+    pre = os.path.join(tmp, name)
+    subprocess.check_call([os.path.join(BIN, "rtk_simulate"), "--prefix", pre] + args + ["--lr-n", "2", "--lr-len", "1000"], stderr=subprocess.DEVNULL)
+    return pre + ".sr.fq"
+
+
+def _self_meeting_genomes(tmp):
+    """Reads tiling (a) a circular 600 bp sequence -- every k-mer has one successor and one predecessor: a closed loop without an end --
+    and (b) W + reverse complement of W: the chain of k-mers runs into its own reverse complement (hairpin)."""
+    import random
+    rnd = random.Random(5)
+    circ = "".join(rnd.choice("ACGT") for _ in range(600))
+    w = "".join(rnd.choice("ACGT") for _ in range(300))
+    hair = w + _rc(w)
+    sr = os.path.join(tmp, "self.sr.fq")
+    with open(sr, "w") as f:
+        n = 0
+        for rep in range(3):
+            for start in range(0, 600, 7):
+                s = (circ + circ)[start:start + 100]
+                f.write("@c%d\n%s\n+\n%s\n" % (n, s, "I" * 100)); n += 1
+            for start in range(0, len(hair) - 100 + 1, 5):
+                s = hair[start:start + 100]
+                f.write("@h%d\n%s\n+\n%s\n" % (n, s, "I" * 100)); n += 1
+    return sr
+
+
+def test_fast_index_build_writes_the_same_files(tmp_path):
+    tmp = str(tmp_path)
+    for name, args in SETS:
+        _same(tmp, name, _simulated(tmp, name, args), "--fast")
+    trace = _same(tmp, "self", _self_meeting_genomes(tmp), "--fast", ks=(31,))
+    n_plain = [int(l.split(":")[1].split()[0]) for l in trace.splitlines() if "chains that meet themselves" in l]
+    assert n_plain and n_plain[0] >= 2, trace  # the loop and the hairpin went through the plain construction inside the fast path
+
+
+@pytest.mark.gpu
+def test_gpu_index_build_writes_the_same_files(tmp_path):
+    """k-mers counted on the device: the files of three seeded sets (and the self-meeting genomes) are the plain tool's, byte for byte."""
+    tmp = str(tmp_path)
+    for name, args in SETS:
+        _same(tmp, name, _simulated(tmp, name, args), "--gpu")
+    _same(tmp, "self", _self_meeting_genomes(tmp), "--gpu", ks=(31,))
+    # a bigger set, several partitions of the k-mer space forced (RTK_INDEX_CAP: k-mers per pass)
+    sr = _simulated(tmp, "c5m", ["--seed", "2", "--ref-len", "3000000", "--het", "0.001", "--sr-cov", "30", "--sr-err", "0.005"])
+    a = _build(sr, os.path.join(tmp, "c5m_plain"), 31, [])
+    b = _build(sr, os.path.join(tmp, "c5m_gpu"), 31, ["--gpu"])
+    os.environ["RTK_INDEX_CAP"] = "30000000"
+    try:
+        c = _build(sr, os.path.join(tmp, "c5m_gpu_parts"), 31, ["--gpu"])
+    finally:
+        del os.environ["RTK_INDEX_CAP"]
+    assert a[0] == b[0] == c[0] and a[1] == b[1] == c[1]
