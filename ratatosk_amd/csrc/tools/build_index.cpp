@@ -28,6 +28,7 @@
 #include <condition_variable>
 #include <deque>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <set>
@@ -73,6 +74,59 @@ template <class F> static void parallel_for(size_t n, unsigned n_thr, F f) { // 
     for (size_t t = 0; t < th.size(); ++t) th[t].join();
 }
 
+// The graph k-mers ONE SUBSTITUTION away from a k-mer, without spelling the 3k variants: such a neighbour shares the first k/2 bases or the
+// last k - k/2 bases with it. All oriented solid k-mers are kept sorted twice -- as they are (the first half leads) and rotated so that the
+// last half leads -- with a table of the first 24 key bits in front; a query scans the few entries that share its half and keeps those
+// whose other half differs in exactly one base. Used by the SNP search of --fast (the plain path probes every variant in the k-mer table).
+struct NeighbourIndex {
+    int k = 0, hi_n = 0, lo_n = 0; uint64_t lomask = 0;
+    std::vector<uint64_t> a, b; std::vector<uint32_t> ia, ib; int shift = 0; // ia / ib: first entry of every value of the top 24 bits of the 2k-bit key
+    uint64_t rot(uint64_t x) const { return ((x & lomask) << (2 * hi_n)) | (x >> (2 * lo_n)); }
+    uint64_t unrot(uint64_t r) const { return ((r & ((1ULL << (2 * hi_n)) - 1ULL)) << (2 * lo_n)) | (r >> (2 * hi_n)); }
+    static void sort_parallel(std::vector<uint64_t>& v, int key_bits, unsigned n_thr) { // bucket by the top 8 key bits, every bucket sorted by a thread
+        const int sh = key_bits > 8 ? key_bits - 8 : 0;
+        std::vector<size_t> cnt(257, 0);
+        for (size_t i = 0; i < v.size(); ++i) ++cnt[(v[i] >> sh) + 1];
+        for (int i = 0; i < 256; ++i) cnt[i + 1] += cnt[i];
+        std::vector<uint64_t> out(v.size()); std::vector<size_t> at(cnt.begin(), cnt.begin() + 256);
+        for (size_t i = 0; i < v.size(); ++i) out[at[v[i] >> sh]++] = v[i];
+        v.swap(out);
+        std::atomic<int> nx(0); std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_thr; ++t) th.emplace_back([&]() { for (;;) { const int bkt = nx.fetch_add(1); if (bkt >= 256) break; std::sort(v.begin() + cnt[bkt], v.begin() + cnt[bkt + 1]); } });
+        for (size_t t = 0; t < th.size(); ++t) th[t].join();
+    }
+    void build(const std::vector<uint64_t>& solid, int k_, unsigned n_thr) {
+        k = k_; hi_n = k / 2; lo_n = k - hi_n; lomask = (1ULL << (2 * lo_n)) - 1ULL;
+        a.resize(2 * solid.size()); b.resize(2 * solid.size());
+        parallel_for(solid.size(), n_thr, [&](size_t bb, size_t ee, unsigned) { for (size_t i = bb; i < ee; ++i) { const uint64_t x = solid[i], y = kmer_revcomp(x, k); a[2 * i] = x; a[2 * i + 1] = y; b[2 * i] = rot(x); b[2 * i + 1] = rot(y); } });
+        sort_parallel(a, 2 * k, n_thr); sort_parallel(b, 2 * k, n_thr);
+        shift = 2 * k > 24 ? 2 * k - 24 : 0;
+        const size_t nb = (static_cast<size_t>(1) << (2 * k - shift)) + 1;
+        auto index = [&](const std::vector<uint64_t>& v, std::vector<uint32_t>& ix) { ix.assign(nb, 0); for (size_t i = 0; i < v.size(); ++i) ++ix[(v[i] >> shift) + 1]; for (size_t i = 0; i + 1 < nb; ++i) ix[i + 1] += ix[i]; };
+        index(a, ia); index(b, ib);
+    }
+    // calls f(offset j, substituted base) for every graph k-mer one substitution away from x, by (j, base) ascending
+    template <class F> void neighbours(uint64_t x, F f) const {
+        uint32_t found[16]; int nf = 0; // (j << 2 | base); more than 16 cannot happen in practice, the rest would be dropped in order
+        { // same first half: the differing base lies in the last lo_n bases
+            const uint64_t lo_key = x & ~lomask, hi_key = x | lomask;
+            size_t i = ia[lo_key >> shift]; const size_t e = ia[(hi_key >> shift) + 1];
+            i = static_cast<size_t>(std::lower_bound(a.begin() + i, a.begin() + e, lo_key) - a.begin());
+            for (; i < e && a[i] <= hi_key; ++i) { const uint64_t d = a[i] ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 16) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((a[i] >> bit) & 3ULL); }
+        }
+        { // same last half: the differing base lies in the first hi_n bases
+            const uint64_t r = rot(x), himask = (1ULL << (2 * hi_n)) - 1ULL; const uint64_t lo_key = r & ~himask, hi_key = r | himask;
+            size_t i = ib[lo_key >> shift]; const size_t e = ib[(hi_key >> shift) + 1];
+            i = static_cast<size_t>(std::lower_bound(b.begin() + i, b.begin() + e, lo_key) - b.begin());
+            for (; i < e && b[i] <= hi_key; ++i) { const uint64_t y = unrot(b[i]); const uint64_t d = y ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 16) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((y >> bit) & 3ULL); }
+        }
+        std::sort(found, found + nf);
+        for (int i = 0; i < nf; ++i) f(static_cast<int>(found[i] >> 2), static_cast<uint64_t>(found[i] & 3u));
+    }
+};
+
+static const std::vector<uint64_t>& solid64(const std::vector<uint64_t>& v) { return v; }
+static const std::vector<uint64_t>& solid64(const std::vector<u128>&) { static const std::vector<uint64_t> none; return none; }
 // (two-word k-mers take the plain path: these overloads are never reached)
 static void fast_table_fill(KTable<u128>&, const std::vector<u128>&, unsigned) {}
 static bool fast_unitigs(KTable<u128>&, const std::vector<u128>&, int, unsigned, std::vector<Unitig>&) { return false; }
@@ -213,7 +267,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
 
     // ---- pass 1: count canonical k-mers. The k-mer space is cut into one shard per thread by a hash; every thread reads the input
     // itself (parsing is cheap next to a table insert) and counts the k-mers of its shard in a table of its own ----
-    unsigned n_thr = std::thread::hardware_concurrency(); if (n_thr == 0) n_thr = 1; if (n_thr > 32) n_thr = 32;
+    unsigned n_thr = std::thread::hardware_concurrency(); if (n_thr == 0) n_thr = 1; if (n_thr > (fast ? 64u : 32u)) n_thr = fast ? 64u : 32u;
     { const char* e = getenv("RTK_INDEX_THREADS"); if (e && atoi(e) > 0) n_thr = static_cast<unsigned>(atoi(e)); }
     std::vector<KM> solid;
     if (gpu) { // the k-mers counted on the device (csrc/hip/rtk_index.hip, through the C ABI of libratatosk_hip.so next to this executable)
@@ -319,6 +373,18 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     }
     fprintf(stderr, "rtk_build_index: %zu unitigs\n", U.size());
     lap("unitigs built");
+    // the unitig FASTA only needs the sequences: with --fast it is compressed (one zlib stream, the same bytes as the plain path writes at the end)
+    // on a thread of its own while the colours, annotations and records are worked out
+    const std::string fn_fasta = prefix + ".index.k" + std::to_string(k) + ".fasta.gz";
+    std::atomic<int> fasta_rc(0);
+    auto write_fasta = [&]() {
+        gzFile gz = gzopen(fn_fasta.c_str(), "wb6");
+        if (!gz) { fasta_rc = 1; return; }
+        for (size_t u = 0; u < U.size(); ++u) { gzprintf(gz, ">%zu\n", u); gzwrite(gz, U[u].seq.data(), static_cast<unsigned>(U[u].seq.size())); gzputc(gz, '\n'); }
+        gzclose(gz);
+    };
+    std::thread fasta_thread;
+    if (fast) fasta_thread = std::thread(write_fasta);
 
     // ---- pass 2: colours (pair ids) and coverage. One reader parses the records and numbers them (a pair keeps one id), worker threads
     // look their k-mers up (the table is only read) and collect (unitig, id) events and per-unitig counts of their own ----
@@ -354,9 +420,69 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                 delete c;
             }
         };
+        bool par_colour = fast;
+        for (size_t f = 0; par_colour && f < col_in.size(); ++f) par_colour = PlainChunks::is_plain(col_in[f]);
+        if (par_colour) {
+            // --fast on plain files: byte ranges of the files parsed and looked up by all threads. The id of a read is the number of name changes
+            // before it (every read with --colour-reads), so a first sweep over the ranges counts the changes inside each and notes its first and last
+            // name; the running sums give every range the id of its first read; the second sweep maps the reads.
+            struct RangeInfo { uint32_t changes = 0; uint64_t n_reads = 0; std::string first, last; };
+            auto base_name = [](const PackedReads& r, size_t i, const char** p, size_t* n) { *p = r.name(i); *n = r.name_len(i); if (*n > 2 && (*p)[*n - 2] == '/' && ((*p)[*n - 1] == '1' || (*p)[*n - 1] == '2')) *n -= 2; };
+            for (unsigned t = 0; t < n_thr; ++t) t_cov[t].assign(n_u, 0);
+            uint32_t next_id = 0; bool have_prev = false; std::string prev_last;
+            for (size_t f = 0; f < col_in.size() && !open_failed; ++f) {
+                PlainChunks pc; if (!pc.open(col_in[f], 32u << 20)) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); open_failed = 1; break; }
+                const size_t nc = pc.n_chunks();
+                std::vector<RangeInfo> info(nc);
+                std::atomic<size_t> nx(0); std::atomic<int> bad(0);
+                { std::vector<std::thread> th;
+                  for (unsigned t = 0; t < n_thr; ++t) th.emplace_back([&]() {
+                      for (;;) { const size_t i = nx.fetch_add(1); if (i >= nc) break;
+                          PackedReads r(false); if (!pc.parse_chunk(i, r)) { bad = 1; break; }
+                          RangeInfo& ri = info[i]; ri.n_reads = r.size();
+                          const char* pp = nullptr; size_t pn = 0;
+                          for (size_t x = 0; x < r.size(); ++x) { const char* p; size_t n; base_name(r, x, &p, &n); if (x == 0) ri.first.assign(p, n); else if (by_read || n != pn || memcmp(p, pp, n) != 0) ++ri.changes; pp = p; pn = n; }
+                          if (r.size()) ri.last.assign(pp, pn);
+                      } });
+                  for (size_t t = 0; t < th.size(); ++t) th[t].join(); }
+                if (bad) { open_failed = 1; break; }
+                std::vector<uint32_t> id0(nc, 0); // id of the first read of every range
+                for (size_t i = 0; i < nc; ++i) {
+                    if (info[i].n_reads == 0) { id0[i] = next_id; continue; }
+                    if (have_prev && (by_read || info[i].first != prev_last)) ++next_id;
+                    id0[i] = next_id; next_id += info[i].changes; have_prev = true; prev_last = info[i].last;
+                }
+                nx = 0;
+                { std::vector<std::thread> th;
+                  for (unsigned t = 0; t < n_thr; ++t) th.emplace_back([&, t]() {
+                      std::vector<uint64_t>& cov = t_cov[t]; std::vector<std::pair<uint32_t, uint32_t> >& ev = t_ev[t];
+                      for (;;) { const size_t i = nx.fetch_add(1); if (i >= nc) break;
+                          PackedReads r(false); if (!pc.parse_chunk(i, r)) { bad = 1; break; }
+                          uint32_t id = id0[i]; const char* pp = nullptr; size_t pn = 0;
+                          for (size_t x = 0; x < r.size(); ++x) {
+                              const char* p; size_t n; base_name(r, x, &p, &n);
+                              if (x != 0 && (by_read || n != pn || memcmp(p, pp, n) != 0)) ++id;
+                              pp = p; pn = n;
+                              const char* seq = r.seq(x); const size_t sl = r.seq_len(x);
+                              KM fw = 0; int valid = 0;
+                              for (size_t y = 0; y < sl; ++y) {
+                                  const int b = base2bits(seq[y]);
+                                  if (b < 0) { valid = 0; fw = 0; continue; }
+                                  fw = ((fw << 2) | static_cast<KM>(b)) & mask;
+                                  if (++valid >= k) {
+                                      const uint64_t* v = km.slot(kmer_canonical(fw, k), false);
+                                      if (v) { const uint32_t u = static_cast<uint32_t>((*v >> 32) - 1); ++cov[u]; if (ev.empty() || ev.back().first != u || ev.back().second != id) ev.push_back(std::make_pair(u, id)); }
+                                  }
+                              }
+                          }
+                      } });
+                  for (size_t t = 0; t < th.size(); ++t) th[t].join(); }
+                if (bad) { open_failed = 1; break; }
+            }
+        }
         std::vector<std::thread> th;
-        for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(work, t);
-        {
+        if (!par_colour) for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(work, t);
+        if (!par_colour) {
             std::string name, seq, qual, prev_name;
             uint32_t pair_id = 0; bool first = true;
             Chunk* cur = new Chunk();
@@ -377,7 +503,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             cv_get.notify_all();
         }
         for (size_t t = 0; t < th.size(); ++t) th[t].join();
-        if (open_failed) return 1;
+        if (open_failed) { if (fasta_thread.joinable()) fasta_thread.join(); return 1; }
         for (unsigned t = 0; t < n_thr; ++t) {
             for (size_t u = 0; u < n_u; ++u) U[u].cov += t_cov[t][u];
             for (size_t e = 0; e < t_ev[t].size(); ++e) U[t_ev[t][e].first].colours.push_back(t_ev[t][e].second);
@@ -537,6 +663,9 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': return 8; case 'M': return 3; case 'R': return 5; case 'S': return 6; case 'V': return 7;
                          case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12; case 'D': return 13; case 'B': return 14; case 'N': return 15; default: return 0; } };
         static const char amb_char[16] = {'.', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N'}; // getAmbiguity
+        std::unique_ptr<NeighbourIndex> nbx_own;
+        if (fast) { nbx_own.reset(new NeighbourIndex()); nbx_own->build(solid64(solid), k, n_thr); lap("1-substitution neighbour index built"); }
+        const NeighbourIndex* const nbx = nbx_own.get();
         auto annotate = [&](size_t u) {
             if (!(shared[u] & 0xffULL)) return; // hasSharedPids (src/Graph.cpp:500)
             const std::string& s = U[u].seq;
@@ -548,26 +677,27 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                 fw = ((fw << 2) | static_cast<KM>(base2bits(s[i]))) & mask;
                 if (i + 1 < static_cast<size_t>(k)) continue;
                 const size_t p = i + 1 - static_cast<size_t>(k);
-                for (int j = 0; j < k; ++j) {
+                auto candidate = [&](int j, uint64_t alt) { // the graph holds the window with base `alt` at offset j
                     const int sh = 2 * (k - 1 - j);
-                    const uint64_t cur = static_cast<uint64_t>(fw >> sh) & 3ULL;
-                    for (uint64_t alt = 0; alt < 4; ++alt) {
-                        if (alt == cur) continue;
-                        const KM y = (fw & ~(static_cast<KM>(3) << sh)) | (static_cast<KM>(alt) << sh);
-                        const uint64_t* v = km.slot(kmer_canonical(y, k), false);
-                        if (!v) continue;
-                        const size_t w = (*v >> 32) - 1;
-                        if (w == u) continue; // a SNP candidate cannot be on the same unitig (src/Graph.cpp:523)
-                        const size_t at = p + static_cast<size_t>(j); // pos_snp_km = first mismatch = the substituted offset
-                        const unsigned f = amb_bits(seq_final[at]), t = amb_bits(seq_tried[at]), kk = 1u << alt;
-                        const char cf = amb_char[f | kk], ct = amb_char[t | kk];
-                        if (seq_tried[at] == ct) continue; // that base was tried at this position before
-                        seq_tried[at] = ct;
-                        if (ok.count(w)) seq_final[at] = cf;
-                        else if (!bad.count(w)) {
-                            if (is_valid(lgt_fw, lgt_bw, u, w)) { seq_final[at] = cf; ok.insert(w); } else bad.insert(w);
-                        }
+                    const KM y = (fw & ~(static_cast<KM>(3) << sh)) | (static_cast<KM>(alt) << sh);
+                    const uint64_t* v = km.slot(kmer_canonical(y, k), false);
+                    if (!v) return;
+                    const size_t w = (*v >> 32) - 1;
+                    if (w == u) return; // a SNP candidate cannot be on the same unitig (src/Graph.cpp:523)
+                    const size_t at = p + static_cast<size_t>(j); // pos_snp_km = first mismatch = the substituted offset
+                    const unsigned f = amb_bits(seq_final[at]), t = amb_bits(seq_tried[at]), kk = 1u << alt;
+                    const char cf = amb_char[f | kk], ct = amb_char[t | kk];
+                    if (seq_tried[at] == ct) return; // that base was tried at this position before
+                    seq_tried[at] = ct;
+                    if (ok.count(w)) seq_final[at] = cf;
+                    else if (!bad.count(w)) {
+                        if (is_valid(lgt_fw, lgt_bw, u, w)) { seq_final[at] = cf; ok.insert(w); } else bad.insert(w);
                     }
+                };
+                if (nbx) nbx->neighbours(static_cast<uint64_t>(fw), candidate); // --fast: the neighbours from the two sorted views of the k-mer set, same order
+                else for (int j = 0; j < k; ++j) {
+                    const uint64_t cur = static_cast<uint64_t>(fw >> (2 * (k - 1 - j))) & 3ULL;
+                    for (uint64_t alt = 0; alt < 4; ++alt) if (alt != cur) candidate(j, alt);
                 }
             }
             for (size_t i = 0; i < seq_final.size(); ++i) if (seq_final[i] != 'A' && seq_final[i] != 'C' && seq_final[i] != 'G' && seq_final[i] != 'T') ambiguity[u].push_back(static_cast<uint32_t>((i << 4) + amb_bits(seq_final[i]))); // UnitigData.hpp:448-451
@@ -634,10 +764,8 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
 
     // ---- write ----
     {
-        gzFile gz = gzopen((prefix + ".index.k" + std::to_string(k) + ".fasta.gz").c_str(), "wb6");
-        if (!gz) { fprintf(stderr, "rtk_build_index: cannot write fasta.gz\n"); return 1; }
-        for (size_t u = 0; u < n; ++u) { gzprintf(gz, ">%zu\n", u); gzwrite(gz, U[u].seq.data(), static_cast<unsigned>(U[u].seq.size())); gzputc(gz, '\n'); }
-        gzclose(gz);
+        if (fast) fasta_thread.join(); else write_fasta();
+        if (fasta_rc) { fprintf(stderr, "rtk_build_index: cannot write fasta.gz\n"); return 1; }
         std::ofstream out((prefix + ".index.k" + std::to_string(k) + ".rtsk").c_str(), std::ios::binary);
         for (size_t u = 0; u < n; ++u) {
             RtskRecord r;

@@ -67,6 +67,15 @@ def test_fast_index_build_writes_the_same_files(tmp_path):
     tmp = str(tmp_path)
     for name, args in SETS:
         _same(tmp, name, _simulated(tmp, name, args), "--fast")
+    # second-pass index (--colour-reads: every read its own colour) through the same fast path
+    sr = _simulated(tmp, "p2", SETS[0][1])
+    lr = os.path.join(tmp, "p2.lr.fq")
+    outs = []
+    for mode in ([], ["--fast"]):
+        out = os.path.join(tmp, "p2_" + ("fast" if mode else "plain"))
+        subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", sr, "--colour-reads", lr, "-o", out] + mode, stderr=subprocess.DEVNULL)
+        outs.append((open(out + ".index.k31.fasta.gz", "rb").read(), open(out + ".index.k31.rtsk", "rb").read()))
+    assert outs[0] == outs[1]
     trace = _same(tmp, "self", _self_meeting_genomes(tmp), "--fast", ks=(31,))
     n_plain = [int(l.split(":")[1].split()[0]) for l in trace.splitlines() if "chains that meet themselves" in l]
     assert n_plain and n_plain[0] >= 2, trace  # the loop and the hairpin went through the plain construction inside the fast path
