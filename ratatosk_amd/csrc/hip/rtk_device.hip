@@ -95,7 +95,7 @@ struct rtk_graph {
 
 static void graph_set_view(rtk_graph* g) {
     GraphView& v = g->dview;
-    v.k = g->info.k; v.n_unitigs = static_cast<uint32_t>(g->info.n_unitigs); v.n_kmers = g->info.n_kmers; v.ht_mask = g->info.table_slots - 1;
+    v.k = g->info.k; v.n_unitigs = static_cast<uint32_t>(g->info.n_unitigs); v.n_kmers = g->info.n_kmers; v.ht_slots = g->info.table_slots;
     v.useq = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_USEQ]); v.uoff = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_UOFF]);
     v.adj = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_ADJ]); v.flags = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_FLAGS]);
     v.kcov = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_KCOV]); v.card = static_cast<const uint32_t*>(g->dbuf[rtk::RTK_BUF_CARD]);
@@ -184,6 +184,10 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
 }
 
 extern "C" int rtk_n_devices(void) { return rtk_device_count(); }
+#ifdef RTK_SIM
+// (the simulator build has the entry point for ABI completeness only: k-mer counting on the device is csrc/hip/rtk_index.hip, its CPU form the index tool's plain path)
+extern "C" int rtk_index_count_kmers(int, int, const char* const*, int, uint32_t, int, uint64_t**, uint64_t*) { return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_count_kmers: not part of the simulator build"); }
+#endif
 extern "C" int rtk_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
     if (!free_bytes || !total_bytes) return rtk_fail(RTK_ERR_ARG, "rtk_device_memory: null argument");
     if (rtk_device_count() <= device || device < 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_device_memory: no such HIP device");

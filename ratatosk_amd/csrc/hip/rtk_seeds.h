@@ -428,7 +428,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
         // A window in flight is remembered by its three scalar words; the k-mers of the few variants that pass the filter are spelled
         // again when their slot arrives, so that only the slot contents wait in vector registers.
         struct Win { uint64_t w_b, w_k1; uint32_t w_ck, w_ck1; };
-        const uint64_t* const ht = g.ht; const uint64_t ht_mask = g.ht_mask; const uint64_t* const bf = g.bf; const uint64_t bf_mask = g.bf_mask; const uint64_t* const bf1 = g.bf1; const uint64_t bf1_mask = g.bf1_mask;
+        const uint64_t* const ht = g.ht; const uint64_t ht_slots = g.ht_slots; const uint64_t* const bf = g.bf; const uint64_t bf_mask = g.bf_mask; const uint64_t* const bf1 = g.bf1; const uint64_t bf1_mask = g.bf1_mask;
         auto stage_probe = [&](Win& wn, uint32_t& pass, uint64_t* skey, uint64_t* sval) { // takes the next candidate off `bal`
             const int sl = rtk_ffs(bal) - 1;
             bal &= bal - 1ull;
@@ -451,7 +451,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
             for (int rr = 0; rr < 4; ++rr) {
                 const bool ps = valid1[rr] && rtk_filter_pass(word[rr], hh[rr]);
                 skey[rr] = RTK_EMPTY_KEY; sval[rr] = 0;
-                if (ps) { pass |= 1u << rr; const uint64_t* sp = ht + 2 * (hh[rr] & ht_mask); skey[rr] = sp[0]; sval[rr] = sp[1]; }
+                if (ps) { pass |= 1u << rr; const uint64_t* sp = ht + 2 * rtk_ht_slot(hh[rr], ht_slots); skey[rr] = sp[0]; sval[rr] = sp[1]; }
             }
         };
         auto stage_resolve = [&](const Win& wn, uint32_t pass, const uint64_t* skey, const uint64_t* sval) {
@@ -464,7 +464,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
                     rtk_kmer_prepare(code, k, &can, &hh, &q);
                     slots += 1;
                     if (skey[rr] == can) hit = rtk_pack_hit(static_cast<uint32_t>(sval[rr] >> 32), static_cast<uint32_t>((sval[rr] & 0xFFFFFFFFull) >> 1), (static_cast<uint32_t>(sval[rr] & 1ull) == q) ? 1u : 0u);
-                    else if (skey[rr] != RTK_EMPTY_KEY) { uint32_t np; hit = rtk_table_lookup(g, can, hh + 1, q, &np); slots += np; } // collision: keep probing from the next slot
+                    else if (skey[rr] != RTK_EMPTY_KEY) { uint32_t np; hit = rtk_table_probe_from(g, can, rtk_ht_next(rtk_ht_slot(hh, ht_slots), ht_slots), q, &np); slots += np; } // collision: keep probing from the next slot
                 }
                 const uint64_t hb = rtk_ballot(hit != RTK_NO_HIT);
                 if (hit != RTK_NO_HIT) { my_code[my_n] = code; my_hit[my_n] = hit; my_kind[my_n] = rtk_variant_kind(rtk_lane() + 64 * rr); any |= my_kind[my_n]; ++my_n; }

@@ -71,7 +71,7 @@ struct GraphView {
     U<int32_t> k;
     U<uint32_t> n_unitigs;
     U<uint64_t> n_kmers;
-    U<uint64_t> ht_mask;          // slots - 1 (power of two)
+    U<uint64_t> ht_slots;         // slots of the k-mer table (any number: a hash is mapped to its slot by multiply-high, rtk_ht_slot)
     U<const uint64_t*> useq;      // unitig bases, 2 bits each, base i of the pool at bits [2*(i&31), +1] of word i>>5
     U<const uint64_t*> uoff;      // [n+1] first base of unitig u in the pool
     U<const uint32_t*> adj;       // [n*8] fw A,C,G,T then reverse-strand A,C,G,T: neighbour unitig<<1|strand or RTK_NONE32
@@ -137,6 +137,17 @@ RTK_HD UMap rtk_unpack_hit(uint64_t h) { UMap u; u.unitig = static_cast<uint32_t
 
 // Exact k-mer lookup (Bifrost find(km,false) [A1]): fw = k-mer code in read orientation. *n_probes = 16-byte table slots visited
 // (0 when the pre-filter already answered).
+// slot of a hash in a table of `slots` entries: floor(hash * slots / 2^64) -- no power-of-two table sizes needed (a 3 Gb graph: 69 GB at load 0.7
+// instead of 137 GB), the high hash bits decide; next slot of the linear probe
+RTK_HD uint64_t rtk_ht_slot(uint64_t hh, uint64_t slots) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RTK_SIM)
+    return __umul64hi(hh, slots);
+#else
+    return static_cast<uint64_t>((static_cast<unsigned __int128>(hh) * static_cast<unsigned __int128>(slots)) >> 64);
+#endif
+}
+RTK_HD uint64_t rtk_ht_next(uint64_t i, uint64_t slots) { return i + 1 == slots ? 0 : i + 1; }
+
 RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probes) {
     const uint64_t rc = rtk_revcomp(fw, g.k);
     const uint64_t can = fw < rc ? fw : rc;
@@ -149,7 +160,7 @@ RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probe
         const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63));
         if ((g.bf[(hh >> 32) & g.bf_mask] & bits) != bits) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; }
     }
-    uint64_t i = hh & g.ht_mask;
+    uint64_t i = rtk_ht_slot(hh, g.ht_slots);
     uint32_t np = 0;
     while (true) {
         const uint64_t key = g.ht[2 * i];
@@ -161,7 +172,7 @@ RTK_HD uint64_t rtk_find_kmer(const GraphView& g, uint64_t fw, uint32_t* n_probe
             return rtk_pack_hit(static_cast<uint32_t>(v >> 32), static_cast<uint32_t>((v & 0xFFFFFFFFull) >> 1), stored_is_can == query_is_can ? 1u : 0u);
         }
         if (key == RTK_EMPTY_KEY) { if (n_probes) *n_probes = np; return RTK_NO_HIT; }
-        i = (i + 1) & g.ht_mask;
+        i = rtk_ht_next(i, g.ht_slots);
     }
 }
 
@@ -205,7 +216,7 @@ RTK_HD uint64_t rtk_find_kmer_wide(const GraphView& g, const RtkKm& fw, uint32_t
     { const uint64_t b1 = (hh >> 12) & g.bf1_mask; if (!((g.bf1[b1 >> 6] >> (b1 & 63ull)) & 1ull)) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; } }
     { const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)); if ((g.bf[(hh >> 32) & g.bf_mask] & bits) != bits) { if (n_probes) *n_probes = 0; return RTK_NO_HIT; } }
     const uint64_t fp = rtk_km_fingerprint(can);
-    uint64_t i = hh & g.ht_mask;
+    uint64_t i = rtk_ht_slot(hh, g.ht_slots);
     uint32_t np = 0;
     while (true) {
         const uint64_t key = g.ht[2 * i];
@@ -218,7 +229,7 @@ RTK_HD uint64_t rtk_find_kmer_wide(const GraphView& g, const RtkKm& fw, uint32_t
             if (rtk_km_eq(urc, fw)) { if (n_probes) *n_probes = np; return rtk_pack_hit(u, off, 0u); } // the query is its reverse complement
         }
         if (key == RTK_EMPTY_KEY) { if (n_probes) *n_probes = np; return RTK_NO_HIT; }
-        i = (i + 1) & g.ht_mask;
+        i = rtk_ht_next(i, g.ht_slots);
     }
 }
 RTK_HD uint64_t rtk_find_km(const GraphView& g, const RtkKm& fw, uint32_t* n_probes) { return g.k <= 31 ? rtk_find_kmer(g, fw.lo, n_probes) : rtk_find_kmer_wide(g, fw, n_probes); }
@@ -230,13 +241,16 @@ RTK_HD void rtk_kmer_prepare(uint64_t fw, int k, uint64_t* can, uint64_t* hh, ui
 }
 RTK_HD bool rtk_filter1_pass(uint64_t word1, uint64_t hh, uint64_t bf1_mask) { const uint64_t b1 = (hh >> 12) & bf1_mask; return (word1 >> (b1 & 63ull)) & 1ull; }
 RTK_HD bool rtk_filter_pass(uint64_t word, uint64_t hh) { const uint64_t bits = (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)); return (word & bits) == bits; }
-RTK_HD uint64_t rtk_table_lookup(const GraphView& g, uint64_t can, uint64_t hh, uint32_t query_is_can, uint32_t* n_slots) {
-    uint64_t i = hh & g.ht_mask; uint32_t np = 0;
+RTK_HD uint64_t rtk_table_probe_from(const GraphView& g, uint64_t can, uint64_t i, uint32_t query_is_can, uint32_t* n_slots);
+RTK_HD uint64_t rtk_table_lookup(const GraphView& g, uint64_t can, uint64_t hh, uint32_t query_is_can, uint32_t* n_slots) { return rtk_table_probe_from(g, can, rtk_ht_slot(hh, g.ht_slots), query_is_can, n_slots); }
+// the linear probe from slot i on (a caller that has read the home slot itself continues at rtk_ht_next of it)
+RTK_HD uint64_t rtk_table_probe_from(const GraphView& g, uint64_t can, uint64_t i, uint32_t query_is_can, uint32_t* n_slots) {
+    uint32_t np = 0;
     while (true) {
         const uint64_t key = g.ht[2 * i]; ++np;
         if (key == can) { const uint64_t v = g.ht[2 * i + 1]; *n_slots = np; return rtk_pack_hit(static_cast<uint32_t>(v >> 32), static_cast<uint32_t>((v & 0xFFFFFFFFull) >> 1), (static_cast<uint32_t>(v & 1ull) == query_is_can) ? 1u : 0u); }
         if (key == RTK_EMPTY_KEY) { *n_slots = np; return RTK_NO_HIT; }
-        i = (i + 1) & g.ht_mask;
+        i = rtk_ht_next(i, g.ht_slots);
     }
 }
 

@@ -32,7 +32,7 @@ static void parallel_slices(size_t n, int n_threads, const std::function<void(si
 
 GraphView FlatGraph::view() const {
     GraphView v;
-    v.k = k; v.n_unitigs = n_unitigs(); v.n_kmers = n_kmers; v.ht_mask = ht.size() / 2 - 1;
+    v.k = k; v.n_unitigs = n_unitigs(); v.n_kmers = n_kmers; v.ht_slots = ht.size() / 2;
     v.useq = useq.data(); v.uoff = uoff.data(); v.adj = adj.data(); v.flags = flags.data(); v.kcov = kcov.data(); v.card = card.data();
     v.loff = loff.data(); v.gid = gid.data(); v.goff = goff.data(); v.col = col.data(); v.ht = ht.data(); v.bf = bf.data(); v.bf_mask = bf.size() - 1;
     v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1;
@@ -97,7 +97,12 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         const int h = (k - 1) / 2;
         const char* e_enum = getenv("RTK_INEXACT_ENUM"); const char* e_gb = getenv("RTK_HX_MAX_GB");
         const double max_gb = e_gb ? atof(e_gb) : 96.0;
-        const double est_gb = static_cast<double>(uoff[n]) * (8.0 * 4.0 + 8.0 * 1.5) / 1e9; // slots at load 0.25..0.5 + list words
+        // size before building: the distinct h-mers are at most 4^h (1.07 G for k = 31: a 3 Gb graph saturates them), the slot table a power of two
+        // >= twice that, the lists one word per h-mer start + one per distinct h-mer
+        double est_gb;
+        { const double bases = static_cast<double>(uoff[n]); const double all_h = std::pow(4.0, h); const double uniq = bases < all_h ? bases : all_h;
+          double hs = 16; while (hs < 2 * uniq) hs *= 2;
+          est_gb = (8.0 * hs + 8.0 * (bases + uniq)) / 1e9; }
         if ((e_enum && e_enum[0] == '1') || est_gb > max_gb || wide) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); } // wide k: second pass only, which has no 1-edit search (src/Graph.cpp:100)
         else {
             std::vector<std::pair<uint64_t, uint64_t> > pairs(uoff[n] - static_cast<uint64_t>(n) * static_cast<uint64_t>(h - 1)); // every h-mer start of every unitig, at its own place
@@ -145,11 +150,14 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         }
     }
     // ---- k-mer -> (unitig, offset, orientation) table, load factor <= 0.5 ----
+    // (small graphs keep the round-2 sizes -- a power of two at load 0.25 .. 0.5; above RTK_HT_DENSE_KMERS k-mers (default 2^28: a 4 GB table) the table
+    // is sized for load 0.7: the slot of a hash is floor(hash * slots / 2^64), any number of slots will do)
     uint64_t slots = 16;
     while (slots < 2 * n_kmers) slots <<= 1;
+    { const char* e = getenv("RTK_HT_DENSE_KMERS"); const uint64_t dense_from = e ? strtoull(e, nullptr, 10) : (1ull << 28);
+      if (n_kmers >= dense_from) slots = n_kmers + n_kmers * 3 / 7 + 16; }
     ht.assign(2 * slots, 0);
     for (uint64_t i = 0; i < slots; ++i) ht[2 * i] = RTK_EMPTY_KEY;
-    const uint64_t hmask = slots - 1;
     // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer.
     // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
     // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.
@@ -173,12 +181,12 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                 bool is_fw; uint64_t can, hh; // can: the key word of the slot
                 if (!wide) { can = kmer_canonical(fwk.lo, k, &is_fw); hh = rtk_hash64(can); }
                 else { const RtkKm rc = rtk_km_revcomp(fwk, k); is_fw = !rtk_km_less(rc, fwk); const RtkKm c2 = is_fw ? fwk : rc; hh = rtk_km_hash(c2); can = rtk_km_fingerprint(c2); }
-                uint64_t h = hh & hmask;
+                uint64_t h = rtk_ht_slot(hh, slots);
                 while (true) { // claim an empty slot with compare-and-swap on its key word (another thread may be filling the table too)
                     uint64_t seen_key = __atomic_load_n(&ht[2 * h], __ATOMIC_RELAXED);
                     if (seen_key == RTK_EMPTY_KEY) { uint64_t expect = RTK_EMPTY_KEY; if (__atomic_compare_exchange_n(&ht[2 * h], &expect, can, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; seen_key = expect; }
                     if (!wide && seen_key == can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
-                    h = (h + 1) & hmask;
+                    h = rtk_ht_next(h, slots);
                 }
                 { __atomic_fetch_or(&bf[(hh >> 32) & (bf_words - 1)], (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)), __ATOMIC_RELAXED);
                   if (!bf1_off) { const uint64_t b1 = (hh >> 12) & (bf1.size() * 64 - 1); __atomic_fetch_or(&bf1[b1 >> 6], 1ull << (b1 & 63ull), __ATOMIC_RELAXED); } }
@@ -186,7 +194,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             }
         }
     });
-    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_mask = hmask; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; v.useq = useq.data(); v.uoff = uoff.data(); return v; }();
+    const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_slots = slots; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; v.useq = useq.data(); v.uoff = uoff.data(); return v; }();
     if (wide) { // fingerprints cannot tell a repeated k-mer while the table is filled: every k-mer has to find ITSELF afterwards
         parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
             for (size_t u = lo; u < hi; ++u) {
