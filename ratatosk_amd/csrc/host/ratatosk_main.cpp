@@ -252,7 +252,14 @@ int main(int argc, char** argv) {
 
     if (opt.verbose) printf("Ratatosk::Ratatosk(): Correcting long reads (%d/2).\n", lrc ? 2 : 1);
     const int n_workers = opt.workers_per_gpu * n_gpus;
-    const size_t q_cap = static_cast<size_t>(n_workers) + 2, ahead_cap = 2 * static_cast<size_t>(n_workers) + 2;
+    // formatters: FASTQ blocks from the fetched views, gzip (-G), pwrite. Their own threads, so that a GPU worker goes on to its next ticket as soon as
+    // the corrected records of the last one are in host memory.
+    const int n_fmt = gz_out ? std::max(2, std::min(opt.cores, 32)) : std::max(2, std::min(opt.cores, 2 * n_workers));
+    const size_t q_cap = static_cast<size_t>(n_workers) + 2, ahead_cap = 2 * static_cast<size_t>(n_workers) + 2 + static_cast<size_t>(n_fmt);
+    struct Fetched { std::unique_ptr<Ticket> t; rtk_batch* b = nullptr; const char* pool = nullptr; const uint64_t* off = nullptr; const uint32_t* olen = nullptr; };
+    std::mutex m_f; std::condition_variable cv_f_empty, cv_f_full; std::deque<Fetched> fq;
+    int gpu_workers_left = n_workers; size_t n_fetched_alive = 0; // fetched batches not yet formatted: each still holds its device buffers and its pinned view
+    const size_t fetched_cap = static_cast<size_t>(n_workers) + 2;
     std::mutex m_in, m_out; std::condition_variable cv_in_full, cv_in_empty, cv_out;
     std::deque<std::unique_ptr<Ticket> > queue; bool reader_done = false;
     size_t next_to_write = 0; // first ticket whose block has no offset yet (every ticket before it is formatted)
@@ -268,6 +275,7 @@ int main(int argc, char** argv) {
         failed = true;
         { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all(); cv_in_empty.notify_all();
         { std::lock_guard<std::mutex> lk(m_out); } cv_out.notify_all();
+        { std::lock_guard<std::mutex> lk(m_f); } cv_f_empty.notify_all(); cv_f_full.notify_all();
     };
 
     // Reader. First pass on plain (uncompressed) files: the files are cut into byte ranges of about one ticket each and -c threads parse them
@@ -364,7 +372,7 @@ int main(int argc, char** argv) {
             }
             const rtk::PackedReads& R = t->reads;
             const uint32_t n = static_cast<uint32_t>(R.size());
-            std::string block;
+            Fetched f;
             if (n != 0) { // (a byte range of the parallel reader may hold no record start at all)
             std::vector<const char*> ps(n); std::vector<uint32_t> len(n);
             for (uint32_t i = 0; i < n; ++i) { ps[i] = R.seq(i); len[i] = R.seq_len(i); }
@@ -405,7 +413,33 @@ int main(int argc, char** argv) {
             }
             us_correct += now_us() - tc0;
             if (rc != RTK_OK) { fail(std::string("Ratatosk::correct(): ") + rtk_last_error()); if (b) rtk_batch_free(b); return; }
+            f.b = b; f.pool = pool; f.off = off; f.olen = olen;
+            }
+            f.t = std::move(t);
+            { // hand the fetched ticket to the formatters and go on with the next one: the GPU side never waits for memcpy, gzip or the file system
+                std::unique_lock<std::mutex> lk(m_f);
+                cv_f_full.wait(lk, [&]() { return n_fetched_alive < fetched_cap || failed; });
+                if (failed) { if (f.b) rtk_batch_free(f.b); return; }
+                ++n_fetched_alive; fq.push_back(std::move(f));
+            }
+            cv_f_empty.notify_one();
+        }
+    };
+    auto formatter = [&]() {
+        for (;;) {
+            Fetched f;
+            {
+                std::unique_lock<std::mutex> lk(m_f);
+                cv_f_empty.wait(lk, [&]() { return !fq.empty() || gpu_workers_left == 0 || failed; });
+                if (fq.empty()) return; // (after a failure: the blocks left in the queue are dropped with the run)
+                f = std::move(fq.front()); fq.pop_front();
+            }
+            const rtk::PackedReads& R = f.t->reads;
+            const uint32_t n = static_cast<uint32_t>(R.size());
+            const char* pool = f.pool; const uint64_t* off = f.off; const uint32_t* olen = f.olen;
+            std::string block;
             const long long tf0 = now_us();
+            if (n != 0 && !failed) {
             if (trim) {
                 for (uint32_t i = 0; i < n; ++i) append_trimmed(block, R.name(i), R.name_len(i), pool + off[i], pool + off[i] + olen[i], olen[i], k_graph, trim);
             } else {
@@ -418,14 +452,16 @@ int main(int argc, char** argv) {
                     memcpy(p, pool + off[i] + olen[i], olen[i]); p += olen[i]; *p++ = '\n';
                 }
             }
-            rtk_batch_free(b);
-            if (gz_out) { std::string z; if (!gzip_member(block, z)) { fail("Ratatosk::search(): gzip compression failed"); return; } block.swap(z); }
-            us_format += now_us() - tf0;
             }
+            if (f.b) rtk_batch_free(f.b);
+            { std::lock_guard<std::mutex> lk(m_f); --n_fetched_alive; } cv_f_full.notify_one(); // the batch (device buffers, pinned view) is free again: gzip and the write do not hold it
+            if (failed) continue;
+            if (gz_out && n != 0) { std::string z; if (!gzip_member(block, z)) { fail("Ratatosk::search(): gzip compression failed"); return; } block.swap(z); }
+            us_format += now_us() - tf0;
             std::vector<std::pair<unsigned long long, std::string> > to_write; // blocks that got their offset by this ticket's arrival (its own, and later ones that were waiting for it)
             {
                 std::unique_lock<std::mutex> lk(m_out);
-                done[t->id].swap(block);
+                done[f.t->id].swap(block);
                 while (!done.empty() && done.begin()->first == next_to_write) {
                     to_write.emplace_back(out_off, std::string()); to_write.back().second.swap(done.begin()->second);
                     out_off += to_write.back().second.size();
@@ -445,9 +481,13 @@ int main(int argc, char** argv) {
             us_write += now_us() - tw0;
         }
     };
+    std::vector<std::thread> fmt_threads;
+    for (int i = 0; i < n_fmt; ++i) fmt_threads.emplace_back(formatter);
     std::vector<std::thread> th;
     for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w);
     for (size_t i = 0; i < th.size(); ++i) th[i].join();
+    { std::lock_guard<std::mutex> lk(m_f); gpu_workers_left = 0; } cv_f_empty.notify_all();
+    for (size_t i = 0; i < fmt_threads.size(); ++i) fmt_threads[i].join();
     { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all();
     reader_thread.join();
     for (size_t i = 0; i < parser_threads.size(); ++i) parser_threads[i].join();

@@ -32,6 +32,7 @@ struct Opt {
     double lr_cov = 30.0;
     size_t lr_len = 10000;     // fixed length (profile uniform) or median (profile ont)
     double lr_err = 0.10;
+    bool lr_truth = false;
     std::string lr_profile = "uniform"; // uniform: sub:ins:del = 4:3:3 ; ont: 35:25:40, log-normal length, homopolymer-biased indels
     double repeat_frac = 0.0;  // fraction of the reference made of two-copy repeats (config 5)
     size_t tandem = 0;         // number of tandem-repeat blocks (unit 7..45 bp, spanning > 2k): short cycles in the graph
@@ -84,6 +85,7 @@ int main(int argc, char** argv) {
         else if (a == "--lr-len") o.lr_len = strtoull(need("--lr-len"), nullptr, 10);
         else if (a == "--lr-err") o.lr_err = atof(need("--lr-err"));
         else if (a == "--lr-profile") o.lr_profile = need("--lr-profile");
+        else if (a == "--lr-truth") o.lr_truth = true;
         else if (a == "--repeat-frac") o.repeat_frac = atof(need("--repeat-frac"));
         else if (a == "--tandem") o.tandem = strtoull(need("--tandem"), nullptr, 10);
         else { fprintf(stderr, "rtk_simulate: unknown option %s\n", a.c_str()); return 2; }
@@ -131,7 +133,8 @@ int main(int argc, char** argv) {
         if (!f) { perror("rtk_simulate: sr"); return 1; }
         const std::string q(o.sr_len, 'I');
         for (size_t p = 0; p < n_pairs; ++p) {
-            const std::string& hap = haps[rng.below(haps.size())];
+            const size_t hap_i = rng.below(haps.size());
+            const std::string& hap = haps[hap_i];
             size_t ins = static_cast<size_t>(std::max(static_cast<double>(o.sr_len), o.ins_mean + o.ins_sd * gauss(rng)));
             if (ins > hap.size()) ins = hap.size();
             const size_t start = rng.below(hap.size() - ins + 1);
@@ -153,10 +156,12 @@ int main(int argc, char** argv) {
         FILE* f = fopen((o.prefix + ".lr.fq").c_str(), "w");
         if (!f) { perror("rtk_simulate: lr"); return 1; }
         const bool ont = (o.lr_profile == "ont");
+        FILE* ft = o.lr_truth ? fopen((o.prefix + ".lr.truth.tsv").c_str(), "w") : nullptr; // --lr-truth: for size-independent checks of big runs (profiles/scripts/config4_dry_run.py)
         size_t total = 0, n = 0;
         const size_t target_bases = static_cast<size_t>(o.lr_cov * o.ref_len);
         while (o.lr_n ? (n < o.lr_n) : (total < target_bases)) {
-            const std::string& hap = haps[rng.below(haps.size())];
+            const size_t hap_i = rng.below(haps.size());
+            const std::string& hap = haps[hap_i];
             size_t len = o.lr_len;
             if (ont) {
                 const double l = std::exp(std::log(static_cast<double>(o.lr_len)) + 0.6 * gauss(rng));
@@ -165,14 +170,16 @@ int main(int argc, char** argv) {
             if (len > hap.size()) len = hap.size();
             const size_t start = rng.below(hap.size() - len + 1);
             std::string s = hap.substr(start, len);
-            if (rng.below(2)) s = reverse_complement(s);
+            const bool rev = rng.below(2) != 0;
+            if (rev) s = reverse_complement(s);
+            if (ft) fprintf(ft, "lr%zu\t%zu\t%zu\t%zu\t%c\n", n, hap_i, start, len, rev ? '-' : '+'); // where the read comes from (haplotype record of ref.fa, 0-based start, length, strand)
             s = mutate_long(s, o, rng);
             std::string q(s.size(), '5');
             for (size_t i = 0; i < q.size(); ++i) q[i] = static_cast<char>(33 + 5 + rng.below(20));
             fprintf(f, "@lr%zu\n%s\n+\n%s\n", n, s.c_str(), q.c_str());
             total += len; ++n;
         }
-        fclose(f);
+        fclose(f); if (ft) fclose(ft);
         fprintf(stderr, "rtk_simulate: %zu long reads, %zu source bases\n", n, total);
     }
     return 0;
