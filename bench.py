@@ -166,20 +166,25 @@ def cli_leg(a, pre, fa, rt):
     env = dict(os.environ, RTK_CLI_STATS="1")
     cores = min(16, os.cpu_count() or 1)
     try:
-        lst = out + ".inputs.txt" # a list file (src/Common.cpp:428-446): the generated FASTQ 24 times, ~3.5 Gb, so that the pipeline runs in steady state
-        with open(lst, "w") as f:     # (the first tickets pay for the pinned staging buffers, the device buffer pool and the first launches: ~0.3 s)
-            f.write((pre + ".lr.fq\n") * 24)
+        lst = out + ".inputs.fq"  # ONE file of ~3.5 Gb (the generated FASTQ 24 times, read names repeat): long-read runs come as few big files, and the
+        with open(pre + ".lr.fq", "rb") as f:  # pipeline has to reach its steady state (the first tickets pay for the pinned staging buffers, the
+            one = f.read()                      # device buffer pool and the first launches: ~0.3 s)
+        with open(lst, "wb") as f:
+            for _ in range(24):
+                f.write(one)
+        del one
         r = subprocess.run([exe, "correct", "-1", "-c", str(cores), "--gpus", "1", "-g", fa, "-d", rt, "-l", lst, "-o", out], capture_output=True, text=True, env=env, timeout=600)
         m = re.search(r"graph load \+ upload ([0-9.]+) s; correction phase ([0-9.]+) s wall, (\d+) bases, ([0-9.e+]+) bases/s on (\d+) GPU\(s\) x (\d+) workers; thread-seconds: parse ([0-9.]+), correct \(pack \+ GPU \+ fetch\) ([0-9.]+), format ([0-9.]+), write ([0-9.]+)", r.stderr + r.stdout)
         if r.returncode != 0 or not m:
             return {"error": (r.stderr or r.stdout)[-300:]}
         res = {"value": int(m.group(3)) / float(m.group(2)), "unit": "bases/s", "bases": int(m.group(3)), "correction_phase_s": float(m.group(2)), "graph_load_upload_s": float(m.group(1)),
                "workers_per_gpu": int(m.group(6)), "thread_seconds": {"parse": float(m.group(7)), "pack+gpu+fetch": float(m.group(8)), "format": float(m.group(9)), "write": float(m.group(10))},
-               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in (list file: the generated reads 24 times, parsed as byte ranges by the -c threads), OUT.2.fastq out (input order, pwrite), wall time of the correction phase" % cores}
-        try:
-            os.remove(out + ".2.fastq")
-        except OSError:
-            pass
+               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in (one file: the generated reads 24 times, parsed as byte ranges by the -c threads), OUT.2.fastq out (input order, FASTQ blocks formatted and written with pwrite by formatter threads), wall time of the correction phase" % cores}
+        for fn in (out + ".2.fastq", lst):
+            try:
+                os.remove(fn)
+            except OSError:
+                pass
         return res
     except Exception as e:  # the host legs never take the bench line down
         return {"error": str(e)[-300:]}

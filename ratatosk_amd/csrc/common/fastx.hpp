@@ -16,9 +16,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include "bgzf.hpp"
 
 namespace rtk {
 
@@ -210,20 +213,28 @@ class PlainChunks {
 public:
     PlainChunks() : fd_(-1), size_(0), chunk_(0), fastq_(false) {}
     ~PlainChunks() { close(); }
-    static bool is_plain(const std::string& fn) { // not gzip (magic 1f 8b) and starts like a FASTA / FASTQ file
+    // a file whose bytes can be reached at any offset: plain (not gzip, starts like a FASTA / FASTQ file) or blocked gzip (BGZF, bgzf.hpp);
+    // an ordinary gzip stream can only be inflated from its start and goes through the one-thread reader
+    static bool is_plain(const std::string& fn) {
         FILE* f = fopen(fn.c_str(), "rb"); if (!f) return false;
-        unsigned char m[2] = {0, 0}; const size_t n = fread(m, 1, 2, f); fclose(f);
-        return n >= 1 && (m[0] == '@' || m[0] == '>');
+        unsigned char m[18]; memset(m, 0, sizeof(m)); const size_t n = fread(m, 1, sizeof(m), f); fclose(f);
+        if (n >= 1 && (m[0] == '@' || m[0] == '>')) return true;
+        if (!BgzfFile::looks_like(m, n)) return false;
+        BgzfFile z; return z.open(fn); // every block checked (a file that merely starts with a BGZF block is streamed)
     }
     bool open(const std::string& fn, size_t chunk_bytes) {
         close();
         fd_ = ::open(fn.c_str(), O_RDONLY); if (fd_ < 0) return false;
         struct stat st; if (fstat(fd_, &st) != 0) { close(); return false; }
         size_ = static_cast<size_t>(st.st_size); chunk_ = chunk_bytes < 256 ? 256 : chunk_bytes;
-        char c = 0; fastq_ = (size_ > 0 && pread(fd_, &c, 1, 0) == 1 && c == '@');
+        { unsigned char m[18]; memset(m, 0, sizeof(m)); const ssize_t n = pread(fd_, m, sizeof(m), 0);
+          if (n > 0 && BgzfFile::looks_like(m, static_cast<size_t>(n))) { bgzf_.reset(new BgzfFile()); if (!bgzf_->open(fn)) { close(); return false; } size_ = static_cast<size_t>(bgzf_->size()); } }
+        if (size_ > chunk_) { const size_t nc = (size_ + chunk_ - 1) / chunk_; chunk_ = (size_ + nc - 1) / nc; } // ranges of equal size (a short last range would be a short ticket: the kernels of a ticket have tails that do not shrink with it)
+        char c = 0; fastq_ = size_ > 0 && (bgzf_ ? bgzf_->read(0, 1, &c) : pread(fd_, &c, 1, 0) == 1) && c == '@';
         return true;
     }
-    void close() { if (fd_ >= 0) { ::close(fd_); fd_ = -1; } }
+    void close() { if (fd_ >= 0) { ::close(fd_); fd_ = -1; } bgzf_.reset(); }
+    bool is_bgzf() const { return bgzf_ != nullptr; }
     size_t n_chunks() const { return size_ == 0 ? 0 : (size_ + chunk_ - 1) / chunk_; }
     size_t file_bytes() const { return size_; }
     // the records of range i appended to `out`; false on a read error. Thread-safe (pread).
@@ -254,6 +265,7 @@ private:
         size_t have = buf.size();
         if (base + have >= upto) return true;
         buf.resize(upto - base);
+        if (bgzf_) return bgzf_->read(base + have, upto - base - have, buf.data() + have);
         while (base + have < upto) { const ssize_t n = pread(fd_, buf.data() + have, upto - base - have, static_cast<off_t>(base + have)); if (n <= 0) return false; have += static_cast<size_t>(n); }
         return true;
     }
@@ -323,6 +335,7 @@ private:
         buf.swap(tmp.buf_);
     }
     int fd_; size_t size_, chunk_; bool fastq_;
+    std::unique_ptr<BgzfFile> bgzf_; // blocked gzip input: offsets are those of the uncompressed stream
 };
 
 // Reads a text file listing one path per line if `fn` is not itself FASTA/FASTQ

@@ -89,25 +89,10 @@ static void append_trimmed(std::string& out, const char* name, size_t name_len, 
     if (run >= k) emit();
 }
 
-static bool gzip_member(const std::string& in, std::string& out) { // one self-contained gzip member; members concatenate into a valid .gz
-    z_stream zs; memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    out.resize(deflateBound(&zs, in.size()) + 32);
-    // zlib counts in 32 bits: a block of a big ticket (name + 2 x bases, -B has no upper bound) is fed and drained in pieces of at most 1 GiB
-    const size_t piece = static_cast<size_t>(1) << 30;
-    size_t ip = 0, op = 0; int rc = Z_OK;
-    do {
-        const size_t ni = std::min(piece, in.size() - ip), no = std::min(piece, out.size() - op);
-        zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(in.data())) + ip; zs.avail_in = static_cast<uInt>(ni);
-        zs.next_out = reinterpret_cast<Bytef*>(&out[0]) + op; zs.avail_out = static_cast<uInt>(no);
-        rc = deflate(&zs, ip + ni == in.size() ? Z_FINISH : Z_NO_FLUSH);
-        ip += ni - zs.avail_in; op += no - zs.avail_out;
-        if (rc == Z_BUF_ERROR && op == out.size()) break; // cannot happen with deflateBound
-    } while (rc == Z_OK || (rc == Z_BUF_ERROR && op < out.size()));
-    out.resize(op);
-    deflateEnd(&zs);
-    return rc == Z_STREAM_END && ip == in.size();
-}
+// -G: a ticket's FASTQ block as blocked gzip (BGZF, common/bgzf.hpp): gzip members of <= 64 KiB that concatenate into a valid .gz -- what
+// `gunzip` / the reference's gzFile reader see is the same byte stream as from one big member, and a block-aware reader (this tool's own
+// first-pass reader, bgzip, htslib) can inflate it on many threads. (Blocks are small, so zlib's 32-bit counters are never near their limit.)
+static bool gzip_member(const std::string& in, std::string& out) { out.clear(); return rtk::bgzf_compress(in.data(), in.size(), out); }
 
 int main(int argc, char** argv) {
     // Every ticket in flight owns a HIP stream (the phasing step of the second pass three), and their kernels are mostly narrow (one long read,
@@ -192,7 +177,7 @@ int main(int argc, char** argv) {
             } else { rtk::FastxReader rd; if (!rd.open(fl[f])) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; } rtk::PackedReads r(false); while (rd.next_packed(r)) { if (r.n_bases() > opt.batch_bases) { bases += r.n_bases(); reads += r.size(); rtk::PackedReads fresh(false); r = std::move(fresh); } } bases += r.n_bases(); reads += r.size(); }
         }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        printf("Ratatosk::parse-only: %zu file(s) (%d plain, read as byte ranges by %d threads), %llu reads, %llu bases, %.3f s: %.3g bases/s, %.2f GB/s of plain file\n", fl.size(), n_plain, opt.cores,
+        printf("Ratatosk::parse-only: %zu file(s) (%d plain or blocked gzip, read as byte ranges by %d threads), %llu reads, %llu bases, %.3f s: %.3g bases/s, %.2f GB/s of FASTA/FASTQ text\n", fl.size(), n_plain, opt.cores,
                reads.load(), bases.load(), dt, dt > 0 ? bases.load() / dt : 0.0, dt > 0 ? bytes.load() / dt / 1e9 : 0.0);
         return 0;
     }
@@ -278,9 +263,10 @@ int main(int argc, char** argv) {
         { std::lock_guard<std::mutex> lk(m_f); } cv_f_empty.notify_all(); cv_f_full.notify_all();
     };
 
-    // Reader. First pass on plain (uncompressed) files: the files are cut into byte ranges of about one ticket each and -c threads parse them
-    // independently (rtk::PlainChunks; ticket id = range number, so the output keeps the input order). Everything else -- gzip input (one
-    // inflate stream per file is sequential), the lock-step pair of files of the second pass -- goes through the one reader thread below.
+    // Reader. First pass on plain (uncompressed) or blocked-gzip (BGZF: bgzip output, this tool's own -G output) files: the files are cut into
+    // byte ranges of their text of about one ticket each and -c threads inflate + parse them independently (rtk::PlainChunks; ticket id =
+    // range number, so the output keeps the input order). Everything else -- ordinary gzip input (one deflate stream can only be inflated
+    // from its start), the lock-step pair of files of the second pass -- goes through the one reader thread below.
     bool par_read = !lrc && !getenv("RTK_SERIAL_READER"); // (the environment switch: A/B against the one-thread reader)
     for (size_t i = 0; par_read && i < files.size(); ++i) par_read = rtk::PlainChunks::is_plain(files[i]);
     std::vector<std::unique_ptr<rtk::PlainChunks> > pcs; std::vector<size_t> pc_first; size_t n_chunks_all = 0;
@@ -491,6 +477,7 @@ int main(int argc, char** argv) {
     { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all();
     reader_thread.join();
     for (size_t i = 0; i < parser_threads.size(); ++i) parser_threads[i].join();
+    if (gz_out && !failed) { std::string e; rtk::bgzf_append_eof(e); if (pwrite(fd_out, e.data(), e.size(), static_cast<off_t>(out_off)) != static_cast<ssize_t>(e.size())) fail("Ratatosk::search(): write error on " + fn_out); }
     const bool write_ok = ::close(fd_out) == 0;
     for (int w = 0; w < n_gpus; ++w) rtk_graph_free(graphs[w]);
     if (failed || !write_ok || !done.empty()) { // a partial OUT.2.fastq must not look like a result

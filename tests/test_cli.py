@@ -203,3 +203,47 @@ def test_parallel_reader_cuts_files_like_the_serial_one(ds_small, tmp_path):
     assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") == 4 * 9
     r = subprocess.run([exe, "correct", "-1", "--parse-only", "-c", "3", "-B", "100", "-l", lst], capture_output=True, text=True)
     assert r.returncode == 0 and "9 reads" in r.stdout, r.stdout + r.stderr
+
+
+def _bgzf_blocks(data, block=700):
+    """BGZF written by an independent encoder (python zlib): gzip members with the 'BC' extra field, `block` text bytes each, + the EOF block."""
+    import struct
+    import zlib
+    out = b""
+    for i in range(0, len(data), block):
+        raw = data[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15); body = c.compress(raw) + c.flush()
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw))
+    return out + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def test_blocked_gzip_input_is_read_as_byte_ranges(ds_small, tmp_path):
+    """BGZF input (bgzip / this tool's -G output): the reader hops over the blocks by their size fields and -c threads inflate + parse byte ranges
+    of the text. Same output as from the plain file, with ranges smaller than a block, of a few blocks, of one ticket; an ordinary .gz of the
+    same text still goes through the one-thread reader; rtk_bgzip writes what python's gzip reads back."""
+    import gzip
+    text = open(ds_small + ".lr.fq", "rb").read()
+    text = text[:text.index(b"\n@", 40000) + 1] if len(text) > 60000 else text
+    plain, bg, gz = str(tmp_path / "in.fq"), str(tmp_path / "in.bgzf.fq.gz"), str(tmp_path / "in.plain.fq.gz")
+    open(plain, "wb").write(text); open(bg, "wb").write(_bgzf_blocks(text)); gzip.open(gz, "wb").write(text)
+    assert gzip.open(bg, "rb").read() == text
+    exe = os.path.join(ROOT, "tests", "hostsim", "Ratatosk_sim")
+    outs = []
+    for tag, inp, batch in (("plain", plain, "3000"), ("bgzf_small_ranges", bg, "100"), ("bgzf_ticket_ranges", bg, "3000"), ("gz_stream", gz, "3000")):
+        out = str(tmp_path / tag)
+        r = subprocess.run([exe, "correct", "-1", "-c", "4", "-B", batch, "-g", ds_small + ".index.k31.fasta.gz", "-d", ds_small + ".index.k31.rtsk", "-l", inp, "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out + ".2.fastq", "rb").read())
+    assert outs[0] == outs[1] == outs[2] == outs[3] and len(outs[0]) > 1000
+    r = subprocess.run([exe, "correct", "-1", "--parse-only", "-c", "3", "-B", "100", "-l", bg], capture_output=True, text=True)
+    assert r.returncode == 0 and "(1 plain or blocked gzip" in r.stdout and "%d reads" % (text.count(b"\n") // 4) in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "correct", "-1", "--parse-only", "-c", "3", "-B", "100", "-l", gz], capture_output=True, text=True)
+    assert r.returncode == 0 and "(0 plain or blocked gzip" in r.stdout, r.stdout
+    mine = str(tmp_path / "mine.gz")
+    assert subprocess.run([os.path.join(BIN, "rtk_bgzip"), plain, mine, "-@", "3"]).returncode == 0
+    assert gzip.open(mine, "rb").read() == text
+    # a file that starts with a BGZF block and goes on as an ordinary member is not taken for blocked gzip
+    mixed = str(tmp_path / "mixed.gz")
+    open(mixed, "wb").write(_bgzf_blocks(text[:2000])[:-28] + gzip.compress(text[2000:]))
+    r = subprocess.run([exe, "correct", "-1", "--parse-only", "-c", "3", "-l", mixed], capture_output=True, text=True)
+    assert r.returncode == 0 and "(0 plain or blocked gzip" in r.stdout and "%d reads" % (text.count(b"\n") // 4) in r.stdout, r.stdout
