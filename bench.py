@@ -57,7 +57,7 @@ def parse():
     return a
 
 
-def make_dataset(workdir, ref_len, lr_bases, snps=True, het=0.0):
+def make_dataset(workdir, ref_len, lr_bases, snps=True, het=0.0, fast="--gpu"):
     """Seeded synthetic inputs + index in the reference's file formats."""
     bin_dir = os.path.join(ROOT, "ratatosk_amd", "bin")
     pre = os.path.join(workdir, "c2")
@@ -65,7 +65,15 @@ def make_dataset(workdir, ref_len, lr_bases, snps=True, het=0.0):
     subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "2", "--ref-len", str(ref_len), "--sr-cov", "30",
                            "--sr-err", "0.005", "--lr-cov", "%.3f" % lr_cov, "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07"] + (["--het", "%g" % het] if het > 0 else []), stderr=subprocess.DEVNULL)
     # --snps: SNP annotations like the reference's default `index` step (detectSNPs runs unless -F, src/Ratatosk.cpp:1120-1127)
-    r = subprocess.run([os.path.join(bin_dir, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + (["--snps"] if snps else []), stderr=subprocess.PIPE, text=True, check=True)
+    # (--gpu: the k-mers of the short reads are counted on the device and the other heavy steps run on the host threads; the files are the plain
+    # tool's byte for byte, tests/test_index_build.py. `fast` = "" under the CPU-only simulator, which has no device to count on.)
+    cmd = [os.path.join(bin_dir, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + (["--snps"] if snps else [])
+    r = subprocess.run(cmd + ([fast] if fast else []), stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0 and fast:
+        sys.stderr.write("rtk_build_index %s failed (%s); building with the plain tool\n" % (fast, r.stderr.strip()[-200:]))
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("rtk_build_index failed: " + r.stderr[-500:])
     for line in r.stderr.splitlines():
         if "SNP annotations" in line:
             sys.stderr.write(line + "\n")
@@ -166,11 +174,11 @@ def cli_leg(a, pre, fa, rt):
     env = dict(os.environ, RTK_CLI_STATS="1")
     cores = min(16, os.cpu_count() or 1)
     try:
-        lst = out + ".inputs.fq"  # ONE file of ~3.5 Gb (the generated FASTQ 24 times, read names repeat): long-read runs come as few big files, and the
+        lst = out + ".inputs.fq"  # ONE file of ~7 Gb (the generated FASTQ 48 times, read names repeat): long-read runs come as few big files, and the
         with open(pre + ".lr.fq", "rb") as f:  # pipeline has to reach its steady state (the first tickets pay for the pinned staging buffers, the
             one = f.read()                      # device buffer pool and the first launches: ~0.3 s)
         with open(lst, "wb") as f:
-            for _ in range(24):
+            for _ in range(48):
                 f.write(one)
         del one
         r = subprocess.run([exe, "correct", "-1", "-c", str(cores), "--gpus", "1", "-g", fa, "-d", rt, "-l", lst, "-o", out], capture_output=True, text=True, env=env, timeout=600)
@@ -179,7 +187,7 @@ def cli_leg(a, pre, fa, rt):
             return {"error": (r.stderr or r.stdout)[-300:]}
         res = {"value": int(m.group(3)) / float(m.group(2)), "unit": "bases/s", "bases": int(m.group(3)), "correction_phase_s": float(m.group(2)), "graph_load_upload_s": float(m.group(1)),
                "workers_per_gpu": int(m.group(6)), "thread_seconds": {"parse": float(m.group(7)), "pack+gpu+fetch": float(m.group(8)), "format": float(m.group(9)), "write": float(m.group(10))},
-               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in (one file: the generated reads 24 times, parsed as byte ranges by the -c threads), OUT.2.fastq out (input order, FASTQ blocks formatted and written with pwrite by formatter threads), wall time of the correction phase" % cores}
+               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in (one file: the generated reads 48 times, parsed as byte ranges by the -c threads), OUT.2.fastq out (input order, FASTQ blocks formatted and written with pwrite by formatter threads), wall time of the correction phase" % cores}
         for fn in (out + ".2.fastq", lst):
             try:
                 os.remove(fn)
@@ -302,7 +310,7 @@ def main():
         # 30x of long reads (configs[1]) gives two tickets; with N ranks every rank gets two tickets of its OWN (2N distinct tickets:
         # the long-read coverage of the synthetic set grows with N, the graph and the per-rank work stay those of configs[1])
         lr_bases = int(2.3 * a.batch_bases * world) + 200_000 if world > 1 else min(need_bases, 30 * a.ref_len) # N > 1: at least 2 distinct tickets per rank (a ticket ends with the read that fills it)
-        pre = make_dataset(workdir, a.ref_len, lr_bases, snps=not a.plain_index, het=a.het)
+        pre = make_dataset(workdir, a.ref_len, lr_bases, snps=not a.plain_index, het=a.het, fast="" if a.sim else "--gpu")
         t_data = time.time() - t0
     else:
         pre, t_data = None, 0.0

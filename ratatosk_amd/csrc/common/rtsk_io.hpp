@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <istream>
 #include <ostream>
@@ -123,6 +124,11 @@ inline void tinybitmap_read(std::istream& in, std::vector<uint32_t>& ids) {
     in.read(reinterpret_cast<char*>(&header), 2);
     if (!in.good()) throw std::runtime_error("rtsk: truncated TinyBitmap header");
     const uint32_t sz = header >> 3, mode = header & 0x6u;
+    if (header & 1u) throw std::runtime_error("rtsk: TinyBitmap header has bit 0 set: not the layout assumed in [A8], refusing to guess");
+    { // [A8] cannot be checked against a Bifrost build here: say so once per process when such a payload is decoded
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "rtsk: note: decoding a Bifrost TinyBitmap colour set with the layout assumed in [A8] (oracle/oracle_graph.hpp); it has not been verified against a Bifrost-written index\n"); }
+    }
     if (sz == 0) return;
     if (sz < 3 || sz > 4096 || (mode != 0 && mode != 2 && mode != 4)) throw std::runtime_error("rtsk: TinyBitmap header does not match the assumed Bifrost layout [A8]");
     std::vector<uint16_t> w(sz); w[0] = header;

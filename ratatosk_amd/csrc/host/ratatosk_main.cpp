@@ -299,7 +299,7 @@ int main(int argc, char** argv) {
         if (parsers_left.fetch_sub(1) == 1) { { std::lock_guard<std::mutex> lk(m_in); reader_done = true; } cv_in_empty.notify_all(); }
     };
     std::vector<std::thread> parser_threads;
-    if (par_read) { const int np = std::max(1, std::min(opt.cores, 16)); parsers_left = np; for (int i = 0; i < np; ++i) parser_threads.emplace_back(parser); }
+    if (par_read) { const int np = std::max(1, std::min(opt.cores, (!pcs.empty() && pcs[0]->is_bgzf()) ? 32 : 16)); /* inflating: ~0.4 GB/s of text per thread */ parsers_left = np; for (int i = 0; i < np; ++i) parser_threads.emplace_back(parser); }
 
     std::thread reader_thread([&]() {
         if (par_read) return;
@@ -348,7 +348,8 @@ int main(int argc, char** argv) {
                 std::unique_lock<std::mutex> lk(m_in);
                 cv_in_empty.wait(lk, [&]() { return !queue.empty() || reader_done || failed; });
                 if (failed || queue.empty()) return;
-                t = std::move(queue.front()); queue.pop_front();
+                size_t pick = 0; for (size_t i = 1; i < queue.size(); ++i) if (queue[i]->id < queue[pick]->id) pick = i; // (the parser threads deliver out of order: the ticket the writer waits for goes first)
+                t = std::move(queue[pick]); queue.erase(queue.begin() + static_cast<std::ptrdiff_t>(pick));
                 cv_in_full.notify_one();
             }
             { // do not run further ahead of the writer than the block map may grow
@@ -479,13 +480,13 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < parser_threads.size(); ++i) parser_threads[i].join();
     if (gz_out && !failed) { std::string e; rtk::bgzf_append_eof(e); if (pwrite(fd_out, e.data(), e.size(), static_cast<off_t>(out_off)) != static_cast<ssize_t>(e.size())) fail("Ratatosk::search(): write error on " + fn_out); }
     const bool write_ok = ::close(fd_out) == 0;
+    const double wall = 1e-6 * (now_us() - t_begin); // the correction phase ends with the output file closed (the device images and pinned pools are torn down after it)
     for (int w = 0; w < n_gpus; ++w) rtk_graph_free(graphs[w]);
     if (failed || !write_ok || !done.empty()) { // a partial OUT.2.fastq must not look like a result
         remove(fn_out.c_str());
         fprintf(stderr, "%s\n", fail_msg.empty() ? "Ratatosk::search(): output incomplete" : fail_msg.c_str());
         exit(1);
     }
-    const double wall = 1e-6 * (now_us() - t_begin);
     if (opt.verbose || getenv("RTK_CLI_STATS"))
         fprintf(opt.verbose ? stdout : stderr, "Ratatosk::correct(): graph load + upload %.2f s; correction phase %.2f s wall, %lld bases, %.3g bases/s on %d GPU(s) x %d workers; "
                 "thread-seconds: parse %.2f, correct (pack + GPU + fetch) %.2f, format %.2f, write %.2f\n", 1e-6 * (t_load1 - t_load0), wall, n_bases.load(),

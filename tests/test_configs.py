@@ -86,7 +86,9 @@ def _sized(tmp, name, sim_args, index_args, sample_bases, skip_bases=0, keep_sho
     t0 = time.time()
     pre = os.path.join(str(tmp), name)
     subprocess.check_call([os.path.join(BIN, "rtk_simulate"), "--prefix", pre] + [str(a) for a in sim_args], stderr=subprocess.DEVNULL)
-    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre] + list(index_args), stderr=subprocess.DEVNULL)
+    # (these sets are only built in the gpu tier: k-mers counted on the device, the other heavy steps on the host threads -- the files are the plain
+    # tool's byte for byte, tests/test_index_build.py)
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", pre + ".sr.fq", "-o", pre, "--gpu"] + list(index_args), stderr=subprocess.DEVNULL)
     if not keep_short_reads:
         os.remove(pre + ".sr.fq")
     t_data = time.time() - t0
