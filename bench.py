@@ -112,6 +112,21 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def same_graph_n1():
+    """N > 1 runs configs[2] (60 Mb diploid graph), the default N = 1 line configs[1] (the metric's config): a step on the diploid graph costs
+    ~1.5 x a step on configs[1] (more and longer weak regions, SNP annotations), so the two are not points of one scaling curve. The committed
+    one-GPU measurement on the configs[2] graph (`bench.py --config2`, profiles/rNN_bench_config2.json) is the N = 1 point that belongs to it."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_config2.json")))
+    if not fs:
+        return None
+    try:
+        d = json.loads(open(fs[-1]).read().strip().splitlines()[-1])
+        return {"value": d["value"], "ms_per_step": d["ms_per_step"], "source": os.path.relpath(fs[-1], ROOT) + " (python bench.py --config2)"}
+    except Exception:
+        return None
+
+
 def host_inclusive_leg(a, api, graph, opts, tickets):
     """Host buffers in, host buffers out through the C ABI: rtk_batch_create (pack + H2D) + rtk_batch_run + rtk_batch_fetch_view
     (D2H into pinned memory) + rtk_batch_free per ticket, `host_callers` threads each owning one ticket at a time (the library overlaps
@@ -413,6 +428,7 @@ def main():
             "config": {"workload": ("configs[2]: k=31 first pass sharded across %d MI355X, %.1f Mb diploid random ref (%.2f %% het SNPs), 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU, >= 2 distinct tickets per GPU" % (world, a.ref_len / 1e6, 100 * a.het, a.batch_bases))
                                    if (world > 1 or a.config2) else ("configs[1]: k=31 first-pass correct, %.1f Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU" % (a.ref_len / 1e6, a.batch_bases)),
                        "graph_replication": repl or None,
+                       "n1_on_this_graph": same_graph_n1() if (world > 1 or a.config2) else None,
                        "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated (one RCCL broadcast per flat buffer)" % world, "per_rank": per_rank,
                        "value_is": "kernel-resident throughput: batches packed and in HBM before the clock starts (the contract's definition); the host-buffer-to-host-buffer rate is host_inclusive, the file-to-file rate cli_file_to_file",
                        "alg_bytes_per_base": round(whole_alg, 1), "setup_s": {"data+index": round(t_data, 1), "graph_load+upload": round(t_graph, 1)}},
