@@ -229,9 +229,9 @@ def second_pass_leg(a, pre):
         t0 = time.time()
         subprocess.run([os.path.join(ROOT, "ratatosk_amd", "bin", "rtk_build_index"), "-s", pre + ".sr.fq", "--colour-reads", out + ".2.fastq", "-k", "63", "-o", out + ".p2"], stderr=subprocess.DEVNULL, check=True, timeout=600)
         t_idx = time.time() - t0
-        # like the first-pass CLI leg: list files (the corrected reads and, in step, the uncorrected ones, six times each) so that the ticket
+        # like the first-pass CLI leg: list files (the corrected reads and, in step, the uncorrected ones, 18 times each: 2.7 Gb, ~80 tickets for 8 in flight) so that the ticket
         # pipeline runs in steady state; the figure of ONE copy of the files (4 tickets: mostly pipeline fill and drain) is kept next to it
-        reps = 6
+        reps = 18
         with open(out + ".p2in.txt", "w") as f:
             f.write((out + ".2.fastq\n") * reps)
         with open(out + ".p2raw.txt", "w") as f:

@@ -316,7 +316,11 @@ RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* rof
                 RtkKm fw; // the read buffer is padded by 64 bytes
                 if (rtk_km_from_text(reinterpret_cast<const unsigned char*>(seq) + b, g.k, &fw)) { uint32_t np; h = rtk_find_km(g, fw, &np); probes += 1; slots += np; }
             }
+#if defined(RTK_SIM) || defined(RTK_NO_NT_STORES)
             hits[b] = h;
+#else
+            __builtin_nontemporal_store(h, hits + b); // 8 B per window streamed out once: kept from evicting the first-level filter (the whole L2 of an XCD for graphs above 5 M k-mers)
+#endif
         }
         // presence bit of every window (bit b & 63 of word b >> 6): the per-read programs scan 64 windows per word instead of 64 hits
         if (hitmap) {

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -255,12 +256,14 @@ int main(int argc, char** argv) {
     std::atomic<long long> us_parse(0), us_correct(0), us_format(0), us_write(0), n_reads(0), n_bases(0);
     const long long t_begin = now_us();
     const bool cli_trace = getenv("RTK_CLI_TRACE") != nullptr; // developer: per-ticket times of the workers
+    std::function<void()> on_fail_extra; // (wakes the threads of the two-file reader, declared further down)
     auto fail = [&](const std::string& msg) {
         { std::lock_guard<std::mutex> lk(m_fail); if (fail_msg.empty()) fail_msg = msg; }
         failed = true;
         { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all(); cv_in_empty.notify_all();
         { std::lock_guard<std::mutex> lk(m_out); } cv_out.notify_all();
         { std::lock_guard<std::mutex> lk(m_f); } cv_f_empty.notify_all(); cv_f_full.notify_all();
+        if (on_fail_extra) on_fail_extra();
     };
 
     // Reader. First pass on plain (uncompressed) or blocked-gzip (BGZF: bgzip output, this tool's own -G output) files: the files are cut into
@@ -301,10 +304,15 @@ int main(int argc, char** argv) {
     std::vector<std::thread> parser_threads;
     if (par_read) { const int np = std::max(1, std::min(opt.cores, (!pcs.empty() && pcs[0]->is_bgzf()) ? 32 : 16)); /* inflating: ~0.4 GB/s of text per thread */ parsers_left = np; for (int i = 0; i < np; ++i) parser_threads.emplace_back(parser); }
 
+    // One-thread reader (ordinary gzip input; the second pass). The second pass reads two files in lock-step (src/Ratatosk.cpp:774-802): the
+    // corrected reads fill a ticket on this thread, the uncorrected reads of the same ticket are parsed and checked on a second one
+    // (raw_thread) while this one is already on the next ticket.
+    std::mutex m_half; std::condition_variable cv_half_full, cv_half_empty; std::deque<std::unique_ptr<Ticket> > half; bool half_done = false;
+    const char* out_of_step = "Ratatosk::correct(): Corrected read file is not in the same order as input long read file. Abort."; // src/Ratatosk.cpp:787,796
+    on_fail_extra = [&]() { { std::lock_guard<std::mutex> lk(m_half); } cv_half_full.notify_all(); cv_half_empty.notify_all(); };
     std::thread reader_thread([&]() {
         if (par_read) return;
-        rtk::FastxReader reader, reader_raw; size_t file_i = 0, file_raw_i = 0; bool file_open = false, file_raw_open = false, eof_all = false; size_t ticket = 0;
-        const char* out_of_step = "Ratatosk::correct(): Corrected read file is not in the same order as input long read file. Abort."; // src/Ratatosk.cpp:787,796
+        rtk::FastxReader reader; size_t file_i = 0; bool file_open = false, eof_all = false; size_t ticket = 0;
         while (!eof_all && !failed) {
             const long long tp0 = now_us();
             std::unique_ptr<Ticket> t(new Ticket(lrc)); t->id = ticket;
@@ -314,22 +322,53 @@ int main(int argc, char** argv) {
                 if (!reader.next_packed(t->reads)) { file_open = false; continue; }
                 if (opt.verbose && ((n_reads.fetch_add(1) + 1) % 1000 == 0)) printf("Ratatosk::correct(): Processed %lld reads \n", n_reads.load());
             }
-            if (lrc) { // the uncorrected reads in lock-step (src/Ratatosk.cpp:774-802)
-                while (t->raw.size() < t->reads.size()) {
-                    if (!file_raw_open) { if (file_raw_i >= files_raw.size()) break; if (!reader_raw.open(files_raw[file_raw_i++])) { fail("Ratatosk::search(): cannot open input file " + files_raw[file_raw_i - 1]); return; } file_raw_open = true; }
-                    if (!reader_raw.next_packed(t->raw)) { file_raw_open = false; continue; }
-                }
-                if (t->raw.size() != t->reads.size()) { fail(out_of_step); return; }
-                for (size_t i = 0; i < t->reads.size(); ++i) { // names are compared from their second character on, like the reference (:794)
-                    const size_t la = t->reads.name_len(i), lb = t->raw.name_len(i);
-                    if (la == 0 || lb == 0 || la != lb || memcmp(t->reads.name(i) + 1, t->raw.name(i) + 1, la - 1) != 0) { fail(out_of_step); return; }
-                    if (t->reads.qual(i) == nullptr && t->reads.seq_len(i)) { fail("Ratatosk::correct(): the second pass needs the base qualities of the first (FASTQ input for -l)"); return; }
-                }
-            }
             us_parse += now_us() - tp0;
             if (t->reads.size() == 0) break;
             n_bases += static_cast<long long>(t->reads.n_bases());
             ++ticket;
+            if (lrc) {
+                std::unique_lock<std::mutex> lk(m_half);
+                cv_half_full.wait(lk, [&]() { return half.size() < 3 || failed; });
+                if (failed) break;
+                half.push_back(std::move(t));
+                cv_half_empty.notify_one();
+            } else {
+                std::unique_lock<std::mutex> lk(m_in);
+                cv_in_full.wait(lk, [&]() { return queue.size() < q_cap || failed; });
+                if (failed) break;
+                queue.push_back(std::move(t));
+                cv_in_empty.notify_one();
+            }
+        }
+        if (lrc) { { std::lock_guard<std::mutex> lk(m_half); half_done = true; } cv_half_empty.notify_all(); return; }
+        { std::lock_guard<std::mutex> lk(m_in); reader_done = true; }
+        cv_in_empty.notify_all();
+    });
+    std::thread raw_thread([&]() {
+        if (par_read || !lrc) return;
+        rtk::FastxReader reader_raw; size_t file_raw_i = 0; bool file_raw_open = false;
+        while (!failed) {
+            std::unique_ptr<Ticket> t;
+            {
+                std::unique_lock<std::mutex> lk(m_half);
+                cv_half_empty.wait(lk, [&]() { return !half.empty() || half_done || failed; });
+                if (failed || half.empty()) break;
+                t = std::move(half.front()); half.pop_front();
+                cv_half_full.notify_one();
+            }
+            const long long tp0 = now_us();
+            t->raw.reserve(t->reads.n_bases() + (t->reads.n_bases() >> 3));
+            while (t->raw.size() < t->reads.size()) { // the uncorrected reads in lock-step (src/Ratatosk.cpp:774-802)
+                if (!file_raw_open) { if (file_raw_i >= files_raw.size()) break; if (!reader_raw.open(files_raw[file_raw_i++])) { fail("Ratatosk::search(): cannot open input file " + files_raw[file_raw_i - 1]); return; } file_raw_open = true; }
+                if (!reader_raw.next_packed(t->raw)) { file_raw_open = false; continue; }
+            }
+            if (t->raw.size() != t->reads.size()) { fail(out_of_step); return; }
+            for (size_t i = 0; i < t->reads.size(); ++i) { // names are compared from their second character on, like the reference (:794)
+                const size_t la = t->reads.name_len(i), lb = t->raw.name_len(i);
+                if (la == 0 || lb == 0 || la != lb || memcmp(t->reads.name(i) + 1, t->raw.name(i) + 1, la - 1) != 0) { fail(out_of_step); return; }
+                if (t->reads.qual(i) == nullptr && t->reads.seq_len(i)) { fail("Ratatosk::correct(): the second pass needs the base qualities of the first (FASTQ input for -l)"); return; }
+            }
+            us_parse += now_us() - tp0;
             std::unique_lock<std::mutex> lk(m_in);
             cv_in_full.wait(lk, [&]() { return queue.size() < q_cap || failed; });
             if (failed) break;
@@ -476,7 +515,8 @@ int main(int argc, char** argv) {
     { std::lock_guard<std::mutex> lk(m_f); gpu_workers_left = 0; } cv_f_empty.notify_all();
     for (size_t i = 0; i < fmt_threads.size(); ++i) fmt_threads[i].join();
     { std::lock_guard<std::mutex> lk(m_in); } cv_in_full.notify_all();
-    reader_thread.join();
+    { std::lock_guard<std::mutex> lk(m_half); } cv_half_full.notify_all(); cv_half_empty.notify_all();
+    reader_thread.join(); raw_thread.join();
     for (size_t i = 0; i < parser_threads.size(); ++i) parser_threads[i].join();
     if (gz_out && !failed) { std::string e; rtk::bgzf_append_eof(e); if (pwrite(fd_out, e.data(), e.size(), static_cast<off_t>(out_off)) != static_cast<ssize_t>(e.size())) fail("Ratatosk::search(): write error on " + fn_out); }
     const bool write_ok = ::close(fd_out) == 0;
