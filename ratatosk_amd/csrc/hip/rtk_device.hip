@@ -307,8 +307,7 @@ RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* rof
         uint64_t h = RTK_NO_HIT;
         // owning read: largest r with roff[r] <= b. One scalar search for the tile's first base; the other lanes step forward from it
         // (a tile rarely spans more than one read boundary).
-        uint32_t lo0 = 0;
-        { uint32_t hi = n_reads; const uint64_t b0 = tile * RTK_WAVE; while (hi - lo0 > 1) { const uint32_t mid = (lo0 + hi) >> 1; if (rtk_ld(roff + mid) <= b0) lo0 = mid; else hi = mid; } }
+        const uint32_t lo0 = rtk_owner_read(roff, n_reads, tile * RTK_WAVE);
         if (b < n_bases) {
             uint32_t lo = lo0;
             while (lo + 1 < n_reads && roff[lo + 1] <= b) ++lo;

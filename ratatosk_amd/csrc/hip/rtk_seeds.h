@@ -359,7 +359,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
 #endif
     const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
     uint32_t lo_tile = 0; // one scalar search per tile: largest r with roff[r] <= first base of the tile
-    { uint32_t hi = n_reads; const uint64_t b0 = tile * 64; while (hi - lo_tile > 1) { const uint32_t mid = (lo_tile + hi) >> 1; if (rtk_ld(roff + mid) <= b0) lo_tile = mid; else hi = mid; } }
+    lo_tile = rtk_owner_read(roff, n_reads, tile * 64);
     for (int sub = 0; sub < n_sub; ++sub) { // the 1-lane simulator visits the 64 positions of the tile one after the other
 #ifdef RTK_SIM
         const uint64_t bb = tile * 64 + static_cast<uint64_t>(sub);
@@ -588,7 +588,7 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
     const int k = g.k;
     const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
     uint32_t lo_tile = 0; // one scalar search per tile: largest r with roff[r] <= first base of the tile
-    { uint32_t hi = n_reads; const uint64_t b0 = tile * 64; while (hi - lo_tile > 1) { const uint32_t mid = (lo_tile + hi) >> 1; if (rtk_ld(roff + mid) <= b0) lo_tile = mid; else hi = mid; } }
+    lo_tile = rtk_owner_read(roff, n_reads, tile * 64);
 #ifdef RTK_SIM
     const int n_sub = 64;
 #else

@@ -165,4 +165,25 @@ RTK_FN_HOT void rtk_wfill(void* dst, int c, uint64_t n) {
     rtk_sync();
 }
 
+// Read that owns base b0 of the concatenated read buffer: the largest r with roff[r] <= b0 (roff[0] = 0). Wave-uniform. 64 pivots per round, one
+// per lane (three dependent loads for a ticket of tens of thousands of reads instead of the 13-16 of a binary search: the tile programs of the
+// k-mer scans start with it).
+RTK_DEV uint32_t rtk_owner_read(const uint64_t* roff_, uint32_t n_reads_, uint64_t b0_) {
+    const uint64_t* roff = rtk_u(roff_); const uint32_t n_reads = rtk_u(n_reads_); const uint64_t b0 = rtk_u(b0_);
+    uint32_t lo = 0, hi = n_reads;
+#ifdef RTK_SIM
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (roff[mid] <= b0) lo = mid; else hi = mid; }
+#else
+    while (hi - lo > 1) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint64_t p = static_cast<uint64_t>(lo) + static_cast<uint64_t>(rtk_lane() + 1) * step; // pivots lo + step, lo + 2 step, ...: "roff[p] <= b0" holds for a prefix of the lanes
+        const bool le = p < hi && roff[p] <= b0;
+        const uint32_t c = static_cast<uint32_t>(rtk_popc(rtk_ballot(le)));
+        const uint64_t nh = static_cast<uint64_t>(lo) + static_cast<uint64_t>(c + 1) * step;
+        lo = rtk_u(lo + c * step); hi = rtk_u(nh < hi ? static_cast<uint32_t>(nh) : hi);
+    }
+#endif
+    return lo;
+}
+
 #endif
