@@ -168,6 +168,39 @@ RTK_FN uint32_t rtk_shared_unitigs(const GraphView& g_, uint32_t u_, uint32_t v_
     return shared;
 }
 
+// The same count, one pair of unitigs PER LANE (no wave collectives): the junction filter of getSeeds evaluates its candidates 64 at a time.
+// Sorted id arrays; the shorter is searched in the longer, the walk stops at `cap` matches.
+RTK_DEV uint32_t rtk_lane_inter_count(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t cap) {
+    if (na > nb) { const uint32_t* t = a; a = b; b = t; const uint32_t tn = na; na = nb; nb = tn; }
+    uint32_t cnt = 0, lo = 0;
+    for (uint32_t i = 0; i < na && cnt < cap && lo < nb; ++i) {
+        const uint32_t x = a[i];
+        uint32_t l = lo, h = nb;
+        while (l < h) { const uint32_t m = (l + h) >> 1; if (b[m] < x) l = m + 1; else h = m; }
+        lo = l;
+        if (lo < nb && b[lo] == x) { ++cnt; ++lo; }
+    }
+    return cnt;
+}
+RTK_DEV uint32_t rtk_lane_shared_unitigs(const GraphView& g, uint32_t u, uint32_t v, uint32_t cap) { // min(|colours(u) & colours(v)|, cap), as rtk_shared_unitigs
+    const int32_t gu = g.gid[u], gv = g.gid[v];
+    const uint32_t* lu = g.col + g.loff[u]; const uint32_t nlu = static_cast<uint32_t>(g.loff[u + 1] - g.loff[u]);
+    const uint32_t* lv = g.col + g.loff[v]; const uint32_t nlv = static_cast<uint32_t>(g.loff[v + 1] - g.loff[v]);
+    if (gu >= 0 && gu == gv) {
+        const uint64_t ng = g.goff[gu + 1] - g.goff[gu];
+        if (ng >= cap) return cap;
+        return static_cast<uint32_t>(ng) + rtk_lane_inter_count(lu, nlu, lv, nlv, cap - static_cast<uint32_t>(ng));
+    }
+    const uint32_t* gul = gu >= 0 ? g.col + g.goff[gu] : nullptr; const uint32_t ngu = gu >= 0 ? static_cast<uint32_t>(g.goff[gu + 1] - g.goff[gu]) : 0u;
+    const uint32_t* gvl = gv >= 0 ? g.col + g.goff[gv] : nullptr; const uint32_t ngv = gv >= 0 ? static_cast<uint32_t>(g.goff[gv + 1] - g.goff[gv]) : 0u;
+    uint32_t shared = 0; // the four partial intersections add up (global and local part of one unitig are disjoint)
+    if (ngu && ngv) shared += rtk_lane_inter_count(gul, ngu, gvl, ngv, cap);
+    if (shared < cap && ngv && nlu) shared += rtk_lane_inter_count(lu, nlu, gvl, ngv, cap - shared);
+    if (shared < cap && ngu && nlv) shared += rtk_lane_inter_count(gul, ngu, lv, nlv, cap - shared);
+    if (shared < cap && nlu && nlv) shared += rtk_lane_inter_count(lu, nlu, lv, nlv, cap - shared);
+    return shared;
+}
+
 // colours(u) = global | local, merged into the running union held in sc.set[cur]; returns new size (0xFFFFFFFF on overflow)
 RTK_FN uint32_t rtk_union_unitig(const GraphView& g_, const SeedScratch& sc_, int& cur_, uint32_t n_cur_, uint32_t u_) {
     const GraphView& g = *rtk_u(&g_); const SeedScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); int& cur = *rtk_u(&cur_); uint32_t n_cur = rtk_u(n_cur_); uint32_t u = rtk_u(u_);
@@ -742,30 +775,65 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
     // ---- adjacent solid anchors on different unitigs must be graph neighbours sharing >= min_cov colours (:329-372) ----
     for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < n1; i += RTK_WAVE) sc.sflag[i] = 0; // 1 = emptied
     rtk_sync();
-    for (uint32_t c0 = 1; c0 < n1; c0 += RTK_WAVE) {
-        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
-        bool cand = false;
-        if (i < n1 && s_pos[i] - s_pos[i - 1] == 1) cand = rtk_hit_unitig(hits[s_pos[i]]) != rtk_hit_unitig(hits[s_pos[i - 1]]);
-        uint64_t bal = rtk_ballot(cand);
-        while (bal) { // junctions are handled one after the other: the emptiness flags carry across them
-            const uint32_t ii = c0 + static_cast<uint32_t>(rtk_ffs(bal)) - 1u;
-            bal &= bal - 1ull;
-            if (sc.sflag[ii - 1] || sc.sflag[ii]) continue;
-            const UMap ul = rtk_unpack_hit(hits[s_pos[ii - 1]]), ur = rtk_unpack_hit(hits[s_pos[ii]]);
-            // right unitig must be the successor of the left one in walk direction (tail/head k-1 overlap) ...
-            bool invalid = true;
-            const uint32_t* a = g.adj + 8ull * ul.unitig + (ul.strand ? 0 : 4);
-            for (int bb = 0; bb < 4; ++bb) if (a[bb] != RTK_NONE32 && (a[bb] >> 1) == ur.unitig && (a[bb] & 1u) == ur.strand) invalid = false;
-            // ... and share enough colours
-            if (!invalid) invalid = rtk_shared_unitigs(g, ul.unitig, ur.unitig, o.min_cov_vertices) < o.min_cov_vertices;
-            if (invalid) {
-                uint32_t i_l = ii - 1, i_r = ii + 1;
-                i_l -= (i_l != 0) ? 1u : 0u;
-                while (i_l > 0 && s_pos[i_l] == s_pos[i_l + 1] - 1 && rtk_hit_unitig(hits[s_pos[i_l]]) == ul.unitig) { sc.sflag[i_l] = 1; --i_l; }
-                while (i_r < n1 && s_pos[i_r] == s_pos[i_r - 1] + 1 && rtk_hit_unitig(hits[s_pos[i_r]]) == ur.unitig) { sc.sflag[i_r] = 1; ++i_r; }
-                sc.sflag[ii - 1] = 1; sc.sflag[ii] = 1;
+    // A junction = two solid anchors at adjacent positions on different unitigs. The verdict on one only depends on its two unitigs, the
+    // emptiness flags it leaves behind carry on to later junctions. This kernel lasts as long as the longest read of the ticket (tens of
+    // thousands of solid anchors, hundreds of junctions, one every other 64-anchor chunk), so nothing here may cost a memory round trip per
+    // chunk or per junction: (1) the junctions are gathered into a list, four chunks of anchors in flight per step; (2) they are judged 64 at
+    // a time, one per lane (adjacency words and colour sets of 64 pairs read side by side); (3) only the invalid ones -- a handful -- are then
+    // visited in order to spread their flags (a valid junction changes nothing, whatever the flags around it say).
+    {
+        uint64_t* const jl = sc.vkey; const uint32_t jcap = 2u * sc.v_cap + 512u; // junction list: index of the right anchor, bit 63 = invalid
+        uint32_t nj = 0;
+        auto flush = [&]() {
+            rtk_sync();
+            for (uint32_t j0 = 0; j0 < nj; j0 += RTK_WAVE) { // (2)
+                const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane());
+                if (j < nj) {
+                    const uint32_t ii = static_cast<uint32_t>(jl[j]);
+                    const UMap ul = rtk_unpack_hit(hits[s_pos[ii - 1]]), ur = rtk_unpack_hit(hits[s_pos[ii]]);
+                    // right unitig must be the successor of the left one in walk direction (tail/head k-1 overlap) ...
+                    bool inv = true;
+                    const uint32_t* a = g.adj + 8ull * ul.unitig + (ul.strand ? 0 : 4);
+                    for (int bb = 0; bb < 4; ++bb) if (a[bb] != RTK_NONE32 && (a[bb] >> 1) == ur.unitig && (a[bb] & 1u) == ur.strand) inv = false;
+                    // ... and share enough colours
+                    if (!inv) inv = rtk_lane_shared_unitigs(g, ul.unitig, ur.unitig, o.min_cov_vertices) < o.min_cov_vertices;
+                    if (inv) jl[j] |= 1ull << 63;
+                }
+            }
+            rtk_sync();
+            for (uint32_t j0 = 0; j0 < nj; j0 += RTK_WAVE) { // (3)
+                const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane());
+                const uint64_t e = j < nj ? jl[j] : 0ull;
+                uint64_t bad = rtk_ballot((e >> 63) != 0);
+                while (bad) {
+                    const int l = rtk_ffs(bad) - 1; bad &= bad - 1ull;
+                    const uint32_t ii = static_cast<uint32_t>(rtk_u(rtk_shfl(e, l)));
+                    if (sc.sflag[ii - 1] || sc.sflag[ii]) continue;
+                    const UMap ul = rtk_unpack_hit(hits[s_pos[ii - 1]]), ur = rtk_unpack_hit(hits[s_pos[ii]]);
+                    uint32_t i_l = ii - 1, i_r = ii + 1;
+                    i_l -= (i_l != 0) ? 1u : 0u;
+                    while (i_l > 0 && s_pos[i_l] == s_pos[i_l + 1] - 1 && rtk_hit_unitig(hits[s_pos[i_l]]) == ul.unitig) { sc.sflag[i_l] = 1; --i_l; }
+                    while (i_r < n1 && s_pos[i_r] == s_pos[i_r - 1] + 1 && rtk_hit_unitig(hits[s_pos[i_r]]) == ur.unitig) { sc.sflag[i_r] = 1; ++i_r; }
+                    sc.sflag[ii - 1] = 1; sc.sflag[ii] = 1;
+                    rtk_sync();
+                }
+            }
+            nj = 0;
+        };
+        const uint32_t lane = static_cast<uint32_t>(rtk_lane());
+        for (uint32_t c0 = 1; c0 < n1; c0 += 4 * RTK_WAVE) { // (1)
+            if (nj + 4u * RTK_WAVE > jcap) flush();
+            uint32_t p[4], q[4]; uint64_t hp[4], hq[4]; bool cand[4];
+            for (int x = 0; x < 4; ++x) { const uint32_t i = c0 + static_cast<uint32_t>(x) * RTK_WAVE + lane; p[x] = q[x] = 0; if (i < n1) { p[x] = s_pos[i]; q[x] = s_pos[i - 1]; } }
+            for (int x = 0; x < 4; ++x) { const uint32_t i = c0 + static_cast<uint32_t>(x) * RTK_WAVE + lane; cand[x] = i < n1 && p[x] - q[x] == 1; hp[x] = hq[x] = 0; if (cand[x]) { hp[x] = hits[p[x]]; hq[x] = hits[q[x]]; } }
+            for (int x = 0; x < 4; ++x) {
+                const bool c = cand[x] && rtk_hit_unitig(hp[x]) != rtk_hit_unitig(hq[x]);
+                const uint64_t bal = rtk_ballot(c);
+                if (c) jl[nj + static_cast<uint32_t>(rtk_popc(bal & ((1ull << lane) - 1ull)))] = c0 + static_cast<uint32_t>(x) * RTK_WAVE + lane;
+                nj += static_cast<uint32_t>(rtk_popc(bal));
             }
         }
+        flush();
     }
     rtk_sync();
     uint32_t n2 = 0;
