@@ -20,7 +20,7 @@ api.myers_batch(["ACGT"], ["ACGT"])
 for L in lens:
     q = "".join(rnd.choice("ACGT") for _ in range(L)); t = mutate(q, 0.1)
     ref = None
-    for waves in (1, 8, 16):
+    for waves in (1, 4, 8, 16):
         t0 = time.time(); r = api.myers_batch([q], [t], [-1], [0], want_path=True, waves=waves)[0]; dt = time.time() - t0
         if ref is None: ref = r
         print("len %6d waves %2d: dist %6d host %.1f ms same=%s" % (L, waves, r[0], dt * 1e3, r == ref), flush=True)
