@@ -11,6 +11,9 @@
 //          "insertion"   k-1 read bases read[p..p+k-1) plus one inserted base (read lacks a base);
 //          "deletion"    k+1 read bases read[p..p+k+1) minus one interior base (read has an extra base);
 //        a window touching a non-ACGT character never matches.
+//        The call passes or_exclusive_match = true (src/Graph.cpp:193). Two readings, switchable at run time (RTK_A2_XOR=union|exclusive, read by
+//        oracle_seeds.cpp and by rtk_opts_default on the device side): union (default) = the hits of all three kinds; exclusive = per window only
+//        the hits of the first kind that has any (substitution, then insertion, then deletion). tests/test_a2_switch.py holds both to each other.
 //   [A3] getSuccessors(): existing neighbours of the unitig end in walk direction, base order A,C,G,T,
 //        as whole-unitig mappings (dist=0, len=size-k+1).
 //   [A4] on-disk Kmer = 2 x u64, 2 bits/base (A0 C1 G2 T3), first base in the MSBs of word 0.

@@ -1,11 +1,12 @@
 // GPU side of the index build (reference: `Ratatosk index`, src/Ratatosk.cpp:1066-1067 Bifrost build + src/Graph.cpp:1561 addCoverage).
-// The reference builds its graph with Bifrost on the CPU; the two data-parallel steps of an index build that touch every base of the 30x short
-// reads are done here on the device, behind the C ABI (include/ratatosk_hip.h), for the index tool (csrc/tools/build_index.cpp --gpu):
+// The reference builds its graph with Bifrost on the CPU; the data-parallel step of an index build that touches every base of the 30x short
+// reads most often -- counting their k-mers -- is done here on the device, behind the C ABI (include/ratatosk_hip.h), for the index tool
+// (csrc/tools/build_index.cpp --gpu):
 //   rtk_index_count_kmers   canonical k-mers of the reads seen >= min_count times: every read position spells its k-mer (one lane per position,
 //                           the window packed 2 bits per base without branches), the k-mers of the pass are radix-sorted (rocPRIM) and the first
 //                           element of every run of >= min_count equal keys is kept. HBM-bound: 1 byte read + 8 bytes written per base, then the sort.
-//   rtk_index_map_reads     the reads against the unitigs (k-mer -> unitig table in HBM): per unitig the number of read k-mers on it, and the
-//                           distinct (unitig, read / pair id) events, sorted: the colour sets and coverages addCoverage computes.
+// (Mapping the reads back onto the unitigs for the colour sets and coverages -- what addCoverage computes -- runs on the host threads of the tool,
+// by byte ranges of the read files; it is the next candidate for the device.)
 // One-word k-mers (k <= 31) only; the tool keeps its CPU path for k = 63 and for gzip input. Own translation unit: rocPRIM's templates.
 #include <string.h>
 
