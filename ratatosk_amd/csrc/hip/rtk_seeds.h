@@ -1007,7 +1007,8 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
     if (rtk_lane() == 0) { // phase profile of the stage (wave cycles), read back under RTK_TRACE
         for (int i = 0; i < iph && i < 7; ++i) rtk_atomic_add(bv.counters + 24 + i, tph[i]);
 #ifndef RTK_SIM
-        atomicMax(bv.counters.get() + 31, rtk_clock() - tstart);
+        { const unsigned long long mine = rtk_clock() - tstart; const unsigned long long was = atomicMax(bv.counters.get() + 31, mine);
+          if (mine > was) for (int i = 0; i < iph && i < 7; ++i) bv.counters[72 + i] = tph[i]; } // (developer trace: the phases of the slowest read so far; races between two record holders are harmless)
 #endif
     }
 #undef RTK_PHASE

@@ -138,6 +138,50 @@ RTK_FN void rtk_sort_pairs(uint64_t* key_, uint64_t* val_, uint32_t n_) {
         rtk_sync();
         return;
     }
+    { // More pairs than the LDS buffer holds (the weak hits of a long read: thousands). The same network, with every run of sub-stages whose
+      // partners lie inside one block of RTK_LDS_SORT_CAP pairs done in LDS: a sort of 4096 pairs makes 10 passes over memory instead of 78.
+        const uint32_t B = RTK_LDS_SORT_CAP;
+        uint64_t* const lk = rtk_lds_sort_buf(); uint64_t* const lv = lk + B;
+        for (uint32_t i = n + static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) { key[i] = ~0ull; val[i] = ~0ull; }
+        rtk_sync();
+        auto in_lds = [&](uint32_t kk_lo, uint32_t kk_hi, uint32_t j_hi) { // for every block: stages kk = kk_lo .. kk_hi, sub-stages j = min(kk / 2, j_hi) .. 1
+            for (uint32_t b0 = 0; b0 < p; b0 += B) {
+                for (uint32_t t = static_cast<uint32_t>(rtk_lane()); t < B; t += RTK_WAVE) { lk[t] = key[b0 + t]; lv[t] = val[b0 + t]; }
+                RTK_WG_SYNC();
+                for (uint32_t kk = kk_lo; kk <= kk_hi; kk <<= 1) {
+                    for (uint32_t j = (kk >> 1) < j_hi ? (kk >> 1) : j_hi; j > 0; j >>= 1) {
+                        for (uint32_t t = static_cast<uint32_t>(rtk_lane()); t < B / 2; t += RTK_WAVE) {
+                            const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+                            const uint64_t ki = lk[i], kl = lk[l], vi = lv[i], vl = lv[l];
+                            const bool gt = (ki > kl) || (ki == kl && vi > vl);
+                            const bool up = (((b0 + i) & kk) == 0);
+                            if (gt == up) { lk[i] = kl; lk[l] = ki; lv[i] = vl; lv[l] = vi; }
+                        }
+                        RTK_WG_SYNC();
+                    }
+                }
+                for (uint32_t t = static_cast<uint32_t>(rtk_lane()); t < B; t += RTK_WAVE) { key[b0 + t] = lk[t]; val[b0 + t] = lv[t]; }
+                RTK_WG_SYNC();
+            }
+        };
+        in_lds(2, B, B / 2); // blocks sorted, alternately up and down
+        for (uint32_t kk = 2 * B; kk <= p; kk <<= 1) {
+            rtk_sync();
+            for (uint32_t j = kk >> 1; j >= B; j >>= 1) { // partners in different blocks: through memory
+                for (uint32_t t = static_cast<uint32_t>(rtk_lane()); t < p / 2; t += RTK_WAVE) {
+                    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;
+                    const uint64_t ki = key[i], kl = key[l], vi = val[i], vl = val[l];
+                    const bool gt = (ki > kl) || (ki == kl && vi > vl);
+                    const bool up = ((i & kk) == 0);
+                    if (gt == up) { key[i] = kl; key[l] = ki; val[i] = vl; val[l] = vi; }
+                }
+                rtk_sync();
+            }
+            in_lds(kk, kk, B / 2);
+        }
+        rtk_sync();
+        return;
+    }
 #endif
     for (uint32_t i = n + static_cast<uint32_t>(rtk_lane()); i < p; i += RTK_WAVE) { key[i] = ~0ull; val[i] = ~0ull; }
     rtk_sync();
