@@ -56,7 +56,11 @@ typedef struct rtk_opts {
      * reported (union of the three searches); 1 = the searches run substitution -> insertion -> deletion and a window that one of them
      * matched is not searched by the next. rtk_opts_default takes it from the environment: RTK_A2_XOR=union (default) | exclusive. */
     int32_t a2_exclusive;
-    int32_t reserved0;
+    /* Bifrost assumption [A3] as a switch: the order in which getSuccessors() hands out the (up to four) neighbours of a unitig end, which is the
+     * order exploreSubGraph pushes them (src/GraphTraversal.cpp:456-587) and so decides between candidates of equal score. 0 = by the base
+     * appended in walk direction, A,C,G,T, on both strands (default); 1 = on the reverse strand by the base as the unitig's own strand spells it
+     * (A,C,G,T there = T,G,C,A in walk direction). rtk_opts_default takes it from the environment: RTK_A3_ORDER=walk (default) | strand. */
+    int32_t a3_strand_order;
 } rtk_opts;
 
 typedef struct rtk_graph_info {

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -262,7 +263,11 @@ void Graph::successors(const UM& um, UM out[4], char base[4], int& n) const {
     const std::string& s = seq[um.unitig];
     // last k-mer of the unitig in walk direction (Bifrost neighborIterator: km_tail = strand ? tail : head.twin())
     std::string tail = um.strand ? s.substr(s.size() - k) : revcomp(s.substr(0, k));
-    for (int b = 0; b < 4; ++b) {
+    // [A3] switch (RTK_A3_ORDER=walk|strand, like rtk_opts::a3_strand_order on the device side): on the reverse strand the neighbours come in the
+    // order of the base appended in walk direction (default) or in the order of the unitig's own strand (T,G,C,A in walk direction)
+    const char* const e3 = getenv("RTK_A3_ORDER"); const bool a3_strand = e3 && !strcmp(e3, "strand"); // (read per call: the tests switch between the readings inside one process)
+    for (int bi = 0; bi < 4; ++bi) {
+        const int b = (a3_strand && !um.strand) ? 3 - bi : bi;
         const std::string next = tail.substr(1) + "ACGT"[b];
         UM f = findKmer(next.c_str());
         if (f.isEmpty()) continue;

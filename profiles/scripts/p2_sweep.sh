@@ -7,7 +7,10 @@ for i in $(seq ${COPIES:-18}); do echo $WD/c2.2.fastq >> $WD/in.txt; echo $WD/c2
 run() { env "$@" RTK_CLI_STATS=1 timeout 300 ratatosk_amd/bin/Ratatosk correct -2 -K 63 -c 16 -g $WD/c2.p2.index.k63.fasta.gz -d $WD/c2.p2.index.k63.rtsk -l $WD/in.txt -L $WD/raw.txt -o $WD/again 2>&1 | grep "correction phase" | sed "s/^.*correction phase/$* : /; s/thread-seconds.*//"; }
 run A=0
 run A=0
-run RTK_PHASE_LWAVES=16 RTK_PHASE_LGRID=64
+run RTK_PHASE_PGRID=2048 RTK_PHASE_MGRID=1600
+run RTK_PHASE_PGRID=2048 RTK_PHASE_MGRID=1600
+run RTK_PHASE_MGRID=1600
+run RTK_PHASE_PGRID=1536 RTK_PHASE_MGRID=1152
 run A=0
-RTK_TRACE=1 timeout 300 ratatosk_amd/bin/Ratatosk correct -2 -K 63 -c 16 -g $WD/c2.p2.index.k63.fasta.gz -d $WD/c2.p2.index.k63.rtsk -l $WD/c2.2.fastq -L $WD/c2.lr.fq -o $WD/again 2>&1 | grep "phase attempt" | head -3
-timeout 900 python -m pytest tests/test_pass2.py tests/test_myers_band.py -x -q -m gpu 2>&1 | tail -2
+run RTK_P2_RGRID=1024
+run RTK_P2_RGRID=256

@@ -590,7 +590,9 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
         // the four neighbour slots and the edge bits of this unitig, fetched together
         const uint32_t a4[4] = { rtk_ld(adj), rtk_ld(adj + 1), rtk_ld(adj + 2), rtk_ld(adj + 3) };
         const uint32_t eb = (rtk_ld(g_flags + um_start.unitig) >> (um_start.strand ? 4 : 0)) & 0xFu; // UnitigData::getSharedPids (UnitigData.hpp:275-284)
-        for (int b = 0; b < 4 && !rtk_failed(s); ++b) {
+        const bool rev_order = rtk_u(c.o.a3_strand_order) != 0 && !um_start.strand; // [A3] switch: slot = base appended in walk direction (A,C,G,T)
+        for (int bi = 0; bi < 4 && !rtk_failed(s); ++bi) {
+            const int b = rev_order ? 3 - bi : bi;
             const uint32_t ab = a4[b];
             if (ab == RTK_NONE32) continue;
             UMap sc; sc.unitig = ab >> 1; sc.strand = ab & 1u; sc.dist = 0; sc.len = rtk_nkm_u(c, sc.unitig);

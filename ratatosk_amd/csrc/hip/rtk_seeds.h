@@ -19,6 +19,7 @@ struct OptsView {
     // second pass (`correct -2`, long_read_correct in the reference): qualities of pass 1 are carried over, no 1-edit search
     U<int32_t> long_read_correct;
     U<uint32_t> max_len_weak_region2;
+    U<uint32_t> a3_strand_order; // [A3] switch (rtk_opts::a3_strand_order): 1 = neighbours of a reverse-strand end visited in the order of the unitig's own strand
     U<uint32_t> a2_exclusive; // [A2] switch (rtk_opts::a2_exclusive): 1 = a window matched by one kind of edit is not searched with the next kind
 };
 
