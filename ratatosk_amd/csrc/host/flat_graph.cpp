@@ -4,6 +4,8 @@
 #include "flat_graph.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -55,6 +57,10 @@ static bool km_from_string(const char* s, int k, RtkKm& out) {
 
 void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads) {
     k = k_;
+    const bool load_trace = getenv("RTK_LOAD_TRACE") != nullptr; // developer: seconds per section of the load
+    const auto lt0 = std::chrono::steady_clock::now(); auto lt_last = lt0;
+    auto lap = [&](const char* what) { if (!load_trace) return; const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rtk load] %-34s %7.2f s (at %7.2f s)\n", what, std::chrono::duration<double>(now - lt_last).count(), std::chrono::duration<double>(now - lt0).count()); lt_last = now; };
     if (k < 3 || k > RTK_MAX_K || !(k & 1)) throw std::runtime_error("k must be odd and <= 63 (MAX_KMER_SIZE = 64 build of the reference, CMakeLists.txt:6)");
     const bool wide = k > 31; // two-word k-mers: fingerprint keys confirmed against the unitig sequence (rtk_find_kmer_wide)
     // ---- unitigs ----
@@ -69,6 +75,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             seqs.push_back(seq);
         }
     }
+    lap("unitig FASTA read");
     const size_t n = seqs.size();
     if (n == 0) throw std::runtime_error("empty graph file " + fasta_gz);
     if (n >= 0x7FFFFFFFull) throw std::runtime_error("too many unitigs for 31-bit ids");
@@ -88,6 +95,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             }
         }
     });
+    lap("unitigs packed to 2 bits");
     // ---- half-k-mer index: every h-mer (h = (k-1)/2) of the forward unitig sequences -> the places it starts. A graph k-mer one edit
     // away from a read window shares its first or its last h characters with the read (the edit cannot be in both), so the 1-edit search
     // looks up read h-mers here and verifies the few k-mers they belong to instead of spelling every variant of the window.
@@ -105,50 +113,70 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
           est_gb = (8.0 * hs + 8.0 * (bases + uniq)) / 1e9; }
         if ((e_enum && e_enum[0] == '1') || est_gb > max_gb || wide) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); } // wide k: second pass only, which has no 1-edit search (src/Graph.cpp:100)
         else {
-            std::vector<std::pair<uint64_t, uint64_t> > pairs(uoff[n] - static_cast<uint64_t>(n) * static_cast<uint64_t>(h - 1)); // every h-mer start of every unitig, at its own place
+            // Every h-mer start of every unitig as a pair (h-mer, place), sorted -- by buckets of the leading h-mer bits, so that every step runs on
+            // all threads: count per (thread, bucket), scatter to the bucket's range, sort the buckets, lay the lists out bucket by bucket (their
+            // offsets from a prefix sum), claim the table slots with compare-and-swap. The lists (hxl) come out as one serial pass would write them;
+            // the slot an h-mer lands on depends on who claims first, which no lookup can tell.
+            typedef std::pair<uint64_t, uint64_t> HP;
+            const uint64_t n_pairs = uoff[n] - static_cast<uint64_t>(n) * static_cast<uint64_t>(h - 1);
             const uint64_t hm = (1ull << (2 * h)) - 1ull;
-            parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+            int nt = n_threads < 1 ? 1 : n_threads; if (static_cast<size_t>(nt) > n) nt = static_cast<int>(n);
+            int bbits = 2 * h < 12 ? 2 * h : 12; while (bbits > 0 && (n_pairs >> bbits) < 4096) --bbits; // ~4096 buckets for big graphs, fewer for small ones
+            const size_t nb = static_cast<size_t>(1) << bbits; const int bshift = 2 * h - bbits;
+            std::vector<std::vector<uint64_t> > cnt(static_cast<size_t>(nt), std::vector<uint64_t>(nb, 0));
+            auto each_hmer = [&](size_t lo, size_t hi, const std::function<void(uint64_t, uint64_t)>& fn) {
                 for (size_t u = lo; u < hi; ++u) {
                     const std::string& s = seqs[u];
-                    uint64_t fw = 0, at = uoff[u] - static_cast<uint64_t>(u) * static_cast<uint64_t>(h - 1);
+                    uint64_t fw = 0;
                     for (size_t i = 0; i < s.size(); ++i) {
                         fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & hm;
-                        if (i + 1 >= static_cast<size_t>(h)) pairs[at++] = std::make_pair(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h));
+                        if (i + 1 >= static_cast<size_t>(h)) fn(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h));
                     }
                 }
-            });
-            { // sorted slices, then pairwise merges (each level on half as many threads)
-                int nt = n_threads < 1 ? 1 : n_threads; while (nt > 1 && pairs.size() / static_cast<size_t>(nt) < (1u << 16)) nt >>= 1;
-                int p2 = 1; while (p2 * 2 <= nt) p2 *= 2; nt = p2;
-                std::vector<size_t> cut(nt + 1); for (int t = 0; t <= nt; ++t) cut[t] = pairs.size() * static_cast<size_t>(t) / static_cast<size_t>(nt);
-                parallel_slices(static_cast<size_t>(nt), nt, [&](size_t lo, size_t hi, int) { for (size_t t = lo; t < hi; ++t) std::sort(pairs.begin() + cut[t], pairs.begin() + cut[t + 1]); });
-                for (int w = 1; w < nt; w *= 2) {
-                    const int groups = nt / (2 * w);
-                    parallel_slices(static_cast<size_t>(groups), groups, [&](size_t lo, size_t hi, int) {
-                        for (size_t gI = lo; gI < hi; ++gI) std::inplace_merge(pairs.begin() + cut[2 * w * gI], pairs.begin() + cut[2 * w * gI + w], pairs.begin() + cut[2 * w * gI + 2 * w]);
-                    });
-                }
-            }
-            uint64_t uniq = 0;
-            for (size_t i = 0; i < pairs.size(); ++i) if (i == 0 || pairs[i].first != pairs[i - 1].first) ++uniq;
-            if (pairs.size() + uniq >= (1ull << 34)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
+            };
+            parallel_slices(n, nt, [&](size_t lo, size_t hi, int t) { std::vector<uint64_t>& c = cnt[static_cast<size_t>(t)]; each_hmer(lo, hi, [&](uint64_t fw, uint64_t) { ++c[fw >> bshift]; }); });
+            std::vector<uint64_t> bstart(nb + 1, 0); // bucket b = [bstart[b], bstart[b + 1]); inside it the threads' shares in thread order
+            { uint64_t at = 0; for (size_t bkt = 0; bkt < nb; ++bkt) { bstart[bkt] = at; for (int t = 0; t < nt; ++t) { const uint64_t c = cnt[static_cast<size_t>(t)][bkt]; cnt[static_cast<size_t>(t)][bkt] = at; at += c; } } bstart[nb] = at; }
+            std::vector<HP> pairs(n_pairs);
+            parallel_slices(n, nt, [&](size_t lo, size_t hi, int t) { std::vector<uint64_t>& c = cnt[static_cast<size_t>(t)]; each_hmer(lo, hi, [&](uint64_t fw, uint64_t place) { pairs[c[fw >> bshift]++] = HP(fw, place); }); });
+            std::atomic<size_t> next_b(0);
+            std::vector<uint64_t> buniq(nb, 0);
+            parallel_slices(static_cast<size_t>(nt), nt, [&](size_t, size_t, int) { // buckets handed out one at a time: sorted, distinct h-mers counted
+                for (;;) { const size_t bkt = next_b.fetch_add(1); if (bkt >= nb) break;
+                    std::sort(pairs.begin() + static_cast<std::ptrdiff_t>(bstart[bkt]), pairs.begin() + static_cast<std::ptrdiff_t>(bstart[bkt + 1]));
+                    uint64_t u = 0; for (uint64_t i = bstart[bkt]; i < bstart[bkt + 1]; ++i) if (i == bstart[bkt] || pairs[i].first != pairs[i - 1].first) ++u;
+                    buniq[bkt] = u; } });
+            uint64_t uniq = 0; std::vector<uint64_t> lstart(nb + 1, 0); // list words of bucket b start at lstart[b]: one count word per distinct h-mer + its places
+            for (size_t bkt = 0; bkt < nb; ++bkt) { lstart[bkt] = bstart[bkt] + uniq; uniq += buniq[bkt]; }
+            lstart[nb] = n_pairs + uniq;
+            if (n_pairs + uniq >= (1ull << 34)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
             uint64_t hslots = 16;
             while (hslots < 2 * uniq) hslots <<= 1;
             hx.assign(hslots, RTK_EMPTY_KEY);
-            hxl.clear(); hxl.reserve(pairs.size() + uniq + 1);
-            for (size_t i = 0; i < pairs.size();) {
-                size_t j = i;
-                while (j < pairs.size() && pairs[j].first == pairs[i].first) ++j;
-                uint64_t q = rtk_hash64(pairs[i].first) & (hslots - 1);
-                while (hx[q] != RTK_EMPTY_KEY) q = (q + 1) & (hslots - 1);
-                hx[q] = (pairs[i].first << 34) | static_cast<uint64_t>(hxl.size());
-                hxl.push_back(static_cast<uint64_t>(j - i));
-                for (size_t t = i; t < j; ++t) hxl.push_back(pairs[t].second);
-                i = j;
-            }
-            hxl.push_back(0);
+            hxl.assign(n_pairs + uniq + 1, 0);
+            next_b = 0;
+            parallel_slices(static_cast<size_t>(nt), nt, [&](size_t, size_t, int) {
+                const size_t RING = 16; uint64_t ring[16]; size_t n_pend = 0; // table words waiting for their (prefetched) slot
+                auto claim = [&](uint64_t word) { uint64_t q = rtk_hash64(word >> 34) & (hslots - 1);
+                    for (;;) { uint64_t expect = RTK_EMPTY_KEY; if (__atomic_load_n(&hx[q], __ATOMIC_RELAXED) == RTK_EMPTY_KEY && __atomic_compare_exchange_n(&hx[q], &expect, word, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; q = (q + 1) & (hslots - 1); } };
+                for (;;) { const size_t bkt = next_b.fetch_add(1); if (bkt >= nb) break;
+                    uint64_t w = lstart[bkt];
+                    for (uint64_t i = bstart[bkt]; i < bstart[bkt + 1];) {
+                        uint64_t j = i; while (j < bstart[bkt + 1] && pairs[j].first == pairs[i].first) ++j;
+                        const uint64_t word = (pairs[i].first << 34) | w;
+                        if (n_pend >= RING) claim(ring[n_pend & (RING - 1)]);
+                        ring[n_pend & (RING - 1)] = word; ++n_pend;
+                        __builtin_prefetch(&hx[rtk_hash64(pairs[i].first) & (hslots - 1)], 1);
+                        hxl[w++] = j - i;
+                        for (uint64_t t = i; t < j; ++t) hxl[w++] = pairs[t].second;
+                        i = j;
+                    } }
+                for (size_t j = n_pend > RING ? n_pend - RING : 0; j < n_pend; ++j) claim(ring[j & (RING - 1)]);
+            });
+            hxl[n_pairs + uniq] = 0;
         }
     }
+    lap("half-k-mer index");
     // ---- k-mer -> (unitig, offset, orientation) table, load factor <= 0.5 ----
     // (small graphs keep the round-2 sizes -- a power of two at load 0.25 .. 0.5; above RTK_HT_DENSE_KMERS k-mers (default 2^28: a 4 GB table) the table
     // is sized for load 0.7: the slot of a hash is floor(hash * slots / 2^64), any number of slots will do)
@@ -157,7 +185,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     { const char* e = getenv("RTK_HT_DENSE_KMERS"); const uint64_t dense_from = e ? strtoull(e, nullptr, 10) : (1ull << 28);
       if (n_kmers >= dense_from) slots = n_kmers + n_kmers * 3 / 7 + 16; }
     ht.assign(2 * slots, 0);
-    for (uint64_t i = 0; i < slots; ++i) ht[2 * i] = RTK_EMPTY_KEY;
+    parallel_slices(static_cast<size_t>(slots), n_threads, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) ht[2 * i] = RTK_EMPTY_KEY; });
     // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer.
     // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
     // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.
@@ -172,6 +200,20 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
       if (n_kmers > cap_bits || (e1 && e1[0] == '1')) bf1.assign(1, ~0ull); else bf1.assign(bits / 64, 0); } // below one bit per key the array stops paying for itself
     const bool bf1_off = bf1.size() == 1;
     parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+        struct Pend { uint64_t can, hh, val; };
+        const size_t RING = 16; Pend ring[16]; size_t n_pend = 0;
+        auto insert = [&](const Pend& pe) {
+            uint64_t h = rtk_ht_slot(pe.hh, slots);
+            while (true) { // claim an empty slot with compare-and-swap on its key word (another thread may be filling the table too)
+                uint64_t seen_key = __atomic_load_n(&ht[2 * h], __ATOMIC_RELAXED);
+                if (seen_key == RTK_EMPTY_KEY) { uint64_t expect = RTK_EMPTY_KEY; if (__atomic_compare_exchange_n(&ht[2 * h], &expect, pe.can, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; seen_key = expect; }
+                if (!wide && seen_key == pe.can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
+                h = rtk_ht_next(h, slots);
+            }
+            __atomic_fetch_or(&bf[(pe.hh >> 32) & (bf_words - 1)], (1ull << (pe.hh & 63)) | (1ull << ((pe.hh >> 6) & 63)), __ATOMIC_RELAXED);
+            if (!bf1_off) { const uint64_t b1 = (pe.hh >> 12) & (bf1.size() * 64 - 1); __atomic_fetch_or(&bf1[b1 >> 6], 1ull << (b1 & 63ull), __ATOMIC_RELAXED); }
+            ht[2 * h + 1] = pe.val;
+        };
         for (size_t u = lo; u < hi; ++u) {
             const std::string& s = seqs[u];
             RtkKm fwk = rtk_km_zero();
@@ -181,18 +223,16 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                 bool is_fw; uint64_t can, hh; // can: the key word of the slot
                 if (!wide) { can = kmer_canonical(fwk.lo, k, &is_fw); hh = rtk_hash64(can); }
                 else { const RtkKm rc = rtk_km_revcomp(fwk, k); is_fw = !rtk_km_less(rc, fwk); const RtkKm c2 = is_fw ? fwk : rc; hh = rtk_km_hash(c2); can = rtk_km_fingerprint(c2); }
-                uint64_t h = rtk_ht_slot(hh, slots);
-                while (true) { // claim an empty slot with compare-and-swap on its key word (another thread may be filling the table too)
-                    uint64_t seen_key = __atomic_load_n(&ht[2 * h], __ATOMIC_RELAXED);
-                    if (seen_key == RTK_EMPTY_KEY) { uint64_t expect = RTK_EMPTY_KEY; if (__atomic_compare_exchange_n(&ht[2 * h], &expect, can, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; seen_key = expect; }
-                    if (!wide && seen_key == can) throw std::runtime_error("k-mer occurs twice in the unitig file: not a compacted de Bruijn graph for this k");
-                    h = rtk_ht_next(h, slots);
-                }
-                { __atomic_fetch_or(&bf[(hh >> 32) & (bf_words - 1)], (1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63)), __ATOMIC_RELAXED);
-                  if (!bf1_off) { const uint64_t b1 = (hh >> 12) & (bf1.size() * 64 - 1); __atomic_fetch_or(&bf1[b1 >> 6], 1ull << (b1 & 63ull), __ATOMIC_RELAXED); } }
-                ht[2 * h + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
+                // the slot and the filter words are asked for now and written a few k-mers later: a table of GBs is a cache miss per access
+                Pend& pe = ring[n_pend & (RING - 1)];
+                if (n_pend >= RING) insert(pe);
+                pe.can = can; pe.hh = hh; pe.val = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (is_fw ? 1ull : 0ull);
+                __builtin_prefetch(&ht[2 * rtk_ht_slot(hh, slots)], 1); __builtin_prefetch(&bf[(hh >> 32) & (bf_words - 1)], 1);
+                if (!bf1_off) __builtin_prefetch(&bf1[((hh >> 12) & (bf1.size() * 64 - 1)) >> 6], 1);
+                ++n_pend;
             }
         }
+        for (size_t j = n_pend > RING ? n_pend - RING : 0; j < n_pend; ++j) insert(ring[j & (RING - 1)]);
     });
     const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_slots = slots; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; v.useq = useq.data(); v.uoff = uoff.data(); return v; }();
     if (wide) { // fingerprints cannot tell a repeated k-mer while the table is filled: every k-mer has to find ITSELF afterwards
@@ -209,6 +249,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             }
         });
     }
+    lap("k-mer table + filters");
     // ---- unitig data (.rtsk) ----
     flags.assign(n, 0); kcov.assign(n, 0); card.assign(n, 0); gid.assign(n, -1); loff.assign(n + 1, 0);
     std::vector<std::vector<uint32_t> > locals(n);
@@ -261,6 +302,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     col.assign(goff[globals.size()] + 1, 0);
     for (size_t u = 0; u < n; ++u) std::copy(locals[u].begin(), locals[u].end(), col.begin() + loff[u]);
     for (size_t g = 0; g < globals.size(); ++g) std::copy(globals[g].begin(), globals[g].end(), col.begin() + goff[g]);
+    lap("unitig data (.rtsk) read");
     // ---- SNP annotations: get_ambiguity_char() order = (position, IUPAC character) (UnitigData.hpp:557-574) ----
     {
         amb.assign(n + 1, 0);
@@ -281,6 +323,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     for (size_t u = 0; u < n; ++u) cycoff[u + 1] = cycoff[u] + cycles[u].size();
     cyc.assign(cycoff[n] / 8 + 2, 0);
     for (size_t u = 0; u < n; ++u) if (!cycles[u].empty()) memcpy(reinterpret_cast<char*>(cyc.data()) + cycoff[u], cycles[u].data(), cycles[u].size());
+    lap("annotations, haplotypes, cycles");
     // ---- adjacency ([A3]: neighbours of the unitig end in walk direction, A,C,G,T) ----
     adj.assign(n * 8, RTK_NONE32);
     parallel_slices(n, n_threads, [&](size_t lo_u, size_t hi_u, int) {
@@ -302,6 +345,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         }
     }
     });
+    lap("adjacency");
     // ---- getMaxKmerCoverage(dbg, 0.001) ----
     {
         std::vector<uint32_t> v(kcov);
