@@ -196,16 +196,22 @@ static bool fast_unitigs(KTable<uint64_t>& km, const std::vector<uint64_t>& soli
     // what is left belongs to chains that meet themselves: the plain construction, which finds every other k-mer taken
     std::vector<Rec> rest;
     {
+        // (the k-mers no chain has claimed are looked for on all threads -- one table probe per solid k-mer, a cache miss each -- and come out in
+        // sorted order, thread after thread; the plain construction then only visits those)
+        std::vector<std::vector<uint64_t> > left_t(n_thr);
+        parallel_for(solid.size(), n_thr, [&](size_t b, size_t e, unsigned t) { for (size_t i = b; i < e; ++i) if (*km.slot(solid[i], false) == 0) left_t[t].push_back(solid[i]); });
+        std::vector<uint64_t> left; for (unsigned t = 0; t < n_thr; ++t) left.insert(left.end(), left_t[t].begin(), left_t[t].end());
         std::set<uint64_t> in_this;
-        for (size_t si = 0; si < solid.size(); ++si) {
-            uint64_t* v0 = km.slot(solid[si], false);
+        for (size_t li = 0; li < left.size(); ++li) {
+            const uint64_t seed_km = left[li];
+            uint64_t* v0 = km.slot(seed_km, false);
             if (*v0 != 0) continue;
-            in_this.clear(); in_this.insert(solid[si]);
-            std::vector<uint64_t> fwd(1, solid[si]), bwd; uint64_t nb[4], nb2[4];
-            for (uint64_t x = solid[si];;) { if (succs(x, nb) != 1) break; const uint64_t y = nb[0]; if (preds(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); fwd.push_back(y); x = y; }
-            for (uint64_t x = solid[si];;) { if (preds(x, nb) != 1) break; const uint64_t y = nb[0]; if (succs(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); bwd.push_back(y); x = y; }
+            in_this.clear(); in_this.insert(seed_km);
+            std::vector<uint64_t> fwd(1, seed_km), bwd; uint64_t nb[4], nb2[4];
+            for (uint64_t x = seed_km;;) { if (succs(x, nb) != 1) break; const uint64_t y = nb[0]; if (preds(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); fwd.push_back(y); x = y; }
+            for (uint64_t x = seed_km;;) { if (preds(x, nb) != 1) break; const uint64_t y = nb[0]; if (succs(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); bwd.push_back(y); x = y; }
             std::vector<uint64_t> path(bwd.rbegin(), bwd.rend()); path.insert(path.end(), fwd.begin(), fwd.end());
-            Rec r; r.seed = solid[si]; r.seq = kmer_decode(path[0], k);
+            Rec r; r.seed = seed_km; r.seq = kmer_decode(path[0], k);
             for (size_t j = 1; j < path.size(); ++j) r.seq.push_back(bits2base(static_cast<int>(path[j] & 3)));
             for (size_t j = 0; j < path.size(); ++j) *km.slot(kmer_canonical(path[j], k), false) = 1;
             rest.push_back(r);
