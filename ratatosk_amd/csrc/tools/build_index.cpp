@@ -273,7 +273,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
 
     // ---- pass 1: count canonical k-mers. The k-mer space is cut into one shard per thread by a hash; every thread reads the input
     // itself (parsing is cheap next to a table insert) and counts the k-mers of its shard in a table of its own ----
-    unsigned n_thr = std::thread::hardware_concurrency(); if (n_thr == 0) n_thr = 1; if (n_thr > (fast ? 64u : 32u)) n_thr = fast ? 64u : 32u;
+    unsigned n_thr = std::thread::hardware_concurrency(); if (n_thr == 0) n_thr = 1; if (n_thr > (fast ? 128u : 32u)) n_thr = fast ? 128u : 32u; // (--fast: the steps are random accesses into GB-sized tables: latency-bound, SMT threads help)
     { const char* e = getenv("RTK_INDEX_THREADS"); if (e && atoi(e) > 0) n_thr = static_cast<unsigned>(atoi(e)); }
     std::vector<KM> solid;
     if (gpu) { // the k-mers counted on the device (csrc/hip/rtk_index.hip, through the C ABI of libratatosk_hip.so next to this executable)
