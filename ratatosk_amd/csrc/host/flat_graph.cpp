@@ -152,8 +152,9 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             if (n_pairs + uniq >= (1ull << 34)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
             uint64_t hslots = 16;
             while (hslots < 2 * uniq) hslots <<= 1;
-            hx.assign(hslots, RTK_EMPTY_KEY);
-            hxl.assign(n_pairs + uniq + 1, 0);
+            hx.alloc_uninitialised(hslots); // (every word of the two arrays is written below, by all threads)
+            parallel_slices(static_cast<size_t>(hslots), nt, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) hx[i] = RTK_EMPTY_KEY; });
+            hxl.alloc_uninitialised(n_pairs + uniq + 1);
             next_b = 0;
             parallel_slices(static_cast<size_t>(nt), nt, [&](size_t, size_t, int) {
                 const size_t RING = 16; uint64_t ring[16]; size_t n_pend = 0; // table words waiting for their (prefetched) slot
@@ -184,8 +185,8 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     while (slots < 2 * n_kmers) slots <<= 1;
     { const char* e = getenv("RTK_HT_DENSE_KMERS"); const uint64_t dense_from = e ? strtoull(e, nullptr, 10) : (1ull << 28);
       if (n_kmers >= dense_from) slots = n_kmers + n_kmers * 3 / 7 + 16; }
-    ht.assign(2 * slots, 0);
-    parallel_slices(static_cast<size_t>(slots), n_threads, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) ht[2 * i] = RTK_EMPTY_KEY; });
+    ht.alloc_uninitialised(2 * slots);
+    parallel_slices(static_cast<size_t>(slots), n_threads, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) { ht[2 * i] = RTK_EMPTY_KEY; ht[2 * i + 1] = 0; } });
     // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer.
     // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
     // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.

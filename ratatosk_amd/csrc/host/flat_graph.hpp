@@ -3,6 +3,7 @@
 #ifndef RTK_FLAT_GRAPH_HPP
 #define RTK_FLAT_GRAPH_HPP
 
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -11,12 +12,28 @@
 
 namespace rtk {
 
+// The three biggest buffers (k-mer table, half-k-mer index: tens of GB each for a whole-genome graph) are filled by all loader threads:
+// a std::vector would write every word once more on one thread (value initialisation) before the first useful store.
+struct BigWords {
+    BigWords() : p_(nullptr), n_(0) {}
+    ~BigWords() { delete[] p_; }
+    BigWords(const BigWords&) = delete; BigWords& operator=(const BigWords&) = delete;
+    size_t size() const { return n_; }
+    uint64_t* data() { return p_; } const uint64_t* data() const { return p_; }
+    uint64_t& operator[](size_t i) { return p_[i]; } const uint64_t& operator[](size_t i) const { return p_[i]; }
+    void alloc_uninitialised(size_t n) { delete[] p_; p_ = nullptr; n_ = 0; p_ = new uint64_t[n ? n : 1]; n_ = n; } // (default-initialised: the pages are not touched here)
+    void assign(size_t n, uint64_t v) { alloc_uninitialised(n); for (size_t i = 0; i < n; ++i) p_[i] = v; }    // small cases; the loader fills big ones itself
+private:
+    uint64_t* p_; size_t n_;
+};
+
 struct FlatGraph {
     int k = 31;
     uint64_t n_kmers = 0, n_global = 0;
-    std::vector<uint64_t> useq, uoff, loff, goff, ht, bf, cycoff; // cycoff[u]..cycoff[u+1]: bytes of unitig u's compact cycles in `cyc`
+    BigWords ht;                                                  // k-mer table (GraphView::ht)
+    std::vector<uint64_t> useq, uoff, loff, goff, bf, cycoff; // cycoff[u]..cycoff[u+1]: bytes of unitig u's compact cycles in `cyc`
     std::vector<uint64_t> bf1;                                    // first-level presence bits
-    std::vector<uint64_t> hx, hxl;                                // half-k-mer index (GraphView::hx / hxl)
+    BigWords hx, hxl;                                             // half-k-mer index (GraphView::hx / hxl)
     std::vector<uint64_t> amb;                                    // SNP annotations (GraphView::amb): n+1 offsets, then the entries
     std::vector<uint64_t> hap;                                    // haplotype ids of each unitig (UnitigData::hap_ids, src/UnitigData.hpp:493-517): n+1 offsets, then the ids. Only the
                                                                   // phased-input options (-p/-P, out of scope) read them; kept so that a reference-written index loads without loss
