@@ -32,6 +32,7 @@
 #include <mutex>
 #include <queue>
 #include <set>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -773,13 +774,22 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         if (fast) fasta_thread.join(); else write_fasta();
         if (fasta_rc) { fprintf(stderr, "rtk_build_index: cannot write fasta.gz\n"); return 1; }
         std::ofstream out((prefix + ".index.k" + std::to_string(k) + ".rtsk").c_str(), std::ios::binary);
-        for (size_t u = 0; u < n; ++u) {
-            RtskRecord r;
-            disk_kmer_from_string(U[u].seq.c_str(), k, r.head);
-            r.kmcov = kmcov[u]; r.shared = shared[u];
-            r.global_ids = global_ids[u]; r.local_ids = local_ids[u]; r.ambiguity_ids = ambiguity[u]; r.cycles = cycles[u];
-            rtsk_write_record(out, r);
-        }
+        // records are encoded (Roaring containers of the colour sets) by ranges of unitigs on all threads and written in order: the same bytes
+        const unsigned n_w = fast ? n_thr : 1u; const size_t per = (n + n_w - 1) / n_w;
+        std::vector<std::string> part(n_w);
+        parallel_for(n, n_w, [&](size_t b, size_t e, unsigned) {
+            std::ostringstream os(std::ios::binary);
+            for (size_t u = b; u < e; ++u) {
+                RtskRecord r;
+                disk_kmer_from_string(U[u].seq.c_str(), k, r.head);
+                r.kmcov = kmcov[u]; r.shared = shared[u];
+                r.global_ids = global_ids[u]; r.local_ids = local_ids[u]; r.ambiguity_ids = ambiguity[u]; r.cycles = cycles[u];
+                rtsk_write_record(os, r);
+            }
+            part[per ? b / per : 0] = os.str();
+        });
+        for (unsigned t = 0; t < n_w; ++t) out.write(part[t].data(), static_cast<std::streamsize>(part[t].size()));
+        if (!out.good()) { fprintf(stderr, "rtk_build_index: cannot write the .rtsk file\n"); return 1; }
     }
     lap("files written");
     return 0;
