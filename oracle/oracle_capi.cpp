@@ -68,6 +68,23 @@ int orc_global_set(void* gp, int64_t id, uint32_t* out, uint64_t cap, uint64_t* 
     return 0;
 }
 
+// annotations of unitig u as the index holds them: SNP annotations (position, IUPAC code; UnitigData.hpp:557-574) and the compact
+// cycles (UnitigData.hpp:312-327) as one byte string of NUL-terminated successor-base strings. For tests/test_annotators.py, which
+// recomputes both from the graph (oracle/oracle_annot.py) and compares.
+int orc_unitig_annotations(void* gp, uint64_t u, uint32_t* amb_pos, char* amb_code, uint64_t amb_cap, uint64_t* n_amb,
+                           char* cyc, uint64_t cyc_cap, uint64_t* n_cyc_bytes) {
+    const Graph* g = static_cast<const Graph*>(gp);
+    if (u >= g->seq.size()) return -1;
+    const UnitigInfo& d = g->info[u];
+    *n_amb = d.amb.size();
+    for (size_t i = 0; i < d.amb.size() && i < amb_cap; ++i) { amb_pos[i] = d.amb[i].first; amb_code[i] = d.amb[i].second; }
+    std::string all;
+    for (size_t i = 0; i < d.cycles.size(); ++i) { all += d.cycles[i]; all.push_back('\0'); }
+    *n_cyc_bytes = all.size();
+    if (cyc && cyc_cap >= all.size()) memcpy(cyc, all.data(), all.size());
+    return 0;
+}
+
 // neighbours of unitig u walking fw (dir 0) / on the reverse strand (dir 1): out[b] = unitig<<1|strand or -1, b in A,C,G,T
 void orc_neighbours(void* gp, uint64_t u, int dir, int64_t out[4]) {
     const Graph* g = static_cast<const Graph*>(gp);

@@ -39,6 +39,8 @@ def lib():
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_global_set.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_neighbours.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_int64)]
+        L.orc_unitig_annotations.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                             C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_myers.restype = C.c_int
         L.orc_myers.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
@@ -154,6 +156,19 @@ class Graph:
         out = (C.c_int64 * 4)()
         lib().orc_neighbours(self.h, u, direction, out)
         return [out[i] for i in range(4)]
+
+    def annotations(self, u):
+        """What the index holds for unitig u: ([(position, IUPAC code)], [compact cycle strings])."""
+        na, nc = C.c_uint64(), C.c_uint64()
+        lib().orc_unitig_annotations(self.h, u, None, None, 0, C.byref(na), None, 0, C.byref(nc))
+        pos = (C.c_uint32 * max(1, na.value))()
+        code = C.create_string_buffer(max(1, na.value))
+        cyc = C.create_string_buffer(max(1, nc.value))
+        lib().orc_unitig_annotations(self.h, u, pos, code, na.value, C.byref(na), cyc, nc.value, C.byref(nc))
+        amb = [(pos[i], code.raw[i:i + 1].decode()) for i in range(na.value)]
+        raw = cyc.raw[:nc.value]
+        cycles = [c.decode() for c in raw.split(b"\0")[:-1]] if nc.value else []
+        return amb, cycles
 
     def fix_snps(self, seq):
         """fixSNPs() of one read (src/Alignment.cpp:846-965)."""
