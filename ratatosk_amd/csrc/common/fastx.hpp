@@ -3,7 +3,10 @@
 // Record conventions follow what the reference expects from Bifrost's FileParser
 // (reference: src/Ratatosk.cpp:658,767 — name = header up to the first whitespace, quality only for
 // FASTQ) and what it writes (src/Ratatosk.cpp:510-520 — "@name\nseq\n+\nqual\n").
-// Multi-line FASTA is supported; FASTQ is the 4-line form.
+// Multi-line FASTA is supported. FASTQ follows kseq (what Bifrost's FileParser reads with): sequence lines up to the line that
+// starts with '+', then quality lines until the quality is as long as the sequence. The byte-range reader (PlainChunks) only takes the
+// 4-line form: a file whose first record is laid out differently goes through the one-thread reader (is_plain() says no), and a
+// record that is not 4-line deeper inside a file makes parse_chunk() fail instead of being misread.
 #ifndef RTK_COMMON_FASTX_HPP
 #define RTK_COMMON_FASTX_HPP
 
@@ -44,15 +47,16 @@ inline void packed_buffer_give(std::vector<char>& v) {
 
 class PackedReads {
 public:
-    explicit PackedReads(bool keep_qual = false) : keep_qual_(keep_qual), n_bases_(0) {}
+    explicit PackedReads(bool keep_qual = false) : keep_qual_(keep_qual), n_bases_(0), malformed_(false) {}
     ~PackedReads() { packed_buffer_give(buf_); }
     PackedReads(const PackedReads&) = delete; PackedReads& operator=(const PackedReads&) = delete;
-    PackedReads(PackedReads&& o) : buf_(std::move(o.buf_)), rec_(std::move(o.rec_)), keep_qual_(o.keep_qual_), n_bases_(o.n_bases_) {}
-    PackedReads& operator=(PackedReads&& o) { packed_buffer_give(buf_); buf_ = std::move(o.buf_); rec_ = std::move(o.rec_); keep_qual_ = o.keep_qual_; n_bases_ = o.n_bases_; return *this; }
+    PackedReads(PackedReads&& o) : buf_(std::move(o.buf_)), rec_(std::move(o.rec_)), keep_qual_(o.keep_qual_), n_bases_(o.n_bases_), malformed_(o.malformed_) {}
+    PackedReads& operator=(PackedReads&& o) { packed_buffer_give(buf_); buf_ = std::move(o.buf_); rec_ = std::move(o.rec_); keep_qual_ = o.keep_qual_; n_bases_ = o.n_bases_; malformed_ = o.malformed_; return *this; }
     void reserve(size_t bytes) { buf_.reserve(bytes); }
     size_t size() const { return rec_.size(); }
     size_t n_bases() const { return n_bases_; }
     bool keeps_qual() const { return keep_qual_; }
+    bool malformed() const { return malformed_; } // set by PlainChunks::parse_chunk: a FASTQ record that is not on four lines
     const char* name(size_t i) const { return buf_.data() + rec_[i].name_off; }
     uint32_t name_len(size_t i) const { return rec_[i].name_len; }
     const char* seq(size_t i) const { return buf_.data() + rec_[i].seq_off; }
@@ -66,6 +70,7 @@ private:
     std::vector<Rec> rec_;
     bool keep_qual_;
     size_t n_bases_;
+    bool malformed_; // the byte-range parser met a FASTQ record that is not on four lines
 };
 
 class FastxReader {
@@ -97,10 +102,14 @@ public:
         size_t e = 1;
         while (e < line.size() && !isspace(static_cast<unsigned char>(line[e]))) ++e;
         name.assign(line, 1, e - 1);
-        if (fastq) {
-            if (!getline(seq)) return false;
-            if (!getline(line)) return false; // '+'
-            if (!getline(qual)) return false;
+        if (fastq) { // kseq: sequence lines up to a line that starts with '+' (or with the next header: a record without quality)
+            while (true) {
+                if (!getline(line)) return true;
+                if (!line.empty() && line[0] == '+') break;
+                if (!line.empty() && (line[0] == '>' || line[0] == '@')) { peek_ = line; has_peek_ = true; return true; }
+                seq += line;
+            }
+            do { if (!getline(line)) break; qual += line; } while (qual.size() < seq.size()); // at least one quality line, more while it is short
             return true;
         }
         // FASTA: concatenate lines until next header
@@ -129,15 +138,19 @@ public:
         PackedReads::Rec r; r.name_off = h0; r.name_len = static_cast<uint32_t>(e - (h0 + 1)); r.has_qual = false; r.qual_off = 0;
         b.resize(h0 + r.name_len);
         r.seq_off = b.size();
-        if (fastq) {
-            if (!getline_append(b)) { b.resize(h0); return false; }
+        if (fastq) { // kseq: sequence lines up to the '+' line, then quality lines until the quality is as long as the sequence
+            bool plus = false;
+            while (true) {
+                const size_t p0 = b.size();
+                if (!getline_append(b)) break;
+                if (b.size() > p0 && b[p0] == '+') { b.resize(p0); plus = true; break; }
+                if (b.size() > p0 && (b[p0] == '>' || b[p0] == '@')) { peek_.assign(&b[p0], b.size() - p0); has_peek_ = true; b.resize(p0); break; }
+            }
             r.seq_len = static_cast<uint32_t>(b.size() - r.seq_off);
             const size_t p0 = b.size();
-            if (!getline_append(b)) { b.resize(h0); return false; } // '+'
-            b.resize(p0);
-            if (!getline_append(b)) { b.resize(h0); return false; }
+            if (plus) { do { if (!getline_append(b)) break; } while (b.size() - p0 < r.seq_len); }
             r.qual_off = p0;
-            if (out.keep_qual_ && b.size() - p0 == r.seq_len) r.has_qual = true; else b.resize(p0);
+            if (plus && out.keep_qual_ && b.size() - p0 == r.seq_len) r.has_qual = true; else b.resize(p0);
         } else {
             while (true) {
                 const size_t p0 = b.size();
@@ -218,9 +231,20 @@ public:
     static bool is_plain(const std::string& fn) {
         FILE* f = fopen(fn.c_str(), "rb"); if (!f) return false;
         unsigned char m[18]; memset(m, 0, sizeof(m)); const size_t n = fread(m, 1, sizeof(m), f); fclose(f);
-        if (n >= 1 && (m[0] == '@' || m[0] == '>')) return true;
+        if (n >= 1 && m[0] == '>') return true;
+        if (n >= 1 && m[0] == '@') { std::vector<char> h(4u << 20); FILE* g = fopen(fn.c_str(), "rb"); if (!g) return false; h.resize(fread(h.data(), 1, h.size(), g)); fclose(g); return four_line_fastq(h.data(), h.size()); }
         if (!BgzfFile::looks_like(m, n)) return false;
-        BgzfFile z; return z.open(fn); // every block checked (a file that merely starts with a BGZF block is streamed)
+        BgzfFile z; if (!z.open(fn)) return false; // every block checked (a file that merely starts with a BGZF block is streamed)
+        std::vector<char> h(static_cast<size_t>(z.size() < (4u << 20) ? z.size() : (4u << 20)));
+        if (h.empty() || !z.read(0, h.size(), h.data())) return false;
+        return h[0] == '>' || (h[0] == '@' && four_line_fastq(h.data(), h.size()));
+    }
+    // is the first record of a FASTQ file laid out on four lines (header, sequence, '+', quality)? Judged from the head of the file; a first
+    // record longer than that head is taken to be (one line of megabases is the 4-line form)
+    static bool four_line_fastq(const char* b, size_t n) {
+        const char* l1 = static_cast<const char*>(memchr(b, '\n', n)); if (!l1) return true;
+        const char* l2 = static_cast<const char*>(memchr(l1 + 1, '\n', n - static_cast<size_t>(l1 + 1 - b))); if (!l2 || static_cast<size_t>(l2 + 1 - b) >= n) return true;
+        return l2[1] == '+';
     }
     bool open(const std::string& fn, size_t chunk_bytes) {
         close();
@@ -257,7 +281,7 @@ public:
         if (hi < size_ && !locate(hi, &end)) return false;
         if (out.rec_.empty() && out.buf_.empty()) { out.buf_.swap(buf); parse_in_place(out, start - base, end - base); }
         else { parse_in_place_from(buf, start - base, end - base, out); packed_buffer_give(buf); }
-        return true;
+        return !out.malformed_;
     }
 private:
     bool fill(std::vector<char>& buf, size_t base, size_t upto) const { // buf = file[base, min(upto, size))
@@ -279,13 +303,12 @@ private:
         while (true) {
             if (p >= n) return base + n >= size_ ? size_ : static_cast<size_t>(-1);
             if (!fastq_) { if (b[p] == '>') return base + p; }
-            else if (b[p] == '@') {
+            else if (b[p] == '@') { // a header when the line two below starts with '+'; a '@' line with fewer than two lines below it before the
+                // end of the FILE is the quality line of the last record (taking it for a header cut that record's quality off and lost the read)
                 const char* l1 = static_cast<const char*>(memchr(b + p, '\n', n - p));
-                if (!l1) return base + n >= size_ ? base + p : static_cast<size_t>(-1);
-                const char* l2 = static_cast<const char*>(memchr(l1 + 1, '\n', n - static_cast<size_t>(l1 + 1 - b)));
-                if (!l2) return base + n >= size_ ? base + p : static_cast<size_t>(-1);
-                if (static_cast<size_t>(l2 + 1 - b) >= n) { if (base + n >= size_) return base + p; return static_cast<size_t>(-1); }
-                if (l2[1] == '+') return base + p;
+                const char* l2 = l1 ? static_cast<const char*>(memchr(l1 + 1, '\n', n - static_cast<size_t>(l1 + 1 - b))) : nullptr;
+                if (l2 && static_cast<size_t>(l2 + 1 - b) < n) { if (l2[1] == '+') return base + p; }
+                else if (base + n < size_) return static_cast<size_t>(-1); // the buffer ends before the answer is known
             }
             const char* q = static_cast<const char*>(memchr(b + p, '\n', n - p));
             if (!q) return base + n >= size_ ? size_ : static_cast<size_t>(-1);
@@ -315,7 +338,9 @@ private:
                 size_t s0, s1, q0, q1;
                 if (!line(s0, s1)) return;
                 r.seq_off = s0; r.seq_len = static_cast<uint32_t>(s1 - s0);
-                if (!line(q0, q1) || !line(q0, q1)) return; // '+' line, quality line
+                if (!line(q0, q1)) return; // '+' line
+                if (q1 == q0 || s[q0] != '+') { out.malformed_ = true; return; } // not the 4-line form: refused, not misread
+                if (!line(q0, q1)) return; // quality line
                 if (out.keep_qual_ && q1 - q0 == r.seq_len) { r.qual_off = q0; r.has_qual = true; }
                 have = line(ls, le);
             } else {
@@ -328,7 +353,7 @@ private:
     }
     // (a ticket that already holds records: the new ones are appended to its buffer)
     void parse_in_place_from(std::vector<char>& buf, size_t from, size_t to, PackedReads& out) const {
-        PackedReads tmp(out.keep_qual_); tmp.buf_.swap(buf); parse_in_place(tmp, from, to);
+        PackedReads tmp(out.keep_qual_); tmp.buf_.swap(buf); parse_in_place(tmp, from, to); if (tmp.malformed_) out.malformed_ = true;
         const size_t shift = out.buf_.size();
         out.buf_.insert(out.buf_.end(), tmp.buf_.begin(), tmp.buf_.begin() + to);
         for (size_t i = 0; i < tmp.rec_.size(); ++i) { PackedReads::Rec r = tmp.rec_[i]; r.name_off += shift; r.seq_off += shift; r.qual_off += shift; out.rec_.push_back(r); out.n_bases_ += r.seq_len; }

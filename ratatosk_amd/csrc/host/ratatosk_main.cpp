@@ -289,7 +289,7 @@ int main(int argc, char** argv) {
             const long long tp0 = now_us();
             size_t f = pcs.size() - 1; while (pc_first[f] > id) --f;
             std::unique_ptr<Ticket> t(new Ticket(lrc)); t->id = id;
-            if (!pcs[f]->parse_chunk(id - pc_first[f], t->reads)) { fail("Ratatosk::search(): read error on " + files[f]); break; }
+            if (!pcs[f]->parse_chunk(id - pc_first[f], t->reads)) { fail(t->reads.malformed() ? "Ratatosk::search(): " + files[f] + " starts as 4-line FASTQ but holds a record laid out differently (multi-line?): the byte-range reader refuses it; RTK_SERIAL_READER=1 reads such a file on one thread" : "Ratatosk::search(): read error on " + files[f]); break; }
             us_parse += now_us() - tp0;
             n_bases += static_cast<long long>(t->reads.n_bases());
             if (opt.verbose) { const long long a = n_reads.fetch_add(static_cast<long long>(t->reads.size())), b2 = a + static_cast<long long>(t->reads.size()); if (a / 1000 != b2 / 1000) printf("Ratatosk::correct(): Processed %lld reads \n", b2 / 1000 * 1000); }

@@ -1,0 +1,159 @@
+"""Input layouts of the long-read files (`-l`, `-L`): the reference reads them with Bifrost's FileParser = kseq (src/Ratatosk.cpp:658,767):
+FASTA or FASTQ, sequence and quality on any number of lines, name = header up to the first whitespace, CR LF tolerated, gzip transparent.
+The host driver has two readers (byte ranges on `-c` threads for plain / blocked-gzip files on four lines; one thread for the rest); every
+layout of the same reads must give the same output file, and a layout the byte-range reader cannot take must be refused, not misread.
+CPU tier: the C++ driver linked against the simulator."""
+import gzip
+import hashlib
+import os
+import random
+import subprocess
+
+import pytest
+
+from conftest import BIN, ROOT, make_dataset
+from oracle import oracle_py as op
+
+SIM = os.path.join(ROOT, "tests", "hostsim", "Ratatosk_sim")
+
+
+def _wrap(s, w):
+    return "\n".join(s[i:i + w] for i in range(0, len(s), w)) if s else ""
+
+
+@pytest.fixture(scope="module")
+def ds(tmp_path_factory):
+    return make_dataset(tmp_path_factory.mktemp("ds_layouts"), "lay", ["--seed", 3, "--ref-len", 20000, "--sr-cov", 30, "--sr-err", 0.003, "--lr-n", 8, "--lr-len", 1500,
+                                                                       "--lr-profile", "ont", "--lr-err", 0.08])
+
+
+def _run(ds, reads, out, env=None, extra=()):
+    e = dict(os.environ, RTK_SIM_DEVICES="1")
+    e.update(env or {})
+    return subprocess.run([SIM, "correct", "-1", "-c", "3", "-B", "4000", "-g", ds + ".index.k31.fasta.gz", "-d", ds + ".index.k31.rtsk", "-l", reads, "-o", out] + list(extra),
+                          capture_output=True, text=True, env=e)
+
+
+def _sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def test_every_layout_of_the_same_reads_gives_the_same_file(ds, tmp_path):
+    recs = op.read_fastq(ds + ".lr.fq")
+    r = _run(ds, ds + ".lr.fq", str(tmp_path / "base"))
+    assert r.returncode == 0, r.stderr
+    want = _sha(str(tmp_path / "base.2.fastq"))
+    # ... which is what the oracle says
+    og = op.Graph(ds + ".index.k31.fasta.gz", ds + ".index.k31.rtsk", 31)
+    out, _ = og.correct_batch([x[1] for x in recs], [x[2] for x in recs], threads=4)
+    assert [(g[1], g[2]) for g in op.read_fastq(str(tmp_path / "base.2.fastq"))] == out
+    rng = random.Random(5)
+    nasty = ["".join(rng.choice("@+>I5") for _ in x[1]) for x in recs]  # quality lines that begin like headers and separators
+    layouts = {
+        "crlf.fq": "".join("@%s\r\n%s\r\n+\r\n%s\r\n" % x for x in recs),
+        "multi.fa": "".join(">%s\n%s\n" % (x[0], _wrap(x[1], 70)) for x in recs),
+        "one_line.fa": "".join(">%s some comment\n%s\n" % (x[0], x[1]) for x in recs),
+        "comment.fq": "".join("@%s comment\tx=1\n%s\n+%s comment\n%s\n" % (x[0], x[1], x[0], x[2]) for x in recs),
+        "multi.fq": "".join("@%s\n%s\n+\n%s\n" % (x[0], _wrap(x[1], 61), _wrap(q, 61)) for x, q in zip(recs, nasty)),
+        "nasty4.fq": "".join("@%s\n%s\n+\n%s\n" % (x[0], x[1], q) for x, q in zip(recs, nasty)),
+        "blank_lines.fq": "".join("@%s\n%s\n+\n%s\n\n" % x for x in recs),
+        "no_final_newline.fq": "".join("@%s\n%s\n+\n%s\n" % x for x in recs)[:-1],
+        "lower.fq": "".join("@%s\n%s\n+\n%s\n" % (x[0], x[1].lower(), x[2]) for x in recs),
+    }
+    for name, text in layouts.items():
+        p = str(tmp_path / name)
+        open(p, "w", newline="").write(text)
+        for env in ({}, {"RTK_SERIAL_READER": "1"}):
+            r = _run(ds, p, str(tmp_path / "o"), env)
+            assert r.returncode == 0, (name, r.stderr)
+            assert _sha(str(tmp_path / "o.2.fastq")) == want, (name, env)
+    # compressed: an ordinary gzip stream (one-thread reader) and blocked gzip (byte ranges), four lines and several
+    for name in ("multi.fq", "nasty4.fq", "multi.fa"):
+        p = str(tmp_path / name)
+        with gzip.open(p + ".gz", "wb") as f:
+            f.write(open(p, "rb").read())
+        subprocess.check_call([os.path.join(BIN, "rtk_bgzip"), p, p + ".bgz.gz"])
+        for q in (p + ".gz", p + ".bgz.gz"):
+            r = _run(ds, q, str(tmp_path / "o"))
+            assert r.returncode == 0, (q, r.stderr)
+            assert _sha(str(tmp_path / "o.2.fastq")) == want, q
+
+
+def test_a_layout_the_range_reader_cannot_take_is_refused_not_misread(ds, tmp_path):
+    recs = op.read_fastq(ds + ".lr.fq")
+    r = _run(ds, ds + ".lr.fq", str(tmp_path / "base"))
+    want = _sha(str(tmp_path / "base.2.fastq"))
+    # four lines first, several lines further down: the sniff at the head of the file cannot see it
+    p = str(tmp_path / "mixed.fq")
+    open(p, "w").write("@%s\n%s\n+\n%s\n" % recs[0] + "".join("@%s\n%s\n+\n%s\n" % (x[0], _wrap(x[1], 80), _wrap(x[2], 80)) for x in recs[1:]))
+    r = _run(ds, p, str(tmp_path / "bad"))
+    assert r.returncode != 0 and "laid out differently" in r.stderr and not os.path.exists(str(tmp_path / "bad.2.fastq"))
+    r = _run(ds, p, str(tmp_path / "ok"), {"RTK_SERIAL_READER": "1"})
+    assert r.returncode == 0 and _sha(str(tmp_path / "ok.2.fastq")) == want
+    # no reads at all
+    open(str(tmp_path / "empty.fq"), "w").close()
+    r = _run(ds, str(tmp_path / "empty.fq"), str(tmp_path / "e"))
+    assert r.returncode == 0 and os.path.getsize(str(tmp_path / "e.2.fastq")) == 0
+    # an empty read and a read shorter than k between ordinary ones: kept, in place (src/Ratatosk.cpp:808-864 corrects what it is given)
+    p = str(tmp_path / "short.fq")
+    open(p, "w").write("@%s\n%s\n+\n%s\n" % recs[0] + "@empty\n\n+\n\n@short\nACGTACGT\n+\nIIIIIIII\n" + "@%s\n%s\n+\n%s\n" % recs[1])
+    r = _run(ds, p, str(tmp_path / "s"))
+    assert r.returncode == 0, r.stderr
+    got = op.read_fastq(str(tmp_path / "s.2.fastq"))
+    assert [g[0] for g in got] == [recs[0][0], "empty", "short", recs[1][0]] and got[1][1] == "" and got[2][1] == "ACGTACGT"
+
+
+def test_second_pass_reads_qualities_on_several_lines(ds, tmp_path):
+    """`-2` carries the input qualities (src/Correction.cpp:779,808,941): the pass-1 file and the uncorrected file re-written on several
+    lines (and the uncorrected one as FASTA) must give the output of the four-line files."""
+    recs = op.read_fastq(ds + ".lr.fq")
+    og = op.Graph(ds + ".index.k31.fasta.gz", ds + ".index.k31.rtsk", 31)
+    out, _ = og.correct_batch([x[1] for x in recs], [x[2] for x in recs], threads=4)
+    p1 = str(tmp_path / "pass1.fq")
+    open(p1, "w").write("".join("@%s\n%s\n+\n%s\n" % (x[0], s, q) for x, (s, q) in zip(recs, out)))
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", ds + ".sr.fq", "--colour-reads", p1, "-o", str(tmp_path / "p2")], stderr=subprocess.DEVNULL)
+    p1m, rawm, rawfa = str(tmp_path / "pass1_multi.fq"), str(tmp_path / "raw_multi.fq"), str(tmp_path / "raw.fa")
+    open(p1m, "w").write("".join("@%s\n%s\n+\n%s\n" % (x[0], _wrap(s, 53), _wrap(q, 53)) for x, (s, q) in zip(recs, out)))
+    open(rawm, "w").write("".join("@%s\n%s\n+\n%s\n" % (x[0], _wrap(x[1], 77), _wrap(x[2], 77)) for x in recs))
+    open(rawfa, "w").write("".join(">%s\n%s\n" % (x[0], _wrap(x[1], 60)) for x in recs))
+    env = dict(os.environ, RTK_SIM_DEVICES="1")
+    shas = []
+    for l, L in ((p1, ds + ".lr.fq"), (p1m, rawm), (p1m, rawfa), (p1, rawfa)):
+        o = str(tmp_path / "o2")
+        r = subprocess.run([SIM, "correct", "-2", "-K", "31", "-c", "2", "-B", "5000", "-g", str(tmp_path / "p2.index.k31.fasta.gz"), "-d", str(tmp_path / "p2.index.k31.rtsk"),
+                            "-l", l, "-L", L, "-o", o], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        shas.append(_sha(o + ".fastq"))
+    assert len(set(shas)) == 1
+    want = og2 = op.Graph(str(tmp_path / "p2.index.k31.fasta.gz"), str(tmp_path / "p2.index.k31.rtsk"), 31)
+    exp = og2.correct_batch2([s for s, _ in out], [q for _, q in out], [x[1] for x in recs], og2.opts(long_read_correct=1), threads=4)
+    assert [(g[1], g[2]) for g in op.read_fastq(str(tmp_path / "o2.fastq"))] == exp
+
+
+def test_range_reader_against_the_one_thread_reader_on_random_files(ds, tmp_path):
+    """Random 4-line FASTQ files of reads shorter than k (nothing to correct: the output is the parse), quality lines full of '@', '+' and
+    '>' — first characters included, the LAST record's too: the file end is where the record-start rule (a '@' line with a '+' line two
+    below) has the fewest lines to look at. Byte ranges of 256 bytes to a few KB against the one-thread reader."""
+    rng = random.Random(99)
+    for it in range(24):
+        n = rng.randint(1, 40)
+        recs = []
+        for i in range(n):
+            L = rng.choice([0, 1, 2, 5, 12, 25, 30]) if rng.random() < 0.7 else rng.randint(0, 30)
+            recs.append(("r%d_%d" % (it, i), "".join(rng.choice("ACGT") for _ in range(L)), "".join(rng.choice("@+>@+I") for _ in range(L))))
+        text = "".join("@%s\n%s\n+\n%s\n" % x for x in recs)
+        if it % 3 == 1:
+            text = text[:-1]  # no newline at the end
+        if it % 3 == 2:
+            text = text.replace("\n", "\r\n")
+        p = str(tmp_path / ("f%d.fq" % it))
+        open(p, "w", newline="").write(text)
+        outs = []
+        for env, B in (({"RTK_SERIAL_READER": "1"}, 1 << 20), ({}, 1), ({}, rng.randint(300, 3000)), ({}, 1 << 20)):
+            r = _run(ds, p, str(tmp_path / "o"), env, ["-B", str(B)])
+            assert r.returncode == 0, r.stderr
+            outs.append(open(str(tmp_path / "o.2.fastq")).read())
+        got = [l for l in outs[0].split("\n")]
+        assert [got[i][1:] for i in range(0, len(got) - 1, 4)] == [x[0] for x in recs], it
+        assert [got[i] for i in range(1, len(got) - 1, 4)] == [x[1] for x in recs], it
+        assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0], it
