@@ -148,6 +148,9 @@ int main(int argc, char** argv) {
             default: usage(); return 0; // the reference returns 0 on option errors too (src/Ratatosk.cpp:1018)
         }
     }
+    // the reference drops arguments that belong to no option without a word (getopt_long permutes them to the end, src/Ratatosk.cpp:186-300):
+    // `-l a.fq b.fq` corrects a.fq only. Same here, but said aloud.
+    for (int i = optind; i < argc - 1; ++i) fprintf(stderr, "Ratatosk::correct: argument '%s' belongs to no option and is ignored (several input files: one -l each, or a text file of paths)\n", argv[1 + i]);
     if (opt.pass1 == opt.pass2) { fprintf(stderr, "Ratatosk::correct: one pass per run with a pre-built index (-g, -d): give -1 or -2\n"); return 1; }
     const bool lrc = opt.pass2;
     if (lrc && opt.in_long_raw.empty()) { fprintf(stderr, "Ratatosk::correct: -2 needs the uncorrected long reads (-L) next to the pass-1 reads (-l)\n"); return 0; }

@@ -157,3 +157,27 @@ def test_range_reader_against_the_one_thread_reader_on_random_files(ds, tmp_path
         assert [got[i][1:] for i in range(0, len(got) - 1, 4)] == [x[0] for x in recs], it
         assert [got[i] for i in range(1, len(got) - 1, 4)] == [x[1] for x in recs], it
         assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0], it
+
+
+def test_several_input_files_and_arguments_that_belong_to_no_option(ds, tmp_path):
+    """Several `-l`, a text file of paths (src/Common.cpp:412-446), FASTQ + FASTA + gzip mixed: the reads in the order of the files.
+    `-l a b` corrects `a` only, like the reference's getopt_long loop (src/Ratatosk.cpp:186-300) — but says so."""
+    recs = op.read_fastq(ds + ".lr.fq")
+    a, b, c = str(tmp_path / "a.fq"), str(tmp_path / "b.fa"), str(tmp_path / "c.fq.gz")
+    open(a, "w").write("".join("@%s\n%s\n+\n%s\n" % x for x in recs[:3]))
+    open(b, "w").write("".join(">%s\n%s\n" % (x[0], x[1]) for x in recs[3:5]))
+    with gzip.open(c, "wt") as f:
+        f.write("".join("@%s\n%s\n+\n%s\n" % x for x in recs[5:]))
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("%s\n%s\n%s\n" % (a, b, c))
+    r = _run(ds, ds + ".lr.fq", str(tmp_path / "base"))
+    want = _sha(str(tmp_path / "base.2.fastq"))
+    r = _run(ds, lst, str(tmp_path / "o1"))
+    assert r.returncode == 0 and _sha(str(tmp_path / "o1.2.fastq")) == want, r.stderr
+    r = _run(ds, a, str(tmp_path / "o2"), extra=["-l", b, "-l", c])
+    assert r.returncode == 0 and _sha(str(tmp_path / "o2.2.fastq")) == want, r.stderr
+    r = _run(ds, a, str(tmp_path / "o3"), extra=[b, c])
+    assert r.returncode == 0 and r.stderr.count("belongs to no option") == 2
+    assert [g[0] for g in op.read_fastq(str(tmp_path / "o3.2.fastq"))] == [x[0] for x in recs[:3]]
+    r = _run(ds, str(tmp_path / "missing.fq"), str(tmp_path / "o4"))
+    assert r.returncode == 1 and "cannot open" in r.stderr
