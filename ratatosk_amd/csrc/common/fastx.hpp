@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "bgzf.hpp"
+#include "mgzip.hpp"
 
 namespace rtk {
 
@@ -75,19 +76,24 @@ private:
 
 class FastxReader {
 public:
-    FastxReader() : fp_(nullptr), pos_(0), end_(0), eof_(false), has_peek_(false) {}
+    FastxReader() : fp_(nullptr), failed_(false), pos_(0), end_(0), eof_(false), has_peek_(false) {}
     ~FastxReader() { close(); }
 
-    bool open(const std::string& fn) {
+    // inflate_threads > 1: a gzip file is inflated member by member on that many threads (mgzip.hpp: a file of several gzip members, the usual
+    // `cat *.fastq.gz`, scales with them; a single member streams as before)
+    bool open(const std::string& fn, int inflate_threads = 1) {
         close();
+        pos_ = end_ = 0; eof_ = false; has_peek_ = false; failed_ = false;
+        if (inflate_threads > 1 && MemberGzipReader::looks_like_gzip(fn)) { mg_.reset(new MemberGzipReader()); if (mg_->open(fn, inflate_threads)) return true; mg_.reset(); }
         fp_ = gzopen(fn.c_str(), "rb"); // zlib reads plain files transparently
         if (!fp_) return false;
         gzbuffer(fp_, 1 << 20);
-        pos_ = end_ = 0; eof_ = false; has_peek_ = false;
         return true;
     }
 
-    void close() { if (fp_) { gzclose(fp_); fp_ = nullptr; } }
+    void close() { if (fp_) { gzclose(fp_); fp_ = nullptr; } mg_.reset(); }
+    // the input ended on a damaged or cut-short gzip stream (what was read before it has been delivered): callers must not take that for the end of the file
+    bool failed() const { return failed_; }
 
     // Reads next record. qual is cleared for FASTA records.
     bool next(std::string& name, std::string& seq, std::string& qual) {
@@ -171,7 +177,7 @@ private:
         while (true) {
             if (pos_ == end_) {
                 if (eof_) break;
-                const int n = gzread(fp_, buf_, sizeof(buf_));
+                const long n = fill_();
                 if (n <= 0) { eof_ = true; break; }
                 pos_ = 0; end_ = static_cast<size_t>(n);
             }
@@ -192,7 +198,7 @@ private:
         while (true) {
             if (pos_ == end_) {
                 if (eof_) break;
-                const int n = gzread(fp_, buf_, sizeof(buf_));
+                const long n = fill_();
                 if (n <= 0) { eof_ = true; break; }
                 pos_ = 0; end_ = static_cast<size_t>(n);
             }
@@ -210,7 +216,15 @@ private:
         return got;
     }
 
+    long fill_() { // next bytes of the text into buf_
+        if (mg_) { const long n = mg_->read(buf_, sizeof(buf_)); if (n < 0 || mg_->failed()) failed_ = true; return n; }
+        const int n = gzread(fp_, buf_, sizeof(buf_));
+        if (n < static_cast<int>(sizeof(buf_))) { int e = Z_OK; gzerror(fp_, &e); if (n < 0 || (e != Z_OK && e != Z_STREAM_END)) failed_ = true; } // (unexpected end of file: Z_BUF_ERROR)
+        return n;
+    }
     gzFile fp_;
+    std::unique_ptr<MemberGzipReader> mg_;
+    bool failed_;
     char buf_[1 << 18];
     size_t pos_, end_;
     bool eof_;

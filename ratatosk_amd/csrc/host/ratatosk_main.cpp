@@ -178,7 +178,7 @@ int main(int argc, char** argv) {
                 for (int t = 0; t < opt.cores; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= pc.n_chunks()) break; rtk::PackedReads r(false); if (!pc.parse_chunk(i, r)) break; bases += r.n_bases(); reads += r.size(); } });
                 for (size_t t = 0; t < th.size(); ++t) th[t].join();
                 bytes += pc.file_bytes();
-            } else { rtk::FastxReader rd; if (!rd.open(fl[f])) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; } rtk::PackedReads r(false); while (rd.next_packed(r)) { if (r.n_bases() > opt.batch_bases) { bases += r.n_bases(); reads += r.size(); rtk::PackedReads fresh(false); r = std::move(fresh); } } bases += r.n_bases(); reads += r.size(); }
+            } else { rtk::FastxReader rd; if (!rd.open(fl[f], std::max(1, std::min(opt.cores, 16)))) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; } rtk::PackedReads r(false); while (rd.next_packed(r)) { if (r.n_bases() > opt.batch_bases) { bases += r.n_bases(); reads += r.size(); rtk::PackedReads fresh(false); r = std::move(fresh); } } bases += r.n_bases(); reads += r.size(); }
         }
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("Ratatosk::parse-only: %zu file(s) (%d plain or blocked gzip, read as byte ranges by %d threads), %llu reads, %llu bases, %.3f s: %.3g bases/s, %.2f GB/s of FASTA/FASTQ text\n", fl.size(), n_plain, opt.cores,
@@ -316,13 +316,14 @@ int main(int argc, char** argv) {
     std::thread reader_thread([&]() {
         if (par_read) return;
         rtk::FastxReader reader; size_t file_i = 0; bool file_open = false, eof_all = false; size_t ticket = 0;
+        const int inflate_threads = std::max(1, std::min(lrc ? opt.cores / 2 : opt.cores, 16)); // gzip input of several members is inflated on these (common/mgzip.hpp)
         while (!eof_all && !failed) {
             const long long tp0 = now_us();
             std::unique_ptr<Ticket> t(new Ticket(lrc)); t->id = ticket;
             t->reads.reserve(opt.batch_bases + (opt.batch_bases >> 3));
             while (t->reads.n_bases() < opt.batch_bases) {
-                if (!file_open) { if (file_i >= files.size()) { eof_all = true; break; } if (!reader.open(files[file_i++])) { fail("Ratatosk::search(): cannot open input file " + files[file_i - 1]); return; } file_open = true; }
-                if (!reader.next_packed(t->reads)) { file_open = false; continue; }
+                if (!file_open) { if (file_i >= files.size()) { eof_all = true; break; } if (!reader.open(files[file_i++], inflate_threads)) { fail("Ratatosk::search(): cannot open input file " + files[file_i - 1]); return; } file_open = true; }
+                if (!reader.next_packed(t->reads)) { if (reader.failed()) { fail("Ratatosk::search(): " + files[file_i - 1] + " ends in a damaged or cut-short gzip stream"); return; } file_open = false; continue; }
                 if (opt.verbose && ((n_reads.fetch_add(1) + 1) % 1000 == 0)) printf("Ratatosk::correct(): Processed %lld reads \n", n_reads.load());
             }
             us_parse += now_us() - tp0;
@@ -362,8 +363,8 @@ int main(int argc, char** argv) {
             const long long tp0 = now_us();
             t->raw.reserve(t->reads.n_bases() + (t->reads.n_bases() >> 3));
             while (t->raw.size() < t->reads.size()) { // the uncorrected reads in lock-step (src/Ratatosk.cpp:774-802)
-                if (!file_raw_open) { if (file_raw_i >= files_raw.size()) break; if (!reader_raw.open(files_raw[file_raw_i++])) { fail("Ratatosk::search(): cannot open input file " + files_raw[file_raw_i - 1]); return; } file_raw_open = true; }
-                if (!reader_raw.next_packed(t->raw)) { file_raw_open = false; continue; }
+                if (!file_raw_open) { if (file_raw_i >= files_raw.size()) break; if (!reader_raw.open(files_raw[file_raw_i++], std::max(1, std::min(opt.cores / 2, 16)))) { fail("Ratatosk::search(): cannot open input file " + files_raw[file_raw_i - 1]); return; } file_raw_open = true; }
+                if (!reader_raw.next_packed(t->raw)) { if (reader_raw.failed()) { fail("Ratatosk::search(): " + files_raw[file_raw_i - 1] + " ends in a damaged or cut-short gzip stream"); return; } file_raw_open = false; continue; }
             }
             if (t->raw.size() != t->reads.size()) { fail(out_of_step); return; }
             for (size_t i = 0; i < t->reads.size(); ++i) { // names are compared from their second character on, like the reference (:794)

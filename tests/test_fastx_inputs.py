@@ -181,3 +181,43 @@ def test_several_input_files_and_arguments_that_belong_to_no_option(ds, tmp_path
     assert [g[0] for g in op.read_fastq(str(tmp_path / "o3.2.fastq"))] == [x[0] for x in recs[:3]]
     r = _run(ds, str(tmp_path / "missing.fq"), str(tmp_path / "o4"))
     assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+def test_gzip_of_several_members_inflated_on_several_threads(ds, tmp_path):
+    """`cat a.fq.gz b.fq.gz ...` (one gzip member per original file) is inflated member by member on the `-c` threads (common/mgzip.hpp): member
+    starts are found by their magic bytes and confirmed by walking the chain of member ends. Same output as the plain file, whatever the
+    members look like: empty ones, records that straddle two members, the magic bytes inside a member's own data (stored blocks, so that
+    they stand verbatim in the file), bytes behind the last member that are no member (zlib ignores them). A member that is cut short or
+    damaged is an error, not the end of the input."""
+    recs = op.read_fastq(ds + ".lr.fq")
+    r = _run(ds, ds + ".lr.fq", str(tmp_path / "base"))
+    want = _sha(str(tmp_path / "base.2.fastq"))
+    magic = "\x1f\x8b\x08\x00" * 40
+    text = "".join("@%s %s\n%s\n+\n%s\n" % (x[0], magic, x[1], x[2]) for x in recs).encode("latin-1")
+    cuts = [0, 1, len(text) // 5, len(text) // 5 + 1, len(text) // 2, len(text) - 7, len(text)]  # pieces of any size, cut anywhere
+    pieces = [text[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    blob = b"".join(gzip.compress(p, lvl) for p, lvl in zip(pieces, [6, 0, 0, 9, 0, 1])) + gzip.compress(b"")
+    assert blob.count(b"\x1f\x8b\x08\x00") > len(pieces) + 50  # false member starts inside the stored blocks
+    for name, data in (("members.fq.gz", blob), ("members_then_junk.fq.gz", blob + b"\x00\x00\x00junk")):
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        assert gzip.decompress(blob) == text
+        for cores in ("1", "2", "7"):
+            rr = subprocess.run([SIM, "correct", "-1", "-c", cores, "-B", "4000", "-g", ds + ".index.k31.fasta.gz", "-d", ds + ".index.k31.rtsk", "-l", p, "-o", str(tmp_path / "o")],
+                                capture_output=True, text=True, env=dict(os.environ, RTK_SIM_DEVICES="1"))
+            assert rr.returncode == 0, rr.stderr
+            assert _sha(str(tmp_path / "o.2.fastq")) == want, (name, cores)
+    # cut short inside the third member / one byte flipped in the fourth: refused by both readers
+    third = len(gzip.compress(pieces[0], 6)) + len(gzip.compress(pieces[1], 0)) + 1000
+    bad1 = str(tmp_path / "cut.fq.gz")
+    open(bad1, "wb").write(blob[:third])
+    flipped = bytearray(blob)
+    at = len(blob) - len(gzip.compress(b"")) - len(gzip.compress(pieces[5], 1)) - len(gzip.compress(pieces[4], 0)) - 200
+    flipped[at] ^= 0x55
+    bad2 = str(tmp_path / "flipped.fq.gz")
+    open(bad2, "wb").write(bytes(flipped))
+    for p in (bad1, bad2):
+        for cores in ("1", "4"):
+            rr = subprocess.run([SIM, "correct", "-1", "-c", cores, "-g", ds + ".index.k31.fasta.gz", "-d", ds + ".index.k31.rtsk", "-l", p, "-o", str(tmp_path / "bad")],
+                                capture_output=True, text=True, env=dict(os.environ, RTK_SIM_DEVICES="1"))
+            assert rr.returncode != 0 and "gzip" in rr.stderr, (p, cores, rr.stderr)
