@@ -88,9 +88,10 @@ template <class Sink>
 bool for_each_sequence_chunk(const std::vector<std::string>& files, int n_threads, uint64_t chunk_bytes, Sink sink, std::string* err) {
     for (size_t f = 0; f < files.size(); ++f) {
         if (!rtk::PlainChunks::is_plain(files[f])) { // gzip or unknown: one reader thread
-            rtk::FastxReader rd; if (!rd.open(files[f])) { *err = "cannot open " + files[f]; return false; }
+            rtk::FastxReader rd; if (!rd.open(files[f], n_threads < 16 ? n_threads : 16)) { *err = "cannot open " + files[f]; return false; } // (a gzip file of several members is inflated on the threads, common/mgzip.hpp)
             std::string name, seq, qual, buf; buf.reserve(chunk_bytes);
             while (rd.next(name, seq, qual)) { buf += seq; buf.push_back('\n'); if (buf.size() >= chunk_bytes) { sink(buf.data(), buf.size()); buf.clear(); } }
+            if (rd.failed()) { *err = files[f] + " ends in a damaged or cut-short gzip stream"; return false; }
             if (!buf.empty()) sink(buf.data(), buf.size());
             continue;
         }

@@ -74,6 +74,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             if (seq.size() < static_cast<size_t>(k)) throw std::runtime_error("unitig shorter than k in " + fasta_gz);
             seqs.push_back(seq);
         }
+        if (fr.failed()) throw std::runtime_error("graph file " + fasta_gz + " ends in a damaged or cut-short gzip stream");
     }
     lap("unitig FASTA read");
     const size_t n = seqs.size();

@@ -311,13 +311,14 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                         if (++valid >= k) { const KM c = kmer_canonical(fw, k); if ((hash_km(c) >> 40) % n_thr == t) ++*cnt.slot(c, true); }
                     }
                 }
+                if (fr.failed()) { bad[t] = 2; return; } // a damaged or cut-short gzip stream is not the end of the reads
             }
             for (size_t i = 0; i < cnt.keys.size(); ++i) if (cnt.keys[i] != EMPTY && cnt.vals[i] >= min_count) part[t].push_back(cnt.keys[i]);
         };
         std::vector<std::thread> th;
         for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(count_shard, t);
         for (size_t t = 0; t < th.size(); ++t) th[t].join();
-        for (unsigned t = 0; t < n_thr; ++t) if (bad[t]) { fprintf(stderr, "rtk_build_index: cannot open an input file\n"); return 1; }
+        for (unsigned t = 0; t < n_thr; ++t) if (bad[t]) { fprintf(stderr, bad[t] == 2 ? "rtk_build_index: an input file ends in a damaged or cut-short gzip stream\n" : "rtk_build_index: cannot open an input file\n"); return 1; }
         // ---- solid k-mers, sorted: unitig construction is independent of table layout ----
         for (unsigned t = 0; t < n_thr; ++t) { solid.insert(solid.end(), part[t].begin(), part[t].end()); std::vector<KM>().swap(part[t]); }
         std::sort(solid.begin(), solid.end());
@@ -495,7 +496,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             Chunk* cur = new Chunk();
             auto flush = [&]() { if (cur->seq.empty()) return; { std::unique_lock<std::mutex> lk(mq); cv_put.wait(lk, [&]() { return q.size() < 4u * n_thr; }); q.push_back(cur); } cv_get.notify_one(); cur = new Chunk(); };
             for (size_t f = 0; f < col_in.size() && !open_failed; ++f) {
-                FastxReader fr; if (!fr.open(col_in[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); open_failed = 1; break; }
+                FastxReader fr; if (!fr.open(col_in[f], fast ? static_cast<int>(n_thr < 8 ? n_thr : 8) : 1)) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); open_failed = 1; break; }
                 while (fr.next(name, seq, qual)) {
                     for (size_t x = 0; x < seq.size(); ++x) seq[x] = static_cast<char>(seq[x] & 0xDF);
                     if (name.size() > 2 && name[name.size() - 2] == '/' && (name[name.size() - 1] == '1' || name[name.size() - 1] == '2')) name.erase(name.size() - 2);
@@ -504,6 +505,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                     cur->bytes += seq.size(); cur->seq.push_back(std::string()); cur->seq.back().swap(seq); cur->id.push_back(pair_id);
                     if (cur->bytes >= (1u << 20)) flush();
                 }
+                if (fr.failed()) { fprintf(stderr, "rtk_build_index: %s ends in a damaged or cut-short gzip stream\n", col_in[f].c_str()); open_failed = 1; }
             }
             flush(); delete cur;
             { std::lock_guard<std::mutex> lk(mq); done = true; }

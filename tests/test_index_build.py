@@ -81,6 +81,39 @@ def test_fast_index_build_writes_the_same_files(tmp_path):
     assert n_plain and n_plain[0] >= 2, trace  # the loop and the hairpin went through the plain construction inside the fast path
 
 
+def test_index_from_gzip_input_of_several_members(tmp_path):
+    """Short reads (and the colour reads of a second-pass index) as ONE gzip stream and as a concatenation of gzip members (inflated member by
+    member on the tool's threads, common/mgzip.hpp): the files of the plain-text input; a cut-short gzip file is refused."""
+    import gzip
+    tmp = str(tmp_path)
+    sr = _simulated(tmp, "gz", SETS[0][1])
+    lr = os.path.join(tmp, "gz.lr.fq")
+    text, ltext = open(sr, "rb").read(), open(lr, "rb").read()
+    def members(t, n):
+        step = len(t) // n + 1
+        return b"".join(gzip.compress(t[i:i + step], 1) for i in range(0, len(t), step))
+    open(sr + ".one.gz", "wb").write(gzip.compress(text, 1))
+    open(sr + ".many.gz", "wb").write(members(text, 9))
+    open(lr + ".many.gz", "wb").write(members(ltext, 5))
+    def run(s_in, l_in, out, mode):
+        r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", s_in, "--colour-reads", l_in, "-o", out] + mode, capture_output=True, text=True)
+        return r, (open(out + ".index.k31.fasta.gz", "rb").read(), open(out + ".index.k31.rtsk", "rb").read()) if r.returncode == 0 else None
+    _, want = run(sr, lr, os.path.join(tmp, "plain"), [])
+    for s_in, l_in, mode in ((sr + ".one.gz", lr, []), (sr + ".many.gz", lr + ".many.gz", []), (sr + ".many.gz", lr + ".many.gz", ["--fast"]), (sr + ".one.gz", lr + ".many.gz", ["--fast"])):
+        r, got = run(s_in, l_in, os.path.join(tmp, "o"), mode)
+        assert r.returncode == 0, r.stderr
+        assert got == want, (s_in, l_in, mode)
+    cut = open(lr + ".many.gz", "rb").read()
+    open(lr + ".cut.gz", "wb").write(cut[:len(cut) * 2 // 3])
+    r, _ = run(sr, lr + ".cut.gz", os.path.join(tmp, "bad"), ["--fast"])
+    assert r.returncode != 0 and "gzip" in r.stderr
+    cut = open(sr + ".one.gz", "rb").read()
+    open(sr + ".cut.gz", "wb").write(cut[:len(cut) // 2])
+    for mode in ([], ["--fast"]):
+        r, _ = run(sr + ".cut.gz", lr, os.path.join(tmp, "bad2"), mode)
+        assert r.returncode != 0 and "gzip" in r.stderr, (mode, r.stderr)
+
+
 @pytest.mark.gpu
 def test_gpu_index_build_writes_the_same_files(tmp_path):
     """k-mers counted on the device: the files of three seeded sets (and the self-meeting genomes) are the plain tool's, byte for byte."""
