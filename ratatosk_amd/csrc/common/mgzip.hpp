@@ -32,6 +32,8 @@
 #include <thread>
 #include <vector>
 
+#include "finflate.hpp"
+
 namespace rtk {
 
 class MemberGzipReader {
@@ -97,7 +99,7 @@ public:
                 if (!cur_->chunks.empty()) {
                     Chunk& c = cur_->chunks.front();
                     const size_t n = std::min(want - got, c.n - cur_chunk_off_);
-                    memcpy(dst + got, c.p.get() + cur_chunk_off_, n); got += n; cur_chunk_off_ += n;
+                    memcpy(dst + got, c.p.get() + c.off + cur_chunk_off_, n); got += n; cur_chunk_off_ += n;
                     if (cur_chunk_off_ == c.n) { cur_->buffered -= c.n; spent.p.swap(c.p); cur_->chunks.pop_front(); cur_chunk_off_ = 0; cv_work_.notify_all(); } // (freed outside the lock)
                 } else if (cur_->done) { ended = true; bad = !cur_->ok; }
                 else return -1; // stopped
@@ -116,7 +118,7 @@ public:
     }
 
 private:
-    struct Chunk { std::unique_ptr<char[]> p; size_t n; Chunk() : n(0) {} }; // (no value initialisation of megabytes per member)
+    struct Chunk { std::unique_ptr<char[]> p; size_t n, off; Chunk() : n(0), off(0) {} }; // text = p[off, off + n) (no value initialisation of megabytes per member; the fast decoder keeps the 32 KB before the text in front of it)
     struct Task {
         size_t off, end, buffered, produced; bool done, ok, head, cancel;
         std::deque<Chunk> chunks;
@@ -158,7 +160,51 @@ private:
     }
     size_t ahead() const { size_t n = 0; for (std::map<size_t, std::shared_ptr<Task> >::const_iterator it = tasks_.begin(); it != tasks_.end(); ++it) n += it->second->done && !it->second->ok ? 0 : 1; return n; } // (failed candidates hold nothing)
 
+    // hands a finished chunk to the consumer; false when the task was cancelled or the reader is closing
+    bool deliver_(Task& t, Chunk& c) {
+        std::unique_lock<std::mutex> lk(m_);
+        t.chunks.emplace_back(); t.chunks.back().p.swap(c.p); t.chunks.back().n = c.n; t.chunks.back().off = c.off; t.buffered += c.n; t.produced += c.n;
+        cv_data_.notify_all();
+        cv_work_.wait(lk, [&]() { return stop_ || t.cancel || t.head || t.buffered < (128u << 20); }); // ahead of the head: bounded
+        if (stop_ || t.cancel) return false;
+        if (t.head) cv_work_.wait(lk, [&]() { return stop_ || t.buffered < (64u << 20); }); // the head: a few chunks in front of the consumer
+        return !stop_;
+    }
+    void finish_(Task& t, bool ok, size_t end) {
+        std::lock_guard<std::mutex> lk(m_);
+        t.ok = ok; t.end = end; t.done = true;
+        if (!ok) { t.chunks.clear(); t.buffered = 0; }
+        cv_data_.notify_all(); cv_work_.notify_all();
+    }
+    static bool use_zlib_() { static const bool z = []() { const char* e = getenv("RTK_ZLIB_INFLATE"); return e && e[0] == '1'; }(); return z; }
+
     void inflate_member(Task& t) {
+        if (use_zlib_()) { inflate_member_zlib(t); return; }
+        FastInflate fi; // (finflate.hpp: ~2x zlib on FASTQ text; CRC-32 and length of the member checked at its end)
+        bool ok = false; size_t end = t.off;
+        if (fi.begin(data_ + t.off, data_ + size_)) {
+            const size_t H = FastInflate::HIST;
+            std::unique_ptr<unsigned char[]> hist(new unsigned char[H]); size_t hn = 0; // the last bytes of the text so far, at the END of hist
+            size_t n_chunks = 0;
+            for (;;) {
+                const size_t CH = n_chunks == 0 ? (128u << 10) : (n_chunks == 1 ? (1u << 20) : (4u << 20)); ++n_chunks;
+                Chunk c; c.p.reset(new char[H + CH + FastInflate::SLACK]); c.off = H;
+                unsigned char* base = reinterpret_cast<unsigned char*>(c.p.get());
+                memcpy(base + H - hn, hist.get() + H - hn, hn);
+                const size_t n = fi.decode(base + H, CH, hn);
+                if (fi.failed()) break;
+                const size_t nn = hn + n < H ? hn + n : H;
+                memcpy(hist.get() + H - nn, base + H + n - nn, nn); hn = nn;
+                const bool last = fi.done();
+                if (n) { c.n = n; if (!deliver_(t, c)) break; }
+                if (last) { ok = true; end = static_cast<size_t>(fi.member_end() - data_); break; }
+                if (n == 0) break; // (cannot happen: no progress without an end or an error)
+            }
+        }
+        finish_(t, ok, end);
+    }
+
+    void inflate_member_zlib(Task& t) {
         z_stream z; memset(&z, 0, sizeof(z));
         bool ok = false; size_t end = t.off;
         if (inflateInit2(&z, 15 + 16) == Z_OK) {

@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 
 def _ensure_built():
-    need = [os.path.join(BIN, "rtk_simulate"), os.path.join(BIN, "rtk_build_index"), SIM_LIB,
+    need = [os.path.join(BIN, "rtk_simulate"), os.path.join(BIN, "rtk_build_index"), os.path.join(BIN, "rtk_gunzip"), SIM_LIB,
             os.path.join(ROOT, "oracle", "liboracle.so"), os.path.join(ROOT, "ratatosk_amd", "libratatosk_hip.so"), os.path.join(BIN, "Ratatosk")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__

@@ -221,3 +221,27 @@ def test_gzip_of_several_members_inflated_on_several_threads(ds, tmp_path):
             rr = subprocess.run([SIM, "correct", "-1", "-c", cores, "-g", ds + ".index.k31.fasta.gz", "-d", ds + ".index.k31.rtsk", "-l", p, "-o", str(tmp_path / "bad")],
                                 capture_output=True, text=True, env=dict(os.environ, RTK_SIM_DEVICES="1"))
             assert rr.returncode != 0 and "gzip" in rr.stderr, (p, cores, rr.stderr)
+
+
+def test_gzip_streams_of_every_block_kind_through_the_fast_decoder(ds, tmp_path):
+    """With `-c` > 1 gzip members are decoded by common/finflate.hpp instead of zlib. The same reads compressed so that the stream consists of
+    stored blocks (level 0), fixed-Huffman blocks (Z_FIXED), literal-only dynamic blocks (Z_HUFFMAN_ONLY), distance-1 matches (Z_RLE), ordinary
+    blocks at levels 1 / 6 / 9 with full-flush points in between, and a small window (so that distances wrap the 32 KB history differently):
+    always the plain file's output, and the same with RTK_ZLIB_INFLATE=1 (zlib inside the same reader)."""
+    import zlib
+    text = open(ds + ".lr.fq", "rb").read()
+    r = _run(ds, ds + ".lr.fq", str(tmp_path / "base"))
+    want = _sha(str(tmp_path / "base.2.fastq"))
+    variants = [(0, zlib.Z_DEFAULT_STRATEGY, 15), (6, zlib.Z_FIXED, 15), (6, zlib.Z_HUFFMAN_ONLY, 15), (6, zlib.Z_RLE, 15), (1, zlib.Z_DEFAULT_STRATEGY, 15),
+                (6, zlib.Z_DEFAULT_STRATEGY, 15), (9, zlib.Z_DEFAULT_STRATEGY, 15), (9, zlib.Z_DEFAULT_STRATEGY, 9), (6, zlib.Z_FILTERED, 12)]
+    for i, (lvl, strat, wbits) in enumerate(variants):
+        co = zlib.compressobj(lvl, zlib.DEFLATED, 16 + wbits, 9, strat)
+        cut = [0, len(text) // 3, len(text) // 3 + 5, len(text)]
+        blob = b"".join(co.compress(text[a:b]) + co.flush(zlib.Z_FULL_FLUSH) for a, b in zip(cut[:-1], cut[1:])) + co.flush()
+        assert gzip.decompress(blob) == text
+        p = str(tmp_path / ("v%d.fq.gz" % i))
+        open(p, "wb").write(blob)
+        for env in ({}, {"RTK_ZLIB_INFLATE": "1"}):
+            rr = _run(ds, p, str(tmp_path / "o"), env)
+            assert rr.returncode == 0, (i, rr.stderr)
+            assert _sha(str(tmp_path / "o.2.fastq")) == want, (i, env)
