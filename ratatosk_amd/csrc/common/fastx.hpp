@@ -79,12 +79,13 @@ public:
     FastxReader() : fp_(nullptr), failed_(false), pos_(0), end_(0), eof_(false), has_peek_(false) {}
     ~FastxReader() { close(); }
 
-    // inflate_threads > 1: a gzip file is inflated member by member on that many threads (mgzip.hpp: a file of several gzip members, the usual
-    // `cat *.fastq.gz`, scales with them; a single member streams as before)
-    bool open(const std::string& fn, int inflate_threads = 1) {
+    // inflate_threads >= 1: a gzip file is inflated by the reader's own decoder on that many threads BESIDE the calling one (mgzip.hpp: a file of
+    // several gzip members, the usual `cat *.fastq.gz`, scales with them; a single member streams, inflate and parsing side by side).
+    // 0: zlib's gzread on the calling thread.
+    bool open(const std::string& fn, int inflate_threads = 0) {
         close();
         pos_ = end_ = 0; eof_ = false; has_peek_ = false; failed_ = false;
-        if (inflate_threads > 1 && MemberGzipReader::looks_like_gzip(fn)) { mg_.reset(new MemberGzipReader()); if (mg_->open(fn, inflate_threads)) return true; mg_.reset(); }
+        if (inflate_threads >= 1 && MemberGzipReader::looks_like_gzip(fn)) { mg_.reset(new MemberGzipReader()); if (mg_->open(fn, inflate_threads)) return true; mg_.reset(); }
         fp_ = gzopen(fn.c_str(), "rb"); // zlib reads plain files transparently
         if (!fp_) return false;
         gzbuffer(fp_, 1 << 20);

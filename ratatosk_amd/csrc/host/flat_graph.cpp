@@ -67,7 +67,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     std::vector<std::string> seqs;
     {
         FastxReader fr;
-        if (!fr.open(fasta_gz)) throw std::runtime_error("cannot open graph file " + fasta_gz);
+        if (!fr.open(fasta_gz, n_threads > 1 ? (n_threads < 8 ? n_threads : 8) : 0)) throw std::runtime_error("cannot open graph file " + fasta_gz); // (threads: the reader's own inflate beside this thread, members side by side)
         std::string name, seq, qual;
         while (fr.next(name, seq, qual)) {
             for (size_t i = 0; i < seq.size(); ++i) seq[i] = static_cast<char>(seq[i] & 0xDF);

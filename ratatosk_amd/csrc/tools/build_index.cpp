@@ -496,7 +496,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             Chunk* cur = new Chunk();
             auto flush = [&]() { if (cur->seq.empty()) return; { std::unique_lock<std::mutex> lk(mq); cv_put.wait(lk, [&]() { return q.size() < 4u * n_thr; }); q.push_back(cur); } cv_get.notify_one(); cur = new Chunk(); };
             for (size_t f = 0; f < col_in.size() && !open_failed; ++f) {
-                FastxReader fr; if (!fr.open(col_in[f], fast ? static_cast<int>(n_thr < 8 ? n_thr : 8) : 1)) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); open_failed = 1; break; }
+                FastxReader fr; if (!fr.open(col_in[f], fast ? static_cast<int>(n_thr < 8 ? n_thr : 8) : 0)) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); open_failed = 1; break; }
                 while (fr.next(name, seq, qual)) {
                     for (size_t x = 0; x < seq.size(); ++x) seq[x] = static_cast<char>(seq[x] & 0xDF);
                     if (name.size() > 2 && name[name.size() - 2] == '/' && (name[name.size() - 1] == '1' || name[name.size() - 1] == '2')) name.erase(name.size() - 2);
