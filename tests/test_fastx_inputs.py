@@ -118,9 +118,13 @@ def test_second_pass_reads_qualities_on_several_lines(ds, tmp_path):
     open(rawfa, "w").write("".join(">%s\n%s\n" % (x[0], _wrap(x[1], 60)) for x in recs))
     env = dict(os.environ, RTK_SIM_DEVICES="1")
     shas = []
-    for l, L in ((p1, ds + ".lr.fq"), (p1m, rawm), (p1m, rawfa), (p1, rawfa)):
+    p1gz, rawgz = p1m + ".gz", rawm + ".gz"  # both files as gzip of several members: two member readers side by side
+    for src, dst in ((p1m, p1gz), (rawm, rawgz)):
+        t = open(src, "rb").read()
+        open(dst, "wb").write(b"".join(gzip.compress(t[a:a + 20011], 1) for a in range(0, len(t), 20011)))
+    for l, L in ((p1, ds + ".lr.fq"), (p1m, rawm), (p1m, rawfa), (p1, rawfa), (p1gz, rawgz), (p1gz, rawfa)):
         o = str(tmp_path / "o2")
-        r = subprocess.run([SIM, "correct", "-2", "-K", "31", "-c", "2", "-B", "5000", "-g", str(tmp_path / "p2.index.k31.fasta.gz"), "-d", str(tmp_path / "p2.index.k31.rtsk"),
+        r = subprocess.run([SIM, "correct", "-2", "-K", "31", "-c", "4", "-B", "5000", "-g", str(tmp_path / "p2.index.k31.fasta.gz"), "-d", str(tmp_path / "p2.index.k31.rtsk"),
                             "-l", l, "-L", L, "-o", o], capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
         shas.append(_sha(o + ".fastq"))
