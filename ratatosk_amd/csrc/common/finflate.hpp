@@ -309,22 +309,20 @@ private:
         const unsigned char* const in_fast = end_ - 8;
 #define RTK_FI_REFILL() do { if (in <= in_fast) { uint64_t w_; memcpy(&w_, in, 8); bb |= w_ << bc; in += (63 - bc) >> 3; bc |= 56; } \
                              else { bitbuf_ = bb; bitcnt_ = bc; in_ = in; refill_(); bb = bitbuf_; bc = bitcnt_; in = in_; } } while (0)
+        RTK_FI_REFILL();
+        uint32_t e = pair[bb & ((1u << LIT_PB) - 1)]; // the entry of the NEXT symbol is always looked up ahead: its load runs beside the stores of the current one
         while (o < o_stop && !err_) {
-            RTK_FI_REFILL();
-            uint32_t e = pair[bb & ((1u << LIT_PB) - 1)];
-            // literals straight from the primary table, one or two per entry, for as long as the bit buffer holds a whole code (15 bits) for the next lookup
-            while (e & 0x80) {
+            if (e & 0x80) { // one or two literals straight from the primary table
                 bb >>= (e & 15); bc -= (e & 15);
-                o[0] = static_cast<unsigned char>(e >> 16); o[1] = static_cast<unsigned char>(e >> 24); o += 1 + ((e >> 6) & 1); // (the second byte is overwritten when the entry holds one)
-                if (bc < 15) { RTK_FI_REFILL(); }
+                const uint16_t two = static_cast<uint16_t>(e >> 16); memcpy(o, &two, 2); o += 1 + ((e >> 6) & 1); // (the second byte is overwritten when the entry holds one)
+                if (bc < 15) { RTK_FI_REFILL(); } // a whole code for the next lookup
                 e = pair[bb & ((1u << LIT_PB) - 1)];
-                if (o >= o_stop) break;
+                continue;
             }
-            if (e & 0x80) continue; // (left the run because the output span is full: nothing of `e` was consumed)
             if (bc < 48) { RTK_FI_REFILL(); } // a length / distance pair takes up to 15 + 5 + 15 + 13 bits (the refill leaves the bits `e` was read from alone)
             if ((e & 0xF0) == K_SUB) {
                 bb >>= LIT_PB; bc -= LIT_PB; e = lit[(e >> 16) + (bb & ((1u << ((e >> 8) & 0xFF)) - 1))];
-                if ((e & 0xF0) == K_LIT) { bb >>= (e & 15); bc -= (e & 15); *o++ = static_cast<unsigned char>(e >> 16); continue; }
+                if ((e & 0xF0) == K_LIT) { bb >>= (e & 15); bc -= (e & 15); *o++ = static_cast<unsigned char>(e >> 16); if (bc < 15) { RTK_FI_REFILL(); } e = pair[bb & ((1u << LIT_PB) - 1)]; continue; }
             }
             bb >>= (e & 15); bc -= (e & 15);
             if ((e & 0xF0) == K_BASE) {
@@ -337,8 +335,13 @@ private:
                 const unsigned db = (d >> 8) & 0xFF;
                 const size_t distance = (d >> 16) + static_cast<size_t>(bb & ((1u << db) - 1)); bb >>= db; bc -= db;
                 if (distance > static_cast<size_t>(o - o_min)) { err_ = true; break; } // before the start of the history
+                RTK_FI_REFILL();
+                e = pair[bb & ((1u << LIT_PB) - 1)]; // (looked up before the copy)
                 const unsigned char* s = o - distance; unsigned char* const oe = o + len;
-                if (distance >= 8) { do { uint64_t w; memcpy(&w, s, 8); memcpy(o, &w, 8); s += 8; o += 8; } while (o < oe); }
+                if (distance >= 8) { // sixteen bytes without asking (most matches of FASTQ text are shorter), the rest in steps of eight
+                    uint64_t w; memcpy(&w, s, 8); memcpy(o, &w, 8); memcpy(&w, s + 8, 8); memcpy(o + 8, &w, 8);
+                    if (len > 16) { s += 16; o += 16; do { memcpy(&w, s, 8); memcpy(o, &w, 8); s += 8; o += 8; } while (o < oe); }
+                }
                 else if (distance == 1) { memset(o, *s, len); }
                 else { do { *o++ = *s++; } while (o < oe); }
                 o = oe;
