@@ -16,8 +16,12 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
+
+#include "finflate.hpp"
 
 namespace rtk {
 
@@ -111,6 +115,22 @@ public:
         if (len == 0) return true;
         if (off + len > usize_) return false;
         size_t b = static_cast<size_t>(std::upper_bound(uoff_.begin(), uoff_.end(), off) - uoff_.begin()) - 1;
+        static const bool use_zlib = []() { const char* e = getenv("RTK_ZLIB_INFLATE"); return e && e[0] == '1'; }();
+        if (!use_zlib) { // the reader's own inflate (finflate.hpp): the whole member, header and trailer included, so its CRC-32 and length are checked too
+            FastBlock& fb = fast_block();
+            const size_t cap = sizeof(fb.buf) - FastInflate::SLACK;
+            while (len) {
+                const uint64_t u0 = uoff_[b]; const size_t ulen = static_cast<size_t>(uoff_[b + 1] - u0);
+                const size_t skip = static_cast<size_t>(off - u0), take = std::min(len, ulen - skip);
+                if (!fb.fi.begin(map_ + coff_[b], map_ + coff_[b] + blen_[b])) return false;
+                size_t got = 0;
+                while (!fb.fi.done()) { const size_t n = fb.fi.decode(fb.buf + got, cap - got, got); if (fb.fi.failed() || (n == 0 && !fb.fi.done())) return false; got += n; if (got > 65536) return false; }
+                if (got != ulen) return false;
+                memcpy(dst, fb.buf + skip, take);
+                dst += take; off += take; len -= take; ++b;
+            }
+            return true;
+        }
         Inflater& z = inflater();
         if (!z.ok) return false;
         unsigned char tmp[65536];
@@ -131,6 +151,8 @@ public:
 private:
     struct Inflater { z_stream zs; bool ok; Inflater() { memset(&zs, 0, sizeof(zs)); ok = inflateInit2(&zs, -15) == Z_OK; } ~Inflater() { if (ok) inflateEnd(&zs); } };
     static Inflater& inflater() { static thread_local Inflater z; return z; }
+    struct FastBlock { FastInflate fi; unsigned char buf[65536 + 192 + FastInflate::SLACK]; };
+    static FastBlock& fast_block() { static thread_local std::unique_ptr<FastBlock> p(new FastBlock()); return *p; }
     const unsigned char* map_; size_t map_bytes_;
     std::vector<uint64_t> coff_, uoff_; std::vector<uint32_t> hdr_, blen_; // per data block: file offset, header bytes, block bytes; uncompressed offset (+ one past the end)
     uint64_t usize_;

@@ -249,3 +249,20 @@ def test_gzip_streams_of_every_block_kind_through_the_fast_decoder(ds, tmp_path)
             rr = _run(ds, p, str(tmp_path / "o"), env)
             assert rr.returncode == 0, (i, rr.stderr)
             assert _sha(str(tmp_path / "o.2.fastq")) == want, (i, env)
+
+
+def test_a_damaged_bgzf_block_is_an_error(ds, tmp_path):
+    """Blocked gzip goes through the byte-range reader, whose blocks are inflated by the reader's own decoder with the block's CRC-32 checked
+    (zlib's raw inflate, used before, did not look at it): one flipped byte in the middle of the file must stop the run."""
+    text = open(ds + ".lr.fq", "rb").read() * 6
+    p = str(tmp_path / "in.fq")
+    open(p, "wb").write(text)
+    subprocess.check_call([os.path.join(BIN, "rtk_bgzip"), p, p + ".gz"])
+    r = _run(ds, p + ".gz", str(tmp_path / "ok"))
+    assert r.returncode == 0, r.stderr
+    b = bytearray(open(p + ".gz", "rb").read())
+    b[len(b) // 2] ^= 0x10
+    open(p + ".bad.gz", "wb").write(bytes(b))
+    for env in ({}, {"RTK_ZLIB_INFLATE": "1"}):
+        r = _run(ds, p + ".bad.gz", str(tmp_path / "bad"), env)
+        assert r.returncode != 0 and ("read error" in r.stderr or "gzip" in r.stderr), r.stderr
