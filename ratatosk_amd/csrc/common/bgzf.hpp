@@ -143,6 +143,9 @@ public:
             z.zs.next_in = const_cast<Bytef*>(map_ + coff_[b] + hdr); z.zs.avail_in = static_cast<uInt>(bsize - hdr - 8);
             z.zs.next_out = direct ? reinterpret_cast<Bytef*>(dst) : tmp; z.zs.avail_out = static_cast<uInt>(direct ? ulen : sizeof(tmp));
             if (inflate(&z.zs, Z_FINISH) != Z_STREAM_END || z.zs.total_out != ulen) return false;
+            { const unsigned char* tr = map_ + coff_[b] + bsize - 8; // the member's CRC-32 (raw inflate does not look at it)
+              const uint32_t want = tr[0] | (tr[1] << 8) | (tr[2] << 16) | (static_cast<uint32_t>(tr[3]) << 24);
+              if (fast_crc32(0, direct ? reinterpret_cast<const unsigned char*>(dst) : tmp, ulen) != want) return false; }
             if (!direct) memcpy(dst, tmp + skip, take);
             dst += take; off += take; len -= take; ++b;
         }
