@@ -131,3 +131,24 @@ def test_gpu_index_build_writes_the_same_files(tmp_path):
     finally:
         del os.environ["RTK_INDEX_CAP"]
     assert a[0] == b[0] == c[0] and a[1] == b[1] == c[1]
+
+
+@pytest.mark.gpu
+def test_gpu_index_build_from_gzip_input(tmp_path):
+    """`--gpu` with the short reads as gzip of several members, as one member and cut short: the device counts the k-mers of text that the host
+    reader inflates (common/mgzip.hpp on the tool's threads); same files as from the plain text, the damaged file refused."""
+    import gzip
+    tmp = str(tmp_path)
+    sr = _simulated(tmp, "gzg", SETS[0][1])
+    text = open(sr, "rb").read()
+    step = len(text) // 7 + 1
+    open(sr + ".many.gz", "wb").write(b"".join(gzip.compress(text[i:i + step], 1) for i in range(0, len(text), step)))
+    open(sr + ".one.gz", "wb").write(gzip.compress(text, 1))
+    want = _build(sr, os.path.join(tmp, "plain"), 31, [])
+    for inp in (sr + ".many.gz", sr + ".one.gz"):
+        got = _build(inp, os.path.join(tmp, "g"), 31, ["--gpu"])
+        assert got[0] == want[0] and got[1] == want[1], inp
+    cut = open(sr + ".one.gz", "rb").read()
+    open(sr + ".cut.gz", "wb").write(cut[:len(cut) // 2])
+    r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", sr + ".cut.gz", "-o", os.path.join(tmp, "bad"), "--gpu"], capture_output=True, text=True)
+    assert r.returncode != 0 and "gzip" in r.stderr, r.stderr
