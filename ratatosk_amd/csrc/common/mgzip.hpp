@@ -152,6 +152,7 @@ private:
                 // candidate that an earlier scan step found (the consumer would take the chain for broken)
                 std::lock_guard<std::mutex> lk(m_);
                 if (o >= size_) { scan_done_ = true; cv_data_.notify_all(); cv_work_.notify_all(); continue; }
+                if (o < pos_.load()) continue; // the chain moved past it while it was being found: a false start inside a consumed member
                 t.reset(new Task()); t->off = o; tasks_[o] = t;
                 cv_data_.notify_all();
             }
@@ -165,8 +166,8 @@ private:
         std::unique_lock<std::mutex> lk(m_);
         t.chunks.emplace_back(); t.chunks.back().p.swap(c.p); t.chunks.back().n = c.n; t.chunks.back().off = c.off; t.buffered += c.n; t.produced += c.n;
         cv_data_.notify_all();
-        cv_work_.wait(lk, [&]() { return stop_ || t.cancel || t.head || t.buffered < (128u << 20); }); // ahead of the head: bounded
-        if (stop_ || t.cancel) return false;
+        cv_work_.wait(lk, [&]() { return stop_ || t.cancel || t.head || t.off < pos_.load() || t.buffered < (128u << 20); }); // ahead of the head: bounded
+        if (stop_ || t.cancel || (!t.head && t.off < pos_.load())) return false; // (behind the chain position without being its head: a false start)
         if (t.head) cv_work_.wait(lk, [&]() { return stop_ || t.buffered < (64u << 20); }); // the head: a few chunks in front of the consumer
         return !stop_;
     }
