@@ -266,3 +266,35 @@ def test_a_damaged_bgzf_block_is_an_error(ds, tmp_path):
     for env in ({}, {"RTK_ZLIB_INFLATE": "1"}):
         r = _run(ds, p + ".bad.gz", str(tmp_path / "bad"), env)
         assert r.returncode != 0 and ("read error" in r.stderr or "gzip" in r.stderr), r.stderr
+
+
+def test_range_reader_on_random_multi_line_fasta(ds, tmp_path):
+    """The byte-range reader takes FASTA on any number of lines (a record starts at every line that begins with '>'): random files of short
+    records with empty lines, empty sequences and lines of every length, ranges from 256 bytes up, against the one-thread reader."""
+    rng = random.Random(123)
+    for it in range(16):
+        n = rng.randint(1, 50)
+        recs, text = [], []
+        for i in range(n):
+            L = rng.choice([0, 1, 3, 17, 29, 30])
+            s = "".join(rng.choice("ACGT") for _ in range(L))
+            w = rng.choice([1, 2, 7, 60])
+            body = "".join(s[a:a + w] + "\n" + ("\n" if rng.random() < 0.1 else "") for a in range(0, len(s), w)) if s else ("\n" if rng.random() < 0.5 else "")
+            text.append(">r%d_%d some words\n%s" % (it, i, body))
+            recs.append(("r%d_%d" % (it, i), s))
+        t = "".join(text)
+        if it % 4 == 1:
+            t = t.rstrip("\n")
+        if it % 4 == 2:
+            t = t.replace("\n", "\r\n")
+        p = str(tmp_path / ("f%d.fa" % it))
+        open(p, "w", newline="").write(t)
+        outs = []
+        for env, B in (({"RTK_SERIAL_READER": "1"}, 1 << 20), ({}, 1), ({}, rng.randint(300, 3000)), ({}, 1 << 20)):
+            r = _run(ds, p, str(tmp_path / "o"), env, ["-B", str(B)])
+            assert r.returncode == 0, r.stderr
+            outs.append(open(str(tmp_path / "o.2.fastq")).read())
+        got = outs[0].split("\n")
+        assert [got[i][1:] for i in range(0, len(got) - 1, 4)] == [x[0] for x in recs], it
+        assert [got[i] for i in range(1, len(got) - 1, 4)] == [x[1] for x in recs], it
+        assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0], it
