@@ -108,18 +108,18 @@ struct NeighbourIndex {
     }
     // calls f(offset j, substituted base) for every graph k-mer one substitution away from x, by (j, base) ascending
     template <class F> void neighbours(uint64_t x, F f) const {
-        uint32_t found[16]; int nf = 0; // (j << 2 | base); more than 16 cannot happen in practice, the rest would be dropped in order
+        uint32_t found[96]; int nf = 0; // (j << 2 | base): at most 3 per offset, 3k <= 93 in all (a k-mer of a tandem repeat at small k has dozens: 16 slots lost some, found by tests/test_annotators.py)
         { // same first half: the differing base lies in the last lo_n bases
             const uint64_t lo_key = x & ~lomask, hi_key = x | lomask;
             size_t i = ia[lo_key >> shift]; const size_t e = ia[(hi_key >> shift) + 1];
             i = static_cast<size_t>(std::lower_bound(a.begin() + i, a.begin() + e, lo_key) - a.begin());
-            for (; i < e && a[i] <= hi_key; ++i) { const uint64_t d = a[i] ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 16) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((a[i] >> bit) & 3ULL); }
+            for (; i < e && a[i] <= hi_key; ++i) { const uint64_t d = a[i] ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 96) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((a[i] >> bit) & 3ULL); }
         }
         { // same last half: the differing base lies in the first hi_n bases
             const uint64_t r = rot(x), himask = (1ULL << (2 * hi_n)) - 1ULL; const uint64_t lo_key = r & ~himask, hi_key = r | himask;
             size_t i = ib[lo_key >> shift]; const size_t e = ib[(hi_key >> shift) + 1];
             i = static_cast<size_t>(std::lower_bound(b.begin() + i, b.begin() + e, lo_key) - b.begin());
-            for (; i < e && b[i] <= hi_key; ++i) { const uint64_t y = unrot(b[i]); const uint64_t d = y ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 16) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((y >> bit) & 3ULL); }
+            for (; i < e && b[i] <= hi_key; ++i) { const uint64_t y = unrot(b[i]); const uint64_t d = y ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 96) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((y >> bit) & 3ULL); }
         }
         std::sort(found, found + nf);
         for (int i = 0; i < nf; ++i) f(static_cast<int>(found[i] >> 2), static_cast<uint64_t>(found[i] & 3u));

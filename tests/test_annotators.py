@@ -88,3 +88,13 @@ def test_fast_tool_writes_what_the_annotators_say(tmp_path):
     pre = make_dataset(tmp_path, "fastann", ["--seed", 77, "--ref-len", 40000, "--het", 0.005, "--repeat-frac", 0.05, "--tandem", 8, "--sr-cov", 35, "--sr-err", 0.005,
                                              "--lr-n", 2, "--lr-len", 1000], ["--snps", "--fast"])
     _check(pre, 31, expect_cycles=True, expect_snps=True)
+
+
+def test_windows_with_dozens_of_neighbours(tmp_path):
+    """k = 21 on a set whose tandem repeats give single k-mers up to 3k one-substitution neighbours in the graph: the set on which this
+    cross-check found the `--fast` tool keeping only 16 candidates per window (fixed; plain and fast tools and this module agree)."""
+    args = ["--seed", 624414, "--ref-len", 90000, "--het", 0.002, "--repeat-frac", 0.05, "--tandem", 5, "--sr-cov", 60, "--sr-err", 0.01, "--lr-n", 2, "--lr-len", 1000]
+    for mode in ([], ["--fast"]):
+        pre = make_dataset(tmp_path, "nb" + ("f" if mode else "p"), args, ["-k", 21, "--snps"] + mode)
+        n, n_cyc, n_amb = _check(pre, 21, expect_cycles=True, expect_snps=True)
+        assert n_amb > 5000
