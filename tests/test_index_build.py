@@ -121,7 +121,7 @@ def test_index_from_gzip_input_of_several_members(tmp_path):
 def test_gpu_index_build_writes_the_same_files(tmp_path):
     """k-mers counted on the device: the files of three seeded sets (and the self-meeting genomes) are the plain tool's, byte for byte."""
     tmp = str(tmp_path)
-    for name, args in SETS:
+    for name, args in SETS[:3]: # (the fourth set exercises host code that --gpu shares with --fast: covered by the CPU tier)
         _same(tmp, name, _simulated(tmp, name, args), "--gpu")
     _same(tmp, "self", _self_meeting_genomes(tmp), "--gpu", ks=(31,))
     # a bigger set, several partitions of the k-mer space forced (RTK_INDEX_CAP: k-mers per pass)
