@@ -85,7 +85,13 @@ public:
         while (got < want) {
             if (!cur_) { // next member of the chain
                 std::unique_lock<std::mutex> lk(m_);
-                if (pos_.load() >= size_ || !is_magic(pos_.load())) break; // end of the file, or bytes that are no member: ignored like zlib does
+                if (pos_.load() >= size_) break; // end of the file
+                if (!is_magic(pos_.load())) {
+                    // a member header of which fewer than 18 bytes are left is a cut-short member (gzread: unexpected end of file), not trailing junk
+                    const size_t o = pos_.load();
+                    if (size_ - o < 18 && size_ - o >= 2 && data_[o] == 0x1f && data_[o + 1] == 0x8b) { error_ = true; return got ? static_cast<long>(got) : -1; }
+                    break; // bytes that are no member: ignored like zlib does
+                }
                 cv_data_.wait(lk, [&]() { return tasks_.count(pos_.load()) != 0 || scan_done_ || stop_; });
                 std::map<size_t, std::shared_ptr<Task> >::iterator it = tasks_.find(pos_.load());
                 if (it == tasks_.end()) { error_ = true; return -1; } // (cannot happen: every magic offset becomes a task)

@@ -81,7 +81,7 @@ template <class F> static void parallel_for(size_t n, unsigned n_thr, F f) { // 
 // whose other half differs in exactly one base. Used by the SNP search of --fast (the plain path probes every variant in the k-mer table).
 struct NeighbourIndex {
     int k = 0, hi_n = 0, lo_n = 0; uint64_t lomask = 0;
-    std::vector<uint64_t> a, b; std::vector<uint32_t> ia, ib; int shift = 0; // ia / ib: first entry of every value of the top 24 bits of the 2k-bit key
+    std::vector<uint64_t> a, b; std::vector<uint64_t> ia, ib; int shift = 0; // ia / ib: first entry of every value of the top 24 bits of the 2k-bit key
     uint64_t rot(uint64_t x) const { return ((x & lomask) << (2 * hi_n)) | (x >> (2 * lo_n)); }
     uint64_t unrot(uint64_t r) const { return ((r & ((1ULL << (2 * hi_n)) - 1ULL)) << (2 * lo_n)) | (r >> (2 * hi_n)); }
     static void sort_parallel(std::vector<uint64_t>& v, int key_bits, unsigned n_thr) { // bucket by the top 8 key bits, every bucket sorted by a thread
@@ -103,7 +103,7 @@ struct NeighbourIndex {
         sort_parallel(a, 2 * k, n_thr); sort_parallel(b, 2 * k, n_thr);
         shift = 2 * k > 24 ? 2 * k - 24 : 0;
         const size_t nb = (static_cast<size_t>(1) << (2 * k - shift)) + 1;
-        auto index = [&](const std::vector<uint64_t>& v, std::vector<uint32_t>& ix) { ix.assign(nb, 0); for (size_t i = 0; i < v.size(); ++i) ++ix[(v[i] >> shift) + 1]; for (size_t i = 0; i + 1 < nb; ++i) ix[i + 1] += ix[i]; };
+        auto index = [&](const std::vector<uint64_t>& v, std::vector<uint64_t>& ix) { ix.assign(nb, 0); for (size_t i = 0; i < v.size(); ++i) ++ix[(v[i] >> shift) + 1]; for (size_t i = 0; i + 1 < nb; ++i) ix[i + 1] += ix[i]; };
         index(a, ia); index(b, ib);
     }
     // calls f(offset j, substituted base) for every graph k-mer one substitution away from x, by (j, base) ascending

@@ -220,7 +220,13 @@ def test_gzip_of_several_members_inflated_on_several_threads(ds, tmp_path):
     flipped[at] ^= 0x55
     bad2 = str(tmp_path / "flipped.fq.gz")
     open(bad2, "wb").write(bytes(flipped))
-    for p in (bad1, bad2):
+    # a last member of which fewer than 18 bytes are left (header cut), and an empty last member cut short: zlib's gzread reports an
+    # unexpected end of file on both, so they are errors, not trailing junk
+    whole = b"".join(gzip.compress(p, lvl) for p, lvl in zip(pieces, [6, 0, 0, 9, 0, 1]))
+    bad3, bad4 = str(tmp_path / "cut_header.fq.gz"), str(tmp_path / "cut_empty.fq.gz")
+    open(bad3, "wb").write(whole + gzip.compress(pieces[0], 6)[:9])
+    open(bad4, "wb").write(whole + gzip.compress(b"")[:13])
+    for p in (bad1, bad2, bad3, bad4):
         for cores in ("1", "4"):
             rr = subprocess.run([SIM, "correct", "-1", "-c", cores, "-g", ds + ".index.k31.fasta.gz", "-d", ds + ".index.k31.rtsk", "-l", p, "-o", str(tmp_path / "bad")],
                                 capture_output=True, text=True, env=dict(os.environ, RTK_SIM_DEVICES="1"))
