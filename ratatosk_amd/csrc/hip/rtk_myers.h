@@ -57,6 +57,12 @@ struct MyersScratch {
 // An entry is 32 bytes: the low 32-bit halves of {Pv, Mv, Ph, Mh}, then their high halves, so that each of the two lanes that share a
 // 64-bit word in the 32-bit sweep writes its four words with ONE 16-byte store.
 struct RtkTbHalf { uint32_t pv, mv, ph, mh; };
+#if defined(RTK_TB_NT) && !defined(RTK_SIM) // A/B build: the table is written once and read along one path: streaming stores, so that it does not push the waves' stacks out of the L2
+typedef uint32_t rtk_v4u __attribute__((ext_vector_type(4)));
+#define RTK_TB_ST(p, hv) __builtin_nontemporal_store(rtk_v4u{(hv).pv, (hv).mv, (hv).ph, (hv).mh}, reinterpret_cast<rtk_v4u*>(p))
+#else
+#define RTK_TB_ST(p, hv) (*(p) = (hv))
+#endif
 RTK_DEV void rtk_tb_put(uint64_t* e, uint64_t Pv, uint64_t Mv, uint64_t Ph, uint64_t Mh) {
     RtkTbHalf lo, hi;
     lo.pv = static_cast<uint32_t>(Pv); lo.mv = static_cast<uint32_t>(Mv); lo.ph = static_cast<uint32_t>(Ph); lo.mh = static_cast<uint32_t>(Mh);
@@ -371,7 +377,7 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
     uint32_t Pv = ~0u, Mv = 0u;
     int hout_prev = 0; uint32_t m1_prev = 0, m2_prev = 0;
     int score = m;
-    int best = 0x7fffffff, first = -1, last = -1, cnt = 0;
+    int vbest = 0x7fffffff, vfirst = -1, vlast = -1, vcnt = 0;
     const int steps = n + W - 1;
     // table entry of (column, 64-bit word) = two RtkTbHalf (low halves, high halves of Pv, Mv, Ph, Mh); this lane owns one of them
     RtkTbHalf* const tbh = reinterpret_cast<RtkTbHalf*>(tb) + 2ull * RTK_TB(0, w >> 1, n) + (w & 1); // this lane's half of the entries of its 64-bit word
@@ -393,21 +399,20 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
         const int col = s - lane;                                                                                                            \
         if (MASKED) {                                                                                                                        \
             const bool active = has_word && col >= 0 && col < n;                                                                             \
-            if (STORE) { if (active) { RtkTbHalf hv; hv.pv = nPv; hv.mv = nMv; hv.ph = Ph; hv.mh = Mh; tbh[2ull * static_cast<uint64_t>(col)] = hv; } } \
+            if (STORE) { if (active) { RtkTbHalf hv; hv.pv = nPv; hv.mv = nMv; hv.ph = Ph; hv.mh = Mh; RTK_TB_ST(&tbh[2ull * static_cast<uint64_t>(col)], hv); } } \
             Pv = active ? nPv : Pv; Mv = active ? nMv : Mv;                                                                                  \
             hout_prev = active ? hout : hout_prev;                                                                                           \
             score += active ? hout : 0;                                                                                                      \
         } else {                                                                                                                             \
-            if (STORE) { if (has_word) { RtkTbHalf hv; hv.pv = nPv; hv.mv = nMv; hv.ph = Ph; hv.mh = Mh; tbh[2ull * static_cast<uint64_t>(col)] = hv; } } \
+            if (STORE) { if (has_word) { RtkTbHalf hv; hv.pv = nPv; hv.mv = nMv; hv.ph = Ph; hv.mh = Mh; RTK_TB_ST(&tbh[2ull * static_cast<uint64_t>(col)], hv); } } \
             Pv = nPv; Mv = nMv; hout_prev = hout; score += hout;                                                                             \
         }                                                                                                                                    \
         m1_prev = m1; m2_prev = m2;                                                                                                          \
         if (TRACK) {                                                                                                                         \
             const int tcol = s - (W - 1);                                                                                                    \
-            if (!(MASKED) || tcol >= 0) { /* wave-uniform: last-row score of column tcol, tracked in scalar registers */                    \
-                const int sv = __builtin_amdgcn_readlane(score, W - 1);                                                                      \
-                if (sv < best) { best = sv; first = tcol; last = tcol; cnt = 1; }                                                            \
-                else if (sv == best) { last = tcol; ++cnt; }                                                                                 \
+            if (!(MASKED) || tcol >= 0) { /* every lane follows the minimum of ITS word's last row (selects, no branches); lane W - 1's is the one read at the end */ \
+                const bool lt_ = score < vbest, eq_ = score == vbest;                                                                        \
+                vbest = lt_ ? score : vbest; vfirst = lt_ ? tcol : vfirst; vlast = (lt_ || eq_) ? tcol : vlast; vcnt = lt_ ? 1 : (vcnt + (eq_ ? 1 : 0)); \
             }                                                                                                                                \
         }                                                                                                                                    \
     }
@@ -424,11 +429,15 @@ __device__ __forceinline__ SweepStat rtk_myers_fast32(const char* __restrict__ q
         int j_full = n - c0; j_full = j_full < j_fill ? j_fill : (j_full > lim ? lim : j_full);
         int j = 0;
         for (; j < j_fill; ++j) RTK_STEP32(1)
+#ifdef RTK_MY_UNROLL
+        _Pragma("unroll 4")
+#endif
         for (; j < j_full; ++j) RTK_STEP32(0)
         for (; j < lim; ++j) RTK_STEP32(1)
     }
 #undef RTK_STEP32
-    st.final_score = __builtin_amdgcn_readlane(score, W - 1); st.best = best; st.first = first; st.last = last; st.cnt = cnt;
+    st.final_score = __builtin_amdgcn_readlane(score, W - 1);
+    if (TRACK) { st.best = __builtin_amdgcn_readlane(vbest, W - 1); st.first = __builtin_amdgcn_readlane(vfirst, W - 1); st.last = __builtin_amdgcn_readlane(vlast, W - 1); st.cnt = __builtin_amdgcn_readlane(vcnt, W - 1); }
     return st;
 }
 

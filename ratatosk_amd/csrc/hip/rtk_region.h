@@ -45,6 +45,7 @@ struct RegionBatch {
     U<char*> qual_rev;                         // pass 2: every read's quality string reversed (q_bw of src/Correction.cpp:186,198)
     U<char*> seg_pool; U<uint64_t> seg_cap; U<unsigned long long*> seg_top;
     U<unsigned long long*> next_region;        // dequeue head of the persistent region kernel
+    U<uint32_t*> rorder; U<unsigned long long*> n_heavy; // dequeue order of the region kernel: the heavy regions (long gaps, read heads / tails) from the front, the light ones from the back (k_region_order); [0] heavy, [1] light
     U<unsigned long long*> n_overflow;         // regions that ran out of scratch in the last launch
     U<char*> out_pool; U<uint64_t> out_cap; U<unsigned long long*> out_top;
     U<uint64_t*> out_off; U<uint32_t*> out_seq_len; U<uint32_t*> out_qual_len; // per read
@@ -78,6 +79,9 @@ struct RegionScratch {
     DriverLocals loc;
     U<unsigned long long> cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
     U<unsigned long long> fine[16]; // developer cycle counters printed with RTK_TRACE (RTK_FINE names in rtk_pipeline_run.inc)
+#ifdef RTK_PROF
+    U<unsigned long long> prof[48]; U<unsigned long long> prof_t; // developer build (-DRTK_PROF): lap profile of the region program, every cycle of a wave attributed to one slot (RTK_PL)
+#endif
 #ifndef RTK_SLIM_HDR
     U<unsigned long long> hist[32]; // region time by size class: [b] cycles, [8 + b] regions, [16 + b] regions that needed the reverse strand too, [24 + b] DFS calls
 #endif
@@ -88,6 +92,11 @@ struct RegionScratch {
 #else
 #define RTK_HIST_ADD(sc, i, v) ((sc).hist[i] += (v))
 #define RTK_HIST_GET(sc, i) ((sc).hist[i])
+#endif
+#ifdef RTK_PROF
+#define RTK_PL(sc, i) do { const unsigned long long t_ = rtk_clock(); (sc).prof[i] += t_ - (sc).prof_t; (sc).prof_t = t_; } while (0)
+#else
+#define RTK_PL(sc, i) ((void)0)
 #endif
 
 // The views of a launch, ONE copy in device memory per batch (written by k_set_ctx in front of the kernels that read it). The wave
@@ -583,6 +592,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
         n_nt = 0; n_nt_live = 0; stk[0] = ~0ull; stk[1] = level; sp = 1; }
     while (sp > 0 && !rtk_failed(s)) {
         --sp;
+        RTK_PL(s, 15);
         const uint64_t hp = rtk_ld(stk + 2 * sp); const uint32_t lvl = static_cast<uint32_t>(rtk_ld(stk + 2 * sp + 1));
         const UMap um_start = (hp == ~0ull) ? um : rtk_rec_back(s, hp);
         const uint32_t* adj = g_adj + 8ull * um_start.unitig + (um_start.strand ? 0 : 4);
@@ -591,21 +601,25 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
         const uint32_t a4[4] = { rtk_ld(adj), rtk_ld(adj + 1), rtk_ld(adj + 2), rtk_ld(adj + 3) };
         const uint32_t eb = (rtk_ld(g_flags + um_start.unitig) >> (um_start.strand ? 4 : 0)) & 0xFu; // UnitigData::getSharedPids (UnitigData.hpp:275-284)
         const bool rev_order = rtk_u(c.o.a3_strand_order) != 0 && !um_start.strand; // [A3] switch: slot = base appended in walk direction (A,C,G,T)
+        RTK_PL(s, 8);
         for (int bi = 0; bi < 4 && !rtk_failed(s); ++bi) {
             const int b = rev_order ? 3 - bi : bi;
             const uint32_t ab = a4[b];
             if (ab == RTK_NONE32) continue;
             UMap sc; sc.unitig = ab >> 1; sc.strand = ab & 1u; sc.dist = 0; sc.len = rtk_nkm_u(c, sc.unitig);
             const bool col_ok = rtk_u(rtk_colour_ok(c, sc.unitig, all_pids, n_all));
+            RTK_PL(s, 9);
             if (!(((eb >> b) & 1u) && col_ok)) continue;
             if (do_terminal && has_end && sc.unitig == um_e.unitig && um_e.strand == sc.strand) { // terminal
                 if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
                 UMap pref = sc;
                 if (pref.strand) { pref.dist = 0; pref.len = um_e.dist + 1; } else { pref.dist = um_e.dist; pref.len = sc.len - um_e.dist; }
                 rtk_wp_extend(c, w, pref);
+                RTK_PL(s, 10);
                 if (rtk_ld(&w.l) <= max_len_path && !rtk_failed(s)) {
                     const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
                     if (sl == 0xFFFFFFFFu) break;
+                    RTK_PL(s, 11);
                     // the first terminal candidate of a call -- usually the only one -- is scored by a stored sweep that its quality
                     // string can be read from afterwards (rtk_myers_nw_and_save); further candidates overwrite nothing
                     double sco;
@@ -615,12 +629,14 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
                         sco = 1.0 - (static_cast<double>(rtk_u(t_saved.nw_dist)) / static_cast<double>(sl));
                         sco = sco > 0.0 ? sco : 0.0; sco = sco < 1.0 ? sco : 1.0;
                     } else sco = rtk_u(rtk_score_path(c, sl, ref, ref_len, true));
+                    RTK_PL(s, 12);
                     if (sco >= score_t1) {
                         if (sco > score_t1) n_t = 0;
                         if (n_t >= list_cap) { rtk_fail_ovf(s, 8); break; }
                         T[n_t++] = rtk_wp_commit(s, w, 2);
                         score_t2 = score_t1; score_t1 = sco;
                     } else if (sco > score_t2) score_t2 = sco;
+                    RTK_PL(s, 13);
                 }
             }
             { // non-terminal
@@ -631,6 +647,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
                 if (hp == ~0ull) rtk_wp_clear(w); else rtk_wp_load(s, w, hp);
                 rtk_wp_extend(c, w, sc);
                 if (rtk_failed(s)) break;
+                RTK_PL(s, 14);
 #ifdef RTK_SIM
                 rtk_sim_site_stat[20][0] += 1; rtk_sim_site_stat[20][1] += sc.len + ((hp == ~0ull) ? static_cast<uint32_t>(rtk_u(c.k)) - 1 : 0); // DFS tree nodes and the columns they add
 #endif
@@ -665,6 +682,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
 #ifdef RTK_SIM
     { const unsigned long long na = s.cnt[3] - dfs_al0; const unsigned b = na > 15 ? 15 : static_cast<unsigned>(na); rtk_sim_site_stat[21][0] += 1; rtk_sim_site_stat[22 + (b >> 3)][b & 7] += 1; rtk_sim_site_stat[24 + (b >> 3)][b & 7] += na; }
 #endif
+    RTK_PL(s, 15);
     s.cnt[0] += n_exp; RTK_HIST_ADD(s, 31, 1);
     s.cnt[14] += (rtk_clock() - td0) - (s.cnt[9] - my0); // DFS bookkeeping: loop time minus the alignments inside it
     bool nt_score_deferred = false;
@@ -689,6 +707,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
             }
         }
     }
+    RTK_PL(s, 16);
     // qualities (:556-584): re-commit every surviving path with its quality string (non-terminal ones: left to the caller when lazy)
     for (int which = 0; which < (lazy_nt ? 1 : 2) && !rtk_failed(s); ++which) {
         uint64_t* L = which ? NT : T; const uint32_t nL = which ? n_nt : n_t;
@@ -696,9 +715,12 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
             rtk_wp_load(s, w, rtk_ld(L + i));
             const uint32_t sl = rtk_u(rtk_ums_to_string(c, rtk_ld(&w.ums), rtk_ld(&w.n), str1));
             if (sl == 0xFFFFFFFFu || sl > rtk_ld(&s.str_cap)) { rtk_fail_ovf(s, 7); break; }
+            RTK_PL(s, 17);
             rtk_score_path_qual(c, sl, ref, ref_len, which ? score_nt1 : score_t1, which ? score_nt2 : score_t2, str2, (which == 0 && n_t_scored == 1) ? &t_saved : nullptr);
+            RTK_PL(s, 18);
             if (sl == rtk_ld(&w.l)) { rtk_wcopy(rtk_ld(&w.qual), str2, sl); w.qlen = sl; } // Path::setQuality only accepts q.length() == l
             L[i] = rtk_wp_commit(s, w, 2);
+            RTK_PL(s, 19);
         }
     }
     out.n_t = n_t; out.n_nt = n_nt; out.t1 = score_t1; out.nt1 = score_nt1; out.nt2 = score_nt2;
@@ -723,6 +745,7 @@ RTK_FN_SEARCH void rtk_explore(const RCtx& c_, const uint32_t* all_pids_, uint32
         RTK_SITE(5); const MyersResult a = rtk_align(c, s.str[0], path_len_prefix, ref, ref_len, -1, RTK_MODE_SHW);
         end_pos_ref = static_cast<uint32_t>(a.first + 1);
     }
+    RTK_PL(s, 7);
     if ((ref_len - end_pos_ref) != 0 && path_len < max_len_path) {
         DfsOut o = rtk_explore_subgraph(c, all_pids, n_all, ref + end_pos_ref, ref_len - end_pos_ref, max_len_path - path_len_prefix, um, um_e, 3);
         if (rtk_failed(s)) return;
@@ -906,6 +929,7 @@ RTK_FN_SEARCH uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pid
         uint64_t qh = rtk_wp_commit(s, w, 1); bool q_has = true; // the queue never holds more than one path (each pop pushes <= 1)
         // a queue entry P (+) Q whose non-terminal sub-path Q has not been given its score / quality string yet (see rtk_explore_subgraph)
         bool q_pending = false; uint64_t pend_hp = 0, pend_hq = 0; NtPending pend; pend.e = 0; pend.nt1 = 0.0; pend.nt2 = 0.0; pend.score_deferred = 0; pend.qual_deferred = 0;
+        RTK_PL(s, 6);
         while (q_has && !rtk_failed(s)) {
             if (q_pending) { // the pop of src/GraphTraversal.cpp:364-366: only a path shorter than max_len_path is ever looked at again
                 q_pending = false;
@@ -931,6 +955,7 @@ RTK_FN_SEARCH uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pid
             const uint64_t hp = qh; q_has = false;
             if (rtk_rec_l(s, hp) < max_len_path) {
                 uint32_t n_t, n_nt;
+                RTK_PL(s, 20);
                 rtk_explore(c, all_pids, n_all, ref, ref_len, has_end ? um_e : rtk_um_empty(), hp, max_len_path, &n_t, &n_nt, &pend);
                 if (rtk_failed(s)) break;
                 if (has_end) {
@@ -993,9 +1018,10 @@ RTK_FN_SEARCH uint64_t rtk_explore_paths(const RCtx& c_, const uint32_t* all_pid
             }
         }
     }
+    RTK_PL(s, 20);
     if (rtk_failed(s) || nv == 0) return ~0ull;
     if (nv > 1) { int bid, bend; RTK_SITE(10); rtk_select_best(c, v, nv, ref, ref_len, RTK_MODE_NW, -1.0, &bid, &bend); if (rtk_failed(s)) return ~0ull; v[0] = v[bid]; }
-    return rtk_path_has_short_cycle(c, v[0]) ? rtk_fix_repeats(c, v[0], ref, ref_len) : v[0];
+    { const uint64_t r_ = rtk_path_has_short_cycle(c, v[0]) ? rtk_fix_repeats(c, v[0], ref, ref_len) : v[0]; RTK_PL(s, 21); return r_; }
 }
 
 // ------------------------------------------------------------------------------------------------ extractSemiWeakPaths (src/Correction.cpp:3-157)
@@ -1028,6 +1054,7 @@ RTK_FN_SEARCH uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_
             UMap um_to = rtk_um_empty(); bool with_end = false;
             if (end) { if (no_end) called = l_len <= (max_len_weak_region / 2); else { called = l_len <= max_len_weak_region; um_to = end_um; with_end = true; } }
             else if (l_len <= max_len_weak_region) { called = true; um_to = rtk_u(rtk_an_um(lvw, lvw_lo + i_weak)); with_end = true; }
+            RTK_PL(s, 5);
             if (called) res = rtk_explore_paths(c, all_pids, n_all, s_read + cur_pos, l_len, um_start, um_to, with_end);
         }
         if (rtk_failed(s)) break;
@@ -1041,6 +1068,7 @@ RTK_FN_SEARCH uint64_t rtk_extract_semi_weak(const RCtx& c_, const char* s_read_
         if (!end) next_weak_pos = rtk_u(rtk_an_pos(lvw, lvw_lo + i_weak)) + k;
         begin = false;
     }
+    RTK_PL(s, 22);
     return (have && !rtk_failed(s)) ? cur : ~0ull;
 }
 
@@ -1562,6 +1590,7 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
 }
 #else
     uint32_t n_all = 0;
+    RTK_PL(s, 2);
     if (rc == nullptr) {
         const unsigned long long t_side0 = rtk_clock();
         // side lists live in list[0..2] memory (u32 unitig + flag bytes)
@@ -1602,7 +1631,9 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
         }
         if (sl.n >= cap / 2 || sr.n >= cap / 2 || sm.n >= cap / 2) { rtk_fail_ovf(s, 8); return; }
         s.fine[7] += rtk_clock() - t_side0;
+        RTK_PL(s, 3);
         { const unsigned long long t0 = rtk_clock(); n_all = rtk_u(rtk_choose_colors(c, sl, sr, sm)); s.cnt[5] += rtk_clock() - t0; }
+        RTK_PL(s, 4);
         if (rtk_failed(s)) return;
         // keep all_pids for the reverse-complement call (rc = &fw): set[0] is preserved by everything below
     } else n_all = rtk_u(rc->n_all);
@@ -1625,6 +1656,7 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
     for (;;) {
         if (do_call) { const unsigned long long t0 = rtk_clock(); complete = rtk_u(rtk_extract_semi_weak(c, s_read, s_len, all_pids, n_all, p1, um1, p2, um2, lvw, lw_lo, lw_hi, first_call ? 0u : i_w_s, &n_partial)); n_partial = rtk_u(n_partial); s.cnt[6] += rtk_clock() - t0; }
         if (rtk_failed(s)) return;
+        RTK_PL(s, 22);
         if (first_call && complete != ~0ull) found_first = true;
         first_call = false;
         if (!(complete == ~0ull && n_partial != 0 && nlw != 0 && n_all >= c.o.min_cov_vertices)) break;
@@ -1654,6 +1686,7 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
         }
     }
     if (rtk_failed(s)) return;
+    RTK_PL(s, 23);
     if (!found_first) {
         if (complete != ~0ull) {
             const uint32_t pl = rtk_rec_to_string(c, complete, s.str[0]); if (pl == 0xFFFFFFFFu) return;
@@ -1689,7 +1722,9 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
         rtk_bm_add_range(res.bm, 0, len_weak_region);
     }
     if (rtk_failed(s)) return;
+    RTK_PL(s, 24);
     if (n_amb != 0) { const unsigned long long ta0 = rtk_clock(); rtk_fix_ambiguity(c, s_corr, sl_, q_corr, ql_, s_read + first_pos, res.old_len, n_amb); s.fine[9] += rtk_clock() - ta0; if (rtk_failed(s)) return; } // :716
+    RTK_PL(s, 25);
     if (rtk_bm_card(res.bm, res.old_len) == res.old_len) { // :718-725 (G20): last k-mer of the WHOLE read vs last k-mer of the corrected region
         bool same = sl_ >= k && s_len >= k;
         for (uint32_t i = 0; same && i < k; ++i) same = rtk_bifrost_code(s_read[s_len - k + i]) == rtk_bifrost_code(s_corr[sl_ - k + i]);
@@ -1706,6 +1741,7 @@ RTK_FN_REGION void rtk_correct_region(const RCtx& c_, const char* s_read_, uint3
         }
     }
     res.seq_len = sl_; res.qual_len = ql_;
+    RTK_PL(s, 26);
 }
 #endif
 
@@ -1757,6 +1793,7 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
     const RCtx& c = *rtk_u(&c_); const ResCorr* fw = rtk_u(fw_); const ResCorr* bw = rtk_u(bw_); RTK_ASSUME_LDS(fw); RTK_ASSUME_LDS(bw); const char* ref = rtk_u(ref_); uint32_t ref_len = rtk_u(ref_len_); double max_norm = rtk_u(max_norm_); char* out_s = rtk_u(out_s_); uint32_t* out_sl = rtk_u(out_sl_); char* out_q = rtk_u(out_q_); uint32_t* out_ql = rtk_u(out_ql_);
     RegionScratch& s = rtk_hdr(c);
     *out_sl = 0; *out_ql = 0;
+    RTK_PL(s, 28);
     const uint32_t nfw = rtk_bm_card(fw->bm, fw->old_len), nbw = rtk_bm_card(bw->bm, bw->old_len);
     auto take = [&](const ResCorr* r) { rtk_app(s, out_s, out_sl, r->seq, r->seq_len); rtk_app(s, out_q, out_ql, r->qual, r->qual_len); return true; };
     if (nbw == 0 && nfw != 0) return take(fw);
@@ -1768,6 +1805,7 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
     RTK_SITE(14); const MyersResult afw = rtk_align_path(c, fw->seq, fw->seq_len, ref, ref_len, RTK_MODE_NW, &nm_fw);
     if (rtk_failed(s) || nm_fw > s.str_cap) { rtk_fail_ovf(s, 7); return false; }
     rtk_wcopy(s.str[3], s.my.moves, nm_fw);
+    RTK_PL(s, 29);
     // Both directions usually arrive at the same corrected string: its alignment against the raw region is then the one just computed
     const bool same_strings = bw->seq_len == fw->seq_len && rtk_str_equal(bw->seq, fw->seq, fw->seq_len);
     MyersResult abw = afw;
@@ -1784,6 +1822,7 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
         if (n_fw > max_norm) return take(bw);
         return take(fw);
     }
+    RTK_PL(s, 30);
     CigCur cf, cb;
     cf.mv = reinterpret_cast<const uint8_t*>(s.str[3].get()); cf.n = nm_fw; cf.idx = 0; cf.qpos = 0; cf.rpos = 0;
     cb.mv = reinterpret_cast<const uint8_t*>(s.str[4].get()); cb.n = nm_bw; cb.idx = 0; cb.qpos = 0; cb.rpos = 0;
@@ -1807,6 +1846,7 @@ RTK_FN bool rtk_generate_consensus(const RCtx& c_, const ResCorr* fw_, const Res
         if (rout == i) { rtk_fail_ovf(s, 11); return false; } // no progress: would loop forever in the reference as well
         i = rout;
     }
+    RTK_PL(s, 31);
     if (max_norm > 0.0 && !rtk_failed(s)) {
         // The merged string is very often one of the two inputs again. Its distance to the raw region is then the one computed above --
         // provided the plain configuration of this last call (edlibDefaultAlignConfig, :460: no IUPAC equalities) cannot tell the two
@@ -1855,6 +1895,10 @@ RTK_DEV RegionScratch* region_scratch_carve(char* base, const RegionScratchCfg& 
     t.memo_v = reinterpret_cast<uint8_t*>(p); p += c.memo_cap;
     t.ovf_word = 0; t.overflow = reinterpret_cast<uint32_t*>(&s->ovf_word); t.my.overflow = t.overflow;
     for (int i = 0; i < 16; ++i) { t.cnt[i] = 0; t.fine[i] = 0; }
+#ifdef RTK_PROF
+    for (int i = 0; i < 48; ++i) t.prof[i] = 0;
+    t.prof_t = rtk_clock();
+#endif
 #ifndef RTK_SLIM_HDR
     for (int i = 0; i < 32; ++i) t.hist[i] = 0;
 #endif
@@ -1906,6 +1950,7 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
     };
     auto app_q = [&](uint32_t pos, uint32_t n, char fill) { if (lrc) rtk_app(s, out_q, &oql, q_fw + pos, n); else rtk_app_fill(s, out_q, &oql, fill, n); }; // q_fw.substr(pos, n) | string(n, fill)
     const uint32_t kind = rtk_u(rd->kind);
+    RTK_PL(s, 34);
     if (kind == RTK_RG_WHOLE_MAX || kind == RTK_RG_WHOLE_MIN) { // :165-171
         rtk_app(s, out_s, &osl, s_fw, L); app_q(0, L, kind == RTK_RG_WHOLE_MAX ? q_max : q_min);
     } else if (kind == RTK_RG_HEAD) { // :776-797
@@ -1933,6 +1978,7 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
             uint64_t mn, mx; rtk_min_max_len(len_unitig_km, c.o.weak_region_len_factor, &mn, &mx);
             sameUnitig = sameUnitig && ((ua.strand && (ua.dist < ub.dist)) || (!ua.strand && (ua.dist > ub.dist)));
             sameUnitig = sameUnitig && (len_query_km >= mn) && (len_query_km <= mx);
+            RTK_PL(s, 0);
             if (sameUnitig) {
                 UMap sub = ua; sub.dist = min_pos; sub.len = len_unitig_km + 1;
                 const uint32_t sl = rtk_ums_to_string(c, &sub, 1, s.str[0]); if (sl == 0xFFFFFFFFu) return;
@@ -1943,8 +1989,10 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
                     rtk_app(s, out_q, &oql, q_fw + prev_pos, pa - prev_pos + buff);
                     if (sl - buff - k > 0) rtk_app_fill(s, out_q, &oql, q_max, sl - buff - k);
                 } else rtk_app_fill(s, out_q, &oql, q_max, (pa - prev_pos) + (sl - k));
+                RTK_PL(s, 1);
             } else isUncorrected = true;
         } else if (pb >= pa + k) {
+            RTK_PL(s, 0);
             rtk_correct_region(c, s_fw, L, so, we, i, i_weak, nullptr, fw, q_fw);
             if (rtk_failed(s)) return;
             const uint32_t l_solid = pa - prev_pos;
@@ -1959,9 +2007,11 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
                 const uint32_t i_solid_bw = so.n - i - 2;
                 uint32_t i_weak_bw = we.n - i_weak;
                 i_weak_bw = rtk_an_first_gt(we_r, 0, i_weak_bw, rtk_an_pos(so_r, i_solid_bw));
+                RTK_PL(s, 27);
 { const uint32_t gl_ = pb - pa; RTK_HIST_ADD(s, 16 + (gl_ < 40 ? 0 : gl_ < 64 ? 1 : gl_ < 128 ? 2 : gl_ < 256 ? 3 : gl_ < 512 ? 4 : gl_ < 1024 ? 5 : 6), 1); }
                 rtk_correct_region(c, s_bw, L, so_r, we_r, i_solid_bw, i_weak_bw, &fw, bw, q_bw);
                 if (rtk_failed(s)) return;
+                RTK_PL(s, 27);
                 rtk_rc_reverse_complement(s, bw, s.bm[2], s.rbuf[6]);
                 if (bw.is_corrected) {
                     // l_solid = (|s_bw| - rev_pos(i_solid_bw + 1) - k) - prev_pos == pa - prev_pos
@@ -1972,6 +2022,7 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
                     const unsigned long long tc0 = rtk_clock();
                     const bool ok = rtk_generate_consensus(c, &fw, &bw, s_fw + pa, ref_len, c.o.weak_region_len_factor, s.rbuf[6], &csl, s.rbuf[7], &cql);
                     s.cnt[7] += rtk_clock() - tc0;
+                    RTK_PL(s, 32);
                     if (rtk_failed(s)) return;
                     if (!ok || csl == 0) { // raw region, k solid qualities then minimum quality (:898-904)
                         csl = 0; cql = 0;
@@ -2013,7 +2064,9 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
         else { rtk_app_fill(s, out_q, &oql, q_max, pa - prev_pos + k); rtk_app_fill(s, out_q, &oql, q_min, L - pa - k); }
     }
     if (rtk_failed(s)) return;
+    RTK_PL(s, 33);
     rtk_emit_segment(c, rd, out_s, osl, out_q, oql);
+    RTK_PL(s, 35);
 }
 
 // ------------------------------------------------------------------------------------------------ region enumeration (one wave per read)
