@@ -3,12 +3,16 @@
 
 A "step" is one pass of the whole hot path (exact k-mer scan -> mask -> 1-edit k-mer scan -> anchor filters -> region
 enumeration -> colour-guided BFS/DFS + Myers scoring -> stitch) over one batch of synthetic long reads that is already
-resident in HBM when the timed region starts (rtk_batch_create is outside, rtk_batch_run inside). Workload = BASELINE.json
-configs[1]: 5 Mb random reference, 30x PE 150 bp short reads (0.5 % substitutions), 30x ONT-R9.4-profile long reads,
-k = 31 first pass; the index is built on the CPU by the repo's own index producer, correction runs on the GPU.
+resident in HBM when the timed region starts (rtk_batch_create is outside, rtk_batch_run inside).
+
+Workload at every N: the HG002-chr20-scale set BASELINE.json's target is written on (configs[2]'s graph: 60 Mb diploid random
+reference, 0.1 % heterozygous SNPs, 30x PE 150 bp short reads at 0.5 % substitutions, ONT-R9.4-profile long reads, k = 31 first
+pass; it fits one GPU). The index is built by the repo's own index producer (k-mers counted on the device), correction runs on
+the GPU. At N = 1 the same run also measures configs[1] (5 Mb haploid reference) as the extra leg `config1`.
 
 N > 1 (torch.distributed.run, one rank per GPU, RCCL): rank 0 loads the flat graph and broadcasts its buffers once; long
-reads are sharded by batch ticket (rank r takes batches r, r+N, ...), no collective on the data path -> weak scaling.
+reads are sharded by batch ticket (rank r takes batches r, r+N, ...), no collective on the data path -> weak scaling. Before
+the sharded run rank 0 measures the one-GPU rate on this very graph in the same process (`config.n1_on_this_graph`).
 
 Prints ONE JSON line on rank 0 (see the driver contract), with `roofline` for the dominant kernel (algorithmic bytes /
 HIP-event duration measured here) and `cpu_baseline` (the oracle, multithreaded, on a bounded sample; N = 1 only).
@@ -36,9 +40,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--serial", action="store_true", help="run the two stages of every step back to back (no overlap between steps)")
-    ap.add_argument("--ref-len", type=int, default=None, help="reference length; default: 5 Mb at N = 1 (configs[1]), 60 Mb at N > 1 (configs[2], the graph the multi-GPU run of BASELINE.json is quoted on)")
-    ap.add_argument("--het", type=float, default=None, help="heterozygous SNP rate of the diploid reference; default: 0 at N = 1 (configs[1]), 0.001 at N > 1 (configs[2])")
-    ap.add_argument("--config2", action="store_true", help="N = 1 on the configs[2] graph (60 Mb diploid): the first point of the scaling series measured on the same graph as N > 1")
+    ap.add_argument("--ref-len", type=int, default=60_000_000, help="reference length of the main workload (default: the 60 Mb chr20-scale set of configs[2], at every N)")
+    ap.add_argument("--het", type=float, default=None, help="heterozygous SNP rate of the diploid reference (default 0.001; 0 with --config1-only)")
+    ap.add_argument("--config2", action="store_true", help="(accepted for older scripts: the 60 Mb set is the default workload now)")
+    ap.add_argument("--config1-only", action="store_true", help="main workload = configs[1] (5 Mb haploid reference): the quick developer line, A/B runs of kernel builds")
+    ap.add_argument("--no-config1-leg", action="store_true", help="N = 1: skip the extra configs[1] measurement")
     ap.add_argument("--batch-bases", type=int, default=64_000_000, help="long-read bases per step (per GPU)")
     ap.add_argument("--cpu-sample-bases", type=int, default=16_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -49,18 +55,19 @@ def parse():
     ap.add_argument("--plain-index", action="store_true", help="index without SNP annotations (like the reference's `index -F`); for A/B measurements only")
     ap.add_argument("--sim", action="store_true", help="CPU-only developer simulator + gloo (tests of the N>1 plumbing); never a benchmark")
     a = ap.parse_args()
-    big = a.gpus > 1 or a.config2
-    if a.ref_len is None:
-        a.ref_len = 60_000_000 if big else 5_000_000
+    if a.config1_only:
+        a.ref_len = 5_000_000 if a.ref_len == 60_000_000 else a.ref_len
+        a.het = 0.0 if a.het is None else a.het
+        a.no_config1_leg = True
     if a.het is None:
-        a.het = 0.001 if big else 0.0
+        a.het = 0.001
     return a
 
 
-def make_dataset(workdir, ref_len, lr_bases, snps=True, het=0.0, fast="--gpu"):
+def make_dataset(workdir, ref_len, lr_bases, snps=True, het=0.0, fast="--gpu", name="c2"):
     """Seeded synthetic inputs + index in the reference's file formats."""
     bin_dir = os.path.join(ROOT, "ratatosk_amd", "bin")
-    pre = os.path.join(workdir, "c2")
+    pre = os.path.join(workdir, name)
     lr_cov = max(1.0, float(lr_bases) / ref_len)
     subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "2", "--ref-len", str(ref_len), "--sr-cov", "30",
                            "--sr-err", "0.005", "--lr-cov", "%.3f" % lr_cov, "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07"] + (["--het", "%g" % het] if het > 0 else []), stderr=subprocess.DEVNULL)
@@ -110,21 +117,6 @@ def pmc_traffic(kernel):
         return int(2.0 * k["fetch_bytes_per_launch_raw"] + k["write_bytes_per_launch_raw"]), os.path.relpath(best[1], ROOT)
     except Exception:
         return None, None
-
-
-def same_graph_n1():
-    """N > 1 runs configs[2] (60 Mb diploid graph), the default N = 1 line configs[1] (the metric's config): a step on the diploid graph costs
-    ~1.5 x a step on configs[1] (more and longer weak regions, SNP annotations), so the two are not points of one scaling curve. The committed
-    one-GPU measurement on the configs[2] graph (`bench.py --config2`, profiles/rNN_bench_config2.json) is the N = 1 point that belongs to it."""
-    import glob
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_config2.json")))
-    if not fs:
-        return None
-    try:
-        d = json.loads(open(fs[-1]).read().strip().splitlines()[-1])
-        return {"value": d["value"], "ms_per_step": d["ms_per_step"], "source": os.path.relpath(fs[-1], ROOT) + " (python bench.py --config2)"}
-    except Exception:
-        return None
 
 
 def host_inclusive_leg(a, api, graph, opts, tickets):
@@ -193,7 +185,8 @@ def cli_leg(a, pre, fa, rt):
         with open(pre + ".lr.fq", "rb") as f:  # pipeline has to reach its steady state (the first tickets pay for the pinned staging buffers, the
             one = f.read()                      # device buffer pool and the first launches: ~0.3 s)
         with open(lst, "wb") as f:
-            for _ in range(48):
+            reps = max(2, min(48, int(7.2e9 // max(1, len(one) // 2))))  # ~7 Gb of bases (a FASTQ record is ~2 bytes per base)
+            for _ in range(reps):
                 f.write(one)
         del one
         r = subprocess.run([exe, "correct", "-1", "-c", str(cores), "--gpus", "1", "-g", fa, "-d", rt, "-l", lst, "-o", out], capture_output=True, text=True, env=env, timeout=600)
@@ -202,7 +195,7 @@ def cli_leg(a, pre, fa, rt):
             return {"error": (r.stderr or r.stdout)[-300:]}
         res = {"value": int(m.group(3)) / float(m.group(2)), "unit": "bases/s", "bases": int(m.group(3)), "correction_phase_s": float(m.group(2)), "graph_load_upload_s": float(m.group(1)),
                "workers_per_gpu": int(m.group(6)), "thread_seconds": {"parse": float(m.group(7)), "pack+gpu+fetch": float(m.group(8)), "format": float(m.group(9)), "write": float(m.group(10))},
-               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in (one file: the generated reads 48 times, parsed as byte ranges by the -c threads), OUT.2.fastq out (input order, FASTQ blocks formatted and written with pwrite by formatter threads), wall time of the correction phase" % cores}
+               "what": "Ratatosk correct -1 -c %d --gpus 1, plain FASTQ in (one file: the generated reads repeated up to ~7 Gb, parsed as byte ranges by the -c threads), OUT.2.fastq out (input order, FASTQ blocks formatted and written with pwrite by formatter threads), wall time of the correction phase" % cores}
         for fn in (out + ".2.fastq", lst):
             try:
                 os.remove(fn)
@@ -299,33 +292,42 @@ def cpu_baseline_leg(a, api, graph, opts, fa, rt, tickets, whole_alg, out):
             "sample": "%d reads / %d bases of step 0 (best of the two legs below)" % (best["reads"], best["bases"]), "legs": legs, "parity_on_sample": got == want}
 
 
-def main():
-    a = parse()
+PMC_NOTE = "from the committed rocprofv3 --pmc passes of this workload (profiles/rNN_pmc_summary.json): counters cannot be collected inside a timed run"
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz; a wave64 VALU instruction issues over 2 cycles
+
+
+def pmc_issue(kernel, avg_ms):
+    """Issue-slot use of `kernel`: (VALU + SALU wave-instructions per launch, from the committed SQ counter pass) / (SIMDs x clock x launch
+    time / 2 cycles per wave64 instruction). Says how far "latency-bound" is from "issue-bound"."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")):
+        m = re.search(r"r(\d+)_pmc_summary", f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    try:
+        sq = json.load(open(best[1]))["kernels"][kernel]["sq"]
+        n = float(sq["SQ_INSTS_VALU"]) + float(sq["SQ_INSTS_SALU"])
+        return round(n / (SIMDS * CLOCK_HZ * avg_ms * 1e-3 / 2.0), 4), int(n)
+    except Exception:
+        return None, None
+
+
+def run_workload(a, ctx, ref_len, het, name, steps, warmup, n1_first=False):
+    """One workload through the timed loop: dataset + index (rank 0), graph replicated, batches resident in HBM, W warm-up steps, K timed
+    steps bracketed by synchronize + barrier. Returns everything the JSON line is made of."""
     import torch
     import torch.distributed as dist
     from ratatosk_amd import api, dist as rdist
-
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    lib_path = os.path.join(ROOT, "tests", "hostsim", "librtk_hostsim.so") if a.sim else None
-    if not a.sim and not torch.cuda.is_available():
-        raise SystemExit("bench.py: no GPU visible (the hot path has no CPU fallback)")
-    device = 0 if a.sim else local_rank
-    if not a.sim:
-        torch.cuda.set_device(device)
-    if world > 1:
-        dist.init_process_group(backend="gloo" if a.sim else "nccl")
-    api.load_library(lib_path)
-
-    # ---- inputs (untimed): rank 0 generates, everyone reads its shard of the long reads ----
-    n_batches = a.steps + a.warmup
-    need_bases = a.batch_bases * n_batches * world
+    rank, world, device, lib_path = ctx["rank"], ctx["world"], ctx["device"], ctx["lib_path"]
+    n_batches = steps + warmup
+    # distinct tickets: two per rank are enough to overlap consecutive steps; at N = 1 up to four (30x of a 60 Mb reference would give 28)
+    lr_bases = int(2.3 * a.batch_bases * world) + 200_000 if world > 1 else min(a.batch_bases * n_batches, 30 * ref_len, int(4.3 * a.batch_bases) + 200_000)
     if rank == 0:
-        workdir = a.workdir or tempfile.mkdtemp(prefix="rtk_bench_")
+        workdir = ctx["workdir"]
         t0 = time.time()
-        # 30x of long reads (configs[1]) gives two tickets; with N ranks every rank gets two tickets of its OWN (2N distinct tickets:
-        # the long-read coverage of the synthetic set grows with N, the graph and the per-rank work stay those of configs[1])
-        lr_bases = int(2.3 * a.batch_bases * world) + 200_000 if world > 1 else min(need_bases, 30 * a.ref_len) # N > 1: at least 2 distinct tickets per rank (a ticket ends with the read that fills it)
-        pre = make_dataset(workdir, a.ref_len, lr_bases, snps=not a.plain_index, het=a.het, fast="" if a.sim else "--gpu")
+        pre = make_dataset(workdir, ref_len, lr_bases, snps=not a.plain_index, het=het, fast="" if a.sim else "--gpu", name=name)
         t_data = time.time() - t0
     else:
         pre, t_data = None, 0.0
@@ -338,12 +340,11 @@ def main():
     repl = {}
     graph = rdist.load_graph_replicated(fa, rt, 31, rank, world, device, lib_path=lib_path, report=repl)
     t_graph = time.time() - t0
-    info = graph.info()
-    seqs, quals = read_long_reads(pre + ".lr.fq", max(need_bases, int(2.3 * a.batch_bases * world) + 200_000) if world > 1 else need_bases)
+    seqs, quals = read_long_reads(pre + ".lr.fq", lr_bases)
     # batches by ticket: consecutive reads until >= batch_bases; rank r owns tickets r, r+N, ...
     tickets, cur_s, cur_q, cur = [], [], [], 0
-    for s, q in zip(seqs, quals):
-        cur_s.append(s); cur_q.append(q); cur += len(s)
+    for s_, q_ in zip(seqs, quals):
+        cur_s.append(s_); cur_q.append(q_); cur += len(s_)
         if cur >= a.batch_bases:
             tickets.append((cur_s, cur_q)); cur_s, cur_q, cur = [], [], 0
     if cur_s and not tickets:
@@ -362,23 +363,37 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def timed(seq_b, serial):
+        t0_ = time.time()
+        if serial:
+            for b in seq_b:
+                b.run(opts)
+        else:
+            api.run_pipelined(seq_b, opts)
+        return t0_
+
     # a step = one batch through both stages. Consecutive steps are software-pipelined on two HIP streams: while the region kernels of
     # step s run, the (latency-bound) seed kernels of step s+1 run beside them. All K steps are complete before the clock stops.
-    api.run_pipelined([batches[w % len(batches)] for w in range(a.warmup)], opts)
+    api.run_pipelined([batches[w % len(batches)] for w in range(warmup)], opts)
     sync()
-    t0 = time.time()
-    seq_b = [batches[(a.warmup + st) % len(batches)] for st in range(a.steps)]
-    done_bases, stats = 0, []
-    if a.serial:
-        for b in seq_b:
-            b.run(opts)
-    else:
-        api.run_pipelined(seq_b, opts)
+    n1 = None
+    if n1_first and world > 1:
+        # the N = 1 point of THIS graph, measured in this process before the sharded run: rank 0 runs K steps alone, the other ranks wait
+        if rank == 0:
+            seq_1 = [batches[(warmup + st) % len(batches)] for st in range(steps)]
+            t0 = timed(seq_1, a.serial)
+            if not a.sim:
+                torch.cuda.synchronize()
+            dt1 = time.time() - t0
+            b1 = sum(b.in_bases for b in seq_1)
+            n1 = {"value": b1 / dt1 if dt1 > 0 else 0.0, "ms_per_step": 1e3 * dt1 / max(1, steps), "steps": steps, "measured": "in this run, on rank 0 alone (the other ranks idle at a barrier), same graph, same tickets, before the sharded steps"}
+        sync()
+    seq_b = [batches[(warmup + st) % len(batches)] for st in range(steps)]
+    t0 = timed(seq_b, a.serial)
     sync()
     dt = time.time() - t0
-    for b in seq_b:
-        done_bases += b.in_bases
-        stats.append(b.stats())
+    done_bases = sum(b.in_bases for b in seq_b)
+    stats = [b.stats() for b in seq_b]
     # per-kernel times of a step on an otherwise idle GPU (after the clock has stopped): in the timed region two batches overlap, and the
     # HIP-event span of the seed kernels of one then includes their wait for wave slots behind the other's persistent region kernel
     stats_serial = []
@@ -397,10 +412,40 @@ def main():
     else:
         dt_all, bases_all = dt, float(done_bases)
         per_rank = [{"rank": 0, "device": device, "bases": int(done_bases), "seconds": round(dt, 4), "distinct_tickets": len(mine), "shared_tickets": shared_tickets}]
+    for b in batches:
+        b.close()
+    return {"pre": pre, "fa": fa, "rt": rt, "graph": graph, "info": graph.info(), "opts": opts, "mine": mine, "repl": repl, "t_data": t_data, "t_graph": t_graph,
+            "dt_all": dt_all, "bases_all": bases_all, "per_rank": per_rank, "stats": stats, "stats_serial": stats_serial, "n1": n1}
+
+
+KERN = {"k_lookup_exact": "ms_lookup_exact", "k_mask": "ms_mask", "k_inexact": "ms_lookup_inexact", "k_finalize": "ms_seeds", "k_regions": "ms_correct", "k_stitch": "ms_stitch"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from ratatosk_amd import api
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    lib_path = os.path.join(ROOT, "tests", "hostsim", "librtk_hostsim.so") if a.sim else None
+    if not a.sim and not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible (the hot path has no CPU fallback)")
+    device = 0 if a.sim else local_rank
+    if not a.sim:
+        torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group(backend="gloo" if a.sim else "nccl")
+    api.load_library(lib_path)
+    ctx = {"rank": rank, "world": world, "device": device, "lib_path": lib_path, "workdir": (a.workdir or tempfile.mkdtemp(prefix="rtk_bench_")) if rank == 0 else None}
+
+    diploid = a.het > 0
+    w = run_workload(a, ctx, a.ref_len, a.het, "c2" if diploid else "c1", a.steps, a.warmup, n1_first=True)
+    stats, stats_serial, info = w["stats"], w["stats_serial"], w["info"]
 
     if rank == 0:
         # ---- roofline of the dominant kernel, from the HIP-event times of this very run ----
-        kern = {"k_lookup_exact": "ms_lookup_exact", "k_mask": "ms_mask", "k_inexact": "ms_lookup_inexact", "k_finalize": "ms_seeds", "k_regions": "ms_correct", "k_stitch": "ms_stitch"}
+        kern = KERN
         tot = {k_: sum(s[v] for s in stats) for k_, v in kern.items()}
         dom = max(tot, key=tot.get)
         n_l = max(1, len(stats))
@@ -416,30 +461,51 @@ def main():
         }
         achieved = alg[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dom)
+        issue_frac, issue_n = pmc_issue(dom, avg_ms)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
+                    "traffic": traffic, "traffic_source": traffic_src, "traffic_note": PMC_NOTE if traffic is not None else None,
+                    "issue_frac": issue_frac, "issue_wave_instructions_per_launch": issue_n, "issue_frac_is": "(SQ_INSTS_VALU + SQ_INSTS_SALU of the committed PMC pass) / (1024 SIMDs x 2.4 GHz x this run's launch time / 2 cycles per wave64 instruction)",
+                    "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
                     "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()},
                     "kernel_ms_per_step_is": "HIP-event spans inside the timed region, where consecutive steps overlap on two streams: the spans of k_mask / k_inexact / k_finalize include waiting for wave slots behind the other step's persistent k_regions; kernel_ms_per_step_serial has the same kernels with one step at a time",
-                    "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in stats_serial) / len(stats_serial), 3) for k_, v in kern.items()} if stats_serial else None), "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")), "index_lookups_inexact_per_step": int(S("n_probes_inexact")), "index_slots_inexact_per_step": int(S("n_slots_inexact")), "k_regions_wave_cycle_share": {kk: round(S(kk) / max(1.0, S("cyc_total")), 3) for kk in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "cyc_walk")}, "alignment_moves_per_step": int(S("n_moves")), "k_regions_wave_ticks_per_step": int(S("cyc_total")), "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
+                    "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in stats_serial) / len(stats_serial), 3) for k_, v in kern.items()} if stats_serial else None), "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")),
+                    "index_lookups_inexact_per_step": int(S("n_probes_inexact")), "index_slots_inexact_per_step": int(S("n_slots_inexact")),
+                    "k_regions_wave_cycle_share": {k_: round(S(k_) / max(1.0, S("cyc_total")), 3) for k_ in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "cyc_walk")},
+                    "alignment_moves_per_step": int(S("n_moves")), "k_regions_wave_ticks_per_step": int(S("cyc_total")), "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
         whole_alg = (8.0 * S("n_probes_exact") + 16.0 * (S("n_slots_exact") + S("n_slots_inexact")) + 40.0 * S("n_expand") + 4.0 * S("n_colour_elem") + 0.25 * S("n_path_base") + 4.0 * S("in_bases")) / max(1.0, S("in_bases"))
+        dt_all, bases_all = w["dt_all"], w["bases_all"]
+        set_name = ("HG002-chr20-scale set (configs[2]'s graph): k=31 first pass, %.1f Mb diploid random ref (%.2f %% het SNPs)" % (a.ref_len / 1e6, 100 * a.het)) if diploid else ("configs[1]: k=31 first-pass correct, %.1f Mb random ref" % (a.ref_len / 1e6))
         out = {
             "metric": "corrected long-read bases/sec", "value": bases_all / dt_all if dt_all > 0 else 0.0, "unit": "bases/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt_all / max(1, a.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("configs[2]: k=31 first pass sharded across %d MI355X, %.1f Mb diploid random ref (%.2f %% het SNPs), 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU, >= 2 distinct tickets per GPU" % (world, a.ref_len / 1e6, 100 * a.het, a.batch_bases))
-                                   if (world > 1 or a.config2) else ("configs[1]: k=31 first-pass correct, %.1f Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU" % (a.ref_len / 1e6, a.batch_bases)),
-                       "graph_replication": repl or None,
-                       "n1_on_this_graph": same_graph_n1() if (world > 1 or a.config2) else None,
-                       "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated (one RCCL broadcast per flat buffer)" % world, "per_rank": per_rank,
+            "ms_per_step": 1e3 * dt_all / max(1, a.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "vs_baseline_note": "null: BASELINE.md holds no published number for this metric and the reference binary cannot be built here (Bifrost, its un-vendored submodule, is absent), so the north_star's '>= 10x the reference CPU' cannot be evaluated against the real binary; cpu_baseline is this repo's port of the path",
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step/GPU%s" % (set_name, a.batch_bases, (", sharded across %d MI355X, >= 2 distinct tickets per GPU" % world) if world > 1 else ", 1 MI355X"),
+                       "graph_replication": w["repl"] or None,
+                       "n1_on_this_graph": w["n1"],
+                       "graph": {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "hbm_bytes": int(info.hbm_bytes)}, "parallelism": "reads sharded by ticket x%d, graph replicated (one RCCL broadcast per flat buffer)" % world, "per_rank": w["per_rank"],
                        "value_is": "kernel-resident throughput: batches packed and in HBM before the clock starts (the contract's definition); the host-buffer-to-host-buffer rate is host_inclusive, the file-to-file rate cli_file_to_file",
-                       "alg_bytes_per_base": round(whole_alg, 1), "setup_s": {"data+index": round(t_data, 1), "graph_load+upload": round(t_graph, 1)}},
+                       "alg_bytes_per_base": round(whole_alg, 1), "setup_s": {"data+index": round(w["t_data"], 1), "graph_load+upload": round(w["t_graph"], 1)}},
             "roofline": roofline,
         }
         if world == 1 and not a.no_host_legs:
-            out["host_inclusive"] = host_inclusive_leg(a, api, graph, opts, mine)
-            out["cli_file_to_file"] = cli_leg(a, pre, fa, rt)
-            out["second_pass"] = second_pass_leg(a, pre)
+            out["host_inclusive"] = host_inclusive_leg(a, api, w["graph"], w["opts"], w["mine"])
+            out["cli_file_to_file"] = cli_leg(a, w["pre"], w["fa"], w["rt"])
+            out["second_pass"] = second_pass_leg(a, w["pre"])
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_leg(a, api, graph, opts, fa, rt, mine, whole_alg, out)
+            out["cpu_baseline"] = cpu_baseline_leg(a, api, w["graph"], w["opts"], w["fa"], w["rt"], w["mine"], whole_alg, out)
+    w["graph"].close()
+    if world == 1 and not a.no_config1_leg:
+        # the metric's other single-GPU configuration, in the same run: configs[1] (5 Mb haploid reference; its graph sits largely in the caches)
+        w1 = run_workload(a, ctx, 5_000_000, 0.0, "c1", a.steps, a.warmup)
+        n1_ = max(1, len(w1["stats"]))
+        out["config1"] = {"workload": "configs[1]: k=31 first-pass correct, 5.0 Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step, same steps / warm-up / overlap as the main line" % a.batch_bases,
+                          "value": w1["bases_all"] / w1["dt_all"] if w1["dt_all"] > 0 else 0.0, "unit": "bases/s", "ms_per_step": 1e3 * w1["dt_all"] / max(1, a.steps),
+                          "kernel_ms_per_step": {k_: round(sum(s_[v] for s_ in w1["stats"]) / n1_, 3) for k_, v in KERN.items()},
+                          "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in w1["stats_serial"]) / len(w1["stats_serial"]), 3) for k_, v in KERN.items()} if w1["stats_serial"] else None),
+                          "graph": {"unitigs": int(w1["info"].n_unitigs), "kmers": int(w1["info"].n_kmers), "hbm_bytes": int(w1["info"].hbm_bytes)}}
+        w1["graph"].close()
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -54,7 +54,8 @@ typedef struct rtk_opts {
     /* Bifrost assumption [A2] as a switch (the reference calls searchSequence(l_s, false, true, true, true, or_exclusive_match = true),
      * src/Graph.cpp:193, and Bifrost is not in the tree): 0 = every graph k-mer one substitution / insertion / deletion away from a window is
      * reported (union of the three searches); 1 = the searches run substitution -> insertion -> deletion and a window that one of them
-     * matched is not searched by the next. rtk_opts_default takes it from the environment: RTK_A2_XOR=union (default) | exclusive. */
+     * matched is not searched by the next; 2 = the same in the order insertion -> deletion -> substitution. rtk_opts_default takes it from the
+     * environment: RTK_A2_XOR=exclusive (default since round 4: the reading the flag's name asks for) | exclusive-ids | union. */
     int32_t a2_exclusive;
     /* Bifrost assumption [A3] as a switch: the order in which getSuccessors() hands out the (up to four) neighbours of a unitig end, which is the
      * order exploreSubGraph pushes them (src/GraphTraversal.cpp:456-587) and so decides between candidates of equal score. 0 = by the base

@@ -128,6 +128,7 @@ void Graph::load(const std::string& fasta_gz, const std::string& rtsk, int k_) {
         if (in_rec) seq.push_back(cur);
     }
     gzclose(f);
+    if (k <= 31) { size_t nk = 0; for (size_t u = 0; u < seq.size(); ++u) if (seq[u].size() >= static_cast<size_t>(k)) nk += seq[u].size() - k + 1; kmap.reserve(nk); }
     for (size_t u = 0; u < seq.size(); ++u) {
         std::string& s = seq[u];
         for (size_t i = 0; i < s.size(); ++i) s[i] = static_cast<char>(s[i] & 0xDF);
@@ -150,7 +151,7 @@ void Graph::load(const std::string& fasta_gz, const std::string& rtsk, int k_) {
                 const uint64_t rc = rc_code(fw, k);
                 const uint64_t can = fw < rc ? fw : rc;
                 const uint64_t val = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(i + 1 - k) << 1) | (fw < rc ? 1ULL : 0ULL);
-                if (!kmap.insert(std::make_pair(can, val)).second) throw std::runtime_error("oracle: duplicate k-mer across unitigs (input is not a compacted dBG)");
+                if (!kmap.insert(can, val)) throw std::runtime_error("oracle: duplicate k-mer across unitigs (input is not a compacted dBG)");
             }
         }
     }
@@ -199,11 +200,11 @@ void Graph::load(const std::string& fasta_gz, const std::string& rtsk, int k_) {
 UM Graph::findKmerCode(uint64_t fw) const {
     const uint64_t rc = rc_code(fw, k);
     const uint64_t can = fw < rc ? fw : rc;
-    std::unordered_map<uint64_t, uint64_t>::const_iterator it = kmap.find(can);
-    if (it == kmap.end()) return UM();
-    const bool stored_is_can = it->second & 1ULL;
+    const uint64_t* it = kmap.find(can);
+    if (!it) return UM();
+    const bool stored_is_can = *it & 1ULL;
     const bool query_is_can = (fw <= rc);
-    return UM(static_cast<int32_t>(it->second >> 32), static_cast<uint32_t>((it->second & 0xFFFFFFFFULL) >> 1), 1, stored_is_can == query_is_can);
+    return UM(static_cast<int32_t>(*it >> 32), static_cast<uint32_t>((*it & 0xFFFFFFFFULL) >> 1), 1, stored_is_can == query_is_can);
 }
 
 static const char kIupac[17] = ".ACMGRSVTWYHKDBN";

@@ -11,9 +11,14 @@
 //          "insertion"   k-1 read bases read[p..p+k-1) plus one inserted base (read lacks a base);
 //          "deletion"    k+1 read bases read[p..p+k+1) minus one interior base (read has an extra base);
 //        a window touching a non-ACGT character never matches.
-//        The call passes or_exclusive_match = true (src/Graph.cpp:193). Two readings, switchable at run time (RTK_A2_XOR=union|exclusive, read by
-//        oracle_seeds.cpp and by rtk_opts_default on the device side): union (default) = the hits of all three kinds; exclusive = per window only
-//        the hits of the first kind that has any (substitution, then insertion, then deletion). tests/test_a2_switch.py holds both to each other.
+//        The call passes or_exclusive_match = true (src/Graph.cpp:193: searchSequence(l_s, exact = false, insertion, deletion, substitution, or_exclusive_match)).
+//        Three readings, switchable at run time (RTK_A2_XOR, read by oracle_seeds.cpp and by rtk_opts_default on the device side):
+//          exclusive (default since round 4: what the flag's name says) = per window the kinds of edit are searched one after the other and a window one
+//            kind has matched is not searched with the next: substitution, then insertion, then deletion (the order of the blocks of Bifrost's
+//            published searchSequence as we remember it: a Roaring set of matched positions grows block by block);
+//          exclusive-ids = the same with the kinds in the order of the function's parameters (insertion, deletion, substitution);
+//          union = the hits of all three kinds (the default of rounds 1-3).
+//        tests/test_a2_switch.py holds oracle and device to each other under every reading; profiles/r04_a2_count.json counts what they decide.
 //   [A3] getSuccessors(): existing neighbours of the unitig end in walk direction, base order A,C,G,T,
 //        as whole-unitig mappings (dist=0, len=size-k+1).
 //        Switchable at run time (RTK_A3_ORDER=walk|strand; rtk_opts::a3_strand_order on the device side): walk (default) = by the base appended in
@@ -67,12 +72,31 @@ struct UnitigInfo { // restatement of the read side of src/UnitigData.hpp:258-49
     UnitigInfo() : kmcov(0), shared(0), global_id(-1), has_ambiguity(false) {}
 };
 
+// canonical k-mer (k <= 31: never all ones) -> value; open addressing, sized once from the number of k-mers of the unitigs. (A node-based
+// std::unordered_map took minutes and several GB on the 60 Mb graphs of the bench / configs[2] tests; same contents, same answers.)
+struct KmerMap64 {
+    std::vector<uint64_t> keys, vals; size_t n, mask;
+    KmerMap64() : n(0), mask(0) {}
+    void clear() { keys.clear(); vals.clear(); n = 0; mask = 0; }
+    void reserve(size_t want) { size_t cap = 16; while (cap < 2 * want + 16) cap <<= 1; keys.assign(cap, ~0ULL); vals.assign(cap, 0); n = 0; mask = cap - 1; }
+    static uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+    bool insert(uint64_t key, uint64_t val) { // false if the key is there already
+        if (keys.empty()) reserve(1024);
+        if (2 * (n + 1) > keys.size()) { KmerMap64 b; b.reserve(2 * n + 16); for (size_t i = 0; i < keys.size(); ++i) if (keys[i] != ~0ULL) b.insert(keys[i], vals[i]); keys.swap(b.keys); vals.swap(b.vals); mask = b.mask; }
+        size_t i = mix(key) & mask;
+        while (keys[i] != ~0ULL) { if (keys[i] == key) return false; i = (i + 1) & mask; }
+        keys[i] = key; vals[i] = val; ++n; return true;
+    }
+    const uint64_t* find(uint64_t key) const { if (keys.empty()) return nullptr; size_t i = mix(key) & mask; while (keys[i] != ~0ULL) { if (keys[i] == key) return &vals[i]; i = (i + 1) & mask; } return nullptr; }
+    size_t size() const { return n; }
+};
+
 struct Graph {
     int k;
     std::vector<std::string> seq;
     std::vector<UnitigInfo> info;
     std::vector<IdSet> globals;
-    std::unordered_map<uint64_t, uint64_t> kmap; // canonical k-mer -> unitig<<32 | offset<<1 | (stored orientation == canonical)
+    KmerMap64 kmap; // canonical k-mer -> unitig<<32 | offset<<1 | (stored orientation == canonical)
     std::unordered_map<std::string, uint64_t> kmap_w; // the same for k in 33..63 (second pass, k2 = 63), keyed by the canonical k-mer as TEXT
 
     // loads PREFIX unitig FASTA(.gz) + .rtsk (formats: SURVEY.md Appendix B). Throws std::runtime_error.

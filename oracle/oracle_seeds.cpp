@@ -110,28 +110,29 @@ std::vector<Anchor> searchInexact(const Graph& g, const std::string& m, Counters
         const uint64_t key = (static_cast<uint64_t>(um.unitig) << 33) | (static_cast<uint64_t>(um.dist) << 1) | (um.strand ? 1ULL : 0ULL);
         if (seen.insert(std::make_pair(p, key)).second) v.push_back(Anchor(p, um));
     };
-    // [A2] as a switch (both readings of Bifrost's or_exclusive_match are kept under test, oracle_graph.hpp): RTK_A2_XOR=exclusive searches
-    // substitution -> insertion -> deletion and does not search a window with the next kind of edit once one kind has matched it
+    // [A2] as a switch (the readings of Bifrost's or_exclusive_match are kept under test, oracle_graph.hpp). RTK_A2_XOR=union: the hits of all three
+    // kinds of edit; exclusive (default): a window is not searched with the next kind once one kind has matched it, kinds in the order substitution ->
+    // insertion -> deletion; exclusive-ids: the same with the kinds in the order insertion -> deletion -> substitution
     const char* a2 = getenv("RTK_A2_XOR");
-    const bool exclusive = a2 && !strcmp(a2, "exclusive");
+    const int mode = (a2 && !strcmp(a2, "union")) ? 0 : ((a2 && !strcmp(a2, "exclusive-ids")) ? 2 : 1);
     for (size_t p = 0; p + k <= n; ++p) {
         if (run[p] + 1 < k) continue; // fewer than k-1 usable characters: no variant exists
         const size_t n_before = v.size();
-        if (run[p] >= k) { // substitutions
-            for (size_t o = 0; o < k; ++o) {
+        auto subs = [&]() {
+            if (run[p] >= k) for (size_t o = 0; o < k; ++o) {
                 km.assign(m, p, k);
                 for (int b = 0; b < 4; ++b) { if ("ACGT"[b] == m[p + o]) continue; km[o] = "ACGT"[b]; probe(p); }
             }
-        }
-        if (!(exclusive && v.size() != n_before)) { // graph k-mer has one extra base w.r.t. the read ("insertion" in Bifrost's terms)
-            for (size_t o = 0; o < k; ++o) for (int b = 0; b < 4; ++b) {
-                km.assign(m, p, o); km.push_back("ACGT"[b]); km.append(m, p + o, k - 1 - o);
-                probe(p);
-            }
-        }
-        if (run[p] >= k + 1 && !(exclusive && v.size() != n_before)) { // graph k-mer lacks one interior read base ("deletion")
-            for (size_t o = 1; o + 1 <= k - 1; ++o) { km.assign(m, p, o); km.append(m, p + o + 1, k - o); probe(p); }
-        }
+        };
+        auto inss = [&]() { // graph k-mer has one extra base w.r.t. the read ("insertion" in Bifrost's terms)
+            for (size_t o = 0; o < k; ++o) for (int b = 0; b < 4; ++b) { km.assign(m, p, o); km.push_back("ACGT"[b]); km.append(m, p + o, k - 1 - o); probe(p); }
+        };
+        auto dels = [&]() { // graph k-mer lacks one interior read base ("deletion")
+            if (run[p] >= k + 1) for (size_t o = 1; o + 1 <= k - 1; ++o) { km.assign(m, p, o); km.append(m, p + o + 1, k - o); probe(p); }
+        };
+        const bool excl = mode != 0;
+        if (mode == 2) { inss(); if (!(excl && v.size() != n_before)) dels(); if (!(excl && v.size() != n_before)) subs(); }
+        else { subs(); if (!(excl && v.size() != n_before)) inss(); if (!(excl && v.size() != n_before)) dels(); }
     }
     return v;
 }

@@ -45,7 +45,7 @@ struct MyersScratch {
     U<uint8_t*> moves_tmp;  // [mv_cap]
     U<uint32_t> mv_cap;
     U<int32_t*> hstack;     // [5 * 64] explicit Hirschberg stack
-    U<uint32_t*> overflow;  // set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
+    UL<uint32_t*> overflow; // (device memory, or the header's own word in LDS) set to non-zero when a capacity is exceeded (work item is re-run with a bigger arena)
     U<uint32_t> tb_gen;     // bumped by everything that writes the traceback table: a saved sweep (MyersSaved) is only resumed on its own table
     U<unsigned long long> walk_cycles, walk_moves, walk_reloads, walk_scalar, walk_calls, walk_tail_cycles; // profile of the traceback walks
     U<unsigned long long> hb_pass, hb_split, hb_leaf, hb_total; // profile of the Hirschberg driver: half passes, column extraction + split search, leaf tracebacks, all
@@ -57,7 +57,9 @@ struct MyersScratch {
 // An entry is 32 bytes: the low 32-bit halves of {Pv, Mv, Ph, Mh}, then their high halves, so that each of the two lanes that share a
 // 64-bit word in the 32-bit sweep writes its four words with ONE 16-byte store.
 struct RtkTbHalf { uint32_t pv, mv, ph, mh; };
-#if defined(RTK_TB_NT) && !defined(RTK_SIM) // A/B build: the table is written once and read along one path: streaming stores, so that it does not push the waves' stacks out of the L2
+#if defined(RTK_EXPERIMENT_NO_TB) && !defined(RTK_SIM) // timing experiment only (results are wrong): the sweeps do not write the table at all
+#define RTK_TB_ST(p, hv) ((void)(p), (void)(hv))
+#elif defined(RTK_TB_NT) && !defined(RTK_SIM) // A/B build: the table is written once and read along one path: streaming stores, so that it does not push the waves' stacks out of the L2
 typedef uint32_t rtk_v4u __attribute__((ext_vector_type(4)));
 #define RTK_TB_ST(p, hv) __builtin_nontemporal_store(rtk_v4u{(hv).pv, (hv).mv, (hv).ph, (hv).mh}, reinterpret_cast<rtk_v4u*>(p))
 #else
@@ -1421,6 +1423,8 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
     prof.hb_total += rtk_clock() - t_all0;
 }
 
+#include "rtk_myers_lt.h"
+
 // edlibAlign(..., k = -1, NW or SHW, TASK_PATH): result and moves. When the whole table fits the in-memory traceback branch of
 // obtainAlignment (edlib.cpp:1191-1193) ONE stored sweep serves both the distance and the traceback: an SHW matrix restricted to
 // columns [0, end] IS the NW matrix of the truncated target edlib re-aligns (same top row, same left column), so the table
@@ -1432,6 +1436,25 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
     *n_moves = 0;
     { MyersScratch& msc = const_cast<MyersScratch&>(sc); msc.tb_gen = rtk_ld(&msc.tb_gen) + 1u; }
     MyersResult r; bool have = false;
+#ifdef RTK_HAVE_LT
+    if (rtk_lt_fits(sc, m, n)) { // small problem: the table lives in LDS, a chunk of steps at a time (rtk_myers_lt.h)
+        SweepStat st;
+        const bool ok = (mode == RTK_MODE_NW) ? rtk_lt_align<0>(sc, q, m, t, n, iupac, RTK_MODE_NW, &st, n_moves) : rtk_lt_align<1>(sc, q, m, t, n, iupac, RTK_MODE_SHW, &st, n_moves);
+        rtk_sync();
+        if (ok) {
+            r.dist = -1; r.first = -1; r.last = -1; r.nloc = 0;
+            if (mode == RTK_MODE_NW) { r.dist = st.final_score; r.first = r.last = n - 1; r.nloc = 1; return r; }
+            int best = st.best; const bool pseudo = (m & 63) != 0;
+            if (pseudo && m < best) best = m;
+            r.dist = best;
+            if (pseudo && m == best) { r.first = -1; r.last = (st.best == best) ? st.last : -1; r.nloc = 1 + ((st.best == best) ? st.cnt : 0); }
+            else { r.first = st.first; r.last = st.last; r.nloc = st.cnt; }
+            if (r.first + 1 <= 0) rtk_myers_alignment(sc, q, m, t, 0, r.dist, iupac, n_moves); // empty target prefix: m inserts (edlib.cpp:1171-1178)
+            return r;
+        }
+        *n_moves = 0;
+    }
+#endif
 #ifndef RTK_SIM
     const long long W = (m + 63) >> 6;
     if (m > 0 && n > 0 && m <= 4096 && static_cast<uint64_t>(4 * W * n) <= sc.tb_cap_words && static_cast<uint32_t>(m + n) <= sc.mv_cap && static_cast<uint32_t>(n) <= sc.t_cap &&
@@ -1471,10 +1494,30 @@ RTK_FN MyersResult rtk_myers_path(const MyersScratch& sc_, const char* q_, int m
 // matrix; its bottom-right cell is the NW distance, the minimum of its last row the SHW result. getScorePath scores a terminal path
 // with NW (src/GraphTraversal.cpp:880) and, if it survives, aligns the same two strings again with SHW + path for its quality string
 // (:727): rtk_myers_nw_and_save answers the first call and keeps what the second one needs; rtk_myers_path_from_saved then only walks.
-struct MyersSaved { uint32_t valid, gen; int32_t m, n, nw_dist; MyersResult shw; };
+struct MyersSaved { uint32_t valid, gen; int32_t m, n, nw_dist; MyersResult shw; uint8_t* stash; uint32_t stash_cap, stash_n; }; // stash (set by the caller, may be null): room for the moves of the alignment, kept from the sweep on (LDS-table route: the table does not outlive the call)
 RTK_FN bool rtk_myers_nw_and_save(const MyersScratch& sc_, const char* q_, int m_, const char* t_, int n_, bool iupac_, MyersSaved* out_) {
     const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); const char* q = rtk_u(q_); const char* t = rtk_u(t_); const int m = rtk_u(m_), n = rtk_u(n_); const bool iupac = rtk_u(iupac_); MyersSaved* out = rtk_u(out_);
     out->valid = 0;
+#ifdef RTK_HAVE_LT
+    if (out->stash && rtk_lt_fits(sc, m, n) && static_cast<uint32_t>(m + n) <= out->stash_cap) {
+        // the SHW path alignment right away (its table lives in LDS and is gone when this call returns); the moves wait in the caller's stash
+        SweepStat st; uint32_t nm = 0;
+        MyersScratch& msc = const_cast<MyersScratch&>(sc); const uint32_t gen = rtk_ld(&msc.tb_gen) + 1u; msc.tb_gen = gen;
+        const bool ok = rtk_lt_align<1>(sc, q, m, t, n, iupac, RTK_MODE_SHW, &st, &nm);
+        rtk_sync();
+        if (ok) {
+            MyersResult r;
+            int best = st.best; const bool pseudo = (m & 63) != 0;
+            if (pseudo && m < best) best = m;
+            r.dist = best;
+            if (pseudo && m == best) { r.first = -1; r.last = (st.best == best) ? st.last : -1; r.nloc = 1 + ((st.best == best) ? st.cnt : 0); }
+            else { r.first = st.first; r.last = st.last; r.nloc = st.cnt; }
+            out->m = m; out->n = n; out->nw_dist = st.final_score; out->shw = r; out->gen = gen;
+            if (r.first + 1 > 0) { nm = rtk_u(nm); rtk_wcopy(out->stash, rtk_ld(&sc.moves), nm); out->stash_n = nm; out->valid = 2u; } // 2: moves in the stash
+            return true;
+        }
+    }
+#endif
 #ifndef RTK_SIM
     const long long W = (m + 63) >> 6;
     if (!(m > 0 && n > 0 && m <= 4096 && static_cast<uint64_t>(4 * W * n) <= sc.tb_cap_words && static_cast<uint32_t>(m + n) <= sc.mv_cap && static_cast<uint32_t>(n) <= sc.t_cap &&
@@ -1501,6 +1544,7 @@ RTK_FN bool rtk_myers_nw_and_save(const MyersScratch& sc_, const char* q_, int m
 RTK_FN bool rtk_myers_path_from_saved(const MyersScratch& sc_, const MyersSaved& sv_, uint32_t* n_moves_, MyersResult* r_) {
     const MyersScratch& sc = *rtk_u(&sc_); RTK_ASSUME_LDS(&sc); const MyersSaved& sv = *rtk_u(&sv_); uint32_t* n_moves = rtk_u(n_moves_); MyersResult* r = rtk_u(r_);
     *n_moves = 0;
+    if (sv.valid == 2u) { *r = sv.shw; rtk_wcopy(rtk_ld(&sc.moves), sv.stash, sv.stash_n); *n_moves = sv.stash_n; return true; } // walked when it was swept
     if (!sv.valid || sv.gen != rtk_ld(&sc.tb_gen)) return false; // the table has been written again since
     *r = sv.shw;
     rtk_myers_walk(sc, sv.m, sv.shw.first + 1, sv.n, sv.shw.dist, n_moves);

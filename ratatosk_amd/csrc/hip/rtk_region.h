@@ -75,7 +75,7 @@ struct RegionScratch {
     U<uint64_t*> list[11]; U<uint32_t> list_cap;                // 6..10: SNP-annotation sets (rtk_ambiguity.h)
     U<uint32_t*> memo_u; U<uint8_t*> memo_v; U<uint32_t> memo_cap; U<uint32_t> memo_n;
     U<uint64_t*> bm[3]; U<uint32_t> bm_words;
-    U<uint32_t*> overflow; U<uint32_t> ovf_word; // the flag itself, next to the header (same memory: LDS in the kernels)
+    UL<uint32_t*> overflow; U<uint32_t> ovf_word; // the flag itself, next to the header (same memory: LDS in the kernels)
     DriverLocals loc;
     U<unsigned long long> cnt[16]; // expand, colour, pathbase, align, cells, then cycles: colour, paths, consensus, total, myers, sets
     U<unsigned long long> fine[16]; // developer cycle counters printed with RTK_TRACE (RTK_FINE names in rtk_pipeline_run.inc)
@@ -106,7 +106,7 @@ struct LaunchCtx { GraphView g; OptsView o; BatchView bv; RegionBatch rb; };
 
 struct RCtx { // everything a region program needs
     const GraphView& g; const OptsView& o; const BatchView& bv; const RegionBatch& rb; // -> the LaunchCtx of the launch
-    U<RegionScratch*> sc;
+    UL<RegionScratch*> sc;
     U<int> k;
 };
 
@@ -572,7 +572,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
     const bool lrc = rtk_u(c.o.long_read_correct) != 0;
     const uint32_t max_len_subpath = static_cast<uint32_t>(static_cast<uint64_t>(static_cast<double>(rtk_u(c.k)) * rtk_u(c.o.large_k_factor)));
     uint32_t n_nt_live = 0, n_t_scored = 0;
-    MyersSaved& t_saved = s.loc.saved; t_saved.valid = 0; t_saved.gen = 0; t_saved.m = 0; t_saved.n = 0; t_saved.nw_dist = 0; t_saved.shw.dist = -1; t_saved.shw.first = -1; t_saved.shw.last = -1; t_saved.shw.nloc = 0;
+    MyersSaved& t_saved = s.loc.saved; t_saved.stash = reinterpret_cast<uint8_t*>(rtk_ld(&s.str[3])); t_saved.stash_cap = rtk_ld(&s.str_cap); t_saved.stash_n = 0; t_saved.valid = 0; t_saved.gen = 0; t_saved.m = 0; t_saved.n = 0; t_saved.nw_dist = 0; t_saved.shw.dist = -1; t_saved.shw.first = -1; t_saved.shw.last = -1; t_saved.shw.nloc = 0;
     unsigned long long n_exp = 0;
     const unsigned long long td0 = rtk_clock(); const unsigned long long my0 = s.cnt[9];
 #ifdef RTK_SIM

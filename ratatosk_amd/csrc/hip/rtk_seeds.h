@@ -20,7 +20,7 @@ struct OptsView {
     U<int32_t> long_read_correct;
     U<uint32_t> max_len_weak_region2;
     U<uint32_t> a3_strand_order; // [A3] switch (rtk_opts::a3_strand_order): 1 = neighbours of a reverse-strand end visited in the order of the unitig's own strand
-    U<uint32_t> a2_exclusive; // [A2] switch (rtk_opts::a2_exclusive): 1 = a window matched by one kind of edit is not searched with the next kind
+    U<uint32_t> a2_exclusive; // [A2] switch (rtk_opts::a2_exclusive): 0 = union; 1, 2 = a window matched by one kind of edit is not searched with the next kind (1: substitution, insertion, deletion; 2: insertion, deletion, substitution)
 };
 
 struct BatchView {
@@ -373,7 +373,13 @@ struct PoolChunk { unsigned long long base; uint32_t left; }; // wave-private sl
 #define RTK_POOL_CHUNK 4096u
 
 RTK_DEV uint32_t rtk_variant_kind(int v) { return v < 93 ? RTK_EDIT_SUB : (v < 217 ? RTK_EDIT_INS : RTK_EDIT_DEL); }
-RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, bool exclusive) {
+// [A2] exclusive readings: of the kinds of edit that matched a window (`any`), the one whose hits are kept. mode 1: substitution -> insertion -> deletion
+// (the order of the blocks in Bifrost's searchSequence as we remember it); mode 2: insertion -> deletion -> substitution (the order of its parameters)
+RTK_DEV uint32_t rtk_a2_keep(uint32_t any, uint32_t mode) {
+    if (mode == 2u) return (any & RTK_EDIT_INS) ? RTK_EDIT_INS : ((any & RTK_EDIT_DEL) ? RTK_EDIT_DEL : (any & RTK_EDIT_SUB));
+    return any & (0u - any);
+}
+RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, uint32_t exclusive) {
     const int k = g.k;
 #ifndef RTK_SIM
     const uint64_t b = tile * 64 + static_cast<uint64_t>(rtk_lane());
@@ -451,7 +457,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
                 if (rtk_variant_code(v, k, c_k1, ck, ck1, &code)) { uint32_t np; hit = rtk_find_kmer(g, code, &np); probes += 1; slots += np; }
                 if (hit != RTK_NO_HIT) { sim_code[total] = code; sim_hit[total] = hit; sim_kind[total] = rtk_variant_kind(v); any |= sim_kind[total]; ++total; }
             }
-            if (exclusive && total) { const uint32_t keep = any & (0u - any); int w2 = 0; for (int i = 0; i < total; ++i) if (sim_kind[i] & keep) { sim_code[w2] = sim_code[i]; sim_hit[w2] = sim_hit[i]; ++w2; } total = w2; }
+            if (exclusive && total) { const uint32_t keep = rtk_a2_keep(any, exclusive); int w2 = 0; for (int i = 0; i < total; ++i) if (sim_kind[i] & keep) { sim_code[w2] = sim_code[i]; sim_hit[w2] = sim_hit[i]; ++w2; } total = w2; }
             emit(bb, total, sim_code, sim_hit, total, probes, slots);
         }
 #else
@@ -506,7 +512,7 @@ RTK_FN void rtk_inexact_tile(const GraphView& g, const BatchView& bv, uint64_t t
             }
             if (exclusive && total) { // [A2] exclusive: only the hits of the first kind of edit (substitution -> insertion -> deletion) that has one in this window
                 for (int o = 32; o > 0; o >>= 1) any |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(any), o, 64));
-                const uint32_t keep = any & (0u - any);
+                const uint32_t keep = rtk_a2_keep(any, exclusive);
                 int w2 = 0; for (int i = 0; i < my_n; ++i) if (my_kind[i] & keep) { my_code[w2] = my_code[i]; my_hit[w2] = my_hit[i]; ++w2; }
                 my_n = w2; total = rtk_wave_sum(my_n);
             }
@@ -618,7 +624,7 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
 #ifndef RTK_SEED_REGS
 #define RTK_SEED_REGS 4 // distinct hits of a window kept in registers; windows with more take the counted slow path
 #endif
-RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, bool exclusive) {
+RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, uint32_t exclusive) {
     const int k = g.k;
     const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
     uint32_t lo_tile = 0; // one scalar search per tile: largest r with roff[r] <= first base of the tile
@@ -652,7 +658,7 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
         uint64_t my_code[RTK_SEED_REGS], my_hit[RTK_SEED_REGS]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
         // [A2] exclusive: the kinds of edit are searched substitution -> insertion -> deletion and the first kind with a hit is the window's only one
         uint32_t keep = 7u;
-        if (exclusive && cand) { uint32_t any = 0, l0 = 0, s0 = 0; rtk_seeded_window(g, k, c_k1, ck, ck1, &l0, &s0, true, [&](uint64_t, uint64_t, uint32_t kinds) { any |= kinds; }); keep = any & (0u - any); }
+        if (exclusive && cand) { uint32_t any = 0, l0 = 0, s0 = 0; rtk_seeded_window(g, k, c_k1, ck, ck1, &l0, &s0, true, [&](uint64_t, uint64_t, uint32_t kinds) { any |= kinds; }); keep = rtk_a2_keep(any, exclusive); }
         if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, exclusive, [&](uint64_t code, uint64_t hit, uint32_t kinds) {
             if (!(kinds & keep)) return;
             for (int i = 0; i < my_n; ++i) if (my_hit[i] == hit) return;

@@ -38,12 +38,25 @@ template <class T> __device__ __forceinline__ T rtk_u(T v) {
 template <class T> RTK_HD T rtk_u(T v) { return v; }
 #endif
 
+// rtk_gp(p): "p points into device (global) memory" -- never into LDS or the wave's private stack. Pointers that the wave programs read from
+// their descriptors are generic to the compiler (they come out of LDS or out of structs), and a generic access is a FLAT instruction: it takes the
+// LDS address path as well as the memory path, counts in both wait counters (so that a wait for an LDS read also waits for it) and computes its
+// 64-bit address per lane. With the address space known the same access is a GLOBAL instruction (scalar base + lane offset, memory counter only).
+// Applied to every pointer FIELD of the views and work-area descriptors (U<T*>); the few fields that may point into LDS are UL<T*> below.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RTK_SIM) && !defined(RTK_NO_GLOBAL_PTRS)
+template <class T> __device__ __forceinline__ T rtk_gp(T v) { return v; }
+// (through an integer: a generic -> global -> generic pointer cast is folded away, and an assumption about the address space is not picked up)
+template <class T> __device__ __forceinline__ T* rtk_gp(T* p) { return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)(p); }
+#else
+template <class T> RTK_HD T rtk_gp(T v) { return v; }
+#endif
+
 // U<T>: a struct field that holds a wave-uniform value (all the view / scratch descriptors below are per wave or per launch).
 // Reads go through rtk_u, so every use site gets the scalar form without being written differently. Same layout as T.
 template <class T> struct U {
     T v;
-    RTK_HD operator T() const { return rtk_u(v); }
-    RTK_HD T get() const { return rtk_u(v); }
+    RTK_HD operator T() const { return rtk_gp(rtk_u(v)); }
+    RTK_HD T get() const { return rtk_gp(rtk_u(v)); }
     RTK_HD U& operator=(T x) { v = x; return *this; }
     template <class X> RTK_HD U& operator+=(X x) { v = static_cast<T>(rtk_u(v) + x); return *this; }
     template <class X> RTK_HD U& operator-=(X x) { v = static_cast<T>(rtk_u(v) - x); return *this; }
@@ -53,9 +66,18 @@ template <class T> struct U {
     RTK_HD U& operator--() { v = rtk_u(v) - 1; return *this; }
     RTK_HD T operator++(int) { const T o = rtk_u(v); v = o + 1; return o; }
     RTK_HD T operator--(int) { const T o = rtk_u(v); v = o - 1; return o; }
+    RTK_HD T operator->() const { return rtk_gp(rtk_u(v)); }
+    RTK_HD decltype(auto) operator*() const { return *rtk_gp(rtk_u(v)); }
+    template <class I> RTK_HD decltype(auto) operator[](I i) const { return rtk_gp(rtk_u(v))[i]; }
+};
+// UL<T*>: a wave-uniform pointer field that may point into LDS (the work-area header of the region kernels and the overflow word inside it)
+template <class T> struct UL {
+    T v;
+    RTK_HD operator T() const { return rtk_u(v); }
+    RTK_HD T get() const { return rtk_u(v); }
+    RTK_HD UL& operator=(T x) { v = x; return *this; }
     RTK_HD T operator->() const { return rtk_u(v); }
     RTK_HD decltype(auto) operator*() const { return *rtk_u(v); }
-    template <class I> RTK_HD decltype(auto) operator[](I i) const { return rtk_u(v)[i]; }
 };
 
 #define RTK_NONE32 0xFFFFFFFFu

@@ -139,6 +139,7 @@ template <class T, class V> RTK_DEV T rtk_atomic_add(const U<T*>& p, V v) { retu
 // uniform load: *p for a p that is the same in every lane
 template <class T> RTK_DEV T rtk_ld(const T* p) { return rtk_u(*p); }
 template <class T> RTK_DEV T rtk_ld(const U<T>* p) { return p->get(); }
+template <class T> RTK_DEV T rtk_ld(const UL<T>* p) { return p->get(); }
 
 // bulk copy / fill (lane-strided); publishes. 16 bytes per lane and step when both sides are 16-byte aligned.
 struct alignas(16) RtkV16 { uint64_t a, b; };

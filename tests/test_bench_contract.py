@@ -24,9 +24,15 @@ def _check_common(d, n):
 
 
 def test_bench_line_single(tmp_path):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--workdir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    """N = 1: the main line is the chr20-scale (diploid) set -- here at a reduced --ref-len -- and the same run carries configs[1] as the extra leg."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--workdir", str(tmp_path)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    _check_common(_line(r.stdout), 1)
+    d = _line(r.stdout)
+    _check_common(d, 1)
+    assert d["config"]["workload"].startswith("HG002-chr20-scale set (configs[2]'s graph)") and "diploid" in d["config"]["workload"] and d["config"]["n1_on_this_graph"] is None
+    assert d["vs_baseline_note"].startswith("null:") and "issue_frac" in d["roofline"]
+    c1 = d["config1"]
+    assert c1["workload"].startswith("configs[1]") and c1["value"] > 0 and c1["ms_per_step"] > 0 and set(c1["kernel_ms_per_step"]) == set(d["roofline"]["kernel_ms_per_step"])
 
 
 def test_bench_line_two_ranks(tmp_path):
@@ -39,6 +45,8 @@ def test_bench_line_two_ranks(tmp_path):
     pr = d["config"]["per_rank"]
     assert sorted(p["rank"] for p in pr) == [0, 1] and all(p["bases"] > 0 for p in pr)
     assert abs(d["value"] - sum(p["bases"] for p in pr) / max(p["seconds"] for p in pr)) / d["value"] < 0.05  # whole-job rate: all ranks' bases over the slowest rank's time
+    n1 = d["config"]["n1_on_this_graph"]  # the one-GPU point of the same graph, measured in this very run on rank 0 (not read from a file)
+    assert n1["value"] > 0 and n1["ms_per_step"] > 0 and n1["steps"] == 1 and "in this run" in n1["measured"] and "config1" not in d
 
 
 def test_bench_line_eight_ranks_is_the_configs2_run(tmp_path):
@@ -50,7 +58,7 @@ def test_bench_line_eight_ranks_is_the_configs2_run(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
     _check_common(d, 8)
-    assert d["config"]["workload"].startswith("configs[2]") and "diploid" in d["config"]["workload"]
+    assert d["config"]["workload"].startswith("HG002-chr20-scale set (configs[2]'s graph)") and "diploid" in d["config"]["workload"] and "sharded across 8 MI355X" in d["config"]["workload"]
     pr = d["config"]["per_rank"]
     assert sorted(p["rank"] for p in pr) == list(range(8)) and all(p["bases"] > 0 and p["distinct_tickets"] >= 2 and not p["shared_tickets"] for p in pr)
     rep = d["config"]["graph_replication"]
@@ -58,15 +66,17 @@ def test_bench_line_eight_ranks_is_the_configs2_run(tmp_path):
     assert abs(d["value"] - sum(p["bases"] for p in pr) / max(p["seconds"] for p in pr)) / d["value"] < 0.05
 
 
-def test_default_graph_of_the_multi_gpu_run():
-    """Without --ref-len, N > 1 (and --config2) take the configs[2] reference: 60 Mb, 0.1 % heterozygous SNPs; N = 1 stays configs[1]."""
+def test_default_graph_is_the_chr20_scale_set_at_every_n():
+    """Without --ref-len every N takes the configs[2] reference (60 Mb, 0.1 % heterozygous SNPs): the set the target is written on and the one
+    graph all points of a scaling series share; --config1-only is the quick developer line on configs[1]."""
     sys.path.insert(0, ROOT)
     import bench
     old = sys.argv
     try:
-        sys.argv = ["bench.py"]; a = bench.parse(); assert (a.ref_len, a.het) == (5_000_000, 0.0)
+        sys.argv = ["bench.py"]; a = bench.parse(); assert (a.ref_len, a.het, a.no_config1_leg) == (60_000_000, 0.001, False)
         sys.argv = ["bench.py", "--gpus", "8"]; a = bench.parse(); assert (a.ref_len, a.het) == (60_000_000, 0.001)
         sys.argv = ["bench.py", "--config2"]; a = bench.parse(); assert (a.ref_len, a.het) == (60_000_000, 0.001)
+        sys.argv = ["bench.py", "--config1-only"]; a = bench.parse(); assert (a.ref_len, a.het, a.no_config1_leg) == (5_000_000, 0.0, True)
         sys.argv = ["bench.py", "--gpus", "4", "--ref-len", "1000"]; a = bench.parse(); assert a.ref_len == 1000
     finally:
         sys.argv = old
