@@ -51,14 +51,25 @@ def main():
         pre = make(d)
         reads = op.read_fastq(pre + ".lr.fq")
         og = op.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31)
-        want, _ = og.correct_batch([r[1] for r in reads], [r[2] for r in reads], threads=os.cpu_count() or 4)
-        out = {"sim_args": SIM_ARGS, "inputs": input_sums(pre), "n_reads": len(reads), "in_bases": sum(len(r[1]) for r in reads),
-               "out_bases": sum(len(w[0]) for w in want),
-               "fastq_sha256": hashlib.sha256(fastq_bytes([r[0] for r in reads], want)).hexdigest(),
-               "read_crc32": [zlib.crc32((w[0] + "\n" + w[1]).encode()) for w in want]}
+        out = {"sim_args": SIM_ARGS, "inputs": input_sums(pre), "n_reads": len(reads), "in_bases": sum(len(r[1]) for r in reads)}
+        # the default reading of assumption [A2] (exclusive, since round 4) at the top level; the union reading (the default of rounds 1-3: these
+        # are the very bytes frozen then) next to it, so that a change of the default is told apart from a change of the correction
+        for key, env in (("", None), ("a2_union", "union")):
+            if env is None:
+                os.environ.pop("RTK_A2_XOR", None)
+            else:
+                os.environ["RTK_A2_XOR"] = env
+            want, _ = og.correct_batch([r[1] for r in reads], [r[2] for r in reads], threads=os.cpu_count() or 4)
+            rec = {"out_bases": sum(len(w[0]) for w in want), "fastq_sha256": hashlib.sha256(fastq_bytes([r[0] for r in reads], want)).hexdigest(),
+                   "read_crc32": [zlib.crc32((w[0] + "\n" + w[1]).encode()) for w in want]}
+            if key:
+                out[key] = rec
+            else:
+                out.update(rec)
+        os.environ.pop("RTK_A2_XOR", None)
     with open(os.path.join(HERE, "config0.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote config0.json:", out["fastq_sha256"])
+    print("wrote config0.json:", out["fastq_sha256"], out["a2_union"]["fastq_sha256"])
 
 
 if __name__ == "__main__":

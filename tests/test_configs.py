@@ -47,6 +47,20 @@ def test_config0_oracle_reproduces_frozen_fastq(config0):
     _check_config0(want, [r[0] for r in reads])
 
 
+def test_config0_union_reading_of_a2_reproduces_the_bytes_frozen_in_rounds_1_to_3(config0, monkeypatch):
+    """[A2] became `exclusive` by default in round 4; under RTK_A2_XOR=union oracle and device program still write the FASTQ frozen before."""
+    from ratatosk_amd import api
+    monkeypatch.setenv("RTK_A2_XOR", "union")
+    reads = op.read_fastq(config0 + ".lr.fq")
+    og = op.Graph(config0 + ".index.k31.fasta.gz", config0 + ".index.k31.rtsk", 31)
+    want, _ = og.correct_batch([r[1] for r in reads], [r[2] for r in reads], threads=4)
+    assert hashlib.sha256(g0.fastq_bytes([r[0] for r in reads], want)).hexdigest() == GOLD0["a2_union"]["fastq_sha256"]
+    pg = api.Graph(config0 + ".index.k31.fasta.gz", config0 + ".index.k31.rtsk", 31, device=0, lib_path=SIM_LIB)
+    got = pg.correct_batch([r[1] for r in reads[:6]], [r[2] for r in reads[:6]])
+    for i, w in enumerate(got):
+        assert zlib.crc32((w[0] + "\n" + w[1]).encode()) == GOLD0["a2_union"]["read_crc32"][i], "read %d" % i
+
+
 def test_config0_device_program_on_simulator(config0):
     """The device programs (host simulator build) on the first reads of configs[0]: same records as frozen."""
     from ratatosk_amd import api
