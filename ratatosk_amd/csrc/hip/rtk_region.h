@@ -45,6 +45,7 @@ struct RegionBatch {
     U<char*> qual_rev;                         // pass 2: every read's quality string reversed (q_bw of src/Correction.cpp:186,198)
     U<char*> seg_pool; U<uint64_t> seg_cap; U<unsigned long long*> seg_top;
     U<unsigned long long*> next_region;        // dequeue head of the persistent region kernel
+    U<uint32_t*> eorder;                       // the regions that need no graph walk (k_regions_easy), in any order; their number is n_heavy[2]
     U<uint32_t*> rorder; U<unsigned long long*> n_heavy; // dequeue order of the region kernel: the heavy regions (long gaps, read heads / tails) from the front, the light ones from the back (k_region_order); [0] heavy, [1] light
     U<unsigned long long*> n_overflow;         // regions that ran out of scratch in the last launch
     U<char*> out_pool; U<uint64_t> out_cap; U<unsigned long long*> out_top;

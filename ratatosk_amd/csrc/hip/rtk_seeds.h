@@ -655,15 +655,21 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
             }
         }
         // pass 1: up to four distinct hits of the lane's window stay in registers
-        uint64_t my_code[RTK_SEED_REGS], my_hit[RTK_SEED_REGS]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
-        // [A2] exclusive: the kinds of edit are searched substitution -> insertion -> deletion and the first kind with a hit is the window's only one
-        uint32_t keep = 7u;
-        if (exclusive && cand) { uint32_t any = 0, l0 = 0, s0 = 0; rtk_seeded_window(g, k, c_k1, ck, ck1, &l0, &s0, true, [&](uint64_t, uint64_t, uint32_t kinds) { any |= kinds; }); keep = rtk_a2_keep(any, exclusive); }
-        if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, exclusive, [&](uint64_t code, uint64_t hit, uint32_t kinds) {
-            if (!(kinds & keep)) return;
-            for (int i = 0; i < my_n; ++i) if (my_hit[i] == hit) return;
-            if (my_n < RTK_SEED_REGS) { my_code[my_n] = code; my_hit[my_n] = hit; ++my_n; } else more = true;
+        uint64_t my_code[RTK_SEED_REGS], my_hit[RTK_SEED_REGS]; uint32_t my_kind[RTK_SEED_REGS]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
+        // [A2] exclusive: the kinds of edit are searched one after the other and the first kind with a hit is the window's only one (rtk_a2_keep). ONE
+        // visit of the window: every hit is kept with the kinds of edit that reach it, the kinds seen anywhere in the window decide which hits stay
+        uint32_t keep = 7u, any = 0;
+        if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, exclusive != 0u, [&](uint64_t code, uint64_t hit, uint32_t kinds) {
+            any |= kinds;
+            for (int i = 0; i < my_n; ++i) if (my_hit[i] == hit) { my_kind[i] |= kinds; return; }
+            if (my_n < RTK_SEED_REGS) { my_code[my_n] = code; my_hit[my_n] = hit; my_kind[my_n] = kinds; ++my_n; } else more = true;
         });
+        if (exclusive && cand && !more) {
+            keep = rtk_a2_keep(any, exclusive);
+            int w2 = 0;
+            for (int i = 0; i < my_n; ++i) if (my_kind[i] & keep) { my_code[w2] = my_code[i]; my_hit[w2] = my_hit[i]; ++w2; }
+            my_n = w2;
+        } else if (exclusive && cand) keep = rtk_a2_keep(any, exclusive);
         *acc_probes += lookups; *acc_slots += slots;
         if (more) { // a window inside a repeat: count every visit, take a private slice of the pool, write them all
             uint32_t n_all = 0, l2 = 0, s2 = 0;
