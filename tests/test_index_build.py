@@ -1,4 +1,7 @@
-"""Index build, fast paths: `rtk_build_index --fast` (thread-parallel table fill, unitig construction, adjacency, cycle search)
+"""Index build. (1) Against an INDEPENDENT oracle (oracle/oracle_index.py: dictionary k-mer count, unitigs by the join relation followed from the
+path starts, colours by pair id, coverage): the unitigs (up to strand / rotation), colour sets and coverages of the files the tool writes -- plain,
+`--fast` and, on the GPU tier, `--gpu` -- are the oracle's, on seeded sets with heterozygous SNPs, repeats and tandem repeats, k = 31 and k = 21, and
+for a second-pass index. (2) Fast paths: `rtk_build_index --fast` (thread-parallel table fill, unitig construction, adjacency, cycle search)
 and `--gpu` (--fast with the k-mers counted on the device: csrc/hip/rtk_index.hip, rtk_index_count_kmers) must write the SAME two files as the
 plain single-path tool, byte for byte -- the plain tool is their oracle. Seeded sets with heterozygous SNPs, two-copy repeats and tandem
 repeats, k = 31 and k = 21, and two hand-made genomes whose chains of k-mers meet themselves (a closed loop, a hairpin): those take the
@@ -64,6 +67,71 @@ def _self_meeting_genomes(tmp):
                 s = hair[start:start + 100]
                 f.write("@h%d\n%s\n+\n%s\n" % (n, s, "I" * 100)); n += 1
     return sr
+
+
+ORACLE_SETS = [  # small enough for a Python dictionary of every read k-mer
+    ("o_het_repeats", ["--seed", "11", "--ref-len", "30000", "--het", "0.004", "--repeat-frac", "0.1", "--sr-cov", "30", "--sr-err", "0.01"]),
+    ("o_tandem", ["--seed", "21", "--ref-len", "40000", "--het", "0.003", "--tandem", "20", "--sr-cov", "25", "--sr-err", "0.005"]),
+    ("o_diploid", ["--seed", "7", "--ref-len", "90000", "--het", "0.002", "--repeat-frac", "0.05", "--sr-cov", "20", "--sr-err", "0.005"]),
+]
+
+
+def _index_vs_oracle(sr, out, k, mode, colour=None):
+    """the unitigs / colours / coverages of the files `rtk_build_index <mode>` writes against oracle/oracle_index.py"""
+    from oracle import oracle_index as oi
+    from oracle import oracle_py as op
+    cmd = [os.path.join(BIN, "rtk_build_index"), "-s", sr, "-o", out, "-k", str(k)] + (["--colour-reads", colour] if colour else []) + mode
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want, solid = oi.build([sr], k, 2, [colour] if colour else None)
+    g = op.Graph(out + ".index.k%d.fasta.gz" % k, out + ".index.k%d.rtsk" % k, k)
+    assert g.n_kmers == len(solid), (g.n_kmers, len(solid))
+    got = {}
+    for u in range(g.n_unitigs):
+        d = g.unitig(u)
+        ids = sorted(set(d["local"]) | (set(g.global_set(d["global_id"])) if d["global_id"] >= 0 else set()))
+        got[oi.canonical(d["seq"])] = (ids, (d["kmcov"] >> 31) & 0x7FFFFFFF, d["seq"])
+    assert len(got) == g.n_unitigs == len(want), (g.n_unitigs, len(want))
+    missing = [key for key in want if key not in got]
+    if missing:  # isolated cycles: the tool opens them elsewhere; compare by their rotation-independent form
+        rot = {oi.unitig_key(v[2], k, True): v for key, v in got.items() if key not in want}
+        for key in missing:
+            assert key in rot, ("unitig of the oracle not in the index", key[:80])
+            got[key] = rot[key]
+    bad = [(key[:50], want[key][1], got[key][1]) for key in want if want[key][1] != got[key][1]]
+    assert not bad, ("coverage differs", bad[:5])
+    bad = [key[:50] for key in want if want[key][0] != got[key][0]]
+    assert not bad, ("colour sets differ", bad[:5])
+    return len(want)
+
+
+def test_index_build_against_the_independent_oracle(tmp_path):
+    tmp = str(tmp_path)
+    for name, args in ORACLE_SETS:
+        sr = _simulated(tmp, name, args)
+        for k in (31, 21):
+            n = _index_vs_oracle(sr, os.path.join(tmp, name + "_plain"), k, [])
+            assert n > 10
+            assert _index_vs_oracle(sr, os.path.join(tmp, name + "_fast"), k, ["--fast"]) == n
+    # second-pass index: the graph of the short reads coloured by the long reads, every read its own id (src/Ratatosk.cpp:1218)
+    sr = _simulated(tmp, "o_p2", ORACLE_SETS[0][1])
+    lr = os.path.join(tmp, "o_p2.lr.fq")
+    for mode in ([], ["--fast"]):
+        _index_vs_oracle(sr, os.path.join(tmp, "o_p2_" + ("fast" if mode else "plain")), 31, mode, colour=lr)
+    # chains of k-mers that meet themselves: a closed loop (compared up to rotation) and a hairpin
+    _index_vs_oracle(_self_meeting_genomes(tmp), os.path.join(tmp, "o_self"), 31, [])
+    _index_vs_oracle(_self_meeting_genomes(tmp), os.path.join(tmp, "o_self_f"), 31, ["--fast"])
+
+
+@pytest.mark.gpu
+def test_gpu_index_build_against_the_independent_oracle(tmp_path):
+    """`--gpu` (k-mers counted on the device) held to oracle/oracle_index.py, not to the repo's own plain tool"""
+    tmp = str(tmp_path)
+    for name, args in ORACLE_SETS:
+        sr = _simulated(tmp, name, args)
+        for k in (31, 21):
+            assert _index_vs_oracle(sr, os.path.join(tmp, name + "_gpu"), k, ["--gpu"]) > 10
+    _index_vs_oracle(_self_meeting_genomes(tmp), os.path.join(tmp, "o_self_g"), 31, ["--gpu"])
 
 
 def test_fast_index_build_writes_the_same_files(tmp_path):
