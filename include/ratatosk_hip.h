@@ -62,6 +62,11 @@ typedef struct rtk_opts {
      * appended in walk direction, A,C,G,T, on both strands (default); 1 = on the reverse strand by the base as the unitig's own strand spells it
      * (A,C,G,T there = T,G,C,A in walk direction). rtk_opts_default takes it from the environment: RTK_A3_ORDER=walk (default) | strand. */
     int32_t a3_strand_order;
+    /* Canonical rule [D1] as a switch. chooseColors visits the anchor colour sets "sorted by cardinality" after iterating an unordered_map keyed by
+     * pointers (src/Correction.cpp:286-293: heap addresses + an unstable sort decide the order of sets of EQUAL cardinality); this build orders
+     * such ties by unitig id: 0 = ascending (default), 1 = descending. rtk_opts_default takes it from the environment: RTK_D1_ORDER=asc | desc.
+     * profiles/r04_d1_count.json counts the reads the choice decides. */
+    int32_t d1_desc;
 } rtk_opts;
 
 typedef struct rtk_graph_info {

@@ -829,9 +829,10 @@ IdSet chooseColors(const Ctx& c, const AnchorSets& s_pid_s, const AnchorSets& s_
     size_t nb_unselected = s_spid.size();
     std::vector<std::pair<int32_t, int> > v_spids;
     for (std::set<int32_t>::const_iterator it = s_spid.begin(); it != s_spid.end(); ++it) v_spids.push_back(std::make_pair(*it, static_cast<int>(std::min(cov, g.cardinality(*it)))));
+    const char* d1 = getenv("RTK_D1_ORDER"); const bool d1_desc = d1 && !strcmp(d1, "desc"); // [D1] as a switch (like rtk_opts::d1_desc on the device side): ties by unitig id, ascending (default) or descending
     std::sort(v_spids.begin(), v_spids.end(), [&](const std::pair<int32_t, int>& a, const std::pair<int32_t, int>& b) { // [D1]
         const size_t ca = g.cardinality(a.first), cb = g.cardinality(b.first);
-        return ca != cb ? ca < cb : a.first < b.first;
+        return ca != cb ? ca < cb : (d1_desc ? a.first > b.first : a.first < b.first);
     });
     for (int i = 5; i >= 0; --i) {
         if (nb_unselected == 0) break;

@@ -170,7 +170,7 @@ RTK_FN uint32_t rtk_choose_colors_small(const RCtx& c_, const SideList& side_s_,
     for (uint32_t j = 0; j + 1 < n_slots; ++j) { const uint32_t uj = rtk_shfl(m_u, static_cast<int>(j)); dup = dup || ((j < lane) && (uj == m_u)); }
     const bool cand = lane < n_slots && m_card >= min_cov_v && !dup;
     const uint64_t cb = rtk_ballot(cand); const uint32_t nsp = static_cast<uint32_t>(rtk_popc(cb));
-    const uint64_t key = (static_cast<uint64_t>(m_card) << 32) | m_u; // distinct among the candidates
+    const uint64_t key = rtk_d1_key(m_card, m_u, c.o.d1_desc); // distinct among the candidates
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n_slots; ++j) { const uint64_t kj = rtk_shfl(key, static_cast<int>(j)); rank += (((cb >> j) & 1ull) && kj < key) ? 1u : 0u; }
     uint32_t src = 0;
@@ -333,9 +333,9 @@ RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, 
       for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i, ++slot) {
         const uint32_t u = sides[sd]->u[i];
         if (g.card[u] < c.o.min_cov_vertices) continue;
-        bool dup = false; for (uint32_t j0 = 0; j0 < nsp && !dup; j0 += RTK_WAVE) { const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane()); dup = rtk_ballot(j < nsp && static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull) == u) != 0ull; }
+        bool dup = false; for (uint32_t j0 = 0; j0 < nsp && !dup; j0 += RTK_WAVE) { const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane()); dup = rtk_ballot(j < nsp && rtk_d1_unitig(keys[j], c.o.d1_desc) == u) != 0ull; }
         if (dup) continue;
-        keys[nsp] = (static_cast<uint64_t>(g.card[u]) << 32) | u; vals[nsp] = slot; ++nsp; rtk_sync();
+        keys[nsp] = rtk_d1_key(g.card[u], u, c.o.d1_desc); vals[nsp] = slot; ++nsp; rtk_sync();
       } }
     rtk_sort_pairs(keys, vals, nsp); // (uses the LDS buffer: before the universe moves in)
     const uint32_t cov = 30;
@@ -423,7 +423,7 @@ RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, 
         nb_unselected = 0;
         RtkBM curr = a2;
         for (uint32_t j = 0; j < nsp; ++j) {
-            const uint32_t u = static_cast<uint32_t>(rtk_ld(keys + j) & 0xFFFFFFFFull);
+            const uint32_t u = rtk_d1_unitig(rtk_ld(keys + j), c.o.d1_desc);
             int quota = static_cast<int>(rtk_ld(vals + j));
             if (quota > 0) {
                 const uint64_t slot = rtk_ld(slot_of + j);

@@ -259,7 +259,7 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
     o->max_km_cov = 128; if (g && g->info.max_km_cov_top > 128) o->max_km_cov = g->info.max_km_cov_top; // src/Ratatosk.cpp:625
     o->weak_region_len_factor = 0.25; o->large_k_factor = 1.5; o->min_score = 0.0; o->max_qual = 40; o->out_qual = 1; o->min_confidence_snp_corr = 0.9;
     o->long_read_correct = 0; o->force_unres_snp_corr = 0; o->max_len_weak_region2 = 5000;
-    { const char* e = getenv("RTK_A2_XOR"); o->a2_exclusive = (e && !strcmp(e, "union")) ? 0 : ((e && !strcmp(e, "exclusive-ids")) ? 2 : 1); const char* e3 = getenv("RTK_A3_ORDER"); o->a3_strand_order = (e3 && !strcmp(e3, "strand")) ? 1 : 0; } // [A2] switch, see rtk_opts
+    { const char* e = getenv("RTK_A2_XOR"); o->a2_exclusive = (e && !strcmp(e, "union")) ? 0 : ((e && !strcmp(e, "exclusive-ids")) ? 2 : 1); const char* e3 = getenv("RTK_A3_ORDER"); o->a3_strand_order = (e3 && !strcmp(e3, "strand")) ? 1 : 0;  const char* e4 = getenv("RTK_D1_ORDER"); o->d1_desc = (e4 && !strcmp(e4, "desc")) ? 1 : 0; } // [A2] switch, see rtk_opts
     return RTK_OK;
 }
 

@@ -1160,10 +1160,10 @@ RTK_FN uint32_t rtk_choose_colors_general(const RCtx& c_, const SideList& side_s
     for (int sd = 0; sd < 3; ++sd) for (uint32_t i = 0; i < sides[sd]->n; ++i) {
         const uint32_t u = sides[sd]->u[i];
         if (g.card[u] < c.o.min_cov_vertices) continue;
-        bool dup = false; for (uint32_t j0 = 0; j0 < nsp && !dup; j0 += RTK_WAVE) { const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane()); dup = rtk_ballot(j < nsp && static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull) == u) != 0ull; }
+        bool dup = false; for (uint32_t j0 = 0; j0 < nsp && !dup; j0 += RTK_WAVE) { const uint32_t j = j0 + static_cast<uint32_t>(rtk_lane()); dup = rtk_ballot(j < nsp && rtk_d1_unitig(keys[j], c.o.d1_desc) == u) != 0ull; }
         if (dup) continue;
         if (2 * (nsp + 1) > s.list_cap) { rtk_fail_ovf(s, 8); return 0; }
-        keys[nsp] = (static_cast<uint64_t>(g.card[u]) << 32) | u; vals[nsp] = 0; ++nsp; rtk_sync();
+        keys[nsp] = rtk_d1_key(g.card[u], u, c.o.d1_desc); vals[nsp] = 0; ++nsp; rtk_sync();
     }
     rtk_sort_pairs(keys, vals, nsp);
     RTK_FINE_LAP(1)
@@ -1218,7 +1218,7 @@ RTK_FN uint32_t rtk_choose_colors_general(const RCtx& c_, const SideList& side_s
             nb_unselected = 0;
             const uint32_t* cur_p = a2.p; uint32_t ncur = n2; int curb = 8; // curr_pid: a_pid2[i] itself until the first selection, then set[7] / set[8] (ping-pong)
             for (uint32_t j = 0; j < nsp && !rtk_failed(s); ++j) {
-                const uint32_t u = static_cast<uint32_t>(keys[j] & 0xFFFFFFFFull);
+                const uint32_t u = rtk_d1_unitig(keys[j], c.o.d1_desc);
                 int quota = static_cast<int>(vals[j]);
                 bool touch = false;
                 if (quota > 0) { touch = (i == 0 || rtk_shared_with_set(g, u, cur_p, ncur, 1) >= 1); RTK_FINE_LAP(4) }

@@ -19,6 +19,7 @@ struct OptsView {
     // second pass (`correct -2`, long_read_correct in the reference): qualities of pass 1 are carried over, no 1-edit search
     U<int32_t> long_read_correct;
     U<uint32_t> max_len_weak_region2;
+    U<uint32_t> d1_desc; // [D1] switch (rtk_opts::d1_desc): anchors of equal colour-set cardinality by unitig id, 0 ascending, 1 descending
     U<uint32_t> a3_strand_order; // [A3] switch (rtk_opts::a3_strand_order): 1 = neighbours of a reverse-strand end visited in the order of the unitig's own strand
     U<uint32_t> a2_exclusive; // [A2] switch (rtk_opts::a2_exclusive): 0 = union; 1, 2 = a window matched by one kind of edit is not searched with the next kind (1: substitution, insertion, deletion; 2: insertion, deletion, substitution)
 };
@@ -372,6 +373,9 @@ RTK_DEV bool rtk_variant_code(int v, int k, uint64_t w_k1, uint32_t w_ck, uint32
 struct PoolChunk { unsigned long long base; uint32_t left; }; // wave-private slice of the raw-hit pool (one device atomic per 4096 entries)
 #define RTK_POOL_CHUNK 4096u
 
+// [D1] sort key of a candidate anchor of chooseColors: (cardinality, unitig id), the id inverted for the descending reading; and the id back out of a key
+RTK_DEV uint64_t rtk_d1_key(uint32_t card, uint32_t u, uint32_t desc) { return (static_cast<uint64_t>(card) << 32) | (desc ? (~u & 0xFFFFFFFFu) : u); }
+RTK_DEV uint32_t rtk_d1_unitig(uint64_t key, uint32_t desc) { const uint32_t lo = static_cast<uint32_t>(key & 0xFFFFFFFFull); return desc ? ~lo : lo; }
 RTK_DEV uint32_t rtk_variant_kind(int v) { return v < 93 ? RTK_EDIT_SUB : (v < 217 ? RTK_EDIT_INS : RTK_EDIT_DEL); }
 // [A2] exclusive readings: of the kinds of edit that matched a window (`any`), the one whose hits are kept. mode 1: substitution -> insertion -> deletion
 // (the order of the blocks in Bifrost's searchSequence as we remember it); mode 2: insertion -> deletion -> substitution (the order of its parameters)
