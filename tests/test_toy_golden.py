@@ -138,3 +138,55 @@ def test_toy_device_program_on_simulator_reproduces_expected(toy_index):
 def test_gpu_toy_reproduces_expected(toy_index):
     pre, reads = toy_index
     assert _device(pre, reads, None) == [(e[1], e[2]) for e in _expected()]
+
+
+# ---- the [A3] toy (tests/golden/toy_a3/NOTE.md): a tie between the two branches of a bubble that the order of getSuccessors() decides ----
+import gen_toy_a3 as toy3  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def toy_a3(tmp_path_factory):
+    hap_a, hap_b = toy3.haplotypes()
+    assert open(os.path.join(toy3.OUT, "hap.fa")).read() == ">hapA\n%s\n>hapB\n%s\n" % (hap_a, hap_b)
+    reads = toy3.long_reads(hap_a)
+    assert [(r[0], r[1]) for r in op.read_fastq(os.path.join(toy3.OUT, "lr.fq"))] == [(n, raw) for n, raw, _ in reads]
+    pre = toy3.build_index(str(tmp_path_factory.mktemp("toy_a3")))
+    og = op.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31)
+    seqs = [og.unitig(u)["seq"] for u in range(og.n_unitigs)]
+    assert sorted(len(s) for s in seqs) == [61, 61, 599, 600]  # NOTE.md "Graph"
+    left = [s for s in seqs if len(s) == 600][0]
+    assert left == hap_a[:600] or left == toy3.rc(hap_a[:600])
+    return pre, reads, left == hap_a[:600]
+
+
+def _a3_expected(reads, left_flank_in_hap_orientation, reading):
+    """NOTE.md "Which branch is listed last": the corrected base by hand"""
+    base = "C" if (left_flank_in_hap_orientation or reading == "walk") else "A"
+    return [(raw[:p] + base + raw[p + 1:], p) for _, raw, p in reads]
+
+
+def _check_a3(correct, toy_a3, monkeypatch):
+    pre, reads, left_fw = toy_a3
+    outs = {}
+    for reading in ("walk", "strand"):
+        monkeypatch.setenv("RTK_A3_ORDER", reading)
+        got = correct(pre, [r[1] for r in reads], ["5" * len(r[1]) for r in reads])
+        for (s, q), (want, p) in zip(got, _a3_expected(reads, left_fw, reading)):
+            assert s == want, (reading, "corrected base at the SNP: %s, by hand: %s" % (s[p], want[p]))
+            assert q[:p] == "I" * p and q[p + 1:] == "I" * (len(s) - p - 1) and q[p] != "I"
+        outs[reading] = got
+    monkeypatch.delenv("RTK_A3_ORDER", raising=False)
+    assert not left_fw and outs["walk"] != outs["strand"]  # the fixture separates the two readings (the tool writes the left flank reverse-complemented)
+    assert correct(pre, [r[1] for r in reads], ["5" * len(r[1]) for r in reads]) == outs["walk"]  # the default is the reading argued for in the note
+
+
+def test_toy_a3_oracle_and_simulator_take_the_hand_derived_branch(toy_a3, monkeypatch):
+    from ratatosk_amd import api
+    _check_a3(lambda pre, s, q: op.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31).correct_batch(s, q)[0], toy_a3, monkeypatch)
+    _check_a3(lambda pre, s, q: api.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31, device=0, lib_path=SIM_LIB).correct_batch(s, q), toy_a3, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_gpu_toy_a3_takes_the_hand_derived_branch(toy_a3, monkeypatch):
+    from ratatosk_amd import api
+    _check_a3(lambda pre, s, q: api.Graph(pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk", 31, device=0).correct_batch(s, q), toy_a3, monkeypatch)
