@@ -47,6 +47,13 @@ template <class T> RTK_HD T rtk_u(T v) { return v; }
 template <class T> __device__ __forceinline__ T rtk_gp(T v) { return v; }
 // (through an integer: a generic -> global -> generic pointer cast is folded away, and an assumption about the address space is not picked up)
 template <class T> __device__ __forceinline__ T* rtk_gp(T* p) { return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)(p); }
+// A pointer-to-const FIELD of a view (the graph's arrays, the reads, the anchors of the seed stage: everything a kernel is handed as input) points to
+// memory that no running kernel writes: the CONSTANT address space. An access through it with a wave-uniform address -- and most of the wave programs'
+// reads of the graph are that: neighbour slots, flag words, offsets of ONE unitig -- becomes a SCALAR load (s_load: scalar cache, no vector-memory
+// instruction, the value lands in SGPRs), with a per-lane address it stays a global load.
+#ifndef RTK_NO_CONST_PTRS
+template <class T> __device__ __forceinline__ const T* rtk_gp(const T* p) { return (const T*)(__attribute__((address_space(4))) const T*)(unsigned long long)(p); }
+#endif
 #else
 template <class T> RTK_HD T rtk_gp(T v) { return v; }
 #endif
