@@ -429,7 +429,7 @@ RTK_FN uint32_t rtk_choose_colors_bits(const RCtx& c_, const SideList& side_s_, 
                 const uint64_t slot = rtk_ld(slot_of + j);
                 const RtkBM cu = rtk_bm_load(store + (2ull * slot) * 64ull) | rtk_bm_load(store + (2ull * slot + 1ull) * 64ull); // all colours of u
                 if (i == 0 || rtk_bm_count(cu & curr) >= 1) {
-                    const uint32_t cd = rtk_ld(rtk_u(g.card) + u); const uint32_t min_cov = cd < cov ? cd : cov;
+                    const uint32_t cd = rtk_ld(g.card.get() + u); const uint32_t min_cov = cd < cov ? cd : cov;
                     const uint32_t sh = rtk_bm_count(cu & all);
                     quota = static_cast<int>(min_cov - (sh < min_cov ? sh : min_cov));
                     if (quota > 0) {

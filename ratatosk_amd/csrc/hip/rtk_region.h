@@ -236,7 +236,7 @@ RTK_DEV uint32_t rtk_rec_l(const RegionScratch& s, uint64_t h) { return rtk_ld(&
 RTK_DEV UMap rtk_rec_back(const RegionScratch& s, uint64_t h) { const int lv = rtk_h_lvl(h); const uint64_t o = rtk_h_off(h); const char* rec = rtk_ld(&s.arena[lv]) + o; return rtk_u(reinterpret_cast<const UMap*>(rec + sizeof(PathHdr))[rtk_ld(&reinterpret_cast<const PathHdr*>(rec)->n) - 1]); }
 
 RTK_DEV uint32_t rtk_nkm_u(const RCtx& c, uint32_t u) { // k-mers of unitig u, uniform
-    const uint64_t* uo = rtk_u(c.g.uoff) + u;
+    const uint64_t* uo = c.g.uoff.get() + u;
     return static_cast<uint32_t>(rtk_ld(uo + 1) - rtk_ld(uo)) - static_cast<uint32_t>(rtk_u(c.k)) + 1u;
 }
 RTK_DEV void rtk_wp_norm_back(const RCtx& c, WPath& p) { // the former end becomes a whole unitig (Path.hpp:319-323)
@@ -352,8 +352,8 @@ RTK_FN void rtk_wp_prune_prefix(const RCtx& c_, WPath& p_, uint32_t len_) {
 // mappedSequenceToString of one mapping into dst (lane-parallel 2-bit decode, reverse complement on the fly)
 RTK_DEV void rtk_um_decode(const RCtx& c, const UMap& um, char* dst, uint32_t skip) {
     const uint32_t n = um.len + static_cast<uint32_t>(rtk_u(c.k)) - 1;
-    const uint64_t b0 = rtk_ld(rtk_u(c.g.uoff) + um.unitig) + um.dist;
-    const uint64_t* useq = rtk_u(c.g.useq);
+    const uint64_t b0 = rtk_ld(c.g.uoff.get() + um.unitig) + um.dist;
+    const uint64_t* useq = c.g.useq.get();
     for (uint32_t i = skip + static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) {
         const uint64_t pos = um.strand ? (b0 + i) : (b0 + (n - 1 - i));
         const uint32_t b = static_cast<uint32_t>((useq[pos >> 5] >> (2 * (pos & 31))) & 3ull);
@@ -520,7 +520,7 @@ RTK_FN_HOT bool rtk_colour_ok(const RCtx& c, uint32_t u_, const uint32_t* all_pi
     }
     const uint32_t mcv = static_cast<uint32_t>(rtk_u(c.o.min_cov_vertices));
     const bool ok = (n_all == 0) || (rtk_u(rtk_shared_with_set(c.g, u, all_pids, n_all, mcv)) >= mcv);
-    s.cnt[1] += rtk_ld(rtk_u(c.g.card) + u) + n_all;
+    s.cnt[1] += rtk_ld(c.g.card.get() + u) + n_all;
     if (mn < rtk_ld(&s.memo_cap)) { const_cast<uint32_t*>(mu)[mn] = u; mvv[mn] = ok ? 1 : 0; s.memo_n = mn + 1; rtk_sync(); }
     s.cnt[15] += rtk_clock() - tk0;
     return ok;
@@ -531,7 +531,7 @@ RTK_DEV bool rtk_edge_bit(const GraphView& g, uint32_t u, uint32_t strand, int b
     return strand ? ((g.flags[u] & (idx << 4)) != 0) : ((g.flags[u] & idx) != 0);
 }
 RTK_DEV int rtk_nb_successors(const GraphView& g, const UMap& um) {
-    const uint32_t* a = rtk_u(g.adj) + 8ull * um.unitig + (um.strand ? 0 : 4);
+    const uint32_t* a = g.adj.get() + 8ull * um.unitig + (um.strand ? 0 : 4);
     int n = 0; for (int b = 0; b < 4; ++b) n += (rtk_ld(a + b) != RTK_NONE32) ? 1 : 0; return n;
 }
 
@@ -565,7 +565,7 @@ RTK_FN_SEARCH DfsOut rtk_explore_subgraph(const RCtx& c, const uint32_t* all_pid
     uint64_t* stk = rtk_ld(&s.list[4]); uint32_t sp = 0; // entries: handle (0 = empty path) and level, two words each
     const uint32_t list_cap = rtk_ld(&s.list_cap);
     char* const str1 = rtk_ld(&s.str[1]); char* const str2 = rtk_ld(&s.str[2]);
-    const uint32_t* const g_adj = rtk_u(c.g.adj); const uint32_t* const g_flags = rtk_u(c.g.flags);
+    const uint32_t* const g_adj = c.g.adj.get(); const uint32_t* const g_flags = c.g.flags.get();
     stk[0] = ~0ull; stk[1] = level; sp = 1;
     WPath& w = s.wp[2];
     const bool has_end = !rtk_um_is_empty(um_e);
