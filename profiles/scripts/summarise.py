@@ -11,7 +11,7 @@ def find(d, pat):
 
 
 def short(name):
-    for k in ("k_lookup_exact", "k_mask", "k_inexact", "k_finalize", "k_regions", "k_stitch", "k_enum", "k_myers_batch"):
+    for k in ("k_lookup_exact", "k_mask", "k_inexact", "k_finalize", "k_regions_easy", "k_region_order", "k_regions", "k_stitch", "k_enum", "k_myers_batch"):
         if k in name:
             return k
     if "index_elementwise" in name or "gather" in name.lower():
@@ -50,7 +50,7 @@ res = {"units": "FETCH_SIZE / WRITE_SIZE are KB as reported by rocprofv3; *_byte
 fe, wr, sq = pmc("fetch", "*counter_collection.csv"), pmc("write", "*counter_collection.csv"), pmc("sq", "*counter_collection.csv")
 cf, cw = pmc("calib_fetch", "*counter_collection.csv"), pmc("calib_write", "*counter_collection.csv")
 kern = {}
-for k in ("k_lookup_exact", "k_mask", "k_inexact", "k_finalize", "k_enum", "k_regions", "k_stitch"):
+for k in ("k_lookup_exact", "k_mask", "k_inexact", "k_finalize", "k_enum", "k_region_order", "k_regions_easy", "k_regions", "k_stitch"):
     e = {}
     if k in fe and "FETCH_SIZE" in fe[k]:
         e["fetch_bytes_per_launch_raw"] = fe[k]["FETCH_SIZE"]["mean_per_launch"] * 1024.0
