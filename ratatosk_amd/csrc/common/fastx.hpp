@@ -26,6 +26,7 @@
 
 #include "bgzf.hpp"
 #include "mgzip.hpp"
+#include "sample_source.hpp"
 
 namespace rtk {
 
@@ -85,6 +86,11 @@ public:
     bool open(const std::string& fn, int inflate_threads = 0) {
         close();
         pos_ = end_ = 0; eof_ = false; has_peek_ = false; failed_ = false;
+        if (SampleSource::is_spec(fn)) { // reads sampled from a reference on the fly (sample_source.hpp): delivered as the FASTQ text they stand for
+            std::string err; ss_ = SampleSource::get(fn, &err); ss_next_ = 0; ss_pend_.clear(); ss_pend_off_ = 0;
+            if (!ss_) fprintf(stderr, "%s\n", err.c_str());
+            return ss_ != nullptr;
+        }
         if (inflate_threads >= 1 && MemberGzipReader::looks_like_gzip(fn)) { mg_.reset(new MemberGzipReader()); if (mg_->open(fn, inflate_threads)) return true; mg_.reset(); }
         fp_ = gzopen(fn.c_str(), "rb"); // zlib reads plain files transparently
         if (!fp_) return false;
@@ -92,7 +98,7 @@ public:
         return true;
     }
 
-    void close() { if (fp_) { gzclose(fp_); fp_ = nullptr; } mg_.reset(); }
+    void close() { if (fp_) { gzclose(fp_); fp_ = nullptr; } mg_.reset(); ss_.reset(); }
     // the input ended on a damaged or cut-short gzip stream (what was read before it has been delivered): callers must not take that for the end of the file
     bool failed() const { return failed_; }
 
@@ -218,6 +224,21 @@ private:
     }
 
     long fill_() { // next bytes of the text into buf_
+        if (ss_) {
+            size_t n = 0;
+            while (n < sizeof(buf_)) {
+                if (ss_pend_off_ == ss_pend_.size()) { // the next pair as two FASTQ records
+                    if (ss_next_ >= ss_->n_pairs()) break;
+                    const uint32_t L = ss_->read_len();
+                    std::string m1(L, 'A'), m2(L, 'A'); ss_->pair(ss_next_, &m1[0], &m2[0]);
+                    const std::string nm = "s" + std::to_string(ss_next_), q(L, 'I');
+                    ss_pend_ = "@" + nm + "\n" + m1 + "\n+\n" + q + "\n@" + nm + "\n" + m2 + "\n+\n" + q + "\n"; ss_pend_off_ = 0; ++ss_next_;
+                }
+                const size_t c = std::min(sizeof(buf_) - n, ss_pend_.size() - ss_pend_off_);
+                memcpy(buf_ + n, ss_pend_.data() + ss_pend_off_, c); n += c; ss_pend_off_ += c;
+            }
+            return static_cast<long>(n);
+        }
         if (mg_) { const long n = mg_->read(buf_, sizeof(buf_)); if (n < 0 || mg_->failed()) failed_ = true; return n; }
         const int n = gzread(fp_, buf_, sizeof(buf_));
         if (n < static_cast<int>(sizeof(buf_))) { int e = Z_OK; gzerror(fp_, &e); if (n < 0 || (e != Z_OK && e != Z_STREAM_END)) failed_ = true; } // (unexpected end of file: Z_BUF_ERROR)
@@ -225,6 +246,7 @@ private:
     }
     gzFile fp_;
     std::unique_ptr<MemberGzipReader> mg_;
+    std::shared_ptr<SampleSource> ss_; uint64_t ss_next_ = 0; std::string ss_pend_; size_t ss_pend_off_ = 0;
     bool failed_;
     char buf_[1 << 18];
     size_t pos_, end_;

@@ -87,6 +87,28 @@ struct PinBuf { void* p = nullptr; ~PinBuf() { if (p) (void)hipHostFree(p); } vo
 template <class Sink>
 bool for_each_sequence_chunk(const std::vector<std::string>& files, int n_threads, uint64_t chunk_bytes, Sink sink, std::string* err) {
     for (size_t f = 0; f < files.size(); ++f) {
+        if (rtk::SampleSource::is_spec(files[f])) { // reads sampled from a reference on the fly (common/sample_source.hpp): pair ranges, generated by the threads
+            std::shared_ptr<rtk::SampleSource> ss = rtk::SampleSource::get(files[f], err);
+            if (!ss) return false;
+            const uint64_t L = ss->read_len(), per = std::max<uint64_t>(1, chunk_bytes / (2 * (L + 1))), n_ch = (ss->n_pairs() + per - 1) / per;
+            std::atomic<uint64_t> next(0); std::mutex m_sink;
+            std::vector<std::thread> th;
+            const int nt = n_threads < 1 ? 1 : n_threads;
+            for (int t = 0; t < nt; ++t) th.emplace_back([&]() {
+                std::string buf;
+                for (;;) {
+                    const uint64_t c = next.fetch_add(1);
+                    if (c >= n_ch) break;
+                    const uint64_t p0 = c * per, p1 = std::min<uint64_t>(ss->n_pairs(), p0 + per);
+                    buf.assign(static_cast<size_t>((p1 - p0) * 2 * (L + 1)), '\n');
+                    for (uint64_t p = p0; p < p1; ++p) ss->pair(p, &buf[static_cast<size_t>((p - p0) * 2 * (L + 1))], &buf[static_cast<size_t>((p - p0) * 2 * (L + 1) + L + 1)]);
+                    std::lock_guard<std::mutex> lk(m_sink);
+                    sink(buf.data(), buf.size());
+                }
+            });
+            for (size_t t = 0; t < th.size(); ++t) th[t].join();
+            continue;
+        }
         if (!rtk::PlainChunks::is_plain(files[f])) { // gzip or unknown: one reader thread
             rtk::FastxReader rd; if (!rd.open(files[f], n_threads < 16 ? n_threads : 16)) { *err = "cannot open " + files[f]; return false; } // (a gzip file of several members is inflated on the threads, common/mgzip.hpp)
             std::string name, seq, qual, buf; buf.reserve(chunk_bytes);
@@ -130,7 +152,7 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
         std::vector<std::string> fl(files, files + n_files);
         // passes: the k-mers of one pass (one hash partition of the k-mer space) must fit twice (radix sort) next to what else lives on the device
         uint64_t total_bytes = 0;
-        for (size_t f = 0; f < fl.size(); ++f) { FILE* fp = fopen(fl[f].c_str(), "rb"); if (!fp) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: cannot open " + fl[f]); fseek(fp, 0, SEEK_END); total_bytes += static_cast<uint64_t>(ftell(fp)); fclose(fp); }
+        for (size_t f = 0; f < fl.size(); ++f) { if (rtk::SampleSource::is_spec(fl[f])) { std::string e_; std::shared_ptr<rtk::SampleSource> ss = rtk::SampleSource::get(fl[f], &e_); if (!ss) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: " + e_); total_bytes += 2 * ss->n_bases(); continue; } FILE* fp = fopen(fl[f].c_str(), "rb"); if (!fp) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: cannot open " + fl[f]); fseek(fp, 0, SEEK_END); total_bytes += static_cast<uint64_t>(ftell(fp)); fclose(fp); }
         size_t fr = 0, tot = 0; rtk_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo");
         const uint64_t est_kmers = total_bytes / 2 + (1u << 20); // FASTQ: half of the bytes are bases (gzip input: a multiple of it; the capacity test below catches that)
         uint64_t cap = static_cast<uint64_t>(fr) / 10 * 4 / 16; // 40 % of the free memory for keys + their sort buffer

@@ -250,6 +250,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     double global_cov_factor = 3.0, min_color_sharing = 0.5;
     bool detect_cycles = true, detect_snps = false;
     bool fast = false, gpu = false; // --fast: the same files from thread-parallel counting-table build / compaction / adjacency / cycle search; --gpu: --fast with the k-mers counted on the device
+    std::string dump_input; // --dump-input FILE: the inputs (sample: sources included) written out as one FASTQ file, nothing else done
     std::vector<std::string> colour_files; // pass-2 index (`Ratatosk index -2`): colours = ids of these (pass-1 corrected long) reads, one id per read
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -264,9 +265,17 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         else if (a == "--fast") fast = true;
         else if (a == "--gpu") { fast = true; gpu = true; }
         else if (a == "--colour-reads") colour_files.push_back(need("--colour-reads"));
+        else if (a == "--dump-input") dump_input = need("--dump-input");
         else { fprintf(stderr, "rtk_build_index: unknown option %s\n", a.c_str()); return 2; }
     }
-    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=63)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--fast | --gpu (k <= 31: same files, threads / the device for the heavy steps)] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
+    if (in_files.empty() || k < 3 || k > RTK_MAX_K || !(k & 1)) { fprintf(stderr, "usage: rtk_build_index -s reads.fq [-s ...] -o PREFIX [-k 31 (odd, <=63)] [--min-count 2] [--global-cov-factor 3.0] [--no-short-cycles] [--snps] [--fast | --gpu (k <= 31: same files, threads / the device for the heavy steps)] [--dump-input FILE] [--colour-reads corrected_long_reads.fq: second-pass index, the graph comes from -s, colours and coverage from these reads]\n"); return 2; }
+    if (!dump_input.empty()) { // what a `sample:` source stands for, as a file (tests compare the index built from either)
+        FILE* fo = fopen(dump_input.c_str(), "wb"); if (!fo) { fprintf(stderr, "rtk_build_index: cannot write %s\n", dump_input.c_str()); return 1; }
+        std::string name, seq, qual;
+        for (size_t f = 0; f < in_files.size(); ++f) { FastxReader fr; if (!fr.open(in_files[f])) { fprintf(stderr, "rtk_build_index: cannot open %s\n", in_files[f].c_str()); return 1; }
+            while (fr.next(name, seq, qual)) fprintf(fo, "@%s\n%s\n+\n%s\n", name.c_str(), seq.c_str(), qual.empty() ? std::string(seq.size(), 'I').c_str() : qual.c_str()); }
+        fclose(fo); return 0;
+    }
     const KM mask = km_mask<KM>(k);
     if (fast && sizeof(KM) != 8) { fprintf(stderr, "rtk_build_index: --fast / --gpu serve one-word k-mers (k <= 31); k = %d takes the plain path\n", k); fast = false; gpu = false; }
     const auto t_start = std::chrono::steady_clock::now();
@@ -429,6 +438,47 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             }
         };
         bool par_colour = fast;
+        bool all_sampled = fast && !by_read && !col_in.empty();
+        for (size_t f = 0; all_sampled && f < col_in.size(); ++f) all_sampled = SampleSource::is_spec(col_in[f]);
+        if (all_sampled) {
+            // reads sampled from a reference on the fly (common/sample_source.hpp): pair p of a source has the id (pairs of the sources before it) + p
+            // (the number of name changes before it: mates share the name "s<p>"); ranges of pairs generated and looked up by all threads
+            par_colour = false;
+            for (unsigned t = 0; t < n_thr; ++t) t_cov[t].assign(n_u, 0);
+            uint64_t id_base = 0;
+            for (size_t f = 0; f < col_in.size() && !open_failed; ++f) {
+                std::string err; std::shared_ptr<SampleSource> ss = SampleSource::get(col_in[f], &err);
+                if (!ss) { fprintf(stderr, "rtk_build_index: %s\n", err.c_str()); open_failed = 1; break; }
+                if (id_base + ss->n_pairs() > 0xFFFFFFFFull) { fprintf(stderr, "rtk_build_index: more than 2^32 read pairs\n"); open_failed = 1; break; }
+                const uint64_t per = 1 << 14, n_ch = (ss->n_pairs() + per - 1) / per; const uint32_t L = ss->read_len();
+                std::atomic<uint64_t> nx(0);
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < n_thr; ++t) th.emplace_back([&, t]() {
+                    std::vector<uint64_t>& cov = t_cov[t]; std::vector<std::pair<uint32_t, uint32_t> >& ev = t_ev[t];
+                    std::string m(2 * static_cast<size_t>(L), 'A');
+                    for (;;) { const uint64_t c = nx.fetch_add(1); if (c >= n_ch) break;
+                        const uint64_t p0 = c * per, p1 = std::min<uint64_t>(ss->n_pairs(), p0 + per);
+                        for (uint64_t p = p0; p < p1; ++p) {
+                            ss->pair(p, &m[0], &m[L]);
+                            const uint32_t id = static_cast<uint32_t>(id_base + p);
+                            for (int mate = 0; mate < 2; ++mate) {
+                                const char* seq = m.data() + mate * L; KM fw = 0; int valid = 0;
+                                for (uint32_t y = 0; y < L; ++y) {
+                                    const int b = base2bits(seq[y]);
+                                    if (b < 0) { valid = 0; fw = 0; continue; }
+                                    fw = ((fw << 2) | static_cast<KM>(b)) & mask;
+                                    if (++valid >= k) {
+                                        const uint64_t* v = km.slot(kmer_canonical(fw, k), false);
+                                        if (v) { const uint32_t u = static_cast<uint32_t>((*v >> 32) - 1); ++cov[u]; if (ev.empty() || ev.back().first != u || ev.back().second != id) ev.push_back(std::make_pair(u, id)); }
+                                    }
+                                }
+                            }
+                        }
+                    } });
+                for (size_t t = 0; t < th.size(); ++t) th[t].join();
+                id_base += ss->n_pairs();
+            }
+        }
         for (size_t f = 0; par_colour && f < col_in.size(); ++f) par_colour = PlainChunks::is_plain(col_in[f]);
         if (par_colour) {
             // --fast on plain files: byte ranges of the files parsed and looked up by all threads. The id of a read is the number of name changes
@@ -489,8 +539,8 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             }
         }
         std::vector<std::thread> th;
-        if (!par_colour) for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(work, t);
-        if (!par_colour) {
+        if (!par_colour && !all_sampled) for (unsigned t = 0; t < n_thr; ++t) th.emplace_back(work, t);
+        if (!par_colour && !all_sampled) {
             std::string name, seq, qual, prev_name;
             uint32_t pair_id = 0; bool first = true;
             Chunk* cur = new Chunk();

@@ -134,6 +134,45 @@ def test_gpu_index_build_against_the_independent_oracle(tmp_path):
     _index_vs_oracle(_self_meeting_genomes(tmp), os.path.join(tmp, "o_self_g"), 31, ["--gpu"])
 
 
+def _sample_spec(tmp, name):
+    """a reference written by rtk_simulate (two haplotypes) + the `sample:` source over it (common/sample_source.hpp)"""
+    pre = os.path.join(tmp, name)
+    subprocess.check_call([os.path.join(BIN, "rtk_simulate"), "--prefix", pre, "--seed", "4", "--ref-len", "120000", "--het", "0.002", "--repeat-frac", "0.05", "--sr-cov", "0", "--lr-n", "2", "--lr-len", "1000"], stderr=subprocess.DEVNULL)
+    return "sample:%s.ref.fa?cov=24&len=150&insert=400&err=0.005&seed=9" % pre
+
+
+def test_index_from_reads_sampled_on_the_fly(tmp_path):
+    """`-s sample:REF.fa?cov=..` (short reads generated inside the tool, pair by pair from (seed, pair number): the input of the whole-genome-scale set
+    never exists as a file) gives the index of the FASTQ file it stands for (`--dump-input`), through the plain and the thread-parallel paths."""
+    tmp = str(tmp_path)
+    spec = _sample_spec(tmp, "smp")
+    dump = os.path.join(tmp, "smp.dump.fq")
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", spec, "--dump-input", dump])
+    lines = open(dump).read().split("\n")
+    assert len(lines) // 4 == 2 * int(24 * 120000 / 300) and lines[0] == lines[4] == "@s0" and lines[8] == "@s1" and len(lines[1]) == 150 and lines[1] != lines[5]
+    want = _build(dump, os.path.join(tmp, "smp_file"), 31, [])
+    for mode in ([], ["--fast"]):
+        got = _build(spec, os.path.join(tmp, "smp_src"), 31, mode)
+        assert got[0] == want[0] and got[1] == want[1], mode
+    assert _index_vs_oracle(dump, os.path.join(tmp, "smp_o"), 31, ["--fast"]) > 10  # and the independent oracle agrees on that file
+
+
+@pytest.mark.gpu
+def test_gpu_index_from_reads_sampled_on_the_fly(tmp_path):
+    """the same with the k-mers counted on the device from pair ranges generated by the tool's threads"""
+    tmp = str(tmp_path)
+    spec = _sample_spec(tmp, "smpg")
+    dump = os.path.join(tmp, "smpg.dump.fq")
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", spec, "--dump-input", dump])
+    want = _build(dump, os.path.join(tmp, "smpg_file"), 31, [])
+    os.environ["RTK_INDEX_CAP"] = "3000000"  # several partitions of the k-mer space: the source is generated once per partition
+    try:
+        got = _build(spec, os.path.join(tmp, "smpg_src"), 31, ["--gpu"])
+    finally:
+        del os.environ["RTK_INDEX_CAP"]
+    assert got[0] == want[0] and got[1] == want[1]
+
+
 def test_fast_index_build_writes_the_same_files(tmp_path):
     tmp = str(tmp_path)
     for name, args in SETS:
