@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--serial", action="store_true", help="run the two stages of every step back to back (no overlap between steps)")
+    ap.add_argument("--serial", action="store_true", help="(the default since round 4) run the two stages of every step back to back")
+    ap.add_argument("--overlap", action="store_true", help="software-pipeline consecutive steps on two streams (stage A of step s+1 beside stage B of step s): the default of rounds 1-3; "
+                                                           "measured slower in round 4 (56.8 vs 54.9 ms per step on the 60 Mb set, 38.8 vs 38.0 on configs[1]): the seed kernels of the next step only take "
+                                                           "wave slots from the region kernel, whose waves are all busy")
     ap.add_argument("--ref-len", type=int, default=60_000_000, help="reference length of the main workload (default: the 60 Mb chr20-scale set of configs[2], at every N)")
     ap.add_argument("--het", type=float, default=None, help="heterozygous SNP rate of the diploid reference (default 0.001; 0 with --config1-only)")
     ap.add_argument("--config2", action="store_true", help="(accepted for older scripts: the 60 Mb set is the default workload now)")
@@ -55,6 +58,7 @@ def parse():
     ap.add_argument("--plain-index", action="store_true", help="index without SNP annotations (like the reference's `index -F`); for A/B measurements only")
     ap.add_argument("--sim", action="store_true", help="CPU-only developer simulator + gloo (tests of the N>1 plumbing); never a benchmark")
     a = ap.parse_args()
+    a.serial = not a.overlap
     if a.config1_only:
         a.ref_len = 5_000_000 if a.ref_len == 60_000_000 else a.ref_len
         a.het = 0.0 if a.het is None else a.het
@@ -380,8 +384,8 @@ def run_workload(a, ctx, ref_len, het, name, steps, warmup, n1_first=False):
             api.run_pipelined(seq_b, opts)
         return t0_
 
-    # a step = one batch through both stages. Consecutive steps are software-pipelined on two HIP streams: while the region kernels of
-    # step s run, the (latency-bound) seed kernels of step s+1 run beside them. All K steps are complete before the clock stops.
+    # a step = one batch through both stages, one step after the other (--overlap: consecutive steps software-pipelined on two HIP streams).
+    # All K steps are complete before the clock stops.
     api.run_pipelined([batches[w % len(batches)] for w in range(warmup)], opts)
     sync()
     n1 = None

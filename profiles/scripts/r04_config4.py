@@ -1,0 +1,111 @@
+"""configs[4] of BASELINE.json at its stated size: whole-genome-scale graph (REF_MB megabases, diploid with 0.1 % heterozygous SNPs, 3 % two-copy
+repeats), SR_COV x PE150 short reads SAMPLED ON THE FLY inside the index tool (`-s sample:...`: the 180 GB FASTQ of a 3 Gb x 30x set never exists),
+index built with `--gpu --snps`, graph loaded and resident in HBM, TICKETS 64 Mb tickets of ONT-profile long reads corrected with three in flight.
+Size-independent checks as in round 3 (the oracle cannot hold this graph): corrected reads against the stretches of the reference they were
+simulated from (edit distances by the device's banded NW), share of k-mer windows found in the graph.
+Usage (GPU box): python profiles/scripts/r04_config4.py [REF_MB=3000] [SR_COV=30] [THREADS=128] [TICKETS=6]      (RTK_C4_OUT=file.json, RTK_C4_DIR=/tmp)
+Leaves the index under $RTK_C4_DIR/c4_keep/ when RTK_C4_KEEP=1 (the profiling passes of r04_config4.sh reuse it)."""
+import ctypes as C, json, os, subprocess, sys, tempfile, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+from ratatosk_amd import api
+ref_mb = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+sr_cov = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+n_tickets = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+base = os.environ.get("RTK_C4_DIR", "/tmp")
+wd = os.path.join(base, "c4_keep") if os.environ.get("RTK_C4_KEEP") else tempfile.mkdtemp(prefix="rtk_c4_", dir=base)
+os.makedirs(wd, exist_ok=True)
+pre = os.path.join(wd, "c4")
+bin_dir = os.path.join(ROOT, "ratatosk_amd", "bin")
+out = {"ref_mb": ref_mb, "sr_cov": sr_cov, "threads": threads, "what": "configs[4]: whole-genome-scale graph resident in HBM; short reads sampled on the fly inside the index tool"}
+def save():
+    if os.environ.get("RTK_C4_OUT"):
+        json.dump(out, open(os.environ["RTK_C4_OUT"], "w"), indent=1)
+lr_bases = n_tickets * 64_000_000 + 2_000_000
+t0 = time.time()
+subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "5", "--ref-len", str(ref_mb * 1000000), "--het", "0.001", "--repeat-frac", "0.03", "--sr-cov", "0",
+                       "--lr-cov", "%.5f" % (lr_bases / (ref_mb * 1e6)), "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07", "--lr-truth"], stderr=subprocess.DEVNULL)
+out["simulate_s"] = round(time.time() - t0, 1); out["ref_fasta_gb"] = round(os.path.getsize(pre + ".ref.fa") / 1e9, 2); save()
+spec = "sample:%s.ref.fa?cov=%g&len=150&insert=400&err=0.005&seed=7" % (pre, sr_cov)
+out["short_reads"] = {"source": spec.replace(wd, "$WD"), "bases": int(sr_cov * ref_mb * 1e6), "fastq_bytes_never_written": int(2 * sr_cov * ref_mb * 1e6 * (150 + 150 + 12) / 300)}
+t0 = time.time()
+r = subprocess.run([os.path.join(bin_dir, "rtk_build_index"), "-s", spec, "-o", pre, "--gpu", "--snps"], stderr=subprocess.PIPE, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1", RTK_INDEX_THREADS=str(threads)))
+out["build_index_s"] = round(time.time() - t0, 1); out["build_index_log"] = r.stderr.strip().splitlines()[-40:]; save()
+assert r.returncode == 0, r.stderr[-2000:]
+out["box"] = {"host_ram_gb": round(os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9), "cpus": os.cpu_count()}
+fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
+out["index_files_gb"] = {"fasta.gz": round(os.path.getsize(fa) / 1e9, 3), "rtsk": round(os.path.getsize(rt) / 1e9, 3)}
+L = api.load_library()
+h = C.c_void_p()
+t0 = time.time(); rc = L.rtk_graph_load(fa.encode(), rt.encode(), 31, threads, C.byref(h)); out["graph_load_s"] = round(time.time() - t0, 1)
+assert rc == 0, L.rtk_last_error()
+t0 = time.time(); rc = L.rtk_graph_upload(h, 0); out["graph_upload_s"] = round(time.time() - t0, 1)
+assert rc == 0, L.rtk_last_error()
+g = api.Graph.__new__(api.Graph); g.L, g.k, g.h = L, 31, h
+info = g.info()
+sizes = (C.c_uint64 * L.rtk_graph_n_buffers(None))(); L.rtk_graph_buffer_bytes(h, sizes, len(sizes))
+names = ["useq", "uoff", "adj", "flags", "kcov", "card", "loff", "gid", "goff", "col", "ht", "bf", "cycoff", "cyc", "bf1", "amb", "hx", "hxl", "hap"]
+out["graph"] = {"unitigs": int(info.n_unitigs), "kmers": int(info.n_kmers), "colour_ids": int(info.n_colour_ids), "hbm_gb": round(info.hbm_bytes / 1e9, 2),
+                "buffers_gb": {(names[i] if i < len(names) else "buf%d" % i): round(sizes[i] / 1e9, 3) for i in range(len(sizes))}}
+save()
+import bench
+seqs, quals = bench.read_long_reads(pre + ".lr.fq", n_tickets * 64_000_000)
+tickets, cs, cq, cur = [], [], [], 0
+for s_, q_ in zip(seqs, quals):
+    cs.append(s_); cq.append(q_); cur += len(s_)
+    if cur >= 64_000_000:
+        tickets.append((cs, cq)); cs, cq, cur = [], [], 0
+opts = g.opts()
+batches = [api.Batch(g, *t) for t in tickets]
+t0 = time.time(); batches[0].run(opts); out["first_ticket_run_s"] = round(time.time() - t0, 2)
+# all tickets, three in flight (the CLI's three workers per GPU): two host threads keep the seed stage of one ticket beside the region stage of another
+import torch
+torch.cuda.synchronize(); t0 = time.time()
+api.run_pipelined(batches, opts)
+torch.cuda.synchronize(); dt = time.time() - t0
+tot = sum(b.in_bases for b in batches)
+st = [b.stats() for b in batches]
+kern = {"k_lookup_exact": "ms_lookup_exact", "k_mask": "ms_mask", "k_inexact": "ms_lookup_inexact", "k_finalize": "ms_seeds", "k_regions": "ms_correct", "k_stitch": "ms_stitch"}
+out["tickets"] = {"n": len(batches), "bases": tot, "seconds": round(dt, 3), "bases_per_s": round(tot / dt), "ms_per_ticket": round(1e3 * dt / len(batches), 2),
+                  "kernel_ms_per_ticket_overlapped": {k_: round(sum(s_[v] for s_ in st) / len(st), 2) for k_, v in kern.items()}, "regions_per_ticket": int(sum(s_["n_regions"] for s_ in st) / len(st))}
+b = batches[0]; b.run(opts); s1 = b.stats()
+out["tickets"]["kernel_ms_one_ticket_alone"] = {k_: round(s1[v], 2) for k_, v in kern.items()}
+got = b.fetch(); seqs0 = tickets[0][0]; save()
+free, total = torch.cuda.mem_get_info(0); out["hbm_in_use_gb_with_%d_tickets" % len(batches)] = round((total - free) / 1e9, 1)
+def rcs(x):
+    return x[::-1].translate(str.maketrans("ACGT", "TGCA"))
+truth = [l.split("\t") for l in open(pre + ".lr.truth.tsv").read().splitlines()][:400]
+need = {}
+for i, (_, hap, start, ln, strand) in enumerate(truth):
+    need.setdefault(int(hap), []).append((int(start), int(ln), strand, i))
+tr = [None] * len(truth)
+hap_i, pos, want = -1, 0, None
+with open(pre + ".ref.fa") as f:  # one pass over the reference (6 GB at 3 Gb diploid): only the truth stretches are kept
+    for line in f:
+        if line.startswith(">"):
+            hap_i += 1; pos = 0; want = sorted(need.get(hap_i, [])); continue
+        line = line.rstrip("\n"); n = len(line)
+        if want:
+            for (s0, ln, strand, i) in want:
+                if s0 < pos + n and s0 + ln > pos:
+                    a, b_ = max(s0, pos) - pos, min(s0 + ln, pos + n) - pos
+                    tr[i] = (tr[i] or "") + line[a:b_]
+            want = [w for w in want if w[0] + w[1] > pos + n]
+        pos += n
+for i, (_, hap, start, ln, strand) in enumerate(truth):
+    assert tr[i] is not None and len(tr[i]) == int(ln), (i, ln, len(tr[i] or ""))
+    if strand == "-":
+        tr[i] = rcs(tr[i])
+n_chk = len(truth)
+d_raw = [r_[0] for r_ in api.myers_batch(seqs0[:n_chk], tr, [-1] * n_chk, [0] * n_chk)]
+d_cor = [r_[0] for r_ in api.myers_batch([g_[0] for g_ in got[:n_chk]], tr, [-1] * n_chk, [0] * n_chk)]
+tot_len = sum(len(t_) for t_ in tr)
+solid = lambda s_: sum(1 for h_ in g.lookup_exact(s_.upper()) if h_ != -1) / max(1, len(s_) - 30)
+sol_raw = sum(solid(s_) for s_ in seqs0[:50]) / 50; sol_cor = sum(solid(g_[0]) for g_ in got[:50]) / 50
+out["property_checks"] = {"reads_checked": n_chk, "error_rate_raw": round(sum(d_raw) / tot_len, 4), "error_rate_corrected": round(sum(d_cor) / tot_len, 4),
+                          "reads_not_closer_to_truth": sum(1 for a_, b_ in zip(d_raw, d_cor) if b_ > a_), "solid_window_share_raw": round(sol_raw, 3), "solid_window_share_corrected": round(sol_cor, 3)}
+save()
+assert out["property_checks"]["error_rate_corrected"] < 0.5 * out["property_checks"]["error_rate_raw"] and sol_cor > sol_raw
+print(json.dumps(out))

@@ -190,3 +190,24 @@ def test_gpu_config3_two_passes_on_the_config2_graph(config2_set):
     assert not bad, "%d of %d reads differ from the oracle (first: %s)" % (len(bad), len(seqs), bad[:5])
     assert sum(1 for a, b in zip(want, s1) if a[0] != b) > 0  # the second pass did something
     print("configs[3] on the configs[2] graph: %d reads / %d bases, second index %.0f s, HIP -2 (host-inclusive) %.1f s, oracle %.1f s" % (n, acc, t_idx, t_gpu, t_cpu))
+
+
+@pytest.mark.gpu
+def test_gpu_config4_scaled_down_graph_above_2_pow_28_kmers(tmp_path):
+    """configs[4] (whole-genome-scale graph resident in HBM) at a tenth of its size, so that the paths only a big graph takes are in this tier: more
+    than 2^28 k-mers (the k-mer table with a number of slots that is not a power of two, 64-bit offsets into the unitig pool and the half-k-mer
+    lists), short reads sampled on the fly inside the index tool (no FASTQ on disk), index with SNP annotations built with the k-mers counted on
+    the device. The oracle cannot hold such a graph: the checks are size-independent -- corrected reads are closer to the stretches of the
+    reference they were simulated from than the raw reads (error rate at least halved, no read further away), more k-mer windows in the graph.
+    profiles/scripts/r04_config4.py is the same program the 3 Gb run of profiles/r04_config4_dry_run.json used."""
+    out = str(tmp_path / "c4.json")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r04_config4.py"), "300", "8", "64", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RTK_C4_OUT=out, RTK_C4_DIR=str(tmp_path)))
+    assert r.returncode == 0, (r.stderr[-1500:], open(out).read()[-1500:] if os.path.exists(out) else "")
+    d = json.load(open(out))
+    assert d["graph"]["kmers"] > (1 << 28) and d["graph"]["hbm_gb"] > 10
+    pc = d["property_checks"]
+    assert pc["reads_checked"] == 400 and pc["error_rate_corrected"] < 0.5 * pc["error_rate_raw"] and pc["reads_not_closer_to_truth"] <= 8
+    assert pc["solid_window_share_corrected"] > 0.8 > pc["solid_window_share_raw"]
+    print("configs[4] at 300 Mb: %.0f s in all (index %.0f s, load %.0f s), %.1f GB in HBM, %.3g bases/s" % (time.time() - t0, d["build_index_s"], d["graph_load_s"], d["graph"]["hbm_gb"], d["tickets"]["bases_per_s"]))
