@@ -61,10 +61,9 @@ opts = g.opts()
 batches = [api.Batch(g, *t) for t in tickets]
 t0 = time.time(); batches[0].run(opts); out["first_ticket_run_s"] = round(time.time() - t0, 2)
 # all tickets, three in flight (the CLI's three workers per GPU): two host threads keep the seed stage of one ticket beside the region stage of another
-import torch
-torch.cuda.synchronize(); t0 = time.time()
-api.run_pipelined(batches, opts)
-torch.cuda.synchronize(); dt = time.time() - t0
+t0 = time.time()
+api.run_pipelined(batches, opts)  # (returns when every ticket's stream has been waited for)
+dt = time.time() - t0
 tot = sum(b.in_bases for b in batches)
 st = [b.stats() for b in batches]
 kern = {"k_lookup_exact": "ms_lookup_exact", "k_mask": "ms_mask", "k_inexact": "ms_lookup_inexact", "k_finalize": "ms_seeds", "k_regions": "ms_correct", "k_stitch": "ms_stitch"}
@@ -73,7 +72,9 @@ out["tickets"] = {"n": len(batches), "bases": tot, "seconds": round(dt, 3), "bas
 b = batches[0]; b.run(opts); s1 = b.stats()
 out["tickets"]["kernel_ms_one_ticket_alone"] = {k_: round(s1[v], 2) for k_, v in kern.items()}
 got = b.fetch(); seqs0 = tickets[0][0]; save()
-free, total = torch.cuda.mem_get_info(0); out["hbm_in_use_gb_with_%d_tickets" % len(batches)] = round((total - free) / 1e9, 1)
+fr, tt = C.c_uint64(), C.c_uint64()
+if L.rtk_device_memory(0, C.byref(fr), C.byref(tt)) == 0:
+    out["hbm_in_use_gb_with_%d_tickets" % len(batches)] = round((tt.value - fr.value) / 1e9, 1); out["hbm_total_gb"] = round(tt.value / 1e9, 1)
 def rcs(x):
     return x[::-1].translate(str.maketrans("ACGT", "TGCA"))
 truth = [l.split("\t") for l in open(pre + ".lr.truth.tsv").read().splitlines()][:400]
