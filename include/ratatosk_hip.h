@@ -96,6 +96,12 @@ typedef struct rtk_stats {
  * flattens everything to SoA/CSR arrays. k must be odd and <= 63: one-word k-mers (k <= 31) serve both passes, two-word k-mers
  * (33 .. 63) the second pass only (long_read_correct = 1; the 1-edit anchor search of the first pass is built on one-word k-mers). */
 int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out);
+/* The same with flags. RTK_LOAD_DEVICE_TABLES: the host only parses the two files and packs the unitigs; the lookup structures Bifrost keeps behind
+ * find() / getSuccessors() -- the k-mer table with its presence filters, the half-k-mer index of the 1-edit search, the adjacency -- are built in HBM by
+ * rtk_graph_upload (hip/rtk_graph_tables.hip; a k-mer that occurs twice in the unitig file is then reported by rtk_graph_upload, RTK_ERR_FORMAT).
+ * What `Ratatosk correct` and the Python front end use; rtk_graph_load (flags = 0: everything on the host threads) stays the definition. */
+#define RTK_LOAD_DEVICE_TABLES 1u
+int rtk_graph_load2(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, uint32_t flags, rtk_graph** out);
 
 /* Copies the flat graph into HBM of `device` (HIP device ordinal). Must precede any compute call. */
 int rtk_graph_upload(rtk_graph* g, int device);
@@ -111,6 +117,13 @@ int rtk_graph_adopt_device(rtk_graph* g);
 /* Same with caller-owned HBM buffers (e.g. torch tensors that torch.distributed broadcasts into); never freed by the library. */
 int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* dev_ptrs, const uint64_t* bytes, int n, const rtk_graph_info* info);
 int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n);
+/* A flat buffer of a resident graph handed over to caller-owned HBM (of at least its rtk_graph_buffer_bytes): copied device to device, the library's own
+ * copy freed. For rank 0 of a multi-GPU job whose tables were built by rtk_graph_upload, before it broadcasts them. */
+int rtk_graph_move_buffer(rtk_graph* g, int idx, void* dev_ptr, uint64_t bytes);
+/* (tests, tools) flat buffer idx of the host image: a pointer into the graph's own memory, valid until rtk_graph_free */
+int rtk_graph_host_buffer(const rtk_graph* g, int idx, const void** p, uint64_t* bytes);
+/* (tests, tools) `bytes` bytes of flat buffer idx of a resident graph copied to host memory */
+int rtk_graph_download_buffer(const rtk_graph* g, int idx, void* host_dst, uint64_t bytes);
 
 /* Single-process multi-GPU (the C++ `Ratatosk correct` driver): the index is parsed and flattened ONCE, uploaded to one GPU and
  * replicated to the others device-to-device (xGMI peer copies, one per flat buffer) -- the reference's worker threads likewise

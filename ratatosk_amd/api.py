@@ -59,6 +59,10 @@ def load_library(path=None):
     L.rtk_last_error.restype = C.c_char_p
     L.rtk_version.restype = C.c_char_p
     L.rtk_graph_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.rtk_graph_load2.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.rtk_graph_move_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+    L.rtk_graph_host_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.rtk_graph_download_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
     L.rtk_graph_upload.argtypes = [C.c_void_p, C.c_int]
     L.rtk_graph_shell.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.rtk_graph_n_buffers.argtypes = [C.c_void_p]
@@ -99,6 +103,9 @@ def load_library(path=None):
     return L
 
 
+RTK_LOAD_DEVICE_TABLES = 1
+
+
 def _b(s):
     return s.encode() if isinstance(s, str) else s
 
@@ -106,12 +113,16 @@ def _b(s):
 class Graph:
     """The compacted coloured de Bruijn graph, loaded from the reference's index files and resident in HBM."""
 
-    def __init__(self, fasta_gz, rtsk, k=31, device=0, lib_path=None, upload=True, n_threads=None):
+    def __init__(self, fasta_gz, rtsk, k=31, device=0, lib_path=None, upload=True, n_threads=None, host_tables=None):
+        """host_tables: build the lookup structures (k-mer table, half-k-mer index, adjacency) on the host threads instead of in HBM at upload time.
+        Default: on the device whenever the graph is uploaded (RTK_LOAD_DEVICE_TABLES); a graph that stays on the host (upload=False) gets the host's."""
         self.L = load_library(lib_path)
         self.h = C.c_void_p()
         if n_threads is None:  # parse + flatten on the host's threads (same image whatever their number)
             n_threads = max(1, min(32, os.cpu_count() or 1))
-        self._check(self.L.rtk_graph_load(_b(fasta_gz), _b(rtsk), k, n_threads, C.byref(self.h)))
+        if host_tables is None:
+            host_tables = not upload or os.environ.get("RTK_HOST_TABLES") == "1"
+        self._check(self.L.rtk_graph_load2(_b(fasta_gz), _b(rtsk), k, n_threads, 0 if host_tables else RTK_LOAD_DEVICE_TABLES, C.byref(self.h)))
         self.k = k
         if upload:
             self._check(self.L.rtk_graph_upload(self.h, device))

@@ -15,6 +15,7 @@
 
 #include "../../../include/ratatosk_hip.h"
 #include "../host/flat_graph.hpp"
+#include "rtk_graph_tables.h"
 #include "rtk_mem.h"
 #include "rtk_myers.h"
 #include "rtk_types.h"
@@ -45,6 +46,8 @@ extern "C" void rtk_free(void* p) { free(p); }
 struct rtk_graph {
     rtk::FlatGraph host;
     bool has_host = false, on_device = false, owns_buffers = true;
+    uint32_t moved = 0;         // bit i: flat buffer i lives in caller-owned memory (rtk_graph_move_buffer)
+    double table_seconds = 0.0; // device build of the lookup structures (RTK_LOAD_DEVICE_TABLES)
     int device = -1;
     void* dbuf[rtk::RTK_N_BUFS];
     uint64_t dbytes[rtk::RTK_N_BUFS];
@@ -111,19 +114,24 @@ static void graph_set_view(rtk_graph* g) {
     v.hx = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HX]); v.hx_mask = g->dbytes[rtk::RTK_BUF_HX] / 8 - 1; v.hxl = static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_HXL]);
 }
 
-extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out) {
+extern "C" int rtk_graph_load2(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, uint32_t flags, rtk_graph** out) {
     if (!unitig_fasta_gz || !rtsk || !out) return rtk_fail(RTK_ERR_ARG, "rtk_graph_load: null argument");
     std::unique_ptr<rtk_graph> g(new rtk_graph());
-    try { g->host.load(unitig_fasta_gz, rtsk, k, n_threads); }
+#ifdef RTK_SIM
+    flags &= ~static_cast<uint32_t>(RTK_LOAD_DEVICE_TABLES); // (the simulator has no device: its tables are the host's)
+#endif
+    try { g->host.load(unitig_fasta_gz, rtsk, k, n_threads, (flags & RTK_LOAD_DEVICE_TABLES) != 0); }
     catch (const std::exception& e) { return rtk_fail(RTK_ERR_FORMAT, std::string("rtk_graph_load: ") + e.what()); }
     g->has_host = true;
     rtk_graph_info& i = g->info;
     i.k = k; i.device = -1; i.n_unitigs = g->host.n_unitigs(); i.n_kmers = g->host.n_kmers; i.n_bases = g->host.uoff.back();
     i.n_colour_ids = g->host.col.size() - 1; i.n_global_sets = g->host.n_global; i.table_slots = g->host.ht.size() / 2; i.hbm_bytes = g->host.bytes();
+    if (g->host.tables_deferred) i.table_slots = rtk::table_sizes(k, g->host.n_kmers, g->host.uoff.back()).ht_slots; // (hbm_bytes: set by rtk_graph_upload, which builds the tables)
     i.max_km_cov_top = g->host.max_km_cov_top;
     *out = g.release();
     return RTK_OK;
 }
+extern "C" int rtk_graph_load(const char* unitig_fasta_gz, const char* rtsk, int k, int n_threads, rtk_graph** out) { return rtk_graph_load2(unitig_fasta_gz, rtsk, k, n_threads, 0u, out); }
 
 extern "C" int rtk_graph_shell(int k, rtk_graph** out) {
     if (!out) return rtk_fail(RTK_ERR_ARG, "rtk_graph_shell: null argument");
@@ -162,7 +170,9 @@ extern "C" int rtk_graph_attach_buffers(rtk_graph* g, int device, void* const* d
 }
 
 extern "C" int rtk_graph_buffer_bytes(const rtk_graph* g, uint64_t* bytes, int n) {
-    if (!g || !bytes || n != rtk::RTK_N_BUFS || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer_bytes: needs a loaded graph");
+    if (!g || !bytes || n != rtk::RTK_N_BUFS || !(g->has_host || g->on_device)) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer_bytes: needs a loaded graph");
+    if (g->on_device) { for (int i = 0; i < n; ++i) bytes[i] = g->dbytes[i]; return RTK_OK; }
+    if (g->host.tables_deferred) return rtk_fail(RTK_ERR_ARG, "rtk_graph_buffer_bytes: the tables of this graph are built by rtk_graph_upload (RTK_LOAD_DEVICE_TABLES): call it first");
     const rtk::FlatGraph& h = g->host;
     const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size(), 8 * h.hx.size(), 8 * h.hxl.size(), 8 * h.hap.size() };
     for (int i = 0; i < n; ++i) bytes[i] = b[i];
@@ -175,9 +185,26 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
     const rtk::FlatGraph& h = g->host;
     const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data(), h.bf.data(), h.cycoff.data(), h.cyc.data(), h.bf1.data(), h.amb.data(), h.hx.data(), h.hxl.data(), h.hap.data() };
     const uint64_t bytes[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size(), 8 * h.hx.size(), 8 * h.hxl.size(), 8 * h.hap.size() };
+    static const int built_here[6] = { rtk::RTK_BUF_HT, rtk::RTK_BUF_BF, rtk::RTK_BUF_BF1, rtk::RTK_BUF_HX, rtk::RTK_BUF_HXL, rtk::RTK_BUF_ADJ };
+    const bool deferred = h.tables_deferred;
     try {
         rtk_set_device(device);
-        for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { if (!g->dbuf[i]) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; } rtk_h2d(g->dbuf[i], src[i], bytes[i]); }
+        for (int i = 0; i < rtk::RTK_N_BUFS; ++i) {
+            bool skip = false; for (int j = 0; j < 6 && deferred; ++j) skip = skip || built_here[j] == i;
+            if (skip) { if (g->dbuf[i]) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: a graph loaded with RTK_LOAD_DEVICE_TABLES allocates its table buffers itself (move them afterwards: rtk_graph_move_buffers)"); continue; }
+            if (!g->dbuf[i]) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; } rtk_h2d(g->dbuf[i], src[i], bytes[i]);
+        }
+#ifndef RTK_SIM
+        if (deferred) { // the lookup structures from the packed unitigs, in HBM (hip/rtk_graph_tables.hip)
+            rtk::DeviceTables t; memset(&t, 0, sizeof(t));
+            try { rtk::device_tables_build(static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_USEQ]), static_cast<const uint64_t*>(g->dbuf[rtk::RTK_BUF_UOFF]), h.n_unitigs(), h.uoff.back(), h.n_kmers, h.k, &t); }
+            catch (const std::exception& e) { return rtk_fail(strstr(e.what(), "occurs twice") ? RTK_ERR_FORMAT : RTK_ERR_DEVICE, std::string("rtk_graph_upload: ") + e.what()); }
+            void* const p[6] = { t.ht, t.bf, t.bf1, t.hx, t.hxl, t.adj }; const uint64_t b[6] = { t.ht_bytes, t.bf_bytes, t.bf1_bytes, t.hx_bytes, t.hxl_bytes, t.adj_bytes };
+            for (int j = 0; j < 6; ++j) { g->dbuf[built_here[j]] = p[j]; g->dbytes[built_here[j]] = b[j]; }
+            g->info.table_slots = t.ht_slots; g->info.hbm_bytes = 0; for (int i = 0; i < rtk::RTK_N_BUFS; ++i) g->info.hbm_bytes += g->dbytes[i];
+            g->table_seconds = t.seconds[3];
+        }
+#endif
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
     g->device = device; g->info.device = device; g->on_device = true;
     graph_set_view(g);
@@ -225,6 +252,39 @@ extern "C" int rtk_graph_buffer(rtk_graph* g, int idx, void** dev_ptr, uint64_t*
     return RTK_OK;
 }
 
+// A resident flat buffer of a graph moved into caller-owned HBM (a torch tensor that torch.distributed then broadcasts from): device to device, the
+// library's own copy freed. For graphs whose tables were built by rtk_graph_upload -- their sizes are not known before. One buffer per call, so that a
+// caller can allocate the destinations one at a time (a whole-genome graph does not fit twice).
+extern "C" int rtk_graph_move_buffer(rtk_graph* g, int idx, void* dev_ptr, uint64_t bytes) {
+    if (!g || idx < 0 || idx >= rtk::RTK_N_BUFS || !dev_ptr || !g->on_device) return rtk_fail(RTK_ERR_ARG, "rtk_graph_move_buffer: needs a resident graph, a buffer index and a destination");
+    if (bytes < g->dbytes[idx]) return rtk_fail(RTK_ERR_ARG, "rtk_graph_move_buffer: the destination is smaller than the buffer");
+    try {
+        rtk_set_device(g->device);
+        rtk_d2d_peer(dev_ptr, g->device, g->dbuf[idx], g->device, g->dbytes[idx]); rtk_dsync();
+        if (g->owns_buffers && !(g->moved >> idx & 1u)) rtk_dfree(g->dbuf[idx]);
+        g->dbuf[idx] = dev_ptr; g->moved |= 1u << idx;
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_graph_move_buffer: ") + e.what()); }
+    graph_set_view(g);
+    return RTK_OK;
+}
+
+// (tests, tools) a flat buffer of the HOST image: pointer into the graph's own memory, valid until rtk_graph_free
+extern "C" int rtk_graph_host_buffer(const rtk_graph* g, int idx, const void** p, uint64_t* bytes) {
+    if (!g || idx < 0 || idx >= rtk::RTK_N_BUFS || !p || !bytes || !g->has_host) return rtk_fail(RTK_ERR_ARG, "rtk_graph_host_buffer: needs a loaded graph");
+    const rtk::FlatGraph& h = g->host;
+    const void* src[rtk::RTK_N_BUFS] = { h.useq.data(), h.uoff.data(), h.adj.data(), h.flags.data(), h.kcov.data(), h.card.data(), h.loff.data(), h.gid.data(), h.goff.data(), h.col.data(), h.ht.data(), h.bf.data(), h.cycoff.data(), h.cyc.data(), h.bf1.data(), h.amb.data(), h.hx.data(), h.hxl.data(), h.hap.data() };
+    const uint64_t b[rtk::RTK_N_BUFS] = { 8 * h.useq.size(), 8 * h.uoff.size(), 4 * h.adj.size(), 4 * h.flags.size(), 4 * h.kcov.size(), 4 * h.card.size(), 8 * h.loff.size(), 4 * h.gid.size(), 8 * h.goff.size(), 4 * h.col.size(), 8 * h.ht.size(), 8 * h.bf.size(), 8 * h.cycoff.size(), 8 * h.cyc.size(), 8 * h.bf1.size(), 8 * h.amb.size(), 8 * h.hx.size(), 8 * h.hxl.size(), 8 * h.hap.size() };
+    *p = src[idx]; *bytes = b[idx];
+    return RTK_OK;
+}
+
+// (tests, tools) a flat buffer of the resident graph copied to host memory
+extern "C" int rtk_graph_download_buffer(const rtk_graph* g, int idx, void* host_dst, uint64_t bytes) {
+    if (!g || idx < 0 || idx >= rtk::RTK_N_BUFS || !host_dst || !g->on_device || bytes > g->dbytes[idx]) return rtk_fail(RTK_ERR_ARG, "rtk_graph_download_buffer: bad argument");
+    try { rtk_set_device(g->device); rtk_d2h(host_dst, g->dbuf[idx], bytes); } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
+    return RTK_OK;
+}
+
 extern "C" int rtk_graph_adopt_device(rtk_graph* g) {
     if (!g) return rtk_fail(RTK_ERR_ARG, "rtk_graph_adopt_device: null");
     for (int i = 0; i < rtk::RTK_N_BUFS; ++i) if (!g->dbuf[i]) return rtk_fail(RTK_ERR_ARG, "rtk_graph_adopt_device: buffers not allocated");
@@ -247,7 +307,7 @@ extern "C" long long rtk_graph_strip_annotations(rtk_graph* g) {
 // is gone, whichever comes last (callers with garbage collectors free the two in any order).
 static void graph_release(rtk_graph* g) {
     if (g->refs.fetch_sub(1) != 1) return;
-    if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) rtk_dfree(g->dbuf[i]);
+    if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) if (!(g->moved >> i & 1u)) rtk_dfree(g->dbuf[i]);
     rtk_dfree(g->scratch[0]); rtk_dfree(g->scratch[1]); g->pool_clear();
     delete g;
 }

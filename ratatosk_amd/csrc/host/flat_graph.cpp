@@ -49,14 +49,50 @@ uint64_t FlatGraph::bytes() const {
     return 8 * (useq.size() + uoff.size() + loff.size() + goff.size() + ht.size() + bf.size() + bf1.size() + cycoff.size() + cyc.size() + amb.size() + hx.size() + hxl.size() + hap.size()) + 4 * (adj.size() + flags.size() + kcov.size() + card.size() + col.size() + gid.size());
 }
 
+TableSizes table_sizes(int k, uint64_t n_kmers, uint64_t n_bases) {
+    TableSizes t;
+    const bool wide = k > 31;
+    t.h = (k - 1) / 2;
+    { // half-k-mer index: not built with RTK_INEXACT_ENUM=1, above RTK_HX_MAX_GB (default 96), for two-word k-mers (second pass only, which has no 1-edit search: src/Graph.cpp:100)
+        const char* e_enum = getenv("RTK_INEXACT_ENUM"); const char* e_gb = getenv("RTK_HX_MAX_GB");
+        const double max_gb = e_gb ? atof(e_gb) : 96.0;
+        // size before building: the distinct h-mers are at most 4^h (1.07 G for k = 31: a 3 Gb graph saturates them), the slot table a power of two
+        // >= twice that, the lists one word per h-mer start + one per distinct h-mer
+        const double bases = static_cast<double>(n_bases); const double all_h = std::pow(4.0, t.h); const double uniq = bases < all_h ? bases : all_h;
+        double hs = 16; while (hs < 2 * uniq) hs *= 2;
+        const double est_gb = (8.0 * hs + 8.0 * (bases + uniq)) / 1e9;
+        t.hx = !((e_enum && e_enum[0] == '1') || est_gb > max_gb || wide);
+    }
+    // k-mer table, load factor <= 0.5: small graphs keep the round-2 sizes -- a power of two at load 0.25 .. 0.5; above RTK_HT_DENSE_KMERS k-mers (default 2^28: a 4 GB
+    // table) the table is sized for load 0.7: the slot of a hash is floor(hash * slots / 2^64), any number of slots will do
+    uint64_t slots = 16;
+    while (slots < 2 * n_kmers) slots <<= 1;
+    { const char* e = getenv("RTK_HT_DENSE_KMERS"); const uint64_t dense_from = e ? strtoull(e, nullptr, 10) : (1ull << 28);
+      if (n_kmers >= dense_from) slots = n_kmers + n_kmers * 3 / 7 + 16; }
+    t.ht_slots = slots;
+    // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer.
+    // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
+    // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.
+    uint64_t bf_words = 16; { const char* e = getenv("RTK_BF_KEYS_PER_WORD"); const uint64_t kpw = e ? strtoull(e, nullptr, 10) : 4; while (bf_words * kpw < n_kmers) bf_words <<= 1; }
+    t.bf_words = bf_words;
+    // First level in front of it: ONE bit per k-mer in 2 MB (>= 3 bits per key, ~27 % false positives; 4 MB for graphs of 5 to 33 M k-mers), meant to stay resident in
+    // the 4 MB of L2 next to each XCD so that most absent k-mers never cross the fabric (k_inexact 18.3 -> 12.8 ms per 32 Mb on the 5 Mb
+    // configuration; 1 MB / 4 MB arrays measured 14.8 / 13.6 ms). Graphs too large for that get a single all-ones word (every query passes).
+    { uint64_t bits = 64; const char* e0 = getenv("RTK_BF1_LOG2BITS"); const uint64_t cap_bits = 1ull << (e0 ? atoi(e0) : (3 * n_kmers > (1ull << 24) ? 25 : 24)); while (bits < 3 * n_kmers && bits < cap_bits) bits <<= 1;
+      if (e0) { bits = cap_bits; }
+      const char* e1 = getenv("RTK_BF1_OFF");
+      t.bf1_words = (n_kmers > cap_bits || (e1 && e1[0] == '1')) ? 1 : bits / 64; } // below one bit per key the array stops paying for itself
+    return t;
+}
+
 static bool km_from_string(const char* s, int k, RtkKm& out) {
     out = rtk_km_zero();
     for (int i = 0; i < k; ++i) { const int b = base2bits(s[i]); if (b < 0) return false; out = rtk_km_push(out, static_cast<uint64_t>(b), k); }
     return true;
 }
 
-void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads) {
-    k = k_;
+void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads, bool defer_tables) {
+    k = k_; tables_deferred = defer_tables;
     const bool load_trace = getenv("RTK_LOAD_TRACE") != nullptr; // developer: seconds per section of the load
     const auto lt0 = std::chrono::steady_clock::now(); auto lt_last = lt0;
     auto lap = [&](const char* what) { if (!load_trace) return; const auto now = std::chrono::steady_clock::now();
@@ -102,17 +138,10 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     // looks up read h-mers here and verifies the few k-mers they belong to instead of spelling every variant of the window.
     // hx: one word per slot, h-mer << 34 | first; hxl[first] = number of places, then the places (unitig << 32 | offset).
     // Not built (a single empty slot; the search then spells the variants) with RTK_INEXACT_ENUM=1 or above RTK_HX_MAX_GB (default 96).
+    const TableSizes tsz = table_sizes(k, n_kmers, uoff[n]);
     {
-        const int h = (k - 1) / 2;
-        const char* e_enum = getenv("RTK_INEXACT_ENUM"); const char* e_gb = getenv("RTK_HX_MAX_GB");
-        const double max_gb = e_gb ? atof(e_gb) : 96.0;
-        // size before building: the distinct h-mers are at most 4^h (1.07 G for k = 31: a 3 Gb graph saturates them), the slot table a power of two
-        // >= twice that, the lists one word per h-mer start + one per distinct h-mer
-        double est_gb;
-        { const double bases = static_cast<double>(uoff[n]); const double all_h = std::pow(4.0, h); const double uniq = bases < all_h ? bases : all_h;
-          double hs = 16; while (hs < 2 * uniq) hs *= 2;
-          est_gb = (8.0 * hs + 8.0 * (bases + uniq)) / 1e9; }
-        if ((e_enum && e_enum[0] == '1') || est_gb > max_gb || wide) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); } // wide k: second pass only, which has no 1-edit search (src/Graph.cpp:100)
+        const int h = tsz.h;
+        if (!tsz.hx || defer_tables) { hx.assign(1, RTK_EMPTY_KEY); hxl.assign(1, 0); }
         else {
             // Every h-mer start of every unitig as a pair (h-mer, place), sorted -- by buckets of the leading h-mer bits, so that every step runs on
             // all threads: count per (thread, bucket), scatter to the bucket's range, sort the buckets, lay the lists out bucket by bucket (their
@@ -179,29 +208,15 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         }
     }
     lap("half-k-mer index");
-    // ---- k-mer -> (unitig, offset, orientation) table, load factor <= 0.5 ----
-    // (small graphs keep the round-2 sizes -- a power of two at load 0.25 .. 0.5; above RTK_HT_DENSE_KMERS k-mers (default 2^28: a 4 GB table) the table
-    // is sized for load 0.7: the slot of a hash is floor(hash * slots / 2^64), any number of slots will do)
-    uint64_t slots = 16;
-    while (slots < 2 * n_kmers) slots <<= 1;
-    { const char* e = getenv("RTK_HT_DENSE_KMERS"); const uint64_t dense_from = e ? strtoull(e, nullptr, 10) : (1ull << 28);
-      if (n_kmers >= dense_from) slots = n_kmers + n_kmers * 3 / 7 + 16; }
+    // ---- k-mer -> (unitig, offset, orientation) table + its two presence filters (sizes: table_sizes) ----
+    const uint64_t slots = defer_tables ? 1 : tsz.ht_slots;
     ht.alloc_uninitialised(2 * slots);
     parallel_slices(static_cast<size_t>(slots), n_threads, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) { ht[2 * i] = RTK_EMPTY_KEY; ht[2 * i + 1] = 0; } });
-    // presence pre-filter in front of the table: blocked Bloom filter, one 64-bit word per query, 2 bits per k-mer.
-    // A miss (the common case for 1-edit variants) costs one 8-byte read of a structure 16x smaller than the table.
-    // 4 k-mers per word: >= 16 bits per key, 1.3 % false positives.
-    uint64_t bf_words = 16; { const char* e = getenv("RTK_BF_KEYS_PER_WORD"); const uint64_t kpw = e ? strtoull(e, nullptr, 10) : 4; while (bf_words * kpw < n_kmers) bf_words <<= 1; }
+    const uint64_t bf_words = defer_tables ? 1 : tsz.bf_words;
     bf.assign(bf_words, 0);
-    // First level in front of it: ONE bit per k-mer in 2 MB (>= 3 bits per key, ~27 % false positives; 4 MB for graphs of 5 to 33 M k-mers), meant to stay resident in
-    // the 4 MB of L2 next to each XCD so that most absent k-mers never cross the fabric (k_inexact 18.3 -> 12.8 ms per 32 Mb on the 5 Mb
-    // configuration; 1 MB / 4 MB arrays measured 14.8 / 13.6 ms). Graphs too large for that get a single all-ones word (every query passes).
-    { uint64_t bits = 64; const char* e0 = getenv("RTK_BF1_LOG2BITS"); const uint64_t cap_bits = 1ull << (e0 ? atoi(e0) : (3 * n_kmers > (1ull << 24) ? 25 : 24)); while (bits < 3 * n_kmers && bits < cap_bits) bits <<= 1;
-      if (e0) { bits = cap_bits; }
-      const char* e1 = getenv("RTK_BF1_OFF");
-      if (n_kmers > cap_bits || (e1 && e1[0] == '1')) bf1.assign(1, ~0ull); else bf1.assign(bits / 64, 0); } // below one bit per key the array stops paying for itself
+    if (tsz.bf1_words == 1 || defer_tables) bf1.assign(1, ~0ull); else bf1.assign(tsz.bf1_words, 0);
     const bool bf1_off = bf1.size() == 1;
-    parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+    if (!defer_tables) parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
         struct Pend { uint64_t can, hh, val; };
         const size_t RING = 16; Pend ring[16]; size_t n_pend = 0;
         auto insert = [&](const Pend& pe) {
@@ -237,7 +252,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         for (size_t j = n_pend > RING ? n_pend - RING : 0; j < n_pend; ++j) insert(ring[j & (RING - 1)]);
     });
     const GraphView gv0 = [&]() { GraphView v; v.k = k; v.ht = ht.data(); v.ht_slots = slots; v.bf = bf.data(); v.bf_mask = bf_words - 1; v.bf1 = bf1.data(); v.bf1_mask = bf1.size() * 64 - 1; v.useq = useq.data(); v.uoff = uoff.data(); return v; }();
-    if (wide) { // fingerprints cannot tell a repeated k-mer while the table is filled: every k-mer has to find ITSELF afterwards
+    if (wide && !defer_tables) { // fingerprints cannot tell a repeated k-mer while the table is filled: every k-mer has to find ITSELF afterwards
         parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
             for (size_t u = lo; u < hi; ++u) {
                 const std::string& s = seqs[u];
@@ -252,6 +267,29 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
         });
     }
     lap("k-mer table + filters");
+    // Deferred tables: the .rtsk records name their unitig by its head k-mer, which is a unitig extremity (anything else is an error below): a table of
+    // the 2n extremity k-mers (hash of the canonical k-mer -> unitig, confirmed against the sequence) answers that without the table of all k-mers.
+    std::vector<uint32_t> ext; uint64_t ext_mask = 0;
+    auto ext_kmer = [&](uint32_t u, int end) { RtkKm x; const std::string& s = seqs[u]; km_from_string(end ? s.c_str() + s.size() - k : s.c_str(), k, x); const RtkKm rc = rtk_km_revcomp(x, k); return rtk_km_less(rc, x) ? rc : x; };
+    if (defer_tables) {
+        uint64_t es = 16; while (es < 4 * n) es <<= 1;
+        ext.assign(es, RTK_NONE32); ext_mask = es - 1;
+        parallel_slices(n, n_threads, [&](size_t lo, size_t hi, int) {
+            for (size_t u = lo; u < hi; ++u) for (int end = 0; end < 2; ++end) {
+                if (end == 1 && seqs[u].size() == static_cast<size_t>(k)) break; // one k-mer: both ends are it
+                uint64_t q = rtk_km_hash(ext_kmer(static_cast<uint32_t>(u), end)) & ext_mask;
+                for (;;) { uint32_t expect = RTK_NONE32; if (__atomic_load_n(&ext[q], __ATOMIC_RELAXED) == RTK_NONE32 && __atomic_compare_exchange_n(&ext[q], &expect, static_cast<uint32_t>(u) << 1 | static_cast<uint32_t>(end), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break; q = (q + 1) & ext_mask; }
+            }
+        });
+        lap("extremity k-mers (deferred tables)");
+    }
+    auto find_head = [&](const RtkKm& code) -> uint64_t { // packed hit of a head k-mer, RTK_NO_HIT if it is no unitig extremity
+        const RtkKm rc = rtk_km_revcomp(code, k); const RtkKm can = rtk_km_less(rc, code) ? rc : code;
+        for (uint64_t q = rtk_km_hash(can) & ext_mask;; q = (q + 1) & ext_mask) {
+            const uint32_t e = ext[q]; if (e == RTK_NONE32) return RTK_NO_HIT;
+            if (rtk_km_eq(ext_kmer(e >> 1, static_cast<int>(e & 1u)), can)) { const uint32_t u = e >> 1; return rtk_pack_hit(u, (e & 1u) ? static_cast<uint32_t>(seqs[u].size()) - k : 0u, 1u); }
+        }
+    };
     // ---- unitig data (.rtsk) ----
     flags.assign(n, 0); kcov.assign(n, 0); card.assign(n, 0); gid.assign(n, -1); loff.assign(n + 1, 0);
     std::vector<std::vector<uint32_t> > locals(n);
@@ -269,8 +307,8 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             const std::string head = disk_kmer_to_string(r.head, k);
             RtkKm code;
             if (!km_from_string(head.c_str(), k, code)) throw std::runtime_error(".rtsk: bad head k-mer");
-            const uint64_t hit = rtk_find_km(gv0, code, nullptr);
-            if (hit == RTK_NO_HIT) throw std::runtime_error(".rtsk: head k-mer not found in the graph (reference aborts too, src/Graph.cpp:773-780)");
+            const uint64_t hit = defer_tables ? find_head(code) : rtk_find_km(gv0, code, nullptr);
+            if (hit == RTK_NO_HIT) throw std::runtime_error(defer_tables ? ".rtsk: head k-mer is not a unitig extremity of the graph (reference aborts too, src/Graph.cpp:773-780)" : ".rtsk: head k-mer not found in the graph (reference aborts too, src/Graph.cpp:773-780)");
             const UMap um = rtk_unpack_hit(hit);
             const uint32_t nk = static_cast<uint32_t>(seqs[um.unitig].size()) - k + 1;
             if (!(um.dist == 0 || um.dist == nk - 1)) throw std::runtime_error(".rtsk: head k-mer is not a unitig extremity");
@@ -328,7 +366,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     lap("annotations, haplotypes, cycles");
     // ---- adjacency ([A3]: neighbours of the unitig end in walk direction, A,C,G,T) ----
     adj.assign(n * 8, RTK_NONE32);
-    parallel_slices(n, n_threads, [&](size_t lo_u, size_t hi_u, int) {
+    if (!defer_tables) parallel_slices(n, n_threads, [&](size_t lo_u, size_t hi_u, int) {
     for (size_t u = lo_u; u < hi_u; ++u) {
         const std::string& s = seqs[u];
         RtkKm tail, head;

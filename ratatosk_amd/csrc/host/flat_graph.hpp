@@ -45,9 +45,21 @@ struct FlatGraph {
     uint32_t n_unitigs() const { return static_cast<uint32_t>(flags.size()); }
     GraphView view() const; // pointers into the host vectors
     uint64_t bytes() const;
-    // throws std::runtime_error
-    void load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads);
+    // throws std::runtime_error. defer_tables: the lookup structures (k-mer table and its two filters, half-k-mer index, adjacency) are left
+    // empty -- rtk_graph_upload builds them on the device from the packed unitigs (hip/rtk_graph_tables.hip); tables_deferred says so.
+    void load(const std::string& fasta_gz, const std::string& rtsk, int k_, int n_threads, bool defer_tables = false);
+    bool tables_deferred = false;
 };
+
+// sizes of the lookup structures of a graph (one policy for the host and the device builders; the environment knobs are read here)
+struct TableSizes {
+    uint64_t ht_slots;   // 16-byte slots of the k-mer table
+    uint64_t bf_words;   // words of the blocked Bloom filter (a power of two)
+    uint64_t bf1_words;  // words of the first-level bit array (a power of two), 1 = disabled (a single all-ones word)
+    bool hx;             // half-k-mer index built (else one empty slot: the 1-edit search spells the variants)
+    int h;               // its h = (k - 1) / 2
+};
+TableSizes table_sizes(int k, uint64_t n_kmers, uint64_t n_bases);
 
 // the flat buffers in a fixed order (upload / RCCL broadcast order)
 enum { RTK_BUF_USEQ = 0, RTK_BUF_UOFF, RTK_BUF_ADJ, RTK_BUF_FLAGS, RTK_BUF_KCOV, RTK_BUF_CARD, RTK_BUF_LOFF, RTK_BUF_GID, RTK_BUF_GOFF, RTK_BUF_COL, RTK_BUF_HT, RTK_BUF_BF, RTK_BUF_CYCOFF, RTK_BUF_CYC, RTK_BUF_BF1, RTK_BUF_AMB, RTK_BUF_HX, RTK_BUF_HXL, RTK_BUF_HAP, RTK_N_BUFS };

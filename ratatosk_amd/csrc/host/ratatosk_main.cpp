@@ -208,7 +208,7 @@ int main(int argc, char** argv) {
             if (rtk_reserve_second_pass(w, 1u, 13ull << 30, 9ull << 30) != RTK_OK && opt.verbose) fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); });
     }
     { // ONE parse + flatten, ONE host image; the other GPUs get device-to-device copies of the flat buffers
-        bool ok = rtk_graph_load(opt.graph.c_str(), opt.udata.c_str(), k_graph, opt.cores, &graphs[0]) == RTK_OK;
+        bool ok = rtk_graph_load2(opt.graph.c_str(), opt.udata.c_str(), k_graph, opt.cores, RTK_LOAD_DEVICE_TABLES, &graphs[0]) == RTK_OK; // (k-mer table, half-k-mer index, adjacency: built in HBM by the upload)
         if (ok && opt.strip) { const long long ns = rtk_graph_strip_annotations(graphs[0]); if (ns > 0) fprintf(stderr, "Ratatosk::Ratatosk(): dropped the short-cycle / SNP annotations of %lld unitigs\n", ns); }
         ok = ok && rtk_graph_upload(graphs[0], 0) == RTK_OK;
         for (int w = 1; ok && w < n_gpus; ++w) ok = rtk_graph_clone_to_device(graphs[0], w, &graphs[w]) == RTK_OK;

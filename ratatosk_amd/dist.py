@@ -21,6 +21,8 @@ def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None,
     import torch.distributed as dist
     L = api.load_library(lib_path)
     sim = lib_path is not None
+    if not sim:
+        torch.zeros(1, device=torch.device("cuda", device))  # torch's HIP context before the library's first HIP call on rank 0 (the other order has failed to find the GPU)
     n_buf = L.rtk_graph_n_buffers(None)
     sizes = (C.c_uint64 * n_buf)()
     info = api.RtkGraphInfo()
@@ -28,7 +30,10 @@ def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None,
     g.L, g.k, g.h = L, k, C.c_void_p()
     if rank == 0:
         t0 = time.time()
-        g._check(L.rtk_graph_load(api._b(fasta_gz), api._b(rtsk), k, n_threads, C.byref(g.h)))
+        # (the simulator builds its tables on the host; on a GPU rank 0 builds them in its own HBM at upload time, and their sizes are known after that)
+        g._check(L.rtk_graph_load2(api._b(fasta_gz), api._b(rtsk), k, n_threads, 0 if sim else api.RTK_LOAD_DEVICE_TABLES, C.byref(g.h)))
+        if not sim:
+            g._check(L.rtk_graph_upload(g.h, device))
         t_load = time.time() - t0
         g._check(L.rtk_graph_buffer_bytes(g.h, sizes, n_buf))
         g._check(L.rtk_graph_get_info(g.h, C.byref(info)))
@@ -41,12 +46,18 @@ def load_graph_replicated(fasta_gz, rtsk, k, rank, world, device, lib_path=None,
         sizes[i] = meta[0][i]
     C.memmove(C.byref(info), meta[1], C.sizeof(info))
     dev = torch.device("cpu") if sim else torch.device("cuda", device)
-    tensors = [torch.empty(max(8, int(sizes[i])), dtype=torch.uint8, device=dev) for i in range(n_buf)]
-    ptrs = (C.c_void_p * n_buf)(*[t.data_ptr() for t in tensors])
     L.rtk_graph_attach_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int, C.POINTER(api.RtkGraphInfo)]
-    g._check(L.rtk_graph_attach_buffers(g.h, device, ptrs, sizes, n_buf, C.byref(info)))
-    if rank == 0:
-        g._check(L.rtk_graph_upload(g.h, device))  # host image -> the attached buffers
+    if rank == 0 and not sim:  # resident image -> the tensors the broadcasts read, one buffer at a time (a whole-genome graph does not fit twice)
+        tensors = []
+        for i in range(n_buf):
+            tensors.append(torch.empty(max(8, int(sizes[i])), dtype=torch.uint8, device=dev))
+            g._check(L.rtk_graph_move_buffer(g.h, i, C.c_void_p(tensors[i].data_ptr()), max(8, int(sizes[i]))))
+    else:
+        tensors = [torch.empty(max(8, int(sizes[i])), dtype=torch.uint8, device=dev) for i in range(n_buf)]
+        ptrs = (C.c_void_p * n_buf)(*[t.data_ptr() for t in tensors])
+        g._check(L.rtk_graph_attach_buffers(g.h, device, ptrs, sizes, n_buf, C.byref(info)))
+        if rank == 0:
+            g._check(L.rtk_graph_upload(g.h, device))  # host image -> the attached buffers
     secs = []
     for t in tensors:  # one large contiguous broadcast per buffer; ring/tree over xGMI is per-link bound
         t0 = time.time()
