@@ -215,6 +215,13 @@ int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* 
  * high bits) that the reads of `files` (plain or gzipped FASTA/FASTQ) hold at least min_count times, sorted ascending; *solid is freed
  * with rtk_free. The tool csrc/tools/build_index.cpp (--gpu) builds the same files with it as its CPU path does. */
 int rtk_index_count_kmers(int device, int k, const char* const* files, int n_files, uint32_t min_count, int n_threads, uint64_t** solid, uint64_t* n_solid);
+/* rtk_index_unitigs: the unitigs of a sorted set of canonical solid k-mers (Bifrost's compaction behind CompactedDBG::build, src/Ratatosk.cpp:1100-1118):
+ * the k-mers in a table in HBM with their eight edge bits, every maximal chain of mutually unique links walked from its ends by one thread each, written
+ * with its smallest canonical k-mer reading forwards, the unitigs in the order of those k-mers: unitig j = seq_pool[seq_off[j] .. seq_off[j + 1]), seeds[j]
+ * its smallest k-mer. Chains that meet themselves (closed loops, hairpins) are not built: their k-mers come back in `left` (sorted) for the caller.
+ * Outputs are freed with rtk_free. RTK_ERR_FORMAT if a k-mer ended up on two unitigs (the tool then takes its plain construction). */
+int rtk_index_unitigs(int device, int k, const uint64_t* solid, uint64_t n_solid, char** seq_pool, uint64_t** seq_off, uint64_t** seeds, uint64_t* n_unitigs,
+                      uint64_t** left, uint64_t* n_left);
 
 void rtk_free(void* p);
 const char* rtk_last_error(void);

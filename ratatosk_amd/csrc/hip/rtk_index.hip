@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -140,6 +141,112 @@ bool for_each_sequence_chunk(const std::vector<std::string>& files, int n_thread
     return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------ unitigs (rtk_index_unitigs)
+// The solid k-mers in a table of 16-byte slots {canonical k-mer, value}: value bits 0..3 = which of the four successors (x << 2 | b) of the canonical
+// orientation are solid, bits 4..7 = which of the four predecessors (b in front), bit 8 = the k-mer lies on a unitig written here.
+#define RTK_UT_CLAIMED 256ull
+__device__ __forceinline__ uint64_t ut_find(const uint64_t* __restrict__ T, uint64_t slots, uint64_t can) {
+    uint64_t s = __umul64hi(idx_hash(can), slots);
+    for (;;) { const uint64_t key = T[2 * s]; if (key == can) return s; if (key == RTK_IDX_SENTINEL) return RTK_IDX_SENTINEL; s = s + 1 == slots ? 0 : s + 1; }
+}
+__device__ __forceinline__ uint32_t rev4(uint32_t n) { return ((n & 1u) << 3) | ((n & 2u) << 1) | ((n & 4u) >> 1) | ((n & 8u) >> 3); }
+// edge bits of an ORIENTED k-mer from those of its canonical form: the successor by base b of the reverse complement is the predecessor by base 3 - b
+__device__ __forceinline__ uint32_t ut_omask(uint32_t m, bool is_can) { return is_can ? (m & 255u) : (rev4((m >> 4) & 15u) | (rev4(m & 15u) << 4)); }
+__device__ __forceinline__ uint32_t ut_mask_of(const uint64_t* __restrict__ T, uint64_t slots, uint64_t x, int k, uint64_t* slot_out) {
+    const uint64_t rc = idx_revcomp(x, k), can = x <= rc ? x : rc;
+    const uint64_t s = ut_find(T, slots, can); if (slot_out) *slot_out = s;
+    return ut_omask(static_cast<uint32_t>(T[2 * s + 1]), x == can);
+}
+// the link the construction follows forwards from x (its oriented edge bits mx): the only successor of x, if x is its only predecessor
+__device__ __forceinline__ bool ut_next(const uint64_t* __restrict__ T, uint64_t slots, int k, uint64_t kmask, uint64_t x, uint32_t mx, uint64_t* y, uint32_t* my, uint64_t* slot_y) {
+    const uint32_t sc = mx & 15u; if (__popc(sc) != 1) return false;
+    const uint64_t yy = ((x << 2) | static_cast<uint64_t>(__ffs(sc) - 1)) & kmask;
+    const uint32_t m = ut_mask_of(T, slots, yy, k, slot_y); if (__popc(m >> 4) != 1) return false;
+    *y = yy; *my = m; return true;
+}
+__device__ __forceinline__ bool ut_prev(const uint64_t* __restrict__ T, uint64_t slots, int k, uint64_t x, uint32_t mx) {
+    const uint32_t pc = mx >> 4; if (__popc(pc) != 1) return false;
+    const uint64_t yy = (x >> 2) | (static_cast<uint64_t>(__ffs(pc) - 1) << (2 * (k - 1)));
+    return __popc(ut_mask_of(T, slots, yy, k, nullptr) & 15u) == 1;
+}
+
+__global__ void k_ut_fill(uint64_t* __restrict__ T, uint64_t slots) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < slots; i += stride) { T[2 * i] = RTK_IDX_SENTINEL; T[2 * i + 1] = 0; }
+}
+__global__ void k_ut_insert(const uint64_t* __restrict__ solid, uint64_t n, uint64_t* __restrict__ T, uint64_t slots) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t c = solid[i]; uint64_t s = __umul64hi(idx_hash(c), slots);
+        while (atomicCAS(reinterpret_cast<unsigned long long*>(T + 2 * s), static_cast<unsigned long long>(RTK_IDX_SENTINEL), static_cast<unsigned long long>(c)) != RTK_IDX_SENTINEL) s = s + 1 == slots ? 0 : s + 1;
+    }
+}
+__global__ void k_ut_edges(const uint64_t* __restrict__ solid, uint64_t n, int k, uint64_t* __restrict__ T, uint64_t slots) {
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t c = solid[i]; uint64_t m = 0;
+        for (uint64_t b = 0; b < 4; ++b) {
+            const uint64_t y = ((c << 2) | b) & kmask, yr = idx_revcomp(y, k); if (ut_find(T, slots, y <= yr ? y : yr) != RTK_IDX_SENTINEL) m |= 1ull << b;
+            const uint64_t z = (c >> 2) | (b << (2 * (k - 1))), zr = idx_revcomp(z, k); if (ut_find(T, slots, z <= zr ? z : zr) != RTK_IDX_SENTINEL) m |= 16ull << b;
+        }
+        T[2 * ut_find(T, slots, c) + 1] = m;
+    }
+}
+// Every maximal chain of mutually unique links is walked from both of its end k-mers; the end whose canonical k-mer is the smaller one owns it (tools/
+// build_index.cpp fast_unitigs: the same rules, so that the two produce the same unitigs). An owner reports the oriented k-mer it starts from, the number of
+// k-mers, the smallest canonical k-mer on the chain (its seed: unitigs are numbered by it) and whether that one reads backwards on the walk (the unitig is
+// then the reverse complement of the walk). record == nullptr: count the owners only.
+__global__ void k_ut_chains(const uint64_t* __restrict__ solid, uint64_t n, int k, const uint64_t* __restrict__ T, uint64_t slots,
+                            unsigned long long* __restrict__ n_chains, uint64_t cap, uint64_t* __restrict__ start, uint64_t* __restrict__ seed, uint32_t* __restrict__ len_rev, uint32_t* __restrict__ too_long) {
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t s = solid[i];
+        const uint32_t ms = ut_mask_of(T, slots, s, k, nullptr);
+        uint64_t y = 0; uint32_t my = 0;
+        const bool has_fw = ut_next(T, slots, k, kmask, s, ms, &y, &my, nullptr), has_bw = ut_prev(T, slots, k, s, ms);
+        if (has_fw && has_bw) continue; // inside a chain (or on a closed loop)
+        uint64_t x = has_bw ? idx_revcomp(s, k) : s; uint32_t mx = has_bw ? ut_omask(ms, false) : ms; // walk inwards from this end
+        const uint64_t x0 = x;
+        uint64_t len = 1, mc = s; bool m_fw = (x == s);
+        while (ut_next(T, slots, k, kmask, x, mx, &y, &my, nullptr)) {
+            x = y; mx = my; ++len;
+            const uint64_t r = idx_revcomp(x, k), c = x <= r ? x : r;
+            if (c < mc) { mc = c; m_fw = (x == c); }
+            if (len > n) break;
+        }
+        const uint64_t xr = idx_revcomp(x, k), end_c = x <= xr ? x : xr;
+        if (len > 1 && end_c == s) continue; // the chain comes back to its own first k-mer (hairpin): left to the plain construction
+        if (end_c < s) continue;            // the other end owns the chain
+        if (len > n) continue;
+        if (len >= (1ull << 31)) { atomicOr(too_long, 1u); continue; }
+        const unsigned long long at = atomicAdd(n_chains, 1ull);
+        if (start && at < cap) { start[at] = x0; seed[at] = mc; len_rev[at] = static_cast<uint32_t>(len) | (m_fw ? 0u : 0x80000000u); }
+    }
+}
+struct ChainBases { const uint32_t* len_rev; const uint32_t* order; int k; __device__ uint64_t operator()(uint64_t j) const { return static_cast<uint64_t>(len_rev[order[j]] & 0x7FFFFFFFu) + static_cast<uint64_t>(k - 1); } };
+// chain order[j] written as unitig j at seq_off[j]: walked again from its start, every k-mer claimed (a k-mer claimed twice: *clash)
+__global__ void k_ut_write(uint64_t n_ch, const uint32_t* __restrict__ order, const uint64_t* __restrict__ start, const uint32_t* __restrict__ len_rev, const uint64_t* __restrict__ seq_off,
+                           int k, uint64_t* __restrict__ T, uint64_t slots, char* __restrict__ pool, uint32_t* __restrict__ clash) {
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < n_ch; j += stride) {
+        const uint32_t c = order[j]; const uint64_t len = len_rev[c] & 0x7FFFFFFFu; const bool rev = (len_rev[c] >> 31) != 0;
+        const uint64_t L = len + static_cast<uint64_t>(k - 1); char* out = pool + seq_off[j];
+        auto put = [&](uint64_t pos, uint32_t b) { if (!rev) out[pos] = "ACGT"[b]; else out[L - 1 - pos] = "TGCA"[b]; }; // base b at position pos of the walk
+        uint64_t x = start[c], slot = 0; uint32_t mx = ut_mask_of(T, slots, x, k, &slot);
+        for (int q = 0; q < k; ++q) put(static_cast<uint64_t>(q), static_cast<uint32_t>((x >> (2 * (k - 1 - q))) & 3ull));
+        if (atomicOr(reinterpret_cast<unsigned long long*>(T + 2 * slot + 1), static_cast<unsigned long long>(RTK_UT_CLAIMED)) & RTK_UT_CLAIMED) atomicOr(clash, 1u);
+        for (uint64_t q = 1; q < len; ++q) {
+            uint64_t y = 0; uint32_t my = 0;
+            if (!ut_next(T, slots, k, kmask, x, mx, &y, &my, &slot)) { atomicOr(clash, 2u); break; }
+            x = y; mx = my; put(static_cast<uint64_t>(k - 1) + q, static_cast<uint32_t>(x & 3ull));
+            if (atomicOr(reinterpret_cast<unsigned long long*>(T + 2 * slot + 1), static_cast<unsigned long long>(RTK_UT_CLAIMED)) & RTK_UT_CLAIMED) atomicOr(clash, 1u);
+        }
+    }
+}
+struct Unclaimed { const uint64_t* solid; const uint64_t* T; uint64_t slots; __device__ bool operator()(uint64_t i) const { return !(T[2 * ut_find(T, slots, solid[i]) + 1] & RTK_UT_CLAIMED); } };
+struct Iota32 { __device__ uint32_t operator()(uint64_t i) const { return static_cast<uint32_t>(i); } };
+
 } // namespace
 
 extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files, int n_files, uint32_t min_count, int n_threads, uint64_t** solid_out, uint64_t* n_solid) {
@@ -219,5 +326,96 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
         if (!solid.empty()) memcpy(out, solid.data(), 8 * solid.size());
         *solid_out = out; *n_solid = solid.size();
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_count_kmers: ") + e.what()); }
+    return RTK_OK;
+}
+
+
+// Unitigs of the solid k-mers: every maximal chain of mutually unique links that does not meet itself, oriented so that its smallest canonical k-mer reads
+// forwards, in the order of those k-mers -- what tools/build_index.cpp fast_unitigs builds on the host threads (the rules are restated there and here;
+// tests/test_index_build.py holds both to the plain construction and to oracle/oracle_index.py). Chains that meet themselves (closed loops, hairpins through
+// a reverse complement) are not built: their k-mers come back in *left (sorted) for the caller's plain construction.
+extern "C" int rtk_index_unitigs(int device, int k, const uint64_t* solid, uint64_t n_solid, char** seq_pool, uint64_t** seq_off, uint64_t** seeds, uint64_t* n_unitigs, uint64_t** left, uint64_t* n_left) {
+    if (!solid || !seq_pool || !seq_off || !seeds || !n_unitigs || !left || !n_left) return rtk_fail(RTK_ERR_ARG, "rtk_index_unitigs: null argument");
+    if (k < 3 || k > 31 || !(k & 1)) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_unitigs: one-word k-mers only (odd k <= 31)");
+    if (rtk_device_count() <= device || device < 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_index_unitigs: no such HIP device (no CPU fallback)");
+    if (n_solid >= (1ull << 32)) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_unitigs: more than 2^32 solid k-mers");
+    *seq_pool = nullptr; *seq_off = nullptr; *seeds = nullptr; *left = nullptr; *n_unitigs = 0; *n_left = 0;
+    const bool trace = getenv("RTK_INDEX_TRACE") != nullptr;
+    try {
+        rtk_check(hipSetDevice(device), "hipSetDevice");
+        const auto t0 = std::chrono::steady_clock::now();
+        auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+        const uint64_t n = n_solid, slots = n + n * 3 / 7 + 16;
+        auto grid = [](uint64_t items) { const uint64_t b = (items + 255) / 256; return dim3(static_cast<unsigned>(b < 1 ? 1 : (b > 65536 ? 65536 : b))); };
+        DevBuf d_solid, d_T, d_cnt, d_flag;
+        d_solid.alloc(8 * n); d_T.alloc(16 * slots); d_cnt.alloc(8); d_flag.alloc(8);
+        rtk_check(hipMemcpy(d_solid.p, solid, 8 * n, hipMemcpyHostToDevice), "hipMemcpy");
+        rtk_check(hipMemset(d_cnt.p, 0, 8), "hipMemset"); rtk_check(hipMemset(d_flag.p, 0, 8), "hipMemset");
+        const uint64_t* ds = static_cast<const uint64_t*>(d_solid.p); uint64_t* T = static_cast<uint64_t*>(d_T.p);
+        uint32_t* d_too_long = static_cast<uint32_t*>(d_flag.p); uint32_t* d_clash = d_too_long + 1;
+        hipLaunchKernelGGL(k_ut_fill, grid(slots), dim3(256), 0, 0, T, slots);
+        hipLaunchKernelGGL(k_ut_insert, grid(n), dim3(256), 0, 0, ds, n, T, slots);
+        hipLaunchKernelGGL(k_ut_edges, grid(n), dim3(256), 0, 0, ds, n, k, T, slots);
+        rtk_check(hipGetLastError(), "kernel launch (unitig table)"); rtk_check(hipDeviceSynchronize(), "unitig table");
+        const double t_table = since();
+        // owners counted, then recorded
+        hipLaunchKernelGGL(k_ut_chains, grid(n), dim3(256), 0, 0, ds, n, k, static_cast<const uint64_t*>(T), slots, static_cast<unsigned long long*>(d_cnt.p), 0ull, static_cast<uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr), static_cast<uint32_t*>(nullptr), d_too_long);
+        rtk_check(hipGetLastError(), "kernel launch (k_ut_chains)"); rtk_check(hipDeviceSynchronize(), "k_ut_chains");
+        unsigned long long n_ch = 0; rtk_check(hipMemcpy(&n_ch, d_cnt.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        uint32_t fl[2] = {0, 0}; rtk_check(hipMemcpy(fl, d_flag.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        if (fl[0]) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_unitigs: a unitig of more than 2^31 k-mers");
+        if (n_ch >= (1ull << 32)) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_unitigs: more than 2^32 unitigs");
+        DevBuf d_start, d_seed, d_seed2, d_lr, d_ord, d_ord2, d_off, d_tmp;
+        d_start.alloc(8 * n_ch); d_seed.alloc(8 * n_ch); d_seed2.alloc(8 * n_ch); d_lr.alloc(4 * n_ch); d_ord.alloc(4 * n_ch); d_ord2.alloc(4 * n_ch); d_off.alloc(8 * (n_ch + 1));
+        rtk_check(hipMemset(d_cnt.p, 0, 8), "hipMemset");
+        hipLaunchKernelGGL(k_ut_chains, grid(n), dim3(256), 0, 0, ds, n, k, static_cast<const uint64_t*>(T), slots, static_cast<unsigned long long*>(d_cnt.p), static_cast<uint64_t>(n_ch), static_cast<uint64_t*>(d_start.p), static_cast<uint64_t*>(d_seed.p), static_cast<uint32_t*>(d_lr.p), d_too_long);
+        rtk_check(hipGetLastError(), "kernel launch (k_ut_chains)"); rtk_check(hipDeviceSynchronize(), "k_ut_chains");
+        const double t_chains = since();
+        std::vector<uint64_t> h_off(n_ch + 1, 0), h_seed(n_ch);
+        uint64_t total = 0;
+        if (n_ch) {
+            // the chains in the order of their seeds (one chain per seed: a k-mer lies on one chain)
+            auto iota = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), Iota32());
+            size_t tb = 0; rtk_check(rocprim::radix_sort_pairs(nullptr, tb, static_cast<uint64_t*>(d_seed.p), static_cast<uint64_t*>(d_seed2.p), iota, static_cast<uint32_t*>(d_ord.p), static_cast<size_t>(n_ch), 0, 2 * k), "rocprim::radix_sort_pairs");
+            d_tmp.alloc(tb);
+            rtk_check(rocprim::radix_sort_pairs(d_tmp.p, tb, static_cast<uint64_t*>(d_seed.p), static_cast<uint64_t*>(d_seed2.p), iota, static_cast<uint32_t*>(d_ord.p), static_cast<size_t>(n_ch), 0, 2 * k), "rocprim::radix_sort_pairs");
+            ChainBases cb; cb.len_rev = static_cast<const uint32_t*>(d_lr.p); cb.order = static_cast<const uint32_t*>(d_ord.p); cb.k = k;
+            auto lens = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), cb);
+            size_t sb = 0; rtk_check(rocprim::exclusive_scan(nullptr, sb, lens, static_cast<uint64_t*>(d_off.p), 0ull, static_cast<size_t>(n_ch), rocprim::plus<uint64_t>()), "rocprim::exclusive_scan");
+            d_tmp.alloc(sb);
+            rtk_check(rocprim::exclusive_scan(d_tmp.p, sb, lens, static_cast<uint64_t*>(d_off.p), 0ull, static_cast<size_t>(n_ch), rocprim::plus<uint64_t>()), "rocprim::exclusive_scan");
+            rtk_check(hipDeviceSynchronize(), "chain order");
+            rtk_check(hipMemcpy(h_off.data(), d_off.p, 8 * n_ch, hipMemcpyDeviceToHost), "hipMemcpy");
+            rtk_check(hipMemcpy(h_seed.data(), d_seed2.p, 8 * n_ch, hipMemcpyDeviceToHost), "hipMemcpy");
+            uint32_t last_c = 0, last_lr = 0; rtk_check(hipMemcpy(&last_c, static_cast<uint32_t*>(d_ord.p) + (n_ch - 1), 4, hipMemcpyDeviceToHost), "hipMemcpy");
+            rtk_check(hipMemcpy(&last_lr, static_cast<uint32_t*>(d_lr.p) + last_c, 4, hipMemcpyDeviceToHost), "hipMemcpy");
+            total = h_off[n_ch - 1] + (last_lr & 0x7FFFFFFFu) + static_cast<uint64_t>(k - 1); h_off[n_ch] = total;
+        }
+        DevBuf d_pool; d_pool.alloc(total ? total : 8);
+        if (n_ch) {
+            hipLaunchKernelGGL(k_ut_write, grid(n_ch), dim3(256), 0, 0, static_cast<uint64_t>(n_ch), static_cast<const uint32_t*>(d_ord.p), static_cast<const uint64_t*>(d_start.p), static_cast<const uint32_t*>(d_lr.p), static_cast<const uint64_t*>(d_off.p), k, T, slots, static_cast<char*>(d_pool.p), d_clash);
+            rtk_check(hipGetLastError(), "kernel launch (k_ut_write)"); rtk_check(hipDeviceSynchronize(), "k_ut_write");
+        }
+        rtk_check(hipMemcpy(fl, d_flag.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        if (fl[1]) return rtk_fail(RTK_ERR_FORMAT, "rtk_index_unitigs: a k-mer ended up on two unitigs"); // (the tool then runs its plain construction)
+        const double t_write = since();
+        // the k-mers on no unitig written here, in sorted order
+        DevBuf d_left, d_nleft; d_left.alloc(8 * (n ? n : 1)); d_nleft.alloc(8);
+        Unclaimed un; un.solid = ds; un.T = T; un.slots = slots;
+        { auto idx = rocprim::make_counting_iterator<uint64_t>(0); auto flags = rocprim::make_transform_iterator(idx, un);
+          size_t sb = 0; rtk_check(rocprim::select(nullptr, sb, ds, flags, static_cast<uint64_t*>(d_left.p), static_cast<unsigned long long*>(d_nleft.p), static_cast<size_t>(n)), "rocprim::select");
+          d_tmp.alloc(sb);
+          rtk_check(rocprim::select(d_tmp.p, sb, ds, flags, static_cast<uint64_t*>(d_left.p), static_cast<unsigned long long*>(d_nleft.p), static_cast<size_t>(n)), "rocprim::select");
+          rtk_check(hipDeviceSynchronize(), "left-over k-mers"); }
+        unsigned long long nl = 0; rtk_check(hipMemcpy(&nl, d_nleft.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        char* o_pool = static_cast<char*>(malloc(total ? total : 1)); uint64_t* o_off = static_cast<uint64_t*>(malloc(8 * (n_ch + 1))); uint64_t* o_seed = static_cast<uint64_t*>(malloc(8 * (n_ch ? n_ch : 1))); uint64_t* o_left = static_cast<uint64_t*>(malloc(8 * (nl ? nl : 1)));
+        if (!o_pool || !o_off || !o_seed || !o_left) { free(o_pool); free(o_off); free(o_seed); free(o_left); return rtk_fail(RTK_ERR_IO, "rtk_index_unitigs: out of host memory"); }
+        if (total) rtk_check(hipMemcpy(o_pool, d_pool.p, total, hipMemcpyDeviceToHost), "hipMemcpy");
+        memcpy(o_off, h_off.data(), 8 * (n_ch + 1)); if (n_ch) memcpy(o_seed, h_seed.data(), 8 * n_ch);
+        if (nl) rtk_check(hipMemcpy(o_left, d_left.p, 8 * nl, hipMemcpyDeviceToHost), "hipMemcpy");
+        *seq_pool = o_pool; *seq_off = o_off; *seeds = o_seed; *n_unitigs = n_ch; *left = o_left; *n_left = nl;
+        if (trace) fprintf(stderr, "rtk_index_unitigs: %llu unitigs, %llu bases, %llu k-mers left to the plain construction; table + edge bits %.2f s, chains %.2f s, order + sequences %.2f s, left-overs + copies %.2f s\n",
+                           n_ch, static_cast<unsigned long long>(total), nl, t_table, t_chains - t_table, t_write - t_chains, since() - t_write);
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_unitigs: ") + e.what()); }
     return RTK_OK;
 }

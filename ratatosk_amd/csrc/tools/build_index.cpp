@@ -130,7 +130,8 @@ static const std::vector<uint64_t>& solid64(const std::vector<uint64_t>& v) { re
 static const std::vector<uint64_t>& solid64(const std::vector<u128>&) { static const std::vector<uint64_t> none; return none; }
 // (two-word k-mers take the plain path: these overloads are never reached)
 static void fast_table_fill(KTable<u128>&, const std::vector<u128>&, unsigned) {}
-static bool fast_unitigs(KTable<u128>&, const std::vector<u128>&, int, unsigned, std::vector<Unitig>&) { return false; }
+struct DeviceUnitigs { const char* pool = nullptr; const uint64_t* off = nullptr; const uint64_t* seeds = nullptr; uint64_t n = 0; const uint64_t* left = nullptr; uint64_t n_left = 0; }; // what rtk_index_unitigs returns (--gpu)
+static bool fast_unitigs(KTable<u128>&, const std::vector<u128>&, int, unsigned, std::vector<Unitig>&, const DeviceUnitigs*) { return false; }
 
 // every solid k-mer into the table with value 0 (slots claimed with a compare-and-swap on the key word; the table does not grow here)
 static void fast_table_fill(KTable<uint64_t>& km, const std::vector<uint64_t>& solid, unsigned n_thr) {
@@ -156,7 +157,7 @@ static void fast_table_fill(KTable<uint64_t>& km, const std::vector<uint64_t>& s
 // smallest k-mers. Chains that do meet themselves (closed loops, hairpins through a reverse complement) are left to the plain code, which
 // then only sees their k-mers; all unitigs are put in the order of their first k-mers at the end. Returns false (nothing kept) if a k-mer
 // ended up on two unitigs -- the caller then runs the plain construction.
-static bool fast_unitigs(KTable<uint64_t>& km, const std::vector<uint64_t>& solid, int k, unsigned n_thr, std::vector<Unitig>& U) {
+static bool fast_unitigs(KTable<uint64_t>& km, const std::vector<uint64_t>& solid, int k, unsigned n_thr, std::vector<Unitig>& U, const DeviceUnitigs* dev) {
     const uint64_t mask = kmer_mask(k);
     auto in_graph = [&](uint64_t oriented) -> bool { return km.slot(kmer_canonical(oriented, k), false) != nullptr; };
     auto succs = [&](uint64_t x, uint64_t out[4]) -> int { int n = 0; for (uint64_t b = 0; b < 4; ++b) { const uint64_t y = ((x << 2) | b) & mask; if (in_graph(y)) out[n++] = y; } return n; };
@@ -167,7 +168,7 @@ static bool fast_unitigs(KTable<uint64_t>& km, const std::vector<uint64_t>& soli
     std::vector<std::vector<Rec> > out(n_thr);
     std::atomic<bool> clash(false);
     auto claim = [&](uint64_t canonical) { uint64_t* v = km.slot(canonical, false); if (__atomic_exchange_n(v, 1ULL, __ATOMIC_RELAXED) != 0) clash = true; };
-    parallel_for(solid.size(), n_thr, [&](size_t b, size_t e, unsigned t) {
+    if (!dev) parallel_for(solid.size(), n_thr, [&](size_t b, size_t e, unsigned t) {
         std::vector<uint64_t> path;
         for (size_t i = b; i < e && !clash; ++i) {
             const uint64_t s = solid[i]; uint64_t y;
@@ -199,28 +200,41 @@ static bool fast_unitigs(KTable<uint64_t>& km, const std::vector<uint64_t>& soli
     {
         // (the k-mers no chain has claimed are looked for on all threads -- one table probe per solid k-mer, a cache miss each -- and come out in
         // sorted order, thread after thread; the plain construction then only visits those)
-        std::vector<std::vector<uint64_t> > left_t(n_thr);
-        parallel_for(solid.size(), n_thr, [&](size_t b, size_t e, unsigned t) { for (size_t i = b; i < e; ++i) if (*km.slot(solid[i], false) == 0) left_t[t].push_back(solid[i]); });
-        std::vector<uint64_t> left; for (unsigned t = 0; t < n_thr; ++t) left.insert(left.end(), left_t[t].begin(), left_t[t].end());
+        std::vector<uint64_t> left;
+        if (dev) left.assign(dev->left, dev->left + dev->n_left); // (--gpu: the chains were walked, written and claimed on the device)
+        else {
+            std::vector<std::vector<uint64_t> > left_t(n_thr);
+            parallel_for(solid.size(), n_thr, [&](size_t b, size_t e, unsigned t) { for (size_t i = b; i < e; ++i) if (*km.slot(solid[i], false) == 0) left_t[t].push_back(solid[i]); });
+            for (unsigned t = 0; t < n_thr; ++t) left.insert(left.end(), left_t[t].begin(), left_t[t].end());
+        }
+        size_t lcap = 16; while (lcap * 6 < left.size() * 10 + 16) lcap <<= 1; lcap <<= 1;
+        KTable<uint64_t> lt(lcap); // the left-over k-mers: 0 = free, 1 = on a unitig built below; a k-mer that is not in it lies on a chain built above
+        for (size_t li = 0; li < left.size(); ++li) *lt.slot(left[li], true) = 0;
+        auto taken = [&](uint64_t c) -> bool { const uint64_t* v = lt.slot(c, false); return !v || *v != 0; };
         std::set<uint64_t> in_this;
         for (size_t li = 0; li < left.size(); ++li) {
             const uint64_t seed_km = left[li];
-            uint64_t* v0 = km.slot(seed_km, false);
-            if (*v0 != 0) continue;
+            if (taken(seed_km)) continue;
             in_this.clear(); in_this.insert(seed_km);
             std::vector<uint64_t> fwd(1, seed_km), bwd; uint64_t nb[4], nb2[4];
-            for (uint64_t x = seed_km;;) { if (succs(x, nb) != 1) break; const uint64_t y = nb[0]; if (preds(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); fwd.push_back(y); x = y; }
-            for (uint64_t x = seed_km;;) { if (preds(x, nb) != 1) break; const uint64_t y = nb[0]; if (succs(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || *km.slot(cy, false) != 0) break; in_this.insert(cy); bwd.push_back(y); x = y; }
+            for (uint64_t x = seed_km;;) { if (succs(x, nb) != 1) break; const uint64_t y = nb[0]; if (preds(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || taken(cy)) break; in_this.insert(cy); fwd.push_back(y); x = y; }
+            for (uint64_t x = seed_km;;) { if (preds(x, nb) != 1) break; const uint64_t y = nb[0]; if (succs(y, nb2) != 1) break; const uint64_t cy = kmer_canonical(y, k); if (in_this.count(cy) || taken(cy)) break; in_this.insert(cy); bwd.push_back(y); x = y; }
             std::vector<uint64_t> path(bwd.rbegin(), bwd.rend()); path.insert(path.end(), fwd.begin(), fwd.end());
             Rec r; r.seed = seed_km; r.seq = kmer_decode(path[0], k);
             for (size_t j = 1; j < path.size(); ++j) r.seq.push_back(bits2base(static_cast<int>(path[j] & 3)));
-            for (size_t j = 0; j < path.size(); ++j) *km.slot(kmer_canonical(path[j], k), false) = 1;
+            for (size_t j = 0; j < path.size(); ++j) *lt.slot(kmer_canonical(path[j], k), false) = 1;
             rest.push_back(r);
         }
     }
     if (getenv("RTK_INDEX_TRACE")) fprintf(stderr, "rtk_build_index: %zu unitigs of chains that meet themselves built by the plain code\n", rest.size());
     // all unitigs in the order of their first k-mers; the table values from the final numbers
     std::vector<Rec*> all;
+    std::vector<Rec> dev_recs;
+    if (dev) { // (already in the order of their seeds; the sequences are cut out of the pool where the table values are set, below)
+        dev_recs.resize(dev->n);
+        parallel_for(dev_recs.size(), n_thr, [&](size_t b, size_t e, unsigned) { for (size_t i = b; i < e; ++i) { dev_recs[i].seed = dev->seeds[i]; dev_recs[i].seq.assign(dev->pool + dev->off[i], dev->pool + dev->off[i + 1]); } });
+        for (size_t i = 0; i < dev_recs.size(); ++i) all.push_back(&dev_recs[i]);
+    }
     for (unsigned t = 0; t < n_thr; ++t) for (size_t i = 0; i < out[t].size(); ++i) all.push_back(&out[t][i]);
     for (size_t i = 0; i < rest.size(); ++i) all.push_back(&rest[i]);
     std::sort(all.begin(), all.end(), [](const Rec* a, const Rec* b) { return a->seed < b->seed; });
@@ -286,6 +300,9 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     unsigned n_thr = std::thread::hardware_concurrency(); if (n_thr == 0) n_thr = 1; if (n_thr > (fast ? 128u : 32u)) n_thr = fast ? 128u : 32u; // (--fast: the steps are random accesses into GB-sized tables: latency-bound, SMT threads help)
     { const char* e = getenv("RTK_INDEX_THREADS"); if (e && atoi(e) > 0) n_thr = static_cast<unsigned>(atoi(e)); }
     std::vector<KM> solid;
+    typedef int (*unitigs_fn)(int, int, const uint64_t*, uint64_t, char**, uint64_t**, uint64_t**, uint64_t*, uint64_t**, uint64_t*);
+    typedef const char* (*gerr_fn)(void); typedef void (*gfree_fn)(void*);
+    unitigs_fn gpu_unitigs_fn = nullptr; gerr_fn gpu_err_fn = nullptr; gfree_fn gpu_free_fn = nullptr;
     if (gpu) { // the k-mers counted on the device (csrc/hip/rtk_index.hip, through the C ABI of libratatosk_hip.so next to this executable)
         typedef int (*count_fn)(int, int, const char* const*, int, uint32_t, int, uint64_t**, uint64_t*);
         typedef const char* (*err_fn)(void); typedef void (*free_fn)(void*);
@@ -294,6 +311,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         void* h = dlopen(lib.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (!h) { fprintf(stderr, "rtk_build_index: --gpu: cannot load %s (%s)\n", lib.c_str(), dlerror()); return 1; }
         count_fn cf = reinterpret_cast<count_fn>(dlsym(h, "rtk_index_count_kmers")); err_fn ef = reinterpret_cast<err_fn>(dlsym(h, "rtk_last_error")); free_fn ff = reinterpret_cast<free_fn>(dlsym(h, "rtk_free"));
+        gpu_unitigs_fn = reinterpret_cast<unitigs_fn>(dlsym(h, "rtk_index_unitigs")); gpu_err_fn = ef; gpu_free_fn = ff;
         if (!cf || !ef || !ff) { fprintf(stderr, "rtk_build_index: --gpu: %s lacks the index entry points\n", lib.c_str()); return 1; }
         std::vector<const char*> fp; for (size_t f = 0; f < in_files.size(); ++f) fp.push_back(in_files[f].c_str());
         uint64_t* sk = nullptr; uint64_t ns = 0;
@@ -347,7 +365,16 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     // ---- unitigs: maximal non-branching paths ----
     std::vector<Unitig> U;
     bool fast_done = false;
-    if (fast) fast_done = fast_unitigs(km, solid, k, n_thr, U);
+    DeviceUnitigs dev_u; bool have_dev_u = false;
+    char* du_pool = nullptr; uint64_t* du_off = nullptr; uint64_t* du_seeds = nullptr; uint64_t* du_left = nullptr;
+    if (gpu && gpu_unitigs_fn && sizeof(KM) == 8 && !getenv("RTK_INDEX_HOST_UNITIGS")) { // the chains walked and written on the device (csrc/hip/rtk_index.hip rtk_index_unitigs)
+        uint64_t nu = 0, nl = 0;
+        const int rc = gpu_unitigs_fn(0, k, reinterpret_cast<const uint64_t*>(solid.data()), solid.size(), &du_pool, &du_off, &du_seeds, &nu, &du_left, &nl);
+        if (rc == 0) { dev_u.pool = du_pool; dev_u.off = du_off; dev_u.seeds = du_seeds; dev_u.n = nu; dev_u.left = du_left; dev_u.n_left = nl; have_dev_u = true; }
+        else fprintf(stderr, "rtk_build_index: --gpu: unitigs on the host threads (%s)\n", gpu_err_fn ? gpu_err_fn() : "?");
+    }
+    if (fast) fast_done = fast_unitigs(km, solid, k, n_thr, U, have_dev_u ? &dev_u : nullptr);
+    if (gpu_free_fn) { gpu_free_fn(du_pool); gpu_free_fn(du_off); gpu_free_fn(du_seeds); gpu_free_fn(du_left); }
     if (!fast_done)
     {
         if (fast) for (size_t i = 0; i < km.vals.size(); ++i) km.vals[i] = 0; // (the thread-parallel construction backed out: every k-mer unvisited again)

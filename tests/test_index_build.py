@@ -30,6 +30,8 @@ def _rc(s):
 def _build(sr, out, k, extra):
     r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", sr, "-o", out, "-k", str(k), "--snps"] + extra, capture_output=True, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1"))
     assert r.returncode == 0, r.stderr
+    if "--gpu" in extra:  # the chains were walked and written on the device (rtk_index_unitigs), not on the host threads behind a failed call
+        assert "rtk_index_unitigs:" in r.stderr and "unitigs on the host threads" not in r.stderr, r.stderr
     return open(out + ".index.k%d.fasta.gz" % k, "rb").read(), open(out + ".index.k%d.rtsk" % k, "rb").read(), r.stderr
 
 
