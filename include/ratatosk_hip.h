@@ -223,6 +223,15 @@ int rtk_index_count_kmers(int device, int k, const char* const* files, int n_fil
 int rtk_index_unitigs(int device, int k, const uint64_t* solid, uint64_t n_solid, char** seq_pool, uint64_t** seq_off, uint64_t** seeds, uint64_t* n_unitigs,
                       uint64_t** left, uint64_t* n_left);
 
+/* rtk_index_colour_*: colours and coverage of an index build (addCoverage, src/Graph.cpp:1561-1985: every k-mer of every read mapped onto its unitig).
+ * begin: unitig u = seq_pool[seq_off[u] .. seq_off[u + 1]); packs them and builds their k-mer table in HBM. chunk (any thread; calls are serialised inside):
+ * sequences separated by '\n', read r starting at starts[r] with the id ids[r] (the caller numbers its reads: a pair keeps one id), at most 64 MB and
+ * 4 M reads per call. end: the distinct events unitig << 32 | id in ascending order and the k-mer coverage of every unitig (rtk_free); releases the job
+ * (with null outputs: only that). */
+int rtk_index_colour_begin(int device, int k, const char* seq_pool, const uint64_t* seq_off, uint64_t n_unitigs, void** job);
+int rtk_index_colour_chunk(void* job, const char* chars, uint64_t n_chars, const uint64_t* starts, const uint32_t* ids, uint32_t n_reads);
+int rtk_index_colour_end(void* job, uint64_t** events, uint64_t* n_events, uint64_t** cov);
+
 void rtk_free(void* p);
 const char* rtk_last_error(void);
 const char* rtk_version(void);

@@ -215,6 +215,9 @@ extern "C" int rtk_n_devices(void) { return rtk_device_count(); }
 #ifdef RTK_SIM
 // (the simulator build has the entry point for ABI completeness only: k-mer counting on the device is csrc/hip/rtk_index.hip, its CPU form the index tool's plain path)
 extern "C" int rtk_index_count_kmers(int, int, const char* const*, int, uint32_t, int, uint64_t**, uint64_t*) { return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_count_kmers: not part of the simulator build"); }
+extern "C" int rtk_index_colour_begin(int, int, const char*, const uint64_t*, uint64_t, void**) { return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_colour_begin: not part of the simulator build"); }
+extern "C" int rtk_index_colour_chunk(void*, const char*, uint64_t, const uint64_t*, const uint32_t*, uint32_t) { return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_colour_chunk: not part of the simulator build"); }
+extern "C" int rtk_index_colour_end(void*, uint64_t**, uint64_t*, uint64_t**) { return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_colour_end: not part of the simulator build"); }
 extern "C" int rtk_index_unitigs(int, int, const uint64_t*, uint64_t, char**, uint64_t**, uint64_t**, uint64_t*, uint64_t**, uint64_t*) { return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_unitigs: not part of the simulator build"); }
 #endif
 extern "C" int rtk_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {

@@ -21,6 +21,10 @@ struct DeviceTables {                     // device pointers (hipMalloc'd here, 
 // file is no compacted de Bruijn graph for this k; out of memory; more than 2^34 list words)
 void device_tables_build(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_t n_unitigs, uint64_t n_bases, uint64_t n_kmers, int k, DeviceTables* out);
 
+// the k-mer table alone, without filters, at load 0.7 (16-byte slots {canonical k-mer, unitig << 32 | offset << 1 | stored_is_canonical}, slot of a hash by
+// multiply-high): what the index build's colouring pass looks the read k-mers up in. One-word k-mers.
+void device_kmer_table(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_t n_unitigs, uint64_t n_bases, uint64_t n_kmers, int k, void** ht_out, uint64_t* slots_out);
+
 } // namespace rtk
 
 #endif

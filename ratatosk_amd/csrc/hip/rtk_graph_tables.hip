@@ -76,7 +76,7 @@ __global__ void k_fill_words(uint64_t* __restrict__ a, uint64_t n, uint64_t v) {
 
 // ---- k-mer table + filters (host/flat_graph.cpp "k-mer table + filters") ----
 __global__ void k_tables_insert(const uint64_t* __restrict__ useq, const uint64_t* __restrict__ uoff, uint32_t n_unitigs, uint64_t n_bases, int k,
-                                uint64_t* __restrict__ ht, uint64_t slots, uint64_t* __restrict__ bf, uint64_t bf_mask, uint64_t* __restrict__ bf1, uint64_t bf1_mask, int bf1_off, uint32_t* __restrict__ err) {
+                                uint64_t* __restrict__ ht, uint64_t slots, uint64_t* __restrict__ bf, uint64_t bf_mask, uint64_t* __restrict__ bf1, uint64_t bf1_mask, int bf1_off, int filters, uint32_t* __restrict__ err) {
     const bool wide = k > 31;
     const uint64_t n_words = (n_bases + 31ull) / 32ull, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < n_words; w += stride) {
@@ -93,6 +93,7 @@ __global__ void k_tables_insert(const uint64_t* __restrict__ useq, const uint64_
                 s = rtk_ht_next(s, slots);
             }
             ht[2 * s + 1] = (static_cast<uint64_t>(u) << 32) | (static_cast<uint64_t>(off) << 1) | (is_fw ? 1ull : 0ull);
+            if (!filters) return; // (the index build's table: looked up without filters)
             atomicOr(reinterpret_cast<unsigned long long*>(bf + ((hh >> 32) & bf_mask)), static_cast<unsigned long long>((1ull << (hh & 63)) | (1ull << ((hh >> 6) & 63))));
             if (!bf1_off) { const uint64_t b1 = (hh >> 12) & bf1_mask; atomicOr(reinterpret_cast<unsigned long long*>(bf1 + (b1 >> 6)), static_cast<unsigned long long>(1ull << (b1 & 63ull))); }
         });
@@ -286,7 +287,7 @@ void device_tables_build(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_
     rtk_check(hipMemset(bf.p, 0, 8 * tsz.bf_words), "hipMemset");
     if (bf1_off) hipLaunchKernelGGL(k_fill_words, dim3(1), dim3(64), 0, 0, bf1.as<uint64_t>(), 1ull, ~0ull); else rtk_check(hipMemset(bf1.p, 0, 8 * tsz.bf1_words), "hipMemset");
     hipLaunchKernelGGL(k_tables_insert, dim3(grid_for(n_words)), dim3(RTK_TB_BLOCK), 0, 0, d_useq, d_uoff, n_unitigs, n_bases, k, ht.as<uint64_t>(), tsz.ht_slots, bf.as<uint64_t>(), tsz.bf_words - 1,
-                       bf1.as<uint64_t>(), tsz.bf1_words * 64 - 1, bf1_off, d_err.as<uint32_t>());
+                       bf1.as<uint64_t>(), tsz.bf1_words * 64 - 1, bf1_off, 1, d_err.as<uint32_t>());
     sync_check("k_tables_insert");
     GraphView gv; memset(&gv, 0, sizeof(gv));
     gv.k = k; gv.n_unitigs = n_unitigs; gv.n_kmers = n_kmers; gv.ht_slots = tsz.ht_slots; gv.useq = d_useq; gv.uoff = d_uoff; gv.ht = ht.as<uint64_t>();
@@ -306,6 +307,18 @@ void device_tables_build(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_
     out->adj = adj.take(); out->adj_bytes = 32ull * n_unitigs;
     out->seconds[0] = t2 - t1; out->seconds[1] = t1 - t0; out->seconds[2] = t3 - t2; out->seconds[3] = t3 - t0;
     if (trace) fprintf(stderr, "[rtk load] device tables: half-k-mer index %.2f s, k-mer table + filters %.2f s, adjacency %.2f s\n", t1 - t0, t2 - t1, t3 - t2);
+}
+
+// the k-mer table alone (no filters), for the index build's colouring pass (rtk_index.hip): slots at load 0.7, any number of k-mers
+void device_kmer_table(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_t n_unitigs, uint64_t n_bases, uint64_t n_kmers, int k, void** ht_out, uint64_t* slots_out) {
+    const uint64_t slots = n_kmers + n_kmers * 3 / 7 + 16, n_words = (n_bases + 31) / 32;
+    Dev ht, d_err; ht.alloc(16 * slots); d_err.alloc(4); rtk_check(hipMemset(d_err.p, 0, 4), "hipMemset");
+    hipLaunchKernelGGL(k_fill_slots, dim3(grid_for(slots)), dim3(RTK_TB_BLOCK), 0, 0, ht.as<uint64_t>(), slots);
+    hipLaunchKernelGGL(k_tables_insert, dim3(grid_for(n_words)), dim3(RTK_TB_BLOCK), 0, 0, d_useq, d_uoff, n_unitigs, n_bases, k, ht.as<uint64_t>(), slots, static_cast<uint64_t*>(nullptr), 0ull, static_cast<uint64_t*>(nullptr), 0ull, 1, 0, d_err.as<uint32_t>());
+    sync_check("k_tables_insert (index build)");
+    uint32_t err = 0; rtk_check(hipMemcpy(&err, d_err.p, 4, hipMemcpyDeviceToHost), "hipMemcpy");
+    if (err) throw std::runtime_error("a k-mer occurs twice in the unitigs");
+    *ht_out = ht.take(); *slots_out = slots;
 }
 
 } // namespace rtk

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -27,6 +28,7 @@
 #include "../../../include/ratatosk_hip.h"
 #include "../common/fastx.hpp"
 #include "../common/kmer.hpp"
+#include "rtk_graph_tables.h"
 #include "rtk_mem.h"
 #include "rtk_types.h"
 
@@ -247,6 +249,83 @@ __global__ void k_ut_write(uint64_t n_ch, const uint32_t* __restrict__ order, co
 struct Unclaimed { const uint64_t* solid; const uint64_t* T; uint64_t slots; __device__ bool operator()(uint64_t i) const { return !(T[2 * ut_find(T, slots, solid[i]) + 1] & RTK_UT_CLAIMED); } };
 struct Iota32 { __device__ uint32_t operator()(uint64_t i) const { return static_cast<uint32_t>(i); } };
 
+
+// ------------------------------------------------------------------------------------------------ colours and coverage (rtk_index_colour_*)
+// unitig sequences (characters, unitig u at off[u]) -> the 2-bit pool of the flat graph (base p at bits 2 (p & 31) of word p >> 5)
+__global__ void k_col_pack(const char* __restrict__ pool, uint64_t n_bases, uint64_t* __restrict__ useq, uint64_t n_words) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        uint64_t x = 0;
+        for (uint64_t j = 0; j < 32 && 32 * w + j < n_bases; ++j) x |= static_cast<uint64_t>(idx_code(static_cast<unsigned char>(pool[32 * w + j])) & 3u) << (2 * j);
+        useq[w] = x;
+    }
+}
+// One lane per character position of a chunk of reads (sequences separated by '\n'): its k-mer looked up in the unitig table. A run of consecutive
+// positions of one read on one unitig is one EVENT (unitig << 32 | id of the read) and one addition of its length to the unitig's coverage, made by
+// the first lane of the run inside its wave (a run that crosses a wave boundary gives two events: duplicates go when the events are sorted).
+__global__ void k_col_map(const char* __restrict__ chars, uint64_t n, int k, const uint64_t* __restrict__ starts, const uint32_t* __restrict__ ids, uint32_t n_reads,
+                          const uint64_t* __restrict__ ht, uint64_t slots, unsigned long long* __restrict__ cov, uint64_t* __restrict__ events, unsigned long long* __restrict__ top, uint64_t cap) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t i0 = static_cast<uint64_t>(blockIdx.x) * blockDim.x; i0 < n; i0 += stride) { // (whole waves take part in every round)
+        const uint64_t i = i0 + threadIdx.x;
+        uint64_t km = 0; bool ok = i + static_cast<uint64_t>(k) <= n;
+        if (ok) for (int j = 0; j < k; ++j) { const uint32_t c = idx_code(static_cast<unsigned char>(chars[i + j])); ok = ok && c < 4u; km = (km << 2) | (c & 3u); }
+        uint32_t u = 0xFFFFFFFFu;
+        if (ok) {
+            const uint64_t rc = idx_revcomp(km, k), can = km <= rc ? km : rc;
+            uint64_t s = __umul64hi(idx_hash(can), slots);
+            for (;;) { const uint64_t key = ht[2 * s]; if (key == can) { u = static_cast<uint32_t>(ht[2 * s + 1] >> 32); break; } if (key == RTK_IDX_SENTINEL) break; s = s + 1 == slots ? 0 : s + 1; }
+        }
+        const bool hit = u != 0xFFFFFFFFu;
+        const uint32_t pu = __shfl_up(u, 1, 64); // (position i - 1 with a k-mer on the same unitig: the same read, its k-mer holds no separator)
+        const bool head = hit && (lane == 0 || pu != u);
+        const uint64_t heads = __ballot(head ? 1 : 0), hits = __ballot(hit ? 1 : 0);
+        if (!heads) continue;
+        const unsigned long long base = __shfl(lane == 0 ? atomicAdd(top, static_cast<unsigned long long>(__popcll(heads))) : 0ull, 0, 64);
+        if (head) {
+            const uint64_t above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1); // the next head of the wave, if any
+            const int nxt = above ? __ffsll(static_cast<unsigned long long>(above)) - 1 : 64;
+            const uint64_t span = (nxt == 64 ? ~0ull : ((1ull << nxt) - 1ull)) & ~((1ull << lane) - 1ull);
+            atomicAdd(cov + u, static_cast<unsigned long long>(__popcll(hits & span)));
+            uint32_t lo = 0, hi = n_reads; // the read of position i: the last one that starts at or before it
+            while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (starts[mid] <= i) lo = mid; else hi = mid; }
+            const uint64_t at = base + static_cast<uint64_t>(__popcll(heads & ((1ull << lane) - 1ull)));
+            if (at < cap) events[at] = (static_cast<uint64_t>(u) << 32) | ids[lo];
+        }
+    }
+}
+
+struct ColourJob {
+    int device = 0, k = 31; uint32_t n_unitigs = 0;
+    DevBuf useq, uoff, ht, cov, events, alt, top, tmp;
+    uint64_t slots = 0, cap = 0, n_events = 0; // n_events: sorted, distinct events at the front of `events`
+    DevBuf d_chars[2], d_starts[2], d_ids[2]; PinBuf h_chars[2], h_starts[2], h_ids[2]; uint64_t chunk_cap = 0, reads_cap = 0;
+    hipStream_t st[2] = {nullptr, nullptr}; int slot = 0;
+    std::mutex m; uint64_t bases = 0, chunks = 0, compactions = 0; double t_table = 0.0;
+    std::chrono::steady_clock::time_point t0;
+    ~ColourJob() { if (st[0]) (void)hipStreamDestroy(st[0]); if (st[1]) (void)hipStreamDestroy(st[1]); }
+    // the events so far sorted, the distinct ones kept (both streams idle)
+    void compact() {
+        rtk_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        unsigned long long n = 0; rtk_check(hipMemcpy(&n, top.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        if (n > cap) throw std::runtime_error("more (unitig, read) events than the device buffer holds between two compactions (RTK_INDEX_EVENTS: number of events to make room for)");
+        if (n == n_events) return;
+        ++compactions;
+        rocprim::double_buffer<uint64_t> db(static_cast<uint64_t*>(events.p), static_cast<uint64_t*>(alt.p));
+        size_t tb = 0; rtk_check(rocprim::radix_sort_keys(nullptr, tb, db, static_cast<size_t>(n), 0, 64), "rocprim::radix_sort_keys");
+        tmp.alloc(tb); rtk_check(rocprim::radix_sort_keys(tmp.p, tb, db, static_cast<size_t>(n), 0, 64), "rocprim::radix_sort_keys");
+        uint64_t* sorted = db.current(); uint64_t* other = db.alternate();
+        DevBuf d_n; d_n.alloc(8);
+        size_t ub = 0; rtk_check(rocprim::unique(nullptr, ub, sorted, other, static_cast<unsigned long long*>(d_n.p), static_cast<size_t>(n)), "rocprim::unique");
+        tmp.alloc(ub); rtk_check(rocprim::unique(tmp.p, ub, sorted, other, static_cast<unsigned long long*>(d_n.p), static_cast<size_t>(n)), "rocprim::unique");
+        rtk_check(hipDeviceSynchronize(), "events sorted");
+        unsigned long long nu = 0; rtk_check(hipMemcpy(&nu, d_n.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        if (other != static_cast<uint64_t*>(events.p)) rtk_check(hipMemcpy(events.p, other, 8 * nu, hipMemcpyDeviceToDevice), "hipMemcpy");
+        n_events = nu; rtk_check(hipMemcpy(top.p, &nu, 8, hipMemcpyHostToDevice), "hipMemcpy");
+    }
+};
+
 } // namespace
 
 extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files, int n_files, uint32_t min_count, int n_threads, uint64_t** solid_out, uint64_t* n_solid) {
@@ -417,5 +496,97 @@ extern "C" int rtk_index_unitigs(int device, int k, const uint64_t* solid, uint6
         if (trace) fprintf(stderr, "rtk_index_unitigs: %llu unitigs, %llu bases, %llu k-mers left to the plain construction; table + edge bits %.2f s, chains %.2f s, order + sequences %.2f s, left-overs + copies %.2f s\n",
                            n_ch, static_cast<unsigned long long>(total), nl, t_table, t_chains - t_table, t_write - t_chains, since() - t_write);
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_unitigs: ") + e.what()); }
+    return RTK_OK;
+}
+
+
+// Colours and coverage of an index build (addCoverage, src/Graph.cpp:1561-1985: every read k-mer mapped onto its unitig) on the device. The caller -- the index
+// tool, which owns the numbering of the reads (a pair keeps one id: name changes, or pair numbers of a sampled source) -- opens a job on the unitigs, feeds its
+// reads chunk by chunk from any number of threads, and gets back the distinct (unitig, read id) events in sorted order and the k-mer coverage of every unitig.
+//   begin  unitig u = seq_pool[seq_off[u] .. seq_off[u + 1]) (characters); the pool is packed to 2 bits and the k-mer table built in HBM (rtk_graph_tables.hip)
+//   chunk  chars: sequences separated by '\n' (n_chars characters); read r starts at starts[r] and has the id ids[r]. At most RTK_COLOUR_CHUNK (64 MB) per call.
+//   end    *events: n_events words unitig << 32 | id, ascending, distinct; *cov: n_unitigs counts. Freed with rtk_free. The job is gone afterwards (also on error).
+extern "C" int rtk_index_colour_begin(int device, int k, const char* seq_pool, const uint64_t* seq_off, uint64_t n_unitigs, void** job_out) {
+    if (!seq_pool || !seq_off || !job_out || n_unitigs == 0) return rtk_fail(RTK_ERR_ARG, "rtk_index_colour_begin: null argument");
+    if (k < 3 || k > 31 || !(k & 1)) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_colour_begin: one-word k-mers only (odd k <= 31)");
+    if (rtk_device_count() <= device || device < 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_index_colour_begin: no such HIP device (no CPU fallback)");
+    if (n_unitigs >= 0xFFFFFFFFull) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_index_colour_begin: more than 2^32 - 1 unitigs");
+    *job_out = nullptr;
+    std::unique_ptr<ColourJob> J(new ColourJob());
+    try {
+        rtk_check(hipSetDevice(device), "hipSetDevice");
+        J->t0 = std::chrono::steady_clock::now();
+        J->device = device; J->k = k; J->n_unitigs = static_cast<uint32_t>(n_unitigs);
+        const uint64_t n_bases = seq_off[n_unitigs], n_kmers = n_bases - n_unitigs * static_cast<uint64_t>(k - 1), n_words = (n_bases + 31) / 32;
+        { DevBuf d_pool; d_pool.alloc(n_bases); rtk_check(hipMemcpy(d_pool.p, seq_pool, n_bases, hipMemcpyHostToDevice), "hipMemcpy");
+          J->useq.alloc(8 * (n_words + 2)); rtk_check(hipMemset(J->useq.p, 0, 8 * (n_words + 2)), "hipMemset");
+          hipLaunchKernelGGL(k_col_pack, dim3(4096), dim3(256), 0, 0, static_cast<const char*>(d_pool.p), n_bases, static_cast<uint64_t*>(J->useq.p), n_words);
+          rtk_check(hipGetLastError(), "kernel launch (k_col_pack)"); rtk_check(hipDeviceSynchronize(), "k_col_pack"); }
+        J->uoff.alloc(8 * (n_unitigs + 1)); rtk_check(hipMemcpy(J->uoff.p, seq_off, 8 * (n_unitigs + 1), hipMemcpyHostToDevice), "hipMemcpy");
+        void* ht = nullptr; rtk::device_kmer_table(static_cast<const uint64_t*>(J->useq.p), static_cast<const uint64_t*>(J->uoff.p), J->n_unitigs, n_bases, n_kmers, k, &ht, &J->slots);
+        J->ht.p = ht;
+        J->cov.alloc(8 * n_unitigs); rtk_check(hipMemset(J->cov.p, 0, 8 * n_unitigs), "hipMemset");
+        J->top.alloc(8); rtk_check(hipMemset(J->top.p, 0, 8), "hipMemset");
+        J->chunk_cap = 64ull << 20; J->reads_cap = J->chunk_cap / 16; // (a read of fewer than 15 characters per 16 bytes of chunk: the caller splits such chunks)
+        for (int i = 0; i < 2; ++i) {
+            J->d_chars[i].alloc(J->chunk_cap); J->d_starts[i].alloc(8 * J->reads_cap); J->d_ids[i].alloc(4 * J->reads_cap);
+            J->h_chars[i].alloc(J->chunk_cap); J->h_starts[i].alloc(8 * J->reads_cap); J->h_ids[i].alloc(4 * J->reads_cap);
+            rtk_check(hipStreamCreate(&J->st[i]), "hipStreamCreate");
+        }
+        size_t fr = 0, tot = 0; rtk_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo");
+        J->cap = static_cast<uint64_t>(fr) / 10 * 6 / 16; // 60 % of what is left for the events and their sort buffer
+        { const char* e = getenv("RTK_INDEX_EVENTS"); if (e) J->cap = strtoull(e, nullptr, 10); }
+        if (J->cap < (1u << 16)) J->cap = 1u << 16;
+        J->events.alloc(8 * J->cap); J->alt.alloc(8 * J->cap);
+        J->t_table = std::chrono::duration<double>(std::chrono::steady_clock::now() - J->t0).count();
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_colour_begin: ") + e.what()); }
+    *job_out = J.release();
+    return RTK_OK;
+}
+
+extern "C" int rtk_index_colour_chunk(void* job, const char* chars, uint64_t n_chars, const uint64_t* starts, const uint32_t* ids, uint32_t n_reads) {
+    ColourJob* J = static_cast<ColourJob*>(job);
+    if (!J || !chars || !starts || !ids) return rtk_fail(RTK_ERR_ARG, "rtk_index_colour_chunk: null argument");
+    if (n_reads == 0 || n_chars == 0) return RTK_OK;
+    if (n_chars > J->chunk_cap || n_reads > J->reads_cap) return rtk_fail(RTK_ERR_ARG, "rtk_index_colour_chunk: chunk larger than 64 MB of characters / 4 M reads");
+    try {
+        std::lock_guard<std::mutex> lk(J->m);
+        rtk_check(hipSetDevice(J->device), "hipSetDevice");
+        // room for this chunk's events (at most one per position): sort and keep the distinct ones when the buffer is half full
+        if (J->chunks && ((J->chunks & 7u) == 0 || J->cap < (1ull << 30))) { // (looked at every 8th chunk: reading the counter waits for the device)
+            rtk_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+            unsigned long long n = 0; rtk_check(hipMemcpy(&n, J->top.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+            if (n > J->cap / 2) J->compact();
+        }
+        const int sl = J->slot; J->slot ^= 1;
+        rtk_check(hipStreamSynchronize(J->st[sl]), "hipStreamSynchronize");
+        memcpy(J->h_chars[sl].p, chars, n_chars); memcpy(J->h_starts[sl].p, starts, 8ull * n_reads); memcpy(J->h_ids[sl].p, ids, 4ull * n_reads);
+        rtk_check(hipMemcpyAsync(J->d_chars[sl].p, J->h_chars[sl].p, n_chars, hipMemcpyHostToDevice, J->st[sl]), "hipMemcpyAsync");
+        rtk_check(hipMemcpyAsync(J->d_starts[sl].p, J->h_starts[sl].p, 8ull * n_reads, hipMemcpyHostToDevice, J->st[sl]), "hipMemcpyAsync");
+        rtk_check(hipMemcpyAsync(J->d_ids[sl].p, J->h_ids[sl].p, 4ull * n_reads, hipMemcpyHostToDevice, J->st[sl]), "hipMemcpyAsync");
+        hipLaunchKernelGGL(k_col_map, dim3(4096), dim3(256), 0, J->st[sl], static_cast<const char*>(J->d_chars[sl].p), n_chars, J->k, static_cast<const uint64_t*>(J->d_starts[sl].p), static_cast<const uint32_t*>(J->d_ids[sl].p), n_reads,
+                           static_cast<const uint64_t*>(J->ht.p), J->slots, static_cast<unsigned long long*>(J->cov.p), static_cast<uint64_t*>(J->events.p), static_cast<unsigned long long*>(J->top.p), J->cap);
+        rtk_check(hipGetLastError(), "kernel launch (k_col_map)");
+        J->bases += n_chars; ++J->chunks;
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_colour_chunk: ") + e.what()); }
+    return RTK_OK;
+}
+
+extern "C" int rtk_index_colour_end(void* job, uint64_t** events, uint64_t* n_events, uint64_t** cov) {
+    std::unique_ptr<ColourJob> J(static_cast<ColourJob*>(job));
+    if (!J) return rtk_fail(RTK_ERR_ARG, "rtk_index_colour_end: null job");
+    if (!events || !n_events || !cov) return RTK_OK; // (abandoned job: released)
+    *events = nullptr; *cov = nullptr; *n_events = 0;
+    try {
+        rtk_check(hipSetDevice(J->device), "hipSetDevice");
+        J->compact();
+        uint64_t* ev = static_cast<uint64_t*>(malloc(8 * (J->n_events ? J->n_events : 1))); uint64_t* cv = static_cast<uint64_t*>(malloc(8ull * J->n_unitigs));
+        if (!ev || !cv) { free(ev); free(cv); return rtk_fail(RTK_ERR_IO, "rtk_index_colour_end: out of host memory"); }
+        if (J->n_events) rtk_check(hipMemcpy(ev, J->events.p, 8 * J->n_events, hipMemcpyDeviceToHost), "hipMemcpy");
+        rtk_check(hipMemcpy(cv, J->cov.p, 8ull * J->n_unitigs, hipMemcpyDeviceToHost), "hipMemcpy");
+        *events = ev; *n_events = J->n_events; *cov = cv;
+        if (getenv("RTK_INDEX_TRACE")) fprintf(stderr, "rtk_index_colour: %llu characters in %llu chunks -> %llu distinct (unitig, read) events (sorted and thinned out %llu times); table %.2f s, all %.2f s\n", static_cast<unsigned long long>(J->bases),
+                                               static_cast<unsigned long long>(J->chunks), static_cast<unsigned long long>(J->n_events), static_cast<unsigned long long>(J->compactions), J->t_table, std::chrono::duration<double>(std::chrono::steady_clock::now() - J->t0).count());
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_colour_end: ") + e.what()); }
     return RTK_OK;
 }

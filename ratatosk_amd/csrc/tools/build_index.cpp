@@ -303,6 +303,8 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     typedef int (*unitigs_fn)(int, int, const uint64_t*, uint64_t, char**, uint64_t**, uint64_t**, uint64_t*, uint64_t**, uint64_t*);
     typedef const char* (*gerr_fn)(void); typedef void (*gfree_fn)(void*);
     unitigs_fn gpu_unitigs_fn = nullptr; gerr_fn gpu_err_fn = nullptr; gfree_fn gpu_free_fn = nullptr;
+    typedef int (*col_begin_fn)(int, int, const char*, const uint64_t*, uint64_t, void**); typedef int (*col_chunk_fn)(void*, const char*, uint64_t, const uint64_t*, const uint32_t*, uint32_t); typedef int (*col_end_fn)(void*, uint64_t**, uint64_t*, uint64_t**);
+    col_begin_fn gpu_col_begin = nullptr; col_chunk_fn gpu_col_chunk = nullptr; col_end_fn gpu_col_end = nullptr;
     if (gpu) { // the k-mers counted on the device (csrc/hip/rtk_index.hip, through the C ABI of libratatosk_hip.so next to this executable)
         typedef int (*count_fn)(int, int, const char* const*, int, uint32_t, int, uint64_t**, uint64_t*);
         typedef const char* (*err_fn)(void); typedef void (*free_fn)(void*);
@@ -312,6 +314,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         if (!h) { fprintf(stderr, "rtk_build_index: --gpu: cannot load %s (%s)\n", lib.c_str(), dlerror()); return 1; }
         count_fn cf = reinterpret_cast<count_fn>(dlsym(h, "rtk_index_count_kmers")); err_fn ef = reinterpret_cast<err_fn>(dlsym(h, "rtk_last_error")); free_fn ff = reinterpret_cast<free_fn>(dlsym(h, "rtk_free"));
         gpu_unitigs_fn = reinterpret_cast<unitigs_fn>(dlsym(h, "rtk_index_unitigs")); gpu_err_fn = ef; gpu_free_fn = ff;
+        gpu_col_begin = reinterpret_cast<col_begin_fn>(dlsym(h, "rtk_index_colour_begin")); gpu_col_chunk = reinterpret_cast<col_chunk_fn>(dlsym(h, "rtk_index_colour_chunk")); gpu_col_end = reinterpret_cast<col_end_fn>(dlsym(h, "rtk_index_colour_end"));
         if (!cf || !ef || !ff) { fprintf(stderr, "rtk_build_index: --gpu: %s lacks the index entry points\n", lib.c_str()); return 1; }
         std::vector<const char*> fp; for (size_t f = 0; f < in_files.size(); ++f) fp.push_back(in_files[f].c_str());
         uint64_t* sk = nullptr; uint64_t ns = 0;
@@ -441,8 +444,28 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         std::mutex mq; std::condition_variable cv_put, cv_get; std::deque<Chunk*> q; bool done = false; int open_failed = 0;
         const size_t n_u = U.size();
         std::vector<std::vector<uint64_t> > t_cov(n_thr); std::vector<std::vector<std::pair<uint32_t, uint32_t> > > t_ev(n_thr);
+        // --gpu: the reads are handed to the device chunk by chunk (csrc/hip/rtk_index.hip rtk_index_colour_*: the k-mer table of the unitigs in HBM, one lane per
+        // read position); this tool keeps what is its own -- reading, and the numbering of the reads. Every thread fills a chunk of its own.
+        void* col_job = nullptr; std::atomic<int> col_failed(0);
+        if (gpu && gpu_col_begin && gpu_col_chunk && gpu_col_end && sizeof(KM) == 8 && !getenv("RTK_INDEX_HOST_COLOURS") && n_u > 0) {
+            std::vector<uint64_t> off(n_u + 1, 0); for (size_t u = 0; u < n_u; ++u) off[u + 1] = off[u] + U[u].seq.size();
+            std::string pool(off[n_u], 'A');
+            parallel_for(n_u, n_thr, [&](size_t b, size_t e, unsigned) { for (size_t u = b; u < e; ++u) memcpy(&pool[off[u]], U[u].seq.data(), U[u].seq.size()); });
+            if (gpu_col_begin(0, k, pool.data(), off.data(), n_u, &col_job) != 0) { fprintf(stderr, "rtk_build_index: --gpu: colours on the host threads (%s)\n", gpu_err_fn()); col_job = nullptr; }
+        }
+        struct Feed {
+            std::string chars; std::vector<uint64_t> starts; std::vector<uint32_t> ids; void* job; col_chunk_fn fn; std::atomic<int>* failed;
+            void flush() { if (ids.empty()) return; if (fn(job, chars.data(), chars.size(), starts.data(), ids.data(), static_cast<uint32_t>(ids.size())) != 0) *failed = 1; chars.clear(); starts.clear(); ids.clear(); }
+            void add(const char* seq, size_t len, uint32_t id) {
+                if (len + 1 > (60u << 20)) { *failed = 1; return; } // (a read longer than a chunk)
+                if (chars.size() + len + 1 > (60u << 20) || ids.size() >= (2u << 20) || (chars.size() >= (24u << 20))) flush();
+                starts.push_back(chars.size()); ids.push_back(id); chars.append(seq, len); chars.push_back('\n');
+            }
+        };
+        std::vector<Feed> feeds(n_thr);
+        for (unsigned t = 0; t < n_thr; ++t) { feeds[t].job = col_job; feeds[t].fn = gpu_col_chunk; feeds[t].failed = &col_failed; }
         auto work = [&](unsigned t) {
-            std::vector<uint64_t>& cov = t_cov[t]; cov.assign(n_u, 0);
+            std::vector<uint64_t>& cov = t_cov[t]; if (!col_job) cov.assign(n_u, 0);
             std::vector<std::pair<uint32_t, uint32_t> >& ev = t_ev[t];
             while (true) {
                 Chunk* c = nullptr;
@@ -450,6 +473,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                 cv_put.notify_one();
                 for (size_t r = 0; r < c->seq.size(); ++r) {
                     const std::string& seq = c->seq[r]; const uint32_t pair_id = c->id[r];
+                    if (col_job) { feeds[t].add(seq.data(), seq.size(), pair_id); continue; }
                     KM fw = 0; int valid = 0;
                     for (size_t x = 0; x < seq.size(); ++x) {
                         const int b = base2bits(seq[x]);
@@ -471,7 +495,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             // reads sampled from a reference on the fly (common/sample_source.hpp): pair p of a source has the id (pairs of the sources before it) + p
             // (the number of name changes before it: mates share the name "s<p>"); ranges of pairs generated and looked up by all threads
             par_colour = false;
-            for (unsigned t = 0; t < n_thr; ++t) t_cov[t].assign(n_u, 0);
+            if (!col_job) for (unsigned t = 0; t < n_thr; ++t) t_cov[t].assign(n_u, 0);
             uint64_t id_base = 0;
             for (size_t f = 0; f < col_in.size() && !open_failed; ++f) {
                 std::string err; std::shared_ptr<SampleSource> ss = SampleSource::get(col_in[f], &err);
@@ -489,6 +513,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                             ss->pair(p, &m[0], &m[L]);
                             const uint32_t id = static_cast<uint32_t>(id_base + p);
                             for (int mate = 0; mate < 2; ++mate) {
+                                if (col_job) { feeds[t].add(m.data() + mate * L, L, id); continue; }
                                 const char* seq = m.data() + mate * L; KM fw = 0; int valid = 0;
                                 for (uint32_t y = 0; y < L; ++y) {
                                     const int b = base2bits(seq[y]);
@@ -513,7 +538,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             // name; the running sums give every range the id of its first read; the second sweep maps the reads.
             struct RangeInfo { uint32_t changes = 0; uint64_t n_reads = 0; std::string first, last; };
             auto base_name = [](const PackedReads& r, size_t i, const char** p, size_t* n) { *p = r.name(i); *n = r.name_len(i); if (*n > 2 && (*p)[*n - 2] == '/' && ((*p)[*n - 1] == '1' || (*p)[*n - 1] == '2')) *n -= 2; };
-            for (unsigned t = 0; t < n_thr; ++t) t_cov[t].assign(n_u, 0);
+            if (!col_job) for (unsigned t = 0; t < n_thr; ++t) t_cov[t].assign(n_u, 0);
             uint32_t next_id = 0; bool have_prev = false; std::string prev_last;
             for (size_t f = 0; f < col_in.size() && !open_failed; ++f) {
                 PlainChunks pc; if (!pc.open(col_in[f], 32u << 20)) { fprintf(stderr, "rtk_build_index: cannot open %s\n", col_in[f].c_str()); open_failed = 1; break; }
@@ -549,6 +574,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
                               if (x != 0 && (by_read || n != pn || memcmp(p, pp, n) != 0)) ++id;
                               pp = p; pn = n;
                               const char* seq = r.seq(x); const size_t sl = r.seq_len(x);
+                              if (col_job) { feeds[t].add(seq, sl, id); continue; }
                               KM fw = 0; int valid = 0;
                               for (size_t y = 0; y < sl; ++y) {
                                   const int b = base2bits(seq[y]);
@@ -589,8 +615,20 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             cv_get.notify_all();
         }
         for (size_t t = 0; t < th.size(); ++t) th[t].join();
+        if (col_job) { // the distinct (unitig, id) events in sorted order and the coverages, back from the device
+            for (unsigned t = 0; t < n_thr; ++t) feeds[t].flush();
+            uint64_t* ev = nullptr; uint64_t* cv = nullptr; uint64_t n_ev = 0;
+            if (gpu_col_end(col_job, &ev, &n_ev, &cv) != 0 || col_failed) { fprintf(stderr, "rtk_build_index: --gpu: colouring on the device failed (%s)\n", gpu_err_fn()); if (fasta_thread.joinable()) fasta_thread.join(); return 1; }
+            parallel_for(n_u, n_thr, [&](size_t b, size_t e, unsigned) {
+                if (b >= e) return;
+                const uint64_t* p = std::lower_bound(ev, ev + n_ev, static_cast<uint64_t>(b) << 32);
+                for (size_t u = b; u < e; ++u) { U[u].cov = cv[u]; const uint64_t* q = p; while (q < ev + n_ev && (*q >> 32) == u) ++q; U[u].colours.resize(static_cast<size_t>(q - p)); for (size_t i = 0; p + i < q; ++i) U[u].colours[i] = static_cast<uint32_t>(p[i] & 0xFFFFFFFFull); p = q; }
+            });
+            gpu_free_fn(ev); gpu_free_fn(cv);
+        }
         if (open_failed) { if (fasta_thread.joinable()) fasta_thread.join(); return 1; }
         for (unsigned t = 0; t < n_thr; ++t) {
+            if (t_cov[t].size() != n_u) continue; // (--gpu: nothing was counted here)
             for (size_t u = 0; u < n_u; ++u) U[u].cov += t_cov[t][u];
             for (size_t e = 0; e < t_ev[t].size(); ++e) U[t_ev[t][e].first].colours.push_back(t_ev[t][e].second);
             std::vector<uint64_t>().swap(t_cov[t]); std::vector<std::pair<uint32_t, uint32_t> >().swap(t_ev[t]);

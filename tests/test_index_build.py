@@ -32,6 +32,7 @@ def _build(sr, out, k, extra):
     assert r.returncode == 0, r.stderr
     if "--gpu" in extra:  # the chains were walked and written on the device (rtk_index_unitigs), not on the host threads behind a failed call
         assert "rtk_index_unitigs:" in r.stderr and "unitigs on the host threads" not in r.stderr, r.stderr
+        assert "rtk_index_colour:" in r.stderr and "colours on the host threads" not in r.stderr, r.stderr  # ... and the reads mapped there (rtk_index_colour_*)
     return open(out + ".index.k%d.fasta.gz" % k, "rb").read(), open(out + ".index.k%d.rtsk" % k, "rb").read(), r.stderr
 
 
@@ -264,3 +265,22 @@ def test_gpu_index_build_from_gzip_input(tmp_path):
     open(sr + ".cut.gz", "wb").write(cut[:len(cut) // 2])
     r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", sr + ".cut.gz", "-o", os.path.join(tmp, "bad"), "--gpu"], capture_output=True, text=True)
     assert r.returncode != 0 and "gzip" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_gpu_index_colours_with_a_small_event_buffer(tmp_path, monkeypatch):
+    """the device keeps the (unitig, read) events in a buffer that it sorts and thins out when it is half full: a buffer far smaller than the events of
+    the input (many compactions) gives the same files; one that cannot hold the events between two looks is an error, not a loss"""
+    tmp = str(tmp_path)
+    name, args = SETS[0]
+    sr = _simulated(tmp, name, args)
+    a = _build(sr, os.path.join(tmp, "ev_plain"), 31, [])
+    monkeypatch.setenv("RTK_INDEX_THREADS", "16")
+    monkeypatch.setenv("RTK_INDEX_EVENTS", "80000")
+    b = _build(sr, os.path.join(tmp, "ev_gpu"), 31, ["--gpu"])
+    assert a[0] == b[0] and a[1] == b[1]
+    import re
+    assert int(re.search(r"thinned out (\d+) times", b[2]).group(1)) >= 2, b[2]
+    monkeypatch.setenv("RTK_INDEX_EVENTS", "4000")
+    r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", sr, "-o", os.path.join(tmp, "ev_bad"), "--gpu"], capture_output=True, text=True)
+    assert r.returncode != 0 and "events" in r.stderr, r.stderr
