@@ -536,7 +536,7 @@ extern "C" int rtk_index_colour_begin(int device, int k, const char* seq_pool, c
         size_t fr = 0, tot = 0; rtk_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo");
         J->cap = static_cast<uint64_t>(fr) / 10 * 6 / 16; // 60 % of what is left for the events and their sort buffer
         { const char* e = getenv("RTK_INDEX_EVENTS"); if (e) J->cap = strtoull(e, nullptr, 10); }
-        if (J->cap < (1u << 16)) J->cap = 1u << 16;
+        if (J->cap < 1024) J->cap = 1024;
         J->events.alloc(8 * J->cap); J->alt.alloc(8 * J->cap);
         J->t_table = std::chrono::duration<double>(std::chrono::steady_clock::now() - J->t0).count();
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_colour_begin: ") + e.what()); }
