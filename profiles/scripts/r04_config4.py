@@ -39,10 +39,19 @@ fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
 out["index_files_gb"] = {"fasta.gz": round(os.path.getsize(fa) / 1e9, 3), "rtsk": round(os.path.getsize(rt) / 1e9, 3)}
 L = api.load_library()
 h = C.c_void_p()
-t0 = time.time(); rc = L.rtk_graph_load(fa.encode(), rt.encode(), 31, threads, C.byref(h)); out["graph_load_s"] = round(time.time() - t0, 1)
-assert rc == 0, L.rtk_last_error()
-t0 = time.time(); rc = L.rtk_graph_upload(h, 0); out["graph_upload_s"] = round(time.time() - t0, 1)
-assert rc == 0, L.rtk_last_error()
+host_tables = os.environ.get("RTK_HOST_TABLES") == "1"  # (the round-4 runs before the device builder: everything on the host threads)
+os.environ["RTK_LOAD_TRACE"] = "1"
+import io, contextlib
+err_path = os.path.join(wd, "load_trace.txt"); saved_err = os.dup(2); fd = os.open(err_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC); os.dup2(fd, 2)  # (the library reports its sections on stderr)
+try:
+    t0 = time.time(); rc = L.rtk_graph_load2(fa.encode(), rt.encode(), 31, threads, 0 if host_tables else api.RTK_LOAD_DEVICE_TABLES, C.byref(h)); out["graph_load_s"] = round(time.time() - t0, 1)
+    assert rc == 0, L.rtk_last_error()
+    t0 = time.time(); rc = L.rtk_graph_upload(h, 0); out["graph_upload_s"] = round(time.time() - t0, 1)
+    assert rc == 0, L.rtk_last_error()
+finally:
+    os.dup2(saved_err, 2); os.close(fd)
+out["graph_tables"] = "host threads" if host_tables else "device (rtk_graph_tables.hip), inside graph_upload_s"
+out["graph_load_trace"] = [l.strip() for l in open(err_path).read().splitlines() if l.startswith("[rtk load]")]
 g = api.Graph.__new__(api.Graph); g.L, g.k, g.h = L, 31, h
 info = g.info()
 sizes = (C.c_uint64 * L.rtk_graph_n_buffers(None))(); L.rtk_graph_buffer_bytes(h, sizes, len(sizes))
