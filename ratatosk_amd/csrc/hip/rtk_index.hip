@@ -9,6 +9,7 @@
 // by byte ranges of the read files; it is the next candidate for the device.)
 // One-word k-mers (k <= 31) only; the tool keeps its CPU path for k = 63 and for gzip input. Own translation unit: rocPRIM's templates.
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -341,14 +342,22 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
         for (size_t f = 0; f < fl.size(); ++f) { if (rtk::SampleSource::is_spec(fl[f])) { std::string e_; std::shared_ptr<rtk::SampleSource> ss = rtk::SampleSource::get(fl[f], &e_); if (!ss) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: " + e_); total_bytes += 2 * ss->n_bases(); continue; } FILE* fp = fopen(fl[f].c_str(), "rb"); if (!fp) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: cannot open " + fl[f]); fseek(fp, 0, SEEK_END); total_bytes += static_cast<uint64_t>(ftell(fp)); fclose(fp); }
         size_t fr = 0, tot = 0; rtk_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo");
         const uint64_t est_kmers = total_bytes / 2 + (1u << 20); // FASTQ: half of the bytes are bases (gzip input: a multiple of it; the capacity test below catches that)
-        uint64_t cap = static_cast<uint64_t>(fr) / 10 * 4 / 16; // 40 % of the free memory for keys + their sort buffer
+        uint64_t cap = static_cast<uint64_t>(fr) / 10 * 7 / 16; // 70 % of the free memory for keys + their sort buffer (the rest: two chunks of text, the sort's histograms)
         { const char* e = getenv("RTK_INDEX_CAP"); if (e) cap = strtoull(e, nullptr, 10); }
         if (cap < (1u << 20)) cap = 1u << 20;
         uint32_t n_part = static_cast<uint32_t>((est_kmers + cap - 1) / cap); if (n_part < 1) n_part = 1;
         const uint64_t chunk_bytes = 256ull << 20;
         std::vector<uint64_t> solid;
+        // Several partitions = several passes over the reads. The text of the first pass is kept in host memory when it fits into half of what is free there
+        // (a 3 Gb x 30x set: 90 GB of sequences, sampled or parsed ONCE instead of once per partition -- 13 passes at 0.5 Gb/s of host-side sampling were 36 minutes)
+        std::vector<std::string> kept; bool keep_text = false, kept_complete = false;
+        std::vector<size_t> run_start; // solid[run_start[p] ..): the sorted k-mers of partition p
+        const bool trace = getenv("RTK_INDEX_TRACE") != nullptr; const auto t_begin = std::chrono::steady_clock::now();
+        auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+        { const uint64_t avail = static_cast<uint64_t>(sysconf(_SC_AVPHYS_PAGES)) * static_cast<uint64_t>(sysconf(_SC_PAGE_SIZE));
+          const char* e = getenv("RTK_INDEX_KEEP_TEXT"); keep_text = e ? atoi(e) != 0 : (est_kmers + est_kmers / 8 < avail / 2); }
         for (bool done = false; !done;) {
-            done = true; solid.clear();
+            done = true; solid.clear(); run_start.clear(); if (!kept_complete) kept.clear(); // (a restart with more partitions keeps the text of the complete first pass)
             const uint64_t cap_p = n_part == 1 ? std::min<uint64_t>(cap, est_kmers + est_kmers / 8) : cap;
             DevBuf d_keys, d_alt, d_top, d_chars[2], d_sel, d_nsel;
             d_keys.alloc(8 * cap_p); d_alt.alloc(8 * cap_p); d_top.alloc(8); d_nsel.alloc(8);
@@ -370,7 +379,13 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
                         slot ^= 1; off += piece;
                     }
                 };
-                if (!for_each_sequence_chunk(fl, n_threads, chunk_bytes, sink, &err)) { (void)hipStreamDestroy(st[0]); (void)hipStreamDestroy(st[1]); return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: " + err); }
+                if (kept_complete) { for (size_t c = 0; c < kept.size(); ++c) sink(kept[c].data(), kept[c].size()); }
+                else if (keep_text && n_part > 1) {
+                    auto sink_keep = [&](const char* chars, size_t n) { kept.push_back(std::string(chars, n)); sink(chars, n); };
+                    if (!for_each_sequence_chunk(fl, n_threads, chunk_bytes, sink_keep, &err)) { (void)hipStreamDestroy(st[0]); (void)hipStreamDestroy(st[1]); return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: " + err); }
+                    kept_complete = true;
+                }
+                else if (!for_each_sequence_chunk(fl, n_threads, chunk_bytes, sink, &err)) { (void)hipStreamDestroy(st[0]); (void)hipStreamDestroy(st[1]); return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: " + err); }
                 rtk_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
                 unsigned long long n_keys = 0; rtk_check(hipMemcpy(&n_keys, d_top.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
                 if (n_keys > cap_p) { // more k-mers than estimated: more partitions, again
@@ -394,15 +409,36 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
                 rtk_check(rocprim::select(d_tmp.p, sb, vals, flags, other, static_cast<unsigned long long*>(d_nsel.p), static_cast<size_t>(n_keys)), "rocprim::select");
                 rtk_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
                 unsigned long long n_sel = 0; rtk_check(hipMemcpy(&n_sel, d_nsel.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
-                const size_t old = solid.size(); solid.resize(old + n_sel);
+                const size_t old = solid.size(); solid.resize(old + n_sel); run_start.push_back(old);
+                if (trace) fprintf(stderr, "rtk_index_count_kmers: partition %u of %u: %llu k-mers, %llu solid (at %.1f s%s)\n", part + 1, n_part, n_keys, n_sel, since(), kept_complete ? ", text kept in host memory" : "");
                 if (n_sel) rtk_check(hipMemcpy(solid.data() + old, other, 8ull * n_sel, hipMemcpyDeviceToHost), "hipMemcpy");
             }
             (void)hipStreamDestroy(st[0]); (void)hipStreamDestroy(st[1]);
         }
-        if (n_part > 1) std::sort(solid.begin(), solid.end()); // (partitions are sorted each; a k-mer lives in one partition)
         uint64_t* out = static_cast<uint64_t*>(malloc(8 * (solid.size() ? solid.size() : 1)));
         if (!out) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: out of host memory");
-        if (!solid.empty()) memcpy(out, solid.data(), 8 * solid.size());
+        if (run_start.size() <= 1) { if (!solid.empty()) memcpy(out, solid.data(), 8 * solid.size()); }
+        else {
+            // the partitions are sorted each and a k-mer lives in one of them: merged by ranges of the key space, one range per thread (every thread finds its
+            // stretch of every partition by bisection; the ranges before it give it its place in the output)
+            const size_t P = run_start.size(); run_start.push_back(solid.size());
+            const int T = n_threads < 1 ? 1 : (n_threads > 256 ? 256 : n_threads);
+            std::vector<std::vector<size_t> > cut(static_cast<size_t>(T) + 1, std::vector<size_t>(P));
+            const unsigned __int128 span = static_cast<unsigned __int128>(1) << (2 * k);
+            for (int t = 0; t <= T; ++t) for (size_t r = 0; r < P; ++r) {
+                if (t == T) { cut[t][r] = run_start[r + 1]; continue; }
+                const uint64_t v = static_cast<uint64_t>(span * static_cast<unsigned __int128>(t) / static_cast<unsigned __int128>(T));
+                cut[t][r] = static_cast<size_t>(std::lower_bound(solid.begin() + static_cast<std::ptrdiff_t>(run_start[r]), solid.begin() + static_cast<std::ptrdiff_t>(run_start[r + 1]), v) - solid.begin());
+            }
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+                size_t at = 0; for (size_t r = 0; r < P; ++r) at += cut[t][r] - run_start[r];
+                std::vector<size_t> head(cut[t]); const std::vector<size_t>& end = cut[t + 1];
+                for (;;) { size_t best = P; uint64_t bv = 0; for (size_t r = 0; r < P; ++r) if (head[r] < end[r] && (best == P || solid[head[r]] < bv)) { best = r; bv = solid[head[r]]; } if (best == P) break; out[at++] = bv; ++head[best]; }
+            });
+            for (size_t t = 0; t < th.size(); ++t) th[t].join();
+        }
+        if (trace) fprintf(stderr, "rtk_index_count_kmers: %zu solid k-mers from %u partition(s) in %.1f s\n", solid.size(), n_part, since());
         *solid_out = out; *n_solid = solid.size();
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, std::string("rtk_index_count_kmers: ") + e.what()); }
     return RTK_OK;

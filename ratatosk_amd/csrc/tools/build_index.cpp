@@ -633,7 +633,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             for (size_t e = 0; e < t_ev[t].size(); ++e) U[t_ev[t][e].first].colours.push_back(t_ev[t][e].second);
             std::vector<uint64_t>().swap(t_cov[t]); std::vector<std::pair<uint32_t, uint32_t> >().swap(t_ev[t]);
         }
-        for (size_t i = 0; i < U.size(); ++i) { std::sort(U[i].colours.begin(), U[i].colours.end()); U[i].colours.erase(std::unique(U[i].colours.begin(), U[i].colours.end()), U[i].colours.end()); }
+        if (!col_job) parallel_for(U.size(), fast ? n_thr : 1u, [&](size_t b, size_t e, unsigned) { for (size_t i = b; i < e; ++i) { std::sort(U[i].colours.begin(), U[i].colours.end()); U[i].colours.erase(std::unique(U[i].colours.begin(), U[i].colours.end()), U[i].colours.end()); } });
     }
 
     // ---- adjacency, branching, edge bits ----
