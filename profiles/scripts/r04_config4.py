@@ -31,9 +31,12 @@ out["simulate_s"] = round(time.time() - t0, 1); out["ref_fasta_gb"] = round(os.p
 spec = "sample:%s.ref.fa?cov=%g&len=150&insert=400&err=0.005&seed=7" % (pre, sr_cov)
 out["short_reads"] = {"source": spec.replace(wd, "$WD"), "bases": int(sr_cov * ref_mb * 1e6), "fastq_bytes_never_written": int(2 * sr_cov * ref_mb * 1e6 * (150 + 150 + 12) / 300)}
 t0 = time.time()
-r = subprocess.run([os.path.join(bin_dir, "rtk_build_index"), "-s", spec, "-o", pre, "--gpu", "--snps"], stderr=subprocess.PIPE, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1", RTK_INDEX_THREADS=str(threads)))
-out["build_index_s"] = round(time.time() - t0, 1); out["build_index_log"] = r.stderr.strip().splitlines()[-40:]; save()
-assert r.returncode == 0, r.stderr[-2000:]
+idx_log = os.environ.get("RTK_C4_INDEX_LOG", os.path.join(wd, "build_index.log"))  # (written as the tool goes: a run that is cut short still shows where it was)
+with open(idx_log, "w") as lf:
+    r = subprocess.run([os.path.join(bin_dir, "rtk_build_index"), "-s", spec, "-o", pre, "--gpu", "--snps"], stderr=lf, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1", RTK_INDEX_THREADS=str(threads)),
+                       timeout=float(os.environ.get("RTK_C4_INDEX_TIMEOUT", "3000")))
+out["build_index_s"] = round(time.time() - t0, 1); out["build_index_log"] = open(idx_log).read().strip().splitlines()[-60:]; save()
+assert r.returncode == 0, out["build_index_log"][-5:]
 out["box"] = {"host_ram_gb": round(os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9), "cpus": os.cpu_count()}
 fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
 out["index_files_gb"] = {"fasta.gz": round(os.path.getsize(fa) / 1e9, 3), "rtsk": round(os.path.getsize(rt) / 1e9, 3)}
