@@ -275,12 +275,14 @@ def test_gpu_index_colours_with_a_small_event_buffer(tmp_path, monkeypatch):
     name, args = SETS[0]
     sr = _simulated(tmp, name, args)
     a = _build(sr, os.path.join(tmp, "ev_plain"), 31, [])
+    import re
     monkeypatch.setenv("RTK_INDEX_THREADS", "16")
-    monkeypatch.setenv("RTK_INDEX_EVENTS", "80000")
+    b = _build(sr, os.path.join(tmp, "ev_gpu0"), 31, ["--gpu"])  # (default buffer: how many distinct events the set has)
+    n_distinct = int(re.search(r"-> (\d+) distinct", b[2]).group(1))
+    monkeypatch.setenv("RTK_INDEX_EVENTS", str(n_distinct * 3 // 2))  # half of it is less than the distinct events alone: thinned out while the reads still come
     b = _build(sr, os.path.join(tmp, "ev_gpu"), 31, ["--gpu"])
     assert a[0] == b[0] and a[1] == b[1]
-    import re
     assert int(re.search(r"thinned out (\d+) times", b[2]).group(1)) >= 2, b[2]
-    monkeypatch.setenv("RTK_INDEX_EVENTS", "4000")
+    monkeypatch.setenv("RTK_INDEX_EVENTS", str(max(1024, n_distinct // 4)))
     r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", sr, "-o", os.path.join(tmp, "ev_bad"), "--gpu"], capture_output=True, text=True)
     assert r.returncode != 0 and "events" in r.stderr, r.stderr
