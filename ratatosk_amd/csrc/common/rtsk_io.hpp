@@ -24,6 +24,7 @@
 #include <istream>
 #include <ostream>
 #include <stdexcept>
+#include <streambuf>
 #include <string>
 #include <vector>
 
@@ -208,6 +209,33 @@ inline bool rtsk_read_record(std::istream& in, RtskRecord& r) {
     if (n) { in.read(&r.cycles[0], static_cast<std::streamsize>(n)); if (!in.good()) throw std::runtime_error("rtsk: truncated cycles"); }
     return true;
 }
+
+// Length in bytes of the record that starts at p (n bytes left in the file), without decoding its id streams: the loader cuts the file into records with
+// it and decodes them on all threads. 0 at a clean end (n == 0); throws on a record that is cut short.
+inline size_t rtsk_record_bytes(const unsigned char* p, size_t n) {
+    if (n == 0) return 0;
+    size_t at = 0;
+    auto need = [&](size_t bytes) { if (at + bytes > n) throw std::runtime_error("rtsk: truncated record"); };
+    need(32); at += 32; // head k-mer, coverage word, shared word
+    for (int s = 0; s < 4; ++s) { // global, local, ambiguity, haplotype ids
+        need(8); uint64_t w; memcpy(&w, p + at, 8); at += 8;
+        const uint64_t flag = w & 7ULL;
+        if (flag == 3) { const size_t len = static_cast<size_t>(static_cast<uint32_t>(w >> 3)); need(len); at += len; }
+        else if (flag == 0) { // (the checks of tinybitmap_read on the header, so that a stream that is no TinyBitmap is named here instead of mis-cutting the file)
+            if (w != 0) throw std::runtime_error("rtsk: PairID flag 0 with a non-zero word (src/PairID.cpp:1158-1167 writes the bare flag before the TinyBitmap)");
+            need(2); uint16_t header; memcpy(&header, p + at, 2); const size_t sz = header >> 3; const uint32_t mode = header & 0x6u;
+            if (header & 1u) throw std::runtime_error("rtsk: TinyBitmap header has bit 0 set: not the layout assumed in [A8], refusing to guess");
+            if (sz != 0 && (sz < 3 || sz > 4096 || (mode != 0 && mode != 2 && mode != 4))) throw std::runtime_error("rtsk: TinyBitmap header does not match the assumed Bifrost layout [A8]");
+            const size_t len = sz == 0 ? 2 : 2 * sz; if (at + len > n) throw std::runtime_error("rtsk: truncated TinyBitmap payload"); at += len; }
+        else if (flag != 1 && flag != 2) throw std::runtime_error("rtsk: unknown PairID flag");
+    }
+    need(8); uint64_t nc; memcpy(&nc, p + at, 8); at += 8;
+    if (nc > n - at) throw std::runtime_error("rtsk: truncated cycles");
+    return at + static_cast<size_t>(nc);
+}
+
+// an istream over a stretch of memory (the records of a file that was read in one piece)
+struct MemStreamBuf : std::streambuf { MemStreamBuf(const char* b, size_t n) { char* p = const_cast<char*>(b); setg(p, p, p + n); } };
 
 inline void rtsk_write_record(std::ostream& out, const RtskRecord& r) {
     out.write(reinterpret_cast<const char*>(r.head), 16);

@@ -300,34 +300,58 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     std::vector<std::vector<uint32_t> > haps(n); // haplotype ids
     std::vector<std::string> cycles(n); // compact cycles of short-cycle unitigs (UnitigData.hpp:307-327): NUL-terminated strings, concatenated
     {
-        std::ifstream in(rtsk.c_str(), std::ios::binary);
-        if (!in.good()) throw std::runtime_error("cannot open unitig data file " + rtsk);
-        RtskRecord r;
-        while (rtsk_read_record(in, r)) {
-            const std::string head = disk_kmer_to_string(r.head, k);
-            RtkKm code;
-            if (!km_from_string(head.c_str(), k, code)) throw std::runtime_error(".rtsk: bad head k-mer");
-            const uint64_t hit = defer_tables ? find_head(code) : rtk_find_km(gv0, code, nullptr);
-            if (hit == RTK_NO_HIT) throw std::runtime_error(defer_tables ? ".rtsk: head k-mer is not a unitig extremity of the graph (reference aborts too, src/Graph.cpp:773-780)" : ".rtsk: head k-mer not found in the graph (reference aborts too, src/Graph.cpp:773-780)");
-            const UMap um = rtk_unpack_hit(hit);
-            const uint32_t nk = static_cast<uint32_t>(seqs[um.unitig].size()) - k + 1;
-            if (!(um.dist == 0 || um.dist == nk - 1)) throw std::runtime_error(".rtsk: head k-mer is not a unitig extremity");
-            const uint32_t u = um.unitig;
-            if (seen[u]) throw std::runtime_error(".rtsk: two records for one unitig");
-            seen[u] = 1;
-            uint32_t f = static_cast<uint32_t>(r.shared & 0xFFull);
-            if (r.shared & 0x100ull) f |= RTK_F_SHORT_CYCLE;
-            cycles[u] = r.cycles;
-            haps[u].swap(r.hap_ids);
-            if (r.kmcov >> 63) f |= RTK_F_BRANCHING;
-            if (!r.ambiguity_ids.empty()) { f |= RTK_F_AMBIGUITY; ambs[u].swap(r.ambiguity_ids); }
-            flags[u] = f;
-            const uint64_t cov = (r.kmcov & 0x7fffffffull) + ((r.kmcov >> 31) & 0x7fffffffull); // phased + unphased (UnitigData.hpp:371-384)
-            kcov[u] = static_cast<uint32_t>(std::round(static_cast<double>(cov) / static_cast<double>(nk)));
-            locals[u].swap(r.local_ids);
-            if (!r.global_ids.empty()) {
-                std::map<std::vector<uint32_t>, int32_t>::iterator it = gdedup.find(r.global_ids);
-                if (it == gdedup.end()) { it = gdedup.insert(std::make_pair(r.global_ids, static_cast<int32_t>(globals.size()))).first; globals.push_back(r.global_ids); }
+        // the file in one piece, cut into records by their lengths (no id stream is decoded for that), the records decoded on all threads; what depends on
+        // the ORDER of the records -- the numbering of the distinct global sets -- is done afterwards, in file order
+        std::vector<char> file;
+        {
+            FILE* fp = fopen(rtsk.c_str(), "rb");
+            if (!fp) throw std::runtime_error("cannot open unitig data file " + rtsk);
+            fseek(fp, 0, SEEK_END); const long long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+            file.resize(sz > 0 ? static_cast<size_t>(sz) : 0);
+            const size_t got = file.empty() ? 0 : fread(file.data(), 1, file.size(), fp);
+            fclose(fp);
+            if (got != file.size()) throw std::runtime_error("read error on unitig data file " + rtsk);
+        }
+        std::vector<size_t> rec_at;
+        for (size_t at = 0; at < file.size();) { const size_t len = rtsk_record_bytes(reinterpret_cast<const unsigned char*>(file.data()) + at, file.size() - at); rec_at.push_back(at); at += len; }
+        rec_at.push_back(file.size());
+        const size_t n_rec = rec_at.size() - 1;
+        lap("unitig data (.rtsk) in memory");
+        std::vector<uint32_t> rec_u(n_rec, RTK_NONE32); std::vector<std::vector<uint32_t> > rec_global(n_rec);
+        parallel_slices(n_rec, n_threads, [&](size_t lo_r, size_t hi_r, int) {
+            RtskRecord r;
+            for (size_t i = lo_r; i < hi_r; ++i) {
+                MemStreamBuf mb(file.data() + rec_at[i], rec_at[i + 1] - rec_at[i]); std::istream in(&mb);
+                if (!rtsk_read_record(in, r)) throw std::runtime_error("rtsk: empty record");
+                const std::string head = disk_kmer_to_string(r.head, k);
+                RtkKm code;
+                if (!km_from_string(head.c_str(), k, code)) throw std::runtime_error(".rtsk: bad head k-mer");
+                const uint64_t hit = defer_tables ? find_head(code) : rtk_find_km(gv0, code, nullptr);
+                if (hit == RTK_NO_HIT) throw std::runtime_error(defer_tables ? ".rtsk: head k-mer is not a unitig extremity of the graph (reference aborts too, src/Graph.cpp:773-780)" : ".rtsk: head k-mer not found in the graph (reference aborts too, src/Graph.cpp:773-780)");
+                const UMap um = rtk_unpack_hit(hit);
+                const uint32_t nk = static_cast<uint32_t>(seqs[um.unitig].size()) - k + 1;
+                if (!(um.dist == 0 || um.dist == nk - 1)) throw std::runtime_error(".rtsk: head k-mer is not a unitig extremity");
+                const uint32_t u = um.unitig;
+                if (__atomic_exchange_n(&seen[u], static_cast<char>(1), __ATOMIC_RELAXED)) throw std::runtime_error(".rtsk: two records for one unitig");
+                rec_u[i] = u;
+                uint32_t f = static_cast<uint32_t>(r.shared & 0xFFull);
+                if (r.shared & 0x100ull) f |= RTK_F_SHORT_CYCLE;
+                cycles[u] = r.cycles;
+                haps[u].swap(r.hap_ids);
+                if (r.kmcov >> 63) f |= RTK_F_BRANCHING;
+                if (!r.ambiguity_ids.empty()) { f |= RTK_F_AMBIGUITY; ambs[u].swap(r.ambiguity_ids); }
+                flags[u] = f;
+                const uint64_t cov = (r.kmcov & 0x7fffffffull) + ((r.kmcov >> 31) & 0x7fffffffull); // phased + unphased (UnitigData.hpp:371-384)
+                kcov[u] = static_cast<uint32_t>(std::round(static_cast<double>(cov) / static_cast<double>(nk)));
+                locals[u].swap(r.local_ids);
+                rec_global[i].swap(r.global_ids);
+            }
+        });
+        for (size_t i = 0; i < n_rec; ++i) { // identical global sets share one id, numbered in the order of their first record
+            const uint32_t u = rec_u[i];
+            if (!rec_global[i].empty()) {
+                std::map<std::vector<uint32_t>, int32_t>::iterator it = gdedup.find(rec_global[i]);
+                if (it == gdedup.end()) { it = gdedup.insert(std::make_pair(rec_global[i], static_cast<int32_t>(globals.size()))).first; globals.push_back(rec_global[i]); }
                 gid[u] = it->second;
             }
             card[u] = static_cast<uint32_t>(locals[u].size() + (gid[u] >= 0 ? globals[gid[u]].size() : 0));
@@ -340,7 +364,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     goff[0] = loff[n];
     for (size_t g = 0; g < globals.size(); ++g) goff[g + 1] = goff[g] + globals[g].size();
     col.assign(goff[globals.size()] + 1, 0);
-    for (size_t u = 0; u < n; ++u) std::copy(locals[u].begin(), locals[u].end(), col.begin() + loff[u]);
+    parallel_slices(n, n_threads, [&](size_t lo_u, size_t hi_u, int) { for (size_t u = lo_u; u < hi_u; ++u) std::copy(locals[u].begin(), locals[u].end(), col.begin() + loff[u]); });
     for (size_t g = 0; g < globals.size(); ++g) std::copy(globals[g].begin(), globals[g].end(), col.begin() + goff[g]);
     lap("unitig data (.rtsk) read");
     // ---- SNP annotations: get_ambiguity_char() order = (position, IUPAC character) (UnitigData.hpp:557-574) ----
