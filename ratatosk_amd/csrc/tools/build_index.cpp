@@ -420,15 +420,39 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
     }
     fprintf(stderr, "rtk_build_index: %zu unitigs\n", U.size());
     lap("unitigs built");
-    // the unitig FASTA only needs the sequences: with --fast it is compressed (one zlib stream, the same bytes as the plain path writes at the end)
-    // on a thread of its own while the colours, annotations and records are worked out
+    // The unitig FASTA only needs the sequences: with --fast it is compressed on threads of its own while the colours, annotations and records are worked out.
+    // Groups of unitigs of >= 32 MB of text are gzip MEMBERS of their own (level 6; a concatenation of members is an ordinary gzip file: zlib's gzread, Bifrost's
+    // reader, reads through them): compressed side by side here and inflated side by side by the loader (common/mgzip.hpp). The same bytes with any number of threads.
     const std::string fn_fasta = prefix + ".index.k" + std::to_string(k) + ".fasta.gz";
     std::atomic<int> fasta_rc(0);
     auto write_fasta = [&]() {
-        gzFile gz = gzopen(fn_fasta.c_str(), "wb6");
-        if (!gz) { fasta_rc = 1; return; }
-        for (size_t u = 0; u < U.size(); ++u) { gzprintf(gz, ">%zu\n", u); gzwrite(gz, U[u].seq.data(), static_cast<unsigned>(U[u].seq.size())); gzputc(gz, '\n'); }
-        gzclose(gz);
+        std::vector<size_t> cut(1, 0);
+        const size_t member_text = getenv("RTK_FASTA_MEMBER_BYTES") ? static_cast<size_t>(strtoull(getenv("RTK_FASTA_MEMBER_BYTES"), nullptr, 10)) : (32u << 20); // (tests: many small members)
+        { size_t bytes = 0; for (size_t u = 0; u < U.size(); ++u) { bytes += U[u].seq.size() + 12; if (bytes >= member_text) { cut.push_back(u + 1); bytes = 0; } } if (cut.back() != U.size() || cut.size() == 1) cut.push_back(U.size()); }
+        FILE* fp = fopen(fn_fasta.c_str(), "wb");
+        if (!fp) { fasta_rc = 1; return; }
+        const size_t n_groups = cut.size() - 1, nt = fast ? std::min<size_t>(std::max<size_t>(1, n_thr / 4), 16) : 1;
+        auto member = [&](size_t g, std::string& out) -> bool {
+            std::string text; char name[32];
+            for (size_t u = cut[g]; u < cut[g + 1]; ++u) { const int nn = snprintf(name, sizeof(name), ">%zu\n", u); text.append(name, static_cast<size_t>(nn)); text += U[u].seq; text.push_back('\n'); }
+            z_stream zs; memset(&zs, 0, sizeof(zs));
+            if (deflateInit2(&zs, 6, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+            out.resize(deflateBound(&zs, static_cast<uLong>(text.size())) + 64);
+            zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(text.data())); zs.avail_in = static_cast<uInt>(text.size());
+            zs.next_out = reinterpret_cast<Bytef*>(&out[0]); zs.avail_out = static_cast<uInt>(out.size());
+            const int rc = deflate(&zs, Z_FINISH); out.resize(out.size() - zs.avail_out); deflateEnd(&zs);
+            return rc == Z_STREAM_END;
+        };
+        for (size_t g0 = 0; g0 < n_groups && !fasta_rc; g0 += nt) {
+            const size_t g1 = std::min(n_groups, g0 + nt);
+            std::vector<std::string> out(g1 - g0); std::vector<int> ok(g1 - g0, 0);
+            std::vector<std::thread> th;
+            for (size_t g = g0 + 1; g < g1; ++g) th.emplace_back([&, g]() { ok[g - g0] = member(g, out[g - g0]) ? 1 : 0; });
+            ok[0] = member(g0, out[0]) ? 1 : 0;
+            for (size_t t = 0; t < th.size(); ++t) th[t].join();
+            for (size_t g = g0; g < g1; ++g) if (!ok[g - g0] || fwrite(out[g - g0].data(), 1, out[g - g0].size(), fp) != out[g - g0].size()) fasta_rc = 1;
+        }
+        if (fclose(fp) != 0) fasta_rc = 1;
     };
     std::thread fasta_thread;
     if (fast) fasta_thread = std::thread(write_fasta);

@@ -146,3 +146,26 @@ def test_a_repeated_kmer_is_reported(tmp_path):
     g = api.Graph.__new__(api.Graph); g.L, g.k, g.h = api.load_library(None), 31, C.c_void_p()
     rc = g.L.rtk_graph_load2(api._b(fa), api._b(rt), 31, 2, 0, C.byref(g.h))
     assert rc != 0 and "occurs twice" in g.L.rtk_last_error().decode()
+
+
+def test_unitig_fasta_of_several_gzip_members(ds_small, tmp_path, monkeypatch):
+    """the index tool writes the unitig FASTA as gzip members of 32 MB of text each (compressed, and later inflated, side by side): a file of many
+    small members is the same text to zlib / Python's gzip and the same graph to the loader, on one thread and on several"""
+    import gzip, os, subprocess
+    from conftest import BIN
+    monkeypatch.setenv("RTK_FASTA_MEMBER_BYTES", "3000")
+    out = str(tmp_path / "mm")
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", ds_small + ".sr.fq", "-o", out, "--fast", "--global-cov-factor", "1.2"], stderr=subprocess.DEVNULL)
+    raw = open(out + ".index.k31.fasta.gz", "rb").read()
+    assert raw.count(b"\x1f\x8b\x08") >= 5
+    assert gzip.decompress(raw) == gzip.open(ds_small + ".index.k31.fasta.gz", "rb").read()
+    assert open(out + ".index.k31.rtsk", "rb").read() == open(ds_small + ".index.k31.rtsk", "rb").read()
+    subprocess.check_call([os.path.join(BIN, "rtk_build_index"), "-s", ds_small + ".sr.fq", "-o", out + "1", "--global-cov-factor", "1.2"], stderr=subprocess.DEVNULL)  # plain path, one thread: the same members
+    assert open(out + "1.index.k31.fasta.gz", "rb").read() == raw
+    for threads in (1, 8):
+        g = api.Graph.__new__(api.Graph); g.L, g.k, g.h = api.load_library(None), 31, C.c_void_p()
+        g._check(g.L.rtk_graph_load2(api._b(out + ".index.k31.fasta.gz"), api._b(out + ".index.k31.rtsk"), 31, threads, 0, C.byref(g.h)))
+        ref = _load(ds_small, 31, False)
+        for name in _BUFS:
+            if name not in ("ht", "hx"):
+                assert (_host_buffer(g, name) == _host_buffer(ref, name)).all(), name
