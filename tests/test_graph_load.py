@@ -169,3 +169,28 @@ def test_unitig_fasta_of_several_gzip_members(ds_small, tmp_path, monkeypatch):
         for name in _BUFS:
             if name not in ("ht", "hx"):
                 assert (_host_buffer(g, name) == _host_buffer(ref, name)).all(), name
+
+
+@pytest.mark.gpu
+def test_gpu_resident_graph_moved_into_caller_buffers(ds_small):
+    """what rank 0 of a multi-GPU job does before it broadcasts (ratatosk_amd/dist.py): the graph is loaded and its tables are built in the library's own
+    HBM, then every flat buffer is moved into a torch tensor of its size; the graph answers as before and nothing is freed twice"""
+    import torch
+    torch.zeros(1, device="cuda:0")
+    dev = _load(ds_small, 31, True, upload=True)
+    useq, uoff = _host_buffer(dev, "useq"), _host_buffer(dev, "uoff")
+    u = int(len(uoff) // 3); s = "".join("ACGT"[(int(useq[p >> 5]) >> (2 * (p & 31))) & 3] for p in range(int(uoff[u]), int(uoff[u + 1])))
+    before = dev.lookup_exact(s)
+    n_buf = len(_BUFS); sizes = (C.c_uint64 * n_buf)()
+    dev._check(dev.L.rtk_graph_buffer_bytes(dev.h, sizes, n_buf))
+    tensors = []
+    for i in range(n_buf):
+        tensors.append(torch.empty(max(8, int(sizes[i])), dtype=torch.uint8, device="cuda:0"))
+        dev._check(dev.L.rtk_graph_move_buffer(dev.h, i, C.c_void_p(tensors[i].data_ptr()), max(8, int(sizes[i]))))
+    torch.cuda.synchronize()
+    assert dev.lookup_exact(s) == before == [(u << 33) | (i << 1) | 1 for i in range(len(s) - 31 + 1)]
+    p, b = C.c_void_p(), C.c_uint64()
+    dev._check(dev.L.rtk_graph_buffer(dev.h, _BUFS.index("ht"), C.byref(p), C.byref(b)))
+    assert p.value == tensors[_BUFS.index("ht")].data_ptr()
+    dev.close()  # (the tensors outlive the graph: the library must not free them)
+    assert int(tensors[0][:8].sum().item()) >= 0
