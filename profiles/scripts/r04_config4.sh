@@ -6,7 +6,7 @@ set -u
 export TMPDIR=/tmp RTK_C4_DIR=/tmp/c4
 OUT=$PWD/gpurun_out/r04_config4; mkdir -p $OUT $RTK_C4_DIR
 REF_MB=${1:-3000}; SR_COV=${2:-30}; TICKETS=${3:-6}
-( time RTK_C4_KEEP=1 RTK_C4_INDEX_LOG=$OUT/build_index.log RTK_C4_INDEX_TIMEOUT=1800 RTK_C4_OUT=$OUT/r04_config4_dry_run.json timeout 2700 python profiles/scripts/r04_config4.py $REF_MB $SR_COV 128 $TICKETS > $OUT/c4_full.log 2>&1 ) 2> $OUT/c4_full_time.txt
+( time RTK_C4_KEEP=1 RTK_C4_INDEX_LOG=$OUT/build_index.log RTK_C4_INDEX_TIMEOUT=${RTK_C4_INDEX_TIMEOUT:-1200} RTK_C4_OUT=$OUT/r04_config4_dry_run.json timeout 2700 python profiles/scripts/r04_config4.py $REF_MB $SR_COV 128 $TICKETS > $OUT/c4_full.log 2>&1 ) 2> $OUT/c4_full_time.txt
 tail -3 $OUT/c4_full.log | cut -c1-600; tail -3 $OUT/c4_full_time.txt; tail -30 $OUT/build_index.log
 [ -f /tmp/c4/c4_keep/c4.index.k31.rtsk ] || exit 1
 P=$OUT/prof; mkdir -p $P

@@ -341,6 +341,7 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
         uint64_t total_bytes = 0;
         for (size_t f = 0; f < fl.size(); ++f) { if (rtk::SampleSource::is_spec(fl[f])) { std::string e_; std::shared_ptr<rtk::SampleSource> ss = rtk::SampleSource::get(fl[f], &e_); if (!ss) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: " + e_); total_bytes += 2 * ss->n_bases(); continue; } FILE* fp = fopen(fl[f].c_str(), "rb"); if (!fp) return rtk_fail(RTK_ERR_IO, "rtk_index_count_kmers: cannot open " + fl[f]); fseek(fp, 0, SEEK_END); total_bytes += static_cast<uint64_t>(ftell(fp)); fclose(fp); }
         size_t fr = 0, tot = 0; rtk_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo");
+        if (getenv("RTK_INDEX_TRACE")) fprintf(stderr, "rtk_index_count_kmers: inputs sized (%.1f GB), %.1f GB of device memory free\n", total_bytes / 1e9, fr / 1e9);
         const uint64_t est_kmers = total_bytes / 2 + (1u << 20); // FASTQ: half of the bytes are bases (gzip input: a multiple of it; the capacity test below catches that)
         uint64_t cap = static_cast<uint64_t>(fr) / 10 * 7 / 16; // 70 % of the free memory for keys + their sort buffer (the rest: two chunks of text, the sort's histograms)
         { const char* e = getenv("RTK_INDEX_CAP"); if (e) cap = strtoull(e, nullptr, 10); }
@@ -366,8 +367,11 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
             hipStream_t st[2]; rtk_check(hipStreamCreate(&st[0]), "hipStreamCreate"); rtk_check(hipStreamCreate(&st[1]), "hipStreamCreate");
             for (uint32_t part = 0; part < n_part && done; ++part) {
                 rtk_check(hipMemset(d_top.p, 0, 8), "hipMemset");
-                int slot = 0; std::string err;
-                auto sink = [&](const char* chars, size_t n) { // one chunk: pinned copy, H2D and the k-mer kernel on the slot's stream (the other slot's work overlaps the next parse)
+                int slot = 0; std::string err; uint64_t n_sunk = 0, b_sunk = 0;
+                if (trace) fprintf(stderr, "rtk_index_count_kmers: partition %u of %u starts at %.1f s (room for %llu k-mers)\n", part + 1, n_part, since(), static_cast<unsigned long long>(cap_p));
+                auto sink = [&](const char* chars, size_t n) {
+                    if (trace && (++n_sunk & 31u) == 0) fprintf(stderr, "rtk_index_count_kmers:   %llu chunks, %.1f GB of text at %.1f s\n", static_cast<unsigned long long>(n_sunk), b_sunk / 1e9, since());
+                    b_sunk += n; // one chunk: pinned copy, H2D and the k-mer kernel on the slot's stream (the other slot's work overlaps the next parse)
                     for (size_t off = 0; off < n;) {
                         const size_t piece = std::min<size_t>(n - off, chunk_bytes + (64u << 20));
                         rtk_check(hipStreamSynchronize(st[slot]), "hipStreamSynchronize");
@@ -392,11 +396,13 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
                     n_part = static_cast<uint32_t>((n_keys * static_cast<uint64_t>(n_part) + cap - 1) / cap) + 1; done = false; break;
                 }
                 if (n_keys == 0) continue;
+                if (trace) fprintf(stderr, "rtk_index_count_kmers:   %llu k-mers on the device at %.1f s; sorting\n", n_keys, since());
                 // sort, then the first key of every run of >= min_count
                 rocprim::double_buffer<uint64_t> db(static_cast<uint64_t*>(d_keys.p), static_cast<uint64_t*>(d_alt.p));
                 size_t tb = 0; rtk_check(rocprim::radix_sort_keys(nullptr, tb, db, static_cast<size_t>(n_keys), 0, 2 * k), "rocprim::radix_sort_keys");
                 DevBuf d_tmp; d_tmp.alloc(tb);
                 rtk_check(rocprim::radix_sort_keys(d_tmp.p, tb, db, static_cast<size_t>(n_keys), 0, 2 * k), "rocprim::radix_sort_keys");
+                if (trace) { rtk_check(hipDeviceSynchronize(), "radix sort"); fprintf(stderr, "rtk_index_count_kmers:   sorted at %.1f s\n", since()); }
                 const uint64_t* sorted = db.current(); uint64_t* other = db.alternate();
                 SolidHead pred; pred.keys = sorted; pred.n = n_keys; pred.min_count = min_count;
                 KeyAt at; at.keys = sorted;
