@@ -28,6 +28,7 @@ t0 = time.time()
 subprocess.check_call([os.path.join(bin_dir, "rtk_simulate"), "--prefix", pre, "--seed", "5", "--ref-len", str(ref_mb * 1000000), "--het", "0.001", "--repeat-frac", "0.03", "--sr-cov", "0",
                        "--lr-cov", "%.5f" % (lr_bases / (ref_mb * 1e6)), "--lr-len", "8000", "--lr-profile", "ont", "--lr-err", "0.07", "--lr-truth"], stderr=subprocess.DEVNULL)
 out["simulate_s"] = round(time.time() - t0, 1); out["ref_fasta_gb"] = round(os.path.getsize(pre + ".ref.fa") / 1e9, 2); save()
+assert abs(os.path.getsize(pre + ".ref.fa") - 2 * ref_mb * 1e6) < 0.01 * 2 * ref_mb * 1e6, "reference FASTA of an unexpected size"
 spec = "sample:%s.ref.fa?cov=%g&len=150&insert=400&err=0.005&seed=7" % (pre, sr_cov)
 out["short_reads"] = {"source": spec.replace(wd, "$WD"), "bases": int(sr_cov * ref_mb * 1e6), "fastq_bytes_never_written": int(2 * sr_cov * ref_mb * 1e6 * (150 + 150 + 12) / 300)}
 t0 = time.time()

@@ -11,10 +11,10 @@ tail -3 $OUT/c4_full.log | cut -c1-600; tail -3 $OUT/c4_full_time.txt; tail -30 
 [ -f /tmp/c4/c4_keep/c4.index.k31.rtsk ] || exit 1
 P=$OUT/prof; mkdir -p $P
 STEPS="python profiles/scripts/r04_config4_steps.py 3 128"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_serial -o stats -- $STEPS > $P/stats.log 2> $P/stats.err
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -o fetch -- $STEPS > /dev/null 2> $P/fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -o write -- $STEPS > /dev/null 2> $P/write.err
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $P/sq -o sq -- $STEPS > /dev/null 2> $P/sq.err
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_serial -o stats -- $STEPS > $P/stats.log 2> $P/stats.err
+timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -o fetch -- $STEPS > /dev/null 2> $P/fetch.err
+timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -o write -- $STEPS > /dev/null 2> $P/write.err
+timeout 420 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $P/sq -o sq -- $STEPS > /dev/null 2> $P/sq.err
 mkdir -p $P/stats $P/calib_fetch $P/calib_write
 python profiles/scripts/summarise.py $P $OUT r04_config4 > $P/summarise.log 2>&1
 cat $P/stats.log | tail -2; ls -la $OUT

@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
     {
         FILE* f = fopen((o.prefix + ".ref.fa").c_str(), "w");
         if (!f) { perror("rtk_simulate: ref"); return 1; }
-        for (size_t h = 0; h < haps.size(); ++h) fprintf(f, ">hap%zu\n%s\n", h, haps[h].c_str());
+        for (size_t h = 0; h < haps.size(); ++h) { fprintf(f, ">hap%zu\n", h); fwrite(haps[h].data(), 1, haps[h].size(), f); fputc('\n', f); } // (not "%s": printf counts in int, a 3 Gb haplotype came out as 2^32 bytes)
         fclose(f);
     }
 
