@@ -33,11 +33,35 @@ spec = "sample:%s.ref.fa?cov=%g&len=150&insert=400&err=0.005&seed=7" % (pre, sr_
 out["short_reads"] = {"source": spec.replace(wd, "$WD"), "bases": int(sr_cov * ref_mb * 1e6), "fastq_bytes_never_written": int(2 * sr_cov * ref_mb * 1e6 * (150 + 150 + 12) / 300)}
 t0 = time.time()
 idx_log = os.environ.get("RTK_C4_INDEX_LOG", os.path.join(wd, "build_index.log"))  # (written as the tool goes: a run that is cut short still shows where it was)
+# The container's control group caps host memory (300 GiB on the GPU boxes of this pool, whatever the machine has): its use is sampled while the tool runs, the
+# tool is stopped before the limit is (a box that runs out of memory is lost), and the peak goes into the report.
+def cgroup(name):
+    try:
+        return int(open("/sys/fs/cgroup/" + name).read().strip())
+    except Exception:
+        return None
+mem_max = cgroup("memory.max")
+snps = os.environ.get("RTK_C4_SNPS", "1" if ref_mb < 2500 else "0") == "1"
+if not snps:
+    out["snp_annotations"] = "left out at this size: the tool's 1-substitution neighbour index (two sorted views of all oriented k-mers, ~100 GB at 3 Gb) does not fit beside its k-mer table (137 GB) under the container's %s GB host-memory limit; the 300 Mb run of the gpu tier has them" % (round(mem_max / 1e9) if mem_max else "?")
+peak = [0]
 with open(idx_log, "w") as lf:
-    r = subprocess.run([os.path.join(bin_dir, "rtk_build_index"), "-s", spec, "-o", pre, "--gpu", "--snps"], stderr=lf, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1", RTK_INDEX_THREADS=str(threads)),
-                       timeout=float(os.environ.get("RTK_C4_INDEX_TIMEOUT", "3000")))
-out["build_index_s"] = round(time.time() - t0, 1); out["build_index_log"] = open(idx_log).read().strip().splitlines()[-60:]; save()
-assert r.returncode == 0, out["build_index_log"][-5:]
+    pr = subprocess.Popen([os.path.join(bin_dir, "rtk_build_index"), "-s", spec, "-o", pre, "--gpu"] + (["--snps"] if snps else []), stderr=lf, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1", RTK_INDEX_THREADS=str(threads)))
+    deadline = time.time() + float(os.environ.get("RTK_C4_INDEX_TIMEOUT", "3000")); why = None
+    while pr.poll() is None:
+        time.sleep(1.0)
+        cur = None
+        try:  # anonymous memory: what cannot be given back (the page cache of the reference and of the output files can)
+            cur = [int(l.split()[1]) for l in open("/sys/fs/cgroup/memory.stat") if l.startswith("anon ")][0]
+        except Exception:
+            cur = cgroup("memory.current")
+        if cur: peak[0] = max(peak[0], cur)
+        if mem_max and cur and cur > 0.85 * mem_max: why = "host memory at %.0f of %.0f GB" % (cur / 1e9, mem_max / 1e9)
+        if time.time() > deadline: why = "time limit"
+        if why:
+            pr.kill(); pr.wait(); break
+out["build_index_s"] = round(time.time() - t0, 1); out["build_index_log"] = open(idx_log).read().strip().splitlines()[-60:]; out["build_index_peak_host_gb"] = round(peak[0] / 1e9, 1); out["host_memory_limit_gb"] = round(mem_max / 1e9, 1) if mem_max else None; save()
+assert why is None and pr.returncode == 0, (why, out["build_index_log"][-5:])
 out["box"] = {"host_ram_gb": round(os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9), "cpus": os.cpu_count()}
 fa, rt = pre + ".index.k31.fasta.gz", pre + ".index.k31.rtsk"
 out["index_files_gb"] = {"fasta.gz": round(os.path.getsize(fa) / 1e9, 3), "rtsk": round(os.path.getsize(rt) / 1e9, 3)}

@@ -355,8 +355,13 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
         std::vector<size_t> run_start; // solid[run_start[p] ..): the sorted k-mers of partition p
         const bool trace = getenv("RTK_INDEX_TRACE") != nullptr; const auto t_begin = std::chrono::steady_clock::now();
         auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
-        { const uint64_t avail = static_cast<uint64_t>(sysconf(_SC_AVPHYS_PAGES)) * static_cast<uint64_t>(sysconf(_SC_PAGE_SIZE));
-          const char* e = getenv("RTK_INDEX_KEEP_TEXT"); keep_text = e ? atoi(e) != 0 : (est_kmers + est_kmers / 8 < avail / 2); }
+        { uint64_t avail = static_cast<uint64_t>(sysconf(_SC_AVPHYS_PAGES)) * static_cast<uint64_t>(sysconf(_SC_PAGE_SIZE));
+          { // a container's memory limit is not what sysconf reports: what is left under the control group's limit, if there is one
+            unsigned long long lim = 0, cur = 0; bool have = false;
+            if (FILE* f1 = fopen("/sys/fs/cgroup/memory.max", "r")) { have = fscanf(f1, "%llu", &lim) == 1; fclose(f1); if (have) { if (FILE* f2 = fopen("/sys/fs/cgroup/memory.current", "r")) { if (fscanf(f2, "%llu", &cur) != 1) cur = 0; fclose(f2); } } }
+            if (have && lim > cur && lim - cur < avail) avail = lim - cur; }
+          const char* e = getenv("RTK_INDEX_KEEP_TEXT"); keep_text = e ? atoi(e) != 0 : (est_kmers + est_kmers / 8 < avail / 2); // (the caller's own tables come on top of it later: half of what is left, no more)
+          if (trace) fprintf(stderr, "rtk_index_count_kmers: %.1f GB of host memory to be had, text %s\n", avail / 1e9, keep_text ? "kept across partitions" : "read again for every partition"); }
         for (bool done = false; !done;) {
             done = true; solid.clear(); run_start.clear(); if (!kept_complete) kept.clear(); // (a restart with more partitions keeps the text of the complete first pass)
             const uint64_t cap_p = n_part == 1 ? std::min<uint64_t>(cap, est_kmers + est_kmers / 8) : cap;

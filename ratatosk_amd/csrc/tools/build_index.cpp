@@ -354,7 +354,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
         std::sort(solid.begin(), solid.end());
     }
     lap("k-mers counted");
-    size_t cap = 16; while (cap * 6 < solid.size() * 10 + 16) cap <<= 1; cap <<= 1;
+    size_t cap = 16; while (cap * 6 < solid.size() * 10 + 16) cap <<= 1; if (solid.size() < (1ull << 30)) cap <<= 1; // (load <= 0.6; below 2^30 k-mers half of that: a 3 Gb genome's table is 137 GB instead of 275)
     KTable<KM> km(cap); // canonical solid k-mer -> 0 (unvisited) or (unitig+1)<<32 | offset<<1 | fw_flag
     if (fast) fast_table_fill(km, solid, n_thr);
     else for (size_t i = 0; i < solid.size(); ++i) *km.slot(solid[i], true) = 0;
