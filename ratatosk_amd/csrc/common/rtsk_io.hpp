@@ -235,7 +235,7 @@ inline size_t rtsk_record_bytes(const unsigned char* p, size_t n) {
 }
 
 // an istream over a stretch of memory (the records of a file that was read in one piece)
-struct MemStreamBuf : std::streambuf { MemStreamBuf(const char* b, size_t n) { char* p = const_cast<char*>(b); setg(p, p, p + n); } };
+struct MemStreamBuf : std::streambuf { MemStreamBuf() {} MemStreamBuf(const char* b, size_t n) { reset(b, n); } void reset(const char* b, size_t n) { char* p = const_cast<char*>(b); setg(p, p, p + n); } };
 
 inline void rtsk_write_record(std::ostream& out, const RtskRecord& r) {
     out.write(reinterpret_cast<const char*>(r.head), 16);

@@ -15,6 +15,11 @@
 #include <functional>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../common/fastx.hpp"
 #include "../common/kmer.hpp"
 #include "../common/rtsk_io.hpp"
@@ -302,26 +307,26 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     {
         // the file in one piece, cut into records by their lengths (no id stream is decoded for that), the records decoded on all threads; what depends on
         // the ORDER of the records -- the numbering of the distinct global sets -- is done afterwards, in file order
-        std::vector<char> file;
+        struct Mapped { const char* p = nullptr; size_t n = 0; int fd = -1; ~Mapped() { if (p && n) munmap(const_cast<char*>(p), n); if (fd >= 0) ::close(fd); } } mf; // (mapped, not read: no second copy of a 10 GB file)
         {
-            FILE* fp = fopen(rtsk.c_str(), "rb");
-            if (!fp) throw std::runtime_error("cannot open unitig data file " + rtsk);
-            fseek(fp, 0, SEEK_END); const long long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
-            file.resize(sz > 0 ? static_cast<size_t>(sz) : 0);
-            const size_t got = file.empty() ? 0 : fread(file.data(), 1, file.size(), fp);
-            fclose(fp);
-            if (got != file.size()) throw std::runtime_error("read error on unitig data file " + rtsk);
+            mf.fd = ::open(rtsk.c_str(), O_RDONLY);
+            if (mf.fd < 0) throw std::runtime_error("cannot open unitig data file " + rtsk);
+            struct stat st; if (fstat(mf.fd, &st) != 0) throw std::runtime_error("cannot stat unitig data file " + rtsk);
+            mf.n = static_cast<size_t>(st.st_size);
+            if (mf.n) { void* q = mmap(nullptr, mf.n, PROT_READ, MAP_PRIVATE, mf.fd, 0); if (q == MAP_FAILED) { mf.n = 0; throw std::runtime_error("cannot map unitig data file " + rtsk); } mf.p = static_cast<const char*>(q); madvise(q, mf.n, MADV_WILLNEED); }
         }
+        const char* file = mf.p; const size_t file_size = mf.n;
         std::vector<size_t> rec_at;
-        for (size_t at = 0; at < file.size();) { const size_t len = rtsk_record_bytes(reinterpret_cast<const unsigned char*>(file.data()) + at, file.size() - at); rec_at.push_back(at); at += len; }
-        rec_at.push_back(file.size());
+        for (size_t at = 0; at < file_size;) { const size_t len = rtsk_record_bytes(reinterpret_cast<const unsigned char*>(file) + at, file_size - at); rec_at.push_back(at); at += len; }
+        rec_at.push_back(file_size);
         const size_t n_rec = rec_at.size() - 1;
         lap("unitig data (.rtsk) in memory");
         std::vector<uint32_t> rec_u(n_rec, RTK_NONE32); std::vector<std::vector<uint32_t> > rec_global(n_rec);
         parallel_slices(n_rec, n_threads, [&](size_t lo_r, size_t hi_r, int) {
             RtskRecord r;
+            MemStreamBuf mb; std::istream in(&mb); // (one stream per thread: constructing a std::istream takes a reference on the global locale, a contended atomic with 128 threads doing it per record)
             for (size_t i = lo_r; i < hi_r; ++i) {
-                MemStreamBuf mb(file.data() + rec_at[i], rec_at[i + 1] - rec_at[i]); std::istream in(&mb);
+                mb.reset(file + rec_at[i], rec_at[i + 1] - rec_at[i]); in.clear();
                 if (!rtsk_read_record(in, r)) throw std::runtime_error("rtsk: empty record");
                 const std::string head = disk_kmer_to_string(r.head, k);
                 RtkKm code;
