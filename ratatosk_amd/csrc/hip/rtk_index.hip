@@ -347,7 +347,9 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
         { const char* e = getenv("RTK_INDEX_CAP"); if (e) cap = strtoull(e, nullptr, 10); }
         if (cap < (1u << 20)) cap = 1u << 20;
         uint32_t n_part = static_cast<uint32_t>((est_kmers + cap - 1) / cap); if (n_part < 1) n_part = 1;
-        const uint64_t chunk_bytes = 256ull << 20;
+        uint64_t chunk_bytes = 256ull << 20;
+        { const char* e = getenv("RTK_INDEX_CHUNK"); if (e && strtoull(e, nullptr, 10) >= 1024) chunk_bytes = strtoull(e, nullptr, 10); } // developer / tests: small chunks, so that long records are cut into pieces
+        const uint64_t chunk_slack = std::min<uint64_t>(64ull << 20, chunk_bytes / 4);
         std::vector<uint64_t> solid;
         // Several partitions = several passes over the reads. The text of the first pass is kept in host memory when it fits into half of what is free there
         // (a 3 Gb x 30x set: 90 GB of sequences, sampled or parsed ONCE instead of once per partition -- 13 passes at 0.5 Gb/s of host-side sampling were 36 minutes)
@@ -367,8 +369,8 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
             const uint64_t cap_p = n_part == 1 ? std::min<uint64_t>(cap, est_kmers + est_kmers / 8) : cap;
             DevBuf d_keys, d_alt, d_top, d_chars[2], d_sel, d_nsel;
             d_keys.alloc(8 * cap_p); d_alt.alloc(8 * cap_p); d_top.alloc(8); d_nsel.alloc(8);
-            d_chars[0].alloc(chunk_bytes + (64u << 20)); d_chars[1].alloc(chunk_bytes + (64u << 20));
-            PinBuf h_chars[2]; h_chars[0].alloc(chunk_bytes + (64u << 20)); h_chars[1].alloc(chunk_bytes + (64u << 20));
+            d_chars[0].alloc(chunk_bytes + chunk_slack); d_chars[1].alloc(chunk_bytes + chunk_slack);
+            PinBuf h_chars[2]; h_chars[0].alloc(chunk_bytes + chunk_slack); h_chars[1].alloc(chunk_bytes + chunk_slack);
             hipStream_t st[2]; rtk_check(hipStreamCreate(&st[0]), "hipStreamCreate"); rtk_check(hipStreamCreate(&st[1]), "hipStreamCreate");
             for (uint32_t part = 0; part < n_part && done; ++part) {
                 rtk_check(hipMemset(d_top.p, 0, 8), "hipMemset");
@@ -378,14 +380,14 @@ extern "C" int rtk_index_count_kmers(int device, int k, const char* const* files
                     if (trace && (++n_sunk & 31u) == 0) fprintf(stderr, "rtk_index_count_kmers:   %llu chunks, %.1f GB of text at %.1f s\n", static_cast<unsigned long long>(n_sunk), b_sunk / 1e9, since());
                     b_sunk += n; // one chunk: pinned copy, H2D and the k-mer kernel on the slot's stream (the other slot's work overlaps the next parse)
                     for (size_t off = 0; off < n;) {
-                        const size_t piece = std::min<size_t>(n - off, chunk_bytes + (64u << 20));
+                        const size_t piece = std::min<size_t>(n - off, chunk_bytes + chunk_slack);
                         rtk_check(hipStreamSynchronize(st[slot]), "hipStreamSynchronize");
                         memcpy(h_chars[slot].p, chars + off, piece);
                         rtk_check(hipMemcpyAsync(d_chars[slot].p, h_chars[slot].p, piece, hipMemcpyHostToDevice, st[slot]), "hipMemcpyAsync");
                         hipLaunchKernelGGL(k_index_kmers, dim3(4096), dim3(256), 0, st[slot], static_cast<const char*>(d_chars[slot].p), static_cast<uint64_t>(piece), k, part, n_part,
                                            static_cast<uint64_t*>(d_keys.p), static_cast<unsigned long long*>(d_top.p), cap_p);
                         rtk_check(hipGetLastError(), "kernel launch (k_index_kmers)");
-                        slot ^= 1; off += piece;
+                        slot ^= 1; off += (off + piece < n) ? piece - static_cast<size_t>(k - 1) : piece; // a cut inside a sequence: the next piece starts k - 1 characters back, so that every window is seen once
                     }
                 };
                 if (kept_complete) { for (size_t c = 0; c < kept.size(); ++c) sink(kept[c].data(), kept[c].size()); }

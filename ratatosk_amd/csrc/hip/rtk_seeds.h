@@ -870,29 +870,52 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
     // 64 windows per step. Windows holding several raw hits are first sorted by k-mer and stripped of duplicates in place (one
     // window at a time, the whole wave on it); then every lane appends the hits of its own window at its prefix-sum offset.
     uint32_t nv = 0; bool ovf = false;
-    // (the descriptors of four chunks are fetched together and a chunk without raw hits -- most of them -- costs nothing more: this loop runs
-    // 1 500 times for a 100 kb read, on the one wave that owns it)
-    for (uint32_t c4 = 0; c4 < nwin && !ovf; c4 += 4 * RTK_WAVE) {
-      uint64_t d4[4];
-      for (int x4 = 0; x4 < 4; ++x4) { const uint32_t xx = c4 + static_cast<uint32_t>(x4) * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); d4[x4] = (xx < nwin) ? bv.wdesc[base + xx] : 0ull; }
-      for (int x4 = 0; x4 < 4 && !ovf; ++x4) {
-        const uint32_t c0 = c4 + static_cast<uint32_t>(x4) * RTK_WAVE;
-        if (c0 >= nwin) break;
-        const uint32_t x = c0 + static_cast<uint32_t>(rtk_lane());
-        const uint64_t d = d4[x4];
-        if (rtk_ballot((d & 0xFFFFFFull) != 0) == 0) continue;
-        const uint64_t off = d >> 24; const uint32_t cnt = static_cast<uint32_t>(d & 0xFFFFFFull);
-        uint32_t ucnt = cnt ? 1u : 0u;
-        uint64_t multi = rtk_ballot(cnt >= 2);
-        while (multi) {
+    // This loop runs on the ONE wave that owns the read, 1 500 chunks for a 100 kb read, and the launch lasts as long as its slowest read: nothing in it
+    // may wait for memory once per chunk. (1) The descriptors of RTK_GQ chunks are fetched together, those of the next step BEFORE this step's chunks are
+    // worked on; a chunk without raw hits -- most of them -- costs nothing more. (2) The hits of the next window with several raw hits are fetched before
+    // the current one is ranked and written back. (3) A lane appends the hits of its window four at a time (four 16-byte loads in flight, then the stores).
+    // The pointers are read from the launch's views once: behind every store the compiler would fetch them again.
+#ifdef RTK_SIM
+#define RTK_GQ 2
+#else
+#define RTK_GQ 8
+#endif
+    {
+      const uint64_t* const wdesc = bv.wdesc.get() + base; uint64_t* const ipool = bv.ipool.get();
+      uint32_t* const vpos = sc.vpos.get(); uint64_t* const vcode = sc.vcode.get(); uint64_t* const vhit = sc.vhit.get(); const uint32_t v_cap = sc.v_cap;
+      const uint32_t lane_u = static_cast<uint32_t>(rtk_lane());
+      uint64_t dn[RTK_GQ];
+      for (int q = 0; q < RTK_GQ; ++q) { const uint32_t xx = static_cast<uint32_t>(q) * RTK_WAVE + lane_u; dn[q] = (xx < nwin) ? wdesc[xx] : 0ull; }
+      for (uint32_t c4 = 0; c4 < nwin && !ovf; c4 += RTK_GQ * RTK_WAVE) {
+        uint64_t d4[RTK_GQ];
+        for (int q = 0; q < RTK_GQ; ++q) d4[q] = dn[q];
+        { const uint32_t cn = c4 + RTK_GQ * RTK_WAVE; // (1)
+          if (cn < nwin) for (int q = 0; q < RTK_GQ; ++q) { const uint32_t xx = cn + static_cast<uint32_t>(q) * RTK_WAVE + lane_u; dn[q] = (xx < nwin) ? wdesc[xx] : 0ull; } }
+        for (int x4 = 0; x4 < RTK_GQ && !ovf; ++x4) {
+          const uint32_t c0 = c4 + static_cast<uint32_t>(x4) * RTK_WAVE;
+          if (c0 >= nwin) break;
+          const uint32_t x = c0 + lane_u;
+          const uint64_t d = d4[x4];
+          if (rtk_ballot((d & 0xFFFFFFull) != 0) == 0) continue;
+          const uint64_t off = d >> 24; const uint32_t cnt = static_cast<uint32_t>(d & 0xFFFFFFull);
+          uint32_t ucnt = cnt ? 1u : 0u;
+          uint64_t multi = rtk_ballot(cnt >= 2);
+#ifndef RTK_SIM
+          // (2) the group of the next window with several hits, one element per lane when it fits (w_cnt <= 64)
+          uint64_t nkey = ~0ull, nval = ~0ull;
+          auto fetch_group = [&](uint64_t m) { nkey = ~0ull; nval = ~0ull; if (!m) return; const int s2 = rtk_ffs(m) - 1; const uint64_t o2 = rtk_u(rtk_shfl(off, s2)); const uint32_t n2_ = rtk_u(rtk_shfl(cnt, s2));
+                                               if (n2_ <= 64 && lane_u < n2_) { nkey = ipool[2 * (o2 + lane_u)]; nval = ipool[2 * (o2 + lane_u) + 1]; } };
+          fetch_group(multi);
+#endif
+          while (multi) {
             const int sl = rtk_ffs(multi) - 1;
             multi &= multi - 1ull;
             const uint64_t w_off = rtk_u(rtk_shfl(off, sl)); const uint32_t w_cnt = rtk_u(rtk_shfl(cnt, sl));
 #ifndef RTK_SIM
+            const uint64_t key = nkey, val = nval;
+            fetch_group(multi);
             if (w_cnt <= 64) { // the usual case: the group fits one element per lane -> rank by all-pairs comparison in registers, no scratch, no barrier
-                const uint32_t li = static_cast<uint32_t>(rtk_lane());
-                uint64_t key = ~0ull, val = ~0ull;
-                if (li < w_cnt) { key = bv.ipool[2 * (w_off + li)]; val = bv.ipool[2 * (w_off + li) + 1]; }
+                const uint32_t li = lane_u;
                 bool dup = false;
                 for (uint32_t j = 0; j < w_cnt; ++j) { // is an equal k-mer ordered before mine? ((k-mer, hit, index) ascending, like the sort + first-of-run rule)
                     const uint64_t kj = rtk_shfl(key, static_cast<int>(j)), vj = rtk_shfl(val, static_cast<int>(j));
@@ -903,34 +926,40 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
                 const uint32_t nu = static_cast<uint32_t>(rtk_popc(ub));
                 uint32_t pos = 0;
                 while (ub) { const int j = rtk_ffs(ub) - 1; ub &= ub - 1ull; pos += (rtk_shfl(key, j) < key) ? 1u : 0u; }
-                if (uq) { bv.ipool[2 * (w_off + pos)] = key; bv.ipool[2 * (w_off + pos) + 1] = val; }
+                if (uq) { ipool[2 * (w_off + pos)] = key; ipool[2 * (w_off + pos) + 1] = val; }
                 if (static_cast<int>(li) == sl) ucnt = nu;
                 continue;
             }
 #endif
             if (2ull * w_cnt > 2ull * sc.v_cap + 512ull) { ovf = true; break; } // vkey / vidx hold 2 * v_cap + 512 entries, the sort pads to a power of two
-            for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < w_cnt; i += RTK_WAVE) { sc.vkey[i] = bv.ipool[2 * (w_off + i)]; sc.vidx[i] = bv.ipool[2 * (w_off + i) + 1]; }
+            for (uint32_t i = lane_u; i < w_cnt; i += RTK_WAVE) { sc.vkey[i] = ipool[2 * (w_off + i)]; sc.vidx[i] = ipool[2 * (w_off + i) + 1]; }
             rtk_sync();
             rtk_sort_pairs(sc.vkey, sc.vidx, w_cnt);
             uint32_t nu = 0; // first entry of every run of equal k-mers goes back to the front of the group
             for (uint32_t i0 = 0; i0 < w_cnt; i0 += RTK_WAVE) {
-                const uint32_t i = i0 + static_cast<uint32_t>(rtk_lane());
+                const uint32_t i = i0 + lane_u;
                 const bool uq = i < w_cnt && (i == 0 || sc.vkey[i] != sc.vkey[i - 1]);
                 const uint64_t ub = rtk_ballot(uq);
-                if (uq) { const uint64_t dst = w_off + nu + static_cast<uint32_t>(rtk_popc(ub & ((1ull << rtk_lane()) - 1ull))); bv.ipool[2 * dst] = sc.vkey[i]; bv.ipool[2 * dst + 1] = sc.vidx[i]; }
+                if (uq) { const uint64_t dst = w_off + nu + static_cast<uint32_t>(rtk_popc(ub & ((1ull << rtk_lane()) - 1ull))); ipool[2 * dst] = sc.vkey[i]; ipool[2 * dst + 1] = sc.vidx[i]; }
                 nu += static_cast<uint32_t>(rtk_popc(ub));
             }
             rtk_sync();
             if (rtk_lane() == sl) ucnt = nu;
+          }
+          if (ovf) break;
+          rtk_sync(); // compacted groups are read back by their window's lane
+          int tot = 0; const uint32_t my_off = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(ucnt), &tot));
+          if (nv + static_cast<uint32_t>(tot) > v_cap) { ovf = true; break; }
+          for (uint32_t i = 0; i < ucnt; i += 4) { // (3)
+              uint64_t cc_[4], hh_[4];
+              for (uint32_t j = 0; j < 4; ++j) if (i + j < ucnt) { cc_[j] = ipool[2 * (off + i + j)]; hh_[j] = ipool[2 * (off + i + j) + 1]; }
+              for (uint32_t j = 0; j < 4; ++j) if (i + j < ucnt) { const uint32_t o = nv + my_off + i + j; vpos[o] = x; vcode[o] = cc_[j]; vhit[o] = hh_[j]; }
+          }
+          nv += static_cast<uint32_t>(tot);
         }
-        if (ovf) break;
-        rtk_sync(); // compacted groups are read back by their window's lane
-        int tot = 0; const uint32_t my_off = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(ucnt), &tot));
-        if (nv + static_cast<uint32_t>(tot) > sc.v_cap) { ovf = true; break; }
-        for (uint32_t i = 0; i < ucnt; ++i) { const uint32_t o = nv + my_off + i; sc.vpos[o] = x; sc.vcode[o] = bv.ipool[2 * (off + i)]; sc.vhit[o] = bv.ipool[2 * (off + i) + 1]; }
-        nv += static_cast<uint32_t>(tot);
       }
     }
+#undef RTK_GQ
     if (ovf) { *sc.overflow = 1; nv = 0; }
     rtk_sync();
     RTK_PHASE();

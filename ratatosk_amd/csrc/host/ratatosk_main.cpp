@@ -174,9 +174,10 @@ int main(int argc, char** argv) {
             if (rtk::PlainChunks::is_plain(fl[f])) {
                 ++n_plain;
                 rtk::PlainChunks pc; if (!pc.open(fl[f], 2 * opt.batch_bases + (opt.batch_bases >> 4))) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; }
-                std::atomic<size_t> next(0); std::vector<std::thread> th;
-                for (int t = 0; t < opt.cores; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= pc.n_chunks()) break; rtk::PackedReads r(false); if (!pc.parse_chunk(i, r)) break; bases += r.n_bases(); reads += r.size(); } });
+                std::atomic<size_t> next(0); std::atomic<bool> bad(false), malformed(false); std::vector<std::thread> th;
+                for (int t = 0; t < opt.cores; ++t) th.emplace_back([&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= pc.n_chunks() || bad.load()) break; rtk::PackedReads r(false); if (!pc.parse_chunk(i, r)) { if (r.malformed()) malformed = true; bad = true; break; } bases += r.n_bases(); reads += r.size(); } });
                 for (size_t t = 0; t < th.size(); ++t) th[t].join();
+                if (bad.load()) { fprintf(stderr, "Ratatosk::search(): %s %s\n", malformed.load() ? "a record that is not laid out as 4-line FASTQ in" : "read error on", fl[f].c_str()); return 1; }
                 bytes += pc.file_bytes();
             } else { rtk::FastxReader rd; if (!rd.open(fl[f], std::max(1, std::min(opt.cores, 16)))) { fprintf(stderr, "cannot open %s\n", fl[f].c_str()); return 1; } rtk::PackedReads r(false); while (rd.next_packed(r)) { if (r.n_bases() > opt.batch_bases) { bases += r.n_bases(); reads += r.size(); rtk::PackedReads fresh(false); r = std::move(fresh); } } bases += r.n_bases(); reads += r.size(); }
         }

@@ -88,6 +88,9 @@ def test_a_layout_the_range_reader_cannot_take_is_refused_not_misread(ds, tmp_pa
     open(p, "w").write("@%s\n%s\n+\n%s\n" % recs[0] + "".join("@%s\n%s\n+\n%s\n" % (x[0], _wrap(x[1], 80), _wrap(x[2], 80)) for x in recs[1:]))
     r = _run(ds, p, str(tmp_path / "bad"))
     assert r.returncode != 0 and "laid out differently" in r.stderr and not os.path.exists(str(tmp_path / "bad.2.fastq"))
+    # the reader-alone mode reports the same file as a failure, not a rate over the part it could parse
+    rp = subprocess.run([os.path.join(ROOT, "tests", "hostsim", "Ratatosk_sim"), "correct", "-1", "--parse-only", "-c", "3", "-B", "500", "-l", p], capture_output=True, text=True)
+    assert rp.returncode != 0 and "not laid out as 4-line FASTQ" in rp.stderr and "bases/s" not in rp.stdout, rp.stdout + rp.stderr
     r = _run(ds, p, str(tmp_path / "ok"), {"RTK_SERIAL_READER": "1"})
     assert r.returncode == 0 and _sha(str(tmp_path / "ok.2.fastq")) == want
     # no reads at all

@@ -247,6 +247,32 @@ def test_gpu_index_build_writes_the_same_files(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_index_counts_the_windows_across_the_pieces_of_a_long_record(tmp_path):
+    """`-s` with records much longer than a staging buffer of the device count (RTK_INDEX_CHUNK: 4 kb here, 256 MB in production): a record is handed
+    to the k-mer kernel in pieces, and the k - 1 windows across each cut must be counted (pieces overlap by k - 1 characters). Three copies of every
+    record with the cuts at different offsets: a window lost at a cut would fall from 3 to 2 occurrences, below --min-count 3."""
+    import random
+    tmp = str(tmp_path); rnd = random.Random(77)
+    recs = ["".join(rnd.choice("ACGT") for _ in range(20000 + 37 * i)) for i in range(5)]
+    fa = os.path.join(tmp, "long.fa")
+    with open(fa, "w") as f:
+        for c in range(3):
+            for i, r in enumerate(recs):
+                f.write(">c%d_r%d\n%s\n" % (c, i, r if c != 1 else _rc(r)))
+    def build(out, extra, env):
+        r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", fa, "-o", out, "-k", "31", "--min-count", "3"] + extra, capture_output=True, text=True, env=dict(os.environ, RTK_INDEX_TRACE="1", **env))
+        assert r.returncode == 0, r.stderr
+        return open(out + ".index.k31.fasta.gz", "rb").read(), open(out + ".index.k31.rtsk", "rb").read()
+    a = build(os.path.join(tmp, "plain"), [], {})
+    b = build(os.path.join(tmp, "gpu"), ["--gpu"], {})
+    c = build(os.path.join(tmp, "gpu_cut"), ["--gpu"], {"RTK_INDEX_CHUNK": "4096"})
+    assert a == b == c
+    import gzip
+    seqs = [l for l in gzip.decompress(a[0]).decode().split("\n") if l and l[0] != ">"]
+    assert sorted(len(x) for x in seqs) == sorted(len(r) for r in recs)  # every record came back as one unitig
+
+
+@pytest.mark.gpu
 def test_gpu_index_build_from_gzip_input(tmp_path):
     """`--gpu` with the short reads as gzip of several members, as one member and cut short: the device counts the k-mers of text that the host
     reader inflates (common/mgzip.hpp on the tool's threads); same files as from the plain text, the damaged file refused."""
