@@ -31,6 +31,7 @@ inline void rtk_stream_destroy(rtk_stream_t) {}
 inline void rtk_ssync(rtk_stream_t) {}
 inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t) { if (n) memcpy(h, d, n); }
 inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t) { if (n) memset(d, 0, n); }
+inline void rtk_dfill_s(void* d, int c, uint64_t n, rtk_stream_t) { if (n) memset(d, c, n); }
 inline int rtk_device_count() { const char* e = getenv("RTK_SIM_DEVICES"); const int n = e ? atoi(e) : 1; return n > 0 ? n : 1; } // pretend GPUs: the multi-GPU host plumbing runs on CPU
 inline void rtk_set_device(int) {}
 inline void rtk_d2d_peer(void* d, int, const void* s, int, uint64_t n) { if (n) memcpy(d, s, n); }
@@ -75,6 +76,7 @@ inline void rtk_stream_destroy(rtk_stream_t s) { if (s) (void)hipStreamDestroy(s
 inline void rtk_ssync(rtk_stream_t s) { rtk_check(hipStreamSynchronize(s), "hipStreamSynchronize"); }
 inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t s) { if (n) { rtk_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "hipMemcpyAsync D2H"); rtk_ssync(s); } }
 inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemsetAsync(d, 0, n, s), "hipMemsetAsync"); }
+inline void rtk_dfill_s(void* d, int c, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemsetAsync(d, c, n, s), "hipMemsetAsync"); }
 inline int rtk_device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline void rtk_set_device(int d) { rtk_check(hipSetDevice(d), "hipSetDevice"); }
 // GPU -> GPU copy of a flat graph buffer (xGMI when the two devices are peers; the runtime stages through the host otherwise)

@@ -260,23 +260,45 @@ RTK_DEV void rtk_scan_hit_runs(const uint64_t* hits, const uint64_t* hmap, uint6
     }
 }
 
-RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r) {
+// Windows [w_lo, w_hi) of read r (both multiples of the segment length, itself a multiple of 64 * RTK_WAVE; the kernel cuts long reads into such segments, one wave each: the launch lasted as
+// long as the longest read of the ticket). The masked copy is all 'N' before the launch (run_seed_stage), so that a segment may open a gap that reaches
+// back into the segment before it. A gap [previous hit, p) belongs to the segment that holds its closing hit p; what the walk of src/Graph.cpp:127-183
+// carries along -- the read's first hit and the last hit before the segment -- is read off the presence bits. The rule for the read's head is applied
+// by the segment that holds the first hit, the rule for its tail by the last segment.
+RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView& bv, const SeedScratch& sc, uint32_t r, uint32_t w_lo, uint32_t w_hi) {
     RTK_ASSUME_LDS(&sc);
     const uint64_t base = bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
     const uint32_t k = static_cast<uint32_t>(g.k);
-    rtk_wfill(bv.masked + base, 'N', L);
     if (L <= k) return; // src/Graph.cpp:49
     const uint32_t nwin = L - k + 1;
+    if (w_lo >= nwin) return;
+    const bool last_seg = w_hi >= nwin;
+    if (w_hi > nwin) w_hi = nwin;
     const uint64_t* hits = bv.hits + base;
     int64_t prev = -1, first = -1;
     const uint64_t* hmap = bv.hitmap;
-    for (uint32_t cc = 0; cc < nwin; cc += 64 * RTK_WAVE) { // every lane fetches the presence bits of one 64-window block, then the blocks are visited in order
+    if (w_lo > 0) { // the first hit of the read and the last one before this segment
+        for (uint32_t cc = 0; cc < w_lo && first < 0; cc += 64 * RTK_WAVE) {
+            const uint32_t my_c0 = cc + 64u * static_cast<uint32_t>(rtk_lane());
+            const uint64_t my_bits = (my_c0 < w_lo) ? rtk_hit_bits(hmap, base + my_c0, 64) : 0ull;
+            const uint64_t any = rtk_ballot(my_bits != 0);
+            if (any) { const int l = rtk_ffs(any) - 1; first = static_cast<int64_t>(cc) + 64 * l + __builtin_ctzll(rtk_u(rtk_shfl(my_bits, l))); }
+        }
+        for (uint32_t hi = w_lo; first >= 0 && hi > 0 && prev < 0; hi -= 64 * RTK_WAVE) { // blocks hi - 64, hi - 128, ...: lane 0 holds the nearest one
+            const uint32_t my_c0 = hi - 64u * (static_cast<uint32_t>(rtk_lane()) + 1u);
+            const uint64_t my_bits = rtk_hit_bits(hmap, base + my_c0, 64);
+            const uint64_t any = rtk_ballot(my_bits != 0);
+            if (any) { const int l = rtk_ffs(any) - 1; prev = static_cast<int64_t>(hi) - 64 * (l + 1) + 63 - __builtin_clzll(rtk_u(rtk_shfl(my_bits, l))); }
+        }
+    }
+    const bool first_is_mine = first < 0;
+    for (uint32_t cc = w_lo; cc < w_hi; cc += 64 * RTK_WAVE) { // every lane fetches the presence bits of one 64-window block, then the blocks are visited in order
         const uint32_t my_c0 = cc + 64u * static_cast<uint32_t>(rtk_lane());
-        const uint64_t my_bits = (my_c0 < nwin) ? rtk_hit_bits(hmap, base + my_c0, nwin - my_c0) : 0ull;
+        const uint64_t my_bits = (my_c0 < w_hi) ? rtk_hit_bits(hmap, base + my_c0, w_hi - my_c0) : 0ull;
       for (int bl = 0; bl < RTK_WAVE; ++bl) {
         const uint32_t c0 = cc + 64u * static_cast<uint32_t>(bl);
-        if (c0 >= nwin) break;
+        if (c0 >= w_hi) break;
         uint64_t bal = rtk_u(rtk_shfl(my_bits, bl));
         if (bal == ~0ull && prev == static_cast<int64_t>(c0) - 1) { if (first < 0) first = c0; prev = c0 + 63; continue; } // inside a run: no gap
         // only the first hit of a run can close a gap: visit run starts, with `prev` = the last hit before each of them
@@ -320,8 +342,8 @@ RTK_FN void rtk_mask_read(const GraphView& g, const OptsView& o, const BatchView
       }
     }
     if (first >= 0) {
-        if (static_cast<uint64_t>(first) >= o.insert_sz / 2) rtk_wcopy(bv.masked + base, bv.seq + base, static_cast<uint64_t>(first) + k - 1);
-        if (L - static_cast<uint64_t>(prev) >= o.insert_sz / 2) rtk_wcopy(bv.masked + base + prev + 1, bv.seq + base + prev + 1, L - static_cast<uint64_t>(prev) - 1);
+        if (first_is_mine && static_cast<uint64_t>(first) >= o.insert_sz / 2) rtk_wcopy(bv.masked + base, bv.seq + base, static_cast<uint64_t>(first) + k - 1);
+        if (last_seg && L - static_cast<uint64_t>(prev) >= o.insert_sz / 2) rtk_wcopy(bv.masked + base + prev + 1, bv.seq + base + prev + 1, L - static_cast<uint64_t>(prev) - 1);
     }
 }
 

@@ -38,6 +38,7 @@ template <class T> inline T* rtk_opaque(T* p) { return p; }
 inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
 template <class T> inline T rtk_atomic_add_raw(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline uint32_t rtk_atomic_or(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long rtk_clock() { return 0; }
 inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1ull); x >>= 1; } return r; }
 
@@ -101,6 +102,7 @@ template <class T> __device__ __forceinline__ T* rtk_opaque(T* p) { unsigned lon
 __device__ __forceinline__ int rtk_popc(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int rtk_ffs(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }
 template <class T> __device__ __forceinline__ T rtk_atomic_add_raw(T* p, T v) { return atomicAdd(p, v); }
+__device__ __forceinline__ uint32_t rtk_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 #ifdef RTK_NO_CLOCK // A/B build: what the cycle counters of the wave programs cost (measured in round 4: nothing, 30.93 against 30.90 ms)
 __device__ __forceinline__ unsigned long long rtk_clock() { return 0ull; }
 #else

@@ -36,3 +36,13 @@ def test_sim_seeds_variant_enumeration_agrees(ds_small, ds_tandem, monkeypatch):
     monkeypatch.setenv("RTK_INEXACT_ENUM", "1")
     assert _check(ds_small, 6, SIM_LIB) > 0
     assert _check(ds_tandem, 10, SIM_LIB) > 0
+
+
+def test_sim_seeds_mask_in_segments(ds_small, ds_clean, monkeypatch):
+    """k_mask cuts a read into segments of RTK_MASK_SEG windows, one wave each (8192 in production: the launch lasted as long as its longest read).
+    With segments of 64 and 192 windows every read of these sets is masked in dozens of pieces: gaps that reach back over a segment border, the read's
+    first hit and the last hit before a segment read off the presence bits, head and tail rules applied once. Same anchors as the oracle."""
+    for seg in ("64", "192"):
+        monkeypatch.setenv("RTK_MASK_SEG", seg)
+        assert _check(ds_small, 12, SIM_LIB) > 0
+        _check(ds_clean, 6, SIM_LIB)
