@@ -50,6 +50,7 @@ struct RegionBatch {
     U<unsigned long long*> n_overflow;         // regions that ran out of scratch in the last launch
     U<char*> out_pool; U<uint64_t> out_cap; U<unsigned long long*> out_top;
     U<uint64_t*> out_off; U<uint32_t*> out_seq_len; U<uint32_t*> out_qual_len; // per read
+    U<uint64_t*> st_off;                       // per segment: quality bytes << 32 | characters of its read in front of it (k_stitch)
 };
 
 struct RegionScratchCfg { ScratchCfg my; uint32_t set_cap, um_cap, str_cap, list_cap, memo_cap, bm_words; uint64_t arena_cap; };
@@ -2088,7 +2089,14 @@ RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const Regi
     }
     uint32_t n_gaps = 0;
     const bool whole = (L <= k) || ns == 0 || (ns == L - k + 1);
-    if (!whole) for (uint32_t c0 = 0; c0 + 1 < ns; c0 += RTK_WAVE) { const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane()); n_gaps += static_cast<uint32_t>(rtk_popc(rtk_ballot(i + 1 < ns && sp[i] != sp[i + 1] - 1))); }
+    // (this program runs on ONE wave per read and the launch lasts as long as its longest read -- tens of thousands of solid anchors: the anchors are
+    // read eight chunks of 64 at a time, and what the descriptors need from a neighbouring anchor comes out of the lanes' registers, not from memory)
+    constexpr uint32_t EU = 8;
+    if (!whole) for (uint32_t c0 = 0; c0 + 1 < ns; c0 += EU * RTK_WAVE) {
+        uint32_t a[EU], b2[EU];
+        for (uint32_t u = 0; u < EU; ++u) { const uint32_t i = c0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); const bool in = i + 1 < ns; a[u] = in ? sp[i] : 0u; b2[u] = in ? sp[i + 1] : 1u; }
+        for (uint32_t u = 0; u < EU; ++u) n_gaps += static_cast<uint32_t>(rtk_popc(rtk_ballot(a[u] != b2[u] - 1u)));
+    }
     const uint32_t total = whole ? 1u : ((sp[0] != 0 ? 1u : 0u) + n_gaps + 1u);
     unsigned long long first = 0;
     if (rtk_lane() == 0) first = rtk_atomic_add(rb.n_regions, static_cast<unsigned long long>(total));
@@ -2106,52 +2114,66 @@ RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const Regi
     uint32_t prev_pos = sp[0];
     // the gaps between runs of consecutive solid anchors, 64 anchors at a time: every lane that sees a gap writes its descriptor. The
     // segment before it stopped at the anchor behind the PREVIOUS gap (prev_pos = sp[previous gap + 1], sp[0] for the first one)
-    for (uint32_t c0 = 0; c0 + 1 < ns; c0 += RTK_WAVE) {
-        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
-        const bool gap = i + 1 < ns && sp[i] != sp[i + 1] - 1;
-        const uint64_t bal = rtk_ballot(gap);
-        if (bal == 0ull) continue;
-        const uint64_t below = bal & ((1ull << rtk_lane()) - 1ull); // gaps of this chunk in front of this lane's
-        if (gap) {
-            uint32_t pp = prev_pos;
-            if (below) pp = sp[c0 + static_cast<uint32_t>(63 - __builtin_clzll(below)) + 1];
-            RegionDesc d; d.read = r; d.kind = RTK_RG_GAP; d.i_solid = i; d.prev_pos = pp; d.seg_off = 0; d.seq_len = 0; d.qual_len = 0; d.status = 0; d.pad = 0;
-            out[w + static_cast<uint32_t>(rtk_popc(below))] = d;
+    for (uint32_t c0 = 0; c0 + 1 < ns; c0 += EU * RTK_WAVE) {
+        uint32_t a[EU], b2[EU]; // a = sp[i], b2 = sp[i + 1] (out of range: a pair without a gap)
+        for (uint32_t u = 0; u < EU; ++u) { const uint32_t i = c0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); const bool in = i + 1 < ns; a[u] = in ? sp[i] : 0u; b2[u] = in ? sp[i + 1] : 1u; }
+        for (uint32_t u = 0; u < EU; ++u) {
+            const uint32_t i = c0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane());
+            const bool gap = a[u] != b2[u] - 1u;
+            const uint64_t bal = rtk_ballot(gap);
+            if (bal == 0ull) continue;
+            const uint64_t below = bal & ((1ull << rtk_lane()) - 1ull); // gaps of this chunk in front of this lane's
+            const uint32_t behind_prev = rtk_shfl(b2[u], below ? (63 - __builtin_clzll(below)) : 0); // the anchor behind the previous gap of the chunk: sp[that gap + 1]
+            if (gap) {
+                RegionDesc d; d.read = r; d.kind = RTK_RG_GAP; d.i_solid = i; d.prev_pos = below ? behind_prev : prev_pos; d.seg_off = 0; d.seq_len = 0; d.qual_len = 0; d.status = 0; d.pad = 0;
+                out[w + static_cast<uint32_t>(rtk_popc(below))] = d;
+            }
+            w += static_cast<uint32_t>(rtk_popc(bal));
+            prev_pos = rtk_u(rtk_shfl(b2[u], 63 - __builtin_clzll(bal)));
         }
-        w += static_cast<uint32_t>(rtk_popc(bal));
-        prev_pos = rtk_u(sp[c0 + static_cast<uint32_t>(63 - __builtin_clzll(bal)) + 1]);
     }
     put(sp[ns - 1] < L - k ? RTK_RG_TAIL : RTK_RG_TAIL_COPY, ns - 1, prev_pos);
     rtk_sync();
 }
 
-// ------------------------------------------------------------------------------------------------ stitch (one wave per read)
-RTK_FN void rtk_stitch_read(const BatchView& bv, const RegionBatch& rb, uint32_t r) {
-    const RegionDesc* rg = rb.regions + rb.r_first[r]; const uint32_t n = rb.r_count[r];
+// ------------------------------------------------------------------------------------------------ stitch
+// Two steps (round 4; one wave per read copied a 100 kb read's thousand segments one after the other while the machine idled):
+// (1) one wave per read adds up the lengths of its segments, reserves the read's place in the output pool and leaves every segment's
+// place inside the read (st_off: characters / quality bytes in front of it); (2) the segments of ALL reads are copied 64 per wave.
+RTK_FN void rtk_stitch_offsets(const BatchView& bv, const RegionBatch& rb, uint32_t r) {
+    const uint64_t f0 = rb.r_first[r];
+    const RegionDesc* rg = rb.regions + f0; uint64_t* st = rb.st_off.get() + f0; const uint32_t n = rb.r_count[r];
     // lengths of the read's segments, 64 at a time (the loads of a chunk are independent: one round trip per chunk, not per segment)
     uint64_t ts = 0, tq = 0;
     for (uint32_t c0 = 0; c0 < n; c0 += RTK_WAVE) {
         const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
         int a = 0, b = 0; if (i < n) { a = static_cast<int>(rg[i].seq_len); b = static_cast<int>(rg[i].qual_len); }
-        int ta, tb; (void)rtk_wave_excl_scan(a, &ta); (void)rtk_wave_excl_scan(b, &tb);
+        int ta, tb; const int pa = rtk_wave_excl_scan(a, &ta), pb = rtk_wave_excl_scan(b, &tb);
+        if (i < n) st[i] = ((tq + static_cast<uint64_t>(pb)) << 32) | (ts + static_cast<uint64_t>(pa));
         ts += static_cast<uint64_t>(rtk_u(ta)); tq += static_cast<uint64_t>(rtk_u(tb));
     }
     unsigned long long off = 0;
     if (rtk_lane() == 0) off = rtk_atomic_add(rb.out_top, static_cast<unsigned long long>(ts + tq));
     off = rtk_shfl(off, 0);
     rb.out_off[r] = off; rb.out_seq_len[r] = static_cast<uint32_t>(ts); rb.out_qual_len[r] = static_cast<uint32_t>(tq);
-    if (off + ts + tq > rb.out_cap) return;
-    uint64_t ws = off, wq = off + ts;
-    for (uint32_t c0 = 0; c0 < n; c0 += RTK_WAVE) { // descriptors of a chunk in registers, then its copies back to back
-        const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
-        uint32_t sl = 0, ql = 0; uint64_t so = 0; if (i < n) { sl = rg[i].seq_len; ql = rg[i].qual_len; so = rg[i].seg_off; }
-        const uint32_t m = (n - c0) < static_cast<uint32_t>(RTK_WAVE) ? (n - c0) : static_cast<uint32_t>(RTK_WAVE);
-        for (uint32_t j = 0; j < m; ++j) {
-            const uint32_t jsl = rtk_shfl(sl, static_cast<int>(j)), jql = rtk_shfl(ql, static_cast<int>(j)); const uint64_t jso = rtk_shfl(so, static_cast<int>(j));
-            rtk_wcopy2(rb.out_pool + ws, rb.seg_pool + jso, jsl, rb.out_pool + wq, rb.seg_pool + jso + jsl, jql); ws += jsl; wq += jql;
-        }
-    }
     (void)bv;
+}
+
+// segments c0 .. c0 + 63 of the flat list: their descriptors and their reads' places one per lane, then the copies back to back
+RTK_FN void rtk_stitch_copy(const RegionBatch& rb, uint64_t c0, uint64_t n_regions) {
+    const uint64_t i = c0 + static_cast<uint64_t>(rtk_lane());
+    uint32_t sl = 0, ql = 0; uint64_t so = 0, ws = 0, wq = 0;
+    if (i < n_regions) {
+        const RegionDesc* rd = rb.regions.get() + i;
+        const uint32_t r = rd->read; const uint64_t st = rb.st_off[i];
+        const uint64_t off = rb.out_off[r], ts = rb.out_seq_len[r], tq = rb.out_qual_len[r];
+        if (off + ts + tq <= rb.out_cap) { sl = rd->seq_len; ql = rd->qual_len; so = rd->seg_off; ws = off + (st & 0xFFFFFFFFull); wq = off + ts + (st >> 32); } // (a read beyond the pool's end is not written: the host sees out_top > out_cap)
+    }
+    const uint32_t m = (n_regions - c0) < static_cast<uint64_t>(RTK_WAVE) ? static_cast<uint32_t>(n_regions - c0) : static_cast<uint32_t>(RTK_WAVE);
+    for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t jsl = rtk_shfl(sl, static_cast<int>(j)), jql = rtk_shfl(ql, static_cast<int>(j)); const uint64_t jso = rtk_shfl(so, static_cast<int>(j)), jws = rtk_shfl(ws, static_cast<int>(j)), jwq = rtk_shfl(wq, static_cast<int>(j));
+        rtk_wcopy2(rb.out_pool + jws, rb.seg_pool + jso, jsl, rb.out_pool + jwq, rb.seg_pool + jso + jsl, jql);
+    }
 }
 
 #endif

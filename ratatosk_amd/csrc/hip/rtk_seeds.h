@@ -899,8 +899,17 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
     // The pointers are read from the launch's views once: behind every store the compiler would fetch them again.
 #ifdef RTK_SIM
 #define RTK_GQ 2
+#define RTK_GH 1
 #else
-#define RTK_GQ 8
+#ifndef RTK_GQ_N
+#define RTK_GQ_N 4
+#endif
+#ifndef RTK_GH_N
+#define RTK_GH_N 4
+#endif
+#define RTK_GQ RTK_GQ_N
+#define RTK_GH RTK_GH_N
+static_assert(RTK_GQ % RTK_GH == 0, "a step is a whole number of halves");
 #endif
     {
       const uint64_t* const wdesc = bv.wdesc.get() + base; uint64_t* const ipool = bv.ipool.get();
@@ -913,15 +922,17 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
         for (int q = 0; q < RTK_GQ; ++q) d4[q] = dn[q];
         { const uint32_t cn = c4 + RTK_GQ * RTK_WAVE; // (1)
           if (cn < nwin) for (int q = 0; q < RTK_GQ; ++q) { const uint32_t xx = cn + static_cast<uint32_t>(q) * RTK_WAVE + lane_u; dn[q] = (xx < nwin) ? wdesc[xx] : 0ull; } }
-        for (int x4 = 0; x4 < RTK_GQ && !ovf; ++x4) {
-          const uint32_t c0 = c4 + static_cast<uint32_t>(x4) * RTK_WAVE;
-          if (c0 >= nwin) break;
-          const uint32_t x = c0 + lane_u;
+        // (a) the windows with several raw hits of all chunks of the step: duplicates out, in place
+        uint32_t ucnt[RTK_GQ];
+#pragma unroll
+        for (int x4 = 0; x4 < RTK_GQ; ++x4) ucnt[x4] = (d4[x4] & 0xFFFFFFull) ? 1u : 0u;
+#pragma unroll
+        for (int x4 = 0; x4 < RTK_GQ; ++x4) {
+          if (ovf) break;
           const uint64_t d = d4[x4];
-          if (rtk_ballot((d & 0xFFFFFFull) != 0) == 0) continue;
           const uint64_t off = d >> 24; const uint32_t cnt = static_cast<uint32_t>(d & 0xFFFFFFull);
-          uint32_t ucnt = cnt ? 1u : 0u;
           uint64_t multi = rtk_ballot(cnt >= 2);
+          if (!multi) continue;
 #ifndef RTK_SIM
           // (2) the group of the next window with several hits, one element per lane when it fits (w_cnt <= 64)
           uint64_t nkey = ~0ull, nval = ~0ull;
@@ -949,7 +960,7 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
                 uint32_t pos = 0;
                 while (ub) { const int j = rtk_ffs(ub) - 1; ub &= ub - 1ull; pos += (rtk_shfl(key, j) < key) ? 1u : 0u; }
                 if (uq) { ipool[2 * (w_off + pos)] = key; ipool[2 * (w_off + pos) + 1] = val; }
-                if (static_cast<int>(li) == sl) ucnt = nu;
+                if (static_cast<int>(li) == sl) ucnt[x4] = nu;
                 continue;
             }
 #endif
@@ -966,22 +977,41 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
                 nu += static_cast<uint32_t>(rtk_popc(ub));
             }
             rtk_sync();
-            if (rtk_lane() == sl) ucnt = nu;
+            if (rtk_lane() == sl) ucnt[x4] = nu;
           }
-          if (ovf) break;
-          rtk_sync(); // compacted groups are read back by their window's lane
-          int tot = 0; const uint32_t my_off = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(ucnt), &tot));
-          if (nv + static_cast<uint32_t>(tot) > v_cap) { ovf = true; break; }
-          for (uint32_t i = 0; i < ucnt; i += 4) { // (3)
-              uint64_t cc_[4], hh_[4];
-              for (uint32_t j = 0; j < 4; ++j) if (i + j < ucnt) { cc_[j] = ipool[2 * (off + i + j)]; hh_[j] = ipool[2 * (off + i + j) + 1]; }
-              for (uint32_t j = 0; j < 4; ++j) if (i + j < ucnt) { const uint32_t o = nv + my_off + i + j; vpos[o] = x; vcode[o] = cc_[j]; vhit[o] = hh_[j]; }
-          }
-          nv += static_cast<uint32_t>(tot);
         }
+        if (ovf) break;
+        rtk_sync(); // compacted groups are read back by their window's lane
+        // (b) where every window's hits go: chunk after chunk, window after window
+        uint32_t my_o[RTK_GQ]; uint32_t nv_step = nv; bool any = false;
+#pragma unroll
+        for (int x4 = 0; x4 < RTK_GQ; ++x4) { int tot = 0; const uint32_t mo = static_cast<uint32_t>(rtk_wave_excl_scan(static_cast<int>(ucnt[x4]), &tot)); my_o[x4] = nv_step + mo; nv_step += static_cast<uint32_t>(rtk_u(tot)); any = any || tot != 0; }
+        if (!any) continue;
+        if (nv_step > v_cap) { ovf = true; break; }
+        // (c) the first hit of every window of the step: the loads of all chunks in flight, then the stores; (3) the further hits of a window four at a time
+#pragma unroll
+        for (int h0 = 0; h0 < RTK_GQ; h0 += RTK_GH) { // (half a step at a time: registers)
+          uint64_t cc_[RTK_GH], hh_[RTK_GH];
+#pragma unroll
+          for (int x4 = 0; x4 < RTK_GH; ++x4) if (ucnt[h0 + x4]) { const uint64_t off = d4[h0 + x4] >> 24; cc_[x4] = ipool[2 * off]; hh_[x4] = ipool[2 * off + 1]; }
+#pragma unroll
+          for (int x4 = 0; x4 < RTK_GH; ++x4) if (ucnt[h0 + x4]) { const uint32_t o = my_o[h0 + x4]; vpos[o] = c4 + static_cast<uint32_t>(h0 + x4) * RTK_WAVE + lane_u; vcode[o] = cc_[x4]; vhit[o] = hh_[x4]; }
+        }
+#pragma unroll
+        for (int x4 = 0; x4 < RTK_GQ; ++x4) {
+          if (rtk_ballot(ucnt[x4] > 1) == 0) continue;
+          const uint64_t off = d4[x4] >> 24; const uint32_t x = c4 + static_cast<uint32_t>(x4) * RTK_WAVE + lane_u;
+          for (uint32_t i = 1; i < ucnt[x4]; i += 4) {
+              uint64_t cc_[4], hh_[4];
+              for (uint32_t j = 0; j < 4; ++j) if (i + j < ucnt[x4]) { cc_[j] = ipool[2 * (off + i + j)]; hh_[j] = ipool[2 * (off + i + j) + 1]; }
+              for (uint32_t j = 0; j < 4; ++j) if (i + j < ucnt[x4]) { const uint32_t o = my_o[x4] + i + j; vpos[o] = x; vcode[o] = cc_[j]; vhit[o] = hh_[j]; }
+          }
+        }
+        nv = nv_step;
       }
     }
 #undef RTK_GQ
+#undef RTK_GH
     if (ovf) { *sc.overflow = 1; nv = 0; }
     rtk_sync();
     RTK_PHASE();
@@ -1011,31 +1041,39 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
             ng += static_cast<uint32_t>(rtk_popc(sb));
         }
         rtk_sync();
+        // (vcode is free once the hits are classified: it takes one word per group -- the variant's position and, for a group of one hit, the
+        // unitig and strand of that hit -- so that the neighbour test below reads a group with independent loads instead of three dependent ones)
+        uint64_t* const ginfo = sc.vcode.get();
         for (uint32_t gi = static_cast<uint32_t>(rtk_lane()); gi < ng; gi += RTK_WAVE) { // one group per lane: extent and position span
             const uint32_t a = sc.gstart[gi], e = (gi + 1 < ng) ? sc.gstart[gi + 1] : nvalid;
             uint32_t ps = 0xFFFFFFFFu, pe = 0;
             for (uint32_t j = a; j < e; ++j) { const uint32_t pp = sc.vpos[sc.vidx[j]]; ps = pp < ps ? pp : ps; pe = (pp + k) > pe ? (pp + k) : pe; }
             sc.gcnt[gi] = e - a; sc.gps[gi] = ps; sc.gpe[gi] = pe; sc.gkeep[gi] = 1;
+            const uint64_t h0 = sc.vhit[sc.vidx[a]];
+            ginfo[gi] = (((static_cast<uint64_t>(rtk_hit_unitig(h0)) << 1) | (h0 & 1ull)) << 32) | (sc.vkey[a] >> 16 & 0xFFFFFFFFull);
         }
         rtk_sync();
         RTK_PHASE();
         // a variant is dropped iff another variant overlaps it within k without sharing a unitig (order independent)
         for (uint32_t gi = static_cast<uint32_t>(rtk_lane()); gi < ng; gi += RTK_WAVE) {
-            const uint64_t k1 = sc.vkey[sc.gstart[gi]]; const uint32_t p1 = static_cast<uint32_t>(k1 >> 16);
+            const uint64_t G1 = ginfo[gi]; const uint32_t p1 = static_cast<uint32_t>(G1 & 0xFFFFFFFFull);
+            const uint32_t ps1 = sc.gps[gi], pe1 = sc.gpe[gi], c1 = sc.gcnt[gi];
             const uint32_t lower = (p1 < k - 1) ? 0u : (p1 - k + 1); const uint32_t upper = ((p1 + k) >= L) ? L : (p1 + k);
             bool conflict = false;
             for (int dir = 0; dir < 2 && !conflict; ++dir) {
                 int64_t gj = dir ? static_cast<int64_t>(gi) + 1 : static_cast<int64_t>(gi) - 1;
                 while (gj >= 0 && gj < static_cast<int64_t>(ng) && !conflict) {
-                    const uint64_t k2 = sc.vkey[sc.gstart[gj]]; const uint32_t p2 = static_cast<uint32_t>(k2 >> 16);
+                    const uint64_t G2 = ginfo[gj]; const uint32_t ps2 = sc.gps[gj], pe2 = sc.gpe[gj], c2 = sc.gcnt[gj]; // (one round trip)
+                    const uint32_t p2 = static_cast<uint32_t>(G2 & 0xFFFFFFFFull);
                     if (p2 < lower || p2 > upper) break;
-                    const bool ov1 = (p1 >= sc.gps[gj]) && (p1 < sc.gpe[gj]);
-                    const bool ov2 = (p2 >= sc.gps[gi]) && (p2 < sc.gpe[gi]);
+                    const bool ov1 = (p1 >= ps2) && (p1 < pe2);
+                    const bool ov2 = (p2 >= ps1) && (p2 < pe1);
                     if (ov1 || ov2) {
                         bool same = false;
-                        for (uint32_t a = 0; a < sc.gcnt[gi] && !same; ++a) {
+                        if (c1 == 1 && c2 == 1) same = (G1 >> 32) == (G2 >> 32);
+                        else for (uint32_t a = 0; a < c1 && !same; ++a) {
                             const uint64_t ha = sc.vhit[sc.vidx[sc.gstart[gi] + a]];
-                            for (uint32_t b2 = 0; b2 < sc.gcnt[gj] && !same; ++b2) {
+                            for (uint32_t b2 = 0; b2 < c2 && !same; ++b2) {
                                 const uint64_t hb = sc.vhit[sc.vidx[sc.gstart[gj] + b2]];
                                 same = (rtk_hit_unitig(ha) == rtk_hit_unitig(hb)) && ((ha & 1ull) == (hb & 1ull));
                             }
