@@ -2081,17 +2081,28 @@ RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const Regi
     { // eight characters per lane in flight: one wave reverses the whole read, and a load-then-store step at a time is a memory round trip each
         const char* __restrict__ const src = bv.seq.get() + base; char* __restrict__ const dst = rb.seq_rc.get() + base;
         const char* __restrict__ const qsrc = (bv.qual.get() != nullptr && rb.qual_rev.get() != nullptr) ? bv.qual.get() + base : nullptr; char* __restrict__ const qdst = qsrc ? rb.qual_rev.get() + base : nullptr;
-        for (uint32_t i0 = 0; i0 < L; i0 += 8u * RTK_WAVE) {
-            char t[8], tq[8];
-            for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); t[u] = i < L ? src[L - 1 - i] : 'N'; tq[u] = (qsrc && i < L) ? qsrc[L - 1 - i] : '!'; }
-            for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); if (i < L) { dst[i] = rtk_comp(t[u]); if (qdst) qdst[i] = tq[u]; } }
+        constexpr uint32_t RU = 32; // characters per lane in flight: a 200 kb read is reversed by ONE wave, and a step is a memory round trip (8: 0.4 ms for that read)
+        if (qsrc) {
+            for (uint32_t i0 = 0; i0 < L; i0 += 8u * RTK_WAVE) {
+                char t[8], tq[8];
+                for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); t[u] = i < L ? src[L - 1 - i] : 'N'; tq[u] = i < L ? qsrc[L - 1 - i] : '!'; }
+                for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); if (i < L) { dst[i] = rtk_comp(t[u]); qdst[i] = tq[u]; } }
+            }
+        } else {
+            for (uint32_t i0 = 0; i0 < L; i0 += RU * RTK_WAVE) {
+                char t[RU];
+#pragma unroll
+                for (uint32_t u = 0; u < RU; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); t[u] = i < L ? src[L - 1 - i] : 'N'; }
+#pragma unroll
+                for (uint32_t u = 0; u < RU; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); if (i < L) dst[i] = rtk_comp(t[u]); }
+            }
         }
     }
     uint32_t n_gaps = 0;
     const bool whole = (L <= k) || ns == 0 || (ns == L - k + 1);
     // (this program runs on ONE wave per read and the launch lasts as long as its longest read -- tens of thousands of solid anchors: the anchors are
-    // read eight chunks of 64 at a time, and what the descriptors need from a neighbouring anchor comes out of the lanes' registers, not from memory)
-    constexpr uint32_t EU = 8;
+    // read sixteen chunks of 64 at a time, and what the descriptors need from a neighbouring anchor comes out of the lanes' registers, not from memory)
+    constexpr uint32_t EU = 16;
     if (!whole) for (uint32_t c0 = 0; c0 + 1 < ns; c0 += EU * RTK_WAVE) {
         uint32_t a[EU], b2[EU];
         for (uint32_t u = 0; u < EU; ++u) { const uint32_t i = c0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); const bool in = i + 1 < ns; a[u] = in ? sp[i] : 0u; b2[u] = in ? sp[i + 1] : 1u; }
