@@ -2072,41 +2072,58 @@ RTK_FN_DRIVER void rtk_region_program(const RCtx& c_, RegionDesc* rd_) {
 }
 
 // ------------------------------------------------------------------------------------------------ region enumeration (one wave per read)
-RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const RegionBatch& rb, uint32_t r) {
+// dst[i] = tab[src[n - 1 - i]] (tab == nullptr: the characters as they are). One wave; four characters per lane and access (the reverse complement of a 64 Mb
+// step was 0.7 of k_enum's 0.8 ms as byte loads, a twelve-way switch per character and byte stores: `tab` is the complement as a 256-byte table in LDS, one
+// entry per bank), eight such words per lane in flight. The words are not aligned (a read starts anywhere): global accesses need not be.
+RTK_DEV uint32_t rtk_ld_u32(const char* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+RTK_DEV void rtk_st_u32(char* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+RTK_FN void rtk_reverse_copy(char* __restrict__ dst_, const char* __restrict__ src_, uint32_t n_, const unsigned char* tab_) {
+    char* __restrict__ const dst = rtk_gp(rtk_u(dst_)); const char* __restrict__ const src = rtk_gp(rtk_u(src_)); const uint32_t n = rtk_u(n_); const unsigned char* const tab = rtk_u(tab_);
+    const uint32_t n4 = n & ~3u;
+    constexpr uint32_t RW = 8;
+    for (uint32_t i0 = 0; i0 < n4; i0 += 4u * RW * RTK_WAVE) {
+        uint32_t w[RW];
+#pragma unroll
+        for (uint32_t u = 0; u < RW; ++u) { const uint32_t i = i0 + 4u * (u * RTK_WAVE + static_cast<uint32_t>(rtk_lane())); w[u] = i < n4 ? rtk_ld_u32(src + (n - 4u - i)) : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < RW; ++u) {
+            const uint32_t i = i0 + 4u * (u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()));
+            uint32_t b0 = w[u] >> 24, b1 = (w[u] >> 16) & 0xFFu, b2 = (w[u] >> 8) & 0xFFu, b3 = w[u] & 0xFFu; // the last character of the word comes first
+            if (tab) { RTK_ASSUME_LDS(tab); b0 = tab[b0]; b1 = tab[b1]; b2 = tab[b2]; b3 = tab[b3]; }
+            if (i < n4) rtk_st_u32(dst + i, b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+        }
+    }
+    for (uint32_t i = n4 + static_cast<uint32_t>(rtk_lane()); i < n; i += RTK_WAVE) { { const unsigned char c = static_cast<unsigned char>(src[n - 1u - i]); unsigned char o = c; if (tab) { RTK_ASSUME_LDS(tab); o = tab[c]; } dst[i] = static_cast<char>(o); } }
+}
+
+RTK_FN void rtk_enum_regions(const GraphView& g, const BatchView& bv, const RegionBatch& rb, uint32_t r, const unsigned char* comp_tab) {
     const uint32_t k = static_cast<uint32_t>(g.k);
     const uint64_t base = bv.roff[r];
     const uint32_t L = static_cast<uint32_t>(bv.roff[r + 1] - base);
     const uint32_t* sp = bv.s_pos + base; const uint32_t ns = bv.n_solid[r];
     // reverse complement of the read (used by the head and backward corrections, src/Correction.cpp:175)
-    { // eight characters per lane in flight: one wave reverses the whole read, and a load-then-store step at a time is a memory round trip each
-        const char* __restrict__ const src = bv.seq.get() + base; char* __restrict__ const dst = rb.seq_rc.get() + base;
-        const char* __restrict__ const qsrc = (bv.qual.get() != nullptr && rb.qual_rev.get() != nullptr) ? bv.qual.get() + base : nullptr; char* __restrict__ const qdst = qsrc ? rb.qual_rev.get() + base : nullptr;
-        constexpr uint32_t RU = 32; // characters per lane in flight: a 200 kb read is reversed by ONE wave, and a step is a memory round trip (8: 0.4 ms for that read)
-        if (qsrc) {
-            for (uint32_t i0 = 0; i0 < L; i0 += 8u * RTK_WAVE) {
-                char t[8], tq[8];
-                for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); t[u] = i < L ? src[L - 1 - i] : 'N'; tq[u] = i < L ? qsrc[L - 1 - i] : '!'; }
-                for (uint32_t u = 0; u < 8; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); if (i < L) { dst[i] = rtk_comp(t[u]); qdst[i] = tq[u]; } }
-            }
-        } else {
-            for (uint32_t i0 = 0; i0 < L; i0 += RU * RTK_WAVE) {
-                char t[RU];
-#pragma unroll
-                for (uint32_t u = 0; u < RU; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); t[u] = i < L ? src[L - 1 - i] : 'N'; }
-#pragma unroll
-                for (uint32_t u = 0; u < RU; ++u) { const uint32_t i = i0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); if (i < L) dst[i] = rtk_comp(t[u]); }
-            }
-        }
+#ifndef RTK_AB_ENUM_RC_REPS // (developer A/B builds: what the reverse complement / the anchor loops cost, by doing them several times)
+#define RTK_AB_ENUM_RC_REPS 1
+#endif
+#ifndef RTK_AB_ENUM_GAP_REPS
+#define RTK_AB_ENUM_GAP_REPS 1
+#endif
+    // reverse complement of the read (used by the head and backward corrections, src/Correction.cpp:175); pass 2: the quality string reversed beside it
+    for (int rep_ = 0; rep_ < RTK_AB_ENUM_RC_REPS; ++rep_) {
+        rtk_reverse_copy(rb.seq_rc.get() + base, bv.seq.get() + base, L, comp_tab);
+        if (bv.qual.get() != nullptr && rb.qual_rev.get() != nullptr) rtk_reverse_copy(rb.qual_rev.get() + base, bv.qual.get() + base, L, nullptr);
     }
     uint32_t n_gaps = 0;
     const bool whole = (L <= k) || ns == 0 || (ns == L - k + 1);
     // (this program runs on ONE wave per read and the launch lasts as long as its longest read -- tens of thousands of solid anchors: the anchors are
     // read sixteen chunks of 64 at a time, and what the descriptors need from a neighbouring anchor comes out of the lanes' registers, not from memory)
     constexpr uint32_t EU = 16;
+    for (int rep_ = 0; rep_ < RTK_AB_ENUM_GAP_REPS; ++rep_) { n_gaps = 0;
     if (!whole) for (uint32_t c0 = 0; c0 + 1 < ns; c0 += EU * RTK_WAVE) {
         uint32_t a[EU], b2[EU];
         for (uint32_t u = 0; u < EU; ++u) { const uint32_t i = c0 + u * RTK_WAVE + static_cast<uint32_t>(rtk_lane()); const bool in = i + 1 < ns; a[u] = in ? sp[i] : 0u; b2[u] = in ? sp[i + 1] : 1u; }
         for (uint32_t u = 0; u < EU; ++u) n_gaps += static_cast<uint32_t>(rtk_popc(rtk_ballot(a[u] != b2[u] - 1u)));
+    }
     }
     const uint32_t total = whole ? 1u : ((sp[0] != 0 ? 1u : 0u) + n_gaps + 1u);
     unsigned long long first = 0;
