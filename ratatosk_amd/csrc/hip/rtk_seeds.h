@@ -1020,15 +1020,42 @@ static_assert(RTK_GQ % RTK_GH == 0, "a step is a whole number of halves");
     uint32_t n_keep = 0;
     if (nv) {
         const char* ref = bv.seq + base;
-        for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nv; i += RTK_WAVE) {
-            const uint64_t key = rtk_weak_key(ref, sc.vpos[i], sc.vcode[i], static_cast<int>(k));
-            sc.vkey[i] = key ? key : ~0ull; sc.vidx[i] = i; sc.vflag[i] = 0;
-        }
-        rtk_sync();
-        rtk_sort_pairs(sc.vkey, sc.vidx, nv);
         uint32_t nvalid = 0;
-        { // number of classified hits = first index with an all-ones key
-            uint32_t lo = 0, hi = nv; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.vkey[mid] == ~0ull) hi = mid; else lo = mid + 1; } nvalid = lo;
+#ifndef RTK_SIM
+        if (nv > RTK_LDS_SORT_CAP && L < (1u << 26)) {
+            // thousands of hits (the read that the launch waits for): the classified ones are compacted in hit order as (32-bit key, hit index) -- variant position,
+            // base mask and kind of the 64-bit key side by side -- and sorted by a stable radix sort (three passes for a 100 kb read; the bitonic network on
+            // 8 192 pairs was a third of that read's time); the group arrays, not in use yet, are the buffers
+            uint32_t* const Ka = sc.gstart.get(); uint32_t* const Ia = sc.gcnt.get(); uint32_t* const Kb = sc.gps.get(); uint32_t* const Ib = sc.gpe.get();
+            const uint64_t lt = (1ull << rtk_lane()) - 1ull;
+            for (uint32_t c0 = 0; c0 < nv; c0 += RTK_WAVE) {
+                const uint32_t i = c0 + static_cast<uint32_t>(rtk_lane());
+                uint64_t key = 0;
+                if (i < nv) { key = rtk_weak_key(ref, sc.vpos[i], sc.vcode[i], static_cast<int>(k)); sc.vflag[i] = 0; }
+                const bool ok = key != 0;
+                const uint64_t bal = rtk_ballot(ok);
+                if (ok) { const uint32_t j = nvalid + static_cast<uint32_t>(rtk_popc(bal & lt)); Ka[j] = static_cast<uint32_t>(((key >> 16) << 6) | (((key >> 8) & 15ull) << 2) | (key & 3ull)); Ia[j] = i; }
+                nvalid += static_cast<uint32_t>(rtk_popc(bal));
+            }
+            rtk_sync();
+            rtk_radix_sort_pairs_u32(Ka, Ia, Kb, Ib, nvalid, (L << 6) | 63u);
+            for (uint32_t j = static_cast<uint32_t>(rtk_lane()); j < nvalid; j += RTK_WAVE) {
+                const uint32_t K = Ka[j];
+                sc.vkey[j] = (static_cast<uint64_t>(K >> 6) << 16) | (static_cast<uint64_t>((K >> 2) & 15u) << 8) | static_cast<uint64_t>(K & 3u); sc.vidx[j] = Ia[j];
+            }
+            rtk_sync();
+        } else
+#endif
+        {
+            for (uint32_t i = static_cast<uint32_t>(rtk_lane()); i < nv; i += RTK_WAVE) {
+                const uint64_t key = rtk_weak_key(ref, sc.vpos[i], sc.vcode[i], static_cast<int>(k));
+                sc.vkey[i] = key ? key : ~0ull; sc.vidx[i] = i; sc.vflag[i] = 0;
+            }
+            rtk_sync();
+            rtk_sort_pairs(sc.vkey, sc.vidx, nv);
+            { // number of classified hits = first index with an all-ones key
+                uint32_t lo = 0, hi = nv; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sc.vkey[mid] == ~0ull) hi = mid; else lo = mid + 1; } nvalid = lo;
+            }
         }
         RTK_PHASE();
         // groups of equal key
