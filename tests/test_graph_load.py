@@ -171,10 +171,8 @@ def test_unitig_fasta_of_several_gzip_members(ds_small, tmp_path, monkeypatch):
                 assert (_host_buffer(g, name) == _host_buffer(ref, name)).all(), name
 
 
-@pytest.mark.gpu
-def test_gpu_resident_graph_moved_into_caller_buffers(ds_small):
-    """what rank 0 of a multi-GPU job does before it broadcasts (ratatosk_amd/dist.py): the graph is loaded and its tables are built in the library's own
-    HBM, then every flat buffer is moved into a torch tensor of its size; the graph answers as before and nothing is freed twice"""
+def _moved_into_caller_buffers(ds_small):
+    """body of test_gpu_resident_graph_moved_into_caller_buffers, run in a process of its own (torch first, then the library: ratatosk_amd/dist.py's order)"""
     import torch
     torch.zeros(1, device="cuda:0")
     dev = _load(ds_small, 31, True, upload=True)
@@ -194,3 +192,18 @@ def test_gpu_resident_graph_moved_into_caller_buffers(ds_small):
     assert p.value == tensors[_BUFS.index("ht")].data_ptr()
     dev.close()  # (the tensors outlive the graph: the library must not free them)
     assert int(tensors[0][:8].sum().item()) >= 0
+
+
+@pytest.mark.gpu
+def test_gpu_resident_graph_moved_into_caller_buffers(ds_small):
+    """what rank 0 of a multi-GPU job does before it broadcasts (ratatosk_amd/dist.py): the graph is loaded and its tables are built in the library's own
+    HBM, then every flat buffer is moved into a torch tensor of its size; the graph answers as before and nothing is freed twice. In a process of its
+    own: torch brings its own HIP runtime and has to be initialised before the library is loaded (as in dist.py and bench.py); in the test process the
+    library of the earlier tests is there first and torch then finds no device."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path[:0] = [%r, %r]; import torch; torch.zeros(1, device='cuda:0'); import test_graph_load as T; T._moved_into_caller_buffers(%r); print('moved ok')" % (here, os.path.dirname(here), ds_small)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "moved ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
