@@ -3,7 +3,7 @@ getSeeds restatement; bit-exact (pos, unitig, dist, strand) for solid and weak a
 import pytest
 
 from conftest import make_dataset
-from test_sim_seeds import _check
+from test_sim_seeds import _check, _check_gap_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -34,3 +34,8 @@ def test_gpu_seeds_mask_in_segments(ds_small, ds_clean, tmp_path, monkeypatch):
     assert _check(pre, 8, None) > 0
     assert _check(ds_small, 12, None) > 0
     _check(ds_clean, 10, None)
+
+
+def test_gpu_seeds_mask_gaps_across_segment_borders(ds_clean, ds_small, monkeypatch):
+    """the constructed reads of the simulator test, six times as long (45 kb: a dozen segments of 4096 windows, five of 8192)"""
+    _check_gap_reads((ds_clean, ds_small), 6, ("4096", "8192"), None, monkeypatch)

@@ -46,3 +46,45 @@ def test_sim_seeds_mask_in_segments(ds_small, ds_clean, monkeypatch):
         monkeypatch.setenv("RTK_MASK_SEG", seg)
         assert _check(ds_small, 12, SIM_LIB) > 0
         _check(ds_clean, 6, SIM_LIB)
+
+
+def _gap_reads(prefix, reps, seed=5):
+    """reads built for the mask's rules: stretches of the reference with stretches of random characters between them whose lengths run through the three
+    cases of a gap (shorter than half the insert size / between half and the whole of it / longer), + reads without hits at the head, at all, at the tail"""
+    import random
+    rnd = random.Random(seed)
+    junk = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+    ref = "".join(l.strip() for l in open(prefix + ".ref.fa") if not l.startswith(">"))
+    reads = []
+    for rep in range(3):
+        parts, p = [], rnd.randrange(0, 2000)
+        for r2 in range(reps):
+            for gap in (60, 130, 240, 250, 260, 300, 380, 460, 499, 500, 501, 640, 900):
+                ln = rnd.randrange(40, 330); parts.append(ref[p % (len(ref) - 400):p % (len(ref) - 400) + ln]); p += ln
+                parts.append(junk(gap + rnd.randrange(0, 3))); p += gap
+        reads.append("".join(parts))
+    reads.append(junk(700 * reps) + ref[3000:3400] + junk(300) + ref[3700:3900])   # first hit in a later segment
+    reads.append(junk(1500 * reps))                                                 # no hit at all
+    reads.append(ref[5000:5300] + junk(1200 * reps))                                # tail without hits
+    reads.append(ref[6000:6100] + junk(255) + ref[6355:6400] + junk(251) + ref[6651:6700])
+    return reads
+
+
+def _check_gap_reads(prefixes, reps, segs, lib_path, monkeypatch):
+    for prefix in prefixes:
+        fa, rt = prefix + ".index.k31.fasta.gz", prefix + ".index.k31.rtsk"
+        og = op.Graph(fa, rt, 31)
+        reads = _gap_reads(prefix, reps)
+        want = [og.seeds(s) for s in reads]
+        for seg in segs:
+            monkeypatch.setenv("RTK_MASK_SEG", seg)
+            pg = api.Graph(fa, rt, 31, device=0, lib_path=lib_path)
+            for s, w in zip(reads, want):
+                assert pg.seeds(s) == w, (prefix, seg, len(s))
+
+
+def test_sim_seeds_mask_gaps_across_segment_borders(ds_clean, ds_small, monkeypatch):
+    """Reads built for the mask's rules (src/Graph.cpp:102-191) and cut into segments of 64 windows: gaps of every kind start, end and lie across segment
+    borders; a read whose first hit comes after several segments without one (the head rule is applied by a later segment), one without any hit, one that
+    ends in a long stretch without hits (tail rule)."""
+    _check_gap_reads((ds_clean, ds_small), 1, ("64", "128", "8192"), SIM_LIB, monkeypatch)
