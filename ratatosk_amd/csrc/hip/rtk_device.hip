@@ -372,12 +372,36 @@ RTK_GLOBAL void k_lookup_exact(GraphView g, const char* seq, const uint64_t* rof
         // owning read: largest r with roff[r] <= b. One scalar search for the tile's first base; the other lanes step forward from it
         // (a tile rarely spans more than one read boundary).
         const uint32_t lo0 = rtk_owner_read(roff, n_reads, tile * RTK_WAVE);
+#ifndef RTK_SIM
+        // k <= 32: the 2-bit codes of the tile's 64 + 64 characters as bit planes (one character of each half per lane, three ballots per half: low bit, high
+        // bit, is-a-base); a lane's k-mer is k bits of each plane from its own position on, reversed (the first character sits in the high bits of a code)
+        // and interleaved. Packing the k characters from text in every lane (rtk_km_from_text: four unaligned words, two 64-bit multiplies each) was ~45 % of
+        // this kernel's issue slots.
+        RtkKm fw_t; fw_t.hi = 0; fw_t.lo = 0; bool ok_t = false; const bool planes = g.k <= 32;
+        if (planes) {
+            const uint64_t a0 = tile * RTK_WAVE + static_cast<uint64_t>(rtk_lane()), a1 = a0 + RTK_WAVE;
+            const unsigned char ca = a0 < n_bases + 64 ? static_cast<unsigned char>(seq[a0]) : 'N', cb = a1 < n_bases + 64 ? static_cast<unsigned char>(seq[a1]) : 'N'; // (the read buffer is padded by 64 bytes)
+            const bool va = ca == 'A' || ca == 'C' || ca == 'G' || ca == 'T', vb = cb == 'A' || cb == 'C' || cb == 'G' || cb == 'T';
+            const uint32_t b1a = (ca >> 1) & 1u, b2a = (ca >> 2) & 1u, b1b = (cb >> 1) & 1u, b2b = (cb >> 2) & 1u; // bits 1-2 of 'A' 0x41, 'C' 0x43, 'G' 0x47, 'T' 0x54: code = b2 : b1 ^ b2
+            const uint64_t L0a = rtk_ballot((b1a ^ b2a) != 0), L1a = rtk_ballot(b2a != 0), Va = rtk_ballot(va), L0b = rtk_ballot((b1b ^ b2b) != 0), L1b = rtk_ballot(b2b != 0), Vb = rtk_ballot(vb);
+            const int sh = rtk_lane(), k_ = g.k;
+            const uint64_t km = k_ < 64 ? ((1ull << k_) - 1ull) : ~0ull;
+            const uint64_t p0 = (sh ? ((L0a >> sh) | (L0b << (64 - sh))) : L0a) & km, p1 = (sh ? ((L1a >> sh) | (L1b << (64 - sh))) : L1a) & km, pv = (sh ? ((Va >> sh) | (Vb << (64 - sh))) : Va) & km;
+            ok_t = pv == km;
+            auto spread = [](uint64_t x) { x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull; x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full; x = (x | (x << 2)) & 0x3333333333333333ull; return (x | (x << 1)) & 0x5555555555555555ull; };
+            fw_t.lo = (spread(rtk_brev64(p1) >> (64 - k_)) << 1) | spread(rtk_brev64(p0) >> (64 - k_));
+        }
+#endif
         if (b < n_bases) {
             uint32_t lo = lo0;
             while (lo + 1 < n_reads && roff[lo + 1] <= b) ++lo;
             if (b + static_cast<uint64_t>(g.k) <= roff[lo + 1]) {
-                RtkKm fw; // the read buffer is padded by 64 bytes
-                if (rtk_km_from_text(reinterpret_cast<const unsigned char*>(seq) + b, g.k, &fw)) { uint32_t np; h = rtk_find_km(g, fw, &np); probes += 1; slots += np; }
+                RtkKm fw; bool ok; // the read buffer is padded by 64 bytes
+#ifndef RTK_SIM
+                if (planes) { fw = fw_t; ok = ok_t; } else
+#endif
+                ok = rtk_km_from_text(reinterpret_cast<const unsigned char*>(seq) + b, g.k, &fw);
+                if (ok) { uint32_t np; h = rtk_find_km(g, fw, &np); probes += 1; slots += np; }
             }
 #if defined(RTK_SIM) || defined(RTK_NO_NT_STORES)
             hits[b] = h;
