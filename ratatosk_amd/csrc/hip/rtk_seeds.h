@@ -785,6 +785,22 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
             const uint32_t my_c0 = cc + 64u * lane;
             const uint64_t my_cur = (my_c0 < nwin) ? rtk_hit_bits(hmap, base + my_c0, nwin - my_c0) : 0ull;
             const uint64_t my_nxt = (my_c0 + 64 < nwin) ? rtk_hit_bits(hmap, base + my_c0 + 64, nwin - my_c0 - 64) : 0ull;
+#ifndef RTK_SIM
+            { // Every lane judges the 64 windows of ITS block with 128-bit shifts: window x is dropped iff a run of hits STARTS at x + 2 .. x + k - 1 (a one above a
+              // zero in the presence bits behind x), i.e. iff the run starts T, OR-ed over a sliding window of k - 2 positions (doubling), have a bit at x + 2.
+              // The sixty-four blocks of a step were visited one after the other, one window per lane (two 64-bit shuffles, a ballot and a store per block).
+                const uint64_t Tl = my_cur & ~(my_cur << 1), Th = my_nxt & ~((my_nxt << 1) | (my_cur >> 63)); // (a start at bit 0 or 1 of the block is never asked for)
+                uint64_t Rl = Tl, Rh = Th; uint32_t have = 1; const uint32_t w = k - 2;
+                auto or_shifted = [&](uint32_t sft) { const uint64_t sl = (Rl >> sft) | (Rh << (64u - sft)), sh = Rh >> sft; Rl |= sl; Rh |= sh; }; // 0 < sft < 64
+                while (2u * have <= w) { or_shifted(have); have *= 2u; }
+                if (have < w) or_shifted(w - have);
+                const uint64_t keep = my_cur & ~((Rl >> 2) | (Rh << 62));
+                int total = 0; const uint32_t off = static_cast<uint32_t>(rtk_wave_excl_scan(rtk_popc(keep), &total));
+                uint32_t o = n1 + off;
+                for (uint64_t m = keep; m; m &= m - 1ull) s_pos[o++] = my_c0 + static_cast<uint32_t>(__builtin_ctzll(m));
+                n1 += static_cast<uint32_t>(rtk_u(total));
+            }
+#else
             for (int bl = 0; bl < RTK_WAVE; ++bl) {
                 const uint32_t c0 = cc + 64u * static_cast<uint32_t>(bl);
                 if (c0 >= nwin) break;
@@ -807,6 +823,7 @@ RTK_FN void rtk_finalize_read(const GraphView& g, const OptsView& o, const Batch
                 n1 += static_cast<uint32_t>(rtk_popc(bal));
 #endif
             }
+#endif
         }
     }
     rtk_sync();
