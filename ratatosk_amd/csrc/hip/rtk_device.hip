@@ -18,6 +18,7 @@
 #include "rtk_graph_tables.h"
 #include "rtk_mem.h"
 #include "rtk_myers.h"
+#include "rtk_myers_lane.h"
 #include "rtk_types.h"
 #include "rtk_wave.h"
 
@@ -539,7 +540,9 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
         if (waves > 1) rtk_launch_myers_batch_waves(grid, waves, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst, dprof);
         else
 #endif
-        rtk_launch(k_myers_batch, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst, dprof);
+        { RtkTimer tk; const bool timed = getenv("RTK_MYERS_TIME") != nullptr && waves <= 1; if (timed) tk.start(0);
+          rtk_launch(k_myers_batch, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, cfg, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst, dprof);
+          if (timed) { tk.stop(0); rtk_dsync(); fprintf(stderr, "[rtk myers time] one wave per problem: %u problems, %d waves, kernel %.3f ms\n", n, grid, tk.elapsed()); } }
         if (dprof) { rtk_dsync(); unsigned long long pc[8]; rtk_d2h(pc, dprof, 64); rtk_dfree(dprof);
             fprintf(stderr, "[rtk myers prof] waves %d: Hirschberg driver %.3g cycles (half passes %.3g, columns + split %.3g, leaf tracebacks %.3g of which walks %.3g)\n", waves, double(pc[0]), double(pc[1]), double(pc[2]), double(pc[3]), double(pc[4])); }
         rtk_dsync();
@@ -562,6 +565,65 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
         }
         rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dmoves); rtk_dfree(dnm); rtk_dfree(dst);
         return rc;
+    } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
+}
+
+// ---- stage entry rtk_myers_batch_lanes: one problem per LANE (csrc/hip/rtk_myers_lane.h) ----
+RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const char* pool, char* scratch, uint64_t stride, int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint32_t* status) {
+    char* const area = scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * stride;
+    uint64_t* const peq = reinterpret_cast<uint64_t*>(area) + rtk_lane();
+    int32_t* const cs = reinterpret_cast<int32_t*>(area + 8ull * RTK_ML_MAXSYM * RTK_ML_MAXW * RTK_WAVE) + rtk_lane();
+    for (uint64_t i0 = static_cast<uint64_t>(RTK_BLOCK_ID) * RTK_WAVE; i0 < n; i0 += static_cast<uint64_t>(grid) * RTK_WAVE) {
+        const uint64_t i = i0 + static_cast<uint64_t>(rtk_lane());
+        if (i >= n) continue;
+        const MyersProb p = probs[i];
+        int32_t d = -1, nl = 0;
+        status[i] = rtk_myers_lane(pool + p.q_off, static_cast<int>(p.qlen), pool + p.t_off, static_cast<int>(p.tlen), p.k, p.mode, peq, cs, &d, &nl, cap_locs ? end_locs + i * cap_locs : nullptr, static_cast<int>(cap_locs));
+        dist[i] = d; n_loc[i] = nl;
+    }
+}
+
+extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
+                                     const int32_t* k, const int32_t* mode, int use_iupac, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs) {
+    if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || (!end_locs && cap_locs)) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch_lanes: null argument");
+    if (rtk_device_count() <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_myers_batch_lanes: no HIP device visible (no CPU fallback)");
+    if (n == 0) return RTK_OK;
+    if (use_iupac) return rtk_myers_batch(n, query, qlen, target, tlen, k, mode, 0, use_iupac, dist, n_loc, end_locs, cap_locs, nullptr, 0); // (IUPAC equality: the wave route)
+    try {
+        std::vector<MyersProb> probs(n);
+        std::string pool;
+        for (uint32_t i = 0; i < n; ++i) {
+            probs[i].q_off = pool.size(); pool.append(query[i], qlen[i]);
+            probs[i].t_off = pool.size(); pool.append(target[i], tlen[i]);
+            probs[i].qlen = qlen[i]; probs[i].tlen = tlen[i]; probs[i].k = k[i]; probs[i].mode = mode[i];
+        }
+        const uint64_t stride = rtk_ml_scratch_bytes();
+        const int grid = static_cast<int>(std::min<uint64_t>((static_cast<uint64_t>(n) + RTK_WAVE - 1) / RTK_WAVE, static_cast<uint64_t>(default_grid())));
+        char* dpool = static_cast<char*>(rtk_dmalloc(pool.size() + 64));
+        MyersProb* dprobs = static_cast<MyersProb*>(rtk_dmalloc(sizeof(MyersProb) * n));
+        char* dscr = static_cast<char*>(rtk_dmalloc(stride * grid));
+        int32_t* ddist = static_cast<int32_t*>(rtk_dmalloc(4ull * n)); int32_t* dnloc = static_cast<int32_t*>(rtk_dmalloc(4ull * n));
+        int32_t* dlocs = static_cast<int32_t*>(rtk_dmalloc(4ull * n * cap_locs + 8)); uint32_t* dst = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
+        rtk_h2d(dpool, pool.data(), pool.size()); rtk_h2d(dprobs, probs.data(), sizeof(MyersProb) * n);
+        { RtkTimer tk; const bool timed = getenv("RTK_MYERS_TIME") != nullptr; if (timed) tk.start(0);
+          rtk_launch(k_myers_batch_lanes, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), dscr, stride, grid, ddist, dnloc, dlocs, cap_locs, dst);
+          if (timed) { tk.stop(0); rtk_dsync(); fprintf(stderr, "[rtk myers time] one lane per problem: %u problems, %d waves, kernel %.3f ms\n", n, grid, tk.elapsed()); } }
+        rtk_dsync();
+        std::vector<uint32_t> st(n);
+        rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); if (cap_locs) rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs); rtk_d2h(st.data(), dst, 4ull * n);
+        rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dst);
+        // the problems that are not for this route (query above 512 characters, target above 2048, more than 8 distinct target characters): one wave each
+        std::vector<uint32_t> rest; for (uint32_t i = 0; i < n; ++i) if (st[i]) rest.push_back(i);
+        if (getenv("RTK_MYERS_TIME")) fprintf(stderr, "[rtk myers time] %zu of %u problems handed on to the wave route\n", rest.size(), n);
+        if (!rest.empty()) {
+            const uint32_t nr = static_cast<uint32_t>(rest.size());
+            std::vector<const char*> q2(nr), t2(nr); std::vector<uint32_t> ql2(nr), tl2(nr); std::vector<int32_t> k2(nr), m2(nr), d2(nr), nl2(nr), loc2(static_cast<size_t>(nr) * cap_locs + 1);
+            for (uint32_t x = 0; x < nr; ++x) { const uint32_t i = rest[x]; q2[x] = query[i]; t2[x] = target[i]; ql2[x] = qlen[i]; tl2[x] = tlen[i]; k2[x] = k[i]; m2[x] = mode[i]; }
+            const int rc = rtk_myers_batch(nr, q2.data(), ql2.data(), t2.data(), tl2.data(), k2.data(), m2.data(), 0, 0, d2.data(), nl2.data(), loc2.data(), cap_locs, nullptr, 0);
+            if (rc != RTK_OK) return rc;
+            for (uint32_t x = 0; x < nr; ++x) { const uint32_t i = rest[x]; dist[i] = d2[x]; n_loc[i] = nl2[x]; for (uint32_t y = 0; y < cap_locs; ++y) end_locs[static_cast<size_t>(i) * cap_locs + y] = loc2[static_cast<size_t>(x) * cap_locs + y]; }
+        }
+        return RTK_OK;
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
 }
 

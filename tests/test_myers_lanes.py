@@ -1,0 +1,74 @@
+"""One alignment per lane (csrc/hip/rtk_myers_lane.h, stage entry rtk_myers_batch_lanes): distance and end locations of edlibAlign for the small problems
+of the region program, held to the reference's golden vectors (those without IUPAC codes: equality is plain there) and to the oracle on random problems --
+plain and with other characters, thresholds k, the three modes, zero lengths, and the problems the route hands on to the wave route (query above 512
+characters, more than 8 distinct target characters). The code of a lane has no cross-lane operation, so the 1-lane simulator runs exactly what a lane of
+the device runs; the gpu test runs the same problems 64 per wavefront."""
+import random
+
+import pytest
+
+from conftest import SIM_LIB, golden_rows
+from oracle import oracle_py as op
+from ratatosk_amd import api
+
+
+def _problems():
+    rnd = random.Random(11)
+    qs, ts, ks, ms = [], [], [], []
+
+    def mutate(s, rate, alpha):
+        out = []
+        for c in s:
+            r = rnd.random()
+            if r < rate / 3:
+                continue
+            if r < 2 * rate / 3:
+                out.append(rnd.choice(alpha))
+            if r < rate:
+                out.append(rnd.choice(alpha)); continue
+            out.append(c)
+        return "".join(out)
+    for i in range(700):
+        alpha = "ACGT" if i % 5 else ("ACGTN" if i % 10 else "ACGTNRYKMSW")  # the last one: more than 8 distinct characters now and then
+        m = rnd.choice((1, 5, 31, 63, 64, 65, 100, 128, 129, 200, 255, 256, 300, 511, 512, 513, 700))
+        q = "".join(rnd.choice(alpha) for _ in range(m))
+        mode = i % 3
+        if mode == 0:
+            t = mutate(q, rnd.choice((0.0, 0.05, 0.15, 0.4)), alpha)
+        else:
+            core = mutate(q, rnd.choice((0.0, 0.1, 0.3)), alpha)
+            t = "".join(rnd.choice(alpha) for _ in range(rnd.randrange(0, 80))) + core + "".join(rnd.choice(alpha) for _ in range(rnd.randrange(0, 80)))
+        if i % 97 == 0:
+            t = ""
+        if i % 101 == 0:
+            q = ""
+        qs.append(q); ts.append(t); ms.append(mode)
+        ks.append(-1 if i % 4 else rnd.choice((0, 3, 10, 40, 200)))
+    return qs, ts, ks, ms
+
+
+def _check(lib):
+    rows = [r for r in golden_rows() if not r["path"] and set(r["q"] + r["t"]) <= set("ACGT")]
+    assert len(rows) > 100
+    res = api.myers_batch([r["q"] for r in rows], [r["t"] for r in rows], [r["k"] for r in rows], [r["mode"] for r in rows], use_iupac=False, lib_path=lib, lanes=True)
+    for r, (d, locs, _) in zip(rows, res):
+        assert d == r["d"] and locs == r["locs"], (r["q"][:40], r["t"][:40], r["k"], r["mode"])
+    qs, ts, ks, ms = _problems()
+    res = api.myers_batch(qs, ts, ks, ms, use_iupac=False, lib_path=lib, lanes=True)
+    for q, t, k, mode, (d, locs, _) in zip(qs, ts, ks, ms, res):
+        w = op.myers(q, t, k, mode, False, iupac=False)
+        assert (d, locs) == (w[0], w[1]), (len(q), len(t), k, mode)
+    # IUPAC equality is the wave route's: same entry, same answers
+    rows = [r for r in golden_rows() if not r["path"]][:200]
+    res = api.myers_batch([r["q"] for r in rows], [r["t"] for r in rows], [r["k"] for r in rows], [r["mode"] for r in rows], use_iupac=True, lib_path=lib, lanes=True)
+    for r, (d, locs, _) in zip(rows, res):
+        assert d == r["d"] and locs == r["locs"]
+
+
+def test_sim_myers_one_problem_per_lane():
+    _check(SIM_LIB)
+
+
+@pytest.mark.gpu
+def test_gpu_myers_one_problem_per_lane():
+    _check(None)
