@@ -211,7 +211,7 @@ int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* 
                           int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar, int waves);
 
 /* The distance part of rtk_myers_batch (dist, n_loc, end_locs; no path) with ONE PROBLEM PER LANE: queries of up to 512 characters against targets of up to 2048
- * with at most 8 distinct characters are computed column by column in a lane's registers, 64 problems per wavefront (csrc/hip/rtk_myers_lane.h); what does not
+ * over A, C, G, T, N are computed column by column in a lane's registers, 64 problems per wavefront (csrc/hip/rtk_myers_lane.h); what does not
  * fit that (and every problem when use_iupac is set) takes the wave route of rtk_myers_batch. Same results (reference: edlibAlign, src/edlib.cpp:131-296).
  * Stage entry: the building block of a lane-per-region region kernel, for parity tests and timing; the correction path does not call it. */
 int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,

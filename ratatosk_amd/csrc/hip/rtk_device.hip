@@ -570,9 +570,13 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
 
 // ---- stage entry rtk_myers_batch_lanes: one problem per LANE (csrc/hip/rtk_myers_lane.h) ----
 RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const char* pool, char* scratch, uint64_t stride, int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint32_t* status) {
-    char* const area = scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * stride;
-    uint64_t* const peq = reinterpret_cast<uint64_t*>(area) + rtk_lane();
-    int32_t* const cs = reinterpret_cast<int32_t*>(area + 8ull * RTK_ML_MAXSYM * RTK_ML_MAXW * RTK_WAVE) + rtk_lane();
+#ifdef RTK_SIM
+    static thread_local uint64_t lpeq[RTK_ML_PEQ_WORDS];
+#else
+    __shared__ uint64_t lpeq[RTK_ML_PEQ_WORDS]; // 20 KB per wave: the match vectors of its 64 problems
+#endif
+    uint64_t* const peq = lpeq + rtk_lane();
+    int32_t* const cs = reinterpret_cast<int32_t*>(scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * stride) + rtk_lane();
     for (uint64_t i0 = static_cast<uint64_t>(RTK_BLOCK_ID) * RTK_WAVE; i0 < n; i0 += static_cast<uint64_t>(grid) * RTK_WAVE) {
         const uint64_t i = i0 + static_cast<uint64_t>(rtk_lane());
         if (i >= n) continue;
@@ -612,7 +616,7 @@ extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const
         std::vector<uint32_t> st(n);
         rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); if (cap_locs) rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs); rtk_d2h(st.data(), dst, 4ull * n);
         rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dst);
-        // the problems that are not for this route (query above 512 characters, target above 2048, more than 8 distinct target characters): one wave each
+        // the problems that are not for this route (query above 512 characters, target above 2048 or with a character outside ACGTN): one wave each
         std::vector<uint32_t> rest; for (uint32_t i = 0; i < n; ++i) if (st[i]) rest.push_back(i);
         if (getenv("RTK_MYERS_TIME")) fprintf(stderr, "[rtk myers time] %zu of %u problems handed on to the wave route\n", rest.size(), n);
         if (!rest.empty()) {

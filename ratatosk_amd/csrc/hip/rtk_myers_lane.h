@@ -8,13 +8,26 @@
 #define RTK_MYERS_LANE_H
 
 #define RTK_ML_MAXW 8      // words of the query (512 characters)
-#define RTK_ML_MAXSYM 8    // distinct characters of the target
+#define RTK_ML_NSYM 5      // target characters of this route: A C T G N (anything else in the target: wave route)
 #define RTK_ML_MAXN 2048   // characters of the target
 
-// bytes of work area per wave: the match vectors of MAXSYM characters and the last-row score of every column, interleaved by lane
-RTK_HD uint64_t rtk_ml_scratch_bytes() { return static_cast<uint64_t>(RTK_WAVE) * (8ull * RTK_ML_MAXSYM * RTK_ML_MAXW + 4ull * RTK_ML_MAXN); }
+// bytes of work area per wave in device memory: the last-row score of every column, interleaved by lane (SHW / HW list every column with the best score)
+RTK_HD uint64_t rtk_ml_scratch_bytes() { return static_cast<uint64_t>(RTK_WAVE) * 4ull * RTK_ML_MAXN; }
+// words of match vectors per wave (LDS on the device: [symbol][word][lane], a lane's words are 64 apart: no bank conflicts)
+#define RTK_ML_PEQ_WORDS (RTK_ML_NSYM * RTK_ML_MAXW * RTK_WAVE)
 
-// returns 0 = done (dist / nloc / locs written), 1 = not a problem for this route (too long, too many distinct characters): the caller takes the wave route
+RTK_DEV uint64_t rtk_ml_ld8(const char* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; } // (the texts are read eight characters at a time; the pool is padded by 64 bytes)
+// bit j = byte j of x equals c
+RTK_DEV uint64_t rtk_ml_eq8(uint64_t x, uint64_t c) {
+    const uint64_t y = x ^ (c * 0x0101010101010101ull);
+    const uint64_t z = ~(((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y) & 0x8080808080808080ull;
+    return ((z >> 7) * 0x0102040810204080ull) >> 56;
+}
+// 0 A, 1 C, 2 T, 3 G ((c >> 1) & 3), 4 N; 5 = not a character of this route
+RTK_DEV int rtk_ml_sym(uint32_t c) { return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? static_cast<int>((c >> 1) & 3u) : (c == 'N' ? 4 : 5); }
+
+// returns 0 = done (dist / nloc / locs written), 1 = not a problem for this route (too long, a target character outside ACGTN): the caller takes the wave route.
+// peq: this lane's slice of the wave's match vectors (word (s * MAXW + w) at peq[(s * MAXW + w) * RTK_WAVE]); cs: its slice of the column scores.
 RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int k, int mode, uint64_t* peq, int32_t* cs, int32_t* dist, int32_t* nloc, int32_t* locs, int cap) {
     *dist = -1; *nloc = 0;
     if (m == 0 || n == 0) { // edlib.cpp:161-179
@@ -24,33 +37,34 @@ RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int 
     if (m > 64 * RTK_ML_MAXW || n > RTK_ML_MAXN) return 1u;
     if (mode == RTK_MODE_NW && k >= 0 && k < (n > m ? n - m : m - n)) return 0u; // edlib.cpp:744-747
     const int W = (m + 63) >> 6, last_bit = (m - 1) & 63;
-    // the distinct characters of the target (packed, one byte each) and their match vectors
-    uint64_t syms = 0; int ns = 0;
-    for (int j = 0; j < n; ++j) {
-        const uint64_t c = static_cast<unsigned char>(t[j]);
-        bool seen = false;
-        for (int s = 0; s < ns; ++s) seen = seen || ((syms >> (8 * s)) & 0xFFull) == c;
-        if (seen) continue;
-        if (ns == RTK_ML_MAXSYM) return 1u;
-        for (int w = 0; w < W; ++w) {
-            uint64_t bits = 0; const int i1 = (64 * w + 64 < m) ? 64 * w + 64 : m;
-            for (int i = 64 * w; i < i1; ++i) bits |= static_cast<uint64_t>(static_cast<unsigned char>(q[i]) == c ? 1u : 0u) << (i & 63);
-            peq[static_cast<uint64_t>(ns * RTK_ML_MAXW + w) * RTK_WAVE] = bits;
+    // match vectors of the five characters: eight query characters per load, eight bits per character and load
+    for (int w = 0; w < W; ++w) {
+        uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
+        for (int g = 0; g < 8 && 64 * w + 8 * g < m; ++g) {
+            const uint64_t x = rtk_ml_ld8(q + 64 * w + 8 * g); const int sh = 8 * g;
+            e0 |= rtk_ml_eq8(x, 'A') << sh; e1 |= rtk_ml_eq8(x, 'C') << sh; e2 |= rtk_ml_eq8(x, 'T') << sh; e3 |= rtk_ml_eq8(x, 'G') << sh; e4 |= rtk_ml_eq8(x, 'N') << sh;
         }
-        syms |= c << (8 * ns); ++ns;
+        const uint64_t keep = (w == W - 1 && last_bit < 63) ? ((2ull << last_bit) - 1ull) : ~0ull; // (characters behind the query's end match nothing)
+        peq[static_cast<uint64_t>(0 * RTK_ML_MAXW + w) * RTK_WAVE] = e0 & keep; peq[static_cast<uint64_t>(1 * RTK_ML_MAXW + w) * RTK_WAVE] = e1 & keep;
+        peq[static_cast<uint64_t>(2 * RTK_ML_MAXW + w) * RTK_WAVE] = e2 & keep; peq[static_cast<uint64_t>(3 * RTK_ML_MAXW + w) * RTK_WAVE] = e3 & keep;
+        peq[static_cast<uint64_t>(4 * RTK_ML_MAXW + w) * RTK_WAVE] = e4 & keep;
     }
     uint64_t Pv[RTK_ML_MAXW], Mv[RTK_ML_MAXW];
 #pragma unroll
     for (int w = 0; w < RTK_ML_MAXW; ++w) { Pv[w] = ~0ull; Mv[w] = 0ull; }
     int score = m, best = 0x7fffffff;
     const int top_h = (mode == RTK_MODE_HW) ? 0 : 1;
+    const bool every_column = mode != RTK_MODE_NW;
+    uint64_t tw = 0;
     for (int j = 0; j < n; ++j) {
-        const uint64_t c = static_cast<unsigned char>(t[j]);
-        int s = 0; for (int x = 1; x < ns; ++x) if (((syms >> (8 * x)) & 0xFFull) == c) s = x;
+        if ((j & 7) == 0) tw = rtk_ml_ld8(t + j);
+        const int s = rtk_ml_sym(static_cast<uint32_t>(tw & 0xFFull)); tw >>= 8;
+        if (s > 4) return 1u;
+        const uint64_t* const e = peq + static_cast<uint64_t>(s * RTK_ML_MAXW) * RTK_WAVE;
         int hin = top_h;
 #pragma unroll
         for (int w = 0; w < RTK_ML_MAXW; ++w) if (w < W) { // edlib.cpp:586-677, one word
-            uint64_t Eq = peq[static_cast<uint64_t>(s * RTK_ML_MAXW + w) * RTK_WAVE];
+            uint64_t Eq = e[static_cast<uint64_t>(w) * RTK_WAVE];
             const uint64_t pv = Pv[w], mv = Mv[w];
             const uint64_t Xv = Eq | mv;
             if (hin < 0) Eq |= 1ull;
@@ -64,8 +78,7 @@ RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int 
             hin = hout;
         }
         score += hin;
-        cs[static_cast<uint64_t>(j) * RTK_WAVE] = score;
-        best = score < best ? score : best;
+        if (every_column) { cs[static_cast<uint64_t>(j) * RTK_WAVE] = score; best = score < best ? score : best; }
     }
     if (mode == RTK_MODE_NW) {
         if (k >= 0 && score > k) return 0u;

@@ -1,7 +1,7 @@
 """One alignment per lane (csrc/hip/rtk_myers_lane.h, stage entry rtk_myers_batch_lanes): distance and end locations of edlibAlign for the small problems
 of the region program, held to the reference's golden vectors (those without IUPAC codes: equality is plain there) and to the oracle on random problems --
 plain and with other characters, thresholds k, the three modes, zero lengths, and the problems the route hands on to the wave route (query above 512
-characters, more than 8 distinct target characters). The code of a lane has no cross-lane operation, so the 1-lane simulator runs exactly what a lane of
+characters, a target character outside ACGTN). The code of a lane has no cross-lane operation, so the 1-lane simulator runs exactly what a lane of
 the device runs; the gpu test runs the same problems 64 per wavefront."""
 import random
 
@@ -29,7 +29,7 @@ def _problems():
             out.append(c)
         return "".join(out)
     for i in range(700):
-        alpha = "ACGT" if i % 5 else ("ACGTN" if i % 10 else "ACGTNRYKMSW")  # the last one: more than 8 distinct characters now and then
+        alpha = "ACGT" if i % 5 else ("ACGTN" if i % 10 else "ACGTNRYKMSW")  # the last one: target characters that are not for the lane route
         m = rnd.choice((1, 5, 31, 63, 64, 65, 100, 128, 129, 200, 255, 256, 300, 511, 512, 513, 700))
         q = "".join(rnd.choice(alpha) for _ in range(m))
         mode = i % 3
