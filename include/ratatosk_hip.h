@@ -210,12 +210,14 @@ int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* 
                           const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
                           int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar, int waves);
 
-/* The distance part of rtk_myers_batch (dist, n_loc, end_locs; no path) with ONE PROBLEM PER LANE: queries of up to 512 characters against targets of up to 2048
- * over A, C, G, T, N are computed column by column in a lane's registers, 64 problems per wavefront (csrc/hip/rtk_myers_lane.h); what does not
- * fit that (and every problem when use_iupac is set) takes the wave route of rtk_myers_batch. Same results (reference: edlibAlign, src/edlib.cpp:131-296).
- * Stage entry: the building block of a lane-per-region region kernel, for parity tests and timing; the correction path does not call it. */
+/* rtk_myers_batch with ONE PROBLEM PER LANE: queries of up to 512 characters against targets of up to 2048 over A, C, G, T, N are computed column by column in a
+ * lane's registers, 64 problems per wavefront (csrc/hip/rtk_myers_lane.h); with want_path the lane keeps the delta vectors of its columns (up to 4096
+ * word-columns) and walks them back. What does not fit that (and every problem when use_iupac is set) takes the wave route of rtk_myers_batch. Same results
+ * (reference: edlibAlign, src/edlib.cpp:131-296). Stage entry: the building block of a lane-per-region region kernel, for parity tests and
+ * timing; the correction path does not call it. */
 int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
-                          const int32_t* k, const int32_t* mode, int use_iupac, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs);
+                          const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
+                          int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar);
 
 /* Index build, device side (the reference builds its index on the CPU: `Ratatosk index`, src/Ratatosk.cpp:1066-1067, Bifrost
  * build + addCoverage src/Graph.cpp:1561). rtk_index_count_kmers: the canonical k-mers (odd k <= 31, A=0 C=1 G=2 T=3, first base in the

@@ -98,8 +98,7 @@ def load_library(path=None):
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int,
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32, C.c_char_p, C.c_uint32]
     L.rtk_myers_batch_waves.argtypes = L.rtk_myers_batch.argtypes + [C.c_int]
-    L.rtk_myers_batch_lanes.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                        C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32]
+    L.rtk_myers_batch_lanes.argtypes = L.rtk_myers_batch.argtypes
     L.rtk_myers_batch_lanes.restype = C.c_int
     L.rtk_free.argtypes = [C.c_void_p]
     _libs[path] = L
@@ -260,8 +259,8 @@ class Batch:
 
 
 def myers_batch(queries, targets, ks=None, modes=None, want_path=False, use_iupac=True, lib_path=None, waves=0, lanes=False):
-    """edlibAlign over a batch on the device: returns [(editDistance, endLocations, cigar)]. lanes=True: one problem per lane (distance and end
-    locations only; stage entry rtk_myers_batch_lanes)."""
+    """edlibAlign over a batch on the device: returns [(editDistance, endLocations, cigar)]. lanes=True: one problem per lane (stage entry
+    rtk_myers_batch_lanes)."""
     L = load_library(lib_path)
     n = len(queries)
     bq = [_b(q) for q in queries]; bt = [_b(t) for t in targets]
@@ -274,10 +273,8 @@ def myers_batch(queries, targets, ks=None, modes=None, want_path=False, use_iupa
     cap_cig = 4 * (max((len(x) for x in bq), default=0) + max((len(x) for x in bt), default=0)) + 16
     dist = (C.c_int32 * n)(); nloc = (C.c_int32 * n)(); locs = (C.c_int32 * (n * cap_locs))()
     cig = C.create_string_buffer(n * cap_cig) if want_path else None
-    if lanes:
-        if want_path:
-            raise RtkError("myers_batch: lanes=True computes distances and end locations, no path")
-        rc = L.rtk_myers_batch_lanes(n, qa, ql, ta, tl, ka, ma, 1 if use_iupac else 0, dist, nloc, locs, cap_locs)
+    if lanes:  # one problem per lane (stage entry; csrc/hip/rtk_myers_lane.h)
+        rc = L.rtk_myers_batch_lanes(n, qa, ql, ta, tl, ka, ma, 1 if want_path else 0, 1 if use_iupac else 0, dist, nloc, locs, cap_locs, cig, cap_cig)
     elif waves > 1:  # the multi-wave schedule of the second pass's whole-read alignment (stage entry)
         rc = L.rtk_myers_batch_waves(n, qa, ql, ta, tl, ka, ma, 1 if want_path else 0, 1 if use_iupac else 0, dist, nloc, locs, cap_locs, cig, cap_cig, waves)
     else:

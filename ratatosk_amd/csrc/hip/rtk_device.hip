@@ -569,63 +569,95 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
 }
 
 // ---- stage entry rtk_myers_batch_lanes: one problem per LANE (csrc/hip/rtk_myers_lane.h) ----
-RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const char* pool, char* scratch, uint64_t stride, int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, uint32_t* status) {
+RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const char* pool, int want_path, char* scratch, uint64_t stride, int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs,
+                                    uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status) {
 #ifdef RTK_SIM
     static thread_local uint64_t lpeq[RTK_ML_PEQ_WORDS];
 #else
     __shared__ uint64_t lpeq[RTK_ML_PEQ_WORDS]; // 20 KB per wave: the match vectors of its 64 problems
 #endif
     uint64_t* const peq = lpeq + rtk_lane();
-    int32_t* const cs = reinterpret_cast<int32_t*>(scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * stride) + rtk_lane();
+    char* const area = scratch + static_cast<uint64_t>(RTK_BLOCK_ID) * stride;
+    int32_t* const cs = reinterpret_cast<int32_t*>(area) + rtk_lane();
+    uint64_t* const tb = reinterpret_cast<uint64_t*>(area + rtk_ml_scratch_bytes()) + rtk_lane(); // (only there when want_path)
     for (uint64_t i0 = static_cast<uint64_t>(RTK_BLOCK_ID) * RTK_WAVE; i0 < n; i0 += static_cast<uint64_t>(grid) * RTK_WAVE) {
         const uint64_t i = i0 + static_cast<uint64_t>(rtk_lane());
         if (i >= n) continue;
         const MyersProb p = probs[i];
-        int32_t d = -1, nl = 0;
-        status[i] = rtk_myers_lane(pool + p.q_off, static_cast<int>(p.qlen), pool + p.t_off, static_cast<int>(p.tlen), p.k, p.mode, peq, cs, &d, &nl, cap_locs ? end_locs + i * cap_locs : nullptr, static_cast<int>(cap_locs));
-        dist[i] = d; n_loc[i] = nl;
+        const int m = static_cast<int>(p.qlen), tn = static_cast<int>(p.tlen);
+        int32_t d = -1, nl = 0, first = -1; uint32_t nm = 0;
+        uint32_t st = rtk_myers_lane(pool + p.q_off, m, pool + p.t_off, tn, p.k, p.mode, peq, cs, &d, &nl, cap_locs ? end_locs + i * cap_locs : nullptr, static_cast<int>(cap_locs), &first);
+        if (st == 0u && want_path && d >= 0 && m > 0 && tn > 0) { // edlib.cpp:271-284: the whole query against target[0 .. first end location]
+            uint8_t* const mv = moves_out + i * cap_moves;
+            if (first + 1 == 0) { if (static_cast<uint32_t>(m) > cap_moves) st = 1u; else { for (int x = 0; x < m; ++x) mv[x] = 1; nm = static_cast<uint32_t>(m); } } // (the padded block's position -1: nothing of the target)
+            else st = rtk_myers_lane_path(m, pool + p.t_off, first + 1, peq, tb, mv, cap_moves, &nm);
+        }
+        status[i] = st; dist[i] = d; n_loc[i] = nl; n_moves_out[i] = nm;
     }
 }
 
 extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
-                                     const int32_t* k, const int32_t* mode, int use_iupac, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs) {
+                                     const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
+                                     int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar) {
     if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || (!end_locs && cap_locs)) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch_lanes: null argument");
     if (rtk_device_count() <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_myers_batch_lanes: no HIP device visible (no CPU fallback)");
     if (n == 0) return RTK_OK;
-    if (use_iupac) return rtk_myers_batch(n, query, qlen, target, tlen, k, mode, 0, use_iupac, dist, n_loc, end_locs, cap_locs, nullptr, 0); // (IUPAC equality: the wave route)
+    if (use_iupac) return rtk_myers_batch(n, query, qlen, target, tlen, k, mode, want_path, use_iupac, dist, n_loc, end_locs, cap_locs, cigar, cap_cigar); // (IUPAC equality: the wave route)
     try {
         std::vector<MyersProb> probs(n);
         std::string pool;
+        uint32_t max_q = 1, max_t = 1;
         for (uint32_t i = 0; i < n; ++i) {
             probs[i].q_off = pool.size(); pool.append(query[i], qlen[i]);
             probs[i].t_off = pool.size(); pool.append(target[i], tlen[i]);
             probs[i].qlen = qlen[i]; probs[i].tlen = tlen[i]; probs[i].k = k[i]; probs[i].mode = mode[i];
+            if (mode[i] == RTK_MODE_HW && want_path) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_myers_batch_lanes: HW path alignment is not on the hot path");
+            max_q = std::max(max_q, qlen[i]); max_t = std::max(max_t, tlen[i]);
         }
-        const uint64_t stride = rtk_ml_scratch_bytes();
-        const int grid = static_cast<int>(std::min<uint64_t>((static_cast<uint64_t>(n) + RTK_WAVE - 1) / RTK_WAVE, static_cast<uint64_t>(default_grid())));
+        const uint64_t stride = rtk_ml_scratch_bytes() + (want_path ? rtk_ml_table_bytes() : 0ull);
+        const int grid = static_cast<int>(std::min<uint64_t>((static_cast<uint64_t>(n) + RTK_WAVE - 1) / RTK_WAVE, static_cast<uint64_t>(want_path ? std::min(default_grid(), 512) : default_grid())));
+        const uint32_t cap_moves = want_path ? (std::min<uint32_t>(max_q, 64u * RTK_ML_MAXW) + std::min<uint32_t>(max_t, RTK_ML_MAXN) + 8) : 1;
         char* dpool = static_cast<char*>(rtk_dmalloc(pool.size() + 64));
         MyersProb* dprobs = static_cast<MyersProb*>(rtk_dmalloc(sizeof(MyersProb) * n));
         char* dscr = static_cast<char*>(rtk_dmalloc(stride * grid));
         int32_t* ddist = static_cast<int32_t*>(rtk_dmalloc(4ull * n)); int32_t* dnloc = static_cast<int32_t*>(rtk_dmalloc(4ull * n));
         int32_t* dlocs = static_cast<int32_t*>(rtk_dmalloc(4ull * n * cap_locs + 8)); uint32_t* dst = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
+        uint8_t* dmoves = static_cast<uint8_t*>(rtk_dmalloc(static_cast<uint64_t>(n) * cap_moves + 8)); uint32_t* dnm = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
         rtk_h2d(dpool, pool.data(), pool.size()); rtk_h2d(dprobs, probs.data(), sizeof(MyersProb) * n);
         { RtkTimer tk; const bool timed = getenv("RTK_MYERS_TIME") != nullptr; if (timed) tk.start(0);
-          rtk_launch(k_myers_batch_lanes, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), dscr, stride, grid, ddist, dnloc, dlocs, cap_locs, dst);
-          if (timed) { tk.stop(0); rtk_dsync(); fprintf(stderr, "[rtk myers time] one lane per problem: %u problems, %d waves, kernel %.3f ms\n", n, grid, tk.elapsed()); } }
+          rtk_launch(k_myers_batch_lanes, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, dscr, stride, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst);
+          if (timed) { tk.stop(0); rtk_dsync(); fprintf(stderr, "[rtk myers time] one lane per problem%s: %u problems, %d waves, kernel %.3f ms\n", want_path ? " (with paths)" : "", n, grid, tk.elapsed()); } }
         rtk_dsync();
-        std::vector<uint32_t> st(n);
-        rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); if (cap_locs) rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs); rtk_d2h(st.data(), dst, 4ull * n);
-        rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dst);
-        // the problems that are not for this route (query above 512 characters, target above 2048 or with a character outside ACGTN): one wave each
+        std::vector<uint32_t> st(n), nm(n);
+        rtk_d2h(dist, ddist, 4ull * n); rtk_d2h(n_loc, dnloc, 4ull * n); if (cap_locs) rtk_d2h(end_locs, dlocs, 4ull * n * cap_locs); rtk_d2h(st.data(), dst, 4ull * n); rtk_d2h(nm.data(), dnm, 4ull * n);
+        int rc = RTK_OK;
+        if (want_path && cigar) {
+            std::vector<uint8_t> mv(static_cast<size_t>(n) * cap_moves);
+            rtk_d2h(mv.data(), dmoves, mv.size());
+            static const char code[4] = {'M', 'I', 'D', 'M'};
+            for (uint32_t i = 0; i < n && rc == RTK_OK; ++i) { // edlibAlignmentToCigar, EDLIB_CIGAR_STANDARD (edlib.cpp:298-347)
+                if (st[i]) continue;
+                std::string c;
+                const uint8_t* a = &mv[static_cast<size_t>(i) * cap_moves];
+                for (uint32_t x = 0; x < nm[i];) { uint32_t y = x; while (y < nm[i] && code[a[y]] == code[a[x]]) ++y; c += std::to_string(y - x); c.push_back(code[a[x]]); x = y; }
+                if (c.size() + 1 > cap_cigar) { rc = rtk_fail(RTK_ERR_ARG, "rtk_myers_batch_lanes: cigar buffer too small"); break; }
+                memcpy(cigar + static_cast<size_t>(i) * cap_cigar, c.c_str(), c.size() + 1);
+            }
+        }
+        rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dst); rtk_dfree(dmoves); rtk_dfree(dnm);
+        if (rc != RTK_OK) return rc;
+        // the problems that are not for this route (query above 512 characters, target above 2048 or with a character outside ACGTN, a path table above 4096 word-columns): one wave each
         std::vector<uint32_t> rest; for (uint32_t i = 0; i < n; ++i) if (st[i]) rest.push_back(i);
         if (getenv("RTK_MYERS_TIME")) fprintf(stderr, "[rtk myers time] %zu of %u problems handed on to the wave route\n", rest.size(), n);
         if (!rest.empty()) {
             const uint32_t nr = static_cast<uint32_t>(rest.size());
             std::vector<const char*> q2(nr), t2(nr); std::vector<uint32_t> ql2(nr), tl2(nr); std::vector<int32_t> k2(nr), m2(nr), d2(nr), nl2(nr), loc2(static_cast<size_t>(nr) * cap_locs + 1);
+            std::vector<char> cg2(want_path && cigar ? static_cast<size_t>(nr) * cap_cigar : 1);
             for (uint32_t x = 0; x < nr; ++x) { const uint32_t i = rest[x]; q2[x] = query[i]; t2[x] = target[i]; ql2[x] = qlen[i]; tl2[x] = tlen[i]; k2[x] = k[i]; m2[x] = mode[i]; }
-            const int rc = rtk_myers_batch(nr, q2.data(), ql2.data(), t2.data(), tl2.data(), k2.data(), m2.data(), 0, 0, d2.data(), nl2.data(), loc2.data(), cap_locs, nullptr, 0);
+            rc = rtk_myers_batch(nr, q2.data(), ql2.data(), t2.data(), tl2.data(), k2.data(), m2.data(), want_path, 0, d2.data(), nl2.data(), loc2.data(), cap_locs, want_path && cigar ? cg2.data() : nullptr, cap_cigar);
             if (rc != RTK_OK) return rc;
-            for (uint32_t x = 0; x < nr; ++x) { const uint32_t i = rest[x]; dist[i] = d2[x]; n_loc[i] = nl2[x]; for (uint32_t y = 0; y < cap_locs; ++y) end_locs[static_cast<size_t>(i) * cap_locs + y] = loc2[static_cast<size_t>(x) * cap_locs + y]; }
+            for (uint32_t x = 0; x < nr; ++x) { const uint32_t i = rest[x]; dist[i] = d2[x]; n_loc[i] = nl2[x]; for (uint32_t y = 0; y < cap_locs; ++y) end_locs[static_cast<size_t>(i) * cap_locs + y] = loc2[static_cast<size_t>(x) * cap_locs + y];
+                if (want_path && cigar) memcpy(cigar + static_cast<size_t>(i) * cap_cigar, &cg2[static_cast<size_t>(x) * cap_cigar], cap_cigar); }
         }
         return RTK_OK;
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }

@@ -28,10 +28,10 @@ RTK_DEV int rtk_ml_sym(uint32_t c) { return (c == 'A' || c == 'C' || c == 'G' ||
 
 // returns 0 = done (dist / nloc / locs written), 1 = not a problem for this route (too long, a target character outside ACGTN): the caller takes the wave route.
 // peq: this lane's slice of the wave's match vectors (word (s * MAXW + w) at peq[(s * MAXW + w) * RTK_WAVE]); cs: its slice of the column scores.
-RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int k, int mode, uint64_t* peq, int32_t* cs, int32_t* dist, int32_t* nloc, int32_t* locs, int cap) {
-    *dist = -1; *nloc = 0;
+RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int k, int mode, uint64_t* peq, int32_t* cs, int32_t* dist, int32_t* nloc, int32_t* locs, int cap, int32_t* first) {
+    *dist = -1; *nloc = 0; *first = -1;
     if (m == 0 || n == 0) { // edlib.cpp:161-179
-        if (mode == RTK_MODE_NW) { *dist = m > n ? m : n; if (cap > 0) locs[0] = n - 1; } else { *dist = m; if (cap > 0) locs[0] = -1; }
+        if (mode == RTK_MODE_NW) { *dist = m > n ? m : n; *first = n - 1; if (cap > 0) locs[0] = n - 1; } else { *dist = m; if (cap > 0) locs[0] = -1; }
         *nloc = 1; return 0u;
     }
     if (m > 64 * RTK_ML_MAXW || n > RTK_ML_MAXN) return 1u;
@@ -82,17 +82,87 @@ RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int 
     }
     if (mode == RTK_MODE_NW) {
         if (k >= 0 && score > k) return 0u;
-        *dist = score; *nloc = 1; if (cap > 0) locs[0] = n - 1;
+        *dist = score; *nloc = 1; *first = n - 1; if (cap > 0) locs[0] = n - 1;
         return 0u;
     }
     const bool pseudo = (m & 63) != 0; // edlib's padded last block exposes target position -1 with score m
     if (pseudo && m < best) best = m;
     if (k >= 0 && best > k) return 0u;
     *dist = best;
-    int nl = 0;
-    if (pseudo && m == best) { if (nl < cap) locs[nl] = -1; ++nl; }
-    for (int j = 0; j < n; ++j) if (cs[static_cast<uint64_t>(j) * RTK_WAVE] == best) { if (nl < cap) locs[nl] = j; ++nl; }
-    *nloc = nl;
+    int nl = 0, f = -2;
+    if (pseudo && m == best) { if (nl < cap) locs[nl] = -1; ++nl; f = -1; }
+    for (int j = 0; j < n; ++j) if (cs[static_cast<uint64_t>(j) * RTK_WAVE] == best) { if (nl < cap) locs[nl] = j; ++nl; if (f == -2) f = j; }
+    *nloc = nl; *first = f;
+    return 0u;
+}
+
+
+// ---- the path of a lane's problem (edlib.cpp:271-284 obtainAlignment below its 1 MB threshold: one NW pass of the whole query over target[0 .. n) that keeps the four
+// delta vectors of every column, then the walk of edlib.cpp:1021-1137 -- up before left before diagonal). tb: this lane's slice of the wave's table, entry
+// ((j * W + w) * 4 + f) * RTK_WAVE with f = 0 Pv, 1 Mv, 2 Ph, 3 Mh (interleaved by lane: the 64 lanes of a wave store 512 contiguous bytes per entry).
+// moves: 0 match, 1 insertion (query character alone), 2 deletion, 3 mismatch, written in alignment order; returns 1 when the table or the move list is too small.
+#define RTK_ML_TB_WORDCOLS 4096 // word-columns of a lane's table (128 KB per lane)
+RTK_HD uint64_t rtk_ml_table_bytes() { return static_cast<uint64_t>(RTK_WAVE) * 32ull * RTK_ML_TB_WORDCOLS; }
+
+RTK_DEV uint32_t rtk_myers_lane_path(int m, const char* t, int n, const uint64_t* peq, uint64_t* tb, uint8_t* moves, uint32_t cap, uint32_t* n_moves) {
+    *n_moves = 0;
+    const int W = (m + 63) >> 6, last_bit = (m - 1) & 63;
+    if (static_cast<uint64_t>(W) * static_cast<uint64_t>(n) > RTK_ML_TB_WORDCOLS || static_cast<uint32_t>(m + n) > cap) return 1u;
+    uint64_t Pv[RTK_ML_MAXW], Mv[RTK_ML_MAXW];
+#pragma unroll
+    for (int w = 0; w < RTK_ML_MAXW; ++w) { Pv[w] = ~0ull; Mv[w] = 0ull; }
+    int cur = m;
+    uint64_t tw = 0;
+    for (int j = 0; j < n; ++j) {
+        if ((j & 7) == 0) tw = rtk_ml_ld8(t + j);
+        const int s = rtk_ml_sym(static_cast<uint32_t>(tw & 0xFFull)); tw >>= 8;
+        if (s > 4) return 1u;
+        const uint64_t* const e = peq + static_cast<uint64_t>(s * RTK_ML_MAXW) * RTK_WAVE;
+        int hin = 1;
+#pragma unroll
+        for (int w = 0; w < RTK_ML_MAXW; ++w) if (w < W) {
+            uint64_t Eq = e[static_cast<uint64_t>(w) * RTK_WAVE];
+            const uint64_t pv = Pv[w], mv = Mv[w];
+            const uint64_t Xv = Eq | mv;
+            if (hin < 0) Eq |= 1ull;
+            const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+            uint64_t Ph = mv | ~(Xh | pv), Mh = pv & Xh;
+            uint64_t* const ent = tb + static_cast<uint64_t>(j * W + w) * 4ull * RTK_WAVE;
+            ent[2 * RTK_WAVE] = Ph; ent[3 * RTK_WAVE] = Mh;
+            const int bit = (w == W - 1) ? last_bit : 63;
+            const int hout = static_cast<int>((Ph >> bit) & 1ull) - static_cast<int>((Mh >> bit) & 1ull);
+            Ph <<= 1; Mh <<= 1;
+            if (hin > 0) Ph |= 1ull; else if (hin < 0) Mh |= 1ull;
+            Pv[w] = Mh | ~(Xv | Ph); Mv[w] = Ph & Xv;
+            ent[0] = Pv[w]; ent[RTK_WAVE] = Mv[w];
+            hin = hout;
+        }
+        cur += hin;
+    }
+    // the walk, from the last cell; the moves are produced last first, at the end of the list, and moved to its front afterwards
+    uint32_t o = cap;
+    int i = m, j = n;
+    while (i > 0 && j > 0) {
+        const int r = i - 1, cc = j - 1, w = r >> 6, b = r & 63;
+        const uint64_t* const ent = tb + static_cast<uint64_t>(cc * W + w) * 4ull * RTK_WAVE;
+        const int vd = static_cast<int>((ent[0] >> b) & 1ull) - static_cast<int>((ent[RTK_WAVE] >> b) & 1ull);
+        const int hd = static_cast<int>((ent[2 * RTK_WAVE] >> b) & 1ull) - static_cast<int>((ent[3 * RTK_WAVE] >> b) & 1ull);
+        if (vd == 1) { moves[--o] = 1; --i; cur -= 1; }
+        else if (hd == 1) { moves[--o] = 2; --j; cur -= 1; }
+        else {
+            const int left = cur - hd;
+            int diag;
+            if (cc == 0) diag = i - 1;
+            else { const uint64_t* const el = tb + static_cast<uint64_t>((cc - 1) * W + w) * 4ull * RTK_WAVE; diag = left - (static_cast<int>((el[0] >> b) & 1ull) - static_cast<int>((el[RTK_WAVE] >> b) & 1ull)); }
+            moves[--o] = static_cast<uint8_t>(diag == cur ? 0 : 3);
+            --i; --j; cur = diag;
+        }
+    }
+    while (i > 0) { moves[--o] = 1; --i; }
+    while (j > 0) { moves[--o] = 2; --j; }
+    const uint32_t nm = cap - o;
+    for (uint32_t x = 0; x < nm; ++x) moves[x] = moves[o + x];
+    *n_moves = nm;
     return 0u;
 }
 

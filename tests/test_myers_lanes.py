@@ -1,4 +1,4 @@
-"""One alignment per lane (csrc/hip/rtk_myers_lane.h, stage entry rtk_myers_batch_lanes): distance and end locations of edlibAlign for the small problems
+"""One alignment per lane (csrc/hip/rtk_myers_lane.h, stage entry rtk_myers_batch_lanes): distance, end locations and path of edlibAlign for the small problems
 of the region program, held to the reference's golden vectors (those without IUPAC codes: equality is plain there) and to the oracle on random problems --
 plain and with other characters, thresholds k, the three modes, zero lengths, and the problems the route hands on to the wave route (query above 512
 characters, a target character outside ACGTN). The code of a lane has no cross-lane operation, so the 1-lane simulator runs exactly what a lane of
@@ -58,6 +58,17 @@ def _check(lib):
     for q, t, k, mode, (d, locs, _) in zip(qs, ts, ks, ms, res):
         w = op.myers(q, t, k, mode, False, iupac=False)
         assert (d, locs) == (w[0], w[1]), (len(q), len(t), k, mode)
+    # paths: the golden vectors with a CIGAR (plain characters), then the random problems again (NW and SHW; HW paths are not on the hot path)
+    rows = [r for r in golden_rows() if r["path"] and set(r["q"] + r["t"]) <= set("ACGT")]
+    assert len(rows) > 50
+    res = api.myers_batch([r["q"] for r in rows], [r["t"] for r in rows], [r["k"] for r in rows], [r["mode"] for r in rows], want_path=True, use_iupac=False, lib_path=lib, lanes=True)
+    for r, (d, locs, cig) in zip(rows, res):
+        assert d == r["d"] and locs == r["locs"] and cig == r["cigar"], (len(r["q"]), len(r["t"]), r["k"], r["mode"])
+    sel = [i for i in range(len(qs)) if ms[i] != 2]
+    res = api.myers_batch([qs[i] for i in sel], [ts[i] for i in sel], [ks[i] for i in sel], [ms[i] for i in sel], want_path=True, use_iupac=False, lib_path=lib, lanes=True)
+    for i, (d, locs, cig) in zip(sel, res):
+        w = op.myers(qs[i], ts[i], ks[i], ms[i], True, iupac=False)
+        assert (d, locs, cig) == (w[0], w[1], w[2]), (len(qs[i]), len(ts[i]), ks[i], ms[i])
     # IUPAC equality is the wave route's: same entry, same answers
     rows = [r for r in golden_rows() if not r["path"]][:200]
     res = api.myers_batch([r["q"] for r in rows], [r["t"] for r in rows], [r["k"] for r in rows], [r["mode"] for r in rows], use_iupac=True, lib_path=lib, lanes=True)
