@@ -569,7 +569,7 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
 }
 
 // ---- stage entry rtk_myers_batch_lanes: one problem per LANE (csrc/hip/rtk_myers_lane.h) ----
-RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const char* pool, int want_path, char* scratch, uint64_t stride, int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs,
+RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const char* pool, int want_path, int use_iupac, char* scratch, uint64_t stride, int grid, int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs,
                                     uint8_t* moves_out, uint32_t* n_moves_out, uint32_t cap_moves, uint32_t* status) {
 #ifdef RTK_SIM
     static thread_local uint64_t lpeq[RTK_ML_PEQ_WORDS];
@@ -586,7 +586,7 @@ RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const ch
         const MyersProb p = probs[i];
         const int m = static_cast<int>(p.qlen), tn = static_cast<int>(p.tlen);
         int32_t d = -1, nl = 0, first = -1; uint32_t nm = 0;
-        uint32_t st = rtk_myers_lane(pool + p.q_off, m, pool + p.t_off, tn, p.k, p.mode, peq, cs, &d, &nl, cap_locs ? end_locs + i * cap_locs : nullptr, static_cast<int>(cap_locs), &first);
+        uint32_t st = rtk_myers_lane(pool + p.q_off, m, pool + p.t_off, tn, p.k, p.mode, use_iupac != 0, peq, cs, &d, &nl, cap_locs ? end_locs + i * cap_locs : nullptr, static_cast<int>(cap_locs), &first);
         if (st == 0u && want_path && d >= 0 && m > 0 && tn > 0) { // edlib.cpp:271-284: the whole query against target[0 .. first end location]
             uint8_t* const mv = moves_out + i * cap_moves;
             if (first + 1 == 0) { if (static_cast<uint32_t>(m) > cap_moves) st = 1u; else { for (int x = 0; x < m; ++x) mv[x] = 1; nm = static_cast<uint32_t>(m); } } // (the padded block's position -1: nothing of the target)
@@ -602,7 +602,6 @@ extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const
     if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || (!end_locs && cap_locs)) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch_lanes: null argument");
     if (rtk_device_count() <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_myers_batch_lanes: no HIP device visible (no CPU fallback)");
     if (n == 0) return RTK_OK;
-    if (use_iupac) return rtk_myers_batch(n, query, qlen, target, tlen, k, mode, want_path, use_iupac, dist, n_loc, end_locs, cap_locs, cigar, cap_cigar); // (IUPAC equality: the wave route)
     try {
         std::vector<MyersProb> probs(n);
         std::string pool;
@@ -625,7 +624,7 @@ extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const
         uint8_t* dmoves = static_cast<uint8_t*>(rtk_dmalloc(static_cast<uint64_t>(n) * cap_moves + 8)); uint32_t* dnm = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
         rtk_h2d(dpool, pool.data(), pool.size()); rtk_h2d(dprobs, probs.data(), sizeof(MyersProb) * n);
         { RtkTimer tk; const bool timed = getenv("RTK_MYERS_TIME") != nullptr; if (timed) tk.start(0);
-          rtk_launch(k_myers_batch_lanes, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, dscr, stride, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst);
+          rtk_launch(k_myers_batch_lanes, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst);
           if (timed) { tk.stop(0); rtk_dsync(); fprintf(stderr, "[rtk myers time] one lane per problem%s: %u problems, %d waves, kernel %.3f ms\n", want_path ? " (with paths)" : "", n, grid, tk.elapsed()); } }
         rtk_dsync();
         std::vector<uint32_t> st(n), nm(n);
@@ -654,7 +653,7 @@ extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const
             std::vector<const char*> q2(nr), t2(nr); std::vector<uint32_t> ql2(nr), tl2(nr); std::vector<int32_t> k2(nr), m2(nr), d2(nr), nl2(nr), loc2(static_cast<size_t>(nr) * cap_locs + 1);
             std::vector<char> cg2(want_path && cigar ? static_cast<size_t>(nr) * cap_cigar : 1);
             for (uint32_t x = 0; x < nr; ++x) { const uint32_t i = rest[x]; q2[x] = query[i]; t2[x] = target[i]; ql2[x] = qlen[i]; tl2[x] = tlen[i]; k2[x] = k[i]; m2[x] = mode[i]; }
-            rc = rtk_myers_batch(nr, q2.data(), ql2.data(), t2.data(), tl2.data(), k2.data(), m2.data(), want_path, 0, d2.data(), nl2.data(), loc2.data(), cap_locs, want_path && cigar ? cg2.data() : nullptr, cap_cigar);
+            rc = rtk_myers_batch(nr, q2.data(), ql2.data(), t2.data(), tl2.data(), k2.data(), m2.data(), want_path, use_iupac, d2.data(), nl2.data(), loc2.data(), cap_locs, want_path && cigar ? cg2.data() : nullptr, cap_cigar);
             if (rc != RTK_OK) return rc;
             for (uint32_t x = 0; x < nr; ++x) { const uint32_t i = rest[x]; dist[i] = d2[x]; n_loc[i] = nl2[x]; for (uint32_t y = 0; y < cap_locs; ++y) end_locs[static_cast<size_t>(i) * cap_locs + y] = loc2[static_cast<size_t>(x) * cap_locs + y];
                 if (want_path && cigar) memcpy(cigar + static_cast<size_t>(i) * cap_cigar, &cg2[static_cast<size_t>(x) * cap_cigar], cap_cigar); }

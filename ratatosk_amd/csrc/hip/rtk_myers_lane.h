@@ -27,8 +27,9 @@ RTK_DEV uint64_t rtk_ml_eq8(uint64_t x, uint64_t c) {
 RTK_DEV int rtk_ml_sym(uint32_t c) { return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? static_cast<int>((c >> 1) & 3u) : (c == 'N' ? 4 : 5); }
 
 // returns 0 = done (dist / nloc / locs written), 1 = not a problem for this route (too long, a target character outside ACGTN): the caller takes the wave route.
+// iupac: equality of edlibAlign with the IUPAC codes as additional equalities (what the region program aligns with); the target's characters are A C G T N either way.
 // peq: this lane's slice of the wave's match vectors (word (s * MAXW + w) at peq[(s * MAXW + w) * RTK_WAVE]); cs: its slice of the column scores.
-RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int k, int mode, uint64_t* peq, int32_t* cs, int32_t* dist, int32_t* nloc, int32_t* locs, int cap, int32_t* first) {
+RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int k, int mode, bool iupac, uint64_t* peq, int32_t* cs, int32_t* dist, int32_t* nloc, int32_t* locs, int cap, int32_t* first) {
     *dist = -1; *nloc = 0; *first = -1;
     if (m == 0 || n == 0) { // edlib.cpp:161-179
         if (mode == RTK_MODE_NW) { *dist = m > n ? m : n; *first = n - 1; if (cap > 0) locs[0] = n - 1; } else { *dist = m; if (cap > 0) locs[0] = -1; }
@@ -42,7 +43,19 @@ RTK_DEV uint32_t rtk_myers_lane(const char* q, int m, const char* t, int n, int 
         uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;
         for (int g = 0; g < 8 && 64 * w + 8 * g < m; ++g) {
             const uint64_t x = rtk_ml_ld8(q + 64 * w + 8 * g); const int sh = 8 * g;
-            e0 |= rtk_ml_eq8(x, 'A') << sh; e1 |= rtk_ml_eq8(x, 'C') << sh; e2 |= rtk_ml_eq8(x, 'T') << sh; e3 |= rtk_ml_eq8(x, 'G') << sh; e4 |= rtk_ml_eq8(x, 'N') << sh;
+            const uint64_t a8 = rtk_ml_eq8(x, 'A'), c8 = rtk_ml_eq8(x, 'C'), t8 = rtk_ml_eq8(x, 'T'), g8 = rtk_ml_eq8(x, 'G'), n8 = rtk_ml_eq8(x, 'N');
+            e0 |= a8 << sh; e1 |= c8 << sh; e2 |= t8 << sh; e3 |= g8 << sh; e4 |= n8 << sh;
+            if (iupac) { // IUPAC equality (edlib's additional equalities, src/Alignment.cpp: a code equals the bases it stands for): a base of the query equals a target N; a
+                         // code of the query -- rare: a merged SNP -- is looked at character by character
+                e4 |= (a8 | c8 | t8 | g8) << sh;
+                uint64_t other = ~(a8 | c8 | t8 | g8) & 0xFFull;
+                const int left = m - (64 * w + 8 * g); if (left < 8) other &= (1ull << left) - 1ull;
+                for (; other; other &= other - 1ull) {
+                    const int b = __builtin_ctzll(other); const unsigned char qc = static_cast<unsigned char>(x >> (8 * b)); const uint64_t bit = 1ull << (sh + b);
+                    if (rtk_chars_equal(qc, 'A', true)) e0 |= bit; if (rtk_chars_equal(qc, 'C', true)) e1 |= bit; if (rtk_chars_equal(qc, 'T', true)) e2 |= bit;
+                    if (rtk_chars_equal(qc, 'G', true)) e3 |= bit; if (rtk_chars_equal(qc, 'N', true)) e4 |= bit;
+                }
+            }
         }
         const uint64_t keep = (w == W - 1 && last_bit < 63) ? ((2ull << last_bit) - 1ull) : ~0ull; // (characters behind the query's end match nothing)
         peq[static_cast<uint64_t>(0 * RTK_ML_MAXW + w) * RTK_WAVE] = e0 & keep; peq[static_cast<uint64_t>(1 * RTK_ML_MAXW + w) * RTK_WAVE] = e1 & keep;

@@ -1,6 +1,6 @@
 """One alignment per lane (csrc/hip/rtk_myers_lane.h, stage entry rtk_myers_batch_lanes): distance, end locations and path of edlibAlign for the small problems
-of the region program, held to the reference's golden vectors (those without IUPAC codes: equality is plain there) and to the oracle on random problems --
-plain and with other characters, thresholds k, the three modes, zero lengths, and the problems the route hands on to the wave route (query above 512
+of the region program, held to the reference's golden vectors (plain equality on those without IUPAC codes, IUPAC equality on all of them) and to the oracle on random problems --
+plain, with other characters and with IUPAC codes in the query, thresholds k, the three modes, zero lengths, and the problems the route hands on to the wave route (query above 512
 characters, a target character outside ACGTN). The code of a lane has no cross-lane operation, so the 1-lane simulator runs exactly what a lane of
 the device runs; the gpu test runs the same problems 64 per wavefront."""
 import random
@@ -69,11 +69,26 @@ def _check(lib):
     for i, (d, locs, cig) in zip(sel, res):
         w = op.myers(qs[i], ts[i], ks[i], ms[i], True, iupac=False)
         assert (d, locs, cig) == (w[0], w[1], w[2]), (len(qs[i]), len(ts[i]), ks[i], ms[i])
-    # IUPAC equality is the wave route's: same entry, same answers
-    rows = [r for r in golden_rows() if not r["path"]][:200]
+    # IUPAC equality (what the region program aligns with): every golden vector, distances and paths; random queries that carry codes against plain targets
+    rows = [r for r in golden_rows() if not r["path"]]
     res = api.myers_batch([r["q"] for r in rows], [r["t"] for r in rows], [r["k"] for r in rows], [r["mode"] for r in rows], use_iupac=True, lib_path=lib, lanes=True)
     for r, (d, locs, _) in zip(rows, res):
         assert d == r["d"] and locs == r["locs"]
+    rows = [r for r in golden_rows() if r["path"]]
+    res = api.myers_batch([r["q"] for r in rows], [r["t"] for r in rows], [r["k"] for r in rows], [r["mode"] for r in rows], want_path=True, use_iupac=True, lib_path=lib, lanes=True)
+    for r, (d, locs, cig) in zip(rows, res):
+        assert d == r["d"] and locs == r["locs"] and cig == r["cigar"]
+    rnd = random.Random(12)
+    q2, t2, k2, m2 = [], [], [], []
+    for i in range(300):
+        m = rnd.choice((20, 64, 100, 130, 256, 400))
+        t = "".join(rnd.choice("ACGT" if i % 3 else "ACGTN") for _ in range(m + rnd.randrange(-10, 40)))
+        q = "".join((rnd.choice("MRSVWYHKDBN") if rnd.random() < 0.05 else c) for c in t[:m] if rnd.random() > 0.04)
+        q2.append(q); t2.append(t); k2.append(-1 if i % 5 else 30); m2.append(i % 2)
+    res = api.myers_batch(q2, t2, k2, m2, want_path=True, use_iupac=True, lib_path=lib, lanes=True)
+    for q, t, k, mode, (d, locs, cig) in zip(q2, t2, k2, m2, res):
+        w = op.myers(q, t, k, mode, True, iupac=True)
+        assert (d, locs, cig) == (w[0], w[1], w[2]), (len(q), len(t), k, mode)
 
 
 def test_sim_myers_one_problem_per_lane():
