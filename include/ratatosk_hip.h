@@ -89,6 +89,10 @@ typedef struct rtk_stats {
     uint64_t n_slots_exact, n_slots_inexact;
     /* traceback walks inside cyc_myers: wave-cycles and alignment moves produced */
     uint64_t cyc_walk, n_moves;
+    /* lane-per-region kernel (k_regions_lanes, hip/rtk_region_lane.h; round 5): its time (also part of ms_correct), the regions of its class, and how many of
+     * them it handed on to the wave kernel (a capacity, a short-cycle unitig, a character outside A C G T N ...: same results, counted) */
+    double ms_lanes;
+    uint64_t n_lane_regions, n_lane_handed;
 } rtk_stats;
 
 /* dbg.read(G.fasta.gz) + readGraphData(G.rtsk) (reference: src/Ratatosk.cpp:1087-1089; src/Graph.cpp:722-784).

@@ -56,7 +56,7 @@ struct rtk_graph {
     rtk_graph_info info;
     // per-wave work areas, kept across batches: slot 0 for the seed stage, slot 1 for the region stage. A stage holds its slot's lock
     // while it runs, so the seed stage of one batch and the region stage of another overlap, two stages of one kind queue up.
-    void* scratch[2] = {nullptr, nullptr}; uint64_t scratch_bytes_[2] = {0, 0}; std::mutex scratch_lock[2];
+    void* scratch[3] = {nullptr, nullptr, nullptr}; uint64_t scratch_bytes_[3] = {0, 0, 0}; std::mutex scratch_lock[3]; // 0 seed stage, 1 region stage (wave kernel), 2 region stage (lane kernel; under lock 1)
     // device buffers of finished batches, by size: a ticket's ~25 buffers are taken from here instead of hipMalloc / hipFree, which
     // cost milliseconds each and (hipFree) wait for the whole device, i.e. for the other batch's kernels
     std::mutex pool_lock; std::multimap<uint64_t, void*> pool; uint64_t pool_bytes = 0;
@@ -313,7 +313,7 @@ extern "C" long long rtk_graph_strip_annotations(rtk_graph* g) {
 static void graph_release(rtk_graph* g) {
     if (g->refs.fetch_sub(1) != 1) return;
     if (g->owns_buffers) for (int i = 0; i < rtk::RTK_N_BUFS; ++i) if (!(g->moved >> i & 1u)) rtk_dfree(g->dbuf[i]);
-    rtk_dfree(g->scratch[0]); rtk_dfree(g->scratch[1]); g->pool_clear();
+    rtk_dfree(g->scratch[0]); rtk_dfree(g->scratch[1]); rtk_dfree(g->scratch[2]); g->pool_clear();
     delete g;
 }
 extern "C" void rtk_graph_free(rtk_graph* g) { if (g) graph_release(g); }
