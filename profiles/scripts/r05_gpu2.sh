@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+RTK_TRACE=1 RTK_LIB_OVERRIDE=$PWD/ratatosk_amd/variants/libratatosk_hip_laneprof.so timeout 1200 python profiles/scripts/r05_lanes_ab.py c1 64000000 64 256 > gpurun_out/r05_lanes_prof_c1.log 2>&1
+grep -E "lap profile|gap<" gpurun_out/r05_lanes_prof_c1.log | tail -12

@@ -26,6 +26,8 @@
 thread_local int rtk_sim_block_id = 0;
 thread_local int rtk_sim_site = 0;
 std::atomic<unsigned long long> rtk_sim_site_stat[32][8];
+std::atomic<unsigned long long> rl_sim_acc[4];
+extern "C" void rtk_sim_lane_accesses(unsigned long long* out, int reset) { for (int i = 0; i < 4; ++i) { out[i] = rl_sim_acc[i].load(); if (reset) rl_sim_acc[i] = 0; } }
 extern "C" void rtk_sim_site_stats(unsigned long long* out, int reset) { for (int i = 0; i < 32; ++i) for (int j = 0; j < 8; ++j) { out[8 * i + j] = rtk_sim_site_stat[i][j].load(); if (reset) rtk_sim_site_stat[i][j] = 0; } }
 #endif
 

@@ -39,7 +39,12 @@ inline int rtk_popc(uint64_t x) { return __builtin_popcountll(x); }
 inline int rtk_ffs(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); } // 1-based, 0 if none
 template <class T> inline T rtk_atomic_add_raw(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline uint32_t rtk_atomic_or(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+#ifdef RTK_LANE_PROF
+#include <x86intrin.h>
+inline unsigned long long rtk_clock() { return __rdtsc(); } // developer build of the simulator: the lap profile of the lane program in host cycles
+#else
 inline unsigned long long rtk_clock() { return 0; }
+#endif
 inline uint64_t rtk_brev64(uint64_t x) { uint64_t r = 0; for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1ull); x >>= 1; } return r; }
 
 #else
