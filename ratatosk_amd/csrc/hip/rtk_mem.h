@@ -28,7 +28,13 @@ inline void rtk_dzero(void* d, uint64_t n) { if (n) memset(d, 0, n); }
 inline void rtk_dsync() {}
 inline rtk_stream_t rtk_stream_create() { return 0; }
 inline void rtk_stream_destroy(rtk_stream_t) {}
+inline rtk_stream_t rtk_stream_create_high() { return 0; }
 inline void rtk_ssync(rtk_stream_t) {}
+typedef int rtk_event_t;
+inline rtk_event_t rtk_event_create() { return 0; }
+inline void rtk_event_destroy(rtk_event_t) {}
+inline void rtk_event_record(rtk_event_t, rtk_stream_t) {}
+inline void rtk_stream_wait(rtk_stream_t, rtk_event_t) {}
 inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t) { if (n) memcpy(h, d, n); }
 inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t) { if (n) memset(d, 0, n); }
 inline void rtk_dfill_s(void* d, int c, uint64_t n, rtk_stream_t) { if (n) memset(d, c, n); }
@@ -73,7 +79,15 @@ inline void rtk_dsync() { rtk_check(hipDeviceSynchronize(), "hipDeviceSynchroniz
 // so the stages of different batches overlap on the device
 inline rtk_stream_t rtk_stream_create() { hipStream_t s = nullptr; rtk_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); return s; }
 inline void rtk_stream_destroy(rtk_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+// a stream whose kernels are dispatched ahead of those of the default-priority streams (the lane kernel of the region stage: few waves, each one long dependent chain)
+inline rtk_stream_t rtk_stream_create_high() { int lo = 0, hi = 0; hipStream_t s = nullptr; if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return rtk_stream_create(); rtk_check(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority"); return s; }
 inline void rtk_ssync(rtk_stream_t s) { rtk_check(hipStreamSynchronize(s), "hipStreamSynchronize"); }
+// ordering between two streams of a batch (the lane kernel of the region stage runs beside the wave kernel)
+typedef hipEvent_t rtk_event_t;
+inline rtk_event_t rtk_event_create() { hipEvent_t e = nullptr; rtk_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); return e; }
+inline void rtk_event_destroy(rtk_event_t e) { if (e) (void)hipEventDestroy(e); }
+inline void rtk_event_record(rtk_event_t e, rtk_stream_t s) { rtk_check(hipEventRecord(e, s), "hipEventRecord"); }
+inline void rtk_stream_wait(rtk_stream_t s, rtk_event_t e) { rtk_check(hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }
 inline void rtk_d2h_s(void* h, const void* d, uint64_t n, rtk_stream_t s) { if (n) { rtk_check(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s), "hipMemcpyAsync D2H"); rtk_ssync(s); } }
 inline void rtk_dzero_s(void* d, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemsetAsync(d, 0, n, s), "hipMemsetAsync"); }
 inline void rtk_dfill_s(void* d, int c, uint64_t n, rtk_stream_t s) { if (n) rtk_check(hipMemsetAsync(d, c, n, s), "hipMemsetAsync"); }

@@ -48,6 +48,7 @@ struct RegionBatch {
     U<uint32_t*> eorder;                       // the regions that need no graph walk (k_regions_easy), in any order; their number is n_heavy[2]
     U<uint32_t*> rorder; U<unsigned long long*> n_heavy; // dequeue order of the region kernel: the heavy regions (long gaps, read heads / tails) from the front, the light ones from the back (k_region_order); [0] heavy, [1] light
     U<unsigned long long*> n_overflow;         // regions that ran out of scratch in the last launch
+    U<uint32_t*> horder; // the regions the lane kernel handed on to the wave kernel; their number is n_heavy[4]
     U<uint32_t*> lorder; U<unsigned long long*> next_lane; U<uint32_t> lane_max_gap; // the regions of the lane-per-region kernel (k_regions_lanes): gaps under lane_max_gap bases, by size class; their number is n_heavy[3]; 0: no such class
     U<char*> out_pool; U<uint64_t> out_cap; U<unsigned long long*> out_top;
     U<uint64_t*> out_off; U<uint32_t*> out_seq_len; U<uint32_t*> out_qual_len; // per read

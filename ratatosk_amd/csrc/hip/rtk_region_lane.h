@@ -22,6 +22,16 @@
 #include "rtk_region.h"
 
 #define RL_STRIDE RTK_WAVE
+// layout of a wave's work area and traceback table in device memory: RL_MS = 1: one contiguous slice per lane (a lane's walk over its own words stays in the
+// cache lines it has fetched: the lane programs are bound by the latency of their own dependent accesses, not by bandwidth); RL_MS = RL_STRIDE: words interleaved
+// by lane (the lanes' accesses to the same logical word coalesce; -DRL_INTERLEAVED, measured slower)
+#ifdef RL_INTERLEAVED
+#define RL_MS RL_STRIDE
+#define RL_LANE_WORDS(words) 1ull
+#else
+#define RL_MS 1
+#define RL_LANE_WORDS(words) static_cast<uint64_t>(words)
+#endif
 
 // ---- capacities (compile-time layout; RlCtx::lim_* are the run-time limits the checks use: a test hook lowers them) ----
 #ifndef RL_STR_BYTES
@@ -183,8 +193,8 @@ struct RlCtx {
     RTK_DEV const OptsView* o() const { return rl_env.o; }
     RTK_DEV const BatchView* bv() const { return rl_env.bv; }
     RTK_DEV const RegionBatch* rb() const { return rl_env.rb; }
-    RTK_DEV uint32_t* m() const { return rtk_gp(rl_env.m) + rtk_lane(); }
-    RTK_DEV uint64_t* tb() const { return rtk_gp(rl_env.tb) + rtk_lane(); }
+    RTK_DEV uint32_t* m() const { return rtk_gp(rl_env.m) + static_cast<uint64_t>(rtk_lane()) * RL_LANE_WORDS(RL_WORDS); }
+    RTK_DEV uint64_t* tb() const { return rtk_gp(rl_env.tb) + static_cast<uint64_t>(rtk_lane()) * RL_LANE_WORDS(RL_TB_WORDCOLS * 2u); }
     RTK_DEV uint64_t* peq() const { return rl_peq_all + rtk_lane(); }
     RTK_DEV uint32_t k() const { return rl_env.k; }
     RTK_DEV uint32_t lim_str() const { return rl_env.lim_str; }
@@ -212,11 +222,11 @@ extern std::atomic<unsigned long long> rl_sim_acc[4]; // developer statistics (s
 #else
 #define RL_ACC(i) ((void)0)
 #endif
-RTK_DEV uint32_t rl_ld(const RlCtx& c, uint32_t w) { RL_ACC(0); return c.m()[static_cast<uint64_t>(w) * RL_STRIDE]; }
-RTK_DEV void rl_st(const RlCtx& c, uint32_t w, uint32_t v) { RL_ACC(1); c.m()[static_cast<uint64_t>(w) * RL_STRIDE] = v; }
+RTK_DEV uint32_t rl_ld(const RlCtx& c, uint32_t w) { RL_ACC(0); return c.m()[static_cast<uint64_t>(w) * RL_MS]; }
+RTK_DEV void rl_st(const RlCtx& c, uint32_t w, uint32_t v) { RL_ACC(1); c.m()[static_cast<uint64_t>(w) * RL_MS] = v; }
 // byte b of the work area (b = 4 * word + byte)
-RTK_DEV unsigned char rl_ldb(const RlCtx& c, uint32_t b) { RL_ACC(2); return reinterpret_cast<const unsigned char*>(c.m() + static_cast<uint64_t>(b >> 2) * RL_STRIDE)[b & 3u]; }
-RTK_DEV void rl_stb(const RlCtx& c, uint32_t b, unsigned char v) { RL_ACC(3); reinterpret_cast<unsigned char*>(c.m() + static_cast<uint64_t>(b >> 2) * RL_STRIDE)[b & 3u] = v; }
+RTK_DEV unsigned char rl_ldb(const RlCtx& c, uint32_t b) { RL_ACC(2); return reinterpret_cast<const unsigned char*>(c.m() + static_cast<uint64_t>(b >> 2) * RL_MS)[b & 3u]; }
+RTK_DEV void rl_stb(const RlCtx& c, uint32_t b, unsigned char v) { RL_ACC(3); reinterpret_cast<unsigned char*>(c.m() + static_cast<uint64_t>(b >> 2) * RL_MS)[b & 3u] = v; }
 RTK_DEV uint32_t rl_sb(uint32_t i) { return 4u * (RL_OFF_STR + i * RL_STR_W); }   // byte offset of string buffer i
 RTK_DEV uint32_t rl_mvb(uint32_t i) { return 4u * (RL_OFF_MV + i * RL_MV_W); }    // byte offset of move buffer i
 
@@ -361,7 +371,7 @@ RTK_FN RlAln rl_myers(RlCtx& c, RlSrc q, int m, RlSrc t, int n, int k, int mode,
             Ph <<= 1; Mh <<= 1;
             if (hin > 0) Ph |= 1ull; else if (hin < 0) Mh |= 1ull;
             Pv[w] = Mh | ~(Xv | Ph); Mv[w] = Ph & Xv;
-            if (store) { uint64_t* const ent = tb + static_cast<uint64_t>(j * W + w) * 2ull * RL_STRIDE; ent[0] = Pv[w]; ent[RL_STRIDE] = Mv[w]; }
+            if (store) { uint64_t* const ent = tb + static_cast<uint64_t>(j * W + w) * 2ull * RL_MS; ent[0] = Pv[w]; ent[RL_MS] = Mv[w]; }
             hin = hout;
         }
         score += hin;
@@ -394,16 +404,16 @@ RTK_FN uint32_t rl_myers_walk(RlCtx& c, int m, int n_cols, uint32_t mv_b, uint32
     if (static_cast<uint32_t>(m + n_cols) > RL_MV_BYTES || static_cast<uint32_t>(m + n_cols) > 2u * c.lim_str()) { rl_fail(c, RL_F_STR); return 0; }
     const uint64_t* const tb = c.tb();
     auto cell = [&](int i, int j) -> int { // D(i, j), j >= 1: column j - 1 of the table
-        const uint64_t* const col = tb + static_cast<uint64_t>((j - 1) * W) * 2ull * RL_STRIDE;
+        const uint64_t* const col = tb + static_cast<uint64_t>((j - 1) * W) * 2ull * RL_MS;
         int v = j;
         const int fw = i >> 6, rb = i & 63;
-        for (int w = 0; w < fw; ++w) v += rtk_popc(col[static_cast<uint64_t>(w) * 2ull * RL_STRIDE]) - rtk_popc(col[(static_cast<uint64_t>(w) * 2ull + 1ull) * RL_STRIDE]);
-        if (rb) { const uint64_t mk = (1ull << rb) - 1ull; v += rtk_popc(col[static_cast<uint64_t>(fw) * 2ull * RL_STRIDE] & mk) - rtk_popc(col[(static_cast<uint64_t>(fw) * 2ull + 1ull) * RL_STRIDE] & mk); }
+        for (int w = 0; w < fw; ++w) v += rtk_popc(col[static_cast<uint64_t>(w) * 2ull * RL_MS]) - rtk_popc(col[(static_cast<uint64_t>(w) * 2ull + 1ull) * RL_MS]);
+        if (rb) { const uint64_t mk = (1ull << rb) - 1ull; v += rtk_popc(col[static_cast<uint64_t>(fw) * 2ull * RL_MS] & mk) - rtk_popc(col[(static_cast<uint64_t>(fw) * 2ull + 1ull) * RL_MS] & mk); }
         return v;
     };
     auto vdelta = [&](int i, int j) -> int { // D(i, j) - D(i - 1, j), i >= 1, j >= 1
-        const int r = i - 1; const uint64_t* const ent = tb + static_cast<uint64_t>((j - 1) * W + (r >> 6)) * 2ull * RL_STRIDE;
-        return static_cast<int>((ent[0] >> (r & 63)) & 1ull) - static_cast<int>((ent[RL_STRIDE] >> (r & 63)) & 1ull);
+        const int r = i - 1; const uint64_t* const ent = tb + static_cast<uint64_t>((j - 1) * W + (r >> 6)) * 2ull * RL_MS;
+        return static_cast<int>((ent[0] >> (r & 63)) & 1ull) - static_cast<int>((ent[RL_MS] >> (r & 63)) & 1ull);
     };
     int i = m, j = n_cols;
     int cur = j > 0 ? cell(i, j) : i;
