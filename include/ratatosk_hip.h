@@ -222,6 +222,9 @@ int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* 
 int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
                           const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
                           int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar);
+/* How the calling thread's last rtk_myers_batch_lanes call split its problems: *lane_route = computed one per lane, *wave_route = handed on to rtk_myers_batch
+ * (tests hold the lane route to every problem that fits it: a lane kernel that took nothing would otherwise pass on the wave route's results). */
+void rtk_myers_lanes_last_routes(uint64_t* lane_route, uint64_t* wave_route);
 
 /* Index build, device side (the reference builds its index on the CPU: `Ratatosk index`, src/Ratatosk.cpp:1066-1067, Bifrost
  * build + addCoverage src/Graph.cpp:1561). rtk_index_count_kmers: the canonical k-mers (odd k <= 31, A=0 C=1 G=2 T=3, first base in the

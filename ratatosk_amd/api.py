@@ -292,6 +292,15 @@ def myers_batch(queries, targets, ks=None, modes=None, want_path=False, use_iupa
     return out
 
 
+def myers_lanes_last_routes(lib_path=None):
+    """(problems computed one per lane, problems handed on to the wave route) of this thread's last myers_batch(..., lanes=True) call."""
+    L = load_library(lib_path)
+    a, b = C.c_uint64(), C.c_uint64()
+    L.rtk_myers_lanes_last_routes.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]; L.rtk_myers_lanes_last_routes.restype = None
+    L.rtk_myers_lanes_last_routes(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def run_pipelined(batches, opts=None):
     """Runs the batches in order with the seed stage of batch i+1 overlapping the region stage of batch i (two host threads,
     one HIP stream per batch). Results are the same as calling run() on each batch."""

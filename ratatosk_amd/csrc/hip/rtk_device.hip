@@ -598,11 +598,14 @@ RTK_GLOBAL void k_myers_batch_lanes(const MyersProb* probs, uint32_t n, const ch
     }
 }
 
+static thread_local uint64_t g_ml_routes[2] = {0, 0}; // problems of the calling thread's last rtk_myers_batch_lanes call: taken by the lane route, handed on to the wave route
+extern "C" void rtk_myers_lanes_last_routes(uint64_t* lane_route, uint64_t* wave_route) { if (lane_route) *lane_route = g_ml_routes[0]; if (wave_route) *wave_route = g_ml_routes[1]; }
 extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
                                      const int32_t* k, const int32_t* mode, int want_path, int use_iupac,
                                      int32_t* dist, int32_t* n_loc, int32_t* end_locs, uint32_t cap_locs, char* cigar, uint32_t cap_cigar) {
     if (!query || !qlen || !target || !tlen || !k || !mode || !dist || !n_loc || (!end_locs && cap_locs)) return rtk_fail(RTK_ERR_ARG, "rtk_myers_batch_lanes: null argument");
     if (rtk_device_count() <= 0) return rtk_fail(RTK_ERR_NO_DEVICE, "rtk_myers_batch_lanes: no HIP device visible (no CPU fallback)");
+    g_ml_routes[0] = 0; g_ml_routes[1] = 0;
     if (n == 0) return RTK_OK;
     try {
         std::vector<MyersProb> probs(n);
@@ -649,6 +652,7 @@ extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const
         if (rc != RTK_OK) return rc;
         // the problems that are not for this route (query above 512 characters, target above 2048 or with a character outside ACGTN, a path table above 4096 word-columns): one wave each
         std::vector<uint32_t> rest; for (uint32_t i = 0; i < n; ++i) if (st[i]) rest.push_back(i);
+        g_ml_routes[0] = n - rest.size(); g_ml_routes[1] = rest.size();
         if (getenv("RTK_MYERS_TIME")) fprintf(stderr, "[rtk myers time] %zu of %u problems handed on to the wave route\n", rest.size(), n);
         if (!rest.empty()) {
             const uint32_t nr = static_cast<uint32_t>(rest.size());

@@ -1,0 +1,95 @@
+"""Lane-per-region kernel (csrc/hip/rtk_region_lane.h, k_regions_lanes; RTK_LANE_MAX_GAP opts in): the gaps of its class are corrected one region per lane,
+whatever the lane program does not hold is handed on to the wave kernel, and the corrected reads -- sequence AND quality strings -- are byte-identical to the
+oracle's either way. A lane's program has no cross-lane operation, so the 1-lane simulator runs exactly what a lane runs on the device; the gpu tests run the
+same program 64 regions per wavefront, beside the wave kernel (second stream, shared queue) and one after the other. The tests also hold the lane route to a
+minimum share of its class: a lane kernel that handed everything on would otherwise pass on the wave kernel's results."""
+import pytest
+
+from conftest import SIM_LIB
+from oracle import oracle_py as op
+from ratatosk_amd import api
+
+
+def _run(prefix, n, lib, k=31, opts=None):
+    fa, rt = prefix + ".index.k%d.fasta.gz" % k, prefix + ".index.k%d.rtsk" % k
+    pg = api.Graph(fa, rt, k, device=0, lib_path=lib)
+    reads = op.read_fastq(prefix + ".lr.fq")[:n]
+    seqs, quals = [r[1] for r in reads], [r[2] for r in reads]
+    b = api.Batch(pg, seqs, quals)
+    b.run(pg.opts(**(opts or {})))
+    return b.fetch(), b.stats(), seqs, quals
+
+
+def _oracle(prefix, seqs, quals, k=31, opts=None):
+    og = op.Graph(prefix + ".index.k%d.fasta.gz" % k, prefix + ".index.k%d.rtsk" % k, k)
+    return og.correct_batch(seqs, quals, opts=og.opts(**(opts or {})), threads=4)[0]
+
+
+def _check(prefix, n, lib, monkeypatch, k=31, max_gap="256", min_lane_share=0.9, opts=None):
+    monkeypatch.setenv("RTK_LANE_MAX_GAP", "0")
+    base, st0, seqs, quals = _run(prefix, n, lib, k, opts)
+    assert st0["n_lane_regions"] == 0
+    want = _oracle(prefix, seqs, quals, k, opts)
+    assert base == want
+    monkeypatch.setenv("RTK_LANE_MAX_GAP", max_gap)
+    got, st, _, _ = _run(prefix, n, lib, k, opts)
+    assert got == want, "lane kernel on: %d reads differ from the oracle" % sum(1 for a, b in zip(got, want) if a != b)
+    assert st["n_lane_regions"] > 0 and st["n_regions"] == st0["n_regions"]
+    done = st["n_lane_regions"] - st["n_lane_handed"]
+    assert done >= min_lane_share * st["n_lane_regions"], (st["n_lane_regions"], st["n_lane_handed"])
+    return st
+
+
+def test_sim_lanes_branching(ds_small, monkeypatch):
+    st = _check(ds_small, 12, SIM_LIB, monkeypatch)
+    assert st["n_lane_regions"] > 100
+
+
+def test_sim_lanes_clean_and_options(ds_clean, ds_small, monkeypatch):
+    _check(ds_clean, 8, SIM_LIB, monkeypatch, min_lane_share=0.5)  # (long unitigs: a handful of regions in the class)
+    _check(ds_small, 8, SIM_LIB, monkeypatch, opts=dict(insert_sz=300, max_len_weak_region1=300, max_qual=30))
+    _check(ds_small, 8, SIM_LIB, monkeypatch, max_gap="64", min_lane_share=0.7)
+
+
+def test_sim_lanes_snp_annotations_cycles_and_other_k(ds_snps_rich, ds_snps, ds_k25, ds_k21, monkeypatch):
+    """SNP annotations (getAmbiguityVector / fixAmbiguity lane by lane), short cycles (handed on: fixRepeats is the wave kernel's), k = 25 and k = 21."""
+    st = _check(ds_snps_rich, 16, SIM_LIB, monkeypatch, min_lane_share=0.8)
+    assert st["n_lane_handed"] > 0  # the tandem repeats of this set
+    _check(ds_snps, 24, SIM_LIB, monkeypatch)
+    _check(ds_snps, 8, SIM_LIB, monkeypatch, opts=dict(min_confidence_snp_corr=0.5, out_qual=3, max_qual=30))
+    _check(ds_k25, 6, SIM_LIB, monkeypatch, k=25)
+    _check(ds_k21, 8, SIM_LIB, monkeypatch, k=21)
+
+
+def test_sim_lanes_tiny_capacities_are_handed_on(ds_small, ds_snps, monkeypatch):
+    """Capacities far too small (test hook): a large part of the class is handed on to the wave kernel, whose own work areas overflow too and are redone:
+    the results do not change."""
+    monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
+    monkeypatch.setenv("RTK_LANE_MAX_GAP", "256")
+    for prefix, n in ((ds_small, 12), (ds_snps, 10)):
+        got, st, seqs, quals = _run(prefix, n, SIM_LIB)
+        assert got == _oracle(prefix, seqs, quals)
+        assert st["n_lane_regions"] > 0 and st["n_lane_handed"] > st["n_lane_regions"] // 4
+
+
+@pytest.mark.gpu
+def test_gpu_lanes_beside_the_wave_kernel(ds_medium, ds_snps_rich, monkeypatch):
+    st = _check(ds_medium, 160, None, monkeypatch)
+    assert st["n_lane_regions"] > 2000
+    _check(ds_medium, 160, None, monkeypatch, max_gap="128")
+    _check(ds_snps_rich, 80, None, monkeypatch, min_lane_share=0.8)
+
+
+@pytest.mark.gpu
+def test_gpu_lanes_serial_small_rounds_and_tiny_capacities(ds_medium, ds_snps, monkeypatch):
+    monkeypatch.setenv("RTK_LANE_SERIAL", "1")
+    _check(ds_medium, 80, None, monkeypatch)
+    monkeypatch.setenv("RTK_LANE_ROUND", "16")
+    monkeypatch.setenv("RTK_LANE_WAVES", "64")  # few persistent waves: several rounds each
+    _check(ds_medium, 80, None, monkeypatch)
+    monkeypatch.delenv("RTK_LANE_SERIAL"); monkeypatch.delenv("RTK_LANE_ROUND")
+    monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
+    monkeypatch.setenv("RTK_LANE_MAX_GAP", "256")
+    got, st, seqs, quals = _run(ds_snps, 20, None)
+    assert got == _oracle(ds_snps, seqs, quals)
+    assert st["n_lane_handed"] > st["n_lane_regions"] // 4
