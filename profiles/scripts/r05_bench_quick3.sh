@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+( RTK_TRACE=1 python bench.py --config1-only --no-cpu-baseline --no-host-legs --steps 3 --warmup 1 2>&1 | grep -E "k_regions attempt|region work areas" | tail -6 ) > gpurun_out/r05_bench_quick3.txt 2>&1
+cat gpurun_out/r05_bench_quick3.txt
