@@ -183,6 +183,73 @@ def host_inclusive_leg(a, api, graph, opts, tickets):
             "what": "rtk_batch_create + rtk_batch_run + rtk_batch_fetch_view + rtk_batch_free per ticket, host buffers in / pinned host records out, PCIe inside"}
 
 
+def ticket_size_leg(a, api, graph, opts, mine):
+    """bases/s through the C ABI by ticket size (the reference hands its workers batches of >= 1 MiB of bases, src/Common.hpp:138 / src/Ratatosk.cpp:757-772;
+    INTEGRATION.md recommends a bigger buffer_sz): the reads of this rank's tickets cut into tickets of >= 1 / 4 / 16 / 64 Mi bases, each size run with one
+    caller and with three (host buffers in, pinned host records out, PCIe inside: the host_inclusive leg at other ticket sizes)."""
+    import types
+    reads = [(s_, q_) for t in mine for s_, q_ in zip(t[0], t[1])]
+    out = {}
+    for mib in (1, 4, 16, 64):
+        want = mib << 20
+        tickets, cs, cq, cur = [], [], [], 0
+        for s_, q_ in reads:
+            cs.append(s_); cq.append(q_); cur += len(s_)
+            if cur >= want:
+                tickets.append((cs, cq)); cs, cq, cur = [], [], 0
+        if not tickets:
+            continue
+        n_t = max(3, min(48, (128 << 20) // want))  # ~128 Mi bases per measurement, at least three tickets
+        row = {"ticket_bases": int(sum(len(x) for x in tickets[0][0])), "tickets": n_t}
+        for callers in (1, 3):
+            r = host_inclusive_leg(types.SimpleNamespace(host_tickets=n_t, host_callers=callers), api, graph, opts, tickets)
+            row["callers_%d" % callers] = r.get("value") if "value" in r else r
+        out["%dMi" % mib] = row
+    return out
+
+
+def lane_kernel_leg(a, api, graph, opts, mine):
+    """The lane-per-region kernel (csrc/hip/rtk_region_lane.h, k_regions_lanes; off by default) on one resident ticket, beside the default path on the same
+    ticket: kernel times of the region stage either way, the class's size, the share the lane program handed on to the wave kernel, and whether the corrected
+    batch is the same bytes."""
+    import hashlib
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            b = api.Batch(graph, *mine[0])
+            best = None
+            for _ in range(3):
+                b.run(opts); st = b.stats()
+                if best is None or st["ms_correct"] < best["ms_correct"]:
+                    best = st
+            h = hashlib.sha256()
+            for g_ in b.fetch():
+                h.update(g_[0].encode()); h.update(g_[1].encode())
+            b.close()
+            return best, h.hexdigest()[:16]
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    try:
+        off, d0 = run({"RTK_LANE_MAX_GAP": "0"})
+        res = {"default": "off (RTK_LANE_MAX_GAP=0): the wave kernel alone", "region_stage_ms_wave_kernel_alone": round(off["ms_correct"], 3), "settings": {}}
+        for name, env in (("gap<128, 1024 lane waves, beside the wave kernel (shared queue)", {"RTK_LANE_MAX_GAP": "128", "RTK_LANE_WAVES": "1024"}),
+                          ("gap<128, 1024 lane waves, one kernel after the other", {"RTK_LANE_MAX_GAP": "128", "RTK_LANE_WAVES": "1024", "RTK_LANE_SERIAL": "1"}),
+                          ("gap<256, 2048 lane waves, one kernel after the other", {"RTK_LANE_MAX_GAP": "256", "RTK_LANE_WAVES": "2048", "RTK_LANE_SERIAL": "1"})):
+            st, d = run(env)
+            res["settings"][name] = {"region_stage_ms": round(st["ms_correct"], 3), "k_regions_lanes_ms": round(st["ms_lanes"], 3), "lane_class_regions": int(st["n_lane_regions"]),
+                                     "handed_on_to_wave_kernel": int(st["n_lane_handed"]), "handed_on_share": round(st["n_lane_handed"] / max(1, st["n_lane_regions"]), 4),
+                                     "regions": int(st["n_regions"]), "same_bytes_as_default": d == d0}
+        return res
+    except Exception as e:  # never takes the bench line down
+        return {"error": str(e)[-300:]}
+
+
 def cli_leg(a, pre, fa, rt):
     """The shipped C++ driver, file to file: `Ratatosk correct -1` on the generated long-read FASTQ (parse + pack + H2D + kernels + D2H
     + format + ordered write); its own statistics line gives the wall time of the correction phase (graph load reported apart)."""
@@ -479,11 +546,18 @@ def main():
                     "issue_frac": issue_frac, "issue_wave_instructions_per_launch": issue_n, "issue_frac_is": "(SQ_INSTS_VALU + SQ_INSTS_SALU of the committed PMC pass) / (1024 SIMDs x 2.4 GHz x this run's launch time / 2 cycles per wave64 instruction)",
                     "alg_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(avg_ms, 3),
                     "kernel_ms_per_step": {k_: round(v / n_l, 3) for k_, v in tot.items()},
-                    "kernel_ms_per_step_is": "HIP-event spans inside the timed region, where consecutive steps overlap on two streams: the spans of k_mask / k_inexact / k_finalize include waiting for wave slots behind the other step's persistent k_regions; kernel_ms_per_step_serial has the same kernels with one step at a time",
-                    "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in stats_serial) / len(stats_serial), 3) for k_, v in kern.items()} if stats_serial else None), "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")),
+                    "kernel_ms_per_step_is": ("HIP-event spans inside the timed region, one step at a time (the default): every kernel has the machine to itself" if a.serial else "HIP-event spans inside the timed region with consecutive steps on two streams (--overlap): the spans of k_mask / k_inexact / k_finalize include waiting for wave slots behind the other step's persistent k_regions; kernel_ms_per_step_serial has the same kernels with one step at a time"),
+                    "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in stats_serial) / len(stats_serial), 3) for k_, v in kern.items()} if stats_serial else {k_: round(v / n_l, 3) for k_, v in tot.items()}), "regions_per_step": int(S("n_regions")), "aligns_per_step": int(S("n_align")), "align_word_columns_per_step": int(S("n_align_cells")), "expansions_per_step": int(S("n_expand")), "colour_ids_per_step": int(S("n_colour_elem")), "path_bases_per_step": int(S("n_path_base")),
                     "index_lookups_inexact_per_step": int(S("n_probes_inexact")), "index_slots_inexact_per_step": int(S("n_slots_inexact")),
                     "k_regions_wave_cycle_share": {k_: round(S(k_) / max(1.0, S("cyc_total")), 3) for k_ in ("cyc_colour", "cyc_paths", "cyc_consensus", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "cyc_walk")},
                     "alignment_moves_per_step": int(S("n_moves")), "k_regions_wave_ticks_per_step": int(S("cyc_total")), "regions_redone_bigger_arena": int(S("n_arena_overflow"))}
+        # the second kernel of the path, the one that is bound by HBM (random 8-byte reads of the half-k-mer index, the unitig pool behind its candidates)
+        ki_ms = tot["k_inexact"] / n_l
+        ki_traffic, ki_src = pmc_traffic("k_inexact")
+        roofline["k_inexact"] = {"bound": "hbm", "achieved": round(alg["k_inexact"] / (ki_ms * 1e-3) / 1e9, 3) if ki_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(alg["k_inexact"] / (ki_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ki_ms > 0 else 0.0, "alg_bytes_per_launch": int(alg["k_inexact"]), "avg_launch_ms": round(ki_ms, 3),
+                                 "traffic": ki_traffic, "traffic_source": ki_src,
+                                 "alg_bytes_are": "8 B per index slot visited + 8 B per list word + 16 B per checked candidate (its entry holds the bases around the half k-mer: no read of the unitig pool) + 1 B per read base + 16 B per hit written"}
         whole_alg = (8.0 * S("n_probes_exact") + 16.0 * (S("n_slots_exact") + S("n_slots_inexact")) + 40.0 * S("n_expand") + 4.0 * S("n_colour_elem") + 0.25 * S("n_path_base") + 4.0 * S("in_bases")) / max(1.0, S("in_bases"))
         dt_all, bases_all = w["dt_all"], w["bases_all"]
         set_name = ("HG002-chr20-scale set (configs[2]'s graph): k=31 first pass, %.1f Mb diploid random ref (%.2f %% het SNPs)" % (a.ref_len / 1e6, 100 * a.het)) if diploid else ("configs[1]: k=31 first-pass correct, %.1f Mb random ref" % (a.ref_len / 1e6))
@@ -504,6 +578,8 @@ def main():
             out["host_inclusive"] = host_inclusive_leg(a, api, w["graph"], w["opts"], w["mine"])
             out["cli_file_to_file"] = cli_leg(a, w["pre"], w["fa"], w["rt"])
             out["second_pass"] = second_pass_leg(a, w["pre"])
+            out["by_ticket_size"] = ticket_size_leg(a, api, w["graph"], w["opts"], w["mine"])
+            out["lane_kernel"] = lane_kernel_leg(a, api, w["graph"], w["opts"], w["mine"])
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(a, api, w["graph"], w["opts"], w["fa"], w["rt"], w["mine"], whole_alg, out)
     w["graph"].close()

@@ -178,7 +178,7 @@ __global__ void k_hx_keys(const uint64_t* __restrict__ useq, const uint64_t* __r
 struct PopcountOf { const uint64_t* w; __device__ uint32_t operator()(uint64_t i) const { return static_cast<uint32_t>(__popcll(w[i])); } };
 
 // sorted keys -> the lists and the slot table. S: the keys of one range of bins, `base` keys lie in the ranges before it.
-__global__ void k_hx_scatter(const uint64_t* __restrict__ S, uint64_t n_s, uint64_t base, const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ rank,
+__global__ void k_hx_scatter(const uint64_t* __restrict__ S, uint64_t n_s, uint64_t base, const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ rank, const uint64_t* __restrict__ useq, int h,
                              const uint64_t* __restrict__ uoff, uint32_t n_unitigs, uint64_t* __restrict__ hx, uint64_t hx_mask, uint64_t* __restrict__ hxl) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_s; i += stride) {
@@ -187,12 +187,20 @@ __global__ void k_hx_scatter(const uint64_t* __restrict__ S, uint64_t n_s, uint6
         uint32_t lo = 0, hi = n_unitigs;
         while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (uoff[mid] <= pos) lo = mid; else hi = mid; }
         const uint64_t gi = base + i;
-        hxl[gi + r + 1] = (static_cast<uint64_t>(lo) << 32) | (pos - uoff[lo]);
+        { // the two words of the place: the h + 1 bases behind and in front of the h-mer (zeros where the unitig ends), then unitig << 32 | behind-exists << 31 | offset
+            const uint64_t u0 = uoff[lo], u1 = uoff[lo + 1], nbf = static_cast<uint64_t>(h) + 1ull;
+            const bool a_ok = pos + static_cast<uint64_t>(h) + nbf <= u1, b_ok = pos >= u0 + nbf;
+            uint64_t after = 0, before = 0;
+            if (a_ok) for (uint64_t x = 0; x < nbf; ++x) { const uint64_t q_ = pos + static_cast<uint64_t>(h) + x; after = (after << 2) | ((useq[q_ >> 5] >> (2ull * (q_ & 31ull))) & 3ull); }
+            if (b_ok) for (uint64_t x = 0; x < nbf; ++x) { const uint64_t q_ = pos - nbf + x; before = (before << 2) | ((useq[q_ >> 5] >> (2ull * (q_ & 31ull))) & 3ull); }
+            hxl[2 * gi + r + 1] = (after << 32) | before;
+            hxl[2 * gi + r + 2] = (static_cast<uint64_t>(lo) << 32) | (a_ok ? (1ull << 31) : 0ull) | (pos - u0);
+        }
         if (i == 0 || (S[i - 1] >> RTK_POS_BITS) != hm) { // first key of its h-mer: the count word and the slot (a range of bins never splits an h-mer)
             uint64_t a = i, b = i + 1, step = 1;
             while (b < n_s && (S[b] >> RTK_POS_BITS) == hm) { a = b; b = b + step < n_s ? b + step : n_s; step <<= 1; } // gallop, then bisect: (a same, b differs or the end)
             while (b - a > 1) { const uint64_t mid = a + (b - a) / 2; if ((S[mid] >> RTK_POS_BITS) == hm) a = mid; else b = mid; }
-            const uint64_t w = gi + r;
+            const uint64_t w = 2 * gi + r;
             hxl[w] = b - i;
             const uint64_t word = (hm << RTK_POS_BITS) | w;
             uint64_t q = rtk_hash64(hm) & hx_mask;
@@ -241,9 +249,9 @@ void device_tables_build(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_
         uint32_t last_rank = 0; uint64_t last_word = 0;
         rtk_check(hipMemcpy(&last_rank, rank.as<uint32_t>() + (bm_words - 1), 4, hipMemcpyDeviceToHost), "hipMemcpy"); rtk_check(hipMemcpy(&last_word, bitmap.as<uint64_t>() + (bm_words - 1), 8, hipMemcpyDeviceToHost), "hipMemcpy");
         const uint64_t uniq = static_cast<uint64_t>(last_rank) + static_cast<uint64_t>(__builtin_popcountll(last_word));
-        if (n_pairs + uniq >= (1ull << RTK_POS_BITS)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
+        if (2 * n_pairs + uniq >= (1ull << RTK_POS_BITS)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
         uint64_t hslots = 16; while (hslots < 2 * uniq) hslots <<= 1;
-        hx_words = hslots; hxl_words = n_pairs + uniq + 1;
+        hx_words = hslots; hxl_words = 2 * n_pairs + uniq + 1;
         hx.alloc(8 * hx_words); hxl.alloc(8 * hxl_words);
         hipLaunchKernelGGL(k_fill_words, dim3(grid_for(hx_words)), dim3(RTK_TB_BLOCK), 0, 0, hx.as<uint64_t>(), hx_words, RTK_EMPTY_KEY);
         rtk_check(hipMemset(hxl.as<uint64_t>() + (hxl_words - 1), 0, 8), "hipMemset");
@@ -271,7 +279,7 @@ void device_tables_build(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_
             rtk_check(hipGetLastError(), "k_hx_keys");
             rocprim::double_buffer<uint64_t> db(keys.as<uint64_t>(), alt.as<uint64_t>());
             size_t tb2 = tb; rtk_check(rocprim::radix_sort_keys(tmp.p, tb2, db, static_cast<size_t>(n_s), 0, RTK_POS_BITS + 2 * h), "rocprim::radix_sort_keys");
-            hipLaunchKernelGGL(k_hx_scatter, dim3(grid_for(n_s)), dim3(RTK_TB_BLOCK), 0, 0, db.current(), n_s, done, bitmap.as<uint64_t>(), rank.as<uint32_t>(), d_uoff, n_unitigs, hx.as<uint64_t>(), hx_words - 1, hxl.as<uint64_t>());
+            hipLaunchKernelGGL(k_hx_scatter, dim3(grid_for(n_s)), dim3(RTK_TB_BLOCK), 0, 0, db.current(), n_s, done, bitmap.as<uint64_t>(), rank.as<uint32_t>(), d_useq, h, d_uoff, n_unitigs, hx.as<uint64_t>(), hx_words - 1, hxl.as<uint64_t>());
             sync_check("half-k-mer index (keys, sort, lists)");
             unsigned long long wrote = 0; rtk_check(hipMemcpy(&wrote, top.p, 8, hipMemcpyDeviceToHost), "hipMemcpy");
             if (wrote != n_s) throw std::runtime_error("half-k-mer index: key count of a range differs from its histogram");

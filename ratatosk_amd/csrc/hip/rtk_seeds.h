@@ -613,13 +613,15 @@ template <class V>
 RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_t ck, uint32_t ck1, uint32_t* n_lookups, uint32_t* n_slots, bool all_kinds, V visit) { // visit(code, hit, kinds)
     const int h = (k - 1) / 2;
     const uint64_t hm = (1ull << (2 * h)) - 1ull;
-    const uint64_t* const hx = g.hx; const uint64_t hx_mask = g.hx_mask; const uint64_t* const hxl = g.hxl; const uint64_t* const uoff = g.uoff;
+    const uint64_t* const hx = g.hx; const uint64_t hx_mask = g.hx_mask; const uint64_t* const hxl = g.hxl;
     // the window's characters as one code: k-1, k or k+1 of them
     uint64_t key[4]; bool first_half[4]; int nkeys = 0;
     key[nkeys] = (w_k1 >> (2 * (k - 1 - h))) & hm; first_half[nkeys++] = true;                       // m[p .. p+h)
     key[nkeys] = w_k1 & hm; first_half[nkeys++] = false;                                              // m[p+k-1-h .. p+k-1): last half when the graph k-mer has an extra base
     if (ck <= 3) { key[nkeys] = ((w_k1 << 2) | static_cast<uint64_t>(ck)) & hm; first_half[nkeys++] = false; } // m[p+k-h .. p+k): substitution
     if (ck <= 3 && ck1 <= 3) { key[nkeys] = ((w_k1 << 4) | (static_cast<uint64_t>(ck) << 2) | static_cast<uint64_t>(ck1)) & hm; first_half[nkeys++] = false; } // m[p+k+1-h .. p+k+1): a read base missing in the graph
+    // (measured in round 5: all eight home slots, then all count words, in flight together -- three rounds of independent loads instead of eight chains -- is SLOWER,
+    // 5.8 against 4.7 ms per 64 Mb on the 60 Mb graph: the lookups of six waves per SIMD already overlap, the arrays of the batched form spill)
     for (int q = 0; q < nkeys; ++q) {
         for (int ori = 0; ori < 2; ++ori) {
             const uint64_t x = ori ? rtk_revcomp(key[q], h) : key[q];
@@ -632,13 +634,14 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
             // read-oriented G = F when the read h-mer itself was found, its reverse complement when the reverse-complemented key was
             const bool at_start = (first_half[q] != (ori != 0));
             for (uint32_t e = 0; e < cnt; ++e) {
-                const uint64_t ent = hxl[first + e];
-                *n_slots += 2; // a candidate costs its list entry, the unitig bounds and 16 bytes of unitig sequence
-                const uint32_t u = static_cast<uint32_t>(ent >> 32), pos = static_cast<uint32_t>(ent & 0xFFFFFFFFull);
-                const uint64_t u0 = uoff[u], ulen = uoff[u + 1] - u0;
-                int64_t t = static_cast<int64_t>(pos) - (at_start ? 0 : (h + 1));
-                if (t < 0 || static_cast<uint64_t>(t) + static_cast<uint64_t>(k) > ulen) continue;
-                const uint64_t F = rtk_pool_kmer(g, u0 + static_cast<uint64_t>(t), k);
+                // a place is two words: the h + 1 bases behind / in front of the h-mer, then unitig << 32 | behind-exists << 31 | offset: the candidate k-mer is the
+                // h-mer with one of its flanks, the entry alone verifies it (round 5: the unitig's bounds and its sequence were two more dependent cache lines each)
+                const uint64_t fl = hxl[first + 2ull * e], ent = hxl[first + 2ull * e + 1ull];
+                *n_slots += 2; // a candidate costs its 16-byte list entry
+                const uint32_t u = static_cast<uint32_t>(ent >> 32), pos = static_cast<uint32_t>(ent & 0x7FFFFFFFull);
+                int64_t t; uint64_t F;
+                if (at_start) { if (!((ent >> 31) & 1ull)) continue; t = pos; F = (x << (2 * (h + 1))) | (fl >> 32); }
+                else { if (pos < static_cast<uint32_t>(h + 1)) continue; t = static_cast<int64_t>(pos) - (h + 1); F = ((fl & 0xFFFFFFFFull) << (2 * h)) | x; }
                 const uint64_t G = ori ? rtk_revcomp(F, k) : F;
                 const uint32_t kinds = rtk_one_edit(G, k, w_k1, ck, ck1, all_kinds);
                 if (kinds) visit(G, rtk_pack_hit(u, static_cast<uint32_t>(t), ori ? 0u : 1u), kinds);

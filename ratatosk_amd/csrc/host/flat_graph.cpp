@@ -62,10 +62,10 @@ TableSizes table_sizes(int k, uint64_t n_kmers, uint64_t n_bases) {
         const char* e_enum = getenv("RTK_INEXACT_ENUM"); const char* e_gb = getenv("RTK_HX_MAX_GB");
         const double max_gb = e_gb ? atof(e_gb) : 96.0;
         // size before building: the distinct h-mers are at most 4^h (1.07 G for k = 31: a 3 Gb graph saturates them), the slot table a power of two
-        // >= twice that, the lists one word per h-mer start + one per distinct h-mer
+        // >= twice that, the lists two words per h-mer start + one per distinct h-mer
         const double bases = static_cast<double>(n_bases); const double all_h = std::pow(4.0, t.h); const double uniq = bases < all_h ? bases : all_h;
         double hs = 16; while (hs < 2 * uniq) hs *= 2;
-        const double est_gb = (8.0 * hs + 8.0 * (bases + uniq)) / 1e9;
+        const double est_gb = (8.0 * hs + 8.0 * (2.0 * bases + uniq)) / 1e9; // (two words per h-mer start)
         t.hx = !((e_enum && e_enum[0] == '1') || est_gb > max_gb || wide);
     }
     // k-mer table, load factor <= 0.5: small graphs keep the round-2 sizes -- a power of two at load 0.25 .. 0.5; above RTK_HT_DENSE_KMERS k-mers (default 2^28: a 4 GB
@@ -141,7 +141,9 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     // ---- half-k-mer index: every h-mer (h = (k-1)/2) of the forward unitig sequences -> the places it starts. A graph k-mer one edit
     // away from a read window shares its first or its last h characters with the read (the edit cannot be in both), so the 1-edit search
     // looks up read h-mers here and verifies the few k-mers they belong to instead of spelling every variant of the window.
-    // hx: one word per slot, h-mer << 34 | first; hxl[first] = number of places, then the places (unitig << 32 | offset).
+    // hx: one word per slot, h-mer << 34 | first; hxl[first] = number of places, then TWO words per place: the h + 1 bases behind the h-mer (high half) and the
+    // h + 1 bases in front of it (low half), first base in the high bits, zeros where the unitig ends; then unitig << 32 | (h + 1 bases behind exist) << 31 | offset.
+    // A candidate k-mer is the h-mer with one of its flanks: the search verifies it from the entry alone, without reading the unitig's bounds or sequence.
     // Not built (a single empty slot; the search then spells the variants) with RTK_INEXACT_ENUM=1 or above RTK_HX_MAX_GB (default 96).
     const TableSizes tsz = table_sizes(k, n_kmers, uoff[n]);
     {
@@ -155,6 +157,15 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             typedef std::pair<uint64_t, uint64_t> HP;
             const uint64_t n_pairs = uoff[n] - static_cast<uint64_t>(n) * static_cast<uint64_t>(h - 1);
             const uint64_t hm = (1ull << (2 * h)) - 1ull;
+            auto flank_words = [&](uint64_t place, uint64_t* fl, uint64_t* pl) { // the two words of a place (see above)
+                const uint32_t u = static_cast<uint32_t>(place >> 32); const uint64_t pos = place & 0xFFFFFFFFull; const std::string& sq = seqs[u];
+                const uint64_t nbf = static_cast<uint64_t>(h) + 1;
+                if (pos >> 31) throw std::runtime_error("half-k-mer index: a unitig of more than 2^31 bases");
+                uint64_t after = 0, before = 0; const bool a_ok = pos + h + nbf <= sq.size(), b_ok = pos >= nbf;
+                if (a_ok) for (uint64_t x = 0; x < nbf; ++x) after = (after << 2) | static_cast<uint64_t>(base2bits(sq[pos + h + x]));
+                if (b_ok) for (uint64_t x = 0; x < nbf; ++x) before = (before << 2) | static_cast<uint64_t>(base2bits(sq[pos - nbf + x]));
+                *fl = (after << 32) | before; *pl = (static_cast<uint64_t>(u) << 32) | (a_ok ? (1ull << 31) : 0ull) | pos;
+            };
             int nt = n_threads < 1 ? 1 : n_threads; if (static_cast<size_t>(nt) > n) nt = static_cast<int>(n);
             int bbits = 2 * h < 12 ? 2 * h : 12; while (bbits > 0 && (n_pairs >> bbits) < 4096) --bbits; // ~4096 buckets for big graphs, fewer for small ones
             const size_t nb = static_cast<size_t>(1) << bbits; const int bshift = 2 * h - bbits;
@@ -182,14 +193,14 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                     uint64_t u = 0; for (uint64_t i = bstart[bkt]; i < bstart[bkt + 1]; ++i) if (i == bstart[bkt] || pairs[i].first != pairs[i - 1].first) ++u;
                     buniq[bkt] = u; } });
             uint64_t uniq = 0; std::vector<uint64_t> lstart(nb + 1, 0); // list words of bucket b start at lstart[b]: one count word per distinct h-mer + its places
-            for (size_t bkt = 0; bkt < nb; ++bkt) { lstart[bkt] = bstart[bkt] + uniq; uniq += buniq[bkt]; }
-            lstart[nb] = n_pairs + uniq;
-            if (n_pairs + uniq >= (1ull << 34)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
+            for (size_t bkt = 0; bkt < nb; ++bkt) { lstart[bkt] = 2 * bstart[bkt] + uniq; uniq += buniq[bkt]; }
+            lstart[nb] = 2 * n_pairs + uniq;
+            if (2 * n_pairs + uniq >= (1ull << 34)) throw std::runtime_error("half-k-mer index: more than 2^34 list words (set RTK_INEXACT_ENUM=1)");
             uint64_t hslots = 16;
             while (hslots < 2 * uniq) hslots <<= 1;
             hx.alloc_uninitialised(hslots); // (every word of the two arrays is written below, by all threads)
             parallel_slices(static_cast<size_t>(hslots), nt, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; ++i) hx[i] = RTK_EMPTY_KEY; });
-            hxl.alloc_uninitialised(n_pairs + uniq + 1);
+            hxl.alloc_uninitialised(2 * n_pairs + uniq + 1);
             next_b = 0;
             parallel_slices(static_cast<size_t>(nt), nt, [&](size_t, size_t, int) {
                 const size_t RING = 16; uint64_t ring[16]; size_t n_pend = 0; // table words waiting for their (prefetched) slot
@@ -204,12 +215,12 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                         ring[n_pend & (RING - 1)] = word; ++n_pend;
                         __builtin_prefetch(&hx[rtk_hash64(pairs[i].first) & (hslots - 1)], 1);
                         hxl[w++] = j - i;
-                        for (uint64_t t = i; t < j; ++t) hxl[w++] = pairs[t].second;
+                        for (uint64_t t = i; t < j; ++t) { uint64_t fl, pl; flank_words(pairs[t].second, &fl, &pl); hxl[w++] = fl; hxl[w++] = pl; }
                         i = j;
                     } }
                 for (size_t j = n_pend > RING ? n_pend - RING : 0; j < n_pend; ++j) claim(ring[j & (RING - 1)]);
             });
-            hxl[n_pairs + uniq] = 0;
+            hxl[2 * n_pairs + uniq] = 0;
         }
     }
     lap("half-k-mer index");
