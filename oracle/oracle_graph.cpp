@@ -68,6 +68,7 @@ void read_pairid(Rd& r, IdSet& out) {
         }
         case 0: { // Bifrost TinyBitmap::write payload, assumed layout [A8] (see oracle_graph.hpp): header, cardinality, offset, data
             if (w != 0) throw std::runtime_error("oracle: PairID flag 0 with payload bits in the flag word");
+            { const char* allow = getenv("RTK_ALLOW_TINYBITMAP"); if (!(allow && allow[0] == '1')) throw std::runtime_error("oracle: the index holds a Bifrost TinyBitmap colour set (assumption [A8], unverified): set RTK_ALLOW_TINYBITMAP=1 to decode it under that assumption"); }
             const uint32_t header = r.u16at(r.p); const uint32_t sz = header >> 3, mode = header & 6u;
             if (sz == 0) { r.p += 2; break; }
             if (sz < 3 || sz > 4096 || r.p + 2ull * sz > r.b.size()) throw std::runtime_error("oracle: TinyBitmap block malformed [A8]");

@@ -17,6 +17,7 @@
 #ifndef RTK_COMMON_RTSK_IO_HPP
 #define RTK_COMMON_RTSK_IO_HPP
 
+#include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -126,9 +127,11 @@ inline void tinybitmap_read(std::istream& in, std::vector<uint32_t>& ids) {
     if (!in.good()) throw std::runtime_error("rtsk: truncated TinyBitmap header");
     const uint32_t sz = header >> 3, mode = header & 0x6u;
     if (header & 1u) throw std::runtime_error("rtsk: TinyBitmap header has bit 0 set: not the layout assumed in [A8], refusing to guess");
-    { // [A8] cannot be checked against a Bifrost build here: say so once per process when such a payload is decoded
+    { // [A8] cannot be checked against a Bifrost build here ("fail loudly until verified"): such a payload is REFUSED unless the caller opts in
+        const char* allow = getenv("RTK_ALLOW_TINYBITMAP");
+        if (!(allow && allow[0] == '1')) throw std::runtime_error("rtsk: the index holds a Bifrost TinyBitmap colour set (PairID flag 0); its layout is assumption [A8] (oracle/oracle_graph.hpp), not verified against a Bifrost-written index: set RTK_ALLOW_TINYBITMAP=1 to decode it under that assumption");
         static bool warned = false;
-        if (!warned) { warned = true; fprintf(stderr, "rtsk: note: decoding a Bifrost TinyBitmap colour set with the layout assumed in [A8] (oracle/oracle_graph.hpp); it has not been verified against a Bifrost-written index\n"); }
+        if (!warned) { warned = true; fprintf(stderr, "rtsk: note: RTK_ALLOW_TINYBITMAP=1: decoding Bifrost TinyBitmap colour sets with the layout assumed in [A8]; it has not been verified against a Bifrost-written index\n"); }
     }
     if (sz == 0) return;
     if (sz < 3 || sz > 4096 || (mode != 0 && mode != 2 && mode != 4)) throw std::runtime_error("rtsk: TinyBitmap header does not match the assumed Bifrost layout [A8]");

@@ -194,7 +194,9 @@ extern "C" int rtk_graph_upload(rtk_graph* g, int device) {
         rtk_set_device(device);
         for (int i = 0; i < rtk::RTK_N_BUFS; ++i) {
             bool skip = false; for (int j = 0; j < 6 && deferred; ++j) skip = skip || built_here[j] == i;
-            if (skip) { if (g->dbuf[i]) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: a graph loaded with RTK_LOAD_DEVICE_TABLES allocates its table buffers itself (move them afterwards: rtk_graph_move_buffers)"); continue; }
+            if (skip) { // built below, in HBM; a second upload (a retry after a device error, another device) frees the tables of the first and builds them again
+                if (g->dbuf[i]) { if (!g->owns_buffers) return rtk_fail(RTK_ERR_ARG, "rtk_graph_upload: the table buffers of this graph were attached by the caller (rtk_graph_attach_buffers): it cannot be uploaded again with RTK_LOAD_DEVICE_TABLES"); rtk_dfree(g->dbuf[i]); g->dbuf[i] = nullptr; g->dbytes[i] = 0; }
+                continue; }
             if (!g->dbuf[i]) { g->dbuf[i] = rtk_dmalloc(bytes[i]); g->dbytes[i] = bytes[i]; } rtk_h2d(g->dbuf[i], src[i], bytes[i]);
         }
 #ifndef RTK_SIM

@@ -1423,7 +1423,7 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
     prof.hb_total += rtk_clock() - t_all0;
 }
 
-#include "rtk_myers_lt.h"
+#include "variants/rtk_myers_lt.h"
 
 // edlibAlign(..., k = -1, NW or SHW, TASK_PATH): result and moves. When the whole table fits the in-memory traceback branch of
 // obtainAlignment (edlib.cpp:1191-1193) ONE stored sweep serves both the distance and the traceback: an SHW matrix restricted to

@@ -198,7 +198,7 @@ def test_run_container_payloads_load_like_the_plain_ones(ds_snps_rich, tmp_path)
     assert pg2.correct_batch(seqs, quals) == want
 
 
-def test_tinybitmap_streams_load_like_roaring_ones(ds_snps_rich, tmp_path):
+def test_tinybitmap_streams_load_like_roaring_ones(ds_snps_rich, tmp_path, monkeypatch):
     """PairID flag 0 = Bifrost TinyBitmap::write payload (src/PairID.cpp:1158-1167), the form every set of more than one id takes
     in a reference-written index until it outgrows a TinyBitmap (PairID::add, src/PairID.cpp:599-637). Bifrost is absent, so the
     layout is the published one as assumed in rtsk_io.hpp [A8] -- unverified against a reference-written file. The same index with
@@ -207,6 +207,14 @@ def test_tinybitmap_streams_load_like_roaring_ones(ds_snps_rich, tmp_path):
     rt2 = str(tmp_path / "tiny.rtsk")
     n_tiny, a, b, c = _rewrite(rt, rt2, lambda v: v, tiny=True)
     assert n_tiny > 300 and min(a, b, c) > 50  # all three modes
+    # refused by default (the layout is an assumption): the product and the oracle's loader both say why and name the switch
+    for load in (lambda: api.Graph(fa, rt2, 31, upload=False), lambda: op.Graph(fa, rt2, 31)):
+        try:
+            load()
+            assert False, "TinyBitmap stream decoded without RTK_ALLOW_TINYBITMAP=1"
+        except Exception as e:
+            assert "RTK_ALLOW_TINYBITMAP" in str(e)
+    monkeypatch.setenv("RTK_ALLOW_TINYBITMAP", "1")
     og1, og2 = op.Graph(fa, rt, 31), op.Graph(fa, rt2, 31)
     pg2 = api.Graph(fa, rt2, 31, device=0, lib_path=SIM_LIB)
     flat = _flat_colours(pg2)
@@ -220,8 +228,9 @@ def test_tinybitmap_streams_load_like_roaring_ones(ds_snps_rich, tmp_path):
     assert pg2.correct_batch(seqs, quals) == og1.correct_batch(seqs, quals, threads=4)[0]
 
 
-def test_malformed_tinybitmap_is_refused_loudly(ds_small, tmp_path):
+def test_malformed_tinybitmap_is_refused_loudly(ds_small, tmp_path, monkeypatch):
     """A flag-0 stream that does not fit the assumed layout must name the problem instead of mis-parsing the rest of the file."""
+    monkeypatch.setenv("RTK_ALLOW_TINYBITMAP", "1")
     rt = ds_small + ".index.k31.rtsk"
     data = bytearray(open(rt, "rb").read())
     data[32:40] = struct.pack("<Q", 0)  # first record's global PairID word -> flag 0; what follows is not a TinyBitmap
