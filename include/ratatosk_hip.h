@@ -67,6 +67,10 @@ typedef struct rtk_opts {
      * such ties by unitig id: 0 = ascending (default), 1 = descending. rtk_opts_default takes it from the environment: RTK_D1_ORDER=asc | desc.
      * profiles/r04_d1_count.json counts the reads the choice decides. */
     int32_t d1_desc;
+    /* sizeof(rtk_opts) of the library that filled the struct (rtk_opts_default writes it; round 5). Every entry that takes an rtk_opts refuses one whose
+     * struct_size is not its own sizeof(rtk_opts) with RTK_ERR_ARG: a caller compiled against an older header (the struct has grown in rounds 2, 3, 4 and 5), or one
+     * that zero-fills the struct instead of calling rtk_opts_default, is told so instead of running with fields it never set. New fields go BEFORE this one. */
+    uint32_t struct_size;
 } rtk_opts;
 
 typedef struct rtk_graph_info {
@@ -251,6 +255,9 @@ int rtk_index_colour_end(void* job, uint64_t** events, uint64_t* n_events, uint6
 void rtk_free(void* p);
 const char* rtk_last_error(void);
 const char* rtk_version(void);
+/* Interface revision, raised whenever a struct of this header grows or a default changes (5: rtk_opts.struct_size, rtk_stats lane fields, a2_exclusive default 1). */
+#define RTK_API_REVISION 5
+int rtk_api_revision(void);
 
 #ifdef __cplusplus
 }

@@ -3,8 +3,8 @@ repeats), SR_COV x PE150 short reads SAMPLED ON THE FLY inside the index tool (`
 index built with `--gpu --snps`, graph loaded and resident in HBM, TICKETS 64 Mb tickets of ONT-profile long reads corrected with three in flight.
 Size-independent checks as in round 3 (the oracle cannot hold this graph): corrected reads against the stretches of the reference they were
 simulated from (edit distances by the device's banded NW), share of k-mer windows found in the graph.
-Usage (GPU box): python profiles/scripts/r04_config4.py [REF_MB=3000] [SR_COV=30] [THREADS=128] [TICKETS=6]      (RTK_C4_OUT=file.json, RTK_C4_DIR=/tmp)
-Leaves the index under $RTK_C4_DIR/c4_keep/ when RTK_C4_KEEP=1 (the profiling passes of r04_config4.sh reuse it)."""
+Usage (GPU box): python profiles/scripts/config4_run.py [REF_MB=3000] [SR_COV=30] [THREADS=128] [TICKETS=6]      (RTK_C4_OUT=file.json, RTK_C4_DIR=/tmp)
+Leaves the index under $RTK_C4_DIR/c4_keep/ when RTK_C4_KEEP=1 (the file-to-file run and the profiling passes of r05_config4.sh reuse it)."""
 import ctypes as C, json, os, subprocess, sys, tempfile, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

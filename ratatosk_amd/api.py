@@ -21,7 +21,7 @@ class RtkOpts(C.Structure):
                 ("max_km_cov", C.c_uint64), ("weak_region_len_factor", C.c_double), ("large_k_factor", C.c_double),
                 ("min_score", C.c_double), ("max_qual", C.c_int32), ("out_qual", C.c_int32), ("min_confidence_snp_corr", C.c_double),
                 ("long_read_correct", C.c_int32), ("force_unres_snp_corr", C.c_int32), ("max_len_weak_region2", C.c_uint64),
-                ("a2_exclusive", C.c_int32), ("a3_strand_order", C.c_int32), ("d1_desc", C.c_int32)]
+                ("a2_exclusive", C.c_int32), ("a3_strand_order", C.c_int32), ("d1_desc", C.c_int32), ("struct_size", C.c_uint32)]
 
 
 class RtkGraphInfo(C.Structure):

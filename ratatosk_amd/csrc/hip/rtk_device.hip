@@ -38,11 +38,12 @@ int rtk_fail(int code, const std::string& msg) { g_last_error = msg; return code
 extern "C" const char* rtk_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* rtk_version(void) {
 #ifdef RTK_SIM
-    return "ratatosk-mi355x 0.1 (host simulator)";
+    return "ratatosk-mi355x 0.5 (host simulator)";
 #else
-    return "ratatosk-mi355x 0.1 (gfx950)";
+    return "ratatosk-mi355x 0.5 (gfx950)";
 #endif
 }
+extern "C" int rtk_api_revision(void) { return RTK_API_REVISION; }
 extern "C" void rtk_free(void* p) { free(p); }
 
 // ------------------------------------------------------------------------------------------------ graph object
@@ -327,7 +328,7 @@ extern "C" int rtk_opts_default(const rtk_graph* g, rtk_opts* o) {
     o->insert_sz = 500; o->min_cov_vertices = 2; o->max_len_weak_region1 = 1000;
     o->max_km_cov = 128; if (g && g->info.max_km_cov_top > 128) o->max_km_cov = g->info.max_km_cov_top; // src/Ratatosk.cpp:625
     o->weak_region_len_factor = 0.25; o->large_k_factor = 1.5; o->min_score = 0.0; o->max_qual = 40; o->out_qual = 1; o->min_confidence_snp_corr = 0.9;
-    o->long_read_correct = 0; o->force_unres_snp_corr = 0; o->max_len_weak_region2 = 5000;
+    o->long_read_correct = 0; o->force_unres_snp_corr = 0; o->max_len_weak_region2 = 5000; o->struct_size = static_cast<uint32_t>(sizeof(rtk_opts));
     { const char* e = getenv("RTK_A2_XOR"); o->a2_exclusive = (e && !strcmp(e, "union")) ? 0 : ((e && !strcmp(e, "exclusive-ids")) ? 2 : 1); const char* e3 = getenv("RTK_A3_ORDER"); o->a3_strand_order = (e3 && !strcmp(e3, "strand")) ? 1 : 0;  const char* e4 = getenv("RTK_D1_ORDER"); o->d1_desc = (e4 && !strcmp(e4, "desc")) ? 1 : 0; } // [A2] switch, see rtk_opts
     return RTK_OK;
 }
@@ -530,13 +531,13 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
         const int grid = static_cast<int>(std::min<uint32_t>(n, static_cast<uint32_t>(default_grid() / 4 > 0 ? default_grid() / 4 : 1)));
         const uint64_t stride = scratch_bytes(cfg) + (waves > 1 ? static_cast<uint64_t>((waves < RTK_LEAF_WAVES ? waves : RTK_LEAF_WAVES) - 1) * scratch_bytes(rtk_leaf_cfg()) : 0ull); // + the leaf-traceback areas of the helper waves
         const uint32_t cap_moves = want_path ? (max_q + max_t + 8) : 1;
-        char* dpool = static_cast<char*>(rtk_dmalloc(pool.size() + 64));
-        MyersProb* dprobs = static_cast<MyersProb*>(rtk_dmalloc(sizeof(MyersProb) * n));
-        char* dscr = static_cast<char*>(rtk_dmalloc(stride * grid));
-        int32_t* ddist = static_cast<int32_t*>(rtk_dmalloc(4ull * n)); int32_t* dnloc = static_cast<int32_t*>(rtk_dmalloc(4ull * n));
-        int32_t* dlocs = static_cast<int32_t*>(rtk_dmalloc(4ull * n * cap_locs + 8));
-        uint8_t* dmoves = static_cast<uint8_t*>(rtk_dmalloc(static_cast<uint64_t>(n) * cap_moves + 8));
-        uint32_t* dnm = static_cast<uint32_t*>(rtk_dmalloc(4ull * n)); uint32_t* dst = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
+        struct Held { std::vector<void*> v; void* get(uint64_t bytes) { v.push_back(nullptr); v.back() = rtk_dmalloc(bytes); return v.back(); } void release() { for (void* p : v) if (p) rtk_dfree(p); v.clear(); } ~Held() { release(); } } held; // (freed on every way out)
+        char* dpool = static_cast<char*>(held.get(pool.size() + 64));
+        MyersProb* dprobs = static_cast<MyersProb*>(held.get(sizeof(MyersProb) * n));
+        char* dscr = static_cast<char*>(held.get(stride * grid));
+        int32_t* ddist = static_cast<int32_t*>(held.get(4ull * n)); int32_t* dnloc = static_cast<int32_t*>(held.get(4ull * n));
+        int32_t* dlocs = static_cast<int32_t*>(held.get(4ull * n * cap_locs + 8)); uint32_t* dst = static_cast<uint32_t*>(held.get(4ull * n));
+        uint8_t* dmoves = static_cast<uint8_t*>(held.get(static_cast<uint64_t>(n) * cap_moves + 8)); uint32_t* dnm = static_cast<uint32_t*>(held.get(4ull * n));
         rtk_h2d(dpool, pool.data(), pool.size()); rtk_h2d(dprobs, probs.data(), sizeof(MyersProb) * n);
         unsigned long long* dprof = nullptr; // RTK_MYERS_PROF=1: cycle counters of the Hirschberg drivers (developer)
         if (getenv("RTK_MYERS_PROF")) { dprof = static_cast<unsigned long long*>(rtk_dmalloc(64)); const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; rtk_h2d(dprof, z, 64); }
@@ -567,7 +568,7 @@ extern "C" int rtk_myers_batch_waves(uint32_t n, const char* const* query, const
                 memcpy(cigar + static_cast<size_t>(i) * cap_cigar, c.c_str(), c.size() + 1);
             }
         }
-        rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dmoves); rtk_dfree(dnm); rtk_dfree(dst);
+        held.release();
         return rc;
     } catch (const std::exception& e) { return rtk_fail(RTK_ERR_DEVICE, e.what()); }
 }
@@ -620,15 +621,19 @@ extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const
             if (mode[i] == RTK_MODE_HW && want_path) return rtk_fail(RTK_ERR_UNSUPPORTED, "rtk_myers_batch_lanes: HW path alignment is not on the hot path");
             max_q = std::max(max_q, qlen[i]); max_t = std::max(max_t, tlen[i]);
         }
-        const uint64_t stride = rtk_ml_scratch_bytes() + (want_path ? rtk_ml_table_bytes() : 0ull);
+        // the path table holds the word-columns the biggest problem of the call can ask for (words x (first end location + 1 <= tlen), never above the route's limit)
+        uint64_t tb_cols = 1;
+        if (want_path) for (uint32_t i = 0; i < n; ++i) tb_cols = std::max(tb_cols, std::min<uint64_t>(static_cast<uint64_t>((qlen[i] + 63u) >> 6) * tlen[i], RTK_ML_TB_WORDCOLS));
+        const uint64_t stride = rtk_ml_scratch_bytes() + (want_path ? static_cast<uint64_t>(RTK_WAVE) * 32ull * tb_cols : 0ull);
         const int grid = static_cast<int>(std::min<uint64_t>((static_cast<uint64_t>(n) + RTK_WAVE - 1) / RTK_WAVE, static_cast<uint64_t>(want_path ? std::min(default_grid(), 512) : default_grid())));
         const uint32_t cap_moves = want_path ? (std::min<uint32_t>(max_q, 64u * RTK_ML_MAXW) + std::min<uint32_t>(max_t, RTK_ML_MAXN) + 8) : 1;
-        char* dpool = static_cast<char*>(rtk_dmalloc(pool.size() + 64));
-        MyersProb* dprobs = static_cast<MyersProb*>(rtk_dmalloc(sizeof(MyersProb) * n));
-        char* dscr = static_cast<char*>(rtk_dmalloc(stride * grid));
-        int32_t* ddist = static_cast<int32_t*>(rtk_dmalloc(4ull * n)); int32_t* dnloc = static_cast<int32_t*>(rtk_dmalloc(4ull * n));
-        int32_t* dlocs = static_cast<int32_t*>(rtk_dmalloc(4ull * n * cap_locs + 8)); uint32_t* dst = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
-        uint8_t* dmoves = static_cast<uint8_t*>(rtk_dmalloc(static_cast<uint64_t>(n) * cap_moves + 8)); uint32_t* dnm = static_cast<uint32_t*>(rtk_dmalloc(4ull * n));
+        struct Held { std::vector<void*> v; void* get(uint64_t bytes) { v.push_back(nullptr); v.back() = rtk_dmalloc(bytes); return v.back(); } void release() { for (void* p : v) if (p) rtk_dfree(p); v.clear(); } ~Held() { release(); } } held; // (freed on every way out)
+        char* dpool = static_cast<char*>(held.get(pool.size() + 64));
+        MyersProb* dprobs = static_cast<MyersProb*>(held.get(sizeof(MyersProb) * n));
+        char* dscr = static_cast<char*>(held.get(stride * grid));
+        int32_t* ddist = static_cast<int32_t*>(held.get(4ull * n)); int32_t* dnloc = static_cast<int32_t*>(held.get(4ull * n));
+        int32_t* dlocs = static_cast<int32_t*>(held.get(4ull * n * cap_locs + 8)); uint32_t* dst = static_cast<uint32_t*>(held.get(4ull * n));
+        uint8_t* dmoves = static_cast<uint8_t*>(held.get(static_cast<uint64_t>(n) * cap_moves + 8)); uint32_t* dnm = static_cast<uint32_t*>(held.get(4ull * n));
         rtk_h2d(dpool, pool.data(), pool.size()); rtk_h2d(dprobs, probs.data(), sizeof(MyersProb) * n);
         { RtkTimer tk; const bool timed = getenv("RTK_MYERS_TIME") != nullptr; if (timed) tk.start(0);
           rtk_launch(k_myers_batch_lanes, grid, 0, static_cast<const MyersProb*>(dprobs), n, static_cast<const char*>(dpool), want_path, use_iupac, dscr, stride, grid, ddist, dnloc, dlocs, cap_locs, dmoves, dnm, cap_moves, dst);
@@ -650,7 +655,7 @@ extern "C" int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const
                 memcpy(cigar + static_cast<size_t>(i) * cap_cigar, c.c_str(), c.size() + 1);
             }
         }
-        rtk_dfree(dpool); rtk_dfree(dprobs); rtk_dfree(dscr); rtk_dfree(ddist); rtk_dfree(dnloc); rtk_dfree(dlocs); rtk_dfree(dst); rtk_dfree(dmoves); rtk_dfree(dnm);
+        held.release();
         if (rc != RTK_OK) return rc;
         // the problems that are not for this route (query above 512 characters, target above 2048 or with a character outside ACGTN, a path table above 4096 word-columns): one wave each
         std::vector<uint32_t> rest; for (uint32_t i = 0; i < n; ++i) if (st[i]) rest.push_back(i);

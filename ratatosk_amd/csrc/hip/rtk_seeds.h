@@ -700,7 +700,8 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
             my_n = w2;
         } else if (exclusive && cand) keep = rtk_a2_keep(any, exclusive);
         *acc_probes += lookups; *acc_slots += slots;
-        if (more) { // a window inside a repeat: count every visit, take a private slice of the pool, write them all
+        if (more) { // a window inside a repeat: count every visit, take a private slice of the pool, write them all. (`more` is raised by hits of ANY kind of edit -- the kinds
+            // kept are only known once the whole window has been visited -- but the slice is sized from the KEPT hits alone: the pool does not grow with the exclusive reading of [A2])
             uint32_t n_all = 0, l2 = 0, s2 = 0;
             rtk_seeded_window(g, k, c_k1, ck, ck1, &l2, &s2, exclusive, [&](uint64_t, uint64_t, uint32_t kinds) { if (kinds & keep) ++n_all; });
             const unsigned long long pb = rtk_atomic_add(bv.ipool_top, static_cast<unsigned long long>(n_all));

@@ -102,6 +102,12 @@ def test_strip_annotations_gives_the_plain_index(ds_snps):
     assert L.rtk_correct_batch(h, C.byref(o), n, sa, qa, la, os_, oq, ol) == 0
     got = [(C.string_at(os_[i], ol[i]).decode(), C.string_at(oq[i], ol[i]).decode()) for i in range(n)]
     assert got == want
+    # an rtk_opts the library's rtk_opts_default did not fill (a zero-filled struct, a caller built against an older, shorter header) is refused, not run
+    assert o.struct_size == C.sizeof(api.RtkOpts) and L.rtk_api_revision() >= 5
+    z = api.RtkOpts()
+    assert L.rtk_correct_batch(h, C.byref(z), n, sa, qa, la, os_, oq, ol) == -3 and b"rtk_opts_default" in L.rtk_last_error()
+    o.struct_size -= 4
+    assert L.rtk_correct_batch(h, C.byref(o), n, sa, qa, la, os_, oq, ol) == -3
     L.rtk_graph_free(h)
 
 
