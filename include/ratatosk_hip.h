@@ -97,6 +97,10 @@ typedef struct rtk_stats {
      * them it handed on to the wave kernel (a capacity, a short-cycle unitig, a character outside A C G T N ...: same results, counted) */
     double ms_lanes;
     uint64_t n_lane_regions, n_lane_handed;
+    /* second pass: time of the phasing() step of the ticket, and the reads whose whole-read alignment was skipped because no stretch of theirs was marked
+     * (the walk over the CIGAR then returns the corrected read as it is, src/Graph.cpp:975-1069) */
+    double ms_phase;
+    uint64_t n_phase_skipped;
 } rtk_stats;
 
 /* dbg.read(G.fasta.gz) + readGraphData(G.rtsk) (reference: src/Ratatosk.cpp:1087-1089; src/Graph.cpp:722-784).

@@ -35,7 +35,7 @@ class RtkStats(C.Structure):
                [(n, C.c_uint64) for n in ("n_windows", "n_probes_exact", "n_probes_inexact", "n_hits_inexact", "n_regions", "n_region_items", "n_arena_overflow",
                                          "n_expand", "n_colour_elem", "n_path_base", "n_align", "n_align_cells", "in_bases", "out_bases",
                                          "cyc_colour", "cyc_paths", "cyc_consensus", "cyc_total", "cyc_myers", "cyc_sets", "cyc_tostring", "cyc_pathqual", "n_slots_exact", "n_slots_inexact", "cyc_walk", "n_moves")] + \
-               [("ms_lanes", C.c_double), ("n_lane_regions", C.c_uint64), ("n_lane_handed", C.c_uint64)]
+               [("ms_lanes", C.c_double), ("n_lane_regions", C.c_uint64), ("n_lane_handed", C.c_uint64), ("ms_phase", C.c_double), ("n_phase_skipped", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

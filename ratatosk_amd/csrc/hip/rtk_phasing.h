@@ -15,6 +15,7 @@ struct PhaseView {
     U<char*> out_pool; U<uint64_t> out_cap; U<unsigned long long*> out_top;
     U<uint64_t*> out_off; U<uint32_t*> out_len;                // per read: sequence at out_off, quality at out_off + out_len
     U<uint32_t> tbf_nb_h;                                      // hash functions of a TinyBloomFilter with 14 bits per element (computed in double on the host)
+    U<uint32_t> align_all;                                     // developer (RTK_PHASE_ALIGN_ALL=1): align every read, also those the alignment cannot change
 };
 
 RTK_DEV uint64_t rtk_wymix(uint64_t a, uint64_t b) {
@@ -90,6 +91,7 @@ RTK_FN void rtk_phase_read(const RCtx& c_, const PhaseView& pv_, uint32_t r_) {
     if (rtk_failed(s)) return;
     // ---- 2. one TinyBloomFilter per stretch (:921-936) ----
     uint64_t* rm = s.bm[0]; // pos2rm, one bit per position of the corrected read
+    bool any_rm = false;    // (wave-uniform) some stretch was not supported: only then does the walk of the alignment change anything
     const uint32_t rm_words = (L + k + 63) / 64 + 1;
     for (uint32_t w = static_cast<uint32_t>(rtk_lane()); w < rm_words; w += RTK_WAVE) rm[w] = 0;
     rtk_sync();
@@ -148,12 +150,26 @@ RTK_FN void rtk_phase_read(const RCtx& c_, const PhaseView& pv_, uint32_t r_) {
             }
             if (!found && compatible) {
                 const uint32_t len_i = static_cast<uint32_t>(rtk_ld(run_ul + i) & 0xFFFFFFFFull);
-                rtk_bm_add_range(rm, static_cast<uint32_t>(pos_i), static_cast<uint32_t>(pos_i) + len_i + k);
+                rtk_bm_add_range(rm, static_cast<uint32_t>(pos_i), static_cast<uint32_t>(pos_i) + len_i + k); any_rm = true;
                 state[i] = rtk_ld(state + i) | 2ull; rtk_sync();
             }
         }
     }
     // ---- 4. corrected read against the raw one (:975-1069): query = raw, target = corrected ----
+    // With pos2rm empty every branch of the walk over the CIGAR copies the corrected read and its qualities (M :1000-1020 and D :1036-1048 append s_corr[i] / q_corr[i]
+    // for every i not in pos2rm, I :1022-1034 appends nothing) and new_base_pos stays empty (s_new is all N, :1071-1089 finds no k-mer): whatever the alignment
+    // is -- NW consumes the whole target -- the result is (s_corr, q_corr). The alignment is the cost of the second pass; reads without an unsupported stretch skip it.
+    if (!rtk_u(any_rm) && !pv.align_all) {
+        if (rtk_lane() == 0) rtk_atomic_add(c.bv.counters + RTK_CNT_PHASE_SKIPPED, 1ull);
+        unsigned long long off0 = 0;
+        if (rtk_lane() == 0) off0 = rtk_atomic_add(pv.out_top, 2ull * L);
+        off0 = rtk_shfl(off0, 0);
+        pv.out_off[r] = off0; pv.out_len[r] = L;
+        if (off0 + 2ull * L > pv.out_cap) return; // the host notices and retries with a bigger pool
+        rtk_wcopy(pv.out_pool + off0, sc_, L);
+        rtk_wcopy(pv.out_pool + off0 + L, qc, L);
+        return;
+    }
     uint32_t nm = 0;
     { const unsigned long long t0 = rtk_clock(); rtk_myers_path(s.my, raw, static_cast<int>(M), sc_, static_cast<int>(L), RTK_MODE_NW, true, &nm); s.cnt[9] += rtk_clock() - t0; s.cnt[3] += 1; }
     nm = rtk_u(nm);

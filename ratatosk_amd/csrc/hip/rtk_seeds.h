@@ -102,6 +102,7 @@ RTK_HD SeedScratch seed_scratch_carve(char* base, const SeedScratchCfg& c) {
 #define RTK_CNT_CELLS 11
 #define RTK_CNT_SLOTS_EXACT 12
 #define RTK_CNT_SLOTS_INEXACT 13
+#define RTK_CNT_PHASE_SKIPPED 210 // second pass: reads whose whole-read alignment was skipped (rtk_phasing.h)
 
 RTK_DEV uint32_t rtk_hit_unitig(uint64_t h) { return static_cast<uint32_t>(h >> 33); }
 RTK_DEV bool rtk_is_branching(const GraphView& g, uint32_t u) { return (g.flags[u] & RTK_F_BRANCHING) != 0; }

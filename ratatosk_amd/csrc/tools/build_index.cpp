@@ -76,51 +76,57 @@ template <class F> static void parallel_for(size_t n, unsigned n_thr, F f) { // 
 }
 
 // The graph k-mers ONE SUBSTITUTION away from a k-mer, without spelling the 3k variants: such a neighbour shares the first k/2 bases or the
-// last k - k/2 bases with it. All oriented solid k-mers are kept sorted twice -- as they are (the first half leads) and rotated so that the
-// last half leads -- with a table of the first 24 key bits in front; a query scans the few entries that share its half and keeps those
-// whose other half differs in exactly one base. Used by the SNP search of --fast (the plain path probes every variant in the k-mer table).
+// last k - k/2 bases with it. The sorted CANONICAL solid k-mers are view one as they stand (the first half leads; not copied); view two holds the same
+// k-mers rotated so that the last half leads, sorted; a table of the first 24 key bits sits in front of each. An oriented k-mer y is in the graph when
+// its canonical form is, so the neighbours of x are the entries one substitution away from x plus the reverse complements of the entries one substitution
+// away from rc(x) (offset k-1-j, complemented base): a query scans the few entries that share a half with x, then with rc(x). Round 5: 8 bytes per
+// solid k-mer beside the k-mer set (26 GB at 3 Gb; the first version kept both orientations in both views, 103 GB + a sorting copy: `--snps` did not fit
+// a 3 Gb run). Used by the SNP search of --fast / --gpu (the plain path probes every variant in the k-mer table).
 struct NeighbourIndex {
     int k = 0, hi_n = 0, lo_n = 0; uint64_t lomask = 0;
-    std::vector<uint64_t> a, b; std::vector<uint64_t> ia, ib; int shift = 0; // ia / ib: first entry of every value of the top 24 bits of the 2k-bit key
+    const uint64_t* a = nullptr; size_t n = 0; std::vector<uint64_t> b; std::vector<uint64_t> ia, ib; int shift = 0; // ia / ib: first entry of every value of the top 24 bits of the 2k-bit key
     uint64_t rot(uint64_t x) const { return ((x & lomask) << (2 * hi_n)) | (x >> (2 * lo_n)); }
     uint64_t unrot(uint64_t r) const { return ((r & ((1ULL << (2 * hi_n)) - 1ULL)) << (2 * lo_n)) | (r >> (2 * hi_n)); }
-    static void sort_parallel(std::vector<uint64_t>& v, int key_bits, unsigned n_thr) { // bucket by the top 8 key bits, every bucket sorted by a thread
-        const int sh = key_bits > 8 ? key_bits - 8 : 0;
-        std::vector<size_t> cnt(257, 0);
-        for (size_t i = 0; i < v.size(); ++i) ++cnt[(v[i] >> sh) + 1];
-        for (int i = 0; i < 256; ++i) cnt[i + 1] += cnt[i];
-        std::vector<uint64_t> out(v.size()); std::vector<size_t> at(cnt.begin(), cnt.begin() + 256);
-        for (size_t i = 0; i < v.size(); ++i) out[at[v[i] >> sh]++] = v[i];
-        v.swap(out);
-        std::atomic<int> nx(0); std::vector<std::thread> th;
-        for (unsigned t = 0; t < n_thr; ++t) th.emplace_back([&]() { for (;;) { const int bkt = nx.fetch_add(1); if (bkt >= 256) break; std::sort(v.begin() + cnt[bkt], v.begin() + cnt[bkt + 1]); } });
-        for (size_t t = 0; t < th.size(); ++t) th[t].join();
-    }
     void build(const std::vector<uint64_t>& solid, int k_, unsigned n_thr) {
         k = k_; hi_n = k / 2; lo_n = k - hi_n; lomask = (1ULL << (2 * lo_n)) - 1ULL;
-        a.resize(2 * solid.size()); b.resize(2 * solid.size());
-        parallel_for(solid.size(), n_thr, [&](size_t bb, size_t ee, unsigned) { for (size_t i = bb; i < ee; ++i) { const uint64_t x = solid[i], y = kmer_revcomp(x, k); a[2 * i] = x; a[2 * i + 1] = y; b[2 * i] = rot(x); b[2 * i + 1] = rot(y); } });
-        sort_parallel(a, 2 * k, n_thr); sort_parallel(b, 2 * k, n_thr);
+        a = solid.data(); n = solid.size();
+        // view two without a second copy: the rotated keys are counted by their top 12 bits per thread slice, scattered to their bucket's place, every bucket sorted by a thread
+        const int bsh = 2 * k > 12 ? 2 * k - 12 : 0; const size_t nbk = static_cast<size_t>(1) << (2 * k - bsh);
+        if (n_thr == 0) n_thr = 1;
+        std::vector<std::vector<size_t> > cnt(n_thr, std::vector<size_t>(nbk, 0));
+        parallel_for(n, n_thr, [&](size_t bb, size_t ee, unsigned t) { for (size_t i = bb; i < ee; ++i) ++cnt[t][rot(a[i]) >> bsh]; });
+        std::vector<size_t> start(nbk + 1, 0);
+        { size_t at = 0; for (size_t q = 0; q < nbk; ++q) { start[q] = at; for (unsigned t = 0; t < n_thr; ++t) { const size_t c = cnt[t][q]; cnt[t][q] = at; at += c; } } start[nbk] = at; }
+        b.resize(n);
+        parallel_for(n, n_thr, [&](size_t bb, size_t ee, unsigned t) { for (size_t i = bb; i < ee; ++i) { const uint64_t r = rot(a[i]); b[cnt[t][r >> bsh]++] = r; } });
+        { std::atomic<size_t> nx(0); std::vector<std::thread> th;
+          for (unsigned t = 0; t < n_thr; ++t) th.emplace_back([&]() { for (;;) { const size_t q = nx.fetch_add(1); if (q >= nbk) break; std::sort(b.begin() + start[q], b.begin() + start[q + 1]); } });
+          for (size_t t = 0; t < th.size(); ++t) th[t].join(); }
         shift = 2 * k > 24 ? 2 * k - 24 : 0;
         const size_t nb = (static_cast<size_t>(1) << (2 * k - shift)) + 1;
-        auto index = [&](const std::vector<uint64_t>& v, std::vector<uint64_t>& ix) { ix.assign(nb, 0); for (size_t i = 0; i < v.size(); ++i) ++ix[(v[i] >> shift) + 1]; for (size_t i = 0; i + 1 < nb; ++i) ix[i + 1] += ix[i]; };
-        index(a, ia); index(b, ib);
+        auto index = [&](const uint64_t* v, std::vector<uint64_t>& ix) { ix.assign(nb, 0); for (size_t i = 0; i < n; ++i) ++ix[(v[i] >> shift) + 1]; for (size_t i = 0; i + 1 < nb; ++i) ix[i + 1] += ix[i]; };
+        std::thread t2([&]() { index(b.data(), ib); }); index(a, ia); t2.join();
     }
-    // calls f(offset j, substituted base) for every graph k-mer one substitution away from x, by (j, base) ascending
-    template <class F> void neighbours(uint64_t x, F f) const {
-        uint32_t found[96]; int nf = 0; // (j << 2 | base): at most 3 per offset, 3k <= 93 in all (a k-mer of a tandem repeat at small k has dozens: 16 slots lost some, found by tests/test_annotators.py)
+    // the canonical k-mers one substitution away from x, as (offset << 2 | base) of the ORIENTED neighbour of the caller's k-mer (flipped: x is its reverse complement)
+    void scan(uint64_t x, bool flipped, uint32_t* found, int& nf) const {
+        auto put = [&](int bit, uint64_t y) { int j = k - 1 - bit / 2; uint32_t base = static_cast<uint32_t>((y >> bit) & 3ULL); if (flipped) { j = k - 1 - j; base = 3u - base; } if (nf < 192) found[nf++] = (static_cast<uint32_t>(j) << 2) | base; };
         { // same first half: the differing base lies in the last lo_n bases
             const uint64_t lo_key = x & ~lomask, hi_key = x | lomask;
             size_t i = ia[lo_key >> shift]; const size_t e = ia[(hi_key >> shift) + 1];
-            i = static_cast<size_t>(std::lower_bound(a.begin() + i, a.begin() + e, lo_key) - a.begin());
-            for (; i < e && a[i] <= hi_key; ++i) { const uint64_t d = a[i] ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 96) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((a[i] >> bit) & 3ULL); }
+            i = static_cast<size_t>(std::lower_bound(a + i, a + e, lo_key) - a);
+            for (; i < e && a[i] <= hi_key; ++i) { const uint64_t d = a[i] ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; put(__builtin_ctzll(m), a[i]); }
         }
         { // same last half: the differing base lies in the first hi_n bases
             const uint64_t r = rot(x), himask = (1ULL << (2 * hi_n)) - 1ULL; const uint64_t lo_key = r & ~himask, hi_key = r | himask;
             size_t i = ib[lo_key >> shift]; const size_t e = ib[(hi_key >> shift) + 1];
             i = static_cast<size_t>(std::lower_bound(b.begin() + i, b.begin() + e, lo_key) - b.begin());
-            for (; i < e && b[i] <= hi_key; ++i) { const uint64_t y = unrot(b[i]); const uint64_t d = y ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; const int bit = __builtin_ctzll(m); const int j = k - 1 - bit / 2; if (nf < 96) found[nf++] = (static_cast<uint32_t>(j) << 2) | static_cast<uint32_t>((y >> bit) & 3ULL); }
+            for (; i < e && b[i] <= hi_key; ++i) { const uint64_t y = unrot(b[i]); const uint64_t d = y ^ x; if (d == 0) continue; const uint64_t m = (d | (d >> 1)) & 0x5555555555555555ULL; if (m & (m - 1)) continue; put(__builtin_ctzll(m), y); }
         }
+    }
+    // calls f(offset j, substituted base) for every graph k-mer one substitution away from x, by (j, base) ascending
+    template <class F> void neighbours(uint64_t x, F f) const {
+        uint32_t found[192]; int nf = 0; // (j << 2 | base): at most 3 per offset, 3k <= 93 in all (a k-mer of a tandem repeat at small k has dozens: 16 slots lost some, found by tests/test_annotators.py)
+        scan(x, false, found, nf); scan(kmer_revcomp(x, k), true, found, nf);
         std::sort(found, found + nf);
         for (int i = 0; i < nf; ++i) f(static_cast<int>(found[i] >> 2), static_cast<uint64_t>(found[i] & 3u));
     }
@@ -851,7 +857,7 @@ template <class KM> static int run(int argc, char** argv) { // KM: uint64_t for 
             for (size_t i = 0; i < seq_final.size(); ++i) if (seq_final[i] != 'A' && seq_final[i] != 'C' && seq_final[i] != 'G' && seq_final[i] != 'T') ambiguity[u].push_back(static_cast<uint32_t>((i << 4) + amb_bits(seq_final[i]))); // UnitigData.hpp:448-451
         };
         { // unitigs are independent and the k-mer table is only read: one strided slice per thread
-            unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64;
+            unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > std::max(64u, n_thr)) nt = std::max(64u, n_thr);
             std::vector<std::thread> th;
             for (unsigned t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (size_t u = t; u < n; u += nt) annotate(u); });
             for (size_t t = 0; t < th.size(); ++t) th[t].join();

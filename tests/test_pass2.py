@@ -74,6 +74,27 @@ def test_sim_pass2_matches_oracle(ds_pass2):
     assert got == want
 
 
+
+def _skip_check(pre, lib_path, monkeypatch, n=None, k=31):
+    """phasing(): a read without an unsupported stretch comes back as it is whatever its alignment against the raw read looks like (src/Graph.cpp:975-1069 with an
+    empty pos2rm), so the device skips that alignment. Same bytes with the skip and with every read aligned (RTK_PHASE_ALIGN_ALL=1), both kinds of read present."""
+    _, pg, seqs, quals, raws = _load(pre, lib_path, k)
+    if n:
+        seqs, quals, raws = seqs[:n], quals[:n], raws[:n]
+    o = pg.opts(long_read_correct=1)
+    b = api.Batch(pg, seqs, quals, raw=raws); b.run(o); got = b.fetch(); st = b.stats()
+    assert 0 < st["n_phase_skipped"] < len(seqs), st["n_phase_skipped"]
+    monkeypatch.setenv("RTK_PHASE_ALIGN_ALL", "1")
+    b2 = api.Batch(pg, seqs, quals, raw=raws); b2.run(o); got_all = b2.fetch()
+    assert b2.stats()["n_phase_skipped"] == 0
+    assert got == got_all
+    return st["n_phase_skipped"], len(seqs)
+
+
+def test_sim_pass2_alignment_skipped_where_it_cannot_matter(ds_pass2, monkeypatch):
+    _skip_check(ds_pass2, SIM_LIB, monkeypatch)
+
+
 def test_sim_pass2_edge_reads(ds_pass2):
     """Reads phasing() leaves alone or empties: shorter than k, all N, raw read unrelated to the corrected one, empty raw read."""
     og, pg, seqs, quals, raws = _load(ds_pass2, SIM_LIB)
