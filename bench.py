@@ -201,7 +201,7 @@ def ticket_size_leg(a, api, graph, opts, mine):
             continue
         n_t = max(3, min(48, (128 << 20) // want))  # ~128 Mi bases per measurement, at least three tickets
         row = {"ticket_bases": int(sum(len(x) for x in tickets[0][0])), "tickets": n_t}
-        for callers in (1, 3):
+        for callers in ((1, 3, 8, 16) if mib <= 4 else (1, 3)):  # (the reference runs `-c` workers, each with a ticket of its own: many callers is ITS way of using small tickets)
             r = host_inclusive_leg(types.SimpleNamespace(host_tickets=n_t, host_callers=callers), api, graph, opts, tickets)
             row["callers_%d" % callers] = r.get("value") if "value" in r else r
         out["%dMi" % mib] = row
@@ -351,6 +351,19 @@ def cpu_baseline_leg(a, api, graph, opts, fa, rt, tickets, whole_alg, out):
         return ss, qq, tot
 
     cores = os.cpu_count() or 1
+    quota = None  # the container's CPU quota (cgroup v2 cpu.max "quota period"): the host may show 256 hardware threads of which the control group grants a part
+    try:
+        q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q_ != "max":
+            quota = float(q_) / float(p_)
+    except Exception:
+        pass
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
     legs = {}
     t32 = min(32, cores)
     ss, qq, tot_b = sample(20 * t32, 1 << 62)
@@ -368,7 +381,8 @@ def cpu_baseline_leg(a, api, graph, opts, fa, rt, tickets, whole_alg, out):
     chk = api.Batch(graph, ss, qq); chk.run(opts); got = chk.fetch(); chk.close()
     best = max(legs.values(), key=lambda x: x["value"])
     return {"value": best["value"], "unit": "bases/s", "cores": best["threads"], "kind": "port", "alignment_layer": alignment_layer,
-            "sample": "%d reads / %d bases of step 0 (best of the two legs below)" % (best["reads"], best["bases"]), "legs": legs, "parity_on_sample": got == want}
+            "sample": "%d reads / %d bases of step 0 (best of the two legs below)" % (best["reads"], best["bases"]), "legs": legs, "parity_on_sample": got == want,
+            "host": {"hardware_threads": os.cpu_count(), "cgroup_cpu_quota": quota, "threads_of_the_all_threads_leg": cores}}
 
 
 PMC_NOTE = "from the committed rocprofv3 --pmc passes of this workload (profiles/rNN_pmc_summary.json): counters cannot be collected inside a timed run"

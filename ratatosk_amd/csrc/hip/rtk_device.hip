@@ -342,14 +342,22 @@ static std::vector<ReservedSlab> g_reserved;
 
 void* rtk_graph::phase_take(uint64_t bytes, uint64_t* got) {
     { std::lock_guard<std::mutex> h(pool_lock);
-      for (size_t i = 0; i < phase_free.size(); ++i) if (phase_free[i].second >= bytes) { void* p = phase_free[i].first; *got = phase_free[i].second; phase_free.erase(phase_free.begin() + i); return p; } }
+      int best = -1; // the smallest one that fits (the slabs of the phasing step and of the region stage of a second-pass ticket circulate in the same list)
+      for (size_t i = 0; i < phase_free.size(); ++i) if (phase_free[i].second >= bytes && (best < 0 || phase_free[i].second < phase_free[static_cast<size_t>(best)].second)) best = static_cast<int>(i);
+      if (best >= 0) { void* p = phase_free[static_cast<size_t>(best)].first; *got = phase_free[static_cast<size_t>(best)].second; phase_free.erase(phase_free.begin() + best); return p; } }
     { std::lock_guard<std::mutex> lk(g_reserved_lock); // reserved ahead (rtk_reserve_second_pass): the smallest one that fits, but not one several times too big (those are the first pass's)
       int best = -1;
       for (size_t i = 0; i < g_reserved.size(); ++i) if (g_reserved[i].device == device && g_reserved[i].bytes >= bytes && g_reserved[i].bytes <= 4 * bytes + (1ull << 30) && (best < 0 || g_reserved[i].bytes < g_reserved[static_cast<size_t>(best)].bytes)) best = static_cast<int>(i);
       if (best < 0) // nothing of a fitting size: any reserved slab that is large enough, before more memory is asked for next to the reservation
           for (size_t i = 0; i < g_reserved.size(); ++i) if (g_reserved[i].device == device && g_reserved[i].bytes >= bytes && (best < 0 || g_reserved[i].bytes < g_reserved[static_cast<size_t>(best)].bytes)) best = static_cast<int>(i);
       if (best >= 0) { void* p = g_reserved[static_cast<size_t>(best)].p; *got = g_reserved[static_cast<size_t>(best)].bytes; g_reserved.erase(g_reserved.begin() + best); return p; } }
-    *got = bytes; return rtk_dmalloc(bytes);
+    // nothing held back fits: new memory, in steps of 2 GB so that the slabs of tickets of slightly different sizes serve one another (the work area of a ticket follows
+    // its longest reads; slabs that just miss the next ticket's size would pile up in the free list)
+    bytes = (bytes + (2ull << 30) - 1) / (2ull << 30) * (2ull << 30);
+    const auto t0 = std::chrono::steady_clock::now();
+    void* p = rtk_dmalloc(bytes);
+    if (getenv("RTK_TRACE")) fprintf(stderr, "[rtk trace] phase_take: %.1f GB of new device memory in %.1f ms\n", bytes / 1073741824.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    *got = bytes; return p;
 }
 
 static char* graph_scratch(rtk_graph* g, int slot, uint64_t bytes) { // grows monotonically; hipMalloc/hipFree of tens of GB per batch would dominate a step

@@ -49,7 +49,23 @@ struct MyersScratch {
     U<uint32_t> tb_gen;     // bumped by everything that writes the traceback table: a saved sweep (MyersSaved) is only resumed on its own table
     U<unsigned long long> walk_cycles, walk_moves, walk_reloads, walk_scalar, walk_calls, walk_tail_cycles; // profile of the traceback walks
     U<unsigned long long> hb_pass, hb_split, hb_leaf, hb_total; // profile of the Hirschberg driver: half passes, column extraction + split search, leaf tracebacks, all
+    // Optional, set by a caller around ONE rtk_myers_path call: a bit per target position, bit i set = the caller looks at the moves that happen at target position i
+    // (the moves over target character i and the insertions in front of it). A sub-problem of the Hirschberg recursion none of whose target positions t0 .. t0 + tn
+    // (both ends) has its bit set is not solved: its moves are written as tn deletions then qm insertions, which carry the only facts such a caller uses -- how many query
+    // and target characters the stretch consumes (phasing(), rtk_phasing.h: the walk of src/Graph.cpp:991-1069 copies the corrected read wherever pos2rm has no bit).
+    // Everything the split of a level decides (distance, split rows) is computed as always, so the sub-problems that ARE solved are those of the full recursion.
+    U<uint64_t*> need_bm; // (NOT a pointer to const: the bitmap is written by the kernel that reads it; a pointer-to-const field is read through the scalar cache, rtk_types.h)
 };
+// no position of [lo, hi] (both included) has its bit set
+RTK_DEV bool rtk_need_none(const uint64_t* bm, int lo, int hi) {
+    for (int w = lo >> 6; w <= (hi >> 6); ++w) {
+        uint64_t mk = ~0ull;
+        if (w == (lo >> 6)) mk &= ~0ull << (lo & 63);
+        if (w == (hi >> 6)) mk &= ~0ull >> (63 - (hi & 63));
+        if (bm[w] & mk) return false;
+    }
+    return true;
+}
 
 // traceback table entry of (column, 64-bit query word): word-major, so that the walk's window of 64 consecutive columns of one word is
 // one contiguous 2 KB run (16 cache lines) instead of 64 entries a table row apart. `ncols` = number of columns of the sweep that stored it.
@@ -783,7 +799,7 @@ struct RtkCoop { RtkCoopJob job[RTK_COOP_MAXJ]; int first[RTK_COOP_MAXJ + 1]; in
                  // a round of leaf tracebacks (rtk_myers_alignment_bfs): every wave of the workgroup takes leaves, each with its own traceback table
                  int n_gangs; RtkGangCtx gctx; // gang sweeps of a round (items 0 .. n_gangs - 1; the row blocks of the jobs follow)
                  int n_leaf_waves; // waves that own a work area for leaf tracebacks (the others sit a leaf round out)
-                 int leaf_mode, liupac; const char* lq; const char* lt; int32_t* llist; uint8_t* lmoves; MyersScratch* lsc; uint32_t lnm[16]; };
+                 int leaf_mode, liupac; const char* lq; const char* lt; int32_t* llist; uint8_t* lmoves; MyersScratch* lsc; uint32_t lnm[16]; const uint64_t* lneed; };
 __device__ __noinline__ void rtk_myers_leaf_item(RtkCoop* st, int wave, int x);
 __device__ __noinline__ void rtk_myers_gang(const RtkGangCtx& C_, int gang_);
 __device__ __forceinline__ RtkCoop* rtk_coop() { __shared__ RtkCoop st; return &st; }
@@ -1309,7 +1325,9 @@ __device__ __noinline__ void rtk_myers_leaf_item(RtkCoop* st, int wave, int x) {
     const bool iupac = rtk_coop_ld(&st->liupac) != 0;
     const int q0 = rtk_ld(L + 6 * x), qm = rtk_ld(L + 6 * x + 1), t0 = rtk_ld(L + 6 * x + 2), tn = rtk_ld(L + 6 * x + 3), off = rtk_ld(L + 6 * x + 5);
     int len = -1;
+    const uint64_t* const need = reinterpret_cast<const uint64_t*>(rtk_u(reinterpret_cast<unsigned long long>(st->lneed)));
     if (qm == 0 || tn == 0) { rtk_wfill(mvs + off, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn)); len = qm + tn; } // edlib.cpp:1171-1178
+    else if (need && rtk_need_none(need, t0, t0 + tn)) { rtk_wfill(mvs + off, 2, static_cast<uint64_t>(tn)); rtk_wfill(mvs + off + tn, 1, static_cast<uint64_t>(qm)); len = qm + tn; } // (MyersScratch::need_bm)
     else {
         const long long W = (qm + 63) >> 6;
         const bool fits = static_cast<uint64_t>(4 * W * tn) <= h.tb_cap_words && static_cast<uint32_t>(qm + tn) + 64u <= h.mv_cap && static_cast<uint32_t>(tn) <= h.t_cap && static_cast<uint32_t>(W) <= h.w_cap;
@@ -1354,6 +1372,11 @@ RTK_FN void rtk_myers_alignment(const MyersScratch& sc_, const char* q_, int m_,
         const int q0 = st[5 * sp], qm = st[5 * sp + 1], t0 = st[5 * sp + 2], tn = st[5 * sp + 3], bs_in = st[5 * sp + 4];
         if (qm == 0 || tn == 0) { // edlib.cpp:1171-1178
             rtk_wfill(sc.moves + *n_moves, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn));
+            *n_moves += static_cast<uint32_t>(qm + tn);
+            continue;
+        }
+        if (bs_in >= 0 && sc.need_bm && rtk_need_none(sc.need_bm, t0, t0 + tn)) { // (MyersScratch::need_bm: nobody looks at the moves of this stretch)
+            rtk_wfill(sc.moves + *n_moves, 2, static_cast<uint64_t>(tn)); rtk_wfill(sc.moves + *n_moves + tn, 1, static_cast<uint64_t>(qm));
             *n_moves += static_cast<uint32_t>(qm + tn);
             continue;
         }
@@ -1579,7 +1602,7 @@ RTK_HD MyersScratch scratch_carve(char* base, const ScratchCfg& c) {
     s.overflow = reinterpret_cast<uint32_t*>(p); p += 64;
     s.tb_gen = 0;
     s.walk_cycles = 0; s.walk_moves = 0; s.walk_reloads = 0; s.walk_scalar = 0; s.walk_calls = 0; s.walk_tail_cycles = 0;
-    s.hb_pass = 0; s.hb_split = 0; s.hb_leaf = 0; s.hb_total = 0;
+    s.hb_pass = 0; s.hb_split = 0; s.hb_leaf = 0; s.hb_total = 0; s.need_bm = nullptr;
     s.carry = reinterpret_cast<int8_t*>(p); p += (c.t_cap + 63) / 64 * 64;
     s.moves = reinterpret_cast<uint8_t*>(p); p += (c.mv_cap + 63) / 64 * 64; s.moves_tmp = reinterpret_cast<uint8_t*>(p); s.mv_cap = c.mv_cap;
     return s;

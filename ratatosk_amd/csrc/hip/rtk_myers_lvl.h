@@ -206,6 +206,7 @@ __device__ __noinline__ bool rtk_myers_alignment_lvl(const MyersScratch& sc, con
     int8_t* const carry = rtk_ld(&sc.carry); int32_t* const colscore = rtk_ld(&sc.colscore); int32_t* const rowL = rtk_ld(&sc.rowL); int32_t* const rowR = rtk_ld(&sc.rowR);
     int32_t* const nodes = rtk_ld(&sc.hstack);
     uint64_t* const peq = rtk_ld(&sc.peq);
+    const uint64_t* const need = static_cast<uint64_t*>(rtk_ld(&sc.need_bm)); // (MyersScratch::need_bm: sub-problems nobody looks at are not solved)
     MyersScratch& prof = const_cast<MyersScratch&>(sc); const unsigned long long t_all0 = rtk_clock();
     RtkGangCtx gc; gc.q = q; gc.t = t; gc.stage = reinterpret_cast<char*>(colscore) + 8; gc.peq = peq; gc.fin = tb; gc.nodes = nodes; gc.n_nodes = 0; gc.iupac = iupac ? 1 : 0;
     if (lane == 0) { cur[0] = 0; cur[1] = m; cur[2] = 0; cur[3] = n; cur[4] = best; cur[5] = 0; }
@@ -220,7 +221,7 @@ __device__ __noinline__ bool rtk_myers_alignment_lvl(const MyersScratch& sc, con
             const int i = c0 + lane; const bool valid = i < n_cur;
             int e[5] = {0, 0, 0, 0, 0};
             if (valid) for (int k = 0; k < 5; ++k) e[k] = cur[6 * i + k];
-            const bool leaf = valid && rtk_hb_is_leaf(e[1], e[3]);
+            const bool leaf = valid && (rtk_hb_is_leaf(e[1], e[3]) || (need && e[4] >= 0 && rtk_need_none(need, e[2], e[2] + e[3])));
             int total; const int excl = rtk_wave_excl_scan(valid ? (leaf ? 1 : 2) : 0, &total);
             const int pos = n_next + excl;
             if (valid && static_cast<uint64_t>(pos) + 2 <= cap) { if (leaf) { for (int k = 0; k < 5; ++k) nxt[6 * pos + k] = e[k]; nxt[6 * pos + 5] = 0; } else cur[6 * i + 5] = pos; }
@@ -311,7 +312,7 @@ __device__ __noinline__ bool rtk_myers_alignment_lvl(const MyersScratch& sc, con
             const int i = c0 + lane; const bool valid = i < n_cur;
             int e[6] = {0, 0, 0, 0, 0, 0};
             if (valid) for (int k = 0; k < 6; ++k) e[k] = cur[6 * i + k];
-            uint64_t todo = rtk_ballot(valid && !rtk_hb_is_leaf(e[1], e[3]));
+            uint64_t todo = rtk_ballot(valid && !(rtk_hb_is_leaf(e[1], e[3]) || (need && e[4] >= 0 && rtk_need_none(need, e[2], e[2] + e[3]))));
             while (todo && !bad) {
                 const int l = rtk_ffs(todo) - 1; todo &= todo - 1ull;
                 const int q0 = rtk_shfl(e[0], l), qm = rtk_shfl(e[1], l), t0 = rtk_shfl(e[2], l), tn = rtk_shfl(e[3], l), bs = rtk_shfl(e[4], l), slot = rtk_shfl(e[5], l);
@@ -382,7 +383,7 @@ __device__ __noinline__ bool rtk_myers_alignment_lvl(const MyersScratch& sc, con
 #ifdef RTK_MULTIWAVE
     MyersScratch* const lsc = reinterpret_cast<MyersScratch*>(rtk_u(reinterpret_cast<unsigned long long>(st->lsc))); // work areas of the waves for leaf tracebacks (nullptr: none)
     if (lsc && nwv > 1) {
-        if (lane == 0) { st->lq = q; st->lt = t; st->liupac = iupac ? 1 : 0; st->llist = rowL; st->lmoves = mvs; st->n_items = n_cur; st->leaf_mode = 1; }
+        if (lane == 0) { st->lq = q; st->lt = t; st->lneed = need; st->liupac = iupac ? 1 : 0; st->llist = rowL; st->lmoves = mvs; st->n_items = n_cur; st->leaf_mode = 1; }
         rtk_myers_round_coop(st, 0);
         if (lane == 0) st->leaf_mode = 0;
         rtk_sync();
@@ -395,6 +396,7 @@ __device__ __noinline__ bool rtk_myers_alignment_lvl(const MyersScratch& sc, con
         if (len < 0) { // not done by a round (single wave, or too big for a helper's work area): here, straight to its final place (total <= off: the leaves behind stay intact)
             uint32_t nm = total;
             if (qm == 0 || tn == 0) { rtk_wfill(mvs + nm, qm == 0 ? 2 : 1, static_cast<uint64_t>(qm + tn)); nm += static_cast<uint32_t>(qm + tn); } // edlib.cpp:1171-1178
+            else if (need && rtk_need_none(need, t0, t0 + tn)) { rtk_wfill(mvs + nm, 2, static_cast<uint64_t>(tn)); rtk_wfill(mvs + nm + tn, 1, static_cast<uint64_t>(qm)); nm += static_cast<uint32_t>(qm + tn); } // (MyersScratch::need_bm)
             else {
                 const long long W = (qm + 63) >> 6;
                 if (static_cast<uint64_t>(4 * W * tn) > tbw) { *sc.overflow = 1; break; }

@@ -171,7 +171,11 @@ RTK_FN void rtk_phase_read(const RCtx& c_, const PhaseView& pv_, uint32_t r_) {
         return;
     }
     uint32_t nm = 0;
+    // The walk below looks at the moves only where pos2rm has a bit (target position of the move); everywhere else it copies the corrected read. The alignment is told so:
+    // the stretches of the Hirschberg recursion without such a position are not solved (MyersScratch::need_bm, rtk_myers.h)
+    if (!pv.align_all) { s.my.need_bm = rm; rtk_sync(); }
     { const unsigned long long t0 = rtk_clock(); rtk_myers_path(s.my, raw, static_cast<int>(M), sc_, static_cast<int>(L), RTK_MODE_NW, true, &nm); s.cnt[9] += rtk_clock() - t0; s.cnt[3] += 1; }
+    s.my.need_bm = nullptr; rtk_sync();
     nm = rtk_u(nm);
     if (rtk_failed(s)) return;
     char* out_s = s.rbuf[0]; char* out_q = s.rbuf[1];

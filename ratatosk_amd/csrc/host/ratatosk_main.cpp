@@ -206,7 +206,7 @@ int main(int argc, char** argv) {
     for (int w = 0; w < n_gpus; ++w) {
         if (!lrc) reservers.emplace_back([w]() { rtk_reserve_scratch(w, 131072u); });
         else for (int t = 0; t < std::min(opt.workers_per_gpu, 4); ++t) reservers.emplace_back([w, &opt]() { // a 32 Mi ticket of long reads: ~12 GB for the phasing step, ~9 GB for its regions
-            if (rtk_reserve_second_pass(w, 1u, 13ull << 30, 9ull << 30) != RTK_OK && opt.verbose) fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); });
+            if (rtk_reserve_second_pass(w, 1u, 14ull << 30, 10ull << 30) != RTK_OK && opt.verbose) fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); });
     }
     { // ONE parse + flatten, ONE host image; the other GPUs get device-to-device copies of the flat buffers
         bool ok = rtk_graph_load2(opt.graph.c_str(), opt.udata.c_str(), k_graph, opt.cores, RTK_LOAD_DEVICE_TABLES, &graphs[0]) == RTK_OK; // (k-mer table, half-k-mer index, adjacency: built in HBM by the upload)
@@ -216,14 +216,22 @@ int main(int argc, char** argv) {
         if (!ok) { fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join(); exit(1); }
     }
     for (size_t i = 0; i < reservers.size(); ++i) reservers[i].join();
+    const int first_reserved = std::min(opt.workers_per_gpu, 4);
     if (lrc && !opt.workers_given) { // second pass, tickets in flight not given: as many as the memory next to the graph image holds (~24 GB of work areas + ~4 GB of buffers each)
         uint64_t fr = 0, tot = 0; int fit = opt.workers_per_gpu;
         for (int w = 0; w < n_gpus; ++w) if (rtk_device_memory(w, &fr, &tot) == RTK_OK) {
-            const uint64_t reserved = static_cast<uint64_t>(std::min(opt.workers_per_gpu, 4)) * (22ull << 30);
+            const uint64_t reserved = static_cast<uint64_t>(std::min(opt.workers_per_gpu, 4)) * (24ull << 30);
             const uint64_t avail = fr + reserved > tot / 8 ? fr + reserved - tot / 8 : 0;
             fit = std::min<int>(fit, static_cast<int>(avail / (28ull << 30)));
         }
         opt.workers_per_gpu = std::max(2, fit);
+    }
+    if (lrc) {
+        // the work areas of the other tickets in flight, now that their number is known: a hipMalloc of 10+ GB in the middle of the correction phase takes up to a second
+        // and every kernel of the device waits for it (the tickets running beside it took 1.5 s instead of 0.25 in the trace that found this)
+        std::vector<std::thread> more;
+        for (int w = 0; w < n_gpus; ++w) for (int t = first_reserved; t < opt.workers_per_gpu; ++t) more.emplace_back([w]() { rtk_reserve_second_pass(w, 1u, 14ull << 30, 10ull << 30); });
+        for (size_t i = 0; i < more.size(); ++i) more[i].join();
     }
     const long long t_load1 = now_us();
     rtk_opts ro; rtk_opts_default(graphs[0], &ro);

@@ -75,7 +75,7 @@ def test_sim_pass2_matches_oracle(ds_pass2):
 
 
 
-def _skip_check(pre, lib_path, monkeypatch, n=None, k=31):
+def _skip_check(pre, lib_path, monkeypatch, n=None, k=31, both_kinds=True):
     """phasing(): a read without an unsupported stretch comes back as it is whatever its alignment against the raw read looks like (src/Graph.cpp:975-1069 with an
     empty pos2rm), so the device skips that alignment. Same bytes with the skip and with every read aligned (RTK_PHASE_ALIGN_ALL=1), both kinds of read present."""
     _, pg, seqs, quals, raws = _load(pre, lib_path, k)
@@ -83,7 +83,7 @@ def _skip_check(pre, lib_path, monkeypatch, n=None, k=31):
         seqs, quals, raws = seqs[:n], quals[:n], raws[:n]
     o = pg.opts(long_read_correct=1)
     b = api.Batch(pg, seqs, quals, raw=raws); b.run(o); got = b.fetch(); st = b.stats()
-    assert 0 < st["n_phase_skipped"] < len(seqs), st["n_phase_skipped"]
+    assert (0 < st["n_phase_skipped"] < len(seqs)) or not both_kinds, st["n_phase_skipped"]
     monkeypatch.setenv("RTK_PHASE_ALIGN_ALL", "1")
     b2 = api.Batch(pg, seqs, quals, raw=raws); b2.run(o); got_all = b2.fetch()
     assert b2.stats()["n_phase_skipped"] == 0
@@ -178,6 +178,18 @@ def test_gpu_pass2_multiwave_kernel(ds_pass2_big, ds_pass2_long, monkeypatch):
     assert got == want
     monkeypatch.setenv("RTK_PHASE_LONG", "0")  # the same reads on one wave each
     assert pg.correct_batch(seqs, quals, pg.opts(long_read_correct=1), raw=raws) == want
+
+
+@pytest.mark.gpu
+def test_gpu_pass2_alignment_skipped_or_pruned(ds_pass2_big, ds_pass2_long, monkeypatch):
+    """The same on the device, whose level-by-level Hirschberg driver (rtk_myers_lvl.h) and multi-wave kernel have their own pruning code: 6 kb reads on one wave each,
+    the same reads on the multi-wave kernel, reads of tens of kb."""
+    _skip_check(ds_pass2_big, GPU_LIB, monkeypatch, k=63)
+    monkeypatch.delenv("RTK_PHASE_ALIGN_ALL")
+    monkeypatch.setenv("RTK_PHASE_LONG", "2000")
+    _skip_check(ds_pass2_big, GPU_LIB, monkeypatch)
+    monkeypatch.delenv("RTK_PHASE_ALIGN_ALL"); monkeypatch.delenv("RTK_PHASE_LONG")
+    _skip_check(ds_pass2_long, GPU_LIB, monkeypatch, both_kinds=False)
 
 
 @pytest.mark.gpu
