@@ -199,10 +199,10 @@ def test_gpu_config4_scaled_down_graph_above_2_pow_28_kmers(tmp_path):
     lists), short reads sampled on the fly inside the index tool (no FASTQ on disk), index with SNP annotations built with the k-mers counted on
     the device. The oracle cannot hold such a graph: the checks are size-independent -- corrected reads are closer to the stretches of the
     reference they were simulated from than the raw reads (error rate at least halved, no read further away), more k-mer windows in the graph.
-    profiles/scripts/r04_config4.py is the same program the 3 Gb run of profiles/r04_config4_dry_run.json used."""
+    profiles/scripts/config4_run.py is the same program the 3 Gb runs of profiles/r04_config4_dry_run.json and profiles/r05_config4_run.json used."""
     out = str(tmp_path / "c4.json")
     t0 = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r04_config4.py"), "300", "8", "64", "1"], capture_output=True, text=True, timeout=900,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "config4_run.py"), "300", "8", "64", "1"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, RTK_C4_OUT=out, RTK_C4_DIR=str(tmp_path)))
     assert r.returncode == 0, (r.stderr[-1500:], open(out).read()[-1500:] if os.path.exists(out) else "")
     d = json.load(open(out))
