@@ -51,6 +51,8 @@ template <class T> __device__ __forceinline__ T* rtk_gp(T* p) { return (T*)(__at
 // memory that no running kernel writes: the CONSTANT address space. An access through it with a wave-uniform address -- and most of the wave programs'
 // reads of the graph are that: neighbour slots, flag words, offsets of ONE unitig -- becomes a SCALAR load (s_load: scalar cache, no vector-memory
 // instruction, the value lands in SGPRs), with a per-lane address it stays a global load.
+// RULE: a pointer-to-const field must never point to memory the same launch writes (the scalar cache is not coherent with the vector stores of the wave: a read may return
+// what was there before). A bitmap, list or string a wave program builds and then reads is held in a pointer to NON-const (MyersScratch::need_bm is the case that went wrong).
 #ifndef RTK_NO_CONST_PTRS
 template <class T> __device__ __forceinline__ const T* rtk_gp(const T* p) { return (const T*)(__attribute__((address_space(4))) const T*)(unsigned long long)(p); }
 #endif
