@@ -14,9 +14,10 @@ for f in sorted(glob.glob(sys.argv[1] + "/*.txt")):
     print("== hip/" + f.split("/")[-1].replace(".txt", ".hip"))
     for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
         name = b.split("\n")[0].split(" ")[0]
-        try: name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
-        except Exception: pass
+        m = re.match(r"_ZN?(?:12_GLOBAL__N_1)?(\d+)", name)  # the kernel's own name out of the mangled one: length-prefixed
+        if m: name = name[m.end():m.end() + int(m.group(1))]
         g = lambda k: (re.search(k + r": (\d+)", b) or [None, "?"])[1]
-        print("  %-34s VGPRs %3s  AGPRs %3s  SGPRs %3s  scratch %5s B/lane  occupancy %s waves/SIMD  LDS %6s B" % (name[-34:], g("VGPRs"), g("AGPRs"), g("SGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]")))
+        if not name.startswith("k_"): lib = locals().get("lib", 0) + 1; continue   # (rocPRIM sort / scan / select instances of the index and table builders: counted, not listed)
+        print("  %-34s VGPRs %3s  AGPRs %3s  SGPRs %3s  scratch %5s B/lane  occupancy %s waves/SIMD  LDS %6s B" % (name[:34], g("VGPRs"), g("AGPRs"), g("SGPRs"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]")))
 PY
 cat ../../profiles/${R}_kernel_resource_usage.txt

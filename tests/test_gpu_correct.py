@@ -58,6 +58,38 @@ def test_gpu_overlapped_stages_give_the_same_records(ds_medium):
         assert b.fetch() == want
 
 
+def test_gpu_small_tickets_of_many_callers(ds_medium):
+    """The reference's way of using the seam: many worker threads, each with a ticket of about a megabase of its own (src/Ratatosk.cpp:727-772). Twelve callers, 36 tickets of
+    ~110 kb through rtk_batch_create / run / fetch at the same time (the stages of different tickets overlap on the device, the graph-wide work areas go from ticket to
+    ticket behind their locks): every ticket equals the oracle."""
+    import threading
+    from ratatosk_amd import api
+    fa, rt = ds_medium + ".index.k31.fasta.gz", ds_medium + ".index.k31.rtsk"
+    og, pg = op.Graph(fa, rt, 31), api.Graph(fa, rt, 31, device=0)
+    reads = op.read_fastq(ds_medium + ".lr.fq")[:156]
+    parts = [reads[i:i + 13] for i in range(0, 156, 13)] * 3
+    out, err, nxt, lock = [None] * len(parts), [], [0], threading.Lock()
+
+    def caller():
+        while True:
+            with lock:
+                i = nxt[0]; nxt[0] += 1
+            if i >= len(parts):
+                return
+            try:
+                b = api.Batch(pg, [r[1] for r in parts[i]], [r[2] for r in parts[i]]); b.run(pg.opts()); out[i] = b.fetch(); b.close()
+            except Exception as e:  # noqa: BLE001
+                err.append(repr(e))
+
+    th = [threading.Thread(target=caller) for _ in range(12)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not err, err[:2]
+    want, _ = og.correct_batch([r[1] for r in reads], [r[2] for r in reads], threads=os.cpu_count() or 4)
+    for i, p_ in enumerate(parts):
+        j = (i % 12) * 13
+        assert out[i] == want[j:j + len(p_)], "ticket %d differs" % i
+
+
 def test_gpu_correct_short_cycles(ds_tandem):
     _check(ds_tandem, 40, None)
 
