@@ -113,7 +113,7 @@ def read_long_reads(path, max_bases):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same workload (profiles/rNN_pmc_summary.json,
-    written by profiles/scripts/profile_round.sh): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 B, MI355X_MICROARCH.md)
+    written by profiles/scripts/profile_set.sh): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 B, MI355X_MICROARCH.md)
     + WRITE_SIZE, both reported in KB. None when no profile has been collected for the current code."""
     import glob
     import re
@@ -604,7 +604,8 @@ def main():
         out["config1"] = {"workload": "configs[1]: k=31 first-pass correct, 5.0 Mb random ref, 30x PE150 short reads, ONT-R9.4-profile long reads, %d bases/step, same steps / warm-up / overlap as the main line" % a.batch_bases,
                           "value": w1["bases_all"] / w1["dt_all"] if w1["dt_all"] > 0 else 0.0, "unit": "bases/s", "ms_per_step": 1e3 * w1["dt_all"] / max(1, a.steps),
                           "kernel_ms_per_step": {k_: round(sum(s_[v] for s_ in w1["stats"]) / n1_, 3) for k_, v in KERN.items()},
-                          "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in w1["stats_serial"]) / len(w1["stats_serial"]), 3) for k_, v in KERN.items()} if w1["stats_serial"] else None),
+                          "kernel_ms_per_step_serial": ({k_: round(sum(s_[v] for s_ in w1["stats_serial"]) / len(w1["stats_serial"]), 3) for k_, v in KERN.items()} if w1["stats_serial"]
+                                                        else {k_: round(sum(s_[v] for s_ in w1["stats"]) / n1_, 3) for k_, v in KERN.items()}),  # (steps one at a time are the default: the spans above ARE serial)
                           "graph": {"unitigs": int(w1["info"].n_unitigs), "kmers": int(w1["info"].n_kmers), "hbm_bytes": int(w1["info"].hbm_bytes)}}
         w1["graph"].close()
     if rank == 0:

@@ -9,6 +9,6 @@ if [ "$W" = tier ] || [ "$W" = all ]; then
   tail -14 gpurun_out/r05_gpu_tier.log
 fi
 if [ "$W" = prof ] || [ "$W" = all ]; then
-  bash profiles/scripts/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1
+  bash profiles/scripts/profile_set.sh r05 > gpurun_out/r05_profile_round.log 2>&1
   tail -12 gpurun_out/r05_profile_round.log
 fi

@@ -1,4 +1,4 @@
-"""Condenses the rocprofv3 CSV output of profile_round.sh into the small files committed under profiles/."""
+"""Condenses the rocprofv3 CSV output of profile_set.sh into the small files committed under profiles/."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
