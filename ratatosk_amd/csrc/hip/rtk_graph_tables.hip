@@ -144,7 +144,7 @@ __global__ void k_hx_mark(const uint64_t* __restrict__ useq, const uint64_t* __r
     const uint64_t n_words = (n_bases + 31ull) / 32ull, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < n_words; w += stride) {
         windows_ending_in_word(useq, uoff, n_unitigs, n_bases, w, h, [&](const RtkKm& fw, uint32_t, uint32_t, uint64_t) {
-            const uint64_t hm = fw.lo;
+            const uint64_t rc_ = rtk_revcomp(fw.lo, h); const uint64_t hm = fw.lo < rc_ ? fw.lo : rc_; // the index is keyed by the canonical h-mer
             atomicOr(reinterpret_cast<unsigned long long*>(bitmap + (hm >> 6)), static_cast<unsigned long long>(1ull << (hm & 63ull)));
             atomicAdd(&lh[hm >> bshift], 1u);
         });
@@ -162,7 +162,7 @@ __global__ void k_hx_keys(const uint64_t* __restrict__ useq, const uint64_t* __r
     for (uint64_t r = 0; r < rounds; ++r) { // (every lane takes part in the scans of every round)
         const uint64_t w = r * stride + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
         uint32_t mine = 0;
-        if (w < n_words) windows_ending_in_word(useq, uoff, n_unitigs, n_bases, w, h, [&](const RtkKm& fw, uint32_t, uint32_t, uint64_t) { const uint32_t b = static_cast<uint32_t>(fw.lo >> bshift); if (b >= bin_lo && b < bin_hi) ++mine; });
+        if (w < n_words) windows_ending_in_word(useq, uoff, n_unitigs, n_bases, w, h, [&](const RtkKm& fw, uint32_t, uint32_t, uint64_t) { const uint64_t rc_ = rtk_revcomp(fw.lo, h); const uint32_t b = static_cast<uint32_t>((fw.lo < rc_ ? fw.lo : rc_) >> bshift); if (b >= bin_lo && b < bin_hi) ++mine; });
         uint32_t incl = mine;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
         const uint32_t tot = __shfl(incl, 63, 64);
@@ -171,7 +171,7 @@ __global__ void k_hx_keys(const uint64_t* __restrict__ useq, const uint64_t* __r
         if (lane == 63) base = atomicAdd(top, static_cast<unsigned long long>(tot));
         base = __shfl(base, 63, 64);
         uint64_t at = base + (incl - mine);
-        if (mine) windows_ending_in_word(useq, uoff, n_unitigs, n_bases, w, h, [&](const RtkKm& fw, uint32_t, uint32_t, uint64_t pos) { const uint32_t b = static_cast<uint32_t>(fw.lo >> bshift); if (b >= bin_lo && b < bin_hi) keys[at++] = (fw.lo << RTK_POS_BITS) | pos; });
+        if (mine) windows_ending_in_word(useq, uoff, n_unitigs, n_bases, w, h, [&](const RtkKm& fw, uint32_t, uint32_t, uint64_t pos) { const uint64_t rc_ = rtk_revcomp(fw.lo, h); const uint64_t cn = fw.lo < rc_ ? fw.lo : rc_; const uint32_t b = static_cast<uint32_t>(cn >> bshift); if (b >= bin_lo && b < bin_hi) keys[at++] = (cn << RTK_POS_BITS) | pos; });
     }
 }
 
@@ -194,7 +194,8 @@ __global__ void k_hx_scatter(const uint64_t* __restrict__ S, uint64_t n_s, uint6
             if (a_ok) for (uint64_t x = 0; x < nbf; ++x) { const uint64_t q_ = pos + static_cast<uint64_t>(h) + x; after = (after << 2) | ((useq[q_ >> 5] >> (2ull * (q_ & 31ull))) & 3ull); }
             if (b_ok) for (uint64_t x = 0; x < nbf; ++x) { const uint64_t q_ = pos - nbf + x; before = (before << 2) | ((useq[q_ >> 5] >> (2ull * (q_ & 31ull))) & 3ull); }
             hxl[2 * gi + r + 1] = (after << 32) | before;
-            hxl[2 * gi + r + 2] = (static_cast<uint64_t>(lo) << 32) | (a_ok ? (1ull << 31) : 0ull) | (pos - u0);
+            uint64_t fwd = 0; for (int x = 0; x < h; ++x) { const uint64_t q_ = pos + static_cast<uint64_t>(x); fwd = (fwd << 2) | ((useq[q_ >> 5] >> (2ull * (q_ & 31ull))) & 3ull); }
+            hxl[2 * gi + r + 2] = (fwd != hm ? (1ull << 63) : 0ull) | (static_cast<uint64_t>(lo) << 32) | (a_ok ? (1ull << 31) : 0ull) | (pos - u0); // bit 63: the unitig spells the reverse complement of the (canonical) key
         }
         if (i == 0 || (S[i - 1] >> RTK_POS_BITS) != hm) { // first key of its h-mer: the count word and the slot (a range of bins never splits an h-mer)
             uint64_t a = i, b = i + 1, step = 1;

@@ -623,23 +623,29 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
     if (ck <= 3 && ck1 <= 3) { key[nkeys] = ((w_k1 << 4) | (static_cast<uint64_t>(ck) << 2) | static_cast<uint64_t>(ck1)) & hm; first_half[nkeys++] = false; } // m[p+k+1-h .. p+k+1): a read base missing in the graph
     // (measured in round 5: all eight home slots, then all count words, in flight together -- three rounds of independent loads instead of eight chains -- is SLOWER,
     // 5.8 against 4.7 ms per 64 Mb on the 60 Mb graph: the lookups of six waves per SIMD already overlap, the arrays of the batched form spill)
+    // The index is keyed by the CANONICAL h-mer (the smaller of an h-mer and its reverse complement; round 5): one look-up per read h-mer finds the places where it
+    // stands in a unitig as it is AND those where its reverse complement does (bit 63 of a place: the unitig holds the reverse complement of the key). Before, the two
+    // orientations were two look-ups -- two random lines of the table each.
     for (int q = 0; q < nkeys; ++q) {
-        for (int ori = 0; ori < 2; ++ori) {
-            const uint64_t x = ori ? rtk_revcomp(key[q], h) : key[q];
-            *n_lookups += 1;
-            uint64_t i = rtk_hash64(x) & hx_mask, first = 0; bool found = false;
-            while (true) { const uint64_t sv = hx[i]; *n_slots += 1; if (sv == RTK_EMPTY_KEY) break; if ((sv >> 34) == x) { first = sv & 0x3FFFFFFFFull; found = true; break; } i = (i + 1) & hx_mask; }
-            if (!found) continue;
-            const uint32_t cnt = static_cast<uint32_t>(hxl[first]); ++first;
-            // the unitig h-mer is the first half of the forward k-mer F starting there, or the last half of the one starting h+1 earlier;
-            // read-oriented G = F when the read h-mer itself was found, its reverse complement when the reverse-complemented key was
-            const bool at_start = (first_half[q] != (ori != 0));
-            for (uint32_t e = 0; e < cnt; ++e) {
-                // a place is two words: the h + 1 bases behind / in front of the h-mer, then unitig << 32 | behind-exists << 31 | offset: the candidate k-mer is the
-                // h-mer with one of its flanks, the entry alone verifies it (round 5: the unitig's bounds and its sequence were two more dependent cache lines each)
-                const uint64_t fl = hxl[first + 2ull * e], ent = hxl[first + 2ull * e + 1ull];
-                *n_slots += 2; // a candidate costs its 16-byte list entry
-                const uint32_t u = static_cast<uint32_t>(ent >> 32), pos = static_cast<uint32_t>(ent & 0x7FFFFFFFull);
+        const uint64_t kq = key[q], rq = rtk_revcomp(kq, h);
+        const uint64_t c = kq < rq ? kq : rq;
+        *n_lookups += 1;
+        uint64_t i = rtk_hash64(c) & hx_mask, first = 0; bool found = false;
+        while (true) { const uint64_t sv = hx[i]; *n_slots += 1; if (sv == RTK_EMPTY_KEY) break; if ((sv >> 34) == c) { first = sv & 0x3FFFFFFFFull; found = true; break; } i = (i + 1) & hx_mask; }
+        if (!found) continue;
+        const uint32_t cnt = static_cast<uint32_t>(hxl[first]); ++first;
+        const bool palin = kq == rq; // (even h only: the h-mer reads the same on both strands, every place is a place of both orientations)
+        for (uint32_t e = 0; e < cnt; ++e) {
+            // a place is two words: the h + 1 bases behind / in front of the h-mer, then reversed << 63 | unitig << 32 | behind-exists << 31 | offset: the candidate k-mer is the
+            // h-mer with one of its flanks, the entry alone verifies it (round 5: the unitig's bounds and its sequence were two more dependent cache lines each)
+            const uint64_t fl = hxl[first + 2ull * e], ent = hxl[first + 2ull * e + 1ull];
+            *n_slots += 2; // a candidate costs its 16-byte list entry
+            const uint64_t x = (ent >> 63) ? (c == kq ? rq : kq) : c; // the h-mer as the unitig spells it
+            const uint32_t u = static_cast<uint32_t>(ent >> 32) & 0x7FFFFFFFu, pos = static_cast<uint32_t>(ent & 0x7FFFFFFFull);
+            for (int ori = (x == kq ? 0 : 1), last = (palin ? 1 : ori); ori <= last; ++ori) { // ori 1: the unitig spells the reverse complement of the read's h-mer
+                // the unitig h-mer is the first half of the forward k-mer F starting there, or the last half of the one starting h+1 earlier;
+                // read-oriented G = F when the read h-mer itself was found, its reverse complement when the reverse-complemented key was
+                const bool at_start = (first_half[q] != (ori != 0));
                 int64_t t; uint64_t F;
                 if (at_start) { if (!((ent >> 31) & 1ull)) continue; t = pos; F = (x << (2 * (h + 1))) | (fl >> 32); }
                 else { if (pos < static_cast<uint32_t>(h + 1)) continue; t = static_cast<int64_t>(pos) - (h + 1); F = ((fl & 0xFFFFFFFFull) << (2 * h)) | x; }

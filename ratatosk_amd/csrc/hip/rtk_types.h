@@ -123,8 +123,8 @@ struct GraphView {
     U<const uint64_t*> amb;       // SNP annotations: amb[u]..amb[u+1] index the entries of unitig u, entry j = amb[n_unitigs + 1 + j] = position<<4 | IUPAC index, by (position, code)
     U<const uint64_t*> hap;       // haplotype ids: hap[u]..hap[u+1] index the ids of unitig u at hap[n_unitigs + 1 + j] (not read by `correct` without -p/-P)
     U<uint64_t> n_amb;            // number of annotation entries (0: getAmbiguityVector / fixAmbiguity are identities)
-    U<const uint64_t*> hx;        // [hx_mask+1] half-k-mer index for the 1-edit search: slot = h-mer << 34 | first (h = (k-1)/2, h-mers of the forward unitig
-    U<uint64_t> hx_mask;          //   sequences), empty = RTK_EMPTY_KEY; hxl[first] = number of places the h-mer starts, then two words per place: flanks (h + 1 bases behind << 32 | h + 1 bases in front), unitig<<32 | behind-exists<<31 | offset.
+    U<const uint64_t*> hx;        // [hx_mask+1] half-k-mer index for the 1-edit search: slot = CANONICAL h-mer << 34 | first (h = (k-1)/2; the smaller of an h-mer of the forward unitig
+    U<uint64_t> hx_mask;          //   sequences and its reverse complement), empty = RTK_EMPTY_KEY; hxl[first] = number of places, then two words per place: flanks (h + 1 bases in front << 32 | h + 1 bases behind, as the unitig spells them), reversed<<63 | unitig<<32 | front-exists<<31 | offset.
     U<const uint64_t*> hxl;       //   hx_mask == 0: no index (the search spells the variants instead)
 };
 

@@ -141,8 +141,9 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
     // ---- half-k-mer index: every h-mer (h = (k-1)/2) of the forward unitig sequences -> the places it starts. A graph k-mer one edit
     // away from a read window shares its first or its last h characters with the read (the edit cannot be in both), so the 1-edit search
     // looks up read h-mers here and verifies the few k-mers they belong to instead of spelling every variant of the window.
-    // hx: one word per slot, h-mer << 34 | first; hxl[first] = number of places, then TWO words per place: the h + 1 bases behind the h-mer (high half) and the
-    // h + 1 bases in front of it (low half), first base in the high bits, zeros where the unitig ends; then unitig << 32 | (h + 1 bases behind exist) << 31 | offset.
+    // hx: one word per slot, CANONICAL h-mer << 34 | first (the smaller of the h-mer and its reverse complement: one look-up serves both strands; round 5);
+    // hxl[first] = number of places, then TWO words per place: the h + 1 bases behind the h-mer (high half) and the
+    // h + 1 bases in front of it (low half), first base in the high bits, zeros where the unitig ends; then (the unitig spells the reverse complement of the key) << 63 | unitig << 32 | (h + 1 bases in front exist) << 31 | offset.
     // A candidate k-mer is the h-mer with one of its flanks: the search verifies it from the entry alone, without reading the unitig's bounds or sequence.
     // Not built (a single empty slot; the search then spells the variants) with RTK_INEXACT_ENUM=1 or above RTK_HX_MAX_GB (default 96).
     const TableSizes tsz = table_sizes(k, n_kmers, uoff[n]);
@@ -154,6 +155,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
             // all threads: count per (thread, bucket), scatter to the bucket's range, sort the buckets, lay the lists out bucket by bucket (their
             // offsets from a prefix sum), claim the table slots with compare-and-swap. The lists (hxl) come out as one serial pass would write them;
             // the slot an h-mer lands on depends on who claims first, which no lookup can tell.
+            if (n >= (1ull << 31)) throw std::runtime_error("half-k-mer index: more than 2^31 unitigs");
             typedef std::pair<uint64_t, uint64_t> HP;
             const uint64_t n_pairs = uoff[n] - static_cast<uint64_t>(n) * static_cast<uint64_t>(h - 1);
             const uint64_t hm = (1ull << (2 * h)) - 1ull;
@@ -164,7 +166,9 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                 uint64_t after = 0, before = 0; const bool a_ok = pos + h + nbf <= sq.size(), b_ok = pos >= nbf;
                 if (a_ok) for (uint64_t x = 0; x < nbf; ++x) after = (after << 2) | static_cast<uint64_t>(base2bits(sq[pos + h + x]));
                 if (b_ok) for (uint64_t x = 0; x < nbf; ++x) before = (before << 2) | static_cast<uint64_t>(base2bits(sq[pos - nbf + x]));
-                *fl = (after << 32) | before; *pl = (static_cast<uint64_t>(u) << 32) | (a_ok ? (1ull << 31) : 0ull) | pos;
+                uint64_t fwd = 0; for (int x = 0; x < h; ++x) fwd = (fwd << 2) | static_cast<uint64_t>(base2bits(sq[pos + static_cast<uint64_t>(x)]));
+                const bool reversed = rtk_revcomp(fwd, h) < fwd; // the list this place is on is keyed by the reverse complement of what the unitig spells here
+                *fl = (after << 32) | before; *pl = (reversed ? (1ull << 63) : 0ull) | (static_cast<uint64_t>(u) << 32) | (a_ok ? (1ull << 31) : 0ull) | pos;
             };
             int nt = n_threads < 1 ? 1 : n_threads; if (static_cast<size_t>(nt) > n) nt = static_cast<int>(n);
             int bbits = 2 * h < 12 ? 2 * h : 12; while (bbits > 0 && (n_pairs >> bbits) < 4096) --bbits; // ~4096 buckets for big graphs, fewer for small ones
@@ -176,7 +180,7 @@ void FlatGraph::load(const std::string& fasta_gz, const std::string& rtsk, int k
                     uint64_t fw = 0;
                     for (size_t i = 0; i < s.size(); ++i) {
                         fw = ((fw << 2) | static_cast<uint64_t>(base2bits(s[i]))) & hm;
-                        if (i + 1 >= static_cast<size_t>(h)) fn(fw, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h));
+                        if (i + 1 >= static_cast<size_t>(h)) { const uint64_t rc = rtk_revcomp(fw, h); fn(fw < rc ? fw : rc, (static_cast<uint64_t>(u) << 32) | static_cast<uint64_t>(i + 1 - h)); } // keyed by the canonical h-mer
                     }
                 }
             };
