@@ -625,7 +625,8 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
     // 5.8 against 4.7 ms per 64 Mb on the 60 Mb graph: the lookups of six waves per SIMD already overlap, the arrays of the batched form spill)
     // The index is keyed by the CANONICAL h-mer (the smaller of an h-mer and its reverse complement; round 5): one look-up per read h-mer finds the places where it
     // stands in a unitig as it is AND those where its reverse complement does (bit 63 of a place: the unitig holds the reverse complement of the key). Before, the two
-    // orientations were two look-ups -- two random lines of the table each.
+    // orientations were two look-ups -- two random lines of the table each. (Also measured in round 5: every read position of a tile looked up once and the list starts shared
+    // by the up to four windows that use them, through LDS -- look-ups 47 M -> 15.7 M per 64 Mb, and the kernel SLOWER, 3.44 -> 4.08 ms: the look-up is not what the lanes wait for.)
     for (int q = 0; q < nkeys; ++q) {
         const uint64_t kq = key[q], rq = rtk_revcomp(kq, h);
         const uint64_t c = kq < rq ? kq : rq;
