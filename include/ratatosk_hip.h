@@ -169,6 +169,14 @@ int rtk_opts_default(const rtk_graph* g, rtk_opts* opts);
  * owned by the caller (release with rtk_free). qual may be NULL (FASTA input). */
 int rtk_correct_batch(rtk_graph* g, const rtk_opts* opts, uint32_t n, const char* const* seq, const char* const* qual,
                       const uint32_t* len, char** out_seq, char** out_qual, uint32_t* out_len);
+/* Revision 6: the tickets of CONCURRENT rtk_correct_batch callers are merged into one launch. The reference's workers each take a ticket of
+ * >= 1 MiB of bases (src/Common.hpp:138, src/Ratatosk.cpp:757-772) and call the loop body on it from `-c` threads at once; a launch that small
+ * lasts as long as its longest read and leaves the device idle, so a call that arrives while another caller gathers a group joins it (first-pass
+ * tickets below RTK_COALESCE_BASES = 16 Mi bases, same rtk_opts bytes, same kind of input; the gatherer waits <= RTK_COALESCE_WAIT_US = 2 000 us
+ * once another caller has been seen, not at all when it is alone), the group runs as one batch and every caller copies out its own reads.
+ * Results are those of the calls made one by one (reads are independent). RTK_COALESCE_BASES=0 switches it off.
+ * rtk_coalesce_stats: groups launched and tickets they held since the graph was loaded (a group of one is a call that ran on its own). */
+int rtk_coalesce_stats(rtk_graph* g, uint64_t* n_groups, uint64_t* n_tickets);
 
 /* Same work split so that a caller can keep the batch resident in HBM across the timed region:
  * create = pack + H2D copy, run = kernels only (synchronous), fetch = D2H + unpack. */
@@ -260,7 +268,7 @@ void rtk_free(void* p);
 const char* rtk_last_error(void);
 const char* rtk_version(void);
 /* Interface revision, raised whenever a struct of this header grows or a default changes (5: rtk_opts.struct_size, rtk_stats lane fields, a2_exclusive default 1). */
-#define RTK_API_REVISION 5
+#define RTK_API_REVISION 6
 int rtk_api_revision(void);
 
 #ifdef __cplusplus

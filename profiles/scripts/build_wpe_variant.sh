@@ -10,7 +10,7 @@
 # 43.0 ms; 3 (168 VGPRs, 3072 waves) 46.1 ms; 2 (256 VGPRs, 2048 waves) 48.7 ms; default build at 3072 waves 43.3 ms.
 set -e
 V=$1; OUT=$(realpath -m $2); T=$(mktemp -d); cd "$(dirname "$0")/../../ratatosk_amd/csrc"
-EXTRA=""; [ "$V" = 5 ] && EXTRA="-DRTK_LDS_SET_CAP=1792u -DRTK_SLIM_HDR"
+EXTRA=""; [ "$V" = 5 ] && EXTRA="-DRTK_LDS_SET_CAP=1472u -DRTK_CS_MAX_IDS=256u -DRTK_SLIM_HDR"; [ "$V" = 6 ] && EXTRA="-DRTK_LDS_SET_CAP=1152u -DRTK_CS_MAX_IDS=128u -DRTK_SLIM_HDR"
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-result -DRTK_REGION_WPE=$V $EXTRA -I../../include"
 /opt/rocm/bin/hipcc $FLAGS --cuda-device-only -emit-llvm -S -o $T/dev.ll hip/rtk_device.hip 2>/dev/null
 python3 - $V $T <<'PY'
@@ -28,5 +28,5 @@ PY
 /opt/rocm/lib/llvm/bin/clang -x ir $T/dev_p.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -o $T/dev.co
 /opt/rocm/lib/llvm/bin/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$T/dev.co -output=$T/dev.hipfb
 /opt/rocm/bin/hipcc $FLAGS --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $T/dev.hipfb -c -o $T/host.o hip/rtk_device.hip 2>/dev/null
-/opt/rocm/bin/hipcc -O3 --hip-link -shared -fPIC -o $OUT host/flat_graph.o hip/rtk_phase_long.o $T/host.o -lz -lpthread
+/opt/rocm/bin/hipcc -O3 --hip-link -shared -fPIC -o $OUT host/flat_graph.o hip/rtk_phase_long.o hip/rtk_index.o hip/rtk_graph_tables.o $T/host.o -lz -lpthread
 rm -rf $T; echo "built $OUT"

@@ -129,7 +129,7 @@ inline void tinybitmap_read(std::istream& in, std::vector<uint32_t>& ids) {
     if (header & 1u) throw std::runtime_error("rtsk: TinyBitmap header has bit 0 set: not the layout assumed in [A8], refusing to guess");
     { // [A8] cannot be checked against a Bifrost build here ("fail loudly until verified"): such a payload is REFUSED unless the caller opts in
         const char* allow = getenv("RTK_ALLOW_TINYBITMAP");
-        if (!(allow && allow[0] == '1')) throw std::runtime_error("rtsk: the index holds a Bifrost TinyBitmap colour set (PairID flag 0); its layout is assumption [A8] (oracle/oracle_graph.hpp), not verified against a Bifrost-written index: set RTK_ALLOW_TINYBITMAP=1 to decode it under that assumption");
+        if (!(allow && allow[0] == '1')) throw std::runtime_error("rtsk: the index holds a Bifrost TinyBitmap colour set (PairID flag 0); its layout is assumption [A8] (oracle/oracle_graph.hpp), not verified against a Bifrost-written index: run `Ratatosk correct` with --allow-tinybitmap (library callers: set RTK_ALLOW_TINYBITMAP=1) to decode it under that assumption");
         static bool warned = false;
         if (!warned) { warned = true; fprintf(stderr, "rtsk: note: RTK_ALLOW_TINYBITMAP=1: decoding Bifrost TinyBitmap colour sets with the layout assumed in [A8]; it has not been verified against a Bifrost-written index\n"); }
     }

@@ -116,7 +116,10 @@ RTK_DEV RtkBM rtk_bm_from_ids(const uint32_t* uni, uint32_t U, uint64_t* scatter
 // three round trips for all slots together instead of five per slot and pass), the candidate anchors are ranked in registers, the
 // ids go from the colour pool straight into LDS (one flat pass over all lists), and the per-slot bit vectors (8 words at this size)
 // stay in LDS. Returns RTK_NONE32 when the case is not small (caller goes on to rtk_choose_colors_bits).
-#define RTK_CS_MAX_IDS 512u
+#ifndef RTK_CS_MAX_IDS
+#define RTK_CS_MAX_IDS 512u // (developer builds with a smaller LDS buffer lower it: profiles/scripts/build_wpe_variant.sh)
+#endif
+static_assert(2u * RTK_CS_MAX_IDS + 768u <= RTK_LDS_SET_CAP && RTK_CS_MAX_IDS <= 512u, "small path of the colour selection: universe + unsorted ids + 24 x 2 x 8 vector words in the LDS buffer");
 // the 512-bit vectors of the small case live in lanes 0..7 (the other lanes hold zero): sums and prefix sums over eight lanes by DPP
 // moves inside one row (quad permutes, half-row mirror, row shifts) instead of six cross-lane permutes through LDS
 RTK_DEV int rtk_sum8(int v) { // every lane of 0..7 gets the sum over lanes 0..7 (callers read lane 0)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -103,6 +104,10 @@ struct rtk_graph {
         if (hpool_bytes + bytes > (8ull << 30)) { rtk_hfree_pinned(p); return; }
         hpool.insert(std::make_pair(bytes, p)); hpool_bytes += bytes;
     }
+    // Tickets of concurrent rtk_correct_batch callers that are merged into one launch (rtk_pipeline_run.inc, "ticket coalescing"): the queue of waiting
+    // tickets, whether a caller is gathering a group right now, the groups whose batch is being created / run / fetched, how many tickets the last group held
+    std::mutex co_m; std::condition_variable co_cv; std::vector<struct CoTicket*> co_q; bool co_gathering = false; int co_running = 0; uint32_t co_last_group = 0;
+    unsigned long long co_groups = 0, co_tickets = 0; // (statistics: rtk_coalesce_stats)
     rtk_graph() { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { dbuf[i] = nullptr; dbytes[i] = 0; } memset(&dview, 0, sizeof(dview)); memset(&info, 0, sizeof(info)); }
 };
 

@@ -69,6 +69,11 @@ __global__ void k_fill_slots(uint64_t* __restrict__ ht, uint64_t slots) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < slots; i += stride) { ht[2 * i] = RTK_EMPTY_KEY; ht[2 * i + 1] = 0; }
 }
+// a place word of the half-k-mer index keeps its in-unitig offset in 31 bits (bit 31 and bit 63 are flags): the same refusal as the host builder's (flat_graph.cpp)
+__global__ void k_check_unitig_lengths(const uint64_t* __restrict__ uoff, uint32_t n_unitigs, uint32_t* __restrict__ err) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t u = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < n_unitigs; u += stride) if ((uoff[u + 1] - uoff[u]) >> 31) atomicOr(err, 2u);
+}
 __global__ void k_fill_words(uint64_t* __restrict__ a, uint64_t n, uint64_t v) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;
@@ -187,7 +192,7 @@ __global__ void k_hx_scatter(const uint64_t* __restrict__ S, uint64_t n_s, uint6
         uint32_t lo = 0, hi = n_unitigs;
         while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (uoff[mid] <= pos) lo = mid; else hi = mid; }
         const uint64_t gi = base + i;
-        { // the two words of the place: the h + 1 bases behind and in front of the h-mer (zeros where the unitig ends), then unitig << 32 | behind-exists << 31 | offset
+        { // the two words of the place: the h + 1 bases behind and in front of the h-mer (zeros where the unitig ends), then unitig << 32 | following-bases-exist (a_ok) << 31 | offset
             const uint64_t u0 = uoff[lo], u1 = uoff[lo + 1], nbf = static_cast<uint64_t>(h) + 1ull;
             const bool a_ok = pos + static_cast<uint64_t>(h) + nbf <= u1, b_ok = pos >= u0 + nbf;
             uint64_t after = 0, before = 0;
@@ -231,6 +236,9 @@ void device_tables_build(const uint64_t* d_useq, const uint64_t* d_uoff, uint32_
     else {
         const int h = tsz.h;
         if (n_bases > RTK_POS_MASK) throw std::runtime_error("half-k-mer index: more than 2^34 bases in the unitig pool (set RTK_INEXACT_ENUM=1)");
+        if (n_unitigs >= (1u << 31)) throw std::runtime_error("half-k-mer index: more than 2^31 unitigs");
+        { hipLaunchKernelGGL(k_check_unitig_lengths, dim3(grid_for(n_unitigs)), dim3(RTK_TB_BLOCK), 0, 0, d_uoff, n_unitigs, d_err.as<uint32_t>()); sync_check("k_check_unitig_lengths");
+          uint32_t e = 0; rtk_check(hipMemcpy(&e, d_err.p, 4, hipMemcpyDeviceToHost), "hipMemcpy"); if (e & 2u) throw std::runtime_error("half-k-mer index: a unitig of more than 2^31 bases"); }
         const uint64_t n_pairs = n_bases - static_cast<uint64_t>(n_unitigs) * static_cast<uint64_t>(h - 1);
         const uint64_t bm_words = ((1ull << (2 * h)) + 63) / 64;
         const int nbits = 2 * h < 12 ? 2 * h : 12; const int bshift = 2 * h - nbits; const uint32_t n_bins = 1u << nbits;

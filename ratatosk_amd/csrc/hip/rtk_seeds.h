@@ -615,12 +615,15 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
     const int h = (k - 1) / 2;
     const uint64_t hm = (1ull << (2 * h)) - 1ull;
     const uint64_t* const hx = g.hx; const uint64_t hx_mask = g.hx_mask; const uint64_t* const hxl = g.hxl;
-    // the window's characters as one code: k-1, k or k+1 of them
-    uint64_t key[4]; bool first_half[4]; int nkeys = 0;
-    key[nkeys] = (w_k1 >> (2 * (k - 1 - h))) & hm; first_half[nkeys++] = true;                       // m[p .. p+h)
-    key[nkeys] = w_k1 & hm; first_half[nkeys++] = false;                                              // m[p+k-1-h .. p+k-1): last half when the graph k-mer has an extra base
-    if (ck <= 3) { key[nkeys] = ((w_k1 << 2) | static_cast<uint64_t>(ck)) & hm; first_half[nkeys++] = false; } // m[p+k-h .. p+k): substitution
-    if (ck <= 3 && ck1 <= 3) { key[nkeys] = ((w_k1 << 4) | (static_cast<uint64_t>(ck) << 2) | static_cast<uint64_t>(ck1)) & hm; first_half[nkeys++] = false; } // m[p+k+1-h .. p+k+1): a read base missing in the graph
+    // the window's characters as one code of k + 1 (ck / ck1 = 0 where the read has none: those keys are not asked for). The four seed h-mers are shifts of it:
+    //   q = 0  m[p .. p+h)              first half of G
+    //   q = 1  m[p+k-1-h .. p+k-1)      last half when the graph k-mer has an extra base
+    //   q = 2  m[p+k-h .. p+k)          last half, substitution              (needs ck)
+    //   q = 3  m[p+k+1-h .. p+k+1)      last half, a read base missing in G  (needs ck and ck1)
+    // Round 6: the keys are computed where they are used. As `key[4]` / `first_half[4]` indexed by the loop variable they lived in the lane's stack: 36 bytes stored per
+    // window = the 3.3 GB a launch wrote whatever the graph (WRITE_SIZE of round 5), and the kernel's 160 bytes of scratch per lane with the hit registers below.
+    const uint64_t S_all = (w_k1 << 4) | (static_cast<uint64_t>(ck <= 3 ? ck : 0u) << 2) | static_cast<uint64_t>(ck1 <= 3 ? ck1 : 0u);
+    const int nkeys = (ck <= 3) ? ((ck1 <= 3) ? 4 : 3) : 2;
     // (measured in round 5: all eight home slots, then all count words, in flight together -- three rounds of independent loads instead of eight chains -- is SLOWER,
     // 5.8 against 4.7 ms per 64 Mb on the 60 Mb graph: the lookups of six waves per SIMD already overlap, the arrays of the batched form spill)
     // The index is keyed by the CANONICAL h-mer (the smaller of an h-mer and its reverse complement; round 5): one look-up per read h-mer finds the places where it
@@ -628,7 +631,8 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
     // orientations were two look-ups -- two random lines of the table each. (Also measured in round 5: every read position of a tile looked up once and the list starts shared
     // by the up to four windows that use them, through LDS -- look-ups 47 M -> 15.7 M per 64 Mb, and the kernel SLOWER, 3.44 -> 4.08 ms: the look-up is not what the lanes wait for.)
     for (int q = 0; q < nkeys; ++q) {
-        const uint64_t kq = key[q], rq = rtk_revcomp(kq, h);
+        const bool first_half_q = q == 0;
+        const uint64_t kq = (S_all >> (q == 0 ? 2 * (k - 1 - h) + 4 : 2 * (3 - q))) & hm, rq = rtk_revcomp(kq, h);
         const uint64_t c = kq < rq ? kq : rq;
         *n_lookups += 1;
         uint64_t i = rtk_hash64(c) & hx_mask, first = 0; bool found = false;
@@ -637,7 +641,7 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
         const uint32_t cnt = static_cast<uint32_t>(hxl[first]); ++first;
         const bool palin = kq == rq; // (even h only: the h-mer reads the same on both strands, every place is a place of both orientations)
         for (uint32_t e = 0; e < cnt; ++e) {
-            // a place is two words: the h + 1 bases behind / in front of the h-mer, then reversed << 63 | unitig << 32 | behind-exists << 31 | offset: the candidate k-mer is the
+            // a place is two words: the h + 1 bases behind / in front of the h-mer, then reversed << 63 | unitig << 32 | following-bases-exist << 31 | offset (bit 31 = `a_ok` of the two builders: the h + 1 bases that FOLLOW the h-mer in the forward unitig sequence exist): the candidate k-mer is the
             // h-mer with one of its flanks, the entry alone verifies it (round 5: the unitig's bounds and its sequence were two more dependent cache lines each)
             const uint64_t fl = hxl[first + 2ull * e], ent = hxl[first + 2ull * e + 1ull];
             *n_slots += 2; // a candidate costs its 16-byte list entry
@@ -646,7 +650,7 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
             for (int ori = (x == kq ? 0 : 1), last = (palin ? 1 : ori); ori <= last; ++ori) { // ori 1: the unitig spells the reverse complement of the read's h-mer
                 // the unitig h-mer is the first half of the forward k-mer F starting there, or the last half of the one starting h+1 earlier;
                 // read-oriented G = F when the read h-mer itself was found, its reverse complement when the reverse-complemented key was
-                const bool at_start = (first_half[q] != (ori != 0));
+                const bool at_start = (first_half_q != (ori != 0));
                 int64_t t; uint64_t F;
                 if (at_start) { if (!((ent >> 31) & 1ull)) continue; t = pos; F = (x << (2 * (h + 1))) | (fl >> 32); }
                 else { if (pos < static_cast<uint32_t>(h + 1)) continue; t = static_cast<int64_t>(pos) - (h + 1); F = ((fl & 0xFFFFFFFFull) << (2 * h)) | x; }
@@ -692,21 +696,34 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
             }
         }
         // pass 1: up to four distinct hits of the lane's window stay in registers
+        // (every index into the three arrays is a compile-time constant -- unrolled loops with predicates -- so that they ARE registers: indexed by my_n they were stack)
         uint64_t my_code[RTK_SEED_REGS], my_hit[RTK_SEED_REGS]; uint32_t my_kind[RTK_SEED_REGS]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
+#pragma unroll
+        for (int i = 0; i < RTK_SEED_REGS; ++i) { my_code[i] = 0; my_hit[i] = RTK_NO_HIT; my_kind[i] = 0; }
         // [A2] exclusive: the kinds of edit are searched one after the other and the first kind with a hit is the window's only one (rtk_a2_keep). ONE
         // visit of the window: every hit is kept with the kinds of edit that reach it, the kinds seen anywhere in the window decide which hits stay
         uint32_t keep = 7u, any = 0;
         if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, exclusive != 0u, [&](uint64_t code, uint64_t hit, uint32_t kinds) {
             any |= kinds;
-            for (int i = 0; i < my_n; ++i) if (my_hit[i] == hit) { my_kind[i] |= kinds; return; }
-            if (my_n < RTK_SEED_REGS) { my_code[my_n] = code; my_hit[my_n] = hit; my_kind[my_n] = kinds; ++my_n; } else more = true;
+            bool dup = false;
+#pragma unroll
+            for (int i = 0; i < RTK_SEED_REGS; ++i) if (i < my_n && my_hit[i] == hit) { my_kind[i] |= kinds; dup = true; }
+            if (dup) return;
+            if (my_n < RTK_SEED_REGS) {
+#pragma unroll
+                for (int i = 0; i < RTK_SEED_REGS; ++i) if (i == my_n) { my_code[i] = code; my_hit[i] = hit; my_kind[i] = kinds; }
+                ++my_n;
+            } else more = true;
         });
-        if (exclusive && cand && !more) {
+        uint32_t live = (1u << my_n) - 1u; // the registers that hold a hit of a kept kind, in discovery order
+        if (exclusive && cand) {
             keep = rtk_a2_keep(any, exclusive);
-            int w2 = 0;
-            for (int i = 0; i < my_n; ++i) if (my_kind[i] & keep) { my_code[w2] = my_code[i]; my_hit[w2] = my_hit[i]; ++w2; }
-            my_n = w2;
-        } else if (exclusive && cand) keep = rtk_a2_keep(any, exclusive);
+            if (!more) {
+#pragma unroll
+                for (int i = 0; i < RTK_SEED_REGS; ++i) if (!(my_kind[i] & keep)) live &= ~(1u << i);
+                my_n = rtk_popc(static_cast<uint64_t>(live));
+            }
+        }
         *acc_probes += lookups; *acc_slots += slots;
         if (more) { // a window inside a repeat: count every visit, take a private slice of the pool, write them all. (`more` is raised by hits of ANY kind of edit -- the kinds
             // kept are only known once the whole window has been visited -- but the slice is sized from the KEPT hits alone: the pool does not grow with the exclusive reading of [A2])
@@ -719,7 +736,7 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
                 bv.wdesc[bb] = (static_cast<uint64_t>(pb) << 24) | static_cast<uint64_t>(n_all);
                 rtk_atomic_add(bv.counters + RTK_CNT_HITS_INEXACT, static_cast<unsigned long long>(n_all));
             } else rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
-            my_n = 0;
+            my_n = 0; live = 0;
         }
         int total; const int off = rtk_wave_excl_scan(my_n, &total);
         if (total > 0) {
@@ -731,7 +748,9 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
             const unsigned long long pbase = chunk->base;
             chunk->base += static_cast<unsigned long long>(total); chunk->left -= static_cast<uint32_t>(total);
             if (pbase + static_cast<unsigned long long>(total) <= bv.ipool_cap) {
-                for (int i = 0; i < my_n; ++i) { bv.ipool[2 * (pbase + off + i)] = my_code[i]; bv.ipool[2 * (pbase + off + i) + 1] = my_hit[i]; }
+                int w_ = 0;
+#pragma unroll
+                for (int i = 0; i < RTK_SEED_REGS; ++i) if ((live >> i) & 1u) { bv.ipool[2 * (pbase + off + w_)] = my_code[i]; bv.ipool[2 * (pbase + off + w_) + 1] = my_hit[i]; ++w_; }
                 if (my_n) bv.wdesc[bb] = (static_cast<uint64_t>(pbase + off) << 24) | static_cast<uint64_t>(my_n);
             } else if (rtk_lane() == 0) rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
             if (rtk_lane() == 0) *acc_hits += static_cast<unsigned long long>(total);

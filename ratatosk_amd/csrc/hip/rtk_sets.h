@@ -107,7 +107,8 @@ RTK_FN uint32_t rtk_set_union(const uint32_t* a_, uint32_t na_, const uint32_t* 
 #ifndef RTK_SIM
 // the same network run in LDS for up to RTK_LDS_SORT_CAP pairs, in the 8 KB buffer of the set searches (one LDS allocation per wave: the
 // region kernel keeps 16 waves per CU)
-#define RTK_LDS_SORT_CAP (RTK_LDS_SET_CAP / 4)
+#define RTK_LDS_SORT_CAP (RTK_LDS_SET_CAP >= 2048u ? 512u : 256u) // a power of two (the block size of the in-LDS stages of rtk_sort_pairs): key + payload words of that many pairs fit the buffer
+static_assert(4u * RTK_LDS_SORT_CAP <= RTK_LDS_SET_CAP, "LDS sort block");
 RTK_DEV uint64_t* rtk_lds_sort_buf() { return reinterpret_cast<uint64_t*>(rtk_lds_set_buf()); }
 #endif
 

@@ -61,6 +61,8 @@ static void usage() {
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
                     "  -r, --correction-rounds  correction rounds of the 1st pass (default 1)\n  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
                     "      --parse-only      developer: read and parse the long reads with -c threads, report the rate, correct nothing\n"
+                    "      --allow-tinybitmap  decode colour sets stored as Bifrost TinyBitmap streams (most sets of an index written by the reference) with the layout\n"
+                    "                        this build ASSUMES for them (unverified here: Bifrost is not part of the reference checkout); refused without it\n"
                     "      --strip-annotations  drop the short-cycle / SNP annotations of the index before correcting (fixRepeats / fixAmbiguity then have nothing to do)\n"
                     "Writes <out_prefix>.2.fastq (plain FASTQ, input order).\n\n"
                     "       Ratatosk correct -2 -g <graph2.fasta.gz> -d <unitig_data2.rtsk> -l <out_prefix>.2.fastq -L <long_reads> -o <out_prefix> [options]\n"
@@ -112,7 +114,7 @@ int main(int argc, char** argv) {
         {"correction-rounds", required_argument, 0, 'r'}, {"no-snp-correction", no_argument, 0, 'F'}, {"force-io-order", no_argument, 0, 'O'}, {"no-graph-index", no_argument, 0, 'I'},
         {"in-unmapped-short", required_argument, 0, 'u'}, {"in-accurate-long", required_argument, 0, 'a'}, {"in-short-phase", required_argument, 0, 'p'}, {"in-long-phase", required_argument, 0, 'P'}, {"force-correct-snp", no_argument, 0, 'f'},
         {"sampling", required_argument, 0, 'S'}, {"min-conf-color2", required_argument, 0, 'M'}, {"min-len-color2", required_argument, 0, 'C'},
-        {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"gpus", required_argument, 0, 1002}, {"workers-per-gpu", required_argument, 0, 1003}, {"parse-only", no_argument, 0, 1004}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
+        {"batch-bases", required_argument, 0, 'B'}, {"strip-annotations", no_argument, 0, 1001}, {"gpus", required_argument, 0, 1002}, {"workers-per-gpu", required_argument, 0, 1003}, {"parse-only", no_argument, 0, 1004}, {"allow-tinybitmap", no_argument, 0, 1005}, {"verbose", no_argument, 0, 'v'}, {0, 0, 0, 0}};
     int c, idx = 0;
     while ((c = getopt_long(argc - 1, argv + 1, "s:l:o:c:g:d:i:k:w:Q:m:B:L:K:W:t:r:u:a:p:P:S:M:C:GFOIf12v", lo, &idx)) != -1) {
         switch (c) {
@@ -144,6 +146,7 @@ int main(int argc, char** argv) {
             case 1002: opt.gpus = atoi(optarg); break;
             case 1003: opt.workers_per_gpu = atoi(optarg); opt.workers_given = true; break;
             case 1004: opt.parse_only = true; break;
+            case 1005: setenv("RTK_ALLOW_TINYBITMAP", "1", 1); break; // the loader reads it (common/rtsk_io.hpp): colour sets written as Bifrost TinyBitmap streams are decoded under assumption [A8]
             case 's': fprintf(stderr, "Ratatosk::correct: short reads are only needed by `index` (not in scope); ignored\n"); break;
             default: usage(); return 0; // the reference returns 0 on option errors too (src/Ratatosk.cpp:1018)
         }
