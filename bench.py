@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--host-callers", type=int, default=3, help="host threads calling create + run + fetch concurrently")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--plain-index", action="store_true", help="index without SNP annotations (like the reference's `index -F`); for A/B measurements only")
+    ap.add_argument("--no-config4", action="store_true", help="N = 1: skip the configs[4] leg (3 Gb graph resident in HBM, bench_config4.py: ~7 minutes, most of it the index build)")
+    ap.add_argument("--config4-ref-mb", type=int, default=3000, help="reference length of the configs[4] leg in Mb (its stated size: 3000)")
+    ap.add_argument("--config4-tickets", type=int, default=16, help="tickets of 64 Mb of distinct long reads of the configs[4] leg")
     ap.add_argument("--sim", action="store_true", help="CPU-only developer simulator + gloo (tests of the N>1 plumbing); never a benchmark")
     a = ap.parse_args()
     a.serial = not a.overlap
@@ -208,8 +211,7 @@ def correct_batch_leg(api, graph, opts, tickets, n_tickets, callers):
             rc = L.rtk_correct_batch(graph.h, C.byref(opts), n, sa, None, la, os_, oq, ol)
             if rc != 0:
                 err.append(L.rtk_last_error().decode()); return
-            for j in range(n):
-                L.rtk_free(os_[j]); L.rtk_free(oq[j])
+            L.rtk_free_many(os_, n); L.rtk_free_many(oq, n)  # (one foreign call each: a Python loop of 2 n ctypes calls costs more than the frees)
             with lock:
                 done_bases[0] += nb
 
@@ -312,6 +314,31 @@ def lane_kernel_leg(a, api, graph, opts, mine):
         return res
     except Exception as e:  # never takes the bench line down
         return {"error": str(e)[-300:]}
+
+
+def config4_leg(a, workdir, t_start):
+    """configs[4] (BASELINE.json: whole-genome-scale graph resident in HBM, long reads, roofline report) as its own process once this one has released the device:
+    bench_config4.py builds the 3 Gb index (short reads sampled inside the index tool), keeps the graph resident and corrects tickets of DISTINCT reads.
+    Guarded: host memory / disk / HBM inside that script, time here -- every refusal is a {"skipped": reason}."""
+    if time.time() - t_start > 900:
+        return {"skipped": "time: this bench run had already used %d s when the leg was due (limit 900 s; run `python bench_config4.py out.json` on its own)" % (time.time() - t_start)}
+    out_fn = os.path.join(workdir, "config4.json")
+    try:
+        os.remove(out_fn)
+    except OSError:
+        pass
+    cmd = [sys.executable, os.path.join(ROOT, "bench_config4.py"), out_fn, str(a.config4_ref_mb), "30", str(a.config4_tickets), "128", os.path.join(workdir, "c4")]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=1500)
+        d = json.load(open(out_fn))
+        if r.returncode != 0 and "skipped" not in d:
+            d["error"] = r.stderr.strip()[-400:]
+        return d
+    except Exception as e:  # never takes the bench line down
+        try:
+            d = json.load(open(out_fn)); d["error"] = str(e)[-300:]; return d
+        except Exception:
+            return {"error": str(e)[-300:]}
 
 
 def cli_leg(a, pre, fa, rt):
@@ -578,6 +605,9 @@ def run_workload(a, ctx, ref_len, het, name, steps, warmup, n1_first=False):
 KERN = {"k_lookup_exact": "ms_lookup_exact", "k_mask": "ms_mask", "k_inexact": "ms_lookup_inexact", "k_finalize": "ms_seeds", "k_regions": "ms_correct", "k_stitch": "ms_stitch"}
 
 
+T_START = time.time()
+
+
 def main():
     a = parse()
     import torch
@@ -675,6 +705,9 @@ def main():
                                                         else {k_: round(sum(s_[v] for s_ in w1["stats"]) / n1_, 3) for k_, v in KERN.items()}),  # (steps one at a time are the default: the spans above ARE serial)
                           "graph": {"unitigs": int(w1["info"].n_unitigs), "kmers": int(w1["info"].n_kmers), "hbm_bytes": int(w1["info"].hbm_bytes)}}
         w1["graph"].close()
+    if world == 1 and not (a.no_config4 or a.no_host_legs or a.config1_only or a.sim):  # (the developer runs that leave out the host legs leave this one out too)
+        # (last: every graph and work area of this process is released by now -- the leg's own process needs the 288 GB)
+        out["config4"] = config4_leg(a, ctx["workdir"], T_START)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -172,8 +172,8 @@ int rtk_correct_batch(rtk_graph* g, const rtk_opts* opts, uint32_t n, const char
 /* Revision 6: the tickets of CONCURRENT rtk_correct_batch callers are merged into one launch. The reference's workers each take a ticket of
  * >= 1 MiB of bases (src/Common.hpp:138, src/Ratatosk.cpp:757-772) and call the loop body on it from `-c` threads at once; a launch that small
  * lasts as long as its longest read and leaves the device idle, so a call that arrives while another caller gathers a group joins it (first-pass
- * tickets below RTK_COALESCE_BASES = 16 Mi bases, same rtk_opts bytes, same kind of input; the gatherer waits <= RTK_COALESCE_WAIT_US = 2 000 us
- * once another caller has been seen, not at all when it is alone), the group runs as one batch and every caller copies out its own reads.
+ * tickets below RTK_COALESCE_BASES = 16 Mi bases, same rtk_opts bytes, same kind of input; the gatherer waits <= RTK_COALESCE_WAIT_US = 1 500 us
+ * when the device idles and another caller has been seen, not at all when it is alone, and for as long as a group in flight has not reached its region stage), the group runs as one batch and every caller copies out its own reads.
  * Results are those of the calls made one by one (reads are independent). RTK_COALESCE_BASES=0 switches it off.
  * rtk_coalesce_stats: groups launched and tickets they held since the graph was loaded (a group of one is a call that ran on its own). */
 int rtk_coalesce_stats(rtk_graph* g, uint64_t* n_groups, uint64_t* n_tickets);
@@ -265,6 +265,8 @@ int rtk_index_colour_chunk(void* job, const char* chars, uint64_t n_chars, const
 int rtk_index_colour_end(void* job, uint64_t** events, uint64_t* n_events, uint64_t** cov);
 
 void rtk_free(void* p);
+/* rtk_free of p[0 .. n) (the out_seq / out_qual arrays of rtk_correct_batch in one call; entries are set to NULL). */
+void rtk_free_many(void** p, uint32_t n);
 const char* rtk_last_error(void);
 const char* rtk_version(void);
 /* Interface revision, raised whenever a struct of this header grows or a default changes (5: rtk_opts.struct_size, rtk_stats lane fields, a2_exclusive default 1). */

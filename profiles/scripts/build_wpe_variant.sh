@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer build: the library with another register budget for the region kernel AND the functions it calls.
-#   profiles/scripts/build_wpe_variant.sh <waves per SIMD: 2|3|5> <out.so>
+#   profiles/scripts/build_wpe_variant.sh <waves per SIMD: 2|3|5|6|7> <out.so> ["extra -D flags"]
 # amdgpu_waves_per_eu is a kernel attribute; the non-inlined wave programs keep the default budget (128 VGPRs), so the kernel's own
 # attribute changes nothing. This script compiles the device side to LLVM IR, puts "amdgpu-waves-per-eu" (and a work-group size of
 # 64) on every function, compiles the IR to a code object and embeds it in the host object (-fcuda-include-gpubinary).
@@ -10,7 +10,7 @@
 # 43.0 ms; 3 (168 VGPRs, 3072 waves) 46.1 ms; 2 (256 VGPRs, 2048 waves) 48.7 ms; default build at 3072 waves 43.3 ms.
 set -e
 V=$1; OUT=$(realpath -m $2); T=$(mktemp -d); cd "$(dirname "$0")/../../ratatosk_amd/csrc"
-EXTRA=""; [ "$V" = 5 ] && EXTRA="-DRTK_LDS_SET_CAP=1472u -DRTK_CS_MAX_IDS=256u -DRTK_SLIM_HDR"; [ "$V" = 6 ] && EXTRA="-DRTK_LDS_SET_CAP=1152u -DRTK_CS_MAX_IDS=128u -DRTK_SLIM_HDR"
+EXTRA=""; [ "$V" = 5 ] && EXTRA="-DRTK_LDS_SET_CAP=1472u -DRTK_CS_MAX_IDS=256u -DRTK_SLIM_HDR"; [ "$V" = 6 ] && EXTRA="-DRTK_LDS_SET_CAP=1152u -DRTK_CS_MAX_IDS=128u -DRTK_SLIM_HDR"; [ "$V" = 7 ] && EXTRA="-DRTK_LDS_SET_CAP=1024u -DRTK_CS_MAX_IDS=128u -DRTK_SLIM_HDR"; EXTRA="$EXTRA $3"
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-result -DRTK_REGION_WPE=$V $EXTRA -I../../include"
 /opt/rocm/bin/hipcc $FLAGS --cuda-device-only -emit-llvm -S -o $T/dev.ll hip/rtk_device.hip 2>/dev/null
 python3 - $V $T <<'PY'

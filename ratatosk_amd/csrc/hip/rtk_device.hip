@@ -46,6 +46,7 @@ extern "C" const char* rtk_version(void) {
 }
 extern "C" int rtk_api_revision(void) { return RTK_API_REVISION; }
 extern "C" void rtk_free(void* p) { free(p); }
+extern "C" void rtk_free_many(void** p, uint32_t n) { if (p) for (uint32_t i = 0; i < n; ++i) { free(p[i]); p[i] = nullptr; } }
 
 // ------------------------------------------------------------------------------------------------ graph object
 struct rtk_graph {
@@ -104,9 +105,23 @@ struct rtk_graph {
         if (hpool_bytes + bytes > (8ull << 30)) { rtk_hfree_pinned(p); return; }
         hpool.insert(std::make_pair(bytes, p)); hpool_bytes += bytes;
     }
+    // The region stage's graph-wide work areas (slot 1) as two halves: a small first-pass ticket that meets another ticket at the region stage runs its persistent
+    // kernel on 2 048 waves in one half while the other half serves the next ticket -- a launch of a few Mb lasts as long as its heaviest region with most wave
+    // slots idle (round 6, tickets of the reference's size). A big ticket (or a lone one, or one whose half would be too small) takes both.
+    std::mutex rs_m; std::condition_variable rs_cv; bool rs_busy[2] = {false, false}; int rs_whole_waiting = 0;
+    int region_slab_take(bool half_if_contended) { // 0 / 1: that half; 2: both
+        std::unique_lock<std::mutex> lk(rs_m);
+        if (half_if_contended && (rs_busy[0] || rs_busy[1] || rs_whole_waiting)) {
+            rs_cv.wait(lk, [&] { return rs_whole_waiting == 0 && (!rs_busy[0] || !rs_busy[1]); });
+            const int h = rs_busy[0] ? 1 : 0; rs_busy[h] = true; return h;
+        }
+        ++rs_whole_waiting; rs_cv.wait(lk, [&] { return !rs_busy[0] && !rs_busy[1]; }); --rs_whole_waiting;
+        rs_busy[0] = rs_busy[1] = true; return 2;
+    }
+    void region_slab_give(int what) { { std::lock_guard<std::mutex> lk(rs_m); if (what == 2) rs_busy[0] = rs_busy[1] = false; else rs_busy[what] = false; } rs_cv.notify_all(); }
     // Tickets of concurrent rtk_correct_batch callers that are merged into one launch (rtk_pipeline_run.inc, "ticket coalescing"): the queue of waiting
     // tickets, whether a caller is gathering a group right now, the groups whose batch is being created / run / fetched, how many tickets the last group held
-    std::mutex co_m; std::condition_variable co_cv; std::vector<struct CoTicket*> co_q; bool co_gathering = false; int co_running = 0; uint32_t co_last_group = 0;
+    std::mutex co_m; std::condition_variable co_cv; std::vector<struct CoTicket*> co_q; bool co_gathering = false; int co_running = 0, co_pre_region = 0; uint32_t co_last_group = 0;
     unsigned long long co_groups = 0, co_tickets = 0; // (statistics: rtk_coalesce_stats)
     rtk_graph() { for (int i = 0; i < rtk::RTK_N_BUFS; ++i) { dbuf[i] = nullptr; dbytes[i] = 0; } memset(&dview, 0, sizeof(dview)); memset(&info, 0, sizeof(info)); }
 };

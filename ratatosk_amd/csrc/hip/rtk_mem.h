@@ -29,6 +29,8 @@ inline void rtk_dsync() {}
 inline rtk_stream_t rtk_stream_create() { return 0; }
 inline void rtk_stream_destroy(rtk_stream_t) {}
 inline rtk_stream_t rtk_stream_create_high() { return 0; }
+inline int rtk_cu_split(bool*) { return 0; }
+inline rtk_stream_t rtk_stream_create_masked(bool) { return 0; }
 inline void rtk_ssync(rtk_stream_t) {}
 typedef int rtk_event_t;
 inline rtk_event_t rtk_event_create() { return 0; }
@@ -79,6 +81,19 @@ inline void rtk_dsync() { rtk_check(hipDeviceSynchronize(), "hipDeviceSynchroniz
 // so the stages of different batches overlap on the device
 inline rtk_stream_t rtk_stream_create() { hipStream_t s = nullptr; rtk_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate"); return s; }
 inline void rtk_stream_destroy(rtk_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+// CU partition (RTK_CU_SPLIT=<n>[,i]: developer knob of round 6, profiles/r06_cu_mask_probe.txt): the seed stage of a batch on a stream whose kernels only get n of the
+// device's compute units, its region stage on a stream that gets the others -- so that the seed kernels of step s + 1 find wave slots while the persistent region
+// kernel of step s holds every slot of its own CUs. `,i`: the n CUs are every (total / n)-th bit of the mask (spread over the XCDs) instead of the lowest n bits.
+inline int rtk_cu_split(bool* interleaved) { static const int v = [] { const char* e = getenv("RTK_CU_SPLIT"); return e ? atoi(e) : 0; }(); static const bool il = [] { const char* e = getenv("RTK_CU_SPLIT"); return e && strstr(e, ",i"); }(); if (interleaved) *interleaved = il; return v; }
+inline rtk_stream_t rtk_stream_create_masked(bool seed_side) {
+    bool il = false; const int n = rtk_cu_split(&il);
+    int dev = 0, cus = 0; if (n <= 0 || hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= n || cus > 1024) return rtk_stream_create();
+    uint32_t mask[32]; for (int i = 0; i < 32; ++i) mask[i] = 0;
+    for (int c = 0; c < cus; ++c) { const bool seed_cu = il ? ((c % (cus / n)) == 0 && (c / (cus / n)) < n) : (c < n); if (seed_cu == seed_side) mask[c >> 5] |= 1u << (c & 31); }
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, static_cast<uint32_t>((cus + 31) / 32), mask) != hipSuccess) { (void)hipGetLastError(); return rtk_stream_create(); }
+    return s;
+}
 // a stream whose kernels are dispatched ahead of those of the default-priority streams (the lane kernel of the region stage: few waves, each one long dependent chain)
 inline rtk_stream_t rtk_stream_create_high() { int lo = 0, hi = 0; hipStream_t s = nullptr; if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return rtk_stream_create(); rtk_check(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority"); return s; }
 inline void rtk_ssync(rtk_stream_t s) { rtk_check(hipStreamSynchronize(s), "hipStreamSynchronize"); }

@@ -665,7 +665,7 @@ RTK_DEV void rtk_seeded_window(const GraphView& g, int k, uint64_t w_k1, uint32_
 #ifndef RTK_SEED_REGS
 #define RTK_SEED_REGS 4 // distinct hits of a window kept in registers; windows with more take the counted slow path
 #endif
-RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, uint32_t exclusive) {
+RTK_DEV void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uint64_t tile, unsigned long long* acc_probes, unsigned long long* acc_slots, unsigned long long* acc_hits, PoolChunk* chunk, uint32_t exclusive) {
     const int k = g.k;
     const uint64_t* const roff = bv.roff; const uint32_t n_reads = bv.n_reads;
     uint32_t lo_tile = 0; // one scalar search per tile: largest r with roff[r] <= first base of the tile
@@ -695,32 +695,31 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
                 }
             }
         }
-        // pass 1: up to four distinct hits of the lane's window stay in registers
-        // (every index into the three arrays is a compile-time constant -- unrolled loops with predicates -- so that they ARE registers: indexed by my_n they were stack)
-        uint64_t my_code[RTK_SEED_REGS], my_hit[RTK_SEED_REGS]; uint32_t my_kind[RTK_SEED_REGS]; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0;
-#pragma unroll
-        for (int i = 0; i < RTK_SEED_REGS; ++i) { my_code[i] = 0; my_hit[i] = RTK_NO_HIT; my_kind[i] = 0; }
+        // pass 1: up to four distinct hits of the lane's window are staged. Round 6: in LDS (64 lanes x 4 hits x 16 bytes = 4 KB per wave, word (2 i + w) of lane l at
+        // [(2 i + w) * 64 + l]), their kinds of edit packed into one register. As arrays indexed by my_n they lived on the lane's stack; as 20 registers indexed
+        // by constants they pushed other values out of the kernel's 80 (six waves per SIMD): a hit is a rare event (3 % of the windows), its staging can be slow.
+#ifdef RTK_SIM
+        uint64_t st_[2 * RTK_SEED_REGS];
+#define RTK_ST(i, w) st_[2 * (i) + (w)]
+#else
+        __shared__ uint64_t rtk_inexact_stage[2 * RTK_SEED_REGS * RTK_WAVE];
+        uint64_t* const st_ = rtk_inexact_stage + rtk_lane();
+#define RTK_ST(i, w) st_[(2 * (i) + (w)) * RTK_WAVE]
+#endif
+        uint32_t kindpack = 0; int my_n = 0; bool more = false; uint32_t lookups = 0, slots = 0; // kinds of hit i: bits [4 i, 4 i + 3)
         // [A2] exclusive: the kinds of edit are searched one after the other and the first kind with a hit is the window's only one (rtk_a2_keep). ONE
         // visit of the window: every hit is kept with the kinds of edit that reach it, the kinds seen anywhere in the window decide which hits stay
         uint32_t keep = 7u, any = 0;
         if (cand) rtk_seeded_window(g, k, c_k1, ck, ck1, &lookups, &slots, exclusive != 0u, [&](uint64_t code, uint64_t hit, uint32_t kinds) {
             any |= kinds;
-            bool dup = false;
-#pragma unroll
-            for (int i = 0; i < RTK_SEED_REGS; ++i) if (i < my_n && my_hit[i] == hit) { my_kind[i] |= kinds; dup = true; }
-            if (dup) return;
-            if (my_n < RTK_SEED_REGS) {
-#pragma unroll
-                for (int i = 0; i < RTK_SEED_REGS; ++i) if (i == my_n) { my_code[i] = code; my_hit[i] = hit; my_kind[i] = kinds; }
-                ++my_n;
-            } else more = true;
+            for (int i = 0; i < my_n; ++i) if (RTK_ST(i, 1) == hit) { kindpack |= kinds << (4 * i); return; }
+            if (my_n < RTK_SEED_REGS) { RTK_ST(my_n, 0) = code; RTK_ST(my_n, 1) = hit; kindpack |= kinds << (4 * my_n); ++my_n; } else more = true;
         });
-        uint32_t live = (1u << my_n) - 1u; // the registers that hold a hit of a kept kind, in discovery order
+        uint32_t live = (1u << my_n) - 1u; // the staged hits of a kept kind, in discovery order
         if (exclusive && cand) {
             keep = rtk_a2_keep(any, exclusive);
             if (!more) {
-#pragma unroll
-                for (int i = 0; i < RTK_SEED_REGS; ++i) if (!(my_kind[i] & keep)) live &= ~(1u << i);
+                for (int i = 0; i < RTK_SEED_REGS; ++i) if (!((kindpack >> (4 * i)) & keep)) live &= ~(1u << i);
                 my_n = rtk_popc(static_cast<uint64_t>(live));
             }
         }
@@ -749,8 +748,7 @@ RTK_FN void rtk_inexact_tile_seeded(const GraphView& g, const BatchView& bv, uin
             chunk->base += static_cast<unsigned long long>(total); chunk->left -= static_cast<uint32_t>(total);
             if (pbase + static_cast<unsigned long long>(total) <= bv.ipool_cap) {
                 int w_ = 0;
-#pragma unroll
-                for (int i = 0; i < RTK_SEED_REGS; ++i) if ((live >> i) & 1u) { bv.ipool[2 * (pbase + off + w_)] = my_code[i]; bv.ipool[2 * (pbase + off + w_) + 1] = my_hit[i]; ++w_; }
+                for (int i = 0; i < RTK_SEED_REGS; ++i) if ((live >> i) & 1u) { bv.ipool[2 * (pbase + off + w_)] = RTK_ST(i, 0); bv.ipool[2 * (pbase + off + w_) + 1] = RTK_ST(i, 1); ++w_; }
                 if (my_n) bv.wdesc[bb] = (static_cast<uint64_t>(pbase + off) << 24) | static_cast<uint64_t>(my_n);
             } else if (rtk_lane() == 0) rtk_atomic_add(bv.counters + RTK_CNT_OVERFLOW, 1ull);
             if (rtk_lane() == 0) *acc_hits += static_cast<unsigned long long>(total);

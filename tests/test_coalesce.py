@@ -40,8 +40,8 @@ def _run_callers(lib_path, ds, n_callers, n_tickets, reads_per_ticket, opts_kw=N
             if rc != 0:
                 err.append((rc, L.rtk_last_error().decode())); return
             out[i] = [(C.string_at(os_[j], ol[j]).decode(), C.string_at(oq[j], ol[j]).decode()) for j in range(n)]
-            for j in range(n):
-                L.rtk_free(os_[j]); L.rtk_free(oq[j])
+            L.rtk_free_many(os_, n); L.rtk_free_many(oq, n)
+            assert not os_[0] and not oq[n - 1]
 
     th = [threading.Thread(target=caller) for _ in range(n_callers)]
     [t.start() for t in th]; [t.join() for t in th]
