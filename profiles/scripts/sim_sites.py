@@ -16,7 +16,7 @@ buf = (C.c_ulonglong * 256)()
 L.rtk_sim_site_stats(buf, 1)
 b = api.Batch(g, seqs, quals); b.run(g.opts()); st = b.stats(); b.close()
 L.rtk_sim_site_stats(buf, 0)
-names = {0: "other", 1: "score terminal NW", 2: "score nonterm HW (ref in path)", 3: "score nonterm HW (path in ref)", 4: "path qual SHW path", 5: "explore prefix SHW", 6: "select nt HW", 7: "resize SHW", 8: "fixRepeats NW", 9: "fixRepeats NW k", 10: "final select NW", 11: "partial select SHW (restart)", 12: "partial select SHW (final)", 13: "trim SHW", 14: "consensus fw NW path", 15: "consensus bw NW path", 16: "consensus final NW"}
+names = {0: "other", 1: "score terminal NW", 2: "score nonterm HW (ref in path)", 3: "score nonterm HW (path in ref)", 4: "path qual SHW path", 5: "explore prefix SHW", 6: "select nt HW", 7: "resize SHW", 8: "fixRepeats NW", 9: "fixRepeats NW k", 10: "final select NW", 11: "partial select SHW (restart)", 12: "partial select SHW (final)", 13: "trim SHW", 14: "consensus fw NW path", 15: "consensus bw NW path", 16: "consensus final NW", 17: "fixAmbiguity SHW path"}
 print("bases %d regions %d aligns %d expansions %d" % (st["in_bases"], st["n_regions"], st["n_align"], st["n_expand"]))
 tot = sum(buf[8 * i + 1] for i in range(20))
 for i in range(20):

@@ -74,6 +74,13 @@ def test_sim_lone_caller_runs_every_call_on_its_own(ds_snps):
     assert groups == tickets == 4  # nobody to merge with: no waiting, no merging
 
 
+def test_sim_a_failed_group_does_not_fail_its_members(ds_snps, monkeypatch):
+    """A merged batch that fails (test hook) is not the callers' failure: every member runs its own ticket again, alone, and gets the oracle's reads."""
+    monkeypatch.setenv("RTK_TEST_COALESCE_FAIL", "1")
+    groups, tickets = _run_callers(SIM_LIB, ds_snps, n_callers=6, n_tickets=12, reads_per_ticket=3)
+    assert tickets == 12
+
+
 @pytest.mark.gpu
 def test_gpu_concurrent_callers_are_merged_and_get_their_own_reads(ds_medium):
     groups, tickets = _run_callers(None, ds_medium, n_callers=12, n_tickets=48, reads_per_ticket=9)
