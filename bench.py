@@ -249,7 +249,7 @@ def ticket_size_leg(a, api, graph, opts, mine):
         n_t = max(3, min(48, (128 << 20) // want))  # ~128 Mi bases per measurement, at least three tickets
         row = {"ticket_bases": int(sum(len(x) for x in tickets[0][0])), "tickets": n_t}
         for callers in ((1, 3, 8, 16) if mib <= 4 else (1, 3)):  # (the reference runs `-c` workers, each with a ticket of its own: many callers is ITS way of using small tickets)
-            best = None  # the better of two runs: the first tickets of a new size allocate their buffers (a hipMalloc of GBs stalls the device), later ones take them from the pool
+            best = None  # the better of two runs: the first tickets of a new size allocate their buffers (a hipMalloc of GBs stalls the device, DESIGN_HISTORY.md 3.3b), later ones take them from the pool
             for _ in range(2):
                 r = host_inclusive_leg(types.SimpleNamespace(host_tickets=n_t, host_callers=callers), api, graph, opts, tickets)
                 if "value" not in r:

@@ -233,7 +233,7 @@ int rtk_myers_batch_waves(uint32_t n, const char* const* query, const uint32_t* 
 /* rtk_myers_batch with ONE PROBLEM PER LANE: queries of up to 512 characters against targets of up to 2048 over A, C, G, T, N are computed column by column in a
  * lane's registers, 64 problems per wavefront (csrc/hip/rtk_myers_lane.h); with want_path the lane keeps the delta vectors of its columns (up to 4096
  * word-columns) and walks them back. What does not fit that takes the wave route of rtk_myers_batch. Same results
- * (reference: edlibAlign, src/edlib.cpp:131-296). Stage entry: one alignment per lane as the lane-per-region kernel does them, for parity tests and
+ * (reference: edlibAlign, src/edlib.cpp:131-296). Stage entry: one alignment per lane as the lane-per-region kernel does them (DESIGN_HISTORY.md section 3.8), for parity tests and
  * timing; the correction path does not call it. */
 int rtk_myers_batch_lanes(uint32_t n, const char* const* query, const uint32_t* qlen, const char* const* target, const uint32_t* tlen,
                           const int32_t* k, const int32_t* mode, int want_path, int use_iupac,

@@ -23,7 +23,7 @@
 //        as whole-unitig mappings (dist=0, len=size-k+1).
 //        Switchable at run time (RTK_A3_ORDER=walk|strand; rtk_opts::a3_strand_order on the device side): walk (default) = by the base appended in
 //        walk direction on both strands; strand = on the reverse strand by the base as the unitig's own strand spells it (T,G,C,A in walk
-//        direction). The order only breaks ties between candidates of equal score (tests/test_a3_switch.py; counts in DESIGN.md section 5).
+//        direction). The order only breaks ties between candidates of equal score (tests/test_a3_switch.py; counts in DESIGN_HISTORY.md section 5).
 //   [A4] on-disk Kmer = 2 x u64, 2 bits/base (A0 C1 G2 T3), first base in the MSBs of word 0.
 //   [A5] FASTA/FASTQ records: name = header up to the first whitespace.
 //   [A6] KmerIterator visits the all-ACGT windows of a string in order; `it += n` moves to the first such window at or after

@@ -34,5 +34,5 @@ if out_fn:
                "hbm_in_use_gb": round((tt.value - fr.value) / 1e9, 1), "peak_GBs": 8000.0,
                "kernels": {k: {"ms": round(ms[k], 3), "alg_bytes": int(alg[k]), "achieved_GBs": round(alg[k] / (ms[k] * 1e-3) / 1e9, 2) if ms[k] > 0 else 0.0, "frac": round(alg[k] / (ms[k] * 1e-3) / 1e9 / 8000.0, 5) if ms[k] > 0 else 0.0} for k in alg},
                "ms_total": round(S("ms_total"), 2), "events_per_ticket": {k: int(S(k)) for k in ("n_regions", "n_expand", "n_colour_elem", "n_path_base", "n_probes_inexact", "n_slots_inexact", "n_hits_inexact", "n_align")},
-               "alg_bytes_are": "bench.py's formulas (DESIGN.md section 5); k_inexact: 16 B per index slot visited or candidate checked (two list words), 1 B per read base, 16 B per hit"},
+               "alg_bytes_are": "bench.py's formulas (DESIGN_HISTORY.md section 5); k_inexact: 16 B per index slot visited or candidate checked (two list words), 1 B per read base, 16 B per hit"},
               open(out_fn, "w"), indent=1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# host I/O of the first pass (developer measurement): reader alone, CLI file to file on plain and on gzipped input
+# host I/O of the first pass (developer measurement; DESIGN_HISTORY.md section 5): reader alone, CLI file to file on plain and on gzipped input
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 WD=$(mktemp -d /tmp/rtk_io_XXXX)
 python - <<PY

@@ -1,5 +1,5 @@
 """Throughput of the two schedules for the small alignments of the region program: one wave per problem (rtk_myers_batch: the route k_regions takes, one 32- or 64-bit
-word of the query per lane) against one LANE per problem (rtk_myers_batch_lanes). Problems shaped like those of a 64 Mb step of configs[1] (DESIGN.md section 3.5:
+word of the query per lane) against one LANE per problem (rtk_myers_batch_lanes). Problems shaped like those of a 64 Mb step of configs[1] (DESIGN_HISTORY.md section 3.5:
 1.16 M alignments of 536 word-columns on average, 80 % of the regions with gaps under 256 bases): queries of 100-320 characters against targets of about the
 same length at 10 % divergence, NW and SHW, distances and paths. RTK_MYERS_TIME=1 makes the library print the kernel times (HIP events)."""
 import os

@@ -1,6 +1,6 @@
 #!/bin/bash
 # CLI file to file on gzip input of several members (cat of gzip files: common/mgzip.hpp) against the same text as ONE member and as a plain file,
-# then the CLI tests of the gpu tier on the same build. Developer measurement.
+# then the CLI tests of the gpu tier on the same build. Developer measurement (DESIGN_HISTORY.md section 5).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 WD=$(mktemp -d /tmp/rtk_mgz_XXXX)
 python - <<PY

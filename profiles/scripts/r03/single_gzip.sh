@@ -1,6 +1,6 @@
 #!/bin/bash
 # CLI file to file on ONE gzip member (an ordinary `gzip reads.fastq`): the reader's own inflate (common/finflate.hpp) against zlib inside the same
-# reader (RTK_ZLIB_INFLATE=1) and against the one-thread gzread path (-c 1). Developer measurement.
+# reader (RTK_ZLIB_INFLATE=1) and against the one-thread gzread path (-c 1). Developer measurement (DESIGN_HISTORY.md section 5).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 WD=$(mktemp -d /tmp/rtk_sgz_XXXX)
 python - <<PY

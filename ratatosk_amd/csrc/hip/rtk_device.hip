@@ -39,9 +39,9 @@ int rtk_fail(int code, const std::string& msg) { g_last_error = msg; return code
 extern "C" const char* rtk_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char* rtk_version(void) {
 #ifdef RTK_SIM
-    return "ratatosk-mi355x 0.5 (host simulator)";
+    return "ratatosk-mi355x 0.6 (host simulator)";
 #else
-    return "ratatosk-mi355x 0.5 (gfx950)";
+    return "ratatosk-mi355x 0.6 (gfx950)";
 #endif
 }
 extern "C" int rtk_api_revision(void) { return RTK_API_REVISION; }

@@ -1,8 +1,8 @@
 // One alignment per LANE: distance and end locations of edlibAlign (NW / SHW / HW, threshold k) for the small problems of the region program -- queries of a
 // few words against targets of a few hundred characters -- computed column by column with the query's delta vectors in the lane's registers (reference:
 // src/edlib.cpp:586-677 the block recurrence, :161-179 zero lengths, :744-747 NW threshold, the padded last block's position -1). The wave programs of
-// rtk_myers.h give such a problem one wave and keep one WORD per lane busy (3-10 % of the lanes); here 64 problems share a wave.
-// Stage entry rtk_myers_batch_lanes: the building block of the lane-per-region formulation, held to the same golden vectors; it is
+// rtk_myers.h give such a problem one wave and keep one WORD per lane busy (3-10 % of the lanes, DESIGN_HISTORY.md section 3.5); here 64 problems share a wave.
+// Stage entry rtk_myers_batch_lanes: the building block of the lane-per-region formulation (DESIGN_HISTORY.md section 9), held to the same golden vectors; it is
 // not called by the correction path yet. No cross-lane operation: the 1-lane simulator runs exactly the code a lane runs on the device.
 #ifndef RTK_MYERS_LANE_H
 #define RTK_MYERS_LANE_H

@@ -3,7 +3,7 @@
 // exploreSubGraph :456-587, getScorePath :722-772 / :867-909, selectBest*Alignment src/Alignment.cpp:3-147 / :967-1015, fixAmbiguity
 // :527-844, generateConsensus :309-470, edlibAlign src/edlib.cpp:586-677 / :945-1144 -- restated for ONE lane that owns ONE gap between two solid
 // anchors. The wave-per-region kernel keeps 3-10 % of its lanes busy in the small alignments of such a region and pays ~700 dependent memory
-// round trips per region with one region in flight per wave; here a wave has 64 regions in flight, every lane runs the
+// round trips per region with one region in flight per wave (DESIGN_HISTORY.md section 3.5); here a wave has 64 regions in flight, every lane runs the
 // whole program on its own compact records, and the lanes meet in the same loops (the Myers column sweep, the 2-bit decode, the set walks).
 //
 // Rules of this file:

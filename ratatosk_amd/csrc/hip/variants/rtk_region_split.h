@@ -1,4 +1,4 @@
-// Measured-and-rejected variant (-DRTK_REGION_SPLIT, end of round 3): rtk_correct_region as three non-inlined programs that share nothing on the wave's
+// Measured-and-rejected variant (-DRTK_REGION_SPLIT, end of round 3; DESIGN_HISTORY.md 9.1): rtk_correct_region as three non-inlined programs that share nothing on the wave's
 // stack (side lists + colours | path search | assembly + trim), their common state in the RegionCall record of the LDS header. Same results on the simulator and GPU tiers;
 // k_regions 31.0 -> 33.1 ms on configs[1] (the calls cost more callee-saved register rows than the smaller frames return). Included by rtk_region.h inside its own
 // #ifdef: not part of the default build.

@@ -3,7 +3,7 @@
 oracle (oracle/oracle_graph.cpp, Graph::successors) and on the device (rtk_explore_subgraph, rtk_opts::a3_strand_order):
   walk    by the base appended in walk direction, A,C,G,T, on both strands                                   (RTK_A3_ORDER unset or =walk)
   strand  on the reverse strand by the base as the unitig's own strand spells it (T,G,C,A in walk direction)   (RTK_A3_ORDER=strand)
-Device == oracle under each; the number of reads the reading decides is printed (DESIGN.md section 4 quotes it for configs[1])."""
+Device == oracle under each; the number of reads the reading decides is printed (DESIGN_HISTORY.md section 4 quotes it for configs[1])."""
 import pytest
 
 from conftest import SIM_LIB

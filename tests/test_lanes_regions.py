@@ -93,3 +93,18 @@ def test_gpu_lanes_serial_small_rounds_and_tiny_capacities(ds_medium, ds_snps, m
     got, st, seqs, quals = _run(ds_snps, 20, None)
     assert got == _oracle(ds_snps, seqs, quals)
     assert st["n_lane_handed"] > st["n_lane_regions"] // 4
+
+
+@pytest.mark.gpu
+def test_gpu_stolen_regions_that_overflow_are_redone(ds_medium, ds_snps, monkeypatch):
+    """beside the wave kernel with ONE slow lane wave (rounds of 4), the wave kernel steals nearly the whole lane class once its own lists are drained; with
+    tiny work areas (test hook) the stolen regions overflow, and the redo launches -- which walk rorder and horder, not the lane class's lists -- must still find them
+    (a stolen region that overflows joins horder). Before the fix such a region was never redone and its read came out with a stale segment, without an error."""
+    monkeypatch.setenv("RTK_LANE_MAX_GAP", "256")
+    monkeypatch.setenv("RTK_LANE_WAVES", "1"); monkeypatch.setenv("RTK_LANE_ROUND", "4")
+    monkeypatch.setenv("RTK_TEST_TINY_SCRATCH", "1")
+    for prefix, n in ((ds_medium, 60), (ds_snps, 20)):
+        got, st, seqs, quals = _run(prefix, n, None)
+        want = _oracle(prefix, seqs, quals)
+        assert got == want, "%d reads differ from the oracle" % sum(1 for a, b in zip(got, want) if a != b)
+        assert st["n_arena_overflow"] > 0
