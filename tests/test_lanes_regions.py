@@ -108,3 +108,24 @@ def test_gpu_stolen_regions_that_overflow_are_redone(ds_medium, ds_snps, monkeyp
         want = _oracle(prefix, seqs, quals)
         assert got == want, "%d reads differ from the oracle" % sum(1 for a, b in zip(got, want) if a != b)
         assert st["n_arena_overflow"] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_big_tickets_take_the_lane_kernel_by_themselves(ds_medium, monkeypatch):
+    """RTK_LANE_AUTO_BASES (default 512 Mi bases): a ticket that large runs the lane kernel for gaps under 128 without RTK_LANE_MAX_GAP, one kernel after the other; the threshold is
+    lowered here so that a 0.6 Mb ticket crosses it. Same bytes as the oracle; a ticket below the threshold does not touch the lane kernel."""
+    monkeypatch.delenv("RTK_LANE_MAX_GAP", raising=False)
+    got0, st0, seqs, quals = _run(ds_medium, 80, None)
+    assert st0["n_lane_regions"] == 0
+    monkeypatch.setenv("RTK_LANE_AUTO_BASES", "1000")
+    # (the threshold is read once per process: a fresh process)
+    import subprocess, sys, json, os
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_lanes_regions import _run\n"
+            "got, st, seqs, quals = _run(%r, 80, None)\n"
+            "print(json.dumps({'got': got, 'lane': st['n_lane_regions'], 'handed': st['n_lane_handed']}))") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ds_medium)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RTK_LANE_AUTO_BASES="1000"), timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [tuple(x) for x in d["got"]] == got0 == _oracle(ds_medium, seqs, quals)
+    assert d["lane"] > 500 and d["handed"] < d["lane"] // 4
