@@ -160,6 +160,11 @@ int rtk_reserve_scratch(int device, uint32_t max_read_len);
 /* Second pass: n_tickets x (work area of the phasing step, work area of the region stage) reserved ahead; every ticket in flight owns a pair.
  * The first call for a device also reserves the work areas of the per-read seed kernels (one slab per graph). */
 int rtk_reserve_second_pass(int device, uint32_t n_tickets, uint64_t phase_bytes, uint64_t region_bytes);
+/* Round 6: the device buffers of n_batches tickets of about bases_per_batch bases / reads_per_batch reads (with_qualities: FASTQ input kept, second pass; raw_bases_per_batch != 0: the
+ * second pass, which also holds the uncorrected reads) taken from the device and parked in the graph's pool, so that the first tickets of a run find them instead of calling hipMalloc inside the
+ * correction phase (a hipMalloc stalls every stream of the device). A batch carves all its arrays out of ONE such buffer. RTK_ERR_DEVICE when an eighth of the device memory would not stay free
+ * (what could be reserved stays reserved). */
+int rtk_graph_reserve_batches(rtk_graph* g, uint32_t n_batches, uint64_t bases_per_batch, uint32_t reads_per_batch, int with_qualities, uint64_t raw_bases_per_batch);
 
 /* Correct_Opt defaults + max_km_cov derived from the graph (reference: src/Common.hpp:101-156, src/Ratatosk.cpp:625). */
 int rtk_opts_default(const rtk_graph* g, rtk_opts* opts);

@@ -102,6 +102,7 @@ def load_library(path=None):
     L.rtk_myers_batch_lanes.argtypes = L.rtk_myers_batch.argtypes
     L.rtk_myers_batch_lanes.restype = C.c_int
     L.rtk_coalesce_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.rtk_graph_reserve_batches.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64]
     L.rtk_free_many.argtypes = [C.POINTER(C.c_void_p), C.c_uint32]; L.rtk_free_many.restype = None
     L.rtk_free.argtypes = [C.c_void_p]
     _libs[path] = L
