@@ -625,6 +625,8 @@ def main():
         dist.init_process_group(backend="gloo" if a.sim else "nccl")
     api.load_library(lib_path)
     ctx = {"rank": rank, "world": world, "device": device, "lib_path": lib_path, "workdir": (a.workdir or tempfile.mkdtemp(prefix="rtk_bench_")) if rank == 0 else None}
+    if ctx["workdir"]:
+        os.makedirs(ctx["workdir"], exist_ok=True)
 
     diploid = a.het > 0
     w = run_workload(a, ctx, a.ref_len, a.het, "c2" if diploid else "c1", a.steps, a.warmup, n1_first=True)
