@@ -47,7 +47,7 @@ struct Opt {
     int cores = 1, gpus = 0, workers_per_gpu = 0, k1 = 31, k2 = 63, max_qual = 40, trim = 0, rounds = 1;
     bool force_snp = false;
     double min_conf_snp = 0.9;
-    size_t insert_sz = 500, w1 = 1000, w2 = 5000, batch_bases = 32u << 20;
+    size_t insert_sz = 500, w1 = 1000, w2 = 5000, batch_bases = 0; // 0: not given (64 Mi for the first pass, 32 Mi for the second)
     bool pass1 = false, pass2 = false, verbose = false, correct = false, strip = false, gzip = false, parse_only = false;
 };
 
@@ -56,7 +56,7 @@ static void usage() {
                     "  -c, --cores           number of host threads (default 1): index parsing, FASTQ formatting\n"
                     "      --gpus            number of GPUs to use (default: all visible)\n"
                     "      --workers-per-gpu tickets in flight per GPU (default 3; with -2 up to 8, as many as the device memory holds)\n"
-                    "  -B, --batch-bases     long-read bases per ticket (default 32 Mi)\n"
+                    "  -B, --batch-bases     long-read bases per ticket (default 64 Mi with -1, 32 Mi with -2)\n"
                     "  -i, --insert-sz       insert size of the short reads (default 500)\n"
                     "  -k, --k1              k-mer length of the 1st pass graph (default 31, <= 31)\n  -w, --max-len-weak1   maximum weak region length, 1st pass (default 1000)\n"
                     "  -r, --correction-rounds  correction rounds of the 1st pass (default 1)\n  -Q, --max-base-qual   maximum base quality (default 40)\n  -m, --min-conf-snp-corr  minimum confidence threshold to correct a SNP (default 0.9)\n  -v, --verbose\n"
@@ -156,6 +156,9 @@ int main(int argc, char** argv) {
     for (int i = optind; i < argc - 1; ++i) fprintf(stderr, "Ratatosk::correct: argument '%s' belongs to no option and is ignored (several input files: one -l each, or a text file of paths)\n", argv[1 + i]);
     if (opt.pass1 == opt.pass2) { fprintf(stderr, "Ratatosk::correct: one pass per run with a pre-built index (-g, -d): give -1 or -2\n"); return 1; }
     const bool lrc = opt.pass2;
+    // ticket size when -B is not given. First pass: 64 Mi (1.22 x 10^9 bases/s file to file against 1.19 at 32 Mi and 1.05-1.20 at 96 Mi, profiles/r06_split_and_cli_B.txt: a ticket's launches carry
+    // ~10 ms of latency whatever it holds). Second pass: 32 Mi (eight tickets in flight with 24 GB of work areas each)
+    if (opt.batch_bases == 0) opt.batch_bases = lrc ? (32u << 20) : (64u << 20);
     if (lrc && opt.in_long_raw.empty()) { fprintf(stderr, "Ratatosk::correct: -2 needs the uncorrected long reads (-L) next to the pass-1 reads (-l)\n"); return 0; }
     if (opt.rounds < 1) { fprintf(stderr, "Ratatosk::Ratatosk(): Number of correction rounds cannot be less than 1.\n"); return 0; } // src/Ratatosk.cpp:348-352
     if (opt.trim < 0 || opt.trim > opt.max_qual) { fprintf(stderr, "Ratatosk::Ratatosk(): Quality score trimming threshold cannot be less than 0 or more than %d (%d given).\n", opt.max_qual, opt.trim); /* src/Ratatosk.cpp:324-326 */ return 0; }
