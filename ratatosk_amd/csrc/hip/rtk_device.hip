@@ -80,7 +80,7 @@ struct rtk_graph {
     }
     void pool_give(void* p, uint64_t bytes) {
         std::lock_guard<std::mutex> h(pool_lock);
-        if (pool_bytes + bytes > (48ull << 30)) { if (bytes >= (64u << 20) && getenv("RTK_TRACE")) fprintf(stderr, "[rtk trace] pool_give: %.2f GB freed (48 GB parked already)\n", bytes / 1073741824.0); rtk_dfree(p); return; } // keep at most 48 GB parked (eight second-pass tickets of ~5 GB)
+        if (pool_bytes + bytes > (64ull << 30)) { if (bytes >= (64u << 20) && getenv("RTK_TRACE")) fprintf(stderr, "[rtk trace] pool_give: %.2f GB freed (64 GB parked already)\n", bytes / 1073741824.0); rtk_dfree(p); return; } // keep at most 64 GB parked (eleven second-pass tickets of ~5 GB: eight in flight, three being formatted)
         pool.insert(std::make_pair(bytes, p)); pool_bytes += bytes;
     }
     // work areas of the phasing step (second pass): one per ticket in flight, so that the hour-glass launches of several tickets (each as

@@ -242,7 +242,7 @@ int main(int argc, char** argv) {
     { // the device buffers of the tickets that will be in flight (one buffer per ticket: the library carves a ticket's arrays out of it), before the correction phase starts
         const uint64_t bb = opt.batch_bases + (opt.batch_bases >> 3); const uint32_t rr = static_cast<uint32_t>(std::min<uint64_t>(bb / 1000 + 64, 1u << 30));
         std::vector<std::thread> rs;
-        for (int w = 0; w < n_gpus; ++w) rs.emplace_back([&, w]() { if (rtk_graph_reserve_batches(graphs[w], static_cast<uint32_t>(opt.workers_per_gpu), bb, rr, lrc ? 1 : 0, lrc ? bb : 0) != RTK_OK && opt.verbose) fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); });
+        for (int w = 0; w < n_gpus; ++w) rs.emplace_back([&, w]() { if (rtk_graph_reserve_batches(graphs[w], static_cast<uint32_t>(opt.workers_per_gpu) + 3u /* tickets whose records the formatter threads still read are alive too */, bb, rr, lrc ? 1 : 0, lrc ? bb : 0) != RTK_OK && opt.verbose) fprintf(stderr, "Ratatosk::Ratatosk(): %s\n", rtk_last_error()); });
         for (size_t i = 0; i < rs.size(); ++i) rs[i].join();
     }
     const long long t_load1 = now_us();
