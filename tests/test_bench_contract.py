@@ -84,11 +84,11 @@ def test_default_graph_is_the_chr20_scale_set_at_every_n():
 
 def test_config4_leg_script_on_the_simulator(tmp_path):
     """bench_config4.py (the `config4` leg of the bench line) end to end on the developer simulator at a three-thousandth of its size: a 1 Mb diploid reference, reads sampled inside
-    the index tool, three 64 Mb tickets of distinct reads (one untimed group, then timed), per-kernel figures, the truth-based property checks; and its guards: a reference that
+    the index tool, two 64 Mb tickets of distinct reads (one untimed group, then timed), per-kernel figures, the truth-based property checks; and its guards: a reference that
     cannot fit the container's memory ends with {"skipped": reason}, exit code 0."""
     out = os.path.join(str(tmp_path), "c4.json")
     env = dict(os.environ, RTK_C4_SIM="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_config4.py"), out, "1", "30", "3", "8", os.path.join(str(tmp_path), "c4")], capture_output=True, text=True, env=env, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_config4.py"), out, "1", "30", "2", "8", os.path.join(str(tmp_path), "c4")], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.load(open(out))
     assert "skipped" not in d and d["graph"]["kmers"] > 900_000 and d["tickets"]["n"] >= 1 and d["tickets"]["distinct"] is True and d["tickets"]["bases_per_s"] > 0
@@ -96,7 +96,7 @@ def test_config4_leg_script_on_the_simulator(tmp_path):
     pc = d["property_checks"]
     assert pc["ok"] and pc["reads_checked"] == 200 and pc["error_rate_corrected"] < 0.2 * pc["error_rate_raw"] and pc["solid_window_share_corrected"] > 0.9
     # a second run finds the index it left
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_config4.py"), out, "1", "30", "3", "8", os.path.join(str(tmp_path), "c4")], capture_output=True, text=True, env=env, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_config4.py"), out, "1", "30", "2", "8", os.path.join(str(tmp_path), "c4")], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and json.load(open(out)).get("index", "").startswith("reused")
     # guard: 10 Tb cannot fit
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_config4.py"), out, "10000000", "30", "3", "8", os.path.join(str(tmp_path), "c4big")], capture_output=True, text=True, env=env, timeout=120)
