@@ -320,8 +320,10 @@ def config4_leg(a, workdir, t_start):
     """configs[4] (BASELINE.json: whole-genome-scale graph resident in HBM, long reads, roofline report) as its own process once this one has released the device:
     bench_config4.py builds the 3 Gb index (short reads sampled inside the index tool), keeps the graph resident and corrects tickets of DISTINCT reads.
     Guarded: host memory / disk / HBM inside that script, time here -- every refusal is a {"skipped": reason}."""
-    if time.time() - t_start > 900:
-        return {"skipped": "time: this bench run had already used %d s when the leg was due (limit 900 s; run `python bench_config4.py out.json` on its own)" % (time.time() - t_start)}
+    # time budget: the leg starts ~4 min into a run and takes ~6.5 min (index build 5.6); it is not started later than 7.5 min in and is cut at 16 min (index build at 10),
+    # so that the whole run stays under 25 min whatever the box does
+    if time.time() - t_start > 450:
+        return {"skipped": "time: this bench run had already used %d s when the leg was due (limit 450 s; run `python bench_config4.py out.json` on its own)" % (time.time() - t_start)}
     out_fn = os.path.join(workdir, "config4.json")
     try:
         os.remove(out_fn)
@@ -329,10 +331,19 @@ def config4_leg(a, workdir, t_start):
         pass
     cmd = [sys.executable, os.path.join(ROOT, "bench_config4.py"), out_fn, str(a.config4_ref_mb), "30", str(a.config4_tickets), "128", os.path.join(workdir, "c4")]
     try:
-        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=1500)
+        import signal
+        pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True, env=dict(os.environ, RTK_C4_INDEX_TIMEOUT=os.environ.get("RTK_C4_INDEX_TIMEOUT", "600")))
+        try:
+            _, err = pr.communicate(timeout=960)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)  # (the whole group: the index tool it started must not outlive it)
+            pr.communicate()
+            d = json.load(open(out_fn)) if os.path.exists(out_fn) else {}
+            d["skipped"] = "time: the leg was cut after 960 s"
+            return d
         d = json.load(open(out_fn))
-        if r.returncode != 0 and "skipped" not in d:
-            d["error"] = r.stderr.strip()[-400:]
+        if pr.returncode != 0 and "skipped" not in d:
+            d["error"] = (err or "").strip()[-400:]
         return d
     except Exception as e:  # never takes the bench line down
         try:
